@@ -1,0 +1,153 @@
+/*
+ * qampy_hip.h - C ABI of libqampy_hip.so: hand-written HIP (gfx950 / MI355X) kernels behind QAMpy's compiled hot path.
+ *
+ * What this replaces.  QAMpy's only native code are two pythran-compiled modules; their `#pythran export` lines are the
+ * de-facto FFI contract of the hot path (paths relative to the QAMpy tree):
+ *   qampy/core/equalisation/pythran_equalisation.py:33-36    apply_filter_to_signal  {f32,f64,c64,c128}
+ *   qampy/core/equalisation/pythran_equalisation.py:78-79    train_equaliser_realvalued {f32,f64}
+ *   qampy/core/equalisation/pythran_equalisation.py:128-129  train_equaliser {c64,c128}
+ *   qampy/core/equalisation/pythran_equalisation.py:304-305  make_decision {c64,c128}
+ *   qampy/core/pythran_dsp.py:45-46                          bps {c64,c128}
+ *   qampy/core/pythran_dsp.py:133-136                        select_angles {f32,f64}
+ * Call sites that bind to them: qampy/core/equalisation/equalisation.py:177,180,555,557;
+ * qampy/core/phaserecovery.py:28-29,149-150; qampy/core/signal_quality.py:26.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; complex data is interleaved (re, im) exactly like numpy complex64/complex128;
+ *   - all arrays C-contiguous, row-major, shapes given in the comments;
+ *   - every function returns a status code (QH_OK == 0); the library never frees or keeps caller memory;
+ *   - `qh_*`      : pointers are HOST memory (numpy arrays); the call stages through HBM and is synchronous;
+ *   - `qh_*_dev`  : array pointers are DEVICE memory obtained from qh_malloc; the call only enqueues work on the
+ *                   library's stream (use qh_sync / events).  Small control arrays (`modes`) stay host pointers.
+ *   - method ids are the QH_M_* / QH_RM_* enums below (the reference matches strings, pythran_equalisation.py:131-152).
+ *
+ * Semantics are those of the reference run sequentially (OMP_NUM_THREADS=1): modes are processed in the order given
+ * and, with adaptive != 0, the adapted step size is carried from one mode into the next.
+ */
+#ifndef QAMPY_HIP_H
+#define QAMPY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (python shim: 1,2 -> ValueError, 3,4 -> RuntimeError) */
+#define QH_OK 0
+#define QH_ERR_METHOD 1   /* unknown method id   (reference: ValueError, pythran_equalisation.py:151-152) */
+#define QH_ERR_ARG 2      /* inconsistent sizes  (reference: asserts that the compiled build drops)          */
+#define QH_ERR_HIP 3      /* HIP runtime failure, text in qh_last_error()                                      */
+#define QH_ERR_NODEVICE 4 /* no usable gfx950 device                                                           */
+
+/* ---- complex trainer methods, pythran_equalisation.py:131-150 */
+enum { QH_M_CMA = 0, QH_M_CMA2, QH_M_SGNCMA, QH_M_MCMA, QH_M_RDE, QH_M_MRDE, QH_M_SBD, QH_M_MDDMA, QH_M_DD, QH_M_SBD_DATA };
+/* ---- real-valued trainer methods, pythran_equalisation.py:81-88 */
+enum { QH_RM_CMA = 0, QH_RM_SGNCMA, QH_RM_DD, QH_RM_DD_DATA };
+
+/* ---- device / runtime --------------------------------------------------------------------------------------- */
+int qh_device_count(int *count);
+int qh_init(int device);                       /* select device, create the library stream; idempotent per device */
+int qh_device_name(char *buf, size_t n);
+const char *qh_last_error(void);
+int qh_sync(void);                             /* wait for the library stream */
+int qh_malloc(void **dptr, size_t bytes);
+int qh_free(void *dptr);
+int qh_memset(void *dptr, int value, size_t bytes);
+int qh_memcpy_h2d(void *dptr, const void *hptr, size_t bytes);
+int qh_memcpy_d2h(void *hptr, const void *dptr, size_t bytes);
+int qh_memcpy_d2d(void *dst, const void *src, size_t bytes);
+/* HIP events recorded on the library stream (bench.py measures kernel time with these) */
+int qh_event_create(void **ev);
+int qh_event_destroy(void *ev);
+int qh_event_record(void *ev);
+int qh_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on `stop` */
+
+/* ---- train_equaliser (complex) ----------------------------------------------------------------------------------
+ *   E        (nmodes, L)                 input field
+ *   mu       in/out step size (the adapted value is returned when adaptive != 0)
+ *   wx       (nmodes, nmodes, ntaps)     taps, updated in place
+ *   modes    (nsel,) int64               output modes to train, processed in this order
+ *   symbols  (nmodes, nsy)               per-method constants / alphabet / training symbols
+ *   err      (nmodes, TrSyms*Niter)      out; rows of unselected modes are zeroed
+ * Requires (TrSyms-1)*os + ntaps <= L, nsel >= 1, modes[i] < nmodes, and nsy >= TrSyms for QH_M_SBD_DATA.
+ */
+int qh_train_equaliser_c64(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu, void *wx,
+                           int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
+                           int method, void *err);
+int qh_train_equaliser_c128(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu, void *wx,
+                            int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
+                            int method, void *err);
+/* device-resident: E, wx, symbols, err, mu are device pointers; err is NOT zeroed for unselected modes unless zero_err */
+int qh_train_equaliser_c64_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
+                               void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
+                               int64_t nsy, int method, void *err, int zero_err);
+int qh_train_equaliser_c128_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev,
+                                void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
+                                int64_t nsy, int method, void *err, int zero_err);
+
+/* ---- train_equaliser_realvalued: same layout with real arrays, update without conjugate ---------------------- */
+int qh_train_equaliser_real_f32(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu, void *wx,
+                                int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
+                                int method, void *err);
+int qh_train_equaliser_real_f64(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu, void *wx,
+                                int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
+                                int method, void *err);
+
+/* ---- apply_filter_to_signal -------------------------------------------------------------------------------------
+ *   out (nsel, N), N = (L - ntaps + 1) / os ;  out[j, i] = sum_k sum_t E[k, i*os + t] * wx[modes[j], k, t]
+ */
+int qh_apply_filter_c64(const void *E, int nmodes, int64_t L, int os, const void *wx, int ntaps, const int64_t *modes,
+                        int nsel, void *out);
+int qh_apply_filter_c128(const void *E, int nmodes, int64_t L, int os, const void *wx, int ntaps, const int64_t *modes,
+                         int nsel, void *out);
+int qh_apply_filter_f32(const void *E, int nmodes, int64_t L, int os, const void *wx, int ntaps, const int64_t *modes,
+                        int nsel, void *out);
+int qh_apply_filter_f64(const void *E, int nmodes, int64_t L, int os, const void *wx, int ntaps, const int64_t *modes,
+                        int nsel, void *out);
+int qh_apply_filter_c64_dev(const void *E, int nmodes, int64_t L, int os, const void *wx, int ntaps, const int64_t *modes,
+                            int nsel, void *out);
+int qh_apply_filter_c128_dev(const void *E, int nmodes, int64_t L, int os, const void *wx, int ntaps, const int64_t *modes,
+                             int nsel, void *out);
+
+/* ---- bps: blind phase search index ---------------------------------------------------------------------------
+ *   E (L,) one mode; testangles (p, A) real with p == 1 (one grid) or p == L (per-symbol grid); symbols (M,)
+ *   idx (L,) int32 out: first arg-min over the A angles of the 2N-symbol windowed min-distance sum; 0 in [0,N) and [L-N,L)
+ */
+int qh_bps_c64(const void *E, int64_t L, const void *testangles, int64_t p, int A, const void *symbols, int M, int N,
+               int32_t *idx);
+int qh_bps_c128(const void *E, int64_t L, const void *testangles, int64_t p, int A, const void *symbols, int M, int N,
+                int32_t *idx);
+int qh_bps_c64_dev(const void *E, int64_t L, const void *testangles, int64_t p, int A, const void *symbols, int M, int N,
+                   int32_t *idx);
+int qh_bps_c128_dev(const void *E, int64_t L, const void *testangles, int64_t p, int A, const void *symbols, int M, int N,
+                    int32_t *idx);
+
+/* device-resident carrier recovery of the host layer qampy/core/phaserecovery.py:145-159 for `nm` modes at once:
+ *   grid = linspace(-pi/4, pi/4, A, endpoint=False); idx = bps(E[m]); ph = grid[idx]; ph[N:-N] = unwrap(4 ph)/4;
+ *   Eout = E * exp(1j ph).   E, Eout (nm, L) complex; ph (nm, L) real; idx (nm, L) int32 scratch/out. */
+int qh_bps_recover_c64_dev(const void *E, int nm, int64_t L, int A, const void *symbols, int M, int N, int32_t *idx,
+                           void *ph, void *Eout);
+int qh_bps_recover_c128_dev(const void *E, int nm, int64_t L, int A, const void *symbols, int M, int N, int32_t *idx,
+                            void *ph, void *Eout);
+
+/* ---- select_angles: out[i] = angles[(p > 1 ? i : 0), idx[i]] ;  idx int64 (L,) ------------------------------- */
+int qh_select_angles_f32(const void *angles, int64_t p, int A, const int64_t *idx, int64_t L, void *out);
+int qh_select_angles_f64(const void *angles, int64_t p, int A, const int64_t *idx, int64_t L, void *out);
+
+/* ---- make_decision: nearest alphabet point, |distance| (not squared) and index (first minimum) --------------- */
+int qh_make_decision_c64(const void *E, int64_t L, const void *symbols, int M, void *det, void *dist, int32_t *idx);
+int qh_make_decision_c128(const void *E, int64_t L, const void *symbols, int M, void *det, void *dist, int32_t *idx);
+int qh_make_decision_c64_dev(const void *E, int64_t L, const void *symbols, int M, void *det, void *dist, int32_t *idx);
+int qh_make_decision_c128_dev(const void *E, int64_t L, const void *symbols, int M, void *det, void *dist, int32_t *idx);
+
+/* ---- measurement helpers ---------------------------------------------------------------------------------------
+ * symbol errors of decided indices against a reference index sequence with a lag: count(idx_rx[i] != idx_tx[i - lag]) */
+int qh_count_errors_dev(const int32_t *idx_rx, const int32_t *idx_tx, int64_t n, int64_t lag, int64_t ntx,
+                        unsigned long long *count_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,228 @@
+"""
+ctypes binding of ``libqampy_hip.so`` (C ABI: include/qampy_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing, or no gfx950 device is visible when a kernel entry
+point is called, the call raises.  (The CPU restatement under ``oracle/`` is test infrastructure and is never imported
+from here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libqampy_hip.so")
+
+QH_OK, QH_ERR_METHOD, QH_ERR_ARG, QH_ERR_HIP, QH_ERR_NODEVICE = 0, 1, 2, 3, 4
+
+# method ids of include/qampy_hip.h (order of the QH_M_* / QH_RM_* enums)
+METHOD_ID = {m: i for i, m in enumerate(("cma", "cma2", "sgncma", "mcma", "rde", "mrde", "sbd", "mddma", "dd", "sbd_data"))}
+REAL_METHOD_ID = {m: i for i, m in enumerate(("cma", "sgncma", "dd", "dd_data"))}
+
+_vp, _i, _i64, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_size_t
+_pf, _pd = C.POINTER(C.c_float), C.POINTER(C.c_double)
+
+_TRAIN = [_vp, _i, _i64, _i64, _i, _i, None, _vp, _i, _vp, _i, _i, _vp, _i64, _i, _vp]      # [6] = mu pointer
+_APPLY = [_vp, _i, _i64, _i, _vp, _i, _vp, _i, _vp]
+_BPS = [_vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp]
+_RECOVER = [_vp, _i, _i64, _i, _vp, _i, _i, _vp, _vp, _vp]
+_SELECT = [_vp, _i64, _i, _vp, _i64, _vp]
+_DECIDE = [_vp, _i64, _vp, _i, _vp, _vp, _vp]
+
+
+def _train_sig(mu_ptr, dev=False):
+    sig = list(_TRAIN)
+    sig[6] = _vp if dev else mu_ptr
+    return sig + ([_i] if dev else [])
+
+
+SIGNATURES = {
+    "qh_device_count": [C.POINTER(_i)],
+    "qh_init": [_i],
+    "qh_device_name": [C.c_char_p, _sz],
+    "qh_sync": [],
+    "qh_malloc": [C.POINTER(_vp), _sz],
+    "qh_free": [_vp],
+    "qh_memset": [_vp, _i, _sz],
+    "qh_memcpy_h2d": [_vp, _vp, _sz],
+    "qh_memcpy_d2h": [_vp, _vp, _sz],
+    "qh_memcpy_d2d": [_vp, _vp, _sz],
+    "qh_event_create": [C.POINTER(_vp)],
+    "qh_event_destroy": [_vp],
+    "qh_event_record": [_vp],
+    "qh_event_elapsed_ms": [_vp, _vp, _pf],
+    "qh_train_equaliser_c64": _train_sig(_pf),
+    "qh_train_equaliser_c128": _train_sig(_pd),
+    "qh_train_equaliser_c64_dev": _train_sig(_pf, dev=True),
+    "qh_train_equaliser_c128_dev": _train_sig(_pd, dev=True),
+    "qh_train_equaliser_real_f32": _train_sig(_pf),
+    "qh_train_equaliser_real_f64": _train_sig(_pd),
+    "qh_apply_filter_c64": _APPLY, "qh_apply_filter_c128": _APPLY, "qh_apply_filter_f32": _APPLY, "qh_apply_filter_f64": _APPLY,
+    "qh_apply_filter_c64_dev": _APPLY, "qh_apply_filter_c128_dev": _APPLY,
+    "qh_bps_c64": _BPS, "qh_bps_c128": _BPS, "qh_bps_c64_dev": _BPS, "qh_bps_c128_dev": _BPS,
+    "qh_bps_recover_c64_dev": _RECOVER, "qh_bps_recover_c128_dev": _RECOVER,
+    "qh_select_angles_f32": _SELECT, "qh_select_angles_f64": _SELECT,
+    "qh_make_decision_c64": _DECIDE, "qh_make_decision_c128": _DECIDE,
+    "qh_make_decision_c64_dev": _DECIDE, "qh_make_decision_c128_dev": _DECIDE,
+    "qh_count_errors_dev": [_vp, _vp, _i64, _i64, _i64, _vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (no device is touched yet).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s not found: build it with qampy_amd/csrc/build.sh (or __graft_entry__.build()); "
+                               "qampy_amd has no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = _i
+        lib.qh_last_error.argtypes = []
+        lib.qh_last_error.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    """Map a status code to the exception the reference raises for the same condition."""
+    if rc == QH_OK:
+        return
+    msg = load().qh_last_error().decode("utf-8", "replace")
+    if rc == QH_ERR_METHOD:
+        raise ValueError("Unknown method (%s)" % msg)
+    if rc == QH_ERR_ARG:
+        raise ValueError(msg)
+    raise RuntimeError("libqampy_hip: %s" % msg)
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))
+
+
+def ptr(a):
+    """Raw pointer of a C-contiguous numpy array or of a DeviceArray."""
+    if isinstance(a, DeviceArray):
+        return a.ptr
+    if a is None:
+        return None
+    assert a.flags.c_contiguous
+    return a.ctypes.data
+
+
+def device_count():
+    n = _i(0)
+    call("qh_device_count", C.byref(n))
+    return n.value
+
+
+def init(device=0):
+    call("qh_init", int(device))
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    call("qh_device_name", buf, 256)
+    return buf.value.decode()
+
+
+def sync():
+    call("qh_sync")
+
+
+def suffix(dtype):
+    """(ABI suffix, real numpy type, complex numpy type) of a supported dtype."""
+    dtype = np.dtype(dtype)
+    if dtype in (np.dtype(np.complex64), np.dtype(np.float32)):
+        return "32", np.float32, np.complex64
+    if dtype in (np.dtype(np.complex128), np.dtype(np.float64)):
+        return "64", np.float64, np.complex128
+    raise TypeError("unsupported dtype %s (the hot path is exported for float32/64 and complex64/128 only)" % dtype)
+
+
+class DeviceArray:
+    """A dense C-ordered array living in HBM (thin owner of a ``qh_malloc`` allocation)."""
+
+    def __init__(self, shape, dtype, zero=False):
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = _vp()
+        call("qh_malloc", C.byref(p), self.nbytes)
+        self.ptr = p.value
+        self._own = True
+        if zero:
+            call("qh_memset", self.ptr, 0, self.nbytes)
+
+    @classmethod
+    def from_host(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        out = cls(arr.shape, arr.dtype)
+        call("qh_memcpy_h2d", out.ptr, arr.ctypes.data, out.nbytes)
+        return out
+
+    def set(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert arr.nbytes == self.nbytes
+        call("qh_memcpy_h2d", self.ptr, arr.ctypes.data, self.nbytes)
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        call("qh_memcpy_d2h", out.ctypes.data, self.ptr, self.nbytes)
+        return out
+
+    def zero(self):
+        call("qh_memset", self.ptr, 0, self.nbytes)
+
+    def copy_from(self, other):
+        assert other.nbytes == self.nbytes
+        call("qh_memcpy_d2d", self.ptr, other.ptr, self.nbytes)
+
+    def row(self, i):
+        """Non-owning view of row ``i`` of a 2-D array."""
+        v = object.__new__(DeviceArray)
+        v.shape = self.shape[1:]
+        v.dtype = self.dtype
+        v.nbytes = self.nbytes // self.shape[0]
+        v.ptr = self.ptr + i * v.nbytes
+        v._own = False
+        return v
+
+    def free(self):
+        if getattr(self, "_own", False) and self.ptr:
+            call("qh_free", self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Event:
+    """HIP event on the library stream (kernel timing in bench.py)."""
+
+    def __init__(self):
+        p = _vp()
+        call("qh_event_create", C.byref(p))
+        self.ptr = p.value
+
+    def record(self):
+        call("qh_event_record", self.ptr)
+
+    def elapsed_ms(self, start):
+        ms = C.c_float(0)
+        call("qh_event_elapsed_ms", start.ptr, self.ptr, C.byref(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                call("qh_event_destroy", self.ptr)
+        except Exception:
+            pass

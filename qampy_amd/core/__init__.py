@@ -1,0 +1,2 @@
+"""Core API (plain ndarrays in/out), mirror of ``qampy.core`` for the equaliser + BPS hot path."""
+from . import equalisation, phaserecovery  # noqa: F401

@@ -1,0 +1,160 @@
+"""
+Drop-in for the compiled module ``qampy.core.equalisation.pythran_equalisation`` on MI355X.
+
+Same entry points, argument order and return values as the ``#pythran export`` lines of
+qampy/core/equalisation/pythran_equalisation.py (:33-36, :78-79, :128-129, :238-239, :304-305); the work is done by the
+HIP kernels in qampy_amd/csrc/{train,apply,bps}.hip through the C ABI of include/qampy_hip.h.  Like a pythran
+extension, the functions insist on exactly matching dtypes (pythran raises TypeError otherwise) and on C-contiguous
+inputs.  Arguments may also be :class:`qampy_amd._lib.DeviceArray` objects where noted (``*_dev`` functions).
+"""
+import ctypes as C
+
+import numpy as np
+
+from ... import _lib
+from ..._lib import DeviceArray
+
+
+def _as_modes(modes, nmax):
+    if modes is None:
+        return np.arange(nmax, dtype=np.int64)
+    return np.ascontiguousarray(np.atleast_1d(modes), dtype=np.int64)
+
+
+def _need(arr, dtype, name):
+    if not isinstance(arr, np.ndarray) or arr.dtype != dtype or not arr.flags.c_contiguous:
+        raise TypeError("%s must be a C-contiguous %s array (got %s %s)" % (
+            name, np.dtype(dtype).name, type(arr).__name__, getattr(arr, "dtype", "")))
+
+
+def train_equaliser(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method):
+    """
+    Stochastic-gradient tap training, complex field.  Returns ``(err, wx, mu)``; ``wx`` is also updated in place
+    (pythran_equalisation.py:128-173).  ``modes`` are trained in the given order; with ``adaptive`` the adapted step is
+    carried from one mode to the next (sequential semantics of the reference).
+    """
+    if method not in _lib.METHOD_ID:
+        raise ValueError("Unknown method %s" % method)
+    suf, rt, ct = _lib.suffix(E.dtype)
+    if not np.iscomplexobj(E):
+        raise TypeError("train_equaliser needs a complex field; use train_equaliser_realvalued for real arrays")
+    _need(E, ct, "E"); _need(wx, ct, "wx")
+    symbols = np.ascontiguousarray(symbols)
+    _need(symbols, ct, "symbols")
+    if E.ndim != 2 or wx.ndim != 3 or symbols.ndim != 2:
+        raise TypeError("E must be 2-d, wx 3-d and symbols 2-d")
+    nmodes, L = E.shape
+    ntaps = wx.shape[-1]
+    if wx.shape[0] != nmodes or wx.shape[1] != nmodes:
+        raise ValueError("wx needs to have at least as many dimensions as the maximum mode")
+    if symbols.shape[0] != nmodes:
+        raise ValueError("symbols must be at least size of modes")
+    modes = _as_modes(modes, nmodes)
+    err = np.zeros((nmodes, int(TrSyms) * int(Niter)), dtype=ct)
+    mu_c = (C.c_float if rt is np.float32 else C.c_double)(mu)
+    _lib.call("qh_train_equaliser_c" + ("64" if suf == "32" else "128"), _lib.ptr(E), nmodes, L, int(TrSyms), int(Niter),
+              int(os), C.byref(mu_c), _lib.ptr(wx), ntaps, _lib.ptr(modes), modes.size, int(bool(adaptive)),
+              _lib.ptr(symbols), symbols.shape[1], _lib.METHOD_ID[method], _lib.ptr(err))
+    return err, wx, rt(mu_c.value)
+
+
+def train_equaliser_realvalued(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method):
+    """Real-valued trainer (pythran_equalisation.py:78-108); ``method`` without the ``_real`` suffix."""
+    if method not in _lib.REAL_METHOD_ID:
+        raise ValueError("Unknown method %s" % method)
+    suf, rt, ct = _lib.suffix(E.dtype)
+    if np.iscomplexobj(E):
+        raise TypeError("train_equaliser_realvalued needs a real-valued (stacked re/im) field")
+    _need(E, rt, "E"); _need(wx, rt, "wx")
+    symbols = np.ascontiguousarray(symbols)
+    _need(symbols, rt, "symbols")
+    nmodes, L = E.shape
+    ntaps = wx.shape[-1]
+    if wx.shape[0] != nmodes or wx.shape[1] != nmodes:
+        raise ValueError("wx needs to have at least as many dimensions as the maximum mode")
+    if symbols.shape[0] != nmodes:
+        raise ValueError("symbols must be at least size of modes")
+    modes = _as_modes(modes, nmodes)
+    err = np.zeros((nmodes, int(TrSyms) * int(Niter)), dtype=rt)
+    mu_c = (C.c_float if rt is np.float32 else C.c_double)(mu)
+    _lib.call("qh_train_equaliser_real_f" + suf, _lib.ptr(E), nmodes, L, int(TrSyms), int(Niter), int(os), C.byref(mu_c),
+              _lib.ptr(wx), ntaps, _lib.ptr(modes), modes.size, int(bool(adaptive)), _lib.ptr(symbols), symbols.shape[1],
+              _lib.REAL_METHOD_ID[method], _lib.ptr(err))
+    return err, wx, rt(mu_c.value)
+
+
+def apply_filter_to_signal(E, os, wx, modes=None):
+    """Butterfly FIR + decimation, ``out (n_sel, (L-ntaps+1)//os)`` (pythran_equalisation.py:33-76); 4 dtypes."""
+    suf, rt, ct = _lib.suffix(E.dtype)
+    if os <= 0:
+        raise ValueError("oversampling factor must be larger than 0")
+    _need(E, E.dtype, "E"); _need(wx, E.dtype, "wx")
+    nmodes, L = E.shape
+    ntaps = wx.shape[-1]
+    if wx.shape[1] != nmodes:
+        raise ValueError("second dimension of wx must equal the number of input modes")
+    modes = _as_modes(modes, wx.shape[0])
+    if modes.size and modes.max() >= wx.shape[0]:
+        raise ValueError("largest mode number is larger than shape of signal")
+    N = max((L - ntaps + 1) // os, 0)
+    out = np.zeros((modes.size, N), dtype=E.dtype)
+    name = "qh_apply_filter_" + (("c64" if suf == "32" else "c128") if np.iscomplexobj(E) else "f" + suf)
+    if wx.shape[0] != nmodes:
+        raise ValueError("wx must be (nmodes, nmodes, ntaps)")
+    _lib.call(name, _lib.ptr(E), nmodes, L, int(os), _lib.ptr(wx), ntaps, _lib.ptr(modes), modes.size, _lib.ptr(out))
+    return out
+
+
+def make_decision(E, symbols):
+    """Nearest alphabet point, its |distance| and index for every sample (pythran_equalisation.py:304-334)."""
+    suf, rt, ct = _lib.suffix(E.dtype)
+    E = np.ascontiguousarray(E)
+    _need(E, ct, "E")
+    symbols = np.ascontiguousarray(symbols)
+    _need(symbols, ct, "symbols")
+    L = E.shape[0]
+    det = np.zeros(L, dtype=ct)
+    dist = np.zeros(L, dtype=rt)
+    idx = np.zeros(L, dtype=np.int32)
+    _lib.call("qh_make_decision_c" + ("64" if suf == "32" else "128"), _lib.ptr(E), L, _lib.ptr(symbols), symbols.size,
+              _lib.ptr(det), _lib.ptr(dist), _lib.ptr(idx))
+    return det, dist, idx
+
+
+def det_symbol(X, symbs):
+    """Scalar decision ``(symbol, squared distance)`` (pythran_equalisation.py:238-265), evaluated on the device."""
+    symbs = np.ascontiguousarray(symbs)
+    det, dist, _ = make_decision(np.array([X], dtype=symbs.dtype), symbs)
+    return det[0], dist[0] ** 2
+
+
+# ------------------------------------------------------------------------------------------------ device-resident forms
+def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method, err, zero_err=False):
+    """
+    Same as :func:`train_equaliser` with every array (and the scalar ``mu``, a 1-element DeviceArray) already in HBM.
+    Only enqueues work on the library stream.
+    """
+    if method not in _lib.METHOD_ID:
+        raise ValueError("Unknown method %s" % method)
+    suf, rt, ct = _lib.suffix(E.dtype)
+    nmodes, L = E.shape
+    ntaps = wx.shape[-1]
+    modes = _as_modes(modes, nmodes)
+    _lib.call("qh_train_equaliser_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, nmodes, L, int(TrSyms), int(Niter),
+              int(os), mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size, int(bool(adaptive)), symbols.ptr,
+              symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)))
+
+
+def apply_filter_to_signal_dev(E, os, wx, modes, out):
+    suf, rt, ct = _lib.suffix(E.dtype)
+    nmodes, L = E.shape
+    modes = _as_modes(modes, wx.shape[0])
+    _lib.call("qh_apply_filter_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, nmodes, L, int(os), wx.ptr, wx.shape[-1],
+              _lib.ptr(modes), modes.size, out.ptr)
+
+
+def make_decision_dev(E, symbols, det, dist, idx):
+    suf, rt, ct = _lib.suffix(E.dtype)
+    L = int(np.prod(E.shape))
+    _lib.call("qh_make_decision_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, L, symbols.ptr, int(np.prod(symbols.shape)),
+              det.ptr if det is not None else None, dist.ptr if dist is not None else None, idx.ptr)

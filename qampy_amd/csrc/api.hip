@@ -1,0 +1,166 @@
+// Runtime part of libqampy_hip: device selection, the library stream, device memory, events, error text.
+#include "common.h"
+#include <mutex>
+#include <string.h>
+
+namespace qh {
+
+hipStream_t g_stream = nullptr;
+int g_device = -1;
+static thread_local std::string g_err;
+static std::mutex g_mu;
+
+void set_error(const std::string &s) { g_err = s; }
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    g_err = std::string(hipGetErrorString(e)) + " in " + what + " (" + file + ":" + std::to_string(line) + ")";
+    (void)hipGetLastError();
+    return QH_ERR_HIP;
+}
+
+static int init_device(int device)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_stream && device == g_device) return QH_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device visible: libqampy_hip needs a gfx950 (MI355X) GPU, there is no CPU fallback");
+        return QH_ERR_NODEVICE;
+    }
+    if (device < 0 || device >= n) { set_error("device index out of range"); return QH_ERR_ARG; }
+    hipDeviceProp_t prop;
+    QH_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("device is ") + prop.gcnArchName + ", libqampy_hip is built for gfx950 only");
+        return QH_ERR_NODEVICE;
+    }
+    QH_HIP(hipSetDevice(device));
+    if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+    QH_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device;
+    return QH_OK;
+}
+
+int ensure_init()
+{
+    if (g_stream) return QH_OK;
+    return init_device(0);
+}
+
+// grow-only scratch slots so that the resident pipeline never allocates (and never synchronises) inside a timed region
+static void *g_scratch[8] = {nullptr};
+static size_t g_scratch_n[8] = {0};
+int scratch(int slot, size_t bytes, void **p)
+{
+    if (bytes > g_scratch_n[slot]) {
+        if (g_scratch[slot]) QH_HIP(hipFree(g_scratch[slot]));
+        g_scratch[slot] = nullptr; g_scratch_n[slot] = 0;
+        QH_HIP(hipMalloc(&g_scratch[slot], bytes));
+        g_scratch_n[slot] = bytes;
+    }
+    *p = g_scratch[slot];
+    return QH_OK;
+}
+
+}  // namespace qh
+
+extern "C" {
+
+int qh_device_count(int *count)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return QH_OK;
+}
+int qh_init(int device) { return qh::init_device(device); }
+int qh_device_name(char *buf, size_t n)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    QH_HIP(hipGetDeviceProperties(&prop, qh::g_device));
+    snprintf(buf, n, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return QH_OK;
+}
+const char *qh_last_error(void) { return qh::g_err.c_str(); }
+int qh_sync(void)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    QH_HIP(hipStreamSynchronize(qh::g_stream));
+    return QH_OK;
+}
+int qh_malloc(void **dptr, size_t bytes)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    QH_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return QH_OK;
+}
+int qh_free(void *dptr)
+{
+    if (dptr) QH_HIP(hipFree(dptr));
+    return QH_OK;
+}
+int qh_memset(void *dptr, int value, size_t bytes)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    if (bytes) QH_HIP(hipMemsetAsync(dptr, value, bytes, qh::g_stream));
+    return QH_OK;
+}
+int qh_memcpy_h2d(void *dptr, const void *hptr, size_t bytes)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    if (bytes) QH_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, qh::g_stream));
+    QH_HIP(hipStreamSynchronize(qh::g_stream));
+    return QH_OK;
+}
+int qh_memcpy_d2h(void *hptr, const void *dptr, size_t bytes)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    if (bytes) QH_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, qh::g_stream));
+    QH_HIP(hipStreamSynchronize(qh::g_stream));
+    return QH_OK;
+}
+int qh_memcpy_d2d(void *dst, const void *src, size_t bytes)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    if (bytes) QH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, qh::g_stream));
+    return QH_OK;
+}
+int qh_event_create(void **ev)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    hipEvent_t e;
+    QH_HIP(hipEventCreate(&e));
+    *ev = (void *)e;
+    return QH_OK;
+}
+int qh_event_destroy(void *ev)
+{
+    if (ev) QH_HIP(hipEventDestroy((hipEvent_t)ev));
+    return QH_OK;
+}
+int qh_event_record(void *ev)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    QH_HIP(hipEventRecord((hipEvent_t)ev, qh::g_stream));
+    return QH_OK;
+}
+int qh_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    QH_HIP(hipEventSynchronize((hipEvent_t)stop));
+    QH_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return QH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,426 @@
+// Blind phase search carrier recovery on gfx950.
+//
+// Reference behaviour:
+//   qampy/core/pythran_dsp.py:45-85   bps: dists[i, a] = min_k |E[i]*exp(j*theta_a) - s_k|^2   (det_symbol :16-23)
+//   qampy/core/pythran_dsp.py:26-42   select_angle_index(dists, 2N): idx[i] = first argmin_a sum_{l=i-N+1}^{i+N} dists[l, a]
+//                                     for N <= i < L-N, else 0 (the reference forms the window sum as a difference of
+//                                     running sums; here it is a direct 2N-term sum)
+//   qampy/core/pythran_dsp.py:133-153 select_angles
+//   qampy/core/phaserecovery.py:145-159 host layer: linspace grid, unwrap(4 ph)/4 on [N, L-N), E*exp(j ph)
+//
+// Bound: fp32 VALU (A*M distance evaluations per symbol, ~25 kflop against 20 B), not HBM.  The (L, A) distance matrix
+// the reference materialises (1 GiB per mode at 2^22 symbols) never leaves the CU:
+//   * one workgroup owns a tile of T output symbols and computes the (T + 2N - 1) x A distances of tile + halo into
+//     LDS (thread <-> (symbol, angle) pairs, alphabet through the scalar cache);
+//   * window sums are column sums over that LDS tile (lane <-> angle, conflict free), written to a padded LDS plane;
+//   * one thread per symbol scans the A sums for the first strict minimum (tie -> lowest angle, like the reference).
+#include "common.h"
+
+namespace qh {
+
+constexpr int BPS_THREADS = 512;
+constexpr size_t BPS_LDS_BUDGET = 120 * 1024;
+
+template <typename R> __device__ __forceinline__ void sincos_(R x, R *s, R *c);
+template <> __device__ __forceinline__ void sincos_<float>(float x, float *s, float *c) { sincosf(x, s, c); }
+template <> __device__ __forceinline__ void sincos_<double>(double x, double *s, double *c) { sincos(x, s, c); }
+
+template <typename R> struct BpsArgs {
+    const Cx<R> *E;        // (L,)
+    const R *angles;       // (p, A)
+    const Cx<R> *symbols;  // (M,)
+    int32_t *idx;          // (L,)
+    int64_t L, p;
+    int A, M, N, T;
+};
+
+template <typename R>
+__global__ void __launch_bounds__(BPS_THREADS) bps_kernel(BpsArgs<R> a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int A = a.A, N = a.N, T = a.T;
+    const int rows = T + 2 * N - 1;
+    R *dist = reinterpret_cast<R *>(smem);                 // [rows][A]
+    R *wsum = dist + (size_t)rows * A;                     // [T][A + 1]
+    const int64_t i0 = (int64_t)blockIdx.x * T;            // first output symbol of this tile
+    const int64_t l0 = i0 - N + 1;                         // symbol index of dist row 0
+    const bool per_symbol = a.p > 1;
+
+    // ---- phase 1: min-distance of every (symbol, test angle) of tile + halo
+    for (int e = threadIdx.x; e < rows * A; e += BPS_THREADS) {
+        const int r = e / A, ja = e - r * A;
+        const int64_t l = l0 + r;
+        R d0 = 0;                                           // rows outside [0, L) only feed outputs that are forced to 0
+        if (l >= 0 && l < a.L) {
+            const Cx<R> x = ldg(a.E + l);
+            R sn, cs;
+            sincos_<R>(a.angles[(per_symbol ? (size_t)l * A : 0) + ja], &sn, &cs);
+            const R tr = fma_(x.re, cs, -(x.im * sn)), ti = fma_(x.re, sn, x.im * cs);
+            d0 = (R)1000.;                                  // det_symbol: strict `<` from d0 = 1000 (:17-22)
+            for (int k = 0; k < a.M; k++) {
+                const Cx<R> s = a.symbols[k];               // wave-uniform -> scalar load
+                const R dr = tr - s.re, di = ti - s.im;
+                const R d = fma_(dr, dr, di * di);
+                d0 = d < d0 ? d : d0;
+            }
+            d0 = d0 < (R)100. ? d0 : (R)100.;               // dists initialised to 100 (:73, :83)
+        }
+        dist[e] = d0;
+    }
+    __syncthreads();
+    // ---- phase 2: windowed sums, output symbol il <-> dist rows il .. il + 2N - 1
+    for (int e = threadIdx.x; e < T * A; e += BPS_THREADS) {
+        const int il = e / A, ja = e - il * A;
+        const R *col = dist + (size_t)il * A + ja;
+        R s = 0;
+        for (int r = 0; r < 2 * N; r++) s += col[(size_t)r * A];
+        wsum[(size_t)il * (A + 1) + ja] = s;
+    }
+    __syncthreads();
+    // ---- phase 3: first arg-min over the test angles (dmin starts at 1000, strict `<`, :31-41)
+    for (int il = threadIdx.x; il < T; il += BPS_THREADS) {
+        const int64_t i = i0 + il;
+        if (i >= a.L) break;
+        int best = 0;
+        if (i >= N && i < a.L - N) {
+            R dmin = (R)1000.;
+            const R *row = wsum + (size_t)il * (A + 1);
+            for (int ja = 0; ja < A; ja++) {
+                const R v = row[ja];
+                if (v < dmin) { dmin = v; best = ja; }
+            }
+        }
+        a.idx[i] = best;
+    }
+}
+
+template <typename R> static int bps_tile(int A, int N, size_t *lds)
+{
+    // largest T with (T + 2N - 1)*A + T*(A + 1) elements inside the LDS budget
+    const int64_t cap = (int64_t)(BPS_LDS_BUDGET / sizeof(R));
+    int64_t T = (cap - (int64_t)(2 * N - 1) * A) / (2 * A + 1);
+    if (T > 1024) T = 1024;
+    if (T < 1) return 0;
+    *lds = ((size_t)(T + 2 * N - 1) * A + (size_t)T * (A + 1)) * sizeof(R);
+    return (int)T;
+}
+
+template <typename R>
+int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, const void *symbols, int M, int N, int32_t *idx)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    QH_REQUIRE(L >= 0 && A >= 1 && M >= 1 && N >= 1, "bps: bad sizes");
+    QH_REQUIRE(p == 1 || p == L, "bps: p must be either 1 or the length of the input signal");
+    if (L == 0) return QH_OK;
+    size_t lds = 0;
+    const int T = bps_tile<R>(A, N, &lds);
+    QH_REQUIRE(T >= 8, "bps: averaging window 2N x test angles does not fit the LDS tile");
+    BpsArgs<R> a;
+    a.E = (const Cx<R> *)E; a.angles = (const R *)angles; a.symbols = (const Cx<R> *)symbols; a.idx = idx;
+    a.L = L; a.p = p; a.A = A; a.M = M; a.N = N; a.T = T;
+    static bool attr_set = false;
+    if (!attr_set) {
+        QH_HIP(hipFuncSetAttribute((const void *)bps_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BPS_LDS_BUDGET));
+        QH_HIP(hipFuncSetAttribute((const void *)bps_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BPS_LDS_BUDGET));
+        attr_set = true;
+    }
+    const unsigned nblk = (unsigned)((L + T - 1) / T);
+    hipLaunchKernelGGL((bps_kernel<R>), dim3(nblk), dim3(BPS_THREADS), lds, g_stream, a);
+    QH_HIP(hipGetLastError());
+    return QH_OK;
+}
+
+template <typename R>
+int bps_host(const void *E, int64_t L, const void *angles, int64_t p, int A, const void *symbols, int M, int N, int32_t *idx)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    QH_REQUIRE(L >= 0 && A >= 1 && M >= 1 && N >= 1, "bps: bad sizes");
+    QH_REQUIRE(p == 1 || p == L, "bps: p must be either 1 or the length of the input signal");
+    if (L == 0) return QH_OK;
+    DevBuf dE, da, ds, di;
+    if ((rc = dE.from_host(E, (size_t)L * sizeof(Cx<R>)))) return rc;
+    if ((rc = da.from_host(angles, (size_t)p * A * sizeof(R)))) return rc;
+    if ((rc = ds.from_host(symbols, (size_t)M * sizeof(Cx<R>)))) return rc;
+    if ((rc = di.alloc((size_t)L * sizeof(int32_t)))) return rc;
+    if ((rc = bps_dev<R>(dE.p, L, da.p, p, A, ds.p, M, N, (int32_t *)di.p))) return rc;
+    if ((rc = di.to_host(idx, di.n))) return rc;
+    QH_HIP(hipStreamSynchronize(g_stream));
+    return QH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ unwrap + de-rotation
+// Device form of phaserecovery.py:145-159 for the resident pipeline.  With the linspace grid 4*ph = -pi + 2*pi*k/A, so
+// np.unwrap's correction is -2*pi when k jumps by more than A/2, +2*pi when it drops by more than A/2 and 0 otherwise
+// (|jump| == A/2 maps to 0: numpy keeps dd = +-pi).  The running correction is an integer prefix sum - exact.
+constexpr int UW_THREADS = 256;
+constexpr int UW_PER_THREAD = 16;
+constexpr int UW_CHUNK = UW_THREADS * UW_PER_THREAD;
+
+__device__ __forceinline__ int unwrap_jump(int kprev, int kcur, int A)
+{
+    const int d = kcur - kprev;
+    return (2 * d > A) ? -1 : ((2 * d < -A) ? 1 : 0);
+}
+
+__global__ void __launch_bounds__(UW_THREADS) unwrap_partial_kernel(const int32_t *idx, int64_t L, int N, int A, int *chunk_sum,
+                                                                     int64_t nchunk)
+{
+    // sums of the jump indicators of one chunk of one mode; interior = [N, L-N), the first interior element has no jump
+    __shared__ int red[UW_THREADS / 64];
+    const int64_t mode = blockIdx.y;
+    const int32_t *ix = idx + mode * L;
+    const int64_t base = (int64_t)blockIdx.x * UW_CHUNK;
+    int s = 0;
+    for (int r = 0; r < UW_PER_THREAD; r++) {
+        const int64_t i = base + threadIdx.x + (int64_t)r * UW_THREADS;
+        if (i > N && i < L - N) s += unwrap_jump(ix[i - 1], ix[i], A);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < UW_THREADS / 64; w++) t += red[w];
+        chunk_sum[mode * nchunk + blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(64) unwrap_scan_kernel(int *chunk_sum, int64_t nchunk)
+{
+    // exclusive scan of the chunk sums of one mode by a single wave (nchunk is a few thousand at most)
+    int *cs = chunk_sum + (int64_t)blockIdx.x * nchunk;
+    int carry = 0;
+    for (int64_t b = 0; b < nchunk; b += 64) {
+        const int64_t i = b + threadIdx.x;
+        int v = i < nchunk ? cs[i] : 0;
+        int incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o);
+            if ((int)threadIdx.x >= o) incl += t;
+        }
+        if (i < nchunk) cs[i] = carry + incl - v;
+        carry += __shfl(incl, 63);
+    }
+}
+
+template <typename R>
+__global__ void __launch_bounds__(UW_THREADS) unwrap_apply_kernel(const Cx<R> *E, const int32_t *idx, const int *chunk_off,
+                                                                   int64_t L, int N, int A, int64_t nchunk, R *ph, Cx<R> *Eout)
+{
+    __shared__ int wsum[UW_THREADS / 64];
+    __shared__ int tsum[UW_THREADS];
+    const int64_t mode = blockIdx.y;
+    const int32_t *ix = idx + mode * L;
+    const int64_t base = (int64_t)blockIdx.x * UW_CHUNK;
+    // each thread owns UW_PER_THREAD consecutive symbols so the in-chunk prefix is a short serial run + a block scan
+    const int64_t t0 = base + (int64_t)threadIdx.x * UW_PER_THREAD;
+    int jmp[UW_PER_THREAD];
+    int local = 0;
+#pragma unroll
+    for (int r = 0; r < UW_PER_THREAD; r++) {
+        const int64_t i = t0 + r;
+        int j = 0;
+        if (i > N && i < L - N) j = unwrap_jump(ix[i - 1], ix[i], A);
+        local += j;
+        jmp[r] = local;                       // inclusive within the thread
+    }
+    // block exclusive scan of `local`
+    int incl = local;
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o);
+        if ((int)(threadIdx.x & 63) >= o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    tsum[threadIdx.x] = incl - local;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) woff += wsum[w];
+    const int off = chunk_off[mode * nchunk + blockIdx.x] + woff + tsum[threadIdx.x];
+    const R pi = (R)3.14159265358979323846;
+    const R step = (pi / 2) / (R)A;            // linspace(-pi/4, pi/4, A, endpoint=False) spacing
+#pragma unroll
+    for (int r = 0; r < UW_PER_THREAD; r++) {
+        const int64_t i = t0 + r;
+        if (i < L) {
+            const bool interior = (i >= N && i < L - N);
+            const int k = ix[i];
+            // edges keep the raw grid value of idx = 0, i.e. -pi/4 (phaserecovery.py:155 unwraps the interior only)
+            R p = -pi / 4 + step * (R)k;
+            if (interior) p += (pi / 2) * (R)(off + jmp[r]);
+            ph[mode * L + i] = p;
+            R sn, cs;
+            sincos_<R>(p, &sn, &cs);
+            const Cx<R> x = ldg(E + mode * L + i);
+            stg(Eout + mode * L + i, Cx<R>{fma_(x.re, cs, -(x.im * sn)), fma_(x.re, sn, x.im * cs)});
+        }
+    }
+}
+
+template <typename R> __global__ void linspace_kernel(R *angles, int A)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const R pi = (R)3.14159265358979323846;
+    if (j < A) angles[j] = -pi / 4 + ((pi / 2) / (R)A) * (R)j;
+}
+
+template <typename R>
+int bps_recover_dev(const void *E, int nm, int64_t L, int A, const void *symbols, int M, int N, int32_t *idx, void *ph, void *Eout)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    QH_REQUIRE(nm >= 1 && L >= 1 && A >= 1, "bps_recover: bad sizes");
+    const int64_t nchunk = (L + UW_CHUNK - 1) / UW_CHUNK;
+    void *dang = nullptr, *dchunk = nullptr;     // grow-only library scratch: no allocation / sync in the steady state
+    if ((rc = scratch(0, (size_t)A * sizeof(R), &dang))) return rc;
+    if ((rc = scratch(1, (size_t)nm * nchunk * sizeof(int), &dchunk))) return rc;
+    hipLaunchKernelGGL((linspace_kernel<R>), dim3((A + 63) / 64), dim3(64), 0, g_stream, (R *)dang, A);
+    for (int m = 0; m < nm; m++)
+        if ((rc = bps_dev<R>((const Cx<R> *)E + (size_t)m * L, L, dang, 1, A, symbols, M, N, idx + (size_t)m * L))) return rc;
+    hipLaunchKernelGGL(unwrap_partial_kernel, dim3((unsigned)nchunk, nm), dim3(UW_THREADS), 0, g_stream, idx, L, N, A,
+                       (int *)dchunk, nchunk);
+    hipLaunchKernelGGL(unwrap_scan_kernel, dim3(nm), dim3(64), 0, g_stream, (int *)dchunk, nchunk);
+    hipLaunchKernelGGL((unwrap_apply_kernel<R>), dim3((unsigned)nchunk, nm), dim3(UW_THREADS), 0, g_stream, (const Cx<R> *)E, idx,
+                       (const int *)dchunk, L, N, A, nchunk, (R *)ph, (Cx<R> *)Eout);
+    QH_HIP(hipGetLastError());
+    return QH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ select_angles
+template <typename R>
+__global__ void select_angles_kernel(const R *angles, int64_t p, int A, const int64_t *idx, int64_t L, R *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < L) out[i] = angles[(p > 1 ? (size_t)i * A : 0) + idx[i]];
+}
+
+template <typename R> int select_angles_host(const void *angles, int64_t p, int A, const int64_t *idx, int64_t L, void *out)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    QH_REQUIRE(p >= 1 && A >= 1 && L >= 0, "select_angles: bad sizes");
+    QH_REQUIRE(p == 1 || p >= L, "select_angles: angle grid has fewer rows than idx");
+    if (L == 0) return QH_OK;
+    DevBuf da, di, dout;
+    if ((rc = da.from_host(angles, (size_t)p * A * sizeof(R)))) return rc;
+    if ((rc = di.from_host(idx, (size_t)L * sizeof(int64_t)))) return rc;
+    if ((rc = dout.alloc((size_t)L * sizeof(R)))) return rc;
+    hipLaunchKernelGGL((select_angles_kernel<R>), dim3((unsigned)((L + 255) / 256)), dim3(256), 0, g_stream, (const R *)da.p, p, A,
+                       (const int64_t *)di.p, L, (R *)dout.p);
+    QH_HIP(hipGetLastError());
+    if ((rc = dout.to_host(out, dout.n))) return rc;
+    QH_HIP(hipStreamSynchronize(g_stream));
+    return QH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ make_decision
+// pythran_equalisation.py:304-334 via det_symbol_argmin :233-236: np.abs distance, first arg-min.
+template <typename R> __device__ __forceinline__ R hypot_(R a, R b);
+template <> __device__ __forceinline__ float hypot_<float>(float a, float b) { return hypotf(a, b); }
+template <> __device__ __forceinline__ double hypot_<double>(double a, double b) { return hypot(a, b); }
+
+template <typename R>
+__global__ void __launch_bounds__(256) make_decision_kernel(const Cx<R> *E, int64_t L, const Cx<R> *symbols, int M, Cx<R> *det,
+                                                            R *dist, int32_t *idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L) return;
+    const Cx<R> x = ldg(E + i);
+    Cx<R> s0 = symbols[0];
+    R best = hypot_<R>(x.re - s0.re, x.im - s0.im);
+    int ib = 0;
+    for (int k = 1; k < M; k++) {
+        const Cx<R> s = symbols[k];
+        const R d = hypot_<R>(x.re - s.re, x.im - s.im);
+        if (d < best) { best = d; ib = k; s0 = s; }
+    }
+    stg(det + i, s0);
+    dist[i] = best;
+    idx[i] = ib;
+}
+
+template <typename R> int make_decision_dev(const void *E, int64_t L, const void *symbols, int M, void *det, void *dist, int32_t *idx)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    QH_REQUIRE(L >= 0 && M >= 1, "make_decision: bad sizes");
+    if (L == 0) return QH_OK;
+    hipLaunchKernelGGL((make_decision_kernel<R>), dim3((unsigned)((L + 255) / 256)), dim3(256), 0, g_stream, (const Cx<R> *)E, L,
+                       (const Cx<R> *)symbols, M, (Cx<R> *)det, (R *)dist, idx);
+    QH_HIP(hipGetLastError());
+    return QH_OK;
+}
+
+template <typename R> int make_decision_host(const void *E, int64_t L, const void *symbols, int M, void *det, void *dist, int32_t *idx)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    QH_REQUIRE(L >= 0 && M >= 1, "make_decision: bad sizes");
+    if (L == 0) return QH_OK;
+    DevBuf dE, ds, dd, dr, di;
+    if ((rc = dE.from_host(E, (size_t)L * sizeof(Cx<R>)))) return rc;
+    if ((rc = ds.from_host(symbols, (size_t)M * sizeof(Cx<R>)))) return rc;
+    if ((rc = dd.alloc((size_t)L * sizeof(Cx<R>)))) return rc;
+    if ((rc = dr.alloc((size_t)L * sizeof(R)))) return rc;
+    if ((rc = di.alloc((size_t)L * sizeof(int32_t)))) return rc;
+    if ((rc = make_decision_dev<R>(dE.p, L, ds.p, M, dd.p, dr.p, (int32_t *)di.p))) return rc;
+    if ((rc = dd.to_host(det, dd.n))) return rc;
+    if ((rc = dr.to_host(dist, dr.n))) return rc;
+    if ((rc = di.to_host(idx, di.n))) return rc;
+    QH_HIP(hipStreamSynchronize(g_stream));
+    return QH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ error counter
+__global__ void __launch_bounds__(256) count_errors_kernel(const int32_t *rx, const int32_t *tx, int64_t n, int64_t lag, int64_t ntx,
+                                                           unsigned long long *count)
+{
+    int c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t it = i - lag;
+        if (it >= 0 && it < ntx) c += rx[i] != tx[it];
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+}
+
+}  // namespace qh
+
+extern "C" {
+int qh_bps_c64(const void *E, int64_t L, const void *t, int64_t p, int A, const void *s, int M, int N, int32_t *idx)
+{ return qh::bps_host<float>(E, L, t, p, A, s, M, N, idx); }
+int qh_bps_c128(const void *E, int64_t L, const void *t, int64_t p, int A, const void *s, int M, int N, int32_t *idx)
+{ return qh::bps_host<double>(E, L, t, p, A, s, M, N, idx); }
+int qh_bps_c64_dev(const void *E, int64_t L, const void *t, int64_t p, int A, const void *s, int M, int N, int32_t *idx)
+{ return qh::bps_dev<float>(E, L, t, p, A, s, M, N, idx); }
+int qh_bps_c128_dev(const void *E, int64_t L, const void *t, int64_t p, int A, const void *s, int M, int N, int32_t *idx)
+{ return qh::bps_dev<double>(E, L, t, p, A, s, M, N, idx); }
+int qh_bps_recover_c64_dev(const void *E, int nm, int64_t L, int A, const void *s, int M, int N, int32_t *idx, void *ph, void *Eout)
+{ return qh::bps_recover_dev<float>(E, nm, L, A, s, M, N, idx, ph, Eout); }
+int qh_bps_recover_c128_dev(const void *E, int nm, int64_t L, int A, const void *s, int M, int N, int32_t *idx, void *ph, void *Eout)
+{ return qh::bps_recover_dev<double>(E, nm, L, A, s, M, N, idx, ph, Eout); }
+int qh_select_angles_f32(const void *angles, int64_t p, int A, const int64_t *idx, int64_t L, void *out)
+{ return qh::select_angles_host<float>(angles, p, A, idx, L, out); }
+int qh_select_angles_f64(const void *angles, int64_t p, int A, const int64_t *idx, int64_t L, void *out)
+{ return qh::select_angles_host<double>(angles, p, A, idx, L, out); }
+int qh_make_decision_c64(const void *E, int64_t L, const void *s, int M, void *det, void *dist, int32_t *idx)
+{ return qh::make_decision_host<float>(E, L, s, M, det, dist, idx); }
+int qh_make_decision_c128(const void *E, int64_t L, const void *s, int M, void *det, void *dist, int32_t *idx)
+{ return qh::make_decision_host<double>(E, L, s, M, det, dist, idx); }
+int qh_make_decision_c64_dev(const void *E, int64_t L, const void *s, int M, void *det, void *dist, int32_t *idx)
+{ return qh::make_decision_dev<float>(E, L, s, M, det, dist, idx); }
+int qh_make_decision_c128_dev(const void *E, int64_t L, const void *s, int M, void *det, void *dist, int32_t *idx)
+{ return qh::make_decision_dev<double>(E, L, s, M, det, dist, idx); }
+int qh_count_errors_dev(const int32_t *rx, const int32_t *tx, int64_t n, int64_t lag, int64_t ntx, unsigned long long *count_dev)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    if (n <= 0) return QH_OK;
+    unsigned nb = (unsigned)((n + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(qh::count_errors_kernel, dim3(nb), dim3(256), 0, qh::g_stream, rx, tx, n, lag, ntx, count_dev);
+    QH_HIP(hipGetLastError());
+    return QH_OK;
+}
+}

@@ -1,0 +1,149 @@
+// Shared device/host helpers of libqampy_hip (gfx950 only; wave64 is hard-coded throughout).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/qampy_hip.h"
+
+namespace qh {
+
+// ---------------------------------------------------------------------------------------------- host-side state
+extern hipStream_t g_stream;
+extern int g_device;
+void set_error(const std::string &s);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define QH_HIP(call)                                                        \
+    do {                                                                    \
+        hipError_t _e = (call);                                             \
+        if (_e != hipSuccess) return qh::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define QH_REQUIRE(cond, msg)                                   \
+    do {                                                        \
+        if (!(cond)) { qh::set_error(msg); return QH_ERR_ARG; } \
+    } while (0)
+
+int ensure_init();
+int scratch(int slot, size_t bytes, void **p);   // grow-only device scratch, slots 0..7
+
+// RAII device scratch used by the host-pointer entry points
+struct DevBuf {
+    void *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        n = bytes;
+        QH_HIP(hipMalloc(&p, bytes ? bytes : 1));
+        return QH_OK;
+    }
+    int from_host(const void *h, size_t bytes) {
+        int rc = alloc(bytes);
+        if (rc) return rc;
+        if (bytes) QH_HIP(hipMemcpyAsync(p, h, bytes, hipMemcpyHostToDevice, g_stream));
+        return QH_OK;
+    }
+    int to_host(void *h, size_t bytes) const {
+        if (bytes) QH_HIP(hipMemcpyAsync(h, p, bytes, hipMemcpyDeviceToHost, g_stream));
+        return QH_OK;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- complex pairs
+template <typename R> struct Cx { R re, im; };
+
+template <typename R> struct Cx2T;
+template <> struct Cx2T<float> { using type = float2; };
+template <> struct Cx2T<double> { using type = double2; };
+
+template <typename R> __device__ __forceinline__ Cx<R> ldg(const Cx<R> *p)
+{
+    using V = typename Cx2T<R>::type;
+    V v = *reinterpret_cast<const V *>(p);
+    return Cx<R>{v.x, v.y};
+}
+template <typename R> __device__ __forceinline__ void stg(Cx<R> *p, Cx<R> v)
+{
+    using V = typename Cx2T<R>::type;
+    V o; o.x = v.re; o.y = v.im;
+    *reinterpret_cast<V *>(p) = o;
+}
+
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float abs_(float a) { return __builtin_fabsf(a); }
+__device__ __forceinline__ double abs_(double a) { return __builtin_fabs(a); }
+__device__ __forceinline__ float min_(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double min_(double a, double b) { return __builtin_fmin(a, b); }
+
+// ---------------------------------------------------------------------------------------------- wave64 cross-lane
+// DPP controls (gfx9 encoding)
+constexpr int DPP_QUAD_1032 = 0xB1;        // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_2301 = 0x4E;        // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+constexpr int DPP_ROW_BCAST15 = 0x142;
+constexpr int DPP_ROW_BCAST31 = 0x143;
+
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp_mov(float v)
+{
+    // lanes whose row is masked off keep `old` (= 0): adding it is a no-op, exactly what the row_bcast steps need
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ double dpp_mov(double v)
+{
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = (int)b, hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ float readlane(float v, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double readlane(double v, int lane)
+{
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_readlane((int)b, lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ int readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// sum over the 64 lanes of a wave; the total is returned wave-uniformly (read back from lane 63)
+template <typename R> __device__ __forceinline__ R wave_sum(R v)
+{
+    v += dpp_mov<DPP_QUAD_1032>(v);
+    v += dpp_mov<DPP_QUAD_2301>(v);
+    v += dpp_mov<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_mov<DPP_ROW_MIRROR>(v);
+    v += dpp_mov<DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_mov<DPP_ROW_BCAST31, 0xC>(v);
+    return readlane(v, 63);
+}
+// two sums with their DPP chains interleaved (re / im of a complex dot product)
+template <typename R> __device__ __forceinline__ void wave_sum2(R &a, R &b)
+{
+    a += dpp_mov<DPP_QUAD_1032>(a);            b += dpp_mov<DPP_QUAD_1032>(b);
+    a += dpp_mov<DPP_QUAD_2301>(a);            b += dpp_mov<DPP_QUAD_2301>(b);
+    a += dpp_mov<DPP_ROW_HALF_MIRROR>(a);      b += dpp_mov<DPP_ROW_HALF_MIRROR>(b);
+    a += dpp_mov<DPP_ROW_MIRROR>(a);           b += dpp_mov<DPP_ROW_MIRROR>(b);
+    a += dpp_mov<DPP_ROW_BCAST15, 0xA>(a);     b += dpp_mov<DPP_ROW_BCAST15, 0xA>(b);
+    a += dpp_mov<DPP_ROW_BCAST31, 0xC>(a);     b += dpp_mov<DPP_ROW_BCAST31, 0xC>(b);
+    a = readlane(a, 63);
+    b = readlane(b, 63);
+}
+// min over the 64 lanes, returned wave-uniformly
+template <typename R> __device__ __forceinline__ R wave_min(R v)
+{
+    // masked-off rows would read `old` = 0, so the bcast steps are written with explicit selects instead
+    v = min_(v, dpp_mov<DPP_QUAD_1032>(v));
+    v = min_(v, dpp_mov<DPP_QUAD_2301>(v));
+    v = min_(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    v = min_(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    R r0 = readlane(v, 0), r1 = readlane(v, 16), r2 = readlane(v, 32), r3 = readlane(v, 48);
+    return min_(min_(r0, r1), min_(r2, r3));
+}
+
+}  // namespace qh

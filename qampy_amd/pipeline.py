@@ -1,0 +1,125 @@
+"""
+Device-resident receiver: dual-mode equalisation + filter application + blind phase search without leaving HBM.
+
+The reference chains ``dual_mode_equalisation`` (qampy/core/equalisation/equalisation.py:400-466) and ``bps``
+(qampy/core/phaserecovery.py:93-159) through host ndarrays; on MI355X the capture, the taps, the error traces and the
+recovered symbols stay in HBM between the stages (SURVEY.md §8b "optional persistent device buffers") and every stage is
+one or a few kernel launches on the library stream.  Host-side logic (constants, tap initialisation, default training
+length) is shared with :mod:`qampy_amd.core.equalisation.equalisation`, so both paths take identical decisions.
+
+Layout in HBM (complex64 for the headline configs):
+    E        (nmodes, L)            capture, 2 samples/symbol, row-major (coalesced along time)
+    wxy      (nmodes, nmodes, Nt)   taps (1312 B at 2x2x41)
+    err1/2   (nmodes, TrSyms*Niter) error traces of the two stages
+    eq       (nmodes, N)            equalised, decimated signal, N = (L - Nt + 1)//os
+    idx, ph, out (nmodes, N)        BPS index, applied phase, phase-recovered symbols
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import DeviceArray
+from .core.equalisation import equalisation as _host
+from .core.equalisation import hip_equalisation as _k
+from .core import hip_dsp as _dsp
+
+
+class ResidentReceiver:
+    """
+    One capture's worth of preallocated device state.
+
+    Parameters mirror ``dual_mode_equalisation`` + ``bps``: ``mu``, ``Niter``, ``methods``, ``adaptive_stepsize`` are
+    2-tuples (pass ``methods=("mcma",)`` etc. with 1-tuples for a single stage), ``Mtestangles``/``Nbps`` the BPS
+    parameters (``Mtestangles=None`` skips carrier recovery).
+    """
+
+    def __init__(self, nmodes, L, os, M, Ntaps, mu, methods=("cma", "mrde"), Niter=(1, 1), adaptive_stepsize=(False, False),
+                 TrSyms=(None, None), Mtestangles=64, Nbps=20, dtype=np.complex64, alphabet=None, modes=None):
+        suf, self.rt, self.ct = _lib.suffix(dtype)
+        self.nmodes, self.L, self.os, self.M, self.Ntaps = int(nmodes), int(L), int(os), int(M), int(Ntaps)
+        self.nstage = len(methods)
+        self.methods = tuple(m.lower() for m in methods)
+        for m in self.methods:
+            if m in _host.REAL_VALUED or m in _host.DATA_AIDED:
+                raise ValueError("the resident pipeline runs the blind / decision-directed complex methods; %s is not one" % m)
+            if m not in _host.TRAINING_FCTS:
+                raise ValueError("%s is unknown method" % m)
+        self.Niter = tuple(int(n) for n in Niter)
+        self.adaptive = tuple(bool(a) for a in adaptive_stepsize)
+        self.modes = np.arange(nmodes) if modes is None else np.atleast_1d(modes)
+        self.TrSyms = tuple(_host._cal_training_symbol_len(os, Ntaps, L) if t is None else int(t) for t in TrSyms[:self.nstage])
+        self.N = (self.L - self.Ntaps + 1) // self.os
+        self.Mtestangles, self.Nbps = Mtestangles, Nbps
+        self.mu0 = tuple(self.rt(m) for m in mu)
+        if alphabet is None:
+            alphabet = _host.generate_symbols_for_eq("sbd", M, self.ct)[0]
+        self.alphabet_host = np.ascontiguousarray(alphabet, dtype=self.ct)
+        # ---- device state
+        self.E = DeviceArray((nmodes, L), self.ct)
+        self.wxy = DeviceArray((nmodes, nmodes, Ntaps), self.ct)
+        self.wxy0 = DeviceArray.from_host(_host._init_taps(Ntaps, nmodes, nmodes, self.ct))
+        self.mu = [DeviceArray.from_host(np.array([m], dtype=self.rt)) for m in self.mu0]
+        self.mu_init = [DeviceArray.from_host(np.array([m], dtype=self.rt)) for m in self.mu0]
+        self.symbols = []
+        for m in self.methods:
+            sy = _host._reshape_symbols(self.alphabet_host if m in _host.DECISION_BASED else None, m, M, self.ct, nmodes)
+            self.symbols.append(DeviceArray.from_host(sy))
+        self.err = [DeviceArray((nmodes, self.TrSyms[s] * self.Niter[s]), self.ct, zero=True) for s in range(self.nstage)]
+        self.eq = DeviceArray((self.modes.size, self.N), self.ct)
+        if Mtestangles:
+            self.alphabet = DeviceArray.from_host(self.alphabet_host)
+            self.idx = DeviceArray((self.modes.size, self.N), np.int32)
+            self.ph = DeviceArray((self.modes.size, self.N), self.rt)
+            self.out = DeviceArray((self.modes.size, self.N), self.ct)
+        _lib.sync()
+
+    # ------------------------------------------------------------------------------------------ data movement
+    def load(self, E):
+        """Host -> HBM copy of the capture (outside any timed region)."""
+        E = np.ascontiguousarray(np.asarray(E), dtype=self.ct)
+        assert E.shape == (self.nmodes, self.L)
+        self.E.set(E)
+
+    # ------------------------------------------------------------------------------------------ stages (enqueue only)
+    def reset(self):
+        """Centre-spike taps and initial step sizes (start of ``dual_mode_equalisation``)."""
+        self.wxy.copy_from(self.wxy0)
+        for m, m0 in zip(self.mu, self.mu_init):
+            m.copy_from(m0)
+
+    def train(self, stage):
+        _k.train_equaliser_dev(self.E, self.TrSyms[stage], self.Niter[stage], self.os, self.mu[stage], self.wxy, self.modes,
+                               self.adaptive[stage], self.symbols[stage], self.methods[stage], self.err[stage])
+
+    def apply(self):
+        _k.apply_filter_to_signal_dev(self.E, self.os, self.wxy, self.modes, self.eq)
+
+    def recover(self):
+        _dsp.bps_recover_dev(self.eq, self.Mtestangles, self.alphabet, self.Nbps, self.idx, self.ph, self.out)
+
+    def run(self):
+        """One pass of the hot path over the resident capture; returns without synchronising."""
+        self.reset()
+        for s in range(self.nstage):
+            self.train(s)
+        self.apply()
+        if self.Mtestangles:
+            self.recover()
+
+    # ------------------------------------------------------------------------------------------ results
+    def fetch(self):
+        """Synchronise and copy the results to the host as a dict of ndarrays."""
+        _lib.sync()
+        res = dict(wxy=self.wxy.to_host(), err=tuple(e.to_host() for e in self.err), eq=self.eq.to_host(),
+                   mu=tuple(m.to_host()[0] for m in self.mu))
+        if self.Mtestangles:
+            res.update(out=self.out.to_host(), ph=self.ph.to_host(), idx=self.idx.to_host())
+        return res
+
+    def bytes_per_symbol(self):
+        """Algorithmic HBM bytes per symbol period of one run() (general formula)."""
+        cs = np.dtype(self.ct).itemsize
+        nsel = self.modes.size
+        train = sum(self.Niter[s] * cs * (self.nmodes * self.os + nsel) for s in range(self.nstage))
+        apply_ = cs * (self.nmodes * self.os + nsel)
+        bps = nsel * (cs + cs + cs // 2) if self.Mtestangles else 0
+        return dict(train=train, apply=apply_, bps=bps, total=train + apply_ + bps)

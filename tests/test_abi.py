@@ -1,0 +1,55 @@
+"""The C-ABI library loads on a CPU-only box, exports every symbol include/qampy_hip.h declares and fails loudly
+(no CPU fallback) when a kernel entry point is called without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from qampy_amd import _lib
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "qampy_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 39
+    for n in names:
+        assert hasattr(lib, n), "%s declared in include/qampy_hip.h but not exported" % n
+    # and the ctypes signature table covers the whole header (minus qh_last_error which returns a string)
+    assert set(names) - {"qh_last_error"} == set(_lib.SIGNATURES)
+
+
+def test_method_ids_match_header():
+    text = open(os.path.join(ROOT, "include", "qampy_hip.h")).read()
+    order = re.search(r"enum \{ (QH_M_CMA.*?) \};", text).group(1).replace(" = 0", "").split(", ")
+    assert [o[5:].lower() for o in order] == list(_lib.METHOD_ID)
+    order = re.search(r"enum \{ (QH_RM_CMA.*?) \};", text).group(1).replace(" = 0", "").split(", ")
+    assert [o[6:].lower() for o in order] == list(_lib.REAL_METHOD_ID)
+
+
+@pytest.mark.skipif(_lib.device_count() > 0, reason="only meaningful on a box without a GPU")
+def test_no_silent_cpu_fallback():
+    from qampy_amd.core.equalisation import hip_equalisation as k
+    E = np.zeros((1, 64), np.complex64)
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        k.apply_filter_to_signal(E, 2, np.zeros((1, 1, 5), np.complex64))
+    with pytest.raises(RuntimeError):
+        _lib.init(0)
+
+
+def test_unknown_method_is_a_value_error_before_touching_the_device():
+    from qampy_amd.core.equalisation import hip_equalisation as k
+    E = np.zeros((1, 64), np.complex64)
+    with pytest.raises(ValueError, match="Unknown method"):
+        k.train_equaliser(E, 4, 1, 2, np.float32(1e-3), np.zeros((1, 1, 5), np.complex64), None, False,
+                          np.ones((1, 1), np.complex64), "nonsense")
+    with pytest.raises(TypeError):
+        k.train_equaliser(E, 4, 1, 2, np.float32(1e-3), np.zeros((1, 1, 5), np.complex128), None, False,
+                          np.ones((1, 1), np.complex64), "cma")
