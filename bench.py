@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""
+bench.py - equalised MSym/s of the adaptive-equaliser + carrier-recovery hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|ns] [--nsym S] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path (dual-mode tap training -> filter application -> blind phase search, unwrap and
+de-rotation of every mode) over one synthetic dual-polarisation 2 SPS capture that is already resident in HBM.  With N
+GPUs every rank processes its own independent channel (seed 1000 + rank, BASELINE.json config 4): weak scaling, no
+collective on the data path; torch.distributed (RCCL) is used only for the barriers, the max-over-ranks of the elapsed
+time and the sum of the symbol-error counters.
+
+The JSON line carries, besides the driver's contract fields:
+  roofline      for the dominant kernel (the stage with the largest share of the step): algorithmic bytes per launch /
+                average launch duration measured with HIP events on the library stream inside the timed region
+  cpu_baseline  the oracle's reference-flag OpenMP build ("port" of the pythran loops) timed on a bounded sample of the
+                same workload on this box's host cores (rank 0, N = 1 only)
+  stages_ms, ser, parity_vs_cpu  supporting numbers
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# SURVEY.md §8d / BASELINE.md configs.  c3 is the 2^22-symbol variant of the north-star configuration (64-QAM, 41 taps,
+# CMA -> MRDE, 64-angle BPS) and the largest single-GPU configuration in BASELINE.json's `configs`.
+WORKLOADS = {
+    "c2": dict(M=16, nsym=2 ** 20, ntaps=21, methods=("mcma",), mu=(1e-3,), niter=(1,), adaptive=(False,), A=32, Nbps=20,
+               snr_db=25, linewidth=50e3, label="16-QAM 2-pol 2 SPS 2^20 sym, 21-tap MCMA + 32-angle BPS"),
+    "c3": dict(M=64, nsym=2 ** 22, ntaps=41, methods=("cma", "mrde"), mu=(1e-3, 5e-4), niter=(1, 1), adaptive=(False, False),
+               A=64, Nbps=20, snr_db=30, linewidth=5e3,
+               label="64-QAM 2-pol 2 SPS 2^22 sym, 41-tap dual-mode CMA->MRDE + 64-angle BPS"),
+    "ns": dict(M=64, nsym=10 ** 7, ntaps=41, methods=("cma", "mrde"), mu=(1e-3, 5e-4), niter=(1, 1), adaptive=(False, False),
+               A=64, Nbps=20, snr_db=30, linewidth=5e3,
+               label="64-QAM 2-pol 2 SPS 10^7 sym, 41-tap dual-mode CMA->MRDE + 64-angle BPS (north star)"),
+}
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_input(cfg, nsym, seed):
+    from qampy_amd import synth
+    return synth.make_capture(cfg["M"], nsym, nmodes=2, os=2, snr_db=cfg["snr_db"], theta=np.pi / 5.6, dgd=30e-12,
+                              linewidth=cfg["linewidth"], fb=20e9, beta=0.1, seed=seed, dtype=np.complex64)
+
+
+def make_receiver(cfg, sig):
+    from qampy_amd.pipeline import ResidentReceiver
+    return ResidentReceiver(2, sig.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"],
+                            adaptive_stepsize=cfg["adaptive"], TrSyms=(None,) * len(cfg["methods"]), Mtestangles=cfg["A"],
+                            Nbps=cfg["Nbps"], dtype=np.complex64, alphabet=sig.coded_symbols)
+
+
+def symbol_errors(out, sig, trim=2000):
+    """(errors, compared) per mode of a recovered signal; alignment on a prefix, decisions counted over the whole run."""
+    from qampy_amd import synth
+    from qampy_amd.core.equalisation import hip_equalisation as hk
+    res = []
+    npre = min(out.shape[1], 1 << 16)
+    tx_idx = [hk.make_decision(np.ascontiguousarray(t), sig.coded_symbols)[2] for t in sig.symbols]
+    for r in out:
+        _, _, m, rot, lag = synth.count_symbol_errors(r[:npre], sig.symbols[:, :npre + 512], sig.coded_symbols, trim=min(trim, npre // 8))
+        lag += min(trim, npre // 8)                                   # lag was measured on the trimmed prefix
+        rx_idx = hk.make_decision(np.ascontiguousarray(r * np.complex64(np.exp(1j * rot * np.pi / 2))), sig.coded_symbols)[2]
+        i0, i1 = trim, r.size - trim
+        a = rx_idx[i0:i1]
+        b = tx_idx[m][i0 - lag:i1 - lag]
+        n = min(a.size, b.size)
+        res.append((int(np.count_nonzero(a[:n] != b[:n])), int(n)))
+    return res
+
+
+def cpu_baseline(cfg, sig, sample_sym):
+    """Oracle (reference-flag OpenMP build) on a bounded prefix of the same capture; returns timing + results."""
+    from oracle import oracle
+    from qampy_amd.core.equalisation import equalisation as host
+    try:
+        oracle.build(fast_native=True)       # -march=native for THIS host
+    except Exception as e:                   # fall back to the prebuilt library
+        print("cpu_baseline: native rebuild failed (%s), using the prebuilt oracle" % e, file=sys.stderr)
+    E = np.ascontiguousarray(np.asarray(sig)[:, :2 * sample_sym])
+    ntaps = cfg["ntaps"]
+    w = host._init_taps(ntaps, 2, 2, np.complex64)
+    tr = host._cal_training_symbol_len(2, ntaps, E.shape[1])
+    syms = [host._reshape_symbols(sig.coded_symbols if m in host.DECISION_BASED else None, m, cfg["M"], np.complex64, 2)
+            for m in cfg["methods"]]
+    angles = np.linspace(-np.pi / 4, np.pi / 4, cfg["A"], endpoint=False, dtype=np.float32).reshape(1, -1)
+    t0 = time.perf_counter()
+    for s, m in enumerate(cfg["methods"]):
+        _, w, _ = oracle.train_equaliser(E, tr, cfg["niter"][s], 2, np.float32(cfg["mu"][s]), w, None, cfg["adaptive"][s], syms[s], m, fast=True)
+    t1 = time.perf_counter()
+    eq = oracle.apply_filter_to_signal(E, 2, w, fast=True)
+    t2 = time.perf_counter()
+    N = cfg["Nbps"]
+    ph = np.array([oracle.select_angles(angles, oracle.bps(eq[m], angles, sig.coded_symbols, N, fast=True)) for m in range(2)])
+    ph[:, N:-N] = np.unwrap(ph[:, N:-N] * 4) / 4
+    out = eq * np.exp(1j * ph)
+    t3 = time.perf_counter()
+    return dict(seconds=t3 - t0, train_s=t1 - t0, apply_s=t2 - t1, bps_s=t3 - t2, wxy=w, out=out.astype(np.complex64))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--nsym", type=int, default=None, help="override the number of symbol periods per capture")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 20, help="symbol periods of the capture the CPU baseline processes")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    cfg = dict(WORKLOADS[args.workload])
+    nsym = args.nsym or cfg["nsym"]
+
+    import torch                                     # plumbing only: barriers / reductions / device sync
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from qampy_amd import _lib
+    _lib.init(local_rank)
+
+    def barrier_sync():
+        _lib.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- independent channel per rank (seed 1000 + channel), synthesised on the host, then made resident
+    sig = make_input(cfg, nsym, 1000 + rank)
+    rx = make_receiver(cfg, sig)
+    rx.load(sig)
+    stage_names = ["train%d:%s" % (s + 1, m) for s, m in enumerate(cfg["methods"])] + ["apply", "bps_recover"]
+    stage_fns = [lambda s=s: rx.train(s) for s in range(rx.nstage)] + [rx.apply, rx.recover]
+
+    for _ in range(args.warmup):
+        rx.run()
+    # ---- timed region: exactly K steps, HIP events between the stages (same stream as the kernels)
+    ev = [[_lib.Event() for _ in range(len(stage_fns) + 1)] for _ in range(args.steps)]
+    barrier_sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        rx.reset()
+        ev[k][0].record()
+        for j, fn in enumerate(stage_fns):
+            fn()
+            ev[k][j + 1].record()
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stage_ms = [float(np.mean([ev[k][j + 1].elapsed_ms(ev[k][j]) for k in range(args.steps)])) for j in range(len(stage_fns))]
+
+    # ---- results of the last step: SER against the transmitted symbols
+    res = rx.fetch()
+    errs = symbol_errors(res["out"], sig)
+    counts = np.array([[e, n] for e, n in errs], dtype=np.float64)
+    if dist is not None:
+        c = torch.tensor(counts, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        counts_all = c.cpu().numpy()
+    else:
+        counts_all = counts
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = nsym * world * args.steps / elapsed / 1e6
+    # ---- roofline of the dominant kernel
+    bps_b = rx.bytes_per_symbol()
+    stage_bytes = []
+    for s in range(rx.nstage):
+        stage_bytes.append(rx.Niter[s] * rx.TrSyms[s] * 8 * (2 * 2 + 2))
+    stage_bytes += [rx.N * bps_b["apply"], rx.N * bps_b["bps"]]
+    dom = int(np.argmax(stage_ms))
+    achieved = stage_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel=stage_names[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
+                    note="exact sequential LMS chain: dependent-issue latency bound, 1 wave per output mode (DESIGN.md)")
+
+    out = dict(metric="equalised MSym/s (2-pol, 2 SPS)", value=round(value, 4), unit="MSym/s", n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
+               vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload=cfg["label"], key=args.workload, nsym_per_channel=nsym, channels=world, ntaps=cfg["ntaps"],
+                           methods=list(cfg["methods"]), niter=list(cfg["niter"]), test_angles=cfg["A"], bps_N=cfg["Nbps"],
+                           complex_dtype="complex64", parallelism="1 independent channel per GPU"),
+               roofline=roofline,
+               stages_ms={n: round(t, 3) for n, t in zip(stage_names, stage_ms)},
+               stages_GBps={n: round(b / (t * 1e-3) / 1e9, 2) for n, b, t in zip(stage_names, stage_bytes, stage_ms)},
+               ser=dict(per_mode_rank0=[e / max(n, 1) for e, n in errs], errors_all=int(counts_all[:, 0].sum()),
+                        symbols_all=int(counts_all[:, 1].sum())),
+               device=_lib.device_name())
+
+    if world == 1 and not args.no_cpu_baseline:
+        sample = min(nsym, args.cpu_sample)
+        cb = cpu_baseline(cfg, sig, sample)
+        # GPU on the identical sample -> SER / tap parity against the CPU path
+        rx2 = make_receiver(cfg, sig[:, :2 * sample])
+        rx2.load(np.asarray(sig)[:, :2 * sample])
+        rx2.run()
+        r2 = rx2.fetch()
+        sig_s = sig.recreate_from_np_array(np.asarray(sig)[:, :2 * sample])
+        sig_s._symbols = sig.symbols[:, :sample]
+        e_gpu = symbol_errors(r2["out"], sig_s)
+        e_cpu = symbol_errors(cb["out"], sig_s)
+        out["cpu_baseline"] = dict(value=round(sample / cb["seconds"] / 1e6, 4), unit="MSym/s", cores=os.cpu_count(), kind="port",
+                                   sample="first %d symbol periods of the same capture (all stages); oracle built with the "
+                                          "reference's flags + OpenMP placement" % sample,
+                                   stages_s=dict(train=round(cb["train_s"], 3), apply=round(cb["apply_s"], 3), bps=round(cb["bps_s"], 3)))
+        out["parity_vs_cpu"] = dict(sample=sample, ser_gpu=[e / n for e, n in e_gpu], ser_cpu=[e / n for e, n in e_cpu],
+                                    errors_gpu=[e for e, _ in e_gpu], errors_cpu=[e for e, _ in e_cpu],
+                                    max_abs_tap_diff=float(np.max(np.abs(r2["wxy"] - cb["wxy"]))))
+        out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

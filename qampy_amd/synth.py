@@ -7,7 +7,8 @@ bench and the tests synthesise their inputs here.  Conventions follow the refere
 carry over:
   * noise:  sigma = sqrt(P)*10^(-snr/20)*sqrt(os), split equally over I and Q   (core/impairments.py:205, 230-233)
   * PMD:    R(-theta) diag(e^{-j w tau/2}, e^{+j w tau/2}) R(theta) in the frequency domain (core/impairments.py:94-104)
-  * phase noise: Wiener process, variance 2*pi*linewidth/fs per sample          (core/impairments.py:155-158)
+  * phase noise: Wiener process, variance 2*pi*linewidth/fs per sample, applied per transmitted mode before the
+    polarisation mixing                                                        (core/impairments.py:155-158)
 This is host-side numpy; it is never inside a timed region.
 """
 import numpy as np
@@ -53,6 +54,13 @@ def make_capture(M, nsym, nmodes=2, os=2, snr_db=None, theta=None, dgd=None, lin
     H = _rrc_frequency_response(L, os, beta)
     x = np.fft.ifft(np.fft.fft(up, axis=1) * H, axis=1)
     x /= np.sqrt(np.mean(np.abs(x) ** 2, axis=1, keepdims=True))
+    if linewidth:
+        # transmitter-side Wiener phase noise, independent per mode like the reference's apply_phase_noise; it is applied
+        # BEFORE the polarisation mixing so that a static 2x2 equaliser still separates the modes and the per-mode BPS
+        # sees one phase process per output
+        var = 2 * np.pi * linewidth / fs
+        ph = np.cumsum(rng.normal(scale=np.sqrt(var), size=(nmodes, L)), axis=1)
+        x = x * np.exp(1j * ph)
     if theta is not None and nmodes == 2:
         omega = 2 * np.pi * np.fft.fftfreq(L, d=1 / fs)
         c, s = np.cos(theta), np.sin(theta)
@@ -65,10 +73,6 @@ def make_capture(M, nsym, nmodes=2, os=2, snr_db=None, theta=None, dgd=None, lin
         X0 = c * a + s * b
         X1 = -s * a + c * b
         x = np.fft.ifft(np.stack([X0, X1]), axis=1)
-    if linewidth:
-        var = 2 * np.pi * linewidth / fs
-        ph = np.cumsum(rng.normal(scale=np.sqrt(var), size=(nmodes, L)), axis=1)
-        x = x * np.exp(1j * ph)
     if snr_db is not None:
         p = np.mean(np.abs(x) ** 2)
         sigma = np.sqrt(p) * 10 ** (-snr_db / 20) * np.sqrt(os)
