@@ -51,11 +51,32 @@ def make_input(cfg, nsym, seed):
                               linewidth=cfg["linewidth"], fb=20e9, beta=0.1, seed=seed, dtype=np.complex64)
 
 
-def make_receiver(cfg, sig):
+def make_receiver(cfg, sig, segments=0, prefix=0):
     from qampy_amd.pipeline import ResidentReceiver
     return ResidentReceiver(2, sig.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"],
                             adaptive_stepsize=cfg["adaptive"], TrSyms=(None,) * len(cfg["methods"]), Mtestangles=cfg["A"],
-                            Nbps=cfg["Nbps"], dtype=np.complex64, alphabet=sig.coded_symbols)
+                            Nbps=cfg["Nbps"], dtype=np.complex64, alphabet=sig.coded_symbols, segments=segments, prefix=prefix)
+
+
+def timed_steps(rx, steps, warmup, barrier_sync):
+    """W warm-up passes, then exactly K passes bracketed by barrier + device sync; HIP events between the stages."""
+    from qampy_amd import _lib
+    stage_fns = [lambda s=s: rx.train(s) for s in range(rx.nstage)] + [rx.apply, rx.recover]
+    for _ in range(warmup):
+        rx.run()
+    ev = [[_lib.Event() for _ in range(len(stage_fns) + 1)] for _ in range(steps)]
+    barrier_sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        rx.reset()
+        ev[k][0].record()
+        for j, fn in enumerate(stage_fns):
+            fn()
+            ev[k][j + 1].record()
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    stage_ms = [float(np.mean([ev[k][j + 1].elapsed_ms(ev[k][j]) for k in range(steps)])) for j in range(len(stage_fns))]
+    return elapsed, stage_ms
 
 
 def symbol_errors(out, sig, trim=2000):
@@ -115,11 +136,16 @@ def main():
     ap.add_argument("--nsym", type=int, default=None, help="override the number of symbol periods per capture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=1 << 20, help="symbol periods of the capture the CPU baseline processes")
+    ap.add_argument("--train-mode", default="exact", choices=["exact", "segmented"],
+                    help="exact = the reference's sequential recurrence (default, parity tier A); segmented = opt-in "
+                         "segment-parallel continuation (tier B, SER-equivalent, not tap-identical)")
+    ap.add_argument("--segments", type=int, default=1024)
+    ap.add_argument("--prefix", type=int, default=1 << 16, help="sequential convergence prefix (steps) of the segmented mode")
+    ap.add_argument("--no-tier-b", action="store_true", help="skip the informational tier-B leg of the default run")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from qampy_amd import sharding
+    rank, local_rank, world = sharding.rank_info()
     cfg = dict(WORKLOADS[args.workload])
     nsym = args.nsym or cfg["nsym"]
 
@@ -139,42 +165,20 @@ def main():
             dist.barrier()
 
     # ---- independent channel per rank (seed 1000 + channel), synthesised on the host, then made resident
-    sig = make_input(cfg, nsym, 1000 + rank)
-    rx = make_receiver(cfg, sig)
+    sig = make_input(cfg, nsym, sharding.channel_seed(rank))
+    seg = dict(segments=args.segments, prefix=args.prefix) if args.train_mode == "segmented" else {}
+    rx = make_receiver(cfg, sig, **seg)
     rx.load(sig)
     stage_names = ["train%d:%s" % (s + 1, m) for s, m in enumerate(cfg["methods"])] + ["apply", "bps_recover"]
-    stage_fns = [lambda s=s: rx.train(s) for s in range(rx.nstage)] + [rx.apply, rx.recover]
 
-    for _ in range(args.warmup):
-        rx.run()
     # ---- timed region: exactly K steps, HIP events between the stages (same stream as the kernels)
-    ev = [[_lib.Event() for _ in range(len(stage_fns) + 1)] for _ in range(args.steps)]
-    barrier_sync()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        rx.reset()
-        ev[k][0].record()
-        for j, fn in enumerate(stage_fns):
-            fn()
-            ev[k][j + 1].record()
-    barrier_sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    stage_ms = [float(np.mean([ev[k][j + 1].elapsed_ms(ev[k][j]) for k in range(args.steps)])) for j in range(len(stage_fns))]
+    elapsed, stage_ms = timed_steps(rx, args.steps, args.warmup, barrier_sync)
+    elapsed = sharding.reduce_max_time(elapsed, dist, device="cuda")
 
     # ---- results of the last step: SER against the transmitted symbols
     res = rx.fetch()
     errs = symbol_errors(res["out"], sig)
-    counts = np.array([[e, n] for e, n in errs], dtype=np.float64)
-    if dist is not None:
-        c = torch.tensor(counts, device="cuda")
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        counts_all = c.cpu().numpy()
-    else:
-        counts_all = counts
+    counts_all = sharding.reduce_sum_counts([[e, n] for e, n in errs], dist, device="cuda")
 
     if rank != 0:
         if dist is not None:
@@ -182,7 +186,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    value = nsym * world * args.steps / elapsed / 1e6
+    value = sharding.aggregate_throughput(nsym, world, args.steps, elapsed)
     # ---- roofline of the dominant kernel
     bps_b = rx.bytes_per_symbol()
     stage_bytes = []
@@ -193,14 +197,16 @@ def main():
     achieved = stage_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9
     roofline = dict(bound="hbm", kernel=stage_names[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
-                    note="exact sequential LMS chain: dependent-issue latency bound, 1 wave per output mode (DESIGN.md)")
+                    note=("exact sequential LMS chain: single-wave dependent-issue bound, 1 wave per output mode (DESIGN.md)"
+                          if args.train_mode == "exact" and dom < rx.nstage else "see DESIGN.md"))
 
     out = dict(metric="equalised MSym/s (2-pol, 2 SPS)", value=round(value, 4), unit="MSym/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
                vs_baseline=None, dtype="f32", data="synthetic",
                config=dict(workload=cfg["label"], key=args.workload, nsym_per_channel=nsym, channels=world, ntaps=cfg["ntaps"],
                            methods=list(cfg["methods"]), niter=list(cfg["niter"]), test_angles=cfg["A"], bps_N=cfg["Nbps"],
-                           complex_dtype="complex64", parallelism="1 independent channel per GPU"),
+                           complex_dtype="complex64", parallelism="1 independent channel per GPU", train_mode=args.train_mode,
+                           **({"segments": args.segments, "prefix": args.prefix} if args.train_mode == "segmented" else {})),
                roofline=roofline,
                stages_ms={n: round(t, 3) for n, t in zip(stage_names, stage_ms)},
                stages_GBps={n: round(b / (t * 1e-3) / 1e9, 2) for n, b, t in zip(stage_names, stage_bytes, stage_ms)},
@@ -228,6 +234,22 @@ def main():
                                     errors_gpu=[e for e, _ in e_gpu], errors_cpu=[e for e, _ in e_cpu],
                                     max_abs_tap_diff=float(np.max(np.abs(r2["wxy"] - cb["wxy"]))))
         out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+
+    if world == 1 and args.train_mode == "exact" and not args.no_tier_b:
+        # informational: the opt-in segment-parallel training on the same capture (NOT the headline `value`)
+        rxb = make_receiver(cfg, sig, segments=args.segments, prefix=args.prefix)
+        rxb.load(sig)
+        el_b, ms_b = timed_steps(rxb, args.steps, 1, barrier_sync)
+        rb = rxb.fetch()
+        e_b = symbol_errors(rb["out"], sig)
+        out["tier_b_segmented"] = dict(value=round(nsym * args.steps / el_b / 1e6, 3), unit="MSym/s", segments=args.segments,
+                                       prefix=args.prefix, stages_ms={n: round(t, 3) for n, t in zip(stage_names, ms_b)},
+                                       ser=[e / max(n, 1) for e, n in e_b], errors=[e for e, _ in e_b],
+                                       max_abs_tap_diff_vs_exact=float(np.max(np.abs(rb["wxy"] - res["wxy"]))),
+                                       note="opt-in; same per-symbol work, different dependency structure: SER-equivalent, "
+                                            "not tap-identical (DESIGN.md tiers)")
+        if "cpu_baseline" in out:
+            out["tier_b_segmented"]["speedup_vs_cpu"] = round(out["tier_b_segmented"]["value"] / out["cpu_baseline"]["value"], 2)
     print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -129,10 +129,15 @@ def det_symbol(X, symbs):
 
 
 # ------------------------------------------------------------------------------------------------ device-resident forms
-def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method, err, zero_err=False):
+def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method, err, zero_err=False, segments=0,
+                        prefix=0):
     """
     Same as :func:`train_equaliser` with every array (and the scalar ``mu``, a 1-element DeviceArray) already in HBM.
     Only enqueues work on the library stream.
+
+    ``segments > 0`` selects the opt-in segment-parallel continuation (tier B): ``prefix`` sequential steps,
+    then ``segments`` concurrently trained contiguous segments per sweep, all starting from the same taps.  This is NOT
+    the reference's recurrence (results agree statistically, not to rounding).
     """
     if method not in _lib.METHOD_ID:
         raise ValueError("Unknown method %s" % method)
@@ -140,9 +145,13 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
     nmodes, L = E.shape
     ntaps = wx.shape[-1]
     modes = _as_modes(modes, nmodes)
-    _lib.call("qh_train_equaliser_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, nmodes, L, int(TrSyms), int(Niter),
-              int(os), mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size, int(bool(adaptive)), symbols.ptr,
-              symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)))
+    args = (E.ptr, nmodes, L, int(TrSyms), int(Niter), int(os), mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size,
+            int(bool(adaptive)), symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)))
+    name = "qh_train_equaliser_c" + ("64" if suf == "32" else "128")
+    if segments and segments > 0:
+        _lib.call(name + "_seg_dev", *args, int(segments), int(prefix))
+    else:
+        _lib.call(name + "_dev", *args)
 
 
 def apply_filter_to_signal_dev(E, os, wx, modes, out):

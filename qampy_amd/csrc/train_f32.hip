@@ -1,0 +1,29 @@
+// C ABI of the trainers, single precision (complex64 / float32).  Kernels: train_impl.h
+#include "train_impl.h"
+
+extern "C" {
+int qh_train_equaliser_c64(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu, void *wx,
+                           int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
+                           int method, void *err)
+{
+    return qh::train_host<float>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err);
+}
+int qh_train_equaliser_c64_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
+                               void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
+                               int64_t nsy, int method, void *err, int zero_err)
+{
+    return qh::train_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err);
+}
+int qh_train_equaliser_real_f32(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu, void *wx,
+                                int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
+                                int method, void *err)
+{
+    return qh::train_real_host<float>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err);
+}
+int qh_train_equaliser_c64_seg_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
+                                   void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
+                                   int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix)
+{
+    return qh::train_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, nseg, prefix);
+}
+}

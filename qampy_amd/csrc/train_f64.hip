@@ -1,0 +1,29 @@
+// C ABI of the trainers, double precision (complex128 / float64).  Kernels: train_impl.h
+#include "train_impl.h"
+
+extern "C" {
+int qh_train_equaliser_c128(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu, void *wx,
+                            int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
+                            int method, void *err)
+{
+    return qh::train_host<double>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err);
+}
+int qh_train_equaliser_c128_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev,
+                                void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
+                                int64_t nsy, int method, void *err, int zero_err)
+{
+    return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err);
+}
+int qh_train_equaliser_real_f64(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu, void *wx,
+                                int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
+                                int method, void *err)
+{
+    return qh::train_real_host<double>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err);
+}
+int qh_train_equaliser_c128_seg_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev,
+                                   void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
+                                   int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix)
+{
+    return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, nseg, prefix);
+}
+}

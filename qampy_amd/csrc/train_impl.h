@@ -9,19 +9,19 @@
 //     live in VGPRs for the whole sweep;
 //   * per step every lane multiplies its taps with its samples, a 6-level DPP butterfly (row_* / row_bcast) sums
 //     re and im across the wave, the error function is evaluated wave-uniformly, and every lane updates its taps;
-//   * the samples of step i+PD are loaded while step i computes (rotating register buffer, no LDS round trip);
-//     the window slides by `os` samples per step so these loads hit the CU's L1/L2;
+//   * the capture is staged chunk-wise (<= 512 steps) into a double-buffered LDS window with coalesced loads - every
+//     HBM byte is read once per sweep - and each step reads its samples from LDS one unrolled group ahead; the error
+//     trace is collected 64 steps at a time in registers and written with one coalesced store (no per-step branch);
 //   * decision-directed methods search the alphabet lane-parallel (lane j <-> symbol j) and pick the FIRST minimum
 //     with ballot + ff1, which is exactly the strict-`<` scan of det_symbol; RDE/MRDE partition look-ups are a ballot
 //     over lane-held partitions;
 //   * with adaptive step size the modes run back to back in one wave because the reference carries `mu` from one
 //     mode into the next when run sequentially; otherwise each mode gets its own workgroup (its own CU).
+#pragma once
 #include "common.h"
 
 namespace qh {
 
-// sample prefetch distance in steps (shrinks with the taps-per-lane count to keep the queue in registers)
-template <int TPL> struct Prefetch { static constexpr int PD = TPL <= 2 ? 4 : (TPL <= 4 ? 2 : 1); };
 constexpr int MAX_TABLE = 64;  // alphabet / partition entries held one per lane; larger tables take the serial path
 
 template <typename R> struct TrainArgs {
@@ -33,6 +33,12 @@ template <typename R> struct TrainArgs {
     int64_t L, TrSyms, nsy;
     int nmodes, ntaps, Niter, os, nsel, adaptive, method;
     int64_t modes[16];
+    // segment-parallel continuation (tier B, NOT the reference's semantics):
+    // blockIdx.y = segment; segment s trains steps [seg_begin + s*seg_len, min(seg_begin + (s+1)*seg_len, TrSyms))
+    // of sweep `seg_iter`, every segment starting from the same taps `wx`; the last segment's taps go to `wx_out`.
+    int64_t seg_begin, seg_len;
+    int nseg, seg_iter;
+    Cx<R> *wx_out;
 };
 
 // ------------------------------------------------------------------------------------------------ error functions
@@ -135,23 +141,75 @@ __device__ __forceinline__ Cx<R> error_fn(Cx<R> X, const Tables<R> &T, R R_re, R
 }
 
 // ------------------------------------------------------------------------------------------------ one chain sweep
+// Staging: the capture is walked in chunks of CH steps.  The (CH-1)*os + ntaps samples of every input mode that a chunk
+// needs are copied ONCE from HBM into LDS (coalesced, double buffered), then every step reads its taps' samples from
+// LDS with immediate offsets; reads for group g+1 are issued while group g computes.
+constexpr int TR_U = 8;            // steps per unrolled group
+constexpr int TR_SLACK = 2 * TR_U; // extra steps' worth of LDS behind a chunk so that the look-ahead reads stay in bounds
+
+template <typename R> struct ChainLds {
+    Cx<R> *buf;        // [2][nmodes][pitch] chunk double buffer followed by a zero pad
+    int pitch;         // samples per input-mode row of one chunk buffer
+    int zero_off;      // element offset of the zero pad (read by lanes that own no tap)
+    int CH;            // steps per chunk
+};
+
+// wave-wide complex sum: on exit re/im hold the totals in every lane
+__device__ __forceinline__ void wave_csum(float &re, float &im)
+{
+    int sr, si;
+    // v_add_f32_dpp needs 2 wait states between a VALU write and the DPP read of the same VGPR; the partner
+    // component's instruction provides one of them, an s_nop the other.
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_readlane_b32 %2, %0, 63\n\t"
+        "v_readlane_b32 %3, %1, 63\n\t"
+        : "+v"(re), "+v"(im), "=s"(sr), "=s"(si));
+    re = __builtin_bit_cast(float, sr);
+    im = __builtin_bit_cast(float, si);
+}
+__device__ __forceinline__ void wave_csum(double &re, double &im) { wave_sum2(re, im); }
+
+// Trains steps [i_begin, i_end) of sweeps [it_begin, it_end) of one output mode.  The exact (reference) semantics is
+// i_begin = 0, i_end = TrSyms, all sweeps, taps read from and written back to a.wx.
 template <typename R, int TPL, int METHOD>
-__device__ __forceinline__ R run_chain(const TrainArgs<R> &a, int mode, R mu, int lane)
+__device__ __forceinline__ R run_chain(const TrainArgs<R> &a, const ChainLds<R> &lds, int mode, R mu, int lane,
+                                       int64_t i_begin, int64_t i_end, int it_begin, int it_end, Cx<R> *w_out)
 {
     const int ntot = a.nmodes * a.ntaps;
     const int64_t L = a.L;
+    const int os = a.os;
     Cx<R> w[TPL];
-    const Cx<R> *xbase[TPL];
-    bool valid[TPL];
-    Cx<R> *wrow = a.wx + (size_t)mode * ntot;
+    int xoff[TPL];          // element offset of this lane's sample inside a chunk buffer at step 0 of the chunk
+    int xstep[TPL];         // per-step advance in elements (0 for lanes that own no tap -> they keep reading the zero pad)
+    const Cx<R> *wrow = a.wx + (size_t)mode * ntot;
 #pragma unroll
     for (int s = 0; s < TPL; s++) {
-        int f = lane + 64 * s;
-        valid[s] = f < ntot;
-        int fc = valid[s] ? f : 0;
-        int k = fc / a.ntaps, t = fc - k * a.ntaps;
-        xbase[s] = a.E + (size_t)k * L + t;
-        w[s] = valid[s] ? ldg(wrow + fc) : Cx<R>{0, 0};
+        const int f = lane + 64 * s;
+        const bool valid = f < ntot;
+        const int fc = valid ? f : 0;
+        const int k = fc / a.ntaps, t = fc - k * a.ntaps;
+        xoff[s] = valid ? k * lds.pitch + t : -1;        // -1: this lane owns no tap in slot s and reads the zero pad
+        xstep[s] = valid ? os : 0;
+        w[s] = valid ? ldg(wrow + fc) : Cx<R>{0, 0};
     }
     // per-mode constants and tables
     const Cx<R> *sy = a.symbols + (size_t)mode * a.nsy;
@@ -177,92 +235,167 @@ __device__ __forceinline__ R run_chain(const TrainArgs<R> &a, int mode, R mu, in
 
     Cx<R> *errow = a.err + (size_t)mode * (a.TrSyms * a.Niter);
     const int64_t TrSyms = a.TrSyms;
-    const int os = a.os;
+    const int CH = lds.CH;
+    const int bufsz = a.nmodes * lds.pitch;              // elements per chunk buffer
+    const int64_t nsteps = i_end - i_begin;
+    const int nchunk = (int)((nsteps + CH - 1) / CH);
+    const int span_full = (CH - 1) * os + a.ntaps;
 
-    constexpr int PD = Prefetch<TPL>::PD;
-    for (int it = 0; it < a.Niter; it++) {
-        Cx<R> xq[PD][TPL];
-        Cx<R> dq[PD];
-#pragma unroll
-        for (int u = 0; u < PD; u++) dq[u] = Cx<R>{0, 0};
-        // prime the prefetch queue
-#pragma unroll
-        for (int u = 0; u < PD; u++) {
-            int64_t ii = u < TrSyms ? u : TrSyms - 1;
-#pragma unroll
-            for (int s = 0; s < TPL; s++) xq[u][s] = valid[s] ? ldg(xbase[s] + ii * os) : Cx<R>{0, 0};
-            if constexpr (METHOD == QH_M_SBD_DATA) dq[u] = ldg(sy + ii);
+    // copy the samples of chunk c (steps i_begin + c*CH ...) into buffer (c & 1)
+    auto stage = [&](int c) {
+        const int64_t s0 = (i_begin + (int64_t)c * CH) * os;
+        int64_t span = L - s0;
+        if (span > span_full + TR_SLACK * os) span = span_full + TR_SLACK * os;
+        Cx<R> *dst = lds.buf + (c & 1) * bufsz;
+        for (int k = 0; k < a.nmodes; k++) {
+            const Cx<R> *src = a.E + (size_t)k * L + s0;
+            for (int j = lane; j < (int)span; j += 64) dst[k * lds.pitch + j] = ldg(src + j);
         }
-        Cx<R> e_prev{0, 0};
+    };
+
+    R ebr = 0, ebi = 0;          // error-trace staging: lane (i & 63) keeps the error of step i until a 64-step flush
+    Cx<R> e_prev{0, 0};
+
+    // one LMS step on samples x[]; i = step index inside the sweep
+    auto step = [&](const Cx<R> (&x)[TPL], int64_t i, Cx<R> dsym) {
+        R pr = 0, pi = 0;
+#pragma unroll
+        for (int s = 0; s < TPL; s++) {                                  // Xest = sum x*w, no conjugate (:24-31)
+            pr = fma_(x[s].re, w[s].re, pr); pr = fma_(-x[s].im, w[s].im, pr);
+            pi = fma_(x[s].re, w[s].im, pi); pi = fma_(x[s].im, w[s].re, pi);
+        }
+        wave_csum(pr, pi);
+        const Cx<R> X{pr, pi};
+        const Cx<R> e = error_fn<R, METHOD>(X, T, R_re, R_im, dsym, lane);
+        const bool mine = lane == (int)((i - i_begin) & 63);
+        ebr = mine ? e.re : ebr;
+        ebi = mine ? e.im : ebi;
+        const R cr = mu * e.re, ci = mu * e.im;                           // w += (mu*e)*conj(x) (:170)
+#pragma unroll
+        for (int s = 0; s < TPL; s++) {
+            w[s].re = fma_(cr, x[s].re, fma_(ci, x[s].im, w[s].re));
+            w[s].im = fma_(ci, x[s].re, fma_(-cr, x[s].im, w[s].im));
+        }
+        if (a.adaptive) {                                                 // adapt_step(mu, err[i], err[i-1]) :12-16, :171-172
+            const bool keep = (i == i_begin) || ((e_prev.re * e.re > 0) && (e_prev.im * e.im > 0));
+            const R den = fma_(mu, fma_(e_prev.re, e_prev.re, e_prev.im * e_prev.im), (R)1);
+            mu = keep ? mu : mu / den;
+            e_prev = e;
+        }
+    };
+
+    for (int it = it_begin; it < it_end; it++) {
         Cx<R> *eout = errow + (size_t)it * TrSyms;
-        for (int64_t i0 = 0; i0 < TrSyms; i0 += PD) {
+        stage(0);
+        for (int c = 0; c < nchunk; c++) {
+            if (c + 1 < nchunk) stage(c + 1);                             // next chunk lands while this one computes
+            const Cx<R> *cb = lds.buf + (c & 1) * bufsz;
+            const int64_t ibase = i_begin + (int64_t)c * CH;
+            const int nst = (int)((i_end - ibase) < CH ? (i_end - ibase) : CH);
+            const Cx<R> *xp[TPL];
 #pragma unroll
-            for (int u = 0; u < PD; u++) {
-                const int64_t i = i0 + u;
-                if (i < TrSyms) {
-                    Cx<R> x[TPL];
+            for (int s = 0; s < TPL; s++) xp[s] = xoff[s] >= 0 ? cb + xoff[s] : lds.buf + lds.zero_off;
+            Cx<R> xa[TR_U][TPL], xb[TR_U][TPL];
+            Cx<R> dq[TR_U];
 #pragma unroll
-                    for (int s = 0; s < TPL; s++) x[s] = xq[u][s];
-                    Cx<R> dsym = dq[u];
-                    // refill this queue slot with the samples of step i + PD
-                    {
-                        int64_t ii = i + PD < TrSyms ? i + PD : TrSyms - 1;
+            for (int u = 0; u < TR_U; u++) dq[u] = Cx<R>{0, 0};
+            auto load_group = [&](Cx<R> (&x)[TR_U][TPL], int g) {         // samples of steps g .. g+U-1 of this chunk
 #pragma unroll
-                        for (int s = 0; s < TPL; s++) xq[u][s] = valid[s] ? ldg(xbase[s] + ii * os) : Cx<R>{0, 0};
-                        if constexpr (METHOD == QH_M_SBD_DATA) dq[u] = ldg(sy + ii);
-                    }
-                    // Xest = sum_f x[f] * w[f]   (no conjugate, :24-31)
-                    R pr = 0, pi = 0;
+                for (int u = 0; u < TR_U; u++)
 #pragma unroll
-                    for (int s = 0; s < TPL; s++) {
-                        pr = fma_(x[s].re, w[s].re, pr); pr = fma_(-x[s].im, w[s].im, pr);
-                        pi = fma_(x[s].re, w[s].im, pi); pi = fma_(x[s].im, w[s].re, pi);
-                    }
-                    wave_sum2(pr, pi);
-                    Cx<R> X{pr, pi};
-                    Cx<R> e = error_fn<R, METHOD>(X, T, R_re, R_im, dsym, lane);
-                    if (lane == 0) stg(eout + i, e);
-                    // w += (mu*e) * conj(x)   (:170)
-                    R cr = mu * e.re, ci = mu * e.im;
+                    for (int s = 0; s < TPL; s++) x[u][s] = xp[s][(g + u) * xstep[s]];
+            };
+            int g = 0;
+            load_group(xa, 0);
+            for (; g + 2 * TR_U <= nst; g += 2 * TR_U) {
+                load_group(xb, g + TR_U);
 #pragma unroll
-                    for (int s = 0; s < TPL; s++) {
-                        w[s].re = fma_(cr, x[s].re, fma_(ci, x[s].im, w[s].re));
-                        w[s].im = fma_(ci, x[s].re, fma_(-cr, x[s].im, w[s].im));
-                    }
-                    if (a.adaptive && i > 0) {                 // adapt_step(mu, err[i], err[i-1]) :12-16, :171-172
-                        bool keep = (e_prev.re * e.re > 0) && (e_prev.im * e.im > 0);
-                        R den = fma_(mu, fma_(e_prev.re, e_prev.re, e_prev.im * e_prev.im), (R)1);
-                        mu = keep ? mu : mu / den;
-                    }
-                    e_prev = e;
+                for (int u = 0; u < TR_U; u++) {
+                    if constexpr (METHOD == QH_M_SBD_DATA) dq[u] = ldg(sy + ibase + g + u);
+                    step(xa[u], ibase + g + u, dq[u]);
+                }
+                load_group(xa, g + 2 * TR_U);                             // may run past nst: stays inside the slack
+#pragma unroll
+                for (int u = 0; u < TR_U; u++) {
+                    if constexpr (METHOD == QH_M_SBD_DATA) dq[u] = ldg(sy + ibase + g + TR_U + u);
+                    step(xb[u], ibase + g + TR_U + u, dq[u]);
+                }
+                if (((ibase - i_begin + g + 2 * TR_U) & 63) == 0) {       // 64 errors staged -> one coalesced store
+                    stg(eout + ibase + g + 2 * TR_U - 64 + lane, Cx<R>{ebr, ebi});
                 }
             }
-        }
-    }
+            for (; g < nst; g++) {                                        // tail of the chunk, one step at a time
+                Cx<R> x1[TPL];
 #pragma unroll
-    for (int s = 0; s < TPL; s++)
-        if (valid[s]) stg(wrow + lane + 64 * s, w[s]);
+                for (int s = 0; s < TPL; s++) x1[s] = xp[s][g * xstep[s]];
+                Cx<R> d1{0, 0};
+                if constexpr (METHOD == QH_M_SBD_DATA) d1 = ldg(sy + ibase + g);
+                step(x1, ibase + g, d1);
+                if (((ibase - i_begin + g + 1) & 63) == 0) stg(eout + ibase + g + 1 - 64 + lane, Cx<R>{ebr, ebi});
+            }
+        }
+        const int rem = (int)(nsteps & 63);                               // errors still staged at the end of the sweep
+        if (lane < rem) stg(eout + (i_end - rem) + lane, Cx<R>{ebr, ebi});
+    }
+    if (w_out) {
+        Cx<R> *wo = w_out + (size_t)mode * ntot;
+#pragma unroll
+        for (int s = 0; s < TPL; s++)
+            if (lane + 64 * s < ntot) stg(wo + lane + 64 * s, w[s]);
+    }
     return mu;
 }
 
 template <typename R, int TPL, int METHOD>
-__global__ void __launch_bounds__(64) train_kernel(TrainArgs<R> a)
+__global__ void __launch_bounds__(64) train_kernel(TrainArgs<R> a, int CH, int pitch)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
+    ChainLds<R> lds;
+    lds.buf = reinterpret_cast<Cx<R> *>(smem);
+    lds.pitch = pitch;
+    lds.CH = CH;
+    lds.zero_off = 2 * a.nmodes * pitch;
+    for (int j = lane; j < TR_SLACK + 64; j += 64) lds.buf[lds.zero_off + j] = Cx<R>{0, 0};
     R mu = *a.mu;
-    if (a.adaptive) {
-        // sequential semantics: one wave walks the modes in order and carries mu
-        for (int j = 0; j < a.nsel; j++) mu = run_chain<R, TPL, METHOD>(a, (int)a.modes[j], mu, lane);
-        if (lane == 0) *a.mu = mu;
-    } else {
-        run_chain<R, TPL, METHOD>(a, (int)a.modes[blockIdx.x], mu, lane);
+    // adaptive: sequential semantics, ONE wave walks the modes in order and carries mu;
+    // otherwise one workgroup (= one CU) per selected mode
+    if (a.nseg > 0) {
+        // tier B: one workgroup per (mode, segment); every segment starts from the same taps and step size
+        const int64_t b = a.seg_begin + (int64_t)blockIdx.y * a.seg_len;
+        int64_t e = b + a.seg_len;
+        if (e > a.TrSyms) e = a.TrSyms;
+        const bool last = (int)blockIdx.y == a.nseg - 1;
+        if (b < e) {
+            mu = run_chain<R, TPL, METHOD>(a, lds, (int)a.modes[blockIdx.x], mu, lane, b, e, a.seg_iter, a.seg_iter + 1,
+                                           last ? a.wx_out : nullptr);
+            // the adapted step size is only handed on by the sequential prefix (nseg == 1); parallel segments keep
+            // theirs private, so a late-starting workgroup can never observe another segment's value
+            if (a.nseg == 1 && a.adaptive && blockIdx.x == a.nsel - 1 && lane == 0) *a.mu = mu;
+        }
+        return;
     }
+    const int jbeg = a.adaptive ? 0 : blockIdx.x, jend = a.adaptive ? a.nsel : blockIdx.x + 1;
+    for (int j = jbeg; j < jend; j++)
+        mu = run_chain<R, TPL, METHOD>(a, lds, (int)a.modes[j], mu, lane, 0, a.TrSyms, 0, a.Niter, a.wx);
+    if (a.adaptive && lane == 0) *a.mu = mu;
 }
 
 template <typename R, int TPL> static int launch_tpl(const TrainArgs<R> &a)
 {
-    dim3 grid(a.adaptive ? 1 : a.nsel), block(64);
-#define QH_CASE(M) case M: hipLaunchKernelGGL((train_kernel<R, TPL, M>), grid, block, 0, g_stream, a); break;
+    dim3 grid(a.nseg > 0 ? a.nsel : (a.adaptive ? 1 : a.nsel), a.nseg > 0 ? a.nseg : 1), block(64);
+    // chunk length: as many steps as fit a 48 KiB double buffer (at most 512)
+    int CH = 512;
+    int pitch = 0;
+    size_t lds = 0;
+    for (;; CH /= 2) {
+        pitch = (CH - 1 + TR_SLACK) * a.os + a.ntaps;
+        pitch = (pitch + 1) & ~1;
+        lds = ((size_t)2 * a.nmodes * pitch + TR_SLACK + 64) * sizeof(Cx<R>);
+        if (lds <= 48 * 1024 || CH <= 2 * TR_U) break;
+    }
+    QH_REQUIRE(lds <= 64 * 1024, "train_equaliser: nmodes*ntaps*os too large for the LDS sample window");
+#define QH_CASE(M) case M: hipLaunchKernelGGL((train_kernel<R, TPL, M>), grid, block, lds, g_stream, a, CH, pitch); break;
     switch (a.method) {
         QH_CASE(QH_M_CMA) QH_CASE(QH_M_CMA2) QH_CASE(QH_M_SGNCMA) QH_CASE(QH_M_MCMA) QH_CASE(QH_M_RDE) QH_CASE(QH_M_MRDE)
         QH_CASE(QH_M_SBD) QH_CASE(QH_M_MDDMA) QH_CASE(QH_M_DD) QH_CASE(QH_M_SBD_DATA)
@@ -273,10 +406,22 @@ template <typename R, int TPL> static int launch_tpl(const TrainArgs<R> &a)
     return QH_OK;
 }
 
+template <typename R> static int launch_any(const TrainArgs<R> &a)
+{
+    const int ntot = a.nmodes * a.ntaps;
+    if (ntot <= 64) return launch_tpl<R, 1>(a);
+    if (ntot <= 128) return launch_tpl<R, 2>(a);
+    if (ntot <= 256) return launch_tpl<R, 4>(a);
+    return launch_tpl<R, 16>(a);
+}
+
+// nseg == 0: the reference's exact sequential semantics.  nseg > 0: "segment-parallel continuation" (tier B): the first
+// `prefix` steps of sweep 0 are trained sequentially, then every sweep is split into nseg segments that all start from
+// the taps at the end of the previous phase; final taps (and step size) are those of the last segment.
 template <typename R>
 int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu_dev, void *wx, int ntaps,
               const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy, int method, void *err,
-              int zero_err)
+              int zero_err, int nseg = 0, int64_t prefix = 0)
 {
     int rc = ensure_init();
     if (rc) return rc;
@@ -296,11 +441,34 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
     a.L = L; a.TrSyms = TrSyms; a.nsy = nsy; a.nmodes = nmodes; a.ntaps = ntaps; a.Niter = Niter; a.os = os;
     a.nsel = nsel; a.adaptive = adaptive ? 1 : 0; a.method = method;
     for (int j = 0; j < 16; j++) a.modes[j] = j < nsel ? modes[j] : 0;
-    if (ntot <= 64) return launch_tpl<R, 1>(a);
-    if (ntot <= 128) return launch_tpl<R, 2>(a);
-    if (ntot <= 256) return launch_tpl<R, 4>(a);
-    if (ntot <= 512) return launch_tpl<R, 8>(a);
-    return launch_tpl<R, 16>(a);
+    a.nseg = 0; a.seg_begin = 0; a.seg_len = 0; a.seg_iter = 0; a.wx_out = nullptr;
+    if (nseg <= 0) return launch_any<R>(a);
+    // ---- tier B
+    QH_REQUIRE(nseg <= 65535 && prefix >= 0, "train_equaliser: bad segment parameters");
+    if (prefix > TrSyms) prefix = TrSyms;
+    void *wtmp = nullptr;
+    if ((rc = scratch(2, (size_t)nmodes * ntot * sizeof(Cx<R>), &wtmp))) return rc;
+    const size_t wbytes = (size_t)nmodes * ntot * sizeof(Cx<R>);
+    for (int it = 0; it < Niter; it++) {
+        int64_t begin = 0;
+        if (it == 0 && prefix > 0) {                         // sequential convergence prefix
+            TrainArgs<R> p = a;       // one "segment" [0, prefix) per mode == the exact chain on the prefix
+            p.nseg = 1; p.seg_begin = 0; p.seg_len = prefix; p.seg_iter = 0; p.wx_out = (Cx<R> *)wtmp;
+            QH_HIP(hipMemcpyAsync(wtmp, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
+            if ((rc = launch_any<R>(p))) return rc;
+            QH_HIP(hipMemcpyAsync(wx, wtmp, wbytes, hipMemcpyDeviceToDevice, g_stream));
+            begin = prefix;
+        }
+        if (begin >= TrSyms) continue;
+        TrainArgs<R> s = a;
+        s.nseg = nseg; s.seg_begin = begin; s.seg_len = (TrSyms - begin + nseg - 1) / nseg; s.seg_iter = it;
+        s.nseg = (int)((TrSyms - begin + s.seg_len - 1) / s.seg_len);     // drop empty trailing segments
+        s.wx_out = (Cx<R> *)wtmp;
+        QH_HIP(hipMemcpyAsync(wtmp, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));   // rows of unselected modes stay as they are
+        if ((rc = launch_any<R>(s))) return rc;
+        QH_HIP(hipMemcpyAsync(wx, wtmp, wbytes, hipMemcpyDeviceToDevice, g_stream));
+    }
+    return QH_OK;
 }
 
 template <typename R>
@@ -464,7 +632,6 @@ int train_real_host(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Ni
         if (ntot <= 64) rc = launch_real_tpl<R, 1>(a);
         else if (ntot <= 128) rc = launch_real_tpl<R, 2>(a);
         else if (ntot <= 256) rc = launch_real_tpl<R, 4>(a);
-        else if (ntot <= 512) rc = launch_real_tpl<R, 8>(a);
         else rc = launch_real_tpl<R, 16>(a);
         if (rc) return rc;
     }
@@ -477,44 +644,3 @@ int train_real_host(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Ni
 
 }  // namespace qh
 
-// ================================================================================================ C ABI
-extern "C" {
-
-int qh_train_equaliser_c64(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu, void *wx,
-                           int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
-                           int method, void *err)
-{
-    return qh::train_host<float>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err);
-}
-int qh_train_equaliser_c128(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu, void *wx,
-                            int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
-                            int method, void *err)
-{
-    return qh::train_host<double>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err);
-}
-int qh_train_equaliser_c64_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
-                               void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
-                               int64_t nsy, int method, void *err, int zero_err)
-{
-    return qh::train_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err);
-}
-int qh_train_equaliser_c128_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev,
-                                void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
-                                int64_t nsy, int method, void *err, int zero_err)
-{
-    return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err);
-}
-int qh_train_equaliser_real_f32(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu, void *wx,
-                                int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
-                                int method, void *err)
-{
-    return qh::train_real_host<float>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err);
-}
-int qh_train_equaliser_real_f64(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu, void *wx,
-                                int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
-                                int method, void *err)
-{
-    return qh::train_real_host<double>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err);
-}
-
-}  // extern "C"

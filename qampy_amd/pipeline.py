@@ -33,7 +33,8 @@ class ResidentReceiver:
     """
 
     def __init__(self, nmodes, L, os, M, Ntaps, mu, methods=("cma", "mrde"), Niter=(1, 1), adaptive_stepsize=(False, False),
-                 TrSyms=(None, None), Mtestangles=64, Nbps=20, dtype=np.complex64, alphabet=None, modes=None):
+                 TrSyms=(None, None), Mtestangles=64, Nbps=20, dtype=np.complex64, alphabet=None, modes=None, segments=0,
+                 prefix=1 << 16):
         suf, self.rt, self.ct = _lib.suffix(dtype)
         self.nmodes, self.L, self.os, self.M, self.Ntaps = int(nmodes), int(L), int(os), int(M), int(Ntaps)
         self.nstage = len(methods)
@@ -49,6 +50,8 @@ class ResidentReceiver:
         self.TrSyms = tuple(_host._cal_training_symbol_len(os, Ntaps, L) if t is None else int(t) for t in TrSyms[:self.nstage])
         self.N = (self.L - self.Ntaps + 1) // self.os
         self.Mtestangles, self.Nbps = Mtestangles, Nbps
+        # segments > 0: opt-in segment-parallel training (tier B); 0 = the reference's exact sequential recurrence
+        self.segments, self.prefix = int(segments), int(prefix)
         self.mu0 = tuple(self.rt(m) for m in mu)
         if alphabet is None:
             alphabet = _host.generate_symbols_for_eq("sbd", M, self.ct)[0]
@@ -88,7 +91,8 @@ class ResidentReceiver:
 
     def train(self, stage):
         _k.train_equaliser_dev(self.E, self.TrSyms[stage], self.Niter[stage], self.os, self.mu[stage], self.wxy, self.modes,
-                               self.adaptive[stage], self.symbols[stage], self.methods[stage], self.err[stage])
+                               self.adaptive[stage], self.symbols[stage], self.methods[stage], self.err[stage],
+                               segments=self.segments, prefix=self.prefix if stage == 0 else 0)
 
     def apply(self):
         _k.apply_filter_to_signal_dev(self.E, self.os, self.wxy, self.modes, self.eq)

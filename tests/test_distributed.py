@@ -1,0 +1,62 @@
+"""The N > 1 path of bench.py on CPU: world size 2, gloo, 127.0.0.1 rendezvous.  Covers the per-rank channel assignment,
+the barrier / MAX-time / SUM-counter reductions and the whole-job throughput formula (no data-path collective exists)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from conftest import ROOT
+from qampy_amd import sharding, synth
+
+
+def test_channel_assignment_is_independent_per_rank():
+    assert sharding.rank_info({}) == (0, 0, 1)
+    assert sharding.rank_info({"RANK": "3", "LOCAL_RANK": "1", "WORLD_SIZE": "8"}) == (3, 1, 8)
+    assert [sharding.channel_seed(r) for r in range(3)] == [1000, 1001, 1002]
+    a = synth.make_capture(16, 256, seed=sharding.channel_seed(0), snr_db=20)
+    b = synth.make_capture(16, 256, seed=sharding.channel_seed(1), snr_db=20)
+    assert a.shape == b.shape and not np.allclose(np.asarray(a), np.asarray(b))
+    assert sharding.aggregate_throughput(2 ** 22, 8, 5, 2.0) == 2 ** 22 * 8 * 5 / 2.0 / 1e6
+    assert sharding.reduce_max_time(1.5) == 1.5                      # no process group: identity
+    assert np.array_equal(sharding.reduce_sum_counts([[1, 2], [3, 4]]), [[1, 2], [3, 4]])
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from qampy_amd import sharding
+    rank, local, world = sharding.rank_info()
+    dist.init_process_group(backend="gloo")
+    dist.barrier()
+    elapsed = 1.0 + rank                      # rank 1 is the slow one
+    tmax = sharding.reduce_max_time(elapsed, dist)
+    counts = sharding.reduce_sum_counts([[rank + 1, 100], [0, 100]], dist)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps(dict(tmax=tmax, counts=counts.tolist(), seed=sharding.channel_seed(rank),
+                              value=sharding.aggregate_throughput(1000, world, 2, tmax))))
+    dist.destroy_process_group()
+""")
+
+
+def test_world_size_two_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    import json
+    res = json.loads(line)
+    assert res["tmax"] == 2.0                                  # MAX over ranks
+    assert res["counts"] == [[3.0, 200.0], [0.0, 200.0]]       # SUM over ranks
+    assert res["value"] == 1000 * 2 * 2 / 2.0 / 1e6

@@ -214,3 +214,31 @@ def test_edge_cases():
     # L < 2N: every index is forced to 0
     idx = hip_dsp.bps(np.ones(15, np.complex64), np.zeros((1, 4), np.float32), np.ones(4, np.complex64), 10)
     assert idx.shape == (15,) and np.all(idx == 0)
+
+
+# ------------------------------------------------------------------------------------------------ tier B (opt-in)
+def test_segment_parallel_training_is_consistent():
+    """The opt-in segment-parallel continuation: one segment == the exact chain bit for bit; many segments stay
+    statistically equivalent (same SER, taps within the LMS misadjustment) and never touch the default path."""
+    from qampy_amd.pipeline import ResidentReceiver
+    sig = synth.make_capture(16, 2 ** 15, nmodes=2, snr_db=25, theta=np.pi / 5.6, dgd=30e-12, linewidth=20e3, seed=77,
+                             dtype=np.complex64)
+    kw = dict(methods=("mcma", "sbd"), Niter=(1, 1), Mtestangles=32, Nbps=20, alphabet=sig.coded_symbols)
+    exact = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (1e-3, 2e-4), **kw)
+    one = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (1e-3, 2e-4), segments=1, prefix=0, **kw)
+    many = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (1e-3, 2e-4), segments=16, prefix=4096, **kw)
+    res = []
+    for rx in (exact, one, many):
+        rx.load(sig)
+        rx.run()
+        res.append(rx.fetch())
+    assert np.array_equal(res[0]["wxy"], res[1]["wxy"]) and np.array_equal(res[0]["err"][0], res[1]["err"][0])
+    assert np.array_equal(res[0]["out"], res[1]["out"])
+    # 16 segments: every error sample is produced, the converged taps agree within the gradient-noise misadjustment
+    assert np.all(np.abs(res[2]["err"][1][:, -100:]) > 0) and np.all(np.isfinite(res[2]["wxy"]))
+    assert np.max(np.abs(res[2]["wxy"] - res[0]["wxy"])) < 0.1
+    # the first `prefix` errors of stage 1 come from the same sequential recurrence
+    assert np.array_equal(res[2]["err"][0][:, :4096], res[0]["err"][0][:, :4096])
+    ser = [synth.cal_ser(r["out"], sig.symbols, sig.coded_symbols, trim=500) for r in res]
+    n = res[0]["out"].shape[1] - 1000
+    assert np.all(np.abs(ser[2] - ser[0]) * n <= 5), ser
