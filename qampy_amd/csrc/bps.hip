@@ -12,7 +12,10 @@
 // the reference materialises (1 GiB per mode at 2^22 symbols) never leaves the CU:
 //   * one workgroup owns a tile of T output symbols and computes the (T + 2N - 1) x A distances of tile + halo into
 //     LDS (thread <-> (symbol, angle) pairs, alphabet through the scalar cache);
-//   * window sums are column sums over that LDS tile (lane <-> angle, conflict free), written to a padded LDS plane;
+//   * square-QAM alphabets (cartesian products, detected on the device) are searched per axis - bit-identical to the
+//     full scan at 2*sqrt(M) instead of M candidates; anything else takes the brute-force scan;
+//   * window sums are column sums over that LDS tile (lane <-> angle, conflict free): direct for the first symbol of a
+//     short run, sliding for the rest, written to a padded LDS plane;
 //   * one thread per symbol scans the A sums for the first strict minimum (tie -> lowest angle, like the reference).
 #include "common.h"
 
@@ -25,14 +28,72 @@ template <typename R> __device__ __forceinline__ void sincos_(R x, R *s, R *c);
 template <> __device__ __forceinline__ void sincos_<float>(float x, float *s, float *c) { sincosf(x, s, c); }
 template <> __device__ __forceinline__ void sincos_<double>(double x, double *s, double *c) { sincos(x, s, c); }
 
+// Alphabet descriptor built on the device by analyse_alphabet_kernel (no host round trip).  A square-QAM alphabet is
+// a cartesian product {re levels} x {im levels}; then  min_k |t - s_k|^2 = fma(dr*, dr*, di* * di*)  with dr* / di* the
+// per-axis minima of |t_re - a_r| / |t_im - b_i| - bit-identical to the brute-force scan (rounding is monotone and
+// the product inside the fma is exact), at 2*sqrt(M) instead of M candidate evaluations.
+constexpr int BPS_MAX_LEVELS = 32;
+template <typename R> struct AlphabetDesc {
+    int product;            // 1: cartesian product detected
+    int nre, nim;
+    R re[BPS_MAX_LEVELS], im[BPS_MAX_LEVELS];
+};
+
+template <typename R>
+__global__ void __launch_bounds__(64) analyse_alphabet_kernel(const Cx<R> *symbols, int M, AlphabetDesc<R> *d)
+{
+    if (threadIdx.x != 0) return;
+    int nre = 0, nim = 0;
+    bool ok = true;
+    for (int k = 0; k < M && ok; k++) {
+        const Cx<R> s = symbols[k];
+        int r = 0, i = 0;
+        while (r < nre && d->re[r] != s.re) r++;
+        if (r == nre) { if (nre < BPS_MAX_LEVELS) d->re[nre++] = s.re; else ok = false; }
+        while (i < nim && d->im[i] != s.im) i++;
+        if (i == nim) { if (nim < BPS_MAX_LEVELS) d->im[nim++] = s.im; else ok = false; }
+    }
+    // every (re, im) combination must occur: M distinct points on an nre x nim grid with M == nre*nim
+    if (ok && (long)nre * nim == M) {
+        for (int k = 0; k < M && ok; k++)
+            for (int q = 0; q < k; q++)
+                if (symbols[k].re == symbols[q].re && symbols[k].im == symbols[q].im) { ok = false; break; }
+    } else {
+        ok = false;
+    }
+    d->product = ok ? 1 : 0;
+    d->nre = nre; d->nim = nim;
+}
+
 template <typename R> struct BpsArgs {
     const Cx<R> *E;        // (L,)
     const R *angles;       // (p, A)
     const Cx<R> *symbols;  // (M,)
+    const AlphabetDesc<R> *desc;
     int32_t *idx;          // (L,)
     int64_t L, p;
-    int A, M, N, T;
+    int A, M, N, T, RUN;
 };
+
+template <typename R> __device__ __forceinline__ R min_distance(R tr, R ti, const BpsArgs<R> &a, bool product)
+{
+    if (product) {
+        const AlphabetDesc<R> *d = a.desc;
+        R mr = (R)3.0e38, mi = (R)3.0e38;
+        for (int r = 0; r < d->nre; r++) mr = min_(mr, abs_(tr - d->re[r]));     // wave-uniform levels: scalar loads
+        for (int i = 0; i < d->nim; i++) mi = min_(mi, abs_(ti - d->im[i]));
+        const R d0 = fma_(mr, mr, mi * mi);
+        return d0 < (R)100. ? d0 : (R)100.;
+    }
+    R d0 = (R)1000.;                                    // det_symbol: strict `<` from d0 = 1000 (:17-22)
+    for (int k = 0; k < a.M; k++) {
+        const Cx<R> s = a.symbols[k];                   // wave-uniform -> scalar load
+        const R dr = tr - s.re, di = ti - s.im;
+        const R d = fma_(dr, dr, di * di);
+        d0 = d < d0 ? d : d0;
+    }
+    return d0 < (R)100. ? d0 : (R)100.;                 // dists initialised to 100 (:73, :83)
+}
 
 template <typename R>
 __global__ void __launch_bounds__(BPS_THREADS) bps_kernel(BpsArgs<R> a)
@@ -42,39 +103,58 @@ __global__ void __launch_bounds__(BPS_THREADS) bps_kernel(BpsArgs<R> a)
     const int rows = T + 2 * N - 1;
     R *dist = reinterpret_cast<R *>(smem);                 // [rows][A]
     R *wsum = dist + (size_t)rows * A;                     // [T][A + 1]
+    Cx<R> *rot = reinterpret_cast<Cx<R> *>(wsum + (size_t)T * (A + 1) + ((size_t)T * (A + 1) & 1));   // [A] rotators
     const int64_t i0 = (int64_t)blockIdx.x * T;            // first output symbol of this tile
     const int64_t l0 = i0 - N + 1;                         // symbol index of dist row 0
     const bool per_symbol = a.p > 1;
+    const bool product = a.desc->product != 0;
 
-    // ---- phase 1: min-distance of every (symbol, test angle) of tile + halo
+    if (!per_symbol) {                                     // exp(j*theta_a) once per tile instead of once per (symbol, angle)
+        for (int ja = threadIdx.x; ja < A; ja += BPS_THREADS) {
+            R sn, cs;
+            sincos_<R>(a.angles[ja], &sn, &cs);
+            rot[ja] = Cx<R>{cs, sn};
+        }
+        __syncthreads();
+    }
+    // ---- phase 1: min-distance of every (symbol, test angle) of tile + halo; lanes <-> consecutive angles
     for (int e = threadIdx.x; e < rows * A; e += BPS_THREADS) {
         const int r = e / A, ja = e - r * A;
         const int64_t l = l0 + r;
         R d0 = 0;                                           // rows outside [0, L) only feed outputs that are forced to 0
         if (l >= 0 && l < a.L) {
             const Cx<R> x = ldg(a.E + l);
-            R sn, cs;
-            sincos_<R>(a.angles[(per_symbol ? (size_t)l * A : 0) + ja], &sn, &cs);
-            const R tr = fma_(x.re, cs, -(x.im * sn)), ti = fma_(x.re, sn, x.im * cs);
-            d0 = (R)1000.;                                  // det_symbol: strict `<` from d0 = 1000 (:17-22)
-            for (int k = 0; k < a.M; k++) {
-                const Cx<R> s = a.symbols[k];               // wave-uniform -> scalar load
-                const R dr = tr - s.re, di = ti - s.im;
-                const R d = fma_(dr, dr, di * di);
-                d0 = d < d0 ? d : d0;
+            Cx<R> c;
+            if (per_symbol) {
+                R sn, cs;
+                sincos_<R>(a.angles[(size_t)l * A + ja], &sn, &cs);
+                c = Cx<R>{cs, sn};
+            } else {
+                c = rot[ja];
             }
-            d0 = d0 < (R)100. ? d0 : (R)100.;               // dists initialised to 100 (:73, :83)
+            const R tr = fma_(x.re, c.re, -(x.im * c.im)), ti = fma_(x.re, c.im, x.im * c.re);
+            d0 = min_distance<R>(tr, ti, a, product);
         }
         dist[e] = d0;
     }
     __syncthreads();
-    // ---- phase 2: windowed sums, output symbol il <-> dist rows il .. il + 2N - 1
-    for (int e = threadIdx.x; e < T * A; e += BPS_THREADS) {
-        const int il = e / A, ja = e - il * A;
-        const R *col = dist + (size_t)il * A + ja;
+    // ---- phase 2: windowed sums.  A thread owns one angle and a run of RUN consecutive output symbols: the first
+    // window is a direct 2N-term sum, the following ones slide (add the entering row, subtract the leaving one); runs
+    // are short, so the running sum is re-anchored every RUN symbols (the reference keeps ONE running sum per capture).
+    const int nrun = (T + a.RUN - 1) / a.RUN;
+    for (int e = threadIdx.x; e < nrun * A; e += BPS_THREADS) {
+        const int ir = e / A, ja = e - ir * A;
+        const int il0 = ir * a.RUN;
+        const int il1 = il0 + a.RUN < T ? il0 + a.RUN : T;
+        const R *col = dist + ja;
         R s = 0;
-        for (int r = 0; r < 2 * N; r++) s += col[(size_t)r * A];
-        wsum[(size_t)il * (A + 1) + ja] = s;
+        for (int r = 0; r < 2 * N; r++) s += col[(size_t)(il0 + r) * A];
+        wsum[(size_t)il0 * (A + 1) + ja] = s;
+        for (int il = il0 + 1; il < il1; il++) {
+            s += col[(size_t)(il + 2 * N - 1) * A];
+            s -= col[(size_t)(il - 1) * A];
+            wsum[(size_t)il * (A + 1) + ja] = s;
+        }
     }
     __syncthreads();
     // ---- phase 3: first arg-min over the test angles (dmin starts at 1000, strict `<`, :31-41)
@@ -96,12 +176,12 @@ __global__ void __launch_bounds__(BPS_THREADS) bps_kernel(BpsArgs<R> a)
 
 template <typename R> static int bps_tile(int A, int N, size_t *lds)
 {
-    // largest T with (T + 2N - 1)*A + T*(A + 1) elements inside the LDS budget
-    const int64_t cap = (int64_t)(BPS_LDS_BUDGET / sizeof(R));
+    // largest T with (T + 2N - 1)*A + T*(A + 1) elements (+ the rotator table) inside the LDS budget
+    const int64_t cap = (int64_t)(BPS_LDS_BUDGET / sizeof(R)) - 2 * A - 2;
     int64_t T = (cap - (int64_t)(2 * N - 1) * A) / (2 * A + 1);
     if (T > 1024) T = 1024;
     if (T < 1) return 0;
-    *lds = ((size_t)(T + 2 * N - 1) * A + (size_t)T * (A + 1)) * sizeof(R);
+    *lds = ((size_t)(T + 2 * N - 1) * A + (size_t)T * (A + 1) + 1 + 2 * (size_t)A) * sizeof(R);
     return (int)T;
 }
 
@@ -116,9 +196,18 @@ int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, cons
     size_t lds = 0;
     const int T = bps_tile<R>(A, N, &lds);
     QH_REQUIRE(T >= 8, "bps: averaging window 2N x test angles does not fit the LDS tile");
+    void *desc = nullptr;
+    if ((rc = scratch(3, sizeof(AlphabetDesc<R>), &desc))) return rc;
+    hipLaunchKernelGGL((analyse_alphabet_kernel<R>), dim3(1), dim3(64), 0, g_stream, (const Cx<R> *)symbols, M, (AlphabetDesc<R> *)desc);
     BpsArgs<R> a;
     a.E = (const Cx<R> *)E; a.angles = (const R *)angles; a.symbols = (const Cx<R> *)symbols; a.idx = idx;
+    a.desc = (const AlphabetDesc<R> *)desc;
     a.L = L; a.p = p; a.A = A; a.M = M; a.N = N; a.T = T;
+    // run length of the sliding window sums: enough runs to keep every thread busy, at least 8 symbols each
+    int run = (int)(((int64_t)T * A + BPS_THREADS - 1) / BPS_THREADS);
+    if (run < 8) run = 8;
+    if (run > T) run = T;
+    a.RUN = run;
     static bool attr_set = false;
     if (!attr_set) {
         QH_HIP(hipFuncSetAttribute((const void *)bps_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BPS_LDS_BUDGET));

@@ -51,7 +51,8 @@ class ResidentReceiver:
         self.N = (self.L - self.Ntaps + 1) // self.os
         self.Mtestangles, self.Nbps = Mtestangles, Nbps
         # segments > 0: opt-in segment-parallel training (tier B); 0 = the reference's exact sequential recurrence
-        self.segments, self.prefix = int(segments), int(prefix)
+        self.segments = int(segments)
+        self.prefix = tuple(int(p) for p in (prefix if isinstance(prefix, (tuple, list)) else (prefix,) * len(methods)))
         self.mu0 = tuple(self.rt(m) for m in mu)
         if alphabet is None:
             alphabet = _host.generate_symbols_for_eq("sbd", M, self.ct)[0]
@@ -92,7 +93,7 @@ class ResidentReceiver:
     def train(self, stage):
         _k.train_equaliser_dev(self.E, self.TrSyms[stage], self.Niter[stage], self.os, self.mu[stage], self.wxy, self.modes,
                                self.adaptive[stage], self.symbols[stage], self.methods[stage], self.err[stage],
-                               segments=self.segments, prefix=self.prefix if stage == 0 else 0)
+                               segments=self.segments, prefix=self.prefix[stage])
 
     def apply(self):
         _k.apply_filter_to_signal_dev(self.E, self.os, self.wxy, self.modes, self.eq)
