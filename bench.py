@@ -63,7 +63,7 @@ def make_receiver(cfg, sig, segments=0, prefix=0):
 def timed_steps(rx, steps, warmup, barrier_sync):
     """W warm-up passes, then exactly K passes bracketed by barrier + device sync; HIP events between the stages."""
     from qampy_amd import _lib
-    stage_fns = [lambda s=s: rx.train(s) for s in range(rx.nstage)] + [rx.apply, rx.recover]
+    stage_fns = [rx.build_gram] + [lambda s=s: rx.train(s) for s in range(rx.nstage)] + [rx.apply, rx.recover]
     for _ in range(warmup):
         rx.run()
     ev = [[_lib.Event() for _ in range(len(stage_fns) + 1)] for _ in range(steps)]
@@ -171,7 +171,7 @@ def main():
     seg = dict(segments=args.segments, prefix=args.prefix) if args.train_mode == "segmented" else {}
     rx = make_receiver(cfg, sig, **seg)
     rx.load(sig)
-    stage_names = ["train%d:%s" % (s + 1, m) for s, m in enumerate(cfg["methods"])] + ["apply", "bps_recover"]
+    stage_names = ["gram"] + ["train%d:%s" % (s + 1, m) for s, m in enumerate(cfg["methods"])] + ["apply", "bps_recover"]
 
     # ---- timed region: exactly K steps, HIP events between the stages (same stream as the kernels)
     elapsed, stage_ms = timed_steps(rx, args.steps, args.warmup, barrier_sync)
@@ -191,7 +191,7 @@ def main():
     value = sharding.aggregate_throughput(nsym, world, args.steps, elapsed)
     # ---- roofline of the dominant kernel
     bps_b = rx.bytes_per_symbol()
-    stage_bytes = []
+    stage_bytes = [rx.TrSyms[0] * (8 * 2 * 2 + 64 * 16)]            # gram: read the capture once, write 1 KiB per step
     for s in range(rx.nstage):
         stage_bytes.append(rx.Niter[s] * rx.TrSyms[s] * 8 * (2 * 2 + 2))
     stage_bytes += [rx.N * bps_b["apply"], rx.N * bps_b["bps"]]
@@ -200,7 +200,7 @@ def main():
     roofline = dict(bound="hbm", kernel=stage_names[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
                     note=("exact sequential LMS chain: single-wave dependent-issue bound, 1 wave per output mode (DESIGN.md)"
-                          if args.train_mode == "exact" and dom < rx.nstage else "see DESIGN.md"))
+                          if args.train_mode == "exact" and 1 <= dom <= rx.nstage else "see DESIGN.md"))
 
     out = dict(metric="equalised MSym/s (2-pol, 2 SPS)", value=round(value, 4), unit="MSym/s", n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",

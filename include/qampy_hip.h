@@ -87,6 +87,19 @@ int qh_train_equaliser_c128_dev(const void *E, int nmodes, int64_t L, int64_t Tr
                                 void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
                                 int64_t nsy, int method, void *err, int zero_err);
 
+/* Gram terms of the look-ahead trainer: G(l, i) = sum_f conj(x_l[f]) x_i[f] for the 127 steps after l, laid out for the
+ * kernel.  They depend on the capture only, so one build serves every mode, stage and sweep over the same
+ * (E, os, ntaps, TrSyms).  The buffer is library-owned scratch: valid until the next qh_gram_build_* call; pass it to
+ * qh_train_equaliser_*_gram_dev, or pass NULL there (and to the plain _dev / host entry points) to build it internally. */
+int qh_gram_build_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram);
+int qh_gram_build_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram);
+int qh_train_equaliser_c64_gram_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
+                                    void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
+                                    int64_t nsy, int method, void *err, int zero_err, const void *gram);
+int qh_train_equaliser_c128_gram_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev,
+                                     void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
+                                     int64_t nsy, int method, void *err, int zero_err, const void *gram);
+
 /* Segment-parallel continuation ("tier B", NOT the reference's semantics - DESIGN.md §tiers): the first `prefix` steps
  * are trained sequentially, then each sweep is cut into `nseg` contiguous segments that are trained concurrently, every
  * segment starting from the taps the previous phase ended with; err is complete, the returned taps are those of the

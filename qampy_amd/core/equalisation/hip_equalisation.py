@@ -129,8 +129,22 @@ def det_symbol(X, symbs):
 
 
 # ------------------------------------------------------------------------------------------------ device-resident forms
+def gram_build_dev(E, os, ntaps, TrSyms):
+    """
+    Build the Gram terms of the look-ahead trainer for a resident capture (they depend on ``E, os, ntaps, TrSyms`` only)
+    and return the opaque device pointer to hand to :func:`train_equaliser_dev` for every mode / stage / sweep over the
+    same capture.  The buffer is library-owned and valid until the next call of this function.
+    """
+    suf, rt, ct = _lib.suffix(E.dtype)
+    nmodes, L = E.shape
+    g = C.c_void_p()
+    _lib.call("qh_gram_build_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, nmodes, L, int(os), int(ntaps), int(TrSyms),
+              C.byref(g))
+    return g.value
+
+
 def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method, err, zero_err=False, segments=0,
-                        prefix=0):
+                        prefix=0, gram=None):
     """
     Same as :func:`train_equaliser` with every array (and the scalar ``mu``, a 1-element DeviceArray) already in HBM.
     Only enqueues work on the library stream.
@@ -150,6 +164,8 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
     name = "qh_train_equaliser_c" + ("64" if suf == "32" else "128")
     if segments and segments > 0:
         _lib.call(name + "_seg_dev", *args, int(segments), int(prefix))
+    elif gram:
+        _lib.call(name + "_gram_dev", *args, gram)
     else:
         _lib.call(name + "_dev", *args)
 

@@ -26,4 +26,14 @@ int qh_train_equaliser_c128_seg_dev(const void *E, int nmodes, int64_t L, int64_
 {
     return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, nseg, prefix);
 }
+int qh_gram_build_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
+{
+    return qh::gram_build<double>(E, nmodes, L, os, ntaps, TrSyms, gram);
+}
+int qh_train_equaliser_c128_gram_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev,
+                                    void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
+                                    int64_t nsy, int method, void *err, int zero_err, const void *gram)
+{
+    return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, 0, 0, gram);
+}
 }

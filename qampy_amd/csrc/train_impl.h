@@ -19,6 +19,8 @@
 //     mode into the next when run sequentially; otherwise each mode gets its own workgroup (its own CU).
 #pragma once
 #include "common.h"
+#include "train_la.h"
+#include <stdlib.h>
 
 namespace qh {
 
@@ -421,7 +423,7 @@ template <typename R> static int launch_any(const TrainArgs<R> &a)
 template <typename R>
 int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu_dev, void *wx, int ntaps,
               const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy, int method, void *err,
-              int zero_err, int nseg = 0, int64_t prefix = 0)
+              int zero_err, int nseg = 0, int64_t prefix = 0, const void *gram = nullptr)
 {
     int rc = ensure_init();
     if (rc) return rc;
@@ -442,7 +444,28 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
     a.nsel = nsel; a.adaptive = adaptive ? 1 : 0; a.method = method;
     for (int j = 0; j < 16; j++) a.modes[j] = j < nsel ? modes[j] : 0;
     a.nseg = 0; a.seg_begin = 0; a.seg_len = 0; a.seg_iter = 0; a.wx_out = nullptr;
-    if (nseg <= 0) return launch_any<R>(a);
+    if (nseg <= 0) {
+        // exact semantics.  Blind methods with a fixed step run in the look-ahead form (train_la.h), everything else
+        // (decision-directed, data-aided, adaptive step, tiny captures) in the direct form below.  Same results up to
+        // the order of additions; QAMPY_HIP_TRAINER=direct forces the direct form (A/B measurements, tests).
+        const char *force = getenv("QAMPY_HIP_TRAINER");
+        const bool direct = force && force[0] == 'd';
+        if (!direct && la_supported(method, adaptive, nmodes, ntaps, TrSyms, nsy)) {
+            void *G = const_cast<void *>(gram);
+            if (!G && (rc = gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G))) return rc;
+            LaArgs<R> la;
+            la.E = a.E; la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.G = (const GramPair<R> *)G; la.mu = mu_dev;
+            la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
+            la.os = os; la.nsel = nsel; la.method = method;
+            for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];
+            for (int it = 0; it < Niter; it++) {                 // one launch per sweep: taps go through HBM in between
+                la.err_off = (int64_t)it * TrSyms;
+                if ((rc = launch_la<R>(la))) return rc;
+            }
+            return QH_OK;
+        }
+        return launch_any<R>(a);
+    }
     // ---- tier B
     QH_REQUIRE(nseg <= 65535 && prefix >= 0, "train_equaliser: bad segment parameters");
     if (prefix > TrSyms) prefix = TrSyms;

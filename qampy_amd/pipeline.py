@@ -90,10 +90,16 @@ class ResidentReceiver:
         for m, m0 in zip(self.mu, self.mu_init):
             m.copy_from(m0)
 
+    def build_gram(self):
+        """Gram terms of the look-ahead trainer: once per capture, shared by all modes, stages and sweeps."""
+        self._gram = None
+        if self.segments == 0 and len(set(self.TrSyms)) == 1:
+            self._gram = _k.gram_build_dev(self.E, self.os, self.Ntaps, self.TrSyms[0])
+
     def train(self, stage):
         _k.train_equaliser_dev(self.E, self.TrSyms[stage], self.Niter[stage], self.os, self.mu[stage], self.wxy, self.modes,
                                self.adaptive[stage], self.symbols[stage], self.methods[stage], self.err[stage],
-                               segments=self.segments, prefix=self.prefix[stage])
+                               segments=self.segments, prefix=self.prefix[stage], gram=getattr(self, "_gram", None))
 
     def apply(self):
         _k.apply_filter_to_signal_dev(self.E, self.os, self.wxy, self.modes, self.eq)
@@ -104,6 +110,7 @@ class ResidentReceiver:
     def run(self):
         """One pass of the hot path over the resident capture; returns without synchronising."""
         self.reset()
+        self.build_gram()
         for s in range(self.nstage):
             self.train(s)
         self.apply()

