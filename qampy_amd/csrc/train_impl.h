@@ -21,6 +21,7 @@
 #include "common.h"
 #include "train_la.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace qh {
 
@@ -450,7 +451,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         // the order of additions; QAMPY_HIP_TRAINER=direct forces the direct form (A/B measurements, tests).
         const char *force = getenv("QAMPY_HIP_TRAINER");
         const bool direct = force && force[0] == 'd';
-        if (!direct && la_supported(method, adaptive, nmodes, ntaps, TrSyms, nsy)) {
+        if (!direct && la_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy)) {
             void *G = const_cast<void *>(gram);
             if (!G && (rc = gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G))) return rc;
             LaArgs<R> la;
@@ -458,9 +459,24 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
             la.os = os; la.nsel = nsel; la.method = method;
             for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];
+            la.prof = nullptr;
+            if (getenv("QAMPY_HIP_LA_PROFILE")) {                // developer aid: per-wave cycle split of workgroup 0
+                void *pp = nullptr;
+                if ((rc = scratch(5, 16 * sizeof(unsigned long long), &pp))) return rc;
+                QH_HIP(hipMemsetAsync(pp, 0, 16 * sizeof(unsigned long long), g_stream));
+                la.prof = (unsigned long long *)pp;
+            }
             for (int it = 0; it < Niter; it++) {                 // one launch per sweep: taps go through HBM in between
                 la.err_off = (int64_t)it * TrSyms;
                 if ((rc = launch_la<R>(la))) return rc;
+            }
+            if (la.prof) {
+                unsigned long long hp[16];
+                QH_HIP(hipMemcpyAsync(hp, la.prof, sizeof(hp), hipMemcpyDeviceToHost, g_stream));
+                QH_HIP(hipStreamSynchronize(g_stream));
+                fprintf(stderr, "[la profile] method %d TrSyms %lld: chain work %llu wait %llu |", method, (long long)TrSyms, hp[0], hp[1]);
+                for (int h = 1; h <= LA_NH; h++) fprintf(stderr, " helper%d update %llu prior %llu wait %llu |", h, hp[4 * h], hp[4 * h + 1], hp[4 * h + 2]);
+                fprintf(stderr, "\n");
             }
             return QH_OK;
         }

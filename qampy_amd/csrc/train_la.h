@@ -22,7 +22,8 @@ namespace qh {
 constexpr int LA_B = 64;          // steps per block = lanes of the chain wave
 constexpr int LA_NH = 3;          // helper waves
 constexpr int LA_PD = 8;          // Gram-row prefetch distance (steps)
-constexpr int LA_HB = 32;         // helper load batch
+constexpr int LA_HB = 32;         // helper load batch (tap update)
+constexpr int LA_MAXSLICE = 32;   // taps per helper held in registers by the prior dot products
 constexpr int LA_MAXPART = 8;     // RDE/MRDE partitions handled by the vector select chain
 
 template <typename R> struct GramPair { Cx<R> cur, next; };   // per (step l, lane i): G(l, blk+i) [i > l-blk] and G(l, blk+64+i)
@@ -117,33 +118,43 @@ template <typename R, int NPART> struct LaConst {
     PartTab<R, NPART> tab;
 };
 
-// SCALE = true: returns c = mu * errfn(y) with mu folded into the scalar factor (one multiply less on the critical
-// path); SCALE = false: the plain error for the trace.
+// SCALE = true: returns c = mu * errfn(y) with mu folded into the scalar factor (fewer instructions on the critical
+// path); SCALE = false: the plain error for the trace.  Written on 2-vectors so that hipcc emits v_pk_* for float.
+template <typename R> struct V2 { typedef R type __attribute__((ext_vector_type(2))); };
+
 template <typename R, int METHOD, int NPART, bool SCALE>
 __device__ __forceinline__ Cx<R> la_errfn(Cx<R> y, const LaConst<R, NPART> &k)
 {
-    Cx<R> e;
-    const R m = SCALE ? k.mu : (R)1;
+    using v2 = typename V2<R>::type;
+    const v2 yy = {y.re, y.im};
+    v2 e;
     if constexpr (METHOD == QH_M_CMA || METHOD == QH_M_SGNCMA) {
-        const R d = (k.R_re - fma_(y.re, y.re, y.im * y.im)) * m;
-        e.re = d * y.re; e.im = d * y.im;
+        const R t = fma_(y.re, y.re, y.im * y.im);
+        const R d = SCALE ? fma_(-k.mu, t, k.mu * k.R_re) : k.R_re - t;       // (R - |y|^2) [* mu]
+        e = yy * d;
     } else if constexpr (METHOD == QH_M_CMA2) {
         const R x2r = fma_(y.re, y.re, -(y.im * y.im)), x2i = (R)2 * y.re * y.im;
+        const R m = SCALE ? k.mu : (R)1;
         const R dr = (k.R_re - x2r) * m, di = (k.R_im - x2i) * m;
-        e.re = fma_(dr, y.re, -(di * y.im)); e.im = fma_(dr, y.im, di * y.re);
+        e = v2{fma_(dr, y.re, -(di * y.im)), fma_(dr, y.im, di * y.re)};
     } else if constexpr (METHOD == QH_M_MCMA) {
-        e.re = ((k.R_re - y.re * y.re) * m) * y.re;
-        e.im = ((k.R_im - y.im * y.im) * m) * y.im;
+        const v2 Rc = {k.R_re, k.R_im};
+        v2 d = Rc - yy * yy;
+        if constexpr (SCALE) d = d * k.mu;
+        e = d * yy;
     } else if constexpr (METHOD == QH_M_RDE) {
         const R sq = fma_(y.re, y.re, y.im * y.im);
-        const R d = (tab_lookup<R, NPART, false>(sq, k.code0_re, k.tab) - sq) * m;
-        e.re = y.re * d; e.im = y.im * d;
+        R d = tab_lookup<R, NPART, false>(sq, k.code0_re, k.tab) - sq;
+        if constexpr (SCALE) d = d * k.mu;
+        e = yy * d;
     } else {   // QH_M_MRDE
-        const R sqr = y.re * y.re, sqi = y.im * y.im;
-        e.re = ((tab_lookup<R, NPART, false>(sqr, k.code0_re, k.tab) - sqr) * m) * y.re;
-        e.im = ((tab_lookup<R, NPART, true>(sqi, k.code0_im, k.tab) - sqi) * m) * y.im;
+        const v2 sq = yy * yy;
+        const v2 r = {tab_lookup<R, NPART, false>(sq.x, k.code0_re, k.tab), tab_lookup<R, NPART, true>(sq.y, k.code0_im, k.tab)};
+        v2 d = r - sq;
+        if constexpr (SCALE) d = d * k.mu;
+        e = d * yy;
     }
-    return e;
+    return Cx<R>{e.x, e.y};
 }
 
 // ------------------------------------------------------------------------------------------------ the sweep kernel
@@ -157,6 +168,7 @@ template <typename R> struct LaArgs {
     int64_t L, TrSyms, nsy, err_pitch, err_off;
     int nmodes, ntaps, os, nsel, method;
     int64_t modes[16];
+    unsigned long long *prof;   // optional [4 waves][4] cycle counters of workgroup 0 (qh_la_profile), else nullptr
 };
 
 template <typename R> struct LaLds {
@@ -168,7 +180,9 @@ template <typename R> struct LaLds {
 template <typename R, int METHOD, int NPART>
 __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
 {
-    __shared__ LaLds<R> lds;
+    extern __shared__ __attribute__((aligned(16))) char la_smem[];
+    LaLds<R> &lds = *reinterpret_cast<LaLds<R> *>(la_smem);
+    Cx<R> *lds_win = reinterpret_cast<Cx<R> *>(la_smem + sizeof(LaLds<R>));   // [LA_NH][2][nmodes][wpitch] helper sample windows
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int mode = (int)a.modes[blockIdx.x];
@@ -205,6 +219,7 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
             yn.im = fma_(cr, g.next.im, fma_(ci, g.next.re, yn.im));
         };
         __syncthreads();                                               // barrier 0: Q_0 is ready
+        unsigned long long t_wait = 0, t_work = 0, t_mark = __builtin_readcyclecounter();
         for (int k = 0; k < nblk; k++) {
             const int64_t s0 = (int64_t)k * LA_B;
             const int nvalid = (int)((TrSyms - s0) < LA_B ? (TrSyms - s0) : LA_B);
@@ -233,8 +248,11 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
             if (lane >= nvalid) c = Cx<R>{0, 0};
             if (lane < nvalid) stg(errow + s0 + lane, e);
             lds.cbuf[k & 1][lane] = c;
+            if (a.prof) { const unsigned long long t = __builtin_readcyclecounter(); t_work += t - t_mark; t_mark = t; }
             __syncthreads();                                           // barrier k+1
+            if (a.prof) { const unsigned long long t = __builtin_readcyclecounter(); t_wait += t - t_mark; t_mark = t; }
         }
+        if (a.prof && blockIdx.x == 0 && lane == 0) { a.prof[0] = t_work; a.prof[1] = t_wait; }
         return;
     }
 
@@ -251,76 +269,111 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
     Cx<R> *wrow = a.wx + (size_t)mode * ntot;
     Cx<R> w = own ? ldg(wrow + fl) : Cx<R>{0, 0};
 
-    // The helpers' loads do not depend on the chain, so they are issued LA_HB at a time ahead of the arithmetic (one
-    // memory round trip per batch instead of one per step) from per-lane base pointers with small uniform offsets; only
-    // the partial last block of a sweep takes the clamped path.
+    // Sample windows.  A helper stages, per 64-step block, the (63*os + ntaps) samples of every input mode into its own
+    // LDS window with coalesced loads (issued early: they do not depend on the chain) and then reads its operands with
+    // immediate-offset ds_reads: x_l[f] = win[k_f * wpitch + (l - s0) * os + t_f].
     const int os_ = a.os;
-    const int64_t Lrow = a.L;
-    // prior outputs of block kb from the current taps: lane <-> step kb*64 + lane
-    auto prior = [&](int kb) {
-        lds.wbuf[h][lane] = w;                                         // same wave writes and reads: LDS keeps order;
-        int64_t s = (int64_t)kb * LA_B + lane;                         // lanes >= nf hold w = 0
-        const bool live = s < TrSyms;
-        if (!live) s = TrSyms - 1;
-        const Cx<R> *ps = a.E + s * os_;                               // x_s[f] = ps[k_f * L + t_f]
-        Cx<R> acc{0, 0};
-        for (int fb = 0; fb < nf; fb += LA_HB) {
-            Cx<R> x[LA_HB];
-            int k2 = (f0 + fb) / a.ntaps, t2 = (f0 + fb) - k2 * a.ntaps;   // walk (mode, tap) without a division per tap
-            int64_t off = (int64_t)k2 * Lrow + t2;                         // wave-uniform element offset
+    const int wlen = (LA_B - 1) * os_ + a.ntaps;                      // samples per mode and block
+    const int wpitch = (wlen + 1) & ~1;
+    const int wsz = a.nmodes * wpitch + 2;                             // + a dummy slot for the surplus staging lanes
+    Cx<R> *win_u = lds_win + (size_t)(h * 2 + 0) * wsz;                // window of the block being folded into the taps
+    Cx<R> *win_p = lds_win + (size_t)(h * 2 + 1) * wsz;                // window of the block whose prior outputs are due
+    constexpr int WREG = 8;                                            // staging registers per lane and window
+    const int wtot = a.nmodes * wpitch;
+    Cx<R> su[WREG], sp[WREG];
+    int64_t soff[WREG];                                                // capture offset of window element lane + 64 q (block 0)
+    int sdst[WREG];                                                    // its LDS slot; surplus lanes write a dummy slot
 #pragma unroll
-            for (int u = 0; u < LA_HB; u++) {
-                x[u] = ldg(ps + off);
-                if (fb + u + 1 < nf) {                                     // stop at the slice's last tap
-                    off++;
-                    if (++t2 == a.ntaps) { t2 = 0; off += Lrow - a.ntaps; }
-                }
-            }
+    for (int q = 0; q < WREG; q++) {
+        const int e = lane + 64 * q;
+        const bool v = e < wtot;
+        const int k2 = v ? e / wpitch : 0, i2 = v ? e - k2 * wpitch : 0;
+        soff[q] = (int64_t)k2 * a.L + i2;
+        sdst[q] = v ? e : wtot;
+    }
+    auto stage_load = [&](Cx<R> (&r)[WREG], int kb) {
+        const int64_t base = (int64_t)kb * LA_B * os_;
+        if (base + wpitch <= a.L) {                                    // whole window inside the capture: no clamping
+            const Cx<R> *pb = a.E + base;
 #pragma unroll
-            for (int u = 0; u < LA_HB; u++) {
-                const Cx<R> wv = lds.wbuf[h][(fb + u) & 63];              // zero beyond the slice
-                acc.re = fma_(x[u].re, wv.re, fma_(-x[u].im, wv.im, acc.re));
-                acc.im = fma_(x[u].re, wv.im, fma_(x[u].im, wv.re, acc.im));
+            for (int q = 0; q < WREG; q++) r[q] = ldg(pb + soff[q]);
+        } else {                                                       // the last block may reach past the capture
+#pragma unroll
+            for (int q = 0; q < WREG; q++) {
+                const int64_t row = soff[q] / a.L * a.L;
+                int64_t g = base + (soff[q] - row);
+                if (g > a.L - 1) g = a.L - 1;
+                r[q] = ldg(a.E + row + g);
             }
         }
-        lds.qbuf[h][kb & 1][lane] = live ? acc : Cx<R>{0, 0};
     };
+    auto stage_store = [&](const Cx<R> (&r)[WREG], Cx<R> *win) {
+#pragma unroll
+        for (int q = 0; q < WREG; q++) win[sdst[q]] = r[q];
+    };
+    const int xoff_u = own ? kf * wpitch + tf : 0;                     // this lane's tap inside a window (update layout)
     // taps after block kb:  w += sum_l c_l conj(x_l);  c_l is zero for the steps past TrSyms of a partial last block
     auto update = [&](int kb) {
-        const int64_t s0 = (int64_t)kb * LA_B;
-        const Cx<R> *pl = xl + s0 * os_;                               // x_l[f_lane] = pl[(l - s0) * os]
-        const bool full = s0 + LA_B <= TrSyms;
-        for (int jb = 0; jb < LA_B; jb += LA_HB) {
-            Cx<R> x[LA_HB];
-            if (full) {
-                const Cx<R> *pb = pl + jb * os_;
-#pragma unroll
-                for (int u = 0; u < LA_HB; u++) x[u] = ldg(pb + u * os_);
-            } else {
-#pragma unroll
-                for (int u = 0; u < LA_HB; u++) {
-                    int64_t l = s0 + jb + u;
-                    if (l > TrSyms - 1) l = TrSyms - 1;
-                    x[u] = ldg(xl + l * os_);
-                }
+        const Cx<R> *xw = win_u + xoff_u;
+        const Cx<R> *cb = lds.cbuf[kb & 1];
+        if (os_ == 2) {                                                // the common case: immediate ds_read offsets
+#pragma unroll 32
+            for (int j = 0; j < LA_B; j++) {
+                const Cx<R> c = cb[j];
+                const Cx<R> x = xw[j * 2];
+                w.re = fma_(c.re, x.re, fma_(c.im, x.im, w.re));
+                w.im = fma_(c.im, x.re, fma_(-c.re, x.im, w.im));
             }
-#pragma unroll
-            for (int u = 0; u < LA_HB; u++) {
-                const Cx<R> c = lds.cbuf[kb & 1][jb + u];
-                w.re = fma_(c.re, x[u].re, fma_(c.im, x[u].im, w.re));
-                w.im = fma_(c.im, x[u].re, fma_(-c.re, x[u].im, w.im));
+        } else {
+#pragma unroll 8
+            for (int j = 0; j < LA_B; j++) {
+                const Cx<R> c = cb[j];
+                const Cx<R> x = xw[j * os_];
+                w.re = fma_(c.re, x.re, fma_(c.im, x.im, w.re));
+                w.im = fma_(c.im, x.re, fma_(-c.re, x.im, w.im));
             }
         }
         if (!own) w = Cx<R>{0, 0};
     };
+    // prior outputs of block kb from the current taps: lane <-> step kb*64 + lane
+    auto prior = [&](int kb) {
+        lds.wbuf[h][lane] = w;                                         // same wave writes and reads: LDS keeps order;
+        const bool live = (int64_t)kb * LA_B + lane < TrSyms;          // lanes >= nf hold w = 0
+        const Cx<R> *xs = win_p + lane * os_;
+        Cx<R> acc{0, 0};
+        int k2 = f0 / a.ntaps, t2 = f0 - k2 * a.ntaps;
+        int off = k2 * wpitch + t2;                                    // wave-uniform window offset of tap f0 + f
+        for (int f = 0; f < nf; f++) {
+            const Cx<R> wv = lds.wbuf[h][f];
+            const Cx<R> x = xs[off];
+            acc.re = fma_(x.re, wv.re, fma_(-x.im, wv.im, acc.re));
+            acc.im = fma_(x.re, wv.im, fma_(x.im, wv.re, acc.im));
+            off++;
+            if (++t2 == a.ntaps) { t2 = 0; off += wpitch - a.ntaps; }
+        }
+        lds.qbuf[h][kb & 1][lane] = live ? acc : Cx<R>{0, 0};
+    };
 
+    stage_load(sp, 0);
+    stage_store(sp, win_p);
     prior(0);
     __syncthreads();                                                   // barrier 0
+    unsigned long long t_wait = 0, t_upd = 0, t_pri = 0, t_mark = __builtin_readcyclecounter();
     for (int k = 0; k < nblk; k++) {
-        if (k >= 1) update(k - 1);                                     // -> W_k
-        if (k + 1 < nblk) prior(k + 1);                                // Q_{k+1} = W_k . x
+#ifndef LA_SKIP_HELPER
+        if (k >= 1) stage_load(su, k - 1);                             // both windows' loads go out first ...
+        if (k + 1 < nblk) stage_load(sp, k + 1);
+        if (k >= 1) { stage_store(su, win_u); update(k - 1); }         // ... -> W_k
+        if (a.prof) { const unsigned long long t = __builtin_readcyclecounter(); t_upd += t - t_mark; t_mark = t; }
+        if (k + 1 < nblk) { stage_store(sp, win_p); prior(k + 1); }    // Q_{k+1} = W_k . x
+        if (a.prof) { const unsigned long long t = __builtin_readcyclecounter(); t_pri += t - t_mark; t_mark = t; }
+#endif
         __syncthreads();                                               // barrier k+1
+        if (a.prof) { const unsigned long long t = __builtin_readcyclecounter(); t_wait += t - t_mark; t_mark = t; }
     }
+    if (a.prof && blockIdx.x == 0 && lane == 0) { a.prof[4 * wave] = t_upd; a.prof[4 * wave + 1] = t_pri; a.prof[4 * wave + 2] = t_wait; }
+    stage_load(su, nblk - 1);
+    stage_store(su, win_u);
     update(nblk - 1);                                                  // taps at the end of the sweep
     if (own) stg(wrow + fl, w);
 }
@@ -352,10 +405,11 @@ template <typename R> int gram_build(const void *E, int nmodes, int64_t L, int o
 }
 
 // can the look-ahead form run this configuration?
-inline bool la_supported(int method, int adaptive, int nmodes, int ntaps, int64_t TrSyms, int64_t nsy)
+inline bool la_supported(int method, int adaptive, int nmodes, int ntaps, int os, int64_t TrSyms, int64_t nsy)
 {
     if (adaptive || TrSyms < 2 * LA_B) return false;
-    if ((nmodes * ntaps + LA_NH - 1) / LA_NH > 64) return false;
+    if (nmodes * (((LA_B - 1) * os + ntaps + 1) & ~1) > 8 * 64) return false;      // helper window: 8 staging registers per lane
+    if ((nmodes * ntaps + LA_NH - 1) / LA_NH > LA_MAXSLICE) return false;
     switch (method) {
     case QH_M_CMA: case QH_M_SGNCMA: case QH_M_CMA2: case QH_M_MCMA: return true;
     case QH_M_RDE: case QH_M_MRDE: return nsy - (nsy + 1) / 2 >= 1 && nsy - (nsy + 1) / 2 <= LA_MAXPART;
@@ -363,10 +417,17 @@ inline bool la_supported(int method, int adaptive, int nmodes, int ntaps, int64_
     }
 }
 
+template <typename R> static size_t la_lds_bytes(const LaArgs<R> &a)
+{
+    const int wpitch = ((LA_B - 1) * a.os + a.ntaps + 1) & ~1;
+    return sizeof(LaLds<R>) + (size_t)LA_NH * 2 * (a.nmodes * wpitch + 2) * sizeof(Cx<R>);
+}
+
 template <typename R, int METHOD> static int launch_la_parts(const LaArgs<R> &a, int npart)
 {
     dim3 grid(a.nsel), block(64 * (1 + LA_NH));
-#define QH_LA_NP(N) case N: hipLaunchKernelGGL((train_la_kernel<R, METHOD, N>), grid, block, 0, g_stream, a); break;
+    const size_t lds = la_lds_bytes(a);
+#define QH_LA_NP(N) case N: hipLaunchKernelGGL((train_la_kernel<R, METHOD, N>), grid, block, lds, g_stream, a); break;
     switch (npart) {
         QH_LA_NP(1) QH_LA_NP(2) QH_LA_NP(3) QH_LA_NP(4) QH_LA_NP(5) QH_LA_NP(6) QH_LA_NP(7) QH_LA_NP(8)
     default: set_error("look-ahead trainer: unsupported partition count"); return QH_ERR_ARG;
@@ -379,11 +440,12 @@ template <typename R> int launch_la(const LaArgs<R> &a)
 {
     dim3 grid(a.nsel), block(64 * (1 + LA_NH));
     const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
+    const size_t lds = la_lds_bytes(a);
     int rc = QH_OK;
     switch (a.method) {
-    case QH_M_CMA: case QH_M_SGNCMA: hipLaunchKernelGGL((train_la_kernel<R, QH_M_CMA, 0>), grid, block, 0, g_stream, a); break;
-    case QH_M_CMA2: hipLaunchKernelGGL((train_la_kernel<R, QH_M_CMA2, 0>), grid, block, 0, g_stream, a); break;
-    case QH_M_MCMA: hipLaunchKernelGGL((train_la_kernel<R, QH_M_MCMA, 0>), grid, block, 0, g_stream, a); break;
+    case QH_M_CMA: case QH_M_SGNCMA: hipLaunchKernelGGL((train_la_kernel<R, QH_M_CMA, 0>), grid, block, lds, g_stream, a); break;
+    case QH_M_CMA2: hipLaunchKernelGGL((train_la_kernel<R, QH_M_CMA2, 0>), grid, block, lds, g_stream, a); break;
+    case QH_M_MCMA: hipLaunchKernelGGL((train_la_kernel<R, QH_M_MCMA, 0>), grid, block, lds, g_stream, a); break;
     case QH_M_RDE: rc = launch_la_parts<R, QH_M_RDE>(a, npart); break;
     case QH_M_MRDE: rc = launch_la_parts<R, QH_M_MRDE>(a, npart); break;
     default: return QH_ERR_METHOD;
