@@ -197,8 +197,19 @@ def main():
     stage_bytes += [rx.N * bps_b["apply"], rx.N * bps_b["bps"]]
     dom = int(np.argmax(stage_ms))
     achieved = stage_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9
+    # HBM bytes per launch of the dominant kernel from the committed PMC pass of the same workload (scripts/gpu_pmc.sh);
+    # counters need their own rocprofv3 run, so they cannot be collected inside this process
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)))
+        if args.train_mode == "exact" and args.nsym is None and 1 <= dom <= rx.nstage:
+            mid = _lib.METHOD_ID[cfg["methods"][dom - 1]]
+            kname = [k for k in pmc["kernels"] if k.startswith("qh::train_la_kernel<float, %d," % mid)]
+            traffic = pmc["kernels"][kname[0]]["hbm_bytes"] if kname else None
+    except (OSError, KeyError, ValueError, IndexError):
+        traffic = None
     roofline = dict(bound="hbm", kernel=stage_names[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, algorithmic_bytes=int(stage_bytes[dom]),
                     note=("exact sequential LMS chain: single-wave dependent-issue bound, 1 wave per output mode (DESIGN.md)"
                           if args.train_mode == "exact" and 1 <= dom <= rx.nstage else "see DESIGN.md"))
 

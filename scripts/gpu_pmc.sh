@@ -1,0 +1,12 @@
+#!/bin/bash
+# HBM traffic counters of one C3 pass (separate --pmc passes, no tracing domains besides the kernel trace).
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+cd /tmp
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --kernel-trace --pmc $C -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o c3 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
+  echo "$C rc=$?"
+done
+cd $GRAFT_REPO_ROOT
+python scripts/rocpd_pmc.py gpurun_out/pmc_FETCH_SIZE/c3_results.db gpurun_out/pmc_WRITE_SIZE/c3_results.db | tee gpurun_out/pmc_summary.txt
