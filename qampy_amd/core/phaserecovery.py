@@ -1,7 +1,7 @@
 """
-Host layer of blind-phase-search carrier recovery, mirror of ``qampy.core.phaserecovery.bps``
-(qampy/core/phaserecovery.py:93-159): test-angle grid, per-mode index search on the GPU, ``np.unwrap`` of the interior
-and de-rotation.  The index search and the angle gather are the HIP kernels of :mod:`.hip_dsp`.
+Host layer of blind-phase-search carrier recovery, mirror of ``qampy.core.phaserecovery.bps`` (qampy/core/phaserecovery.py:
+93-159) and ``bps_twostage`` (:222-288): test-angle grid, per-mode index search on the GPU, ``np.unwrap`` and de-rotation.
+The index search (one grid or a per-symbol grid) and the angle gather are the HIP kernels of :mod:`.hip_dsp`.
 """
 import numpy as np
 
@@ -37,3 +37,32 @@ def bps(E, Mtestangles, symbols, N, method="pyt", **kwargs):
     if E.ndim == 1:
         return (Ew * np.exp(1.j * ph)).flatten(), ph.flatten()
     return Ew * np.exp(1.j * ph), ph
+
+
+def bps_twostage(E, Mtestangles, symbols, N, B=4, method="pyt", **kwargs):
+    """
+    Two-stage blind phase search (Zhuge et al., OFC 2011), same contract as qampy/core/phaserecovery.py:222-288: a
+    coarse search over ``Mtestangles`` angles, then ``B`` angles around each symbol's coarse estimate (a per-symbol
+    ``(L, B)`` grid, the ``p == L`` branch of the kernel).  Returns ``(Eout, ph)``; the whole phase track is unwrapped.
+    """
+    if method.lower() not in ("pyt", "hip"):
+        raise ValueError("Method needs to be 'pyt' or 'hip' (the py/pyx/af back-ends of the reference are not provided)")
+    rdt = E.real.dtype
+    angles = np.linspace(-np.pi / 4, np.pi / 4, Mtestangles, endpoint=False, dtype=rdt).reshape(1, -1)
+    Ew = np.atleast_2d(E)
+    symbols = np.asarray(symbols).astype(E.dtype, copy=False)
+    ph_out = []
+    for i in range(Ew.shape[0]):
+        Ei = np.ascontiguousarray(np.asarray(Ew[i]))
+        idx = _bps_idx_hip(Ei, angles, symbols, N)
+        ph = select_angles(np.copy(angles), idx)
+        b = np.linspace(-B / 2, B / 2, B)
+        phn = (ph[:, np.newaxis] + b[np.newaxis, :] / (B * Mtestangles) * np.pi / 2).astype(rdt)
+        idx2 = _bps_idx_hip(Ei, phn, symbols, N)
+        phf = select_angles(np.copy(phn), idx2)
+        ph_out.append(np.unwrap(phf * 4, discont=np.pi * 4 / 4) / 4)
+    ph_out = np.asarray(ph_out, dtype=rdt)
+    En = Ew * np.exp(1.j * ph_out)
+    if E.ndim == 1:
+        return En.flatten(), ph_out.flatten()
+    return En, ph_out

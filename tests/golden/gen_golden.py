@@ -292,6 +292,40 @@ def gen_bps():
     return cases
 
 
+# ------------------------------------------------------------------------------------------------ bps_twostage (row f.1)
+def gen_twostage():
+    """Two-stage BPS (qampy/core/phaserecovery.py:222-288) through the basic wrapper qampy/phaserec.py:24-60."""
+    arr = {}
+    cases = []
+    rng = np.random.default_rng(4242)
+    t0 = time.time()
+    for (M, A, N, B, L) in ((16, 16, 10, 4, 900), (64, 32, 15, 4, 700), (4, 8, 8, 6, 600)):
+        alphabet = ref_signals.SignalQAMGrayCoded(M, 8).coded_symbols
+        nm = 2
+        tx = alphabet[rng.integers(0, M, size=(nm, L))]
+        ph = np.cumsum(rng.normal(scale=np.sqrt(2 * np.pi * 50e3 / 20e9), size=(nm, L)), axis=1) - 0.25
+        snr = {4: 14, 16: 22, 64: 28}[M]
+        noise = (rng.standard_normal((nm, L)) + 1j * rng.standard_normal((nm, L))) * 10 ** (-snr / 20) / np.sqrt(2)
+        E128 = (tx + noise) * np.exp(1j * ph)
+        base = "ts_M%d_A%d_N%d_B%d" % (M, A, N, B)
+        arr[base + "__E"] = E128
+        arr[base + "__alphabet"] = alphabet
+        for dn in ("c128", "c64"):
+            ct = CT[dn]
+            sig = SignalQAM(E128.astype(ct), M, coded_symbols=alphabet.astype(ct))
+            Eout, phout = ref_basic_ph.bps_twostage(sig, A, N, B=B)
+            assert type(Eout) is SignalQAM, type(Eout)
+            arr["%s_%s__Eout" % (base, dn)] = np.asarray(Eout)
+            arr["%s_%s__ph" % (base, dn)] = np.asarray(phout)
+            e1, p1 = ref_core_ph.bps_twostage(E128[0].astype(ct), A, alphabet.astype(ct), N, B=B)
+            arr["%s_%s__Eout1d" % (base, dn)] = np.asarray(e1)
+            arr["%s_%s__ph1d" % (base, dn)] = np.asarray(p1)
+            cases.append(dict(name="%s_%s" % (base, dn), base=base, M=M, A=A, N=N, B=B, L=L, dtype=dn))
+    print("twostage cases: %.1f s" % (time.time() - t0))
+    save("twostage.npz", arr)
+    return cases
+
+
 # ------------------------------------------------------------------------------------------------ make_decision (row I)
 def gen_decision():
     arr = {}
@@ -381,6 +415,7 @@ def main():
     cases["train"] = gen_train(inp)
     cases["apply"] = gen_apply(inp)
     cases["bps"] = gen_bps()
+    cases["twostage"] = gen_twostage()
     gen_decision()
     cases["e2e"] = gen_e2e(inp, meta)
     cases["versions"] = dict(numpy=np.__version__, python=sys.version.split()[0], reference="QAMpy v0.5.1 (/root/reference)")

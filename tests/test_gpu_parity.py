@@ -135,6 +135,22 @@ def test_bps_host_layer_on_gpu(golden, case):
     np.testing.assert_allclose(ph, ref, atol=np.pi / 2 / case["A"] * 1.01)
 
 
+@pytest.mark.parametrize("case", golden_cases("twostage"), ids=lambda c: c["name"])
+def test_bps_twostage_on_gpu(golden, case):
+    g = golden["twostage"]
+    dn = case["dtype"]
+    E = g[case["base"] + "__E"].astype(CT[dn])
+    sig = SignalQAM(E, case["M"], coded_symbols=g[case["base"] + "__alphabet"].astype(CT[dn]))
+    Eout, ph = qampy_amd.phaserec.bps_twostage(sig, case["A"], case["N"], B=case["B"])
+    assert type(Eout) is SignalQAM and ph.dtype == RT[dn]
+    ref = g[case["name"] + "__ph"]
+    # a flipped near-tie in either stage moves single symbols by at most one coarse step; allow a handful
+    step = np.pi / 2 / case["A"]
+    bad = np.abs(ph - ref) > 1e-6
+    assert bad.mean() < (2e-3 if dn == "c128" else 1e-2)
+    assert np.all(np.abs(np.angle(np.exp(4j * (ph - ref))) / 4) <= 1.01 * step)
+
+
 # ------------------------------------------------------------------------------------------------ vs oracle, seeded, larger
 @pytest.mark.parametrize("method,M,ntaps,adaptive", [("cma", 64, 41, False), ("mrde", 64, 41, False), ("mcma", 16, 21, True),
                                                      ("sbd", 16, 21, True), ("rde", 16, 13, False), ("dd", 64, 17, False),

@@ -178,6 +178,19 @@ def test_bps_host_layer(golden, oracle_kernels, case):
         assert e1.ndim == 1 and np.array_equal(e1, g[case["name"] + "__Eout1d"]) and np.array_equal(p1, g[case["name"] + "__ph1d"])
 
 
+@pytest.mark.parametrize("case", __import__("conftest").golden_cases("twostage"), ids=lambda c: c["name"])
+def test_bps_twostage_host_layer(golden, oracle_kernels, case):
+    g = golden["twostage"]
+    dn = case["dtype"]
+    E = g[case["base"] + "__E"].astype(CT[dn])
+    sig = SignalQAM(E, case["M"], coded_symbols=g[case["base"] + "__alphabet"].astype(CT[dn]))
+    Eout, ph = qampy_amd.phaserec.bps_twostage(sig, case["A"], case["N"], B=case["B"])
+    assert type(Eout) is SignalQAM and Eout.dtype == CT[dn] and ph.dtype == RT[dn]
+    assert np.array_equal(ph, g[case["name"] + "__ph"]) and np.array_equal(np.asarray(Eout), g[case["name"] + "__Eout"])
+    e1, p1 = core_ph.bps_twostage(E[0], case["A"], sig.coded_symbols, case["N"], B=case["B"])
+    assert e1.ndim == 1 and np.array_equal(p1, g[case["name"] + "__ph1d"]) and np.array_equal(e1, g[case["name"] + "__Eout1d"])
+
+
 def test_bps_rejects_unknown_backend():
     with pytest.raises(ValueError):
         core_ph.bps(np.zeros(8, np.complex64), 4, np.ones(4, np.complex64), 2, method="af")
