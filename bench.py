@@ -53,11 +53,12 @@ def make_input(cfg, nsym, seed):
                               linewidth=cfg["linewidth"], fb=20e9, beta=0.1, seed=seed, dtype=np.complex64)
 
 
-def make_receiver(cfg, sig, segments=0, prefix=0):
+def make_receiver(cfg, sig, segments=0, prefix=0, prefix_mu=None):
     from qampy_amd.pipeline import ResidentReceiver
     return ResidentReceiver(2, sig.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"],
                             adaptive_stepsize=cfg["adaptive"], TrSyms=(None,) * len(cfg["methods"]), Mtestangles=cfg["A"],
-                            Nbps=cfg["Nbps"], dtype=np.complex64, alphabet=sig.coded_symbols, segments=segments, prefix=prefix)
+                            Nbps=cfg["Nbps"], dtype=np.complex64, alphabet=sig.coded_symbols, segments=segments, prefix=prefix,
+                            prefix_mu=prefix_mu)
 
 
 def timed_steps(rx, steps, warmup, barrier_sync):

@@ -101,15 +101,16 @@ int qh_train_equaliser_c128_gram_dev(const void *E, int nmodes, int64_t L, int64
                                      int64_t nsy, int method, void *err, int zero_err, const void *gram);
 
 /* Segment-parallel continuation ("tier B", NOT the reference's semantics - DESIGN.md §tiers): the first `prefix` steps
- * are trained sequentially, then each sweep is cut into `nseg` contiguous segments that are trained concurrently, every
- * segment starting from the taps the previous phase ended with; err is complete, the returned taps are those of the
- * last segment.  Opt-in, never used by the drop-in entry points above. */
+ * are trained sequentially (with step size `prefix_mu` if it is > 0: "gear shifting" while the taps converge), then each
+ * sweep is cut into `nseg` contiguous segments that are trained concurrently, every segment starting from the taps the
+ * previous phase ended with; err is complete, the returned taps are those of the last segment.  Only meaningful when the
+ * taps have converged by the end of the prefix.  Opt-in, never used by the drop-in entry points above. */
 int qh_train_equaliser_c64_seg_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
                                    void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
-                                   int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix);
+                                   int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix, double prefix_mu);
 int qh_train_equaliser_c128_seg_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev,
                                     void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
-                                    int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix);
+                                    int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix, double prefix_mu);
 
 /* ---- train_equaliser_realvalued: same layout with real arrays, update without conjugate ---------------------- */
 int qh_train_equaliser_real_f32(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu, void *wx,

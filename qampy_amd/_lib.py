@@ -55,8 +55,8 @@ SIGNATURES = {
     "qh_train_equaliser_c128": _train_sig(_pd),
     "qh_train_equaliser_c64_dev": _train_sig(_pf, dev=True),
     "qh_train_equaliser_c128_dev": _train_sig(_pd, dev=True),
-    "qh_train_equaliser_c64_seg_dev": _train_sig(_pf, dev=True) + [_i, _i64],
-    "qh_train_equaliser_c128_seg_dev": _train_sig(_pd, dev=True) + [_i, _i64],
+    "qh_train_equaliser_c64_seg_dev": _train_sig(_pf, dev=True) + [_i, _i64, C.c_double],
+    "qh_train_equaliser_c128_seg_dev": _train_sig(_pd, dev=True) + [_i, _i64, C.c_double],
     "qh_gram_build_c64_dev": [_vp, _i, _i64, _i, _i, _i64, C.POINTER(_vp)],
     "qh_gram_build_c128_dev": [_vp, _i, _i64, _i, _i, _i64, C.POINTER(_vp)],
     "qh_train_equaliser_c64_gram_dev": _train_sig(_pf, dev=True) + [_vp],

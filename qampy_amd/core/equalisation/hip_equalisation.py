@@ -144,7 +144,7 @@ def gram_build_dev(E, os, ntaps, TrSyms):
 
 
 def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method, err, zero_err=False, segments=0,
-                        prefix=0, gram=None):
+                        prefix=0, gram=None, prefix_mu=0.):
     """
     Same as :func:`train_equaliser` with every array (and the scalar ``mu``, a 1-element DeviceArray) already in HBM.
     Only enqueues work on the library stream.
@@ -163,7 +163,7 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
             int(bool(adaptive)), symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)))
     name = "qh_train_equaliser_c" + ("64" if suf == "32" else "128")
     if segments and segments > 0:
-        _lib.call(name + "_seg_dev", *args, int(segments), int(prefix))
+        _lib.call(name + "_seg_dev", *args, int(segments), int(prefix), float(prefix_mu or 0.))
     elif gram:
         _lib.call(name + "_gram_dev", *args, gram)
     else:

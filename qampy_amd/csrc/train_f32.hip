@@ -22,9 +22,9 @@ int qh_train_equaliser_real_f32(const void *E, int nmodes, int64_t L, int64_t Tr
 }
 int qh_train_equaliser_c64_seg_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
                                    void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
-                                   int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix)
+                                   int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix, double prefix_mu)
 {
-    return qh::train_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, nseg, prefix);
+    return qh::train_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, nseg, prefix, nullptr, prefix_mu);
 }
 int qh_gram_build_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
 {

@@ -424,7 +424,7 @@ template <typename R> static int launch_any(const TrainArgs<R> &a)
 template <typename R>
 int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu_dev, void *wx, int ntaps,
               const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy, int method, void *err,
-              int zero_err, int nseg = 0, int64_t prefix = 0, const void *gram = nullptr)
+              int zero_err, int nseg = 0, int64_t prefix = 0, const void *gram = nullptr, double prefix_mu = 0)
 {
     int rc = ensure_init();
     if (rc) return rc;
@@ -493,6 +493,14 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         if (it == 0 && prefix > 0) {                         // sequential convergence prefix
             TrainArgs<R> p = a;       // one "segment" [0, prefix) per mode == the exact chain on the prefix
             p.nseg = 1; p.seg_begin = 0; p.seg_len = prefix; p.seg_iter = 0; p.wx_out = (Cx<R> *)wtmp;
+            if (prefix_mu > 0) {      // "gear shifting": a larger step size while the taps converge
+                void *pm = nullptr;
+                if ((rc = scratch(6, sizeof(R), &pm))) return rc;
+                const R v = (R)prefix_mu;
+                QH_HIP(hipMemcpyAsync(pm, &v, sizeof(R), hipMemcpyHostToDevice, g_stream));
+                QH_HIP(hipStreamSynchronize(g_stream));     // `v` lives on this stack frame
+                p.mu = (R *)pm;
+            }
             QH_HIP(hipMemcpyAsync(wtmp, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
             if ((rc = launch_any<R>(p))) return rc;
             QH_HIP(hipMemcpyAsync(wx, wtmp, wbytes, hipMemcpyDeviceToDevice, g_stream));
