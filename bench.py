@@ -153,13 +153,15 @@ def main():
     nsym = args.nsym or cfg["nsym"]
 
     import torch                                     # plumbing only: barriers / reductions / device sync
+    from qampy_amd import _lib
+    ndev = max(_lib.device_count(), 1)
+    dev = local_rank % ndev                          # a launcher may expose a single device per rank
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    from qampy_amd import _lib
-    _lib.init(local_rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+    _lib.init(dev)
 
     def barrier_sync():
         _lib.sync()
