@@ -112,6 +112,17 @@ int qh_train_equaliser_c128_seg_dev(const void *E, int nmodes, int64_t L, int64_
                                     void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
                                     int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix, double prefix_mu);
 
+/* Batch of independent equaliser runs on `nwin` windows E[:, win_start[v] : win_start[v] + win_len] of one capture, all from
+ * the same initial taps wx0 and step size mu - what the frame synchronisation of the pilot receiver does in a Python loop
+ * (qampy/core/pilotbased_receiver.py:395-400).  Results are those of nwin separate qh_train_equaliser_* calls; the windows
+ * run concurrently (one wavefront each).  wx_out (nwin, nmodes, nmodes, ntaps), err (nwin, nmodes, TrSyms*Niter), mu_out (nwin). */
+int qh_train_equaliser_windows_c64(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len,
+                                   int64_t TrSyms, int Niter, int os, float mu, const void *wx0, int ntaps, const int64_t *modes, int nsel,
+                                   int adaptive, const void *symbols, int64_t nsy, int method, void *wx_out, void *err, float *mu_out);
+int qh_train_equaliser_windows_c128(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len,
+                                    int64_t TrSyms, int Niter, int os, double mu, const void *wx0, int ntaps, const int64_t *modes, int nsel,
+                                    int adaptive, const void *symbols, int64_t nsy, int method, void *wx_out, void *err, double *mu_out);
+
 /* ---- train_equaliser_realvalued: same layout with real arrays, update without conjugate ---------------------- */
 int qh_train_equaliser_real_f32(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu, void *wx,
                                 int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,

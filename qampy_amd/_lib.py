@@ -61,6 +61,8 @@ SIGNATURES = {
     "qh_gram_build_c128_dev": [_vp, _i, _i64, _i, _i, _i64, C.POINTER(_vp)],
     "qh_train_equaliser_c64_gram_dev": _train_sig(_pf, dev=True) + [_vp],
     "qh_train_equaliser_c128_gram_dev": _train_sig(_pd, dev=True) + [_vp],
+    "qh_train_equaliser_windows_c64": [_vp, _i, _i64, _vp, _i, _i64, _i64, _i, _i, C.c_float, _vp, _i, _vp, _i, _i, _vp, _i64, _i, _vp, _vp, _vp],
+    "qh_train_equaliser_windows_c128": [_vp, _i, _i64, _vp, _i, _i64, _i64, _i, _i, C.c_double, _vp, _i, _vp, _i, _i, _vp, _i64, _i, _vp, _vp, _vp],
     "qh_train_equaliser_real_f32": _train_sig(_pf),
     "qh_train_equaliser_real_f64": _train_sig(_pd),
     "qh_apply_filter_c64": _APPLY, "qh_apply_filter_c128": _APPLY, "qh_apply_filter_f32": _APPLY, "qh_apply_filter_f64": _APPLY,

@@ -191,3 +191,27 @@ def dual_mode_equalisation(E, os, mu, M, wxy=None, Ntaps=None, TrSyms=(None, Non
     if apply:
         return apply_filter(E, os, wxy2, modes=modes), wxy2, (err1, err2)
     return wxy2, (err1, err2)
+
+
+def equalise_signal_windows(E, os, mu, M, starts, win_len, Ntaps=None, TrSyms=None, Niter=1, method="mcma",
+                            adaptive_stepsize=False, symbols=None, modes=None, **kwargs):
+    """
+    ``equalise_signal(E[:, s:s + win_len], os, mu, M, Ntaps=Ntaps, ...)`` for every ``s`` in ``starts`` in ONE kernel launch
+    (all windows are independent and start from centre-spike taps).  Returns ``(wxy (nwin, nmodes, nmodes, Ntaps),
+    err (nwin, nmodes, TrSyms*Niter))``.  MI355X-native replacement of the Python loop of the frame synchronisation
+    (qampy/core/pilotbased_receiver.py:395-400): a window is one sequential chain, so hundreds of them fill the chip.
+    """
+    method = method.lower()
+    if method in REAL_VALUED or method in DATA_AIDED:
+        raise ValueError("window batches support the complex blind / decision-directed methods, not %s" % method)
+    E = np.array(np.asarray(E), copy=True, order="C", subok=False)
+    mu = E.real.dtype.type(mu)
+    nmodes = E.shape[0]
+    modes = np.arange(nmodes) if modes is None else np.atleast_1d(modes)
+    wxy0 = _init_taps(Ntaps, nmodes, nmodes, E.dtype)
+    if TrSyms is None:
+        TrSyms = _cal_training_symbol_len(os, Ntaps, win_len)
+    symbols = _reshape_symbols(symbols, method, M, E.dtype, nmodes)
+    err, wxy, _ = _kernels.train_equaliser_windows(E, starts, win_len, TrSyms, Niter, os, mu, wxy0, modes, adaptive_stepsize,
+                                                   symbols.copy(), method)
+    return wxy, err

@@ -58,6 +58,34 @@ def train_equaliser(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, meth
     return err, wx, rt(mu_c.value)
 
 
+def train_equaliser_windows(E, starts, win_len, TrSyms, Niter, os, mu, wx0, modes, adaptive, symbols, method):
+    """
+    Independent equaliser runs on the windows ``E[:, s : s + win_len]`` for ``s`` in ``starts``, all from the taps ``wx0`` and
+    the step size ``mu`` - one launch instead of the reference's Python loop over ``equalise_signal`` calls
+    (qampy/core/pilotbased_receiver.py:395-400).  Returns ``(err (nwin, nmodes, TrSyms*Niter), wx (nwin, nmodes, nmodes,
+    ntaps), mu (nwin,))``, each window's result being what :func:`train_equaliser` returns for that slice.
+    """
+    if method not in _lib.METHOD_ID:
+        raise ValueError("Unknown method %s" % method)
+    suf, rt, ct = _lib.suffix(E.dtype)
+    _need(E, ct, "E"); _need(wx0, ct, "wx0")
+    symbols = np.ascontiguousarray(symbols)
+    _need(symbols, ct, "symbols")
+    nmodes, L = E.shape
+    ntaps = wx0.shape[-1]
+    modes = _as_modes(modes, nmodes)
+    starts = np.ascontiguousarray(starts, dtype=np.int64)
+    nwin = starts.size
+    err = np.zeros((nwin, nmodes, int(TrSyms) * int(Niter)), dtype=ct)
+    wx = np.zeros((nwin,) + wx0.shape, dtype=ct)
+    mu_out = np.zeros(nwin, dtype=rt)
+    _lib.call("qh_train_equaliser_windows_c" + ("64" if suf == "32" else "128"), _lib.ptr(E), nmodes, L, _lib.ptr(starts), nwin,
+              int(win_len), int(TrSyms), int(Niter), int(os), rt(mu), _lib.ptr(wx0), ntaps, _lib.ptr(modes), modes.size,
+              int(bool(adaptive)), _lib.ptr(symbols), symbols.shape[1], _lib.METHOD_ID[method], _lib.ptr(wx), _lib.ptr(err),
+              _lib.ptr(mu_out))
+    return err, wx, mu_out
+
+
 def train_equaliser_realvalued(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method):
     """Real-valued trainer (pythran_equalisation.py:78-108); ``method`` without the ``_real`` suffix."""
     if method not in _lib.REAL_METHOD_ID:

@@ -66,3 +66,33 @@ def bps_twostage(E, Mtestangles, symbols, N, B=4, method="pyt", **kwargs):
     if E.ndim == 1:
         return En.flatten(), ph_out.flatten()
     return En, ph_out
+
+
+def find_freq_offset(sig, os=1, average_over_modes=True, fft_size=2 ** 16):
+    """
+    Blind frequency-offset estimate from the spectral peak of the signal raised to the 4th power, in units of the symbol
+    rate (qampy/core/phaserecovery.py:385-433).  Host-side FFT (the pilot receiver calls it on a few thousand symbols).
+    """
+    if not ((np.log2(fft_size) % 2 == 0) | (np.log2(fft_size) % 2 == 1)):
+        fft_size = 2 ** (int(np.ceil(np.log2(fft_size))))
+    sig = np.atleast_2d(sig)
+    npols = sig.shape[0]
+    fvec = np.fft.fftfreq(fft_size, 1 / os) / 4
+    off = np.zeros([npols, 1])
+    for k in range(npols):
+        spec = np.abs(np.fft.fft(sig[k, :] ** 4, fft_size)) ** 2
+        off[k, 0] = fvec[np.argmax(np.abs(spec))]
+    if average_over_modes:
+        off = np.mean(off) * np.ones(off.shape)
+    return off
+
+
+def comp_freq_offset(sig, freq_offset, os=1):
+    """Remove a frequency offset given in units of the symbol rate (qampy/core/phaserecovery.py:435-473)."""
+    ndim = sig.ndim
+    sig = np.atleast_2d(sig)
+    out = np.zeros(sig.shape, dtype=sig.dtype)
+    t = np.arange(1, sig.shape[1] + 1, dtype=float)
+    for k in range(sig.shape[0]):
+        out[k, :] = sig[k, :] * np.exp(-1j * (2 * np.pi * t * freq_offset[k] / os))
+    return out.flatten() if ndim == 1 else out

@@ -36,4 +36,11 @@ int qh_train_equaliser_c128_gram_dev(const void *E, int nmodes, int64_t L, int64
 {
     return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, 0, 0, gram);
 }
+int qh_train_equaliser_windows_c128(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len,
+                                     int64_t TrSyms, int Niter, int os, double mu, const void *wx0, int ntaps, const int64_t *modes, int nsel,
+                                     int adaptive, const void *symbols, int64_t nsy, int method, void *wx_out, void *err, double *mu_out)
+{
+    return qh::train_windows_host<double>(E, nmodes, L, win_start, nwin, win_len, TrSyms, Niter, os, mu, wx0, ntaps, modes, nsel, adaptive,
+                                      symbols, nsy, method, wx_out, err, mu_out);
+}
 }

@@ -42,6 +42,14 @@ template <typename R> struct TrainArgs {
     int64_t seg_begin, seg_len;
     int nseg, seg_iter;
     Cx<R> *wx_out;
+    // batch of independent windows (frame synchronisation, qampy/core/pilotbased_receiver.py:395-400): blockIdx.y = window;
+    // window v trains on E[:, win_start[v] : win_start[v] + win_len] from the shared initial taps `wx` and step size `mu`
+    // and writes its own taps / error trace / final step size
+    const int64_t *win_start;
+    int64_t win_len;
+    int nwin;
+    R *win_mu;
+    int64_t e_off;          // sample offset of the chain's view into E (0 except for windows)
 };
 
 // ------------------------------------------------------------------------------------------------ error functions
@@ -246,7 +254,7 @@ __device__ __forceinline__ R run_chain(const TrainArgs<R> &a, const ChainLds<R> 
 
     // copy the samples of chunk c (steps i_begin + c*CH ...) into buffer (c & 1)
     auto stage = [&](int c) {
-        const int64_t s0 = (i_begin + (int64_t)c * CH) * os;
+        const int64_t s0 = a.e_off + (i_begin + (int64_t)c * CH) * os;
         int64_t span = L - s0;
         if (span > span_full + TR_SLACK * os) span = span_full + TR_SLACK * os;
         Cx<R> *dst = lds.buf + (c & 1) * bufsz;
@@ -363,6 +371,20 @@ __global__ void __launch_bounds__(64) train_kernel(TrainArgs<R> a, int CH, int p
     R mu = *a.mu;
     // adaptive: sequential semantics, ONE wave walks the modes in order and carries mu;
     // otherwise one workgroup (= one CU) per selected mode
+    if (a.nwin > 0) {
+        // batch of independent windows: one wave per window walks the selected modes (sequential semantics, mu carried)
+        TrainArgs<R> b = a;
+        const int v = blockIdx.y;
+        b.e_off = a.win_start[v];
+        b.L = a.L;                                      // row pitch; the staging clamp uses L - e_off - ...
+        b.err = a.err + (size_t)v * a.nmodes * a.TrSyms * a.Niter;
+        Cx<R> *wout = a.wx_out + (size_t)v * a.nmodes * a.nmodes * a.ntaps;
+        const int jb = a.adaptive ? 0 : blockIdx.x, je = a.adaptive ? a.nsel : blockIdx.x + 1;
+        for (int j = jb; j < je; j++)
+            mu = run_chain<R, TPL, METHOD>(b, lds, (int)a.modes[j], mu, lane, 0, a.TrSyms, 0, a.Niter, wout);
+        if (lane == 0 && (a.adaptive || blockIdx.x == 0)) a.win_mu[v] = mu;
+        return;
+    }
     if (a.nseg > 0) {
         // tier B: one workgroup per (mode, segment); every segment starts from the same taps and step size
         const int64_t b = a.seg_begin + (int64_t)blockIdx.y * a.seg_len;
@@ -386,7 +408,7 @@ __global__ void __launch_bounds__(64) train_kernel(TrainArgs<R> a, int CH, int p
 
 template <typename R, int TPL> static int launch_tpl(const TrainArgs<R> &a)
 {
-    dim3 grid(a.nseg > 0 ? a.nsel : (a.adaptive ? 1 : a.nsel), a.nseg > 0 ? a.nseg : 1), block(64);
+    dim3 grid(a.nseg > 0 ? a.nsel : (a.adaptive ? 1 : a.nsel), a.nwin > 0 ? a.nwin : (a.nseg > 0 ? a.nseg : 1)), block(64);
     // chunk length: as many steps as fit a 48 KiB double buffer (at most 512)
     int CH = 512;
     int pitch = 0;
@@ -445,6 +467,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
     a.nsel = nsel; a.adaptive = adaptive ? 1 : 0; a.method = method;
     for (int j = 0; j < 16; j++) a.modes[j] = j < nsel ? modes[j] : 0;
     a.nseg = 0; a.seg_begin = 0; a.seg_len = 0; a.seg_iter = 0; a.wx_out = nullptr;
+    a.win_start = nullptr; a.win_len = 0; a.nwin = 0; a.win_mu = nullptr; a.e_off = 0;
     if (nseg <= 0) {
         // exact semantics.  Blind methods with a fixed step run in the look-ahead form (train_la.h), everything else
         // (decision-directed, data-aided, adaptive step, tiny captures) in the direct form below.  Same results up to
@@ -515,6 +538,57 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         if ((rc = launch_any<R>(s))) return rc;
         QH_HIP(hipMemcpyAsync(wx, wtmp, wbytes, hipMemcpyDeviceToDevice, g_stream));
     }
+    return QH_OK;
+}
+
+// Batch of independent equaliser runs on windows of one capture (host pointers).  Equivalent to calling train_host once per
+// window with E[:, start : start + win_len], the same initial taps and step size; all windows run concurrently.
+//   wx0 (nmodes, nmodes, ntaps) in;  wx_out (nwin, nmodes, nmodes, ntaps), err (nwin, nmodes, TrSyms*Niter), mu_out (nwin) out
+template <typename R>
+int train_windows_host(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len, int64_t TrSyms,
+                       int Niter, int os, R mu, const void *wx0, int ntaps, const int64_t *modes, int nsel, int adaptive,
+                       const void *symbols, int64_t nsy, int method, void *wx_out, void *err, R *mu_out)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (method < 0 || method > QH_M_SBD_DATA) { set_error("unknown equaliser method id"); return QH_ERR_METHOD; }
+    QH_REQUIRE(nmodes >= 1 && L >= 1 && ntaps >= 1 && nsy >= 1 && TrSyms >= 0 && Niter >= 0 && os >= 1, "train_equaliser_windows: bad sizes");
+    QH_REQUIRE(nwin >= 1 && nwin <= 65535, "train_equaliser_windows: between 1 and 65535 windows");
+    QH_REQUIRE(nsel >= 1 && nsel <= 16, "train_equaliser_windows: between 1 and 16 modes can be selected");
+    QH_REQUIRE(TrSyms == 0 || (TrSyms - 1) * os + ntaps <= win_len, "train_equaliser_windows: window shorter than TrSyms*os + ntaps");
+    QH_REQUIRE(method != QH_M_SBD_DATA, "train_equaliser_windows: data-aided training is not supported on window batches");
+    for (int j = 0; j < nsel; j++) QH_REQUIRE(modes[j] >= 0 && modes[j] < nmodes, "train_equaliser_windows: mode number >= nmodes");
+    for (int v = 0; v < nwin; v++) QH_REQUIRE(win_start[v] >= 0 && win_start[v] + win_len <= L, "train_equaliser_windows: window outside the field");
+    const int ntot = nmodes * ntaps;
+    QH_REQUIRE(ntot <= 64 * 16, "train_equaliser_windows: more than 1024 taps per output mode are not supported");
+    const size_t cs = sizeof(Cx<R>);
+    const size_t wsz = (size_t)nmodes * ntot, esz = (size_t)nmodes * TrSyms * Niter;
+    DevBuf dE, dw, ds, dwo, de, dmu, dmo, dst;
+    if ((rc = dE.from_host(E, (size_t)nmodes * L * cs))) return rc;
+    if ((rc = dw.from_host(wx0, wsz * cs))) return rc;
+    if ((rc = ds.from_host(symbols, (size_t)nmodes * nsy * cs))) return rc;
+    if ((rc = dmu.from_host(&mu, sizeof(R)))) return rc;
+    if ((rc = dst.from_host(win_start, (size_t)nwin * sizeof(int64_t)))) return rc;
+    if ((rc = dwo.alloc((size_t)nwin * wsz * cs))) return rc;
+    if ((rc = de.alloc((size_t)nwin * esz * cs))) return rc;
+    if ((rc = dmo.alloc((size_t)nwin * sizeof(R)))) return rc;
+    QH_HIP(hipMemsetAsync(de.p, 0, de.n ? de.n : 1, g_stream));
+    for (int v = 0; v < nwin; v++)                       // every window starts from (and keeps, for unselected modes) the initial taps
+        QH_HIP(hipMemcpyAsync((char *)dwo.p + (size_t)v * wsz * cs, dw.p, wsz * cs, hipMemcpyDeviceToDevice, g_stream));
+    if (TrSyms > 0 && Niter > 0) {
+        TrainArgs<R> a;
+        a.E = (const Cx<R> *)dE.p; a.wx = (Cx<R> *)dw.p; a.symbols = (const Cx<R> *)ds.p; a.err = (Cx<R> *)de.p; a.mu = (R *)dmu.p;
+        a.L = L; a.TrSyms = TrSyms; a.nsy = nsy; a.nmodes = nmodes; a.ntaps = ntaps; a.Niter = Niter; a.os = os;
+        a.nsel = nsel; a.adaptive = adaptive ? 1 : 0; a.method = method;
+        for (int j = 0; j < 16; j++) a.modes[j] = j < nsel ? modes[j] : 0;
+        a.nseg = 0; a.seg_begin = 0; a.seg_len = 0; a.seg_iter = 0; a.wx_out = (Cx<R> *)dwo.p;
+        a.win_start = (const int64_t *)dst.p; a.win_len = win_len; a.nwin = nwin; a.win_mu = (R *)dmo.p; a.e_off = 0;
+        if ((rc = launch_any<R>(a))) return rc;
+    }
+    if ((rc = dwo.to_host(wx_out, dwo.n))) return rc;
+    if ((rc = de.to_host(err, de.n))) return rc;
+    if ((rc = dmo.to_host(mu_out, dmo.n))) return rc;
+    QH_HIP(hipStreamSynchronize(g_stream));
     return QH_OK;
 }
 

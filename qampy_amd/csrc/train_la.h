@@ -113,6 +113,21 @@ template <typename R, int N, bool IM> __device__ __forceinline__ R tab_lookup(R 
     }
 }
 
+// float variant of the look-up without compares: with h = (sq - part) * 2^60 (sign-exact, zero only at equality),
+// med3(r, code, h) = code if sq > part else r, because the codes are non-negative and non-decreasing.  The products for
+// the two axes come from ONE v_pk_fma, so a partition costs 3 instructions for both axes instead of 4.
+template <int N> __device__ __forceinline__ void tab_lookup_med3(float sqr, float sqi, float &rr, float &ri, const PartTab<float, N> &t)
+{
+    if constexpr (N > 0) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        constexpr float BIG = 1152921504606846976.0f;                 // 2^60
+        const v2f h = v2f{sqr, sqi} * BIG - v2f{t.part_re, t.part_im} * BIG;
+        rr = __builtin_amdgcn_fmed3f(rr, t.code_re, h.x);
+        ri = __builtin_amdgcn_fmed3f(ri, t.code_im, h.y);
+        tab_lookup_med3<N - 1>(sqr, sqi, rr, ri, t.next);
+    }
+}
+
 template <typename R, int NPART> struct LaConst {
     R mu, R_re, R_im, code0_re, code0_im;
     PartTab<R, NPART> tab;
@@ -149,7 +164,14 @@ __device__ __forceinline__ Cx<R> la_errfn(Cx<R> y, const LaConst<R, NPART> &k)
         e = yy * d;
     } else {   // QH_M_MRDE
         const v2 sq = yy * yy;
-        const v2 r = {tab_lookup<R, NPART, false>(sq.x, k.code0_re, k.tab), tab_lookup<R, NPART, true>(sq.y, k.code0_im, k.tab)};
+        v2 r;
+        if constexpr (sizeof(R) == 4) {
+            float rr = k.code0_re, ri = k.code0_im;
+            tab_lookup_med3<NPART>(sq.x, sq.y, rr, ri, k.tab);
+            r = v2{rr, ri};
+        } else {
+            r = v2{tab_lookup<R, NPART, false>(sq.x, k.code0_re, k.tab), tab_lookup<R, NPART, true>(sq.y, k.code0_im, k.tab)};
+        }
         v2 d = r - sq;
         if constexpr (SCALE) d = d * k.mu;
         e = d * yy;

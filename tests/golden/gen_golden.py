@@ -326,6 +326,76 @@ def gen_twostage():
     return cases
 
 
+# ------------------------------------------------------------------------------------------------ pilot receiver (row f.3)
+def gen_pilot():
+    """
+    Core pilot-based receiver (qampy/core/pilotbased_receiver.py) on plain arrays: frame_sync, coarse FOE compensation,
+    equalize_pilot_sequence, filter application to one frame, pilot_based_cpe_new.  The reference's signal classes and
+    impairment chain are used here only to PRODUCE the test capture; every array the functions see is stored.
+    """
+    from qampy.core import pilotbased_receiver as ref_pil
+    from qampy.core import ber_functions as ref_ber
+    from qampy.core import filter as ref_filter
+    from qampy import impairments as ref_imp
+    arr = {}
+    np.random.seed(20240928)
+    t0 = time.time()
+    frame_len, seq_len, ins_rat, M = 2 ** 12, 2 ** 8, 32, 64
+    sig = ref_signals.SignalWithPilots(M, frame_len, seq_len, ins_rat, nmodes=2, Mpilots=4, nframes=3, fb=24e9)
+    sig2 = sig.resample(sig.fb * 2, beta=0.1)
+    rx = ref_imp.simulate_transmission(sig2, snr=27, dgd=10e-12, freq_off=40e6, lwdth=50e3, roll_frame_sync=True,
+                                       modal_delay=(700, 500))
+    os_ = int(rx.os)
+    pilot_seq = np.asarray(sig.pilot_seq)
+    ph_pilots = np.asarray(sig.ph_pilots)
+    idx_pil = np.asarray(sig._idx_pil)
+    E = np.array(rx, dtype=np.complex128, copy=True)
+    arr.update(rx=E, pilot_seq=pilot_seq, ph_pilots=ph_pilots, idx_pil=idx_pil, frame_len=np.int64(frame_len), os=np.int64(os_),
+               tx_frame=np.asarray(sig)[:, :frame_len], alphabet=np.asarray(sig.symbols.coded_symbols), M=np.int64(M))
+    # --- helpers
+    arr["fso_x"] = pilot_seq[0]
+    arr["fso_y"] = np.roll(pilot_seq[0], 17)[:200] * 1j
+    ix, y2, ii, acm = ref_ber.find_sequence_offset_complex(arr["fso_x"], arr["fso_y"])
+    arr.update(fso_ix=np.int64(ix), fso_ii=np.int64(ii), fso_acm=np.float64(acm))
+    arr["mavg_in"] = np.random.randn(2, 50)
+    arr["mavg_out"] = ref_filter.moving_average(arr["mavg_in"], 5)
+    # --- frame sync (sync2frame defaults, qampy/signals.py:1725-1733)
+    shift, foe, order, wx1, ok = ref_pil.frame_sync(E, pilot_seq, os_, frame_len=frame_len, M_pilot=4, mu=5e-3, Ntaps=17,
+                                                    adaptive_stepsize=True, Niter=10, method="cma")
+    arr.update(fs_shift=shift.copy(), fs_foe=np.asarray(foe), fs_order=order.copy(), fs_wx1=wx1, fs_ok=np.bool_(ok))
+    # --- what sync2frame / corr_foe do with it
+    E2 = E[order, :]
+    shift2 = shift.copy()
+    shift2[shift2 < 0] += frame_len * os_
+    shiftfctrs = shift2[order]
+    foe_off = np.ones(np.asarray(foe).shape) * np.mean(foe)
+    E3 = ref_core_ph.comp_freq_offset(E2, foe_off)
+    arr.update(synced=E3, shiftfctrs=shiftfctrs)
+    arr["ffo_in"] = E3[:, :4096:2]
+    arr["ffo_out"] = ref_core_ph.find_freq_offset(arr["ffo_in"], fft_size=2 ** 12)
+    # --- pilot equaliser (qampy/equalisation.py:268-338 with Ntaps=45, synctaps=17, frame 0)
+    Ntaps = 45
+    eq_shift = shiftfctrs - (Ntaps - 17) // 2
+    taps, foe_all = ref_pil.equalize_pilot_sequence(E3, pilot_seq, eq_shift, os_, mu=(1e-3, 1e-3), foe_comp=False, Ntaps=Ntaps,
+                                                    methods=("cma", "sbd"))
+    arr.update(eq_shift=eq_shift, eq_taps=taps, eq_foe=foe_all)
+    frames = []
+    for m in range(2):                       # _apply_to_pilotsignal with per-mode shift factors (qampy/equalisation.py:42-87)
+        i0 = eq_shift[m]
+        frames.append(ref_core_eq.apply_filter(E3[:, i0:i0 + frame_len * os_ + Ntaps - 1], os_, taps, modes=[m])[0])
+    eq = np.array(frames)
+    arr["eq_frame"] = eq
+    # --- pilot CPE (qampy/phaserec.py:156-192 with use_seq=False, N=5)
+    idx = np.nonzero(idx_pil)[0][seq_len:]
+    out, ph = ref_pil.pilot_based_cpe_new(eq, ph_pilots, idx, frame_len, seq_len=None, max_num_blocks=None, use_pilot_ratio=1,
+                                          num_average=5, nframes=1)
+    arr.update(cpe_idx=idx, cpe_out=out, cpe_ph=ph)
+    foe_p, foe_pm, cond = ref_pil.pilot_based_foe(eq[:, :seq_len], pilot_seq)
+    arr.update(pfoe=np.float64(foe_p), pfoe_modes=foe_pm, pfoe_cond=cond)
+    print("pilot cases: %.1f s, sync ok=%s shift=%s order=%s" % (time.time() - t0, ok, shift, order))
+    save("pilot.npz", arr)
+
+
 # ------------------------------------------------------------------------------------------------ make_decision (row I)
 def gen_decision():
     arr = {}
@@ -416,6 +486,7 @@ def main():
     cases["apply"] = gen_apply(inp)
     cases["bps"] = gen_bps()
     cases["twostage"] = gen_twostage()
+    gen_pilot()
     gen_decision()
     cases["e2e"] = gen_e2e(inp, meta)
     cases["versions"] = dict(numpy=np.__version__, python=sys.version.split()[0], reference="QAMpy v0.5.1 (/root/reference)")

@@ -1,0 +1,90 @@
+"""
+Pilot-based receiver (BASELINE config 5 shape): core functions on plain arrays against vectors captured
+from the reference (tests/golden/pilot.npz, generator tests/golden/gen_golden.py::gen_pilot).  The CPU variant runs the host
+layer on the oracle's kernels; the gpu variant runs the real HIP path, including the one-launch window batch of frame_sync.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from qampy_amd.core import pilotbased_receiver as pil
+from qampy_amd.core import ber_functions, phaserecovery
+from qampy_amd.core.filter import moving_average
+from qampy_amd.core.equalisation import equalisation as core_eq
+
+
+def _oracle_windows(E, starts, win_len, TrSyms, Niter, os_, mu, wx0, modes, adaptive, symbols, method):
+    errs, wxs, mus = [], [], []
+    for s in np.asarray(starts):
+        seg = np.ascontiguousarray(E[:, s:s + win_len])
+        e, w, m = oracle.train_equaliser(seg, TrSyms, Niter, os_, mu, wx0.copy(), modes, adaptive, symbols, method)
+        errs.append(e); wxs.append(w); mus.append(m)
+    return np.array(errs), np.array(wxs), np.array(mus)
+
+
+@pytest.fixture
+def oracle_kernels(monkeypatch):
+    k = core_eq._kernels
+    monkeypatch.setattr(k, "train_equaliser", oracle.train_equaliser)
+    monkeypatch.setattr(k, "train_equaliser_realvalued", oracle.train_equaliser_realvalued)
+    monkeypatch.setattr(k, "apply_filter_to_signal", oracle.apply_filter_to_signal)
+    monkeypatch.setattr(k, "train_equaliser_windows", _oracle_windows)
+
+
+def test_helpers_match_reference(golden):
+    g = golden["pilot"]
+    ix, y2, ii, acm = ber_functions.find_sequence_offset_complex(g["fso_x"], g["fso_y"])
+    assert ix == g["fso_ix"] and ii == g["fso_ii"] and np.isclose(acm, g["fso_acm"])
+    assert np.array_equal(moving_average(g["mavg_in"], 5), g["mavg_out"])
+    assert np.array_equal(phaserecovery.find_freq_offset(g["ffo_in"], fft_size=2 ** 12), g["ffo_out"])
+    foe = g["fs_foe"]
+    E2 = g["rx"][g["fs_order"], :]
+    np.testing.assert_allclose(phaserecovery.comp_freq_offset(E2, np.ones(foe.shape) * np.mean(foe)), g["synced"], rtol=0, atol=1e-12)
+
+
+def _run_chain(g, rtol):
+    os_, frame_len = int(g["os"]), int(g["frame_len"])
+    shift, foe, order, wx1, ok = pil.frame_sync(g["rx"], g["pilot_seq"], os_, frame_len=frame_len, M_pilot=4, mu=5e-3, Ntaps=17,
+                                                adaptive_stepsize=True, Niter=10, method="cma")
+    assert ok == bool(g["fs_ok"]) and np.array_equal(shift, g["fs_shift"]) and np.array_equal(order, g["fs_order"])
+    np.testing.assert_allclose(foe, g["fs_foe"], rtol=1e-12)
+    np.testing.assert_allclose(wx1, g["fs_wx1"], rtol=rtol, atol=rtol)
+    E3 = g["synced"]
+    taps, foe_all = pil.equalize_pilot_sequence(E3, g["pilot_seq"], g["eq_shift"], os_, mu=(1e-3, 1e-3), foe_comp=False, Ntaps=45,
+                                                methods=("cma", "sbd"))
+    np.testing.assert_allclose(taps, g["eq_taps"], rtol=rtol, atol=rtol)
+    assert np.array_equal(foe_all, g["eq_foe"])
+    frames = [core_eq.apply_filter(E3[:, i0:i0 + frame_len * os_ + 44], os_, taps, modes=[m])[0] for m, i0 in enumerate(g["eq_shift"])]
+    eq = np.array(frames)
+    np.testing.assert_allclose(eq, g["eq_frame"], rtol=rtol, atol=10 * rtol)
+    out, ph = pil.pilot_based_cpe_new(eq, g["ph_pilots"], g["cpe_idx"], frame_len, seq_len=None, max_num_blocks=None,
+                                      use_pilot_ratio=1, num_average=5, nframes=1)
+    np.testing.assert_allclose(ph, g["cpe_ph"], rtol=0, atol=100 * rtol)
+    np.testing.assert_allclose(out, g["cpe_out"], rtol=0, atol=100 * rtol)
+    f, fm, c = pil.pilot_based_foe(eq[:, :g["pilot_seq"].shape[1]], g["pilot_seq"])
+    np.testing.assert_allclose(fm, g["pfoe_modes"], rtol=1e-5, atol=1e-9)
+    return out
+
+
+def test_pilot_chain_on_oracle_kernels(golden, oracle_kernels):
+    _run_chain(golden["pilot"], 1e-9)
+
+
+@pytest.mark.gpu
+def test_pilot_chain_on_gpu(golden):
+    _run_chain(golden["pilot"], 1e-8)
+
+
+@pytest.mark.gpu
+def test_window_batch_equals_single_calls(golden, monkeypatch):
+    """frame_sync's one-launch batch gives exactly what separate equalise_signal calls give (same kernel, same order)."""
+    monkeypatch.setenv("QAMPY_HIP_TRAINER", "direct")        # the batch runs the direct-form kernel
+    g = golden["pilot"]
+    E = np.ascontiguousarray(g["rx"].astype(np.complex64))
+    starts = np.arange(2, 20) * 256
+    for adaptive, method in ((True, "cma"), (False, "mcma")):
+        w_all, e_all = core_eq.equalise_signal_windows(E, 2, 5e-3, 4, starts, 512, Ntaps=17, Niter=4, method=method,
+                                                       adaptive_stepsize=adaptive)
+        for i, s in enumerate(starts):
+            w, e = core_eq.equalise_signal(E[:, s:s + 512], 2, 5e-3, 4, Ntaps=17, Niter=4, method=method, adaptive_stepsize=adaptive)
+            assert np.array_equal(w, w_all[i]) and np.array_equal(e, e_all[i])
