@@ -42,25 +42,27 @@ template <typename R> struct AlphabetDesc {
 template <typename R>
 __global__ void __launch_bounds__(64) analyse_alphabet_kernel(const Cx<R> *symbols, int M, AlphabetDesc<R> *d)
 {
+    __shared__ R sre[1024], sim[1024];
+    __shared__ unsigned char seen[BPS_MAX_LEVELS * BPS_MAX_LEVELS];
+    if (M > 1024) { if (threadIdx.x == 0) d->product = 0; return; }
+    for (int k = threadIdx.x; k < M; k += 64) { const Cx<R> s = symbols[k]; sre[k] = s.re; sim[k] = s.im; }
+    for (int k = threadIdx.x; k < BPS_MAX_LEVELS * BPS_MAX_LEVELS; k += 64) seen[k] = 0;
+    __syncthreads();
     if (threadIdx.x != 0) return;
+    R lre[BPS_MAX_LEVELS], lim[BPS_MAX_LEVELS];
     int nre = 0, nim = 0;
     bool ok = true;
     for (int k = 0; k < M && ok; k++) {
-        const Cx<R> s = symbols[k];
         int r = 0, i = 0;
-        while (r < nre && d->re[r] != s.re) r++;
-        if (r == nre) { if (nre < BPS_MAX_LEVELS) d->re[nre++] = s.re; else ok = false; }
-        while (i < nim && d->im[i] != s.im) i++;
-        if (i == nim) { if (nim < BPS_MAX_LEVELS) d->im[nim++] = s.im; else ok = false; }
+        while (r < nre && lre[r] != sre[k]) r++;
+        if (r == nre) { if (nre < BPS_MAX_LEVELS) lre[nre++] = sre[k]; else ok = false; }
+        while (i < nim && lim[i] != sim[k]) i++;
+        if (i == nim) { if (nim < BPS_MAX_LEVELS) lim[nim++] = sim[k]; else ok = false; }
+        // every (re, im) combination must occur exactly once: M distinct points on an nre x nim grid with M == nre*nim
+        if (ok) { if (seen[r * BPS_MAX_LEVELS + i]) ok = false; else seen[r * BPS_MAX_LEVELS + i] = 1; }
     }
-    // every (re, im) combination must occur: M distinct points on an nre x nim grid with M == nre*nim
-    if (ok && (long)nre * nim == M) {
-        for (int k = 0; k < M && ok; k++)
-            for (int q = 0; q < k; q++)
-                if (symbols[k].re == symbols[q].re && symbols[k].im == symbols[q].im) { ok = false; break; }
-    } else {
-        ok = false;
-    }
+    ok = ok && (long)nre * nim == M;
+    for (int r = 0; r < BPS_MAX_LEVELS; r++) { d->re[r] = r < nre ? lre[r] : (R)0; d->im[r] = r < nim ? lim[r] : (R)0; }
     d->product = ok ? 1 : 0;
     d->nre = nre; d->nim = nim;
 }
@@ -75,25 +77,7 @@ template <typename R> struct BpsArgs {
     int A, M, N, T, RUN;
 };
 
-template <typename R> __device__ __forceinline__ R min_distance(R tr, R ti, const BpsArgs<R> &a, bool product)
-{
-    if (product) {
-        const AlphabetDesc<R> *d = a.desc;
-        R mr = (R)3.0e38, mi = (R)3.0e38;
-        for (int r = 0; r < d->nre; r++) mr = min_(mr, abs_(tr - d->re[r]));     // wave-uniform levels: scalar loads
-        for (int i = 0; i < d->nim; i++) mi = min_(mi, abs_(ti - d->im[i]));
-        const R d0 = fma_(mr, mr, mi * mi);
-        return d0 < (R)100. ? d0 : (R)100.;
-    }
-    R d0 = (R)1000.;                                    // det_symbol: strict `<` from d0 = 1000 (:17-22)
-    for (int k = 0; k < a.M; k++) {
-        const Cx<R> s = a.symbols[k];                   // wave-uniform -> scalar load
-        const R dr = tr - s.re, di = ti - s.im;
-        const R d = fma_(dr, dr, di * di);
-        d0 = d < d0 ? d : d0;
-    }
-    return d0 < (R)100. ? d0 : (R)100.;                 // dists initialised to 100 (:73, :83)
-}
+constexpr int BPS_EPT = 8;        // (symbol, angle) elements a thread carries through the candidate loop at once
 
 template <typename R>
 __global__ void __launch_bounds__(BPS_THREADS) bps_kernel(BpsArgs<R> a)
@@ -104,10 +88,12 @@ __global__ void __launch_bounds__(BPS_THREADS) bps_kernel(BpsArgs<R> a)
     R *dist = reinterpret_cast<R *>(smem);                 // [rows][A]
     R *wsum = dist + (size_t)rows * A;                     // [T][A + 1]
     Cx<R> *rot = reinterpret_cast<Cx<R> *>(wsum + (size_t)T * (A + 1) + ((size_t)T * (A + 1) & 1));   // [A] rotators
+    R *lev = reinterpret_cast<R *>(rot + A);               // [2][BPS_MAX_LEVELS] per-axis levels of a product alphabet
     const int64_t i0 = (int64_t)blockIdx.x * T;            // first output symbol of this tile
     const int64_t l0 = i0 - N + 1;                         // symbol index of dist row 0
     const bool per_symbol = a.p > 1;
     const bool product = a.desc->product != 0;
+    const int nre = product ? a.desc->nre : 0, nim = product ? a.desc->nim : 0;
 
     if (!per_symbol) {                                     // exp(j*theta_a) once per tile instead of once per (symbol, angle)
         for (int ja = threadIdx.x; ja < A; ja += BPS_THREADS) {
@@ -115,27 +101,73 @@ __global__ void __launch_bounds__(BPS_THREADS) bps_kernel(BpsArgs<R> a)
             sincos_<R>(a.angles[ja], &sn, &cs);
             rot[ja] = Cx<R>{cs, sn};
         }
-        __syncthreads();
     }
-    // ---- phase 1: min-distance of every (symbol, test angle) of tile + halo; lanes <-> consecutive angles
-    for (int e = threadIdx.x; e < rows * A; e += BPS_THREADS) {
-        const int r = e / A, ja = e - r * A;
-        const int64_t l = l0 + r;
-        R d0 = 0;                                           // rows outside [0, L) only feed outputs that are forced to 0
-        if (l >= 0 && l < a.L) {
-            const Cx<R> x = ldg(a.E + l);
+    if (product && threadIdx.x < BPS_MAX_LEVELS) {
+        lev[threadIdx.x] = threadIdx.x < nre ? a.desc->re[threadIdx.x] : (R)0;
+        lev[BPS_MAX_LEVELS + threadIdx.x] = threadIdx.x < nim ? a.desc->im[threadIdx.x] : (R)0;
+    }
+    __syncthreads();
+    // ---- phase 1: min-distance of every (symbol, test angle) of tile + halo; lanes <-> consecutive angles.  A thread
+    // rotates BPS_EPT elements, then walks the candidates ONCE for all of them (one candidate fetch per 8 updates).
+    const int total = rows * A;
+    for (int e0 = threadIdx.x; e0 < total; e0 += BPS_THREADS * BPS_EPT) {
+        R tr[BPS_EPT], ti[BPS_EPT];
+        bool ok[BPS_EPT];
+#pragma unroll
+        for (int q = 0; q < BPS_EPT; q++) {
+            const int e = e0 + q * BPS_THREADS;
+            const int ec = e < total ? e : total - 1;
+            const int r = ec / A, ja = ec - r * A;
+            const int64_t l = l0 + r;
+            ok[q] = e < total && l >= 0 && l < a.L;        // rows outside [0, L) only feed outputs that are forced to 0
+            const int64_t lc = l < 0 ? 0 : (l < a.L ? l : a.L - 1);
+            const Cx<R> x = ldg(a.E + lc);
             Cx<R> c;
             if (per_symbol) {
                 R sn, cs;
-                sincos_<R>(a.angles[(size_t)l * A + ja], &sn, &cs);
+                sincos_<R>(a.angles[(size_t)lc * A + ja], &sn, &cs);
                 c = Cx<R>{cs, sn};
             } else {
                 c = rot[ja];
             }
-            const R tr = fma_(x.re, c.re, -(x.im * c.im)), ti = fma_(x.re, c.im, x.im * c.re);
-            d0 = min_distance<R>(tr, ti, a, product);
+            tr[q] = fma_(x.re, c.re, -(x.im * c.im));
+            ti[q] = fma_(x.re, c.im, x.im * c.re);
         }
-        dist[e] = d0;
+        R d0[BPS_EPT];
+        if (product) {
+            R mr[BPS_EPT], mi[BPS_EPT];
+#pragma unroll
+            for (int q = 0; q < BPS_EPT; q++) mr[q] = mi[q] = (R)3.0e38;
+            for (int r = 0; r < nre; r++) {
+                const R lv = lev[r];
+#pragma unroll
+                for (int q = 0; q < BPS_EPT; q++) mr[q] = min_(mr[q], abs_(tr[q] - lv));
+            }
+            for (int r = 0; r < nim; r++) {
+                const R lv = lev[BPS_MAX_LEVELS + r];
+#pragma unroll
+                for (int q = 0; q < BPS_EPT; q++) mi[q] = min_(mi[q], abs_(ti[q] - lv));
+            }
+#pragma unroll
+            for (int q = 0; q < BPS_EPT; q++) d0[q] = fma_(mr[q], mr[q], mi[q] * mi[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < BPS_EPT; q++) d0[q] = (R)1000.;            // det_symbol: strict `<` from d0 = 1000 (:17-22)
+            for (int k = 0; k < a.M; k++) {
+                const Cx<R> sk = a.symbols[k];                              // wave-uniform -> scalar load
+#pragma unroll
+                for (int q = 0; q < BPS_EPT; q++) {
+                    const R dr = tr[q] - sk.re, di = ti[q] - sk.im;
+                    const R d = fma_(dr, dr, di * di);
+                    d0[q] = d < d0[q] ? d : d0[q];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < BPS_EPT; q++) {
+            const int e = e0 + q * BPS_THREADS;
+            if (e < total) dist[e] = ok[q] ? (d0[q] < (R)100. ? d0[q] : (R)100.) : (R)0;   // dists start at 100 (:73, :83)
+        }
     }
     __syncthreads();
     // ---- phase 2: windowed sums.  A thread owns one angle and a run of RUN consecutive output symbols: the first
@@ -177,11 +209,11 @@ __global__ void __launch_bounds__(BPS_THREADS) bps_kernel(BpsArgs<R> a)
 template <typename R> static int bps_tile(int A, int N, size_t *lds)
 {
     // largest T with (T + 2N - 1)*A + T*(A + 1) elements (+ the rotator table) inside the LDS budget
-    const int64_t cap = (int64_t)(BPS_LDS_BUDGET / sizeof(R)) - 2 * A - 2;
+    const int64_t cap = (int64_t)(BPS_LDS_BUDGET / sizeof(R)) - 2 * A - 2 - 2 * BPS_MAX_LEVELS;
     int64_t T = (cap - (int64_t)(2 * N - 1) * A) / (2 * A + 1);
     if (T > 1024) T = 1024;
     if (T < 1) return 0;
-    *lds = ((size_t)(T + 2 * N - 1) * A + (size_t)T * (A + 1) + 1 + 2 * (size_t)A) * sizeof(R);
+    *lds = ((size_t)(T + 2 * N - 1) * A + (size_t)T * (A + 1) + 1 + 2 * (size_t)A + 2 * BPS_MAX_LEVELS) * sizeof(R);
     return (int)T;
 }
 
@@ -244,7 +276,7 @@ int bps_host(const void *E, int64_t L, const void *angles, int64_t p, int A, con
 // np.unwrap's correction is -2*pi when k jumps by more than A/2, +2*pi when it drops by more than A/2 and 0 otherwise
 // (|jump| == A/2 maps to 0: numpy keeps dd = +-pi).  The running correction is an integer prefix sum - exact.
 constexpr int UW_THREADS = 256;
-constexpr int UW_PER_THREAD = 16;
+constexpr int UW_PER_THREAD = 4;
 constexpr int UW_CHUNK = UW_THREADS * UW_PER_THREAD;
 
 __device__ __forceinline__ int unwrap_jump(int kprev, int kcur, int A)
