@@ -35,6 +35,9 @@ if ROOT not in sys.path:
 # converges on both modes over 2^22 symbols (verified with the CPU oracle, seeds 1000-1001).  c3 is the 2^22-symbol variant of the north-star configuration (64-QAM, 41 taps,
 # CMA -> MRDE, 64-angle BPS) and the largest single-GPU configuration in BASELINE.json's `configs`.
 WORKLOADS = {
+    # configs[0]: the reference's own CPU-runnable plumbing case (Scripts/cma_equaliser.py): a parity-test case, not a bench line
+    "c1": dict(M=4, nsym=2 ** 16, nmodes=1, ntaps=11, methods=("cma",), mu=(1e-3,), niter=(1,), adaptive=(False,), A=None, Nbps=0,
+               snr_db=14, linewidth=0., label="QPSK 1-pol 2 SPS 2^16 sym, 11-tap CMA (no carrier recovery)"),
     "c2": dict(M=16, nsym=2 ** 20, ntaps=21, methods=("mcma",), mu=(1e-3,), niter=(1,), adaptive=(False,), A=32, Nbps=20,
                snr_db=25, linewidth=50e3, label="16-QAM 2-pol 2 SPS 2^20 sym, 21-tap MCMA + 32-angle BPS"),
     "c3": dict(M=64, nsym=2 ** 22, ntaps=41, methods=("cma", "mrde"), mu=(2e-4, 2e-4), niter=(1, 1), adaptive=(False, False),
@@ -49,13 +52,14 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 
 def make_input(cfg, nsym, seed):
     from qampy_amd import synth
-    return synth.make_capture(cfg["M"], nsym, nmodes=2, os=2, snr_db=cfg["snr_db"], theta=np.pi / 5.6, dgd=30e-12,
+    nm = cfg.get("nmodes", 2)
+    return synth.make_capture(cfg["M"], nsym, nmodes=nm, os=2, snr_db=cfg["snr_db"], theta=np.pi / 5.6 if nm == 2 else None, dgd=30e-12,
                               linewidth=cfg["linewidth"], fb=20e9, beta=0.1, seed=seed, dtype=np.complex64)
 
 
 def make_receiver(cfg, sig, segments=0, prefix=0, prefix_mu=None):
     from qampy_amd.pipeline import ResidentReceiver
-    return ResidentReceiver(2, sig.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"],
+    return ResidentReceiver(sig.shape[0], sig.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"],
                             adaptive_stepsize=cfg["adaptive"], TrSyms=(None,) * len(cfg["methods"]), Mtestangles=cfg["A"],
                             Nbps=cfg["Nbps"], dtype=np.complex64, alphabet=sig.coded_symbols, segments=segments, prefix=prefix,
                             prefix_mu=prefix_mu)
@@ -64,7 +68,7 @@ def make_receiver(cfg, sig, segments=0, prefix=0, prefix_mu=None):
 def timed_steps(rx, steps, warmup, barrier_sync):
     """W warm-up passes, then exactly K passes bracketed by barrier + device sync; HIP events between the stages."""
     from qampy_amd import _lib
-    stage_fns = [rx.build_gram] + [lambda s=s: rx.train(s) for s in range(rx.nstage)] + [rx.apply, rx.recover]
+    stage_fns = [rx.build_gram] + [lambda s=s: rx.train(s) for s in range(rx.nstage)] + [rx.apply] + ([rx.recover] if rx.Mtestangles else [])
     for _ in range(warmup):
         rx.run()
     ev = [[_lib.Event() for _ in range(len(stage_fns) + 1)] for _ in range(steps)]
@@ -111,11 +115,12 @@ def cpu_baseline(cfg, sig, sample_sym):
         print("cpu_baseline: native rebuild failed (%s), using the prebuilt oracle" % e, file=sys.stderr)
     E = np.ascontiguousarray(np.asarray(sig)[:, :2 * sample_sym])
     ntaps = cfg["ntaps"]
-    w = host._init_taps(ntaps, 2, 2, np.complex64)
+    w = host._init_taps(ntaps, E.shape[0], E.shape[0], np.complex64)
     tr = host._cal_training_symbol_len(2, ntaps, E.shape[1])
-    syms = [host._reshape_symbols(sig.coded_symbols if m in host.DECISION_BASED else None, m, cfg["M"], np.complex64, 2)
+    nm = E.shape[0]
+    syms = [host._reshape_symbols(sig.coded_symbols if m in host.DECISION_BASED else None, m, cfg["M"], np.complex64, nm)
             for m in cfg["methods"]]
-    angles = np.linspace(-np.pi / 4, np.pi / 4, cfg["A"], endpoint=False, dtype=np.float32).reshape(1, -1)
+    angles = np.linspace(-np.pi / 4, np.pi / 4, cfg["A"] or 1, endpoint=False, dtype=np.float32).reshape(1, -1)
     t0 = time.perf_counter()
     for s, m in enumerate(cfg["methods"]):
         _, w, _ = oracle.train_equaliser(E, tr, cfg["niter"][s], 2, np.float32(cfg["mu"][s]), w, None, cfg["adaptive"][s], syms[s], m, fast=True)
@@ -123,9 +128,12 @@ def cpu_baseline(cfg, sig, sample_sym):
     eq = oracle.apply_filter_to_signal(E, 2, w, fast=True)
     t2 = time.perf_counter()
     N = cfg["Nbps"]
-    ph = np.array([oracle.select_angles(angles, oracle.bps(eq[m], angles, sig.coded_symbols, N, fast=True)) for m in range(2)])
-    ph[:, N:-N] = np.unwrap(ph[:, N:-N] * 4) / 4
-    out = eq * np.exp(1j * ph)
+    if cfg["A"]:
+        ph = np.array([oracle.select_angles(angles, oracle.bps(eq[m], angles, sig.coded_symbols, N, fast=True)) for m in range(nm)])
+        ph[:, N:-N] = np.unwrap(ph[:, N:-N] * 4) / 4
+        out = eq * np.exp(1j * ph)
+    else:
+        out = eq
     t3 = time.perf_counter()
     return dict(seconds=t3 - t0, train_s=t1 - t0, apply_s=t2 - t1, bps_s=t3 - t2, wxy=w, out=out.astype(np.complex64))
 
@@ -174,7 +182,7 @@ def main():
     seg = dict(segments=args.segments, prefix=args.prefix) if args.train_mode == "segmented" else {}
     rx = make_receiver(cfg, sig, **seg)
     rx.load(sig)
-    stage_names = ["gram"] + ["train%d:%s" % (s + 1, m) for s, m in enumerate(cfg["methods"])] + ["apply", "bps_recover"]
+    stage_names = ["gram"] + ["train%d:%s" % (s + 1, m) for s, m in enumerate(cfg["methods"])] + ["apply"] + (["bps_recover"] if cfg["A"] else [])
 
     # ---- timed region: exactly K steps, HIP events between the stages (same stream as the kernels)
     elapsed, stage_ms = timed_steps(rx, args.steps, args.warmup, barrier_sync)
@@ -182,7 +190,7 @@ def main():
 
     # ---- results of the last step: SER against the transmitted symbols
     res = rx.fetch()
-    errs = symbol_errors(res["out"], sig)
+    errs = symbol_errors(res["out"] if cfg["A"] else res["eq"], sig)
     counts_all = sharding.reduce_sum_counts([[e, n] for e, n in errs], dist, device="cuda")
 
     if rank != 0:
@@ -194,10 +202,10 @@ def main():
     value = sharding.aggregate_throughput(nsym, world, args.steps, elapsed)
     # ---- roofline of the dominant kernel
     bps_b = rx.bytes_per_symbol()
-    stage_bytes = [rx.TrSyms[0] * (8 * 2 * 2 + 64 * 16)]            # gram: read the capture once, write 1 KiB per step
+    stage_bytes = [rx.TrSyms[0] * (8 * 2 * rx.nmodes + 64 * 16)]     # gram: read the capture once, write 1 KiB per step
     for s in range(rx.nstage):
-        stage_bytes.append(rx.Niter[s] * rx.TrSyms[s] * 8 * (2 * 2 + 2))
-    stage_bytes += [rx.N * bps_b["apply"], rx.N * bps_b["bps"]]
+        stage_bytes.append(rx.Niter[s] * rx.TrSyms[s] * 8 * (rx.nmodes * 2 + rx.modes.size))
+    stage_bytes += [rx.N * bps_b["apply"]] + ([rx.N * bps_b["bps"]] if cfg["A"] else [])
     dom = int(np.argmax(stage_ms))
     achieved = stage_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9
     # HBM bytes per launch of the dominant kernel from the committed PMC pass of the same workload (scripts/gpu_pmc.sh);
@@ -240,7 +248,7 @@ def main():
         r2 = rx2.fetch()
         sig_s = sig.recreate_from_np_array(np.asarray(sig)[:, :2 * sample])
         sig_s._symbols = sig.symbols[:, :sample]
-        e_gpu = symbol_errors(r2["out"], sig_s)
+        e_gpu = symbol_errors(r2["out"] if cfg["A"] else r2["eq"], sig_s)
         e_cpu = symbol_errors(cb["out"], sig_s)
         out["cpu_baseline"] = dict(value=round(sample / cb["seconds"] / 1e6, 4), unit="MSym/s", cores=os.cpu_count(), kind="port",
                                    sample="first %d symbol periods of the same capture (all stages); oracle built with the "
