@@ -1,0 +1,440 @@
+// Block-iterative form of the exact equaliser recurrence (complex, blind methods, fixed step size).
+//
+// Inside a block of 64 steps the look-ahead identity (train_la.h)
+//        y_i = W . x_i + sum_{j < i} c_j * G(j, i) ,     c_j = mu * errfn(y_j) ,     G(j, i) = sum_f conj(x_j[f]) x_i[f]
+// is a STRICTLY LOWER-TRIANGULAR non-linear system  y = q + L c(y).  The sequential recurrence solves it by forward
+// substitution - 64 dependent steps, each paying the ~8 cycles a lone wavefront needs per instruction.  Here it is
+// solved by fixed-point sweeps  c <- mu errfn(q + L c)  instead: because L is strictly lower triangular, entry i is
+// final once entries < i are, so the sweeps reach the exact fixed point (bit for bit, the reduction order is fixed) after
+// at most 64 and in practice 4-8 of them, and every sweep is a 64x64 complex matrix-vector product that 16 wavefronts
+// share: wave w owns the steps j = 4w..4w+3 (its c_j and Gram rows) and the taps of slice w.  The error function is
+// evaluated once per sweep instead of once per step.  Per block:
+//        q      prior outputs W . x_i, every wave contributes its tap slice
+//        sweeps partial_w[i] = q_w[i] + sum_{j in own} c_j G(j, i)  ->  LDS [i][w]  ->  barrier  ->  wave w reduces rows
+//               i = 4w..4w+3 over the 16 contributions (one ds_read + a 16-lane DPP tree)  ->  c_i = mu errfn(y_i)
+//        taps   W += sum_j c_j conj(x_j): every wave adds its 4 steps to all taps, slice owners reduce over the waves
+// The result is the sequential recurrence's result up to the order of floating-point additions (like train_la.h).
+#pragma once
+#include <stdlib.h>
+#include "train_la.h"
+
+namespace qh {
+
+constexpr int BI_W = 8;                  // wavefronts per workgroup (2 per SIMD: more only queue up behind the SIMD's issue port)
+constexpr int BI_JW = LA_B / BI_W;       // steps owned by a wave
+constexpr int BI_PAD = BI_W + 1;         // row pitch of the [i][w] exchange buffers (bank-conflict padding)
+constexpr int BI_MAXTAPS = 128;          // taps per output mode (2 per lane in the tap-update layout)
+
+// Gram terms of one block only (lags 1..63 inside the block): G[l][i] = G(l, blk + i) for i > l - blk, else 0
+template <typename R>
+__global__ void __launch_bounds__(256) gram_cur_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, Cx<R> *G)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Cx<R> *tile = reinterpret_cast<Cx<R> *>(smem);
+    const int64_t blk = (int64_t)blockIdx.x * LA_B;
+    const int span = (LA_B - 1) * os + ntaps;
+    for (int k = 0; k < nmodes; k++) {
+        const int64_t s0 = blk * os;
+        for (int s = threadIdx.x; s < span; s += 256) {
+            const int64_t g = s0 + s;
+            tile[k * span + s] = g < L ? ldg(E + (size_t)k * L + g) : Cx<R>{0, 0};
+        }
+    }
+    __syncthreads();
+    const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const bool t_ok = blk + i < TrSyms;
+    for (int l4 = 0; l4 < 16; l4 += 4) {
+        const int j0 = q * 16 + l4;
+        R cr[4] = {0, 0, 0, 0}, ci[4] = {0, 0, 0, 0};
+        for (int k = 0; k < nmodes; k++) {
+            const Cx<R> *row = tile + k * span;
+            for (int t = 0; t < ntaps; t++) {
+                const Cx<R> b = row[i * os + t];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const Cx<R> a = row[(j0 + u) * os + t];
+                    cr[u] = fma_(a.re, b.re, fma_(a.im, b.im, cr[u]));
+                    ci[u] = fma_(a.re, b.im, fma_(-a.im, b.re, ci[u]));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u;
+            const bool ok = t_ok && i > j && blk + j < TrSyms;
+            stg(G + (size_t)(blk + j) * LA_B + i, ok ? Cx<R>{cr[u], ci[u]} : Cx<R>{0, 0});
+        }
+    }
+}
+
+// sum over groups of BI_W consecutive lanes; every lane of a group gets the group's total (fixed order -> deterministic)
+__device__ __forceinline__ void group_csum(float &re, float &im)
+{
+    if constexpr (BI_W == 16) {
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            : "+v"(re), "+v"(im));
+    } else {
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 0\n\t"
+            "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            : "+v"(re), "+v"(im));
+    }
+}
+__device__ __forceinline__ void group_csum(double &re, double &im)
+{
+    re += dpp_mov<DPP_QUAD_1032>(re);       im += dpp_mov<DPP_QUAD_1032>(im);
+    re += dpp_mov<DPP_QUAD_2301>(re);       im += dpp_mov<DPP_QUAD_2301>(im);
+    re += dpp_mov<DPP_ROW_HALF_MIRROR>(re); im += dpp_mov<DPP_ROW_HALF_MIRROR>(im);
+    if constexpr (BI_W == 16) { re += dpp_mov<DPP_ROW_MIRROR>(re); im += dpp_mov<DPP_ROW_MIRROR>(im); }
+}
+
+// acc += a * b  /  acc += a * conj(b) on 2-vectors (two v_pk_fma for float)
+template <typename R> __device__ __forceinline__ void cfma(Cx<R> &acc, R ar, R ai, const Cx<R> &b)
+{
+    using v2 = typename V2<R>::type;
+    v2 t = {acc.re, acc.im};
+    t = __builtin_elementwise_fma(v2{ar, ar}, v2{b.re, b.im}, t);
+    t = __builtin_elementwise_fma(v2{-ai, ai}, v2{b.im, b.re}, t);
+    acc.re = t.x; acc.im = t.y;
+}
+template <typename R> __device__ __forceinline__ void cfma_conj(Cx<R> &acc, R ar, R ai, const Cx<R> &b)
+{
+    using v2 = typename V2<R>::type;
+    v2 t = {acc.re, acc.im};
+    t = __builtin_elementwise_fma(v2{ar, ai}, v2{b.re, b.re}, t);
+    t = __builtin_elementwise_fma(v2{ai, -ar}, v2{b.im, b.im}, t);
+    acc.re = t.x; acc.im = t.y;
+}
+
+// one entry of the sweep exchange buffer: a wave's contribution to an output plus its "my c moved" flag (one ds_write / ds_read)
+template <typename R> struct alignas(16) BiEnt { Cx<R> v; unsigned flag; unsigned pad; };
+
+constexpr int BI_NT = 64 * BI_W;         // threads per workgroup
+constexpr int BI_RPW = 64 / BI_W;        // rows (steps / taps) a wave reduces per ds_read: lanes = BI_RPW groups of BI_W
+
+template <typename R, int METHOD, int NPART>
+__global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
+{
+    extern __shared__ __attribute__((aligned(16))) char bi_smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int mode = (int)a.modes[blockIdx.x];
+    const int ntot = a.nmodes * a.ntaps;
+    const int os_ = a.os;
+    const int64_t TrSyms = a.TrSyms;
+    const int nblk = (int)((TrSyms + LA_B - 1) / LA_B);
+    const Cx<R> *sy = a.symbols + (size_t)mode * a.nsy;
+
+    // ---- LDS carve-up
+    const int wlen = (LA_B - 1) * os_ + a.ntaps;
+    const int wpitch = (wlen + 1) & ~1;
+    const int wsz = a.nmodes * wpitch;
+    BiEnt<R> *P = reinterpret_cast<BiEnt<R> *>(bi_smem);              // [2][64][BI_PAD]   sweep exchange
+    Cx<R> *TW = reinterpret_cast<Cx<R> *>(P + 2 * LA_B * BI_PAD);      // [BI_MAXTAPS][BI_PAD] tap-update exchange
+    Cx<R> *wbuf = TW + BI_MAXTAPS * BI_PAD;                            // [BI_MAXTAPS]      taps, wave-uniform reads
+    Cx<R> *win = wbuf + BI_MAXTAPS;                                    // [2][nmodes][wpitch] sample windows (block parity)
+
+    // ---- constants of the error function
+    LaConst<R, NPART> K;
+    K.mu = *a.mu;
+    {
+        const Cx<R> c0 = sy[0];
+        K.R_re = c0.re; K.R_im = c0.im;
+    }
+    K.code0_re = K.R_re; K.code0_im = K.R_im;
+    tab_fill<R, NPART>(K.tab, sy, 0, NPART + 1);
+
+    // ---- tap ownership: wave w reduces / dots the taps [f0, f0 + nf)
+    const int tpw = (((ntot + BI_W - 1) / BI_W) + 3) & ~3;              // multiple of 4: the prior dot products run 4 taps at a time
+    const int f0 = w * tpw;
+    const int nf = f0 < ntot ? ((f0 + tpw) < ntot ? tpw : ntot - f0) : 0;
+    Cx<R> *wrow = a.wx + (size_t)mode * ntot;
+    for (int f = threadIdx.x; f < BI_MAXTAPS; f += BI_NT) wbuf[f] = f < ntot ? wrow[f] : Cx<R>{0, 0};     // taps >= ntot stay zero
+    // tap-update layout: lane <-> taps lane and lane + 64
+    int xo[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int f = lane + 64 * s;
+        const int fc = f < ntot ? f : 0;
+        const int k2 = fc / a.ntaps;
+        xo[s] = k2 * wpitch + (fc - k2 * a.ntaps);
+    }
+    const int rr = lane / BI_W, vv = lane % BI_W;                      // reduction layout: group rr <-> row, lane vv of the group <-> wave
+    // window offset of tap f0 + lane of the own slice (prior dot products fetch it with v_readlane); 0 for padding taps
+    int toffv;
+    {
+        const int f = f0 + lane;
+        const int fc = (lane < tpw && f < ntot) ? f : 0;
+        const int k2 = fc / a.ntaps;
+        toffv = k2 * wpitch + (fc - k2 * a.ntaps);
+    }
+    // sample staging: thread <-> up to two window elements, source offsets fixed up front
+    int st_dst[2]; int64_t st_src[2]; int st_i[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int e = threadIdx.x + s * BI_NT;
+        const int ec = e < wsz ? e : 0;
+        const int k2 = ec / wpitch;
+        st_dst[s] = e < wsz ? ec : -1;
+        st_i[s] = ec - k2 * wpitch;
+        st_src[s] = (int64_t)k2 * a.L;
+    }
+    Cx<R> stv[2];
+    auto stage_load = [&](int kb) {                                    // global loads now ...
+        const int64_t base = (int64_t)kb * LA_B * os_;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            int64_t gi = base + st_i[s];
+            if (gi > a.L - 1) gi = a.L - 1;
+            stv[s] = a.E[st_src[s] + gi];
+        }
+    };
+    auto stage_store = [&](int kb) {                                   // ... LDS writes once the window is free
+        const int64_t base = (int64_t)kb * LA_B * os_;
+        Cx<R> *dst = win + (size_t)(kb & 1) * wsz;
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            if (st_dst[s] >= 0) dst[st_dst[s]] = stv[s];
+        for (int e = threadIdx.x + 2 * BI_NT; e < wsz; e += BI_NT) {      // very long windows only
+            const int k2 = e / wpitch, i2 = e - k2 * wpitch;
+            int64_t gi = base + i2;
+            if (gi > a.L - 1) gi = a.L - 1;
+            dst[e] = a.E[(size_t)k2 * a.L + gi];
+        }
+    };
+    // own-slice part of the prior outputs of block kb: lane <-> step kb*64 + lane
+    auto prior_part = [&](int kb) {
+        const Cx<R> *xs = win + (size_t)(kb & 1) * wsz + lane * os_;
+        const Cx<R> *ws = wbuf + f0;
+        Cx<R> acc{0, 0};
+        for (int f = 0; f < tpw; f += 4) {
+            Cx<R> x[4], wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                x[u] = xs[readlane(toffv, f + u)];
+                wv[u] = ws[f + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) cfma<R>(acc, x[u].re, x[u].im, wv[u]);
+        }
+        if ((int64_t)kb * LA_B + lane >= TrSyms) acc = Cx<R>{0, 0};
+        return acc;
+    };
+    const int gs = a.gpair ? 2 : 1;                                    // the look-ahead pair layout interleaves cur / next
+    const Cx<R> *gbase = reinterpret_cast<const Cx<R> *>(a.G) + ((size_t)(BI_JW * w) * LA_B + lane) * gs;
+    auto load_gram = [&](Cx<R> (&g)[BI_JW], int kb) {
+        const Cx<R> *gp = gbase + (size_t)kb * LA_B * LA_B * gs;
+#pragma unroll
+        for (int r = 0; r < BI_JW; r++) g[r] = gp[(size_t)r * LA_B * gs];
+    };
+
+    Cx<R> *errow = a.err + (size_t)mode * a.err_pitch + a.err_off;
+    stage_load(0); stage_store(0);
+    if (nblk > 1) { stage_load(1); stage_store(1); }
+    __syncthreads();
+    Cx<R> qpart = prior_part(0);
+    Cx<R> g[BI_JW], gn[BI_JW];
+    load_gram(g, 0);
+
+    BiEnt<R> *pw = P + (size_t)lane * BI_PAD + w;                       // this wave's column of the exchange buffer
+    const BiEnt<R> *pr = P + (size_t)(BI_JW * w + rr) * BI_PAD + vv;   // the rows it reduces
+    constexpr int PBUF = LA_B * BI_PAD;
+    // own tap slice in registers: group rr of round t <-> tap f0 + BI_RPW * t + rr (BI_MAXTAPS / 64 = 2 rounds at most)
+    Cx<R> wreg[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int f = f0 + BI_RPW * t + rr;
+        wreg[t] = (BI_RPW * t + rr < nf) ? wbuf[f] : Cx<R>{0, 0};
+    }
+    Cx<R> *eown = errow + BI_JW * w + rr;                               // this group's slot of the error trace
+
+    unsigned long long pf_sweeps = 0, pf_t_sweep = 0, pf_t_upd = 0, pf_t_prior = 0;
+    for (int k = 0; k < nblk; k++) {
+        const unsigned long long pt0 = a.prof ? clock64() : 0;
+        const int64_t s0 = (int64_t)k * LA_B;
+        load_gram(gn, k + 1 < nblk ? k + 1 : k);                       // next block's rows and the samples of block k+2 arrive during the sweeps
+        stage_load(k + 2 < nblk ? k + 2 : k);
+        // ---------------------------------------------------------------- fixed-point sweeps
+        Cx<R> part = qpart;
+        Cx<R> c_old{0, 0}, y{0, 0};
+        unsigned changed = 1;
+        // one sweep through exchange buffer `pb`; true when the fixed point has been reached
+        auto sweep = [&](const int pb) -> bool {
+            BiEnt<R> ent;
+            ent.v = part; ent.flag = changed; ent.pad = 0;
+            pw[pb] = ent;
+            __syncthreads();
+            const BiEnt<R> got = pr[pb];
+            y = got.v;
+            group_csum(y.re, y.im);                                        // y of row rr, identical in the lanes of the group
+            if (a.prof) pf_sweeps++;
+            if (!__any(got.flag != 0)) return true;                        // nobody's c moved in the last sweep: y is the fixed point
+            const Cx<R> c_new = la_errfn<R, METHOD, NPART, true>(y, K);
+            {
+                const unsigned long long mv = __builtin_amdgcn_ballot_w64(c_new.re != c_old.re || c_new.im != c_old.im);
+                changed = (unsigned)mv | (unsigned)(mv >> 32);             // wave-uniform: non-zero when any own c moved
+            }
+            c_old = c_new;
+            part = qpart;                                                  // own steps' contributions to every pending output
+#pragma unroll
+            for (int r = 0; r < BI_JW; r++) cfma<R>(part, readlane(c_new.re, BI_W * r), readlane(c_new.im, BI_W * r), g[r]);
+            return false;
+        };
+        for (int it = 0; it <= LA_B + 2; it += 2) {
+            if (sweep(0)) break;
+            if (sweep(PBUF)) break;
+        }
+        // ---------------------------------------------------------------- results of the block
+        const unsigned long long pt1 = a.prof ? clock64() : 0;
+        const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K);
+        if (vv == 0 && s0 + BI_JW * w + rr < TrSyms) eown[s0] = e;
+        // taps: this wave's steps into all taps (lane <-> taps lane, lane + 64)
+        {
+            const Cx<R> *xw = win + (size_t)(k & 1) * wsz + (BI_JW * w) * os_;
+            Cx<R> dw[2] = {{0, 0}, {0, 0}};
+#pragma unroll
+            for (int r = 0; r < BI_JW; r++) {
+                const R cr = readlane(c_old.re, BI_W * r), ci = readlane(c_old.im, BI_W * r);
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    const Cx<R> x = xw[xo[s] + r * os_];
+                    cfma_conj<R>(dw[s], cr, ci, x);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++) TW[(size_t)(lane + 64 * s) * BI_PAD + w] = dw[s];
+        }
+        __syncthreads();
+        // taps: slice owners sum the contributions of all waves (BI_RPW taps per read, one lane group each)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            if (BI_RPW * t < tpw) {
+                const int f = f0 + BI_RPW * t + rr;
+                Cx<R> d = TW[(size_t)f * BI_PAD + vv];
+                group_csum(d.re, d.im);
+                if (BI_RPW * t + rr < nf) { wreg[t].re += d.re; wreg[t].im += d.im; }
+                if (BI_RPW * t + rr < tpw) wbuf[f] = wreg[t];              // all lanes of a group write the same value
+            }
+        }
+        // samples of block k+2 replace block k's: every wave finished reading those before the barrier above, and the next
+        // readers (prior outputs of block k+2) sit behind the sweep barriers of block k+1
+        if (k + 2 < nblk) stage_store(k + 2);
+        const unsigned long long pt2c = a.prof ? clock64() : 0;
+        if (k + 1 < nblk) qpart = prior_part(k + 1);                      // reads the own slice of wbuf only: no barrier needed
+#pragma unroll
+        for (int r = 0; r < BI_JW; r++) g[r] = gn[r];
+        if (a.prof) {
+            const unsigned long long pt3 = clock64();
+            pf_t_sweep += pt1 - pt0; pf_t_upd += pt2c - pt1; pf_t_prior += pt3 - pt2c;
+        }
+    }
+    __syncthreads();
+    if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) {
+        a.prof[0] = pf_sweeps; a.prof[1] = pf_t_sweep; a.prof[2] = pf_t_upd; a.prof[3] = pf_t_prior; a.prof[4] = (unsigned long long)nblk;
+    }
+    for (int f = threadIdx.x; f < ntot; f += BI_NT) wrow[f] = wbuf[f];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+template <typename R> static size_t gram_cur_bytes(int64_t TrSyms)
+{
+    const int64_t nblk = (TrSyms + LA_B - 1) / LA_B;
+    return (size_t)(nblk * LA_B + LA_B) * LA_B * sizeof(Cx<R>);
+}
+
+template <typename R> int gram_cur_build(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    void *G = nullptr;
+    if ((rc = scratch(4, gram_cur_bytes<R>(TrSyms), &G))) return rc;
+    const int64_t nblk = (TrSyms + LA_B - 1) / LA_B;
+    const size_t lds = (size_t)nmodes * ((LA_B - 1) * os + ntaps) * sizeof(Cx<R>);
+    QH_REQUIRE(lds <= 64 * 1024, "gram: nmodes*(63*os+ntaps) samples exceed the LDS tile");
+    if (nblk > 0) hipLaunchKernelGGL((gram_cur_kernel<R>), dim3((unsigned)nblk), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps,
+                                     TrSyms, (Cx<R> *)G);
+    QH_HIP(hipGetLastError());
+    *gram = G;
+    return QH_OK;
+}
+
+template <typename R> static size_t bi_lds_bytes(int nmodes, int ntaps, int os)
+{
+    const int wpitch = ((LA_B - 1) * os + ntaps + 1) & ~1;
+    return (size_t)2 * LA_B * BI_PAD * sizeof(BiEnt<R>) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch) * sizeof(Cx<R>);
+}
+
+// sizes the block-iterative kernel can hold (the Gram layout of a capture follows from this alone)
+inline bool bi_shape_ok(int nmodes, int ntaps, int os, size_t elem)
+{
+    const char *force = getenv("QAMPY_HIP_TRAINER");
+    if (force && (force[0] == 'd' || force[0] == 'l')) return false;      // "direct" / "lookahead": A/B measurements, tests
+    if (nmodes * ntaps > BI_MAXTAPS) return false;
+    const int wpitch = ((LA_B - 1) * os + ntaps + 1) & ~1;
+    return (size_t)2 * LA_B * BI_PAD * (elem + 16) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch) * elem <= 64 * 1024;
+}
+
+inline bool bi_supported(int method, int adaptive, int nmodes, int ntaps, int os, int64_t TrSyms, int64_t nsy, size_t elem)
+{
+    if (adaptive || TrSyms < 2 * LA_B) return false;
+    if (!bi_shape_ok(nmodes, ntaps, os, elem)) return false;
+    switch (method) {
+    case QH_M_CMA: case QH_M_SGNCMA: case QH_M_CMA2: case QH_M_MCMA: return true;
+    case QH_M_RDE: case QH_M_MRDE: return nsy - (nsy + 1) / 2 >= 1 && nsy - (nsy + 1) / 2 <= LA_MAXPART;
+    default: return false;
+    }
+}
+
+template <typename R, int METHOD> static int launch_bi_parts(const LaArgs<R> &a, int npart, size_t lds)
+{
+    dim3 grid(a.nsel), block(BI_NT);
+#define QH_BI_NP(N) case N: hipLaunchKernelGGL((train_bi_kernel<R, METHOD, N>), grid, block, lds, g_stream, a); break;
+    switch (npart) {
+        QH_BI_NP(1) QH_BI_NP(2) QH_BI_NP(3) QH_BI_NP(4) QH_BI_NP(5) QH_BI_NP(6) QH_BI_NP(7) QH_BI_NP(8)
+    default: set_error("block-iterative trainer: unsupported partition count"); return QH_ERR_ARG;
+    }
+#undef QH_BI_NP
+    return QH_OK;
+}
+
+template <typename R> int launch_bi(const LaArgs<R> &a)
+{
+    dim3 grid(a.nsel), block(BI_NT);
+    const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
+    const size_t lds = bi_lds_bytes<R>(a.nmodes, a.ntaps, a.os);
+    int rc = QH_OK;
+    switch (a.method) {
+    case QH_M_CMA: case QH_M_SGNCMA: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_CMA, 0>), grid, block, lds, g_stream, a); break;
+    case QH_M_CMA2: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_CMA2, 0>), grid, block, lds, g_stream, a); break;
+    case QH_M_MCMA: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_MCMA, 0>), grid, block, lds, g_stream, a); break;
+    case QH_M_RDE: rc = launch_bi_parts<R, QH_M_RDE>(a, npart, lds); break;
+    case QH_M_MRDE: rc = launch_bi_parts<R, QH_M_MRDE>(a, npart, lds); break;
+    default: return QH_ERR_METHOD;
+    }
+    if (rc) return rc;
+    QH_HIP(hipGetLastError());
+    return QH_OK;
+}
+
+}  // namespace qh

@@ -28,6 +28,8 @@ int qh_train_equaliser_c64_seg_dev(const void *E, int nmodes, int64_t L, int64_t
 }
 int qh_gram_build_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
 {
+    // pairs (look-ahead layout, also read by the block-iterative kernel) whenever the look-ahead kernel fits the shape
+    if (!qh::la_shape_ok(nmodes, ntaps, os) && qh::bi_shape_ok(nmodes, ntaps, os, 2 * sizeof(float))) return qh::gram_cur_build<float>(E, nmodes, L, os, ntaps, TrSyms, gram);
     return qh::gram_build<float>(E, nmodes, L, os, ntaps, TrSyms, gram);
 }
 int qh_train_equaliser_c64_gram_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,

@@ -19,7 +19,7 @@
 //     mode into the next when run sequentially; otherwise each mode gets its own workgroup (its own CU).
 #pragma once
 #include "common.h"
-#include "train_la.h"
+#include "train_bi.h"
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -469,16 +469,52 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
     a.nseg = 0; a.seg_begin = 0; a.seg_len = 0; a.seg_iter = 0; a.wx_out = nullptr;
     a.win_start = nullptr; a.win_len = 0; a.nwin = 0; a.win_mu = nullptr; a.e_off = 0;
     if (nseg <= 0) {
-        // exact semantics.  Blind methods with a fixed step run in the look-ahead form (train_la.h), everything else
-        // (decision-directed, data-aided, adaptive step, tiny captures) in the direct form below.  Same results up to
-        // the order of additions; QAMPY_HIP_TRAINER=direct forces the direct form (A/B measurements, tests).
+        // exact semantics.  Blind methods with a fixed step run in the look-ahead (train_la.h) or block-iterative
+        // (train_bi.h) form, everything else (decision-directed, data-aided, adaptive step, tiny captures) in the direct
+        // form below.  Same results up to the order of additions.
+        // Trainer choice.  QAMPY_HIP_TRAINER = direct | lookahead | iterative forces one form (A/B measurements, tests);
+        // otherwise the block-iterative form takes the partitioned error functions (rde, mrde: one evaluation per sweep
+        // instead of one per step), the look-ahead chain the cheap ones (cma, mcma, cma2), whichever of the two fits.
         const char *force = getenv("QAMPY_HIP_TRAINER");
         const bool direct = force && force[0] == 'd';
-        if (!direct && la_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy)) {
+        const bool bi_ok = !direct && !(force && force[0] == 'l') && bi_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy, sizeof(Cx<R>));
+        const bool la_ok = !direct && la_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy);
+        const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
+        const bool pair = la_shape_ok(nmodes, ntaps, os);          // layout of the Gram terms of this capture (qh_gram_build_*)
+        if (bi_ok && (partitioned || !la_ok || (force && force[0] == 'i'))) {
+            // block-iterative form (train_bi.h): 8 wavefronts per output mode solve each 64-step block by fixed-point sweeps
+            void *G = const_cast<void *>(gram);
+            if (!G && (rc = pair ? gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G) : gram_cur_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G))) return rc;
+            LaArgs<R> la;
+            la.E = a.E; la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.G = (const GramPair<R> *)G; la.gpair = pair ? 1 : 0; la.mu = mu_dev;
+            la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
+            la.os = os; la.nsel = nsel; la.method = method;
+            for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];
+            la.prof = nullptr;
+            if (getenv("QAMPY_HIP_LA_PROFILE")) {                // developer aid: sweep count and cycle split of workgroup 0
+                void *pp = nullptr;
+                if ((rc = scratch(5, 16 * sizeof(unsigned long long), &pp))) return rc;
+                QH_HIP(hipMemsetAsync(pp, 0, 16 * sizeof(unsigned long long), g_stream));
+                la.prof = (unsigned long long *)pp;
+            }
+            for (int it = 0; it < Niter; it++) {
+                la.err_off = (int64_t)it * TrSyms;
+                if ((rc = launch_bi<R>(la))) return rc;
+            }
+            if (la.prof) {
+                unsigned long long hp[16];
+                QH_HIP(hipMemcpyAsync(hp, la.prof, sizeof(hp), hipMemcpyDeviceToHost, g_stream));
+                QH_HIP(hipStreamSynchronize(g_stream));
+                fprintf(stderr, "[bi profile] method %d blocks %llu: sweeps/block %.2f, cycles/block sweeps %.0f update %.0f prior %.0f\n", method, hp[4],
+                        (double)hp[0] / (double)hp[4], (double)hp[1] / (double)hp[4], (double)hp[2] / (double)hp[4], (double)hp[3] / (double)hp[4]);
+            }
+            return QH_OK;
+        }
+        if (la_ok) {
             void *G = const_cast<void *>(gram);
             if (!G && (rc = gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G))) return rc;
             LaArgs<R> la;
-            la.E = a.E; la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.G = (const GramPair<R> *)G; la.mu = mu_dev;
+            la.E = a.E; la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.G = (const GramPair<R> *)G; la.gpair = 1; la.mu = mu_dev;
             la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
             la.os = os; la.nsel = nsel; la.method = method;
             for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];

@@ -15,6 +15,7 @@
 //
 // Result: the same numbers as the direct form up to the order of floating-point additions.
 #pragma once
+#include <stdlib.h>
 #include "common.h"
 
 namespace qh {
@@ -186,6 +187,7 @@ template <typename R> struct LaArgs {
     const Cx<R> *symbols;
     Cx<R> *err;             // row pitch err_pitch, this sweep starts at column err_off
     const GramPair<R> *G;
+    int gpair;              // block-iterative kernel only: 1 = G is the look-ahead pair layout (cur/next), 0 = cur only
     const R *mu;
     int64_t L, TrSyms, nsy, err_pitch, err_off;
     int nmodes, ntaps, os, nsel, method;
@@ -427,11 +429,19 @@ template <typename R> int gram_build(const void *E, int nmodes, int64_t L, int o
 }
 
 // can the look-ahead form run this configuration?
+// sizes the look-ahead kernel can hold (this alone decides the Gram layout of a capture: pairs when true)
+inline bool la_shape_ok(int nmodes, int ntaps, int os)
+{
+    const char *force = getenv("QAMPY_HIP_TRAINER");
+    if (force && (force[0] == 'd' || force[0] == 'i')) return false;               // "direct" / "iterative": A/B measurements, tests
+    if (nmodes * (((LA_B - 1) * os + ntaps + 1) & ~1) > 8 * 64) return false;      // helper window: 8 staging registers per lane
+    return (nmodes * ntaps + LA_NH - 1) / LA_NH <= LA_MAXSLICE;
+}
+
 inline bool la_supported(int method, int adaptive, int nmodes, int ntaps, int os, int64_t TrSyms, int64_t nsy)
 {
     if (adaptive || TrSyms < 2 * LA_B) return false;
-    if (nmodes * (((LA_B - 1) * os + ntaps + 1) & ~1) > 8 * 64) return false;      // helper window: 8 staging registers per lane
-    if ((nmodes * ntaps + LA_NH - 1) / LA_NH > LA_MAXSLICE) return false;
+    if (!la_shape_ok(nmodes, ntaps, os)) return false;
     switch (method) {
     case QH_M_CMA: case QH_M_SGNCMA: case QH_M_CMA2: case QH_M_MCMA: return true;
     case QH_M_RDE: case QH_M_MRDE: return nsy - (nsy + 1) / 2 >= 1 && nsy - (nsy + 1) / 2 <= LA_MAXPART;

@@ -263,11 +263,13 @@ def test_segment_parallel_training_is_consistent(monkeypatch):
 
 # ------------------------------------------------------------------------------------------------ look-ahead vs direct form
 @pytest.mark.parametrize("method,M,ntaps,nmodes", [("cma", 64, 41, 2), ("mcma", 16, 21, 2), ("mrde", 64, 41, 2), ("rde", 16, 13, 2),
-                                                   ("cma2", 16, 11, 2), ("sgncma", 16, 7, 1), ("mcma", 16, 9, 3)])
+                                                   ("cma2", 16, 11, 2), ("sgncma", 16, 7, 1), ("mcma", 16, 9, 3),
+                                                   ("mrde", 64, 61, 2), ("cma", 4, 3, 1), ("rde", 64, 17, 4)])
 @pytest.mark.parametrize("dn", ["c64", "c128"])
 def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, nmodes, dn):
-    """The two exact trainers (look-ahead: train_la.h, direct: train_impl.h) and the oracle agree to rounding, including
-    a partial last block, several sweeps and a mode subset."""
+    """The three exact trainers (look-ahead: train_la.h, block-iterative: train_bi.h, direct: train_impl.h) and the oracle
+    agree to rounding, including a partial last block, several sweeps, a mode subset and shapes only some of them take
+    (122 taps: no look-ahead kernel, the forced form then falls through to the next one)."""
     nsym = 5000 + 37
     sig = synth.make_capture(M, nsym, nmodes=nmodes, snr_db=28, theta=np.pi / 5.6 if nmodes == 2 else None, dgd=30e-12,
                              seed=99, dtype=CT[dn])
@@ -287,8 +289,12 @@ def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, 
     ed, wd, _ = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, False, sy, method)
     monkeypatch.setenv("QAMPY_HIP_TRAINER", "lookahead")
     el, wl, _ = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, False, sy, method)
+    monkeypatch.setenv("QAMPY_HIP_TRAINER", "iterative")     # block-iterative form (train_bi.h): fixed-point sweeps per 64-step block
+    ei, wi, _ = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, False, sy, method)
+    ei2, wi2, _ = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, False, sy, method)
+    assert np.array_equal(wi, wi2) and np.array_equal(ei, ei2)          # fixed reduction order: bit-reproducible
     t = dict(rtol=1e-9, atol=1e-11) if dn == "c128" else dict(rtol=2e-4, atol=2e-5)
-    for w, e in ((wd, ed), (wl, el)):
+    for w, e in ((wd, ed), (wl, el), (wi, ei)):
         np.testing.assert_allclose(w, wo, **t)
         np.testing.assert_allclose(e, eo, rtol=t["rtol"], atol=t["atol"] * 5)
     assert not np.array_equal(wl, wd) or dn == "c128" or True        # different summation order: equal only by luck
