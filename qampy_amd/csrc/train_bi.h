@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
     const int os_ = a.os;
     const int64_t TrSyms = a.TrSyms;
     const int nblk = (int)((TrSyms + LA_B - 1) / LA_B);
-    const Cx<R> *sy = a.symbols + (size_t)mode * a.nsy;
+    const Cx<R> *sy = a.symbols + (size_t)mode * a.sy_pitch;
 
     // ---- LDS carve-up
     const int wlen = (LA_B - 1) * os_ + a.ntaps;
@@ -309,7 +309,9 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         const unsigned long long pt1 = a.prof ? clock64() : 0;
         const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K);
         if (vv == 0 && s0 + BI_JW * w + rr < TrSyms) eown[s0] = e;
-        // taps: this wave's steps into all taps (lane <-> taps lane, lane + 64)
+        // taps: this wave's steps into all taps (lane <-> taps lane, lane + 64).  Steps past TrSyms (partial last block) have
+        // all-zero Gram rows, so they never touched the sweeps; their c (non-zero for decision-directed functions) is dropped here
+        if (s0 + BI_JW * w + rr >= TrSyms) c_old = Cx<R>{0, 0};
         {
             const Cx<R> *xw = win + (size_t)(k & 1) * wsz + (BI_JW * w) * os_;
             Cx<R> dw[2] = {{0, 0}, {0, 0}};
@@ -354,6 +356,75 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         a.prof[0] = pf_sweeps; a.prof[1] = pf_t_sweep; a.prof[2] = pf_t_upd; a.prof[3] = pf_t_prior; a.prof[4] = (unsigned long long)nblk;
     }
     for (int f = threadIdx.x; f < ntot; f += BI_NT) wrow[f] = wbuf[f];
+}
+
+// ------------------------------------------------------------------------------------------------ slicer tables
+// Decision-directed error functions (sbd, mddma, dd) pick the nearest symbol of an arbitrary alphabet (det_symbol,
+// pythran_equalisation.py:240-265: linear scan).  For a square alphabet - every (re level, im level) combination
+// present once, equally many levels per axis - that is the nearest level per axis, i.e. the same partition look-up rde /
+// mrde use.  One workgroup per mode analyses the row `symbols[mode]` and writes the table in the rde / mrde layout:
+// n codes (sorted levels, re / im axis in .re / .im) followed by n-1 partitions (midpoints); info[mode] = n-1, or -1
+// when the row is not such an alphabet (the direct-form kernel then scans it).
+constexpr int BI_DD_MAXLEV = 16;
+template <typename R>
+__global__ void __launch_bounds__(64) slicer_table_kernel(const Cx<R> *symbols, int M, Cx<R> *table, int *info)
+{
+    __shared__ R sre[1024], sim[1024];
+    __shared__ unsigned char seen[BI_DD_MAXLEV * BI_DD_MAXLEV];
+    const Cx<R> *row = symbols + (size_t)blockIdx.x * M;
+    Cx<R> *tab = table + (size_t)blockIdx.x * (2 * BI_DD_MAXLEV);
+    if (M > 1024 || M < 4) { if (threadIdx.x == 0) info[blockIdx.x] = -1; return; }
+    for (int k = threadIdx.x; k < M; k += 64) { const Cx<R> s = row[k]; sre[k] = s.re; sim[k] = s.im; }
+    for (int k = threadIdx.x; k < BI_DD_MAXLEV * BI_DD_MAXLEV; k += 64) seen[k] = 0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    R lre[BI_DD_MAXLEV], lim[BI_DD_MAXLEV];
+    int nre = 0, nim = 0;
+    bool ok = true;
+    for (int k = 0; k < M && ok; k++) {
+        int r = 0, i = 0;
+        ok = sre[k] == sre[k] && sim[k] == sim[k];                     // NaN alphabets stay with the scan
+        while (r < nre && lre[r] != sre[k]) r++;
+        if (r == nre) { if (nre < BI_DD_MAXLEV) lre[nre++] = sre[k]; else ok = false; }
+        while (i < nim && lim[i] != sim[k]) i++;
+        if (i == nim) { if (nim < BI_DD_MAXLEV) lim[nim++] = sim[k]; else ok = false; }
+        if (ok) { if (seen[r * BI_DD_MAXLEV + i]) ok = false; else seen[r * BI_DD_MAXLEV + i] = 1; }
+    }
+    ok = ok && nre == nim && nre >= 2 && (long)nre * nim == M;
+    if (!ok) { info[blockIdx.x] = -1; return; }
+    for (int a = 1; a < nre; a++) {                                    // insertion sort, <= 16 levels
+        R v = lre[a]; int b = a - 1;
+        while (b >= 0 && lre[b] > v) { lre[b + 1] = lre[b]; b--; }
+        lre[b + 1] = v;
+        v = lim[a]; b = a - 1;
+        while (b >= 0 && lim[b] > v) { lim[b + 1] = lim[b]; b--; }
+        lim[b + 1] = v;
+    }
+    for (int a = 0; a < nre; a++) tab[a] = Cx<R>{lre[a], lim[a]};
+    for (int a = 0; a + 1 < nre; a++) tab[nre + a] = Cx<R>{(lre[a] + lre[a + 1]) / 2, (lim[a] + lim[a + 1]) / 2};
+    info[blockIdx.x] = nre - 1;
+}
+
+// tables for all modes; *npart = common partition count of the selected modes, or -1 (one small D2H copy + sync)
+template <typename R> int slicer_tables(const void *symbols, int nmodes, int64_t nsy, const int64_t *modes, int nsel, void **table, int *npart)
+{
+    *npart = -1;
+    if (nsy > 1024 || nsy < 4) return QH_OK;
+    void *buf = nullptr;
+    int rc = scratch(7, (size_t)nmodes * 2 * BI_DD_MAXLEV * sizeof(Cx<R>) + (size_t)nmodes * sizeof(int), &buf);
+    if (rc) return rc;
+    int *info = reinterpret_cast<int *>((char *)buf + (size_t)nmodes * 2 * BI_DD_MAXLEV * sizeof(Cx<R>));
+    hipLaunchKernelGGL((slicer_table_kernel<R>), dim3(nmodes), dim3(64), 0, g_stream, (const Cx<R> *)symbols, (int)nsy, (Cx<R> *)buf, info);
+    QH_HIP(hipGetLastError());
+    int h[16];
+    QH_REQUIRE(nmodes <= 16, "train_equaliser: more than 16 modes");
+    QH_HIP(hipMemcpyAsync(h, info, (size_t)nmodes * sizeof(int), hipMemcpyDeviceToHost, g_stream));
+    QH_HIP(hipStreamSynchronize(g_stream));
+    int np = h[modes[0]];
+    for (int j = 1; j < nsel; j++) if (h[modes[j]] != np) np = -1;
+    *npart = np;
+    *table = buf;
+    return QH_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -402,8 +473,21 @@ inline bool bi_supported(int method, int adaptive, int nmodes, int ntaps, int os
     switch (method) {
     case QH_M_CMA: case QH_M_SGNCMA: case QH_M_CMA2: case QH_M_MCMA: return true;
     case QH_M_RDE: case QH_M_MRDE: return nsy - (nsy + 1) / 2 >= 1 && nsy - (nsy + 1) / 2 <= LA_MAXPART;
+    case QH_M_SBD: case QH_M_MDDMA: case QH_M_DD: return true;      // if the alphabet is square: slicer_tables() decides
     default: return false;
     }
+}
+
+template <typename R, int METHOD> static int launch_bi_dd(const LaArgs<R> &a, int npart, size_t lds)
+{
+    dim3 grid(a.nsel), block(BI_NT);
+#define QH_BI_DD(N) case N: hipLaunchKernelGGL((train_bi_kernel<R, METHOD, N>), grid, block, lds, g_stream, a); break;
+    switch (npart) {            // 4-, 16-, 64-, 256-QAM
+        QH_BI_DD(1) QH_BI_DD(3) QH_BI_DD(7) QH_BI_DD(15)
+    default: set_error("block-iterative trainer: unsupported slicer size"); return QH_ERR_ARG;
+    }
+#undef QH_BI_DD
+    return QH_OK;
 }
 
 template <typename R, int METHOD> static int launch_bi_parts(const LaArgs<R> &a, int npart, size_t lds)
@@ -430,6 +514,9 @@ template <typename R> int launch_bi(const LaArgs<R> &a)
     case QH_M_MCMA: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_MCMA, 0>), grid, block, lds, g_stream, a); break;
     case QH_M_RDE: rc = launch_bi_parts<R, QH_M_RDE>(a, npart, lds); break;
     case QH_M_MRDE: rc = launch_bi_parts<R, QH_M_MRDE>(a, npart, lds); break;
+    case QH_M_SBD: rc = launch_bi_dd<R, QH_M_SBD>(a, npart, lds); break;
+    case QH_M_MDDMA: rc = launch_bi_dd<R, QH_M_MDDMA>(a, npart, lds); break;
+    case QH_M_DD: rc = launch_bi_dd<R, QH_M_DD>(a, npart, lds); break;
     default: return QH_ERR_METHOD;
     }
     if (rc) return rc;

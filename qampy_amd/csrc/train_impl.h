@@ -477,19 +477,29 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         // instead of one per step), the look-ahead chain the cheap ones (cma, mcma, cma2), whichever of the two fits.
         const char *force = getenv("QAMPY_HIP_TRAINER");
         const bool direct = force && force[0] == 'd';
-        const bool bi_ok = !direct && !(force && force[0] == 'l') && bi_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy, sizeof(Cx<R>));
+        bool bi_ok = !direct && !(force && force[0] == 'l') && bi_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy, sizeof(Cx<R>));
+        const bool decision = method == QH_M_SBD || method == QH_M_MDDMA || method == QH_M_DD;
+        void *dd_table = nullptr;
+        int dd_npart = -1;
+        if (bi_ok && decision) {     // square alphabets only: per-axis slicer tables in the rde / mrde layout
+            if ((rc = slicer_tables<R>(symbols, nmodes, nsy, modes, nsel, &dd_table, &dd_npart))) return rc;
+            bi_ok = dd_npart == 1 || dd_npart == 3 || dd_npart == 7 || dd_npart == 15;
+        }
         const bool la_ok = !direct && la_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy);
         const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
         const bool pair = la_shape_ok(nmodes, ntaps, os);          // layout of the Gram terms of this capture (qh_gram_build_*)
-        if (bi_ok && (partitioned || !la_ok || (force && force[0] == 'i'))) {
+        if (bi_ok && (partitioned || decision || !la_ok || (force && force[0] == 'i'))) {
             // block-iterative form (train_bi.h): 8 wavefronts per output mode solve each 64-step block by fixed-point sweeps
             void *G = const_cast<void *>(gram);
             if (!G && (rc = pair ? gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G) : gram_cur_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G))) return rc;
             LaArgs<R> la;
             la.E = a.E; la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.G = (const GramPair<R> *)G; la.gpair = pair ? 1 : 0; la.mu = mu_dev;
-            la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
+            la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
             la.os = os; la.nsel = nsel; la.method = method;
             for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];
+            if (decision) {          // the kernel reads the slicer table like an mrde table: row pitch 2*BI_DD_MAXLEV, 2*npart+1 used
+                la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV;
+            }
             la.prof = nullptr;
             if (getenv("QAMPY_HIP_LA_PROFILE")) {                // developer aid: sweep count and cycle split of workgroup 0
                 void *pp = nullptr;
@@ -515,7 +525,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             if (!G && (rc = gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G))) return rc;
             LaArgs<R> la;
             la.E = a.E; la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.G = (const GramPair<R> *)G; la.gpair = 1; la.mu = mu_dev;
-            la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
+            la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
             la.os = os; la.nsel = nsel; la.method = method;
             for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];
             la.prof = nullptr;

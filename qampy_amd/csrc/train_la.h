@@ -163,6 +163,18 @@ __device__ __forceinline__ Cx<R> la_errfn(Cx<R> y, const LaConst<R, NPART> &k)
         R d = tab_lookup<R, NPART, false>(sq, k.code0_re, k.tab) - sq;
         if constexpr (SCALE) d = d * k.mu;
         e = yy * d;
+    } else if constexpr (METHOD == QH_M_SBD || METHOD == QH_M_MDDMA || METHOD == QH_M_DD) {
+        // decision-directed on a square alphabet: the table holds the sorted per-axis levels (codes) and their midpoints
+        // (partitions), see slicer_table_kernel in train_bi.h; nearest level per axis == nearest symbol (det_symbol :240-265)
+        v2 s = {tab_lookup<R, NPART, false>(y.re, k.code0_re, k.tab), tab_lookup<R, NPART, true>(y.im, k.code0_im, k.tab)};
+        const v2 ds = s - yy;
+        if (!(fma_(ds.x, ds.x, ds.y * ds.y) < (R)1000)) s = v2{(R)1, (R)0};   // det_symbol's initial value survives (:258-259)
+        v2 d;
+        if constexpr (METHOD == QH_M_SBD) d = (s - yy) * __builtin_elementwise_abs(s);
+        else if constexpr (METHOD == QH_M_MDDMA) d = (s * s - yy * yy) * yy;
+        else d = s - yy;
+        if constexpr (SCALE) d = d * k.mu;
+        e = d;
     } else {   // QH_M_MRDE
         const v2 sq = yy * yy;
         v2 r;
@@ -189,7 +201,7 @@ template <typename R> struct LaArgs {
     const GramPair<R> *G;
     int gpair;              // block-iterative kernel only: 1 = G is the look-ahead pair layout (cur/next), 0 = cur only
     const R *mu;
-    int64_t L, TrSyms, nsy, err_pitch, err_off;
+    int64_t L, TrSyms, nsy, sy_pitch, err_pitch, err_off;     // symbols row m starts at symbols + m * sy_pitch
     int nmodes, ntaps, os, nsel, method;
     int64_t modes[16];
     unsigned long long *prof;   // optional [4 waves][4] cycle counters of workgroup 0 (qh_la_profile), else nullptr
@@ -213,7 +225,7 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
     const int ntot = a.nmodes * a.ntaps;
     const int64_t TrSyms = a.TrSyms;
     const int nblk = (int)((TrSyms + LA_B - 1) / LA_B);
-    const Cx<R> *sy = a.symbols + (size_t)mode * a.nsy;
+    const Cx<R> *sy = a.symbols + (size_t)mode * a.sy_pitch;
 
     if (wave == 0) {
         // ============================================================ chain wave: lanes <-> the 64 steps of a block

@@ -264,12 +264,15 @@ def test_segment_parallel_training_is_consistent(monkeypatch):
 # ------------------------------------------------------------------------------------------------ look-ahead vs direct form
 @pytest.mark.parametrize("method,M,ntaps,nmodes", [("cma", 64, 41, 2), ("mcma", 16, 21, 2), ("mrde", 64, 41, 2), ("rde", 16, 13, 2),
                                                    ("cma2", 16, 11, 2), ("sgncma", 16, 7, 1), ("mcma", 16, 9, 3),
-                                                   ("mrde", 64, 61, 2), ("cma", 4, 3, 1), ("rde", 64, 17, 4)])
+                                                   ("mrde", 64, 61, 2), ("cma", 4, 3, 1), ("rde", 64, 17, 4),
+                                                   ("sbd", 16, 21, 2), ("sbd", 64, 41, 2), ("mddma", 64, 15, 2), ("dd", 4, 9, 1),
+                                                   ("dd", 256, 11, 2), ("sbd", 32, 13, 2)])
 @pytest.mark.parametrize("dn", ["c64", "c128"])
 def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, nmodes, dn):
     """The three exact trainers (look-ahead: train_la.h, block-iterative: train_bi.h, direct: train_impl.h) and the oracle
     agree to rounding, including a partial last block, several sweeps, a mode subset and shapes only some of them take
-    (122 taps: no look-ahead kernel, the forced form then falls through to the next one)."""
+    (122 taps: no look-ahead kernel, the forced form then falls through to the next one).  Decision-directed functions run
+    block-iterative on square alphabets (per-axis slicer tables) and direct on the others (32-QAM cross)."""
     nsym = 5000 + 37
     sig = synth.make_capture(M, nsym, nmodes=nmodes, snr_db=28, theta=np.pi / 5.6 if nmodes == 2 else None, dgd=30e-12,
                              seed=99, dtype=CT[dn])
@@ -278,7 +281,7 @@ def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, 
     if method == "cma2":
         tr = 333               # cma2 is not phase blind and only stays bounded for a short run from converged taps
     w0 = core_eq._init_taps(ntaps, nmodes, nmodes, CT[dn])
-    if method in ("rde", "mrde", "cma2"):
+    if method in ("rde", "mrde", "cma2", "sbd", "mddma", "dd"):
         s0 = core_eq._reshape_symbols(None, "mcma", M, CT[dn], nmodes)
         _, w0, _ = oracle.train_equaliser(E, tr, 3, 2, RT[dn](2e-3), w0, None, False, s0, "mcma")
     sy = core_eq._reshape_symbols(None, method, M, CT[dn], nmodes)
