@@ -189,8 +189,10 @@ def main():
     elapsed = sharding.reduce_max_time(elapsed, dist, device="cuda")
 
     # ---- results of the last step: SER against the transmitted symbols
-    res = rx.fetch()
-    errs = symbol_errors(res["out"] if cfg["A"] else res["eq"], sig)
+    # (on-device harness: alignment search + decisions + count in HBM, qh_ser_*_dev; nothing but 7 integers per row moves)
+    ser_rows = rx.ser(sig.symbols, maxlag=256, window=8192, trim=2000)
+    errs = [(d["errors"], d["compared"]) for d in ser_rows]
+    res = dict(wxy=rx.wxy.to_host())
     counts_all = sharding.reduce_sum_counts([[e, n] for e, n in errs], dist, device="cuda")
 
     if rank != 0:
@@ -215,13 +217,14 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)))
         if args.train_mode == "exact" and args.nsym is None and 1 <= dom <= rx.nstage:
             mid = _lib.METHOD_ID[cfg["methods"][dom - 1]]
-            kname = [k for k in pmc["kernels"] if k.startswith("qh::train_la_kernel<float, %d," % mid)]
+            kname = [k for k in pmc["kernels"] if k.startswith("qh::train_la_kernel<float, %d," % mid)
+                     or k.startswith("qh::train_bi_kernel<float, %d," % mid)]
             traffic = pmc["kernels"][kname[0]]["hbm_bytes"] if kname else None
     except (OSError, KeyError, ValueError, IndexError):
         traffic = None
     roofline = dict(bound="hbm", kernel=stage_names[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, algorithmic_bytes=int(stage_bytes[dom]),
-                    note=("exact sequential LMS chain: single-wave dependent-issue bound, 1 wave per output mode (DESIGN.md)"
+                    note=("exact sequential LMS recurrence: dependent-issue / barrier-latency bound, one workgroup per output mode (DESIGN.md 3.1)"
                           if args.train_mode == "exact" and 1 <= dom <= rx.nstage else "see DESIGN.md"))
 
     out = dict(metric="equalised MSym/s (2-pol, 2 SPS)", value=round(value, 4), unit="MSym/s", n_gpus=world, steps=args.steps,

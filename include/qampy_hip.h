@@ -183,6 +183,17 @@ int qh_make_decision_c128_dev(const void *E, int64_t L, const void *symbols, int
 int qh_count_errors_dev(const int32_t *idx_rx, const int32_t *idx_tx, int64_t n, int64_t lag, int64_t ntx,
                         unsigned long long *count_dev);
 
+/* On-device SER harness (reference: cal_ser core/signals.py:295-335 = sync_and_adjust /
+ * find_sequence_offset_complex core/ber_functions.py:33-160 + make_decision + compare).  E: one recovered row (N,) in
+ * HBM; idx_tx: decided indices of the transmitted symbols (nmodes, ntx) int32 in HBM (qh_make_decision_*_dev); symbols
+ * (M,) in HBM.  Bounded search over tx mode x quadrant rotation x lag in [-maxlag, maxlag] on a `window` of decided
+ * symbols from the middle of the run, then errors over [trim, N - trim).  result (HOST, 7 x int64): errors, compared,
+ * tx mode, rotation k (row was multiplied by j^k), lag (rx[i] <-> tx[i - lag]), matches in the window, window length. */
+int qh_ser_c64_dev(const void *E, int64_t N, const int32_t *idx_tx, int nmodes, int64_t ntx, const void *symbols, int M,
+                   int maxlag, int64_t window, int64_t trim, int64_t *result);
+int qh_ser_c128_dev(const void *E, int64_t N, const int32_t *idx_tx, int nmodes, int64_t ntx, const void *symbols, int M,
+                    int maxlag, int64_t window, int64_t trim, int64_t *result);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,8 @@ SIGNATURES = {
     "qh_make_decision_c64": _DECIDE, "qh_make_decision_c128": _DECIDE,
     "qh_make_decision_c64_dev": _DECIDE, "qh_make_decision_c128_dev": _DECIDE,
     "qh_count_errors_dev": [_vp, _vp, _i64, _i64, _i64, _vp],
+    "qh_ser_c64_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
+    "qh_ser_c128_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
 }
 
 _lib = None

@@ -1,7 +1,8 @@
 """
 Sequence alignment helpers of the pilot receiver / SER harness, behaviour of ``qampy.core.ber_functions``
 (qampy/core/ber_functions.py:33-106): delay of one sequence inside another from the peak of their full cross-correlation,
-trying the four quarter-turn rotations for complex data.  Host-side numpy/scipy (a few thousand samples per call).
+trying the four quarter-turn rotations for complex data.  Host-side numpy/scipy (a few thousand samples per call).  :func:`cal_ser_dev` is the device-resident counterpart of
+``SignalQAM.cal_ser`` (qampy/core/signals.py:295-335) for captures that stay in HBM.
 """
 import numpy as np
 from scipy.signal import fftconvolve
@@ -29,3 +30,48 @@ def find_sequence_offset_complex(x, y):
         if peak > best:
             best, best_i, best_idx = peak, i, idx
     return best_idx, y * 1.j ** best_i, best_i, best
+
+
+def tx_indices_dev(symbols_tx, alphabet):
+    """Decided indices of the transmitted symbols ``(nmodes, Nsym)`` as an int32 DeviceArray (once per capture)."""
+    from .. import _lib
+    from .equalisation import hip_equalisation as hk
+    tx = symbols_tx if isinstance(symbols_tx, _lib.DeviceArray) else _lib.DeviceArray.from_host(np.ascontiguousarray(symbols_tx))
+    alpha = alphabet if isinstance(alphabet, _lib.DeviceArray) else _lib.DeviceArray.from_host(
+        np.ascontiguousarray(alphabet, dtype=tx.dtype))
+    idx = _lib.DeviceArray(tx.shape, np.int32)
+    hk.make_decision_dev(tx, alpha, None, None, idx)
+    return idx
+
+
+def cal_ser_dev(out, idx_tx, alphabet, maxlag=256, window=4096, trim=0):
+    """
+    Symbol error rate of recovered rows that live in HBM, without moving them to the host.
+
+    What ``cal_ser`` does on the host - synchronise with the transmitted sequence over the four quarter-turn rotations
+    (``sync_and_adjust`` / ``find_sequence_offset_complex``, ber_functions.py:33-160), decide, compare - as a bounded-lag
+    search on decided indices plus one counting pass (``qh_ser_*_dev``).
+
+    Parameters
+    ----------
+    out : DeviceArray (nrows, N) complex
+    idx_tx : DeviceArray (nmodes, Nsym) int32 from :func:`tx_indices_dev`
+    alphabet : DeviceArray (M,) complex, same dtype as ``out``
+    maxlag : largest |lag| (symbols) searched;  window : symbols used for the search;  trim : symbols ignored at both ends
+
+    Returns
+    -------
+    list of dicts per row: ``errors, compared, ser, tx_mode, rotation, lag, window_matches, window``
+    """
+    from .. import _lib
+    suf = "c64" if np.dtype(out.dtype) == np.complex64 else "c128"
+    nrows, N = out.shape
+    nmodes, ntx = idx_tx.shape
+    res = []
+    for r in range(nrows):
+        h = np.zeros(7, np.int64)
+        _lib.call("qh_ser_%s_dev" % suf, out.row(r).ptr, N, idx_tx.ptr, nmodes, ntx, alphabet.ptr, int(np.prod(alphabet.shape)),
+                  int(maxlag), int(window), int(trim), _lib.ptr(h))
+        res.append(dict(errors=int(h[0]), compared=int(h[1]), ser=float(h[0]) / max(int(h[1]), 1), tx_mode=int(h[2]),
+                        rotation=int(h[3]), lag=int(h[4]), window_matches=int(h[5]), window=int(h[6])))
+    return res

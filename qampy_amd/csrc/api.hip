@@ -50,8 +50,8 @@ int ensure_init()
 }
 
 // grow-only scratch slots so that the resident pipeline never allocates (and never synchronises) inside a timed region
-static void *g_scratch[8] = {nullptr};
-static size_t g_scratch_n[8] = {0};
+static void *g_scratch[12] = {nullptr};
+static size_t g_scratch_n[12] = {0};
 int scratch(int slot, size_t bytes, void **p)
 {
     if (bytes > g_scratch_n[slot]) {

@@ -456,8 +456,8 @@ __global__ void __launch_bounds__(256) make_decision_kernel(const Cx<R> *E, int6
         const R d = hypot_<R>(x.re - s.re, x.im - s.im);
         if (d < best) { best = d; ib = k; s0 = s; }
     }
-    stg(det + i, s0);
-    dist[i] = best;
+    if (det) stg(det + i, s0);             // det / dist are optional for device-resident callers
+    if (dist) dist[i] = best;
     idx[i] = ib;
 }
 

@@ -129,6 +129,19 @@ class ResidentReceiver:
             res.update(out=self.out.to_host(), ph=self.ph.to_host(), idx=self.idx.to_host())
         return res
 
+    def ser(self, symbols_tx, maxlag=256, window=4096, trim=0):
+        """Symbol error rate of the recovered (else equalised) rows against the transmitted symbols, computed in HBM
+        (``qampy_amd.core.ber_functions.cal_ser_dev``); needs the alphabet.  Returns one dict per row."""
+        from .core import ber_functions as _ber
+        if self.alphabet_host is None:
+            raise ValueError("ser() needs the alphabet")
+        if getattr(self, "alphabet", None) is None:
+            self.alphabet = DeviceArray.from_host(self.alphabet_host)
+        if getattr(self, "_idx_tx", None) is None or self._idx_tx_src is not symbols_tx:
+            self._idx_tx = _ber.tx_indices_dev(np.ascontiguousarray(symbols_tx, dtype=self.ct), self.alphabet)
+            self._idx_tx_src = symbols_tx
+        return _ber.cal_ser_dev(self.out if self.Mtestangles else self.eq, self._idx_tx, self.alphabet, maxlag, window, trim)
+
     def bytes_per_symbol(self):
         """Algorithmic HBM bytes per symbol period of one run() (general formula)."""
         cs = np.dtype(self.ct).itemsize

@@ -1,10 +1,17 @@
 #!/usr/bin/env python3
 """Per-kernel average of rocprofv3 PMC counters (rocpd sqlite databases, one per --pmc pass) -> text for profiles/."""
+import json
 import sqlite3
 import sys
 
+args = sys.argv[1:]
+json_out = workload = None
+if "--json" in args:                       # --json OUT.json WORKLOAD: per-launch HBM bytes for bench.py's roofline.traffic
+    i = args.index("--json")
+    json_out, workload = args[i + 1], args[i + 2]
+    del args[i:i + 3]
 rows = {}
-for path in sys.argv[1:]:
+for path in args:
     db = sqlite3.connect(path)
     try:
         cur = db.execute("select name, counter_name, count(*), avg(counter_value), sum(counter_value) from pmc_events "
@@ -19,3 +26,17 @@ for path in sys.argv[1:]:
 print("%-90s %-12s %6s %16s %18s" % ("kernel", "counter", "calls", "avg", "total"))
 for (name, ctr), (n, avg, tot) in sorted(rows.items(), key=lambda kv: -kv[1][2]):
     print("%-90s %-12s %6d %16.1f %18.1f" % (name[:90], ctr, n, avg, tot))
+
+if json_out:
+    kern = {}
+    for (name, ctr), (n, avg, tot) in rows.items():
+        short = name[5:] if name.startswith("void ") else name
+        short = short.split("(")[0]
+        kern.setdefault(short, {})[ctr + "_KB"] = round(avg, 1)
+    for k, v in kern.items():
+        v["hbm_bytes"] = int((2 * v.get("FETCH_SIZE_KB", 0.) + v.get("WRITE_SIZE_KB", 0.)) * 1024)
+    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (scripts/gpu_pmc.sh), KB per launch. hbm_bytes applies the "
+            "gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128 B request for coalesced streams -> x2; "
+            "confirmed here on apply/bps/make_decision/gram whose known read volume is exactly 2x the counter); WRITE_SIZE "
+            "matched the known 4 GiB of gram_kernel 1:1.")
+    json.dump(dict(workload=workload, note=note, kernels=kern), open(json_out, "w"), indent=1)

@@ -135,3 +135,51 @@ def test_resident_receiver_full_c2_pass():
     assert np.all(np.isfinite(res["wxy"])) and np.all(np.abs(res["err"][0][:, -1000:]) > 0)
     ser = synth.cal_ser(res["out"][:, 2000:-2000][:, :2 ** 17], sig.symbols, sig.coded_symbols, max_lag=4096)
     assert ser.max() < 1e-3, ser
+
+
+# ------------------------------------------------------------------------------------------------ on-device SER harness (8f.2)
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_device_ser_harness_matches_host_count(dtype):
+    """qh_ser_*_dev (bounded-lag search on decided indices + counting pass in HBM) finds the same tx mode, rotation and lag
+    as the host cross-correlation and counts exactly the same symbol errors (cal_ser semantics, core/signals.py:295-335)."""
+    from qampy_amd._lib import DeviceArray
+    from qampy_amd.core import ber_functions as ber
+    rng = np.random.default_rng(5)
+    M, n = 16, 30000
+    sig = synth.make_capture(M, n + 64, nmodes=2, snr_db=17, seed=11, dtype=dtype)
+    tx = np.asarray(sig.symbols)
+    alphabet = np.ascontiguousarray(sig.coded_symbols, dtype=dtype)
+    noise = (rng.normal(size=(2, n)) + 1j * rng.normal(size=(2, n))) * 0.12
+    # row 0: tx mode 1 delayed by 7 symbols and rotated by -j;  row 1: tx mode 0 advanced by 19 symbols, rotated by -1
+    rx = np.empty((2, n), dtype)
+    rx[0] = (np.roll(tx[1], 7)[:n] * (-1j) + noise[0]).astype(dtype)
+    rx[1] = (np.roll(tx[0], -19)[:n] * (-1) + noise[1]).astype(dtype)
+    d_rx, d_al = DeviceArray.from_host(rx), DeviceArray.from_host(alphabet)
+    idx_tx = ber.tx_indices_dev(np.ascontiguousarray(tx, dtype=dtype), d_al)
+    res = ber.cal_ser_dev(d_rx, idx_tx, d_al, maxlag=64, window=2048, trim=100)
+    for r, row in zip(res, rx):
+        nerr, ncmp, mode, rot, lag = synth.count_symbol_errors(row, tx, alphabet, max_lag=64, trim=0)
+        assert (r["tx_mode"], r["rotation"], r["lag"]) == (mode, rot, lag)
+        # same decisions on [trim, n - trim)
+        d_r = synth.decide(row * np.exp(1j * rot * np.pi / 2), alphabet)[100:n - 100]
+        d_t = synth.decide(tx[mode], alphabet)[100 - lag:n - 100 - lag]
+        assert r["compared"] == d_r.size and r["errors"] == int(np.count_nonzero(d_r != d_t))
+        assert 0 < r["errors"] < 0.1 * r["compared"] and r["window_matches"] > 0.9 * r["window"]
+    assert (res[0]["tx_mode"], res[0]["rotation"], res[0]["lag"]) == (1, 1, 7)
+    assert (res[1]["tx_mode"], res[1]["rotation"], res[1]["lag"]) == (0, 2, -19)
+
+
+def test_resident_receiver_device_ser_equals_host_ser():
+    from qampy_amd.pipeline import ResidentReceiver
+    sig = synth.make_capture(16, 2 ** 16, nmodes=2, snr_db=22, theta=np.pi / 5.6, dgd=30e-12, linewidth=50e3, seed=1001,
+                             dtype=np.complex64)
+    rx = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (1e-3,), methods=("mcma",), Niter=(2,), adaptive_stepsize=(False,),
+                          TrSyms=(None,), Mtestangles=32, Nbps=20, alphabet=sig.coded_symbols)
+    rx.load(sig)
+    rx.run()
+    dev = rx.ser(sig.symbols, maxlag=256, trim=2000)
+    out = rx.fetch()["out"]
+    for d, row in zip(dev, out):
+        nerr, ncmp, mode, rot, lag = synth.count_symbol_errors(row, sig.symbols, sig.coded_symbols, max_lag=256, trim=2000)
+        assert (d["tx_mode"], d["rotation"]) == (mode, rot) and d["lag"] == lag + 2000      # host lag is relative to the trimmed row
+        assert abs(d["errors"] - nerr) <= 2 and abs(d["compared"] - ncmp) <= 2 * 256 + 4000, (d, nerr, ncmp)
