@@ -133,7 +133,28 @@ template <typename R> struct alignas(16) BiEnt { Cx<R> v; unsigned flag; unsigne
 constexpr int BI_NT = 64 * BI_W;         // threads per workgroup
 constexpr int BI_RPW = 64 / BI_W;        // rows (steps / taps) a wave reduces per ds_read: lanes = BI_RPW groups of BI_W
 
-template <typename R, int METHOD, int NPART>
+// Adaptive step size (adapt_step, pythran_equalisation.py:12-16, :171-172) inside the block-iterative form.  After step
+// i > 0 the reference keeps mu when both component products of err[i], err[i-1] are positive and else sets
+// mu <- mu / (1 + mu |err[i-1]|^2), i.e. 1/mu grows by |err[i-1]|^2: in r = 1/mu the recurrence is a PREFIX SUM of
+// decrements d_i that depend on the errors only.  Every sweep therefore re-derives the step sizes of its 64 steps from the
+// current errors (own rows: DPP prefix in a compact lane <-> row layout; other waves: their totals of the last sweep,
+// exchanged next to the contributions), c_i = e_i / r_i, and the fixed point is again the sequential recurrence's
+// (mu itself differs from the reference's float recurrence only by the rounding of 1/(r + d) vs mu/(1 + mu d)).
+template <typename R> struct alignas(16) BiAd { R S, er, ei, pad; };     // a wave's decrement total and last error of the sweep
+
+__device__ __forceinline__ float bperm(float v, int byte_addr)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ double bperm(double v, int byte_addr)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, (int)b), hi = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114;
+
+template <typename R, int METHOD, int NPART, bool ADAPT = false>
 __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
 {
     extern __shared__ __attribute__((aligned(16))) char bi_smem[];
@@ -154,6 +175,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
     Cx<R> *TW = reinterpret_cast<Cx<R> *>(P + 2 * LA_B * BI_PAD);      // [BI_MAXTAPS][BI_PAD] tap-update exchange
     Cx<R> *wbuf = TW + BI_MAXTAPS * BI_PAD;                            // [BI_MAXTAPS]      taps, wave-uniform reads
     Cx<R> *win = wbuf + BI_MAXTAPS;                                    // [2][nmodes][wpitch] sample windows (block parity)
+    BiAd<R> *adx = reinterpret_cast<BiAd<R> *>(win + 2 * wsz);         // [2][BI_W] adaptive-step exchange (ADAPT only)
 
     // ---- constants of the error function
     LaConst<R, NPART> K;
@@ -268,6 +290,11 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         wreg[t] = (BI_RPW * t + rr < nf) ? wbuf[f] : Cx<R>{0, 0};
     }
     Cx<R> *eown = errow + BI_JW * w + rr;                               // this group's slot of the error trace
+    // adaptive step: r = 1/mu at the start of the block, last error of the previous block, compact layout helpers
+    R r_blk = ADAPT ? (R)1 / K.mu : (R)0;
+    Cx<R> e_carry{0, 0};
+    const int cl = lane & 7;                                            // compact layout: lane <-> row (lane & 7) of this wave
+    const int csrc = cl * BI_W * 4;                                     // ds_bpermute byte address of that row's group
 
     unsigned long long pf_sweeps = 0, pf_t_sweep = 0, pf_t_upd = 0, pf_t_prior = 0;
     for (int k = 0; k < nblk; k++) {
@@ -280,25 +307,64 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         Cx<R> c_old{0, 0}, y{0, 0};
         unsigned changed = 1;
         // one sweep through exchange buffer `pb`; true when the fixed point has been reached
+        Cx<R> e_last{0, 0};                                             // ADAPT: own total / last error published with the next exchange
+        R S_own = 0;
+        R r_next = r_blk;
         auto sweep = [&](const int pb) -> bool {
             BiEnt<R> ent;
             ent.v = part; ent.flag = changed; ent.pad = 0;
             pw[pb] = ent;
+            if constexpr (ADAPT) adx[(pb ? BI_W : 0) + w] = BiAd<R>{S_own, e_last.re, e_last.im, 0};
             __syncthreads();
             const BiEnt<R> got = pr[pb];
             y = got.v;
             group_csum(y.re, y.im);                                        // y of row rr, identical in the lanes of the group
             if (a.prof) pf_sweeps++;
-            if (!__any(got.flag != 0)) return true;                        // nobody's c moved in the last sweep: y is the fixed point
-            const Cx<R> c_new = la_errfn<R, METHOD, NPART, true>(y, K);
-            {
+            Cx<R> c_new;
+            if constexpr (ADAPT) {
+                const BiAd<R> ax = adx[(pb ? BI_W : 0) + cl];               // lane <-> wave (lane & 7): totals of the last sweep
+                R below = cl < w ? ax.S : (R)0, all = ax.S;                  // decrements of the waves before this one / of the block
+                below += dpp_mov<DPP_QUAD_1032>(below);       all += dpp_mov<DPP_QUAD_1032>(all);
+                below += dpp_mov<DPP_QUAD_2301>(below);       all += dpp_mov<DPP_QUAD_2301>(all);
+                below += dpp_mov<DPP_ROW_HALF_MIRROR>(below); all += dpp_mov<DPP_ROW_HALF_MIRROR>(all);
+                r_next = r_blk + all;                                        // 1/mu after the block (final once converged)
+                if (!__any(got.flag != 0)) {                                 // converged: remember the block's last error
+                    e_carry = Cx<R>{readlane(ax.er, BI_W - 1), readlane(ax.ei, BI_W - 1)};
+                    return true;
+                }
+                const Cx<R> eprev0 = w == 0 ? e_carry : Cx<R>{readlane(ax.er, w > 0 ? w - 1 : 0), readlane(ax.ei, w > 0 ? w - 1 : 0)};
+                const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K);
+                const Cx<R> ec{bperm(e.re, csrc), bperm(e.im, csrc)};       // compact: lane <-> row cl
+                Cx<R> ep{dpp_mov<DPP_ROW_SHR1>(ec.re), dpp_mov<DPP_ROW_SHR1>(ec.im)};
+                if (cl == 0) ep = eprev0;
+                const int64_t gi = s0 + BI_JW * w + cl;                       // global step of the row
+                const bool keep = ec.re * ep.re > 0 && ec.im * ep.im > 0;
+                R d = (keep || gi == 0 || gi >= TrSyms) ? (R)0 : fma_(ep.re, ep.re, ep.im * ep.im);
+                R inc = d;                                                   // inclusive prefix over the 8 rows
+                { const R t = dpp_mov<DPP_ROW_SHR1>(inc); inc += cl >= 1 ? t : (R)0; }
+                { const R t = dpp_mov<DPP_ROW_SHR2>(inc); inc += cl >= 2 ? t : (R)0; }
+                { const R t = dpp_mov<DPP_ROW_SHR4>(inc); inc += cl >= 4 ? t : (R)0; }
+                const R r_row = (r_blk + below) + (inc - d);                 // 1/mu in force at this row's step
+                const R mu_row = (R)1 / r_row;
+                c_new = Cx<R>{mu_row * ec.re, mu_row * ec.im};
+                const R S_new = readlane(inc, BI_JW - 1);
+                const Cx<R> el_new{readlane(ec.re, BI_JW - 1), readlane(ec.im, BI_JW - 1)};
+                const unsigned long long mv = __builtin_amdgcn_ballot_w64(c_new.re != c_old.re || c_new.im != c_old.im);
+                changed = (unsigned)mv | (unsigned)(mv >> 32) | (S_new != S_own) | (el_new.re != e_last.re) | (el_new.im != e_last.im);
+                S_own = S_new; e_last = el_new;
+            } else {
+                if (!__any(got.flag != 0)) return true;                    // nobody's c moved in the last sweep: y is the fixed point
+                c_new = la_errfn<R, METHOD, NPART, true>(y, K);
                 const unsigned long long mv = __builtin_amdgcn_ballot_w64(c_new.re != c_old.re || c_new.im != c_old.im);
                 changed = (unsigned)mv | (unsigned)(mv >> 32);             // wave-uniform: non-zero when any own c moved
             }
             c_old = c_new;
             part = qpart;                                                  // own steps' contributions to every pending output
 #pragma unroll
-            for (int r = 0; r < BI_JW; r++) cfma<R>(part, readlane(c_new.re, BI_W * r), readlane(c_new.im, BI_W * r), g[r]);
+            for (int r = 0; r < BI_JW; r++) {
+                const int src = ADAPT ? r : BI_W * r;                      // compact layout holds row r in lane r
+                cfma<R>(part, readlane(c_new.re, src), readlane(c_new.im, src), g[r]);
+            }
             return false;
         };
         for (int it = 0; it <= LA_B + 2; it += 2) {
@@ -311,13 +377,14 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         if (vv == 0 && s0 + BI_JW * w + rr < TrSyms) eown[s0] = e;
         // taps: this wave's steps into all taps (lane <-> taps lane, lane + 64).  Steps past TrSyms (partial last block) have
         // all-zero Gram rows, so they never touched the sweeps; their c (non-zero for decision-directed functions) is dropped here
-        if (s0 + BI_JW * w + rr >= TrSyms) c_old = Cx<R>{0, 0};
+        if (s0 + BI_JW * w + (ADAPT ? cl : rr) >= TrSyms) c_old = Cx<R>{0, 0};
+        if constexpr (ADAPT) r_blk = r_next;
         {
             const Cx<R> *xw = win + (size_t)(k & 1) * wsz + (BI_JW * w) * os_;
             Cx<R> dw[2] = {{0, 0}, {0, 0}};
 #pragma unroll
             for (int r = 0; r < BI_JW; r++) {
-                const R cr = readlane(c_old.re, BI_W * r), ci = readlane(c_old.im, BI_W * r);
+                const R cr = readlane(c_old.re, ADAPT ? r : BI_W * r), ci = readlane(c_old.im, ADAPT ? r : BI_W * r);
 #pragma unroll
                 for (int s = 0; s < 2; s++) {
                     const Cx<R> x = xw[xo[s] + r * os_];
@@ -356,6 +423,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         a.prof[0] = pf_sweeps; a.prof[1] = pf_t_sweep; a.prof[2] = pf_t_upd; a.prof[3] = pf_t_prior; a.prof[4] = (unsigned long long)nblk;
     }
     for (int f = threadIdx.x; f < ntot; f += BI_NT) wrow[f] = wbuf[f];
+    if constexpr (ADAPT) if (threadIdx.x == 0) *a.mu_out = (R)1 / r_blk;
 }
 
 // ------------------------------------------------------------------------------------------------ slicer tables
@@ -453,7 +521,8 @@ template <typename R> int gram_cur_build(const void *E, int nmodes, int64_t L, i
 template <typename R> static size_t bi_lds_bytes(int nmodes, int ntaps, int os)
 {
     const int wpitch = ((LA_B - 1) * os + ntaps + 1) & ~1;
-    return (size_t)2 * LA_B * BI_PAD * sizeof(BiEnt<R>) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch) * sizeof(Cx<R>);
+    return (size_t)2 * LA_B * BI_PAD * sizeof(BiEnt<R>) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch) * sizeof(Cx<R>) +
+           2 * BI_W * sizeof(BiAd<R>);
 }
 
 // sizes the block-iterative kernel can hold (the Gram layout of a capture follows from this alone)
@@ -463,12 +532,13 @@ inline bool bi_shape_ok(int nmodes, int ntaps, int os, size_t elem)
     if (force && (force[0] == 'd' || force[0] == 'l')) return false;      // "direct" / "lookahead": A/B measurements, tests
     if (nmodes * ntaps > BI_MAXTAPS) return false;
     const int wpitch = ((LA_B - 1) * os + ntaps + 1) & ~1;
-    return (size_t)2 * LA_B * BI_PAD * (elem + 16) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch) * elem <= 64 * 1024;
+    return (size_t)2 * LA_B * BI_PAD * (elem + 16) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch) * elem + 2 * BI_W * 2 * elem <= 64 * 1024;
 }
 
 inline bool bi_supported(int method, int adaptive, int nmodes, int ntaps, int os, int64_t TrSyms, int64_t nsy, size_t elem)
 {
-    if (adaptive || TrSyms < 2 * LA_B) return false;
+    (void)adaptive;                       // the adaptive step runs in this form too (one mode after the other, mu carried)
+    if (TrSyms < 2 * LA_B) return false;
     if (!bi_shape_ok(nmodes, ntaps, os, elem)) return false;
     switch (method) {
     case QH_M_CMA: case QH_M_SGNCMA: case QH_M_CMA2: case QH_M_MCMA: return true;
@@ -478,10 +548,10 @@ inline bool bi_supported(int method, int adaptive, int nmodes, int ntaps, int os
     }
 }
 
-template <typename R, int METHOD> static int launch_bi_dd(const LaArgs<R> &a, int npart, size_t lds)
+template <typename R, int METHOD, bool ADAPT> static int launch_bi_dd(const LaArgs<R> &a, int npart, size_t lds)
 {
     dim3 grid(a.nsel), block(BI_NT);
-#define QH_BI_DD(N) case N: hipLaunchKernelGGL((train_bi_kernel<R, METHOD, N>), grid, block, lds, g_stream, a); break;
+#define QH_BI_DD(N) case N: hipLaunchKernelGGL((train_bi_kernel<R, METHOD, N, ADAPT>), grid, block, lds, g_stream, a); break;
     switch (npart) {            // 4-, 16-, 64-, 256-QAM
         QH_BI_DD(1) QH_BI_DD(3) QH_BI_DD(7) QH_BI_DD(15)
     default: set_error("block-iterative trainer: unsupported slicer size"); return QH_ERR_ARG;
@@ -490,10 +560,10 @@ template <typename R, int METHOD> static int launch_bi_dd(const LaArgs<R> &a, in
     return QH_OK;
 }
 
-template <typename R, int METHOD> static int launch_bi_parts(const LaArgs<R> &a, int npart, size_t lds)
+template <typename R, int METHOD, bool ADAPT> static int launch_bi_parts(const LaArgs<R> &a, int npart, size_t lds)
 {
     dim3 grid(a.nsel), block(BI_NT);
-#define QH_BI_NP(N) case N: hipLaunchKernelGGL((train_bi_kernel<R, METHOD, N>), grid, block, lds, g_stream, a); break;
+#define QH_BI_NP(N) case N: hipLaunchKernelGGL((train_bi_kernel<R, METHOD, N, ADAPT>), grid, block, lds, g_stream, a); break;
     switch (npart) {
         QH_BI_NP(1) QH_BI_NP(2) QH_BI_NP(3) QH_BI_NP(4) QH_BI_NP(5) QH_BI_NP(6) QH_BI_NP(7) QH_BI_NP(8)
     default: set_error("block-iterative trainer: unsupported partition count"); return QH_ERR_ARG;
@@ -502,26 +572,32 @@ template <typename R, int METHOD> static int launch_bi_parts(const LaArgs<R> &a,
     return QH_OK;
 }
 
-template <typename R> int launch_bi(const LaArgs<R> &a)
+template <typename R, bool ADAPT> static int launch_bi_t(const LaArgs<R> &a)
 {
     dim3 grid(a.nsel), block(BI_NT);
     const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
     const size_t lds = bi_lds_bytes<R>(a.nmodes, a.ntaps, a.os);
     int rc = QH_OK;
     switch (a.method) {
-    case QH_M_CMA: case QH_M_SGNCMA: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_CMA, 0>), grid, block, lds, g_stream, a); break;
-    case QH_M_CMA2: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_CMA2, 0>), grid, block, lds, g_stream, a); break;
-    case QH_M_MCMA: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_MCMA, 0>), grid, block, lds, g_stream, a); break;
-    case QH_M_RDE: rc = launch_bi_parts<R, QH_M_RDE>(a, npart, lds); break;
-    case QH_M_MRDE: rc = launch_bi_parts<R, QH_M_MRDE>(a, npart, lds); break;
-    case QH_M_SBD: rc = launch_bi_dd<R, QH_M_SBD>(a, npart, lds); break;
-    case QH_M_MDDMA: rc = launch_bi_dd<R, QH_M_MDDMA>(a, npart, lds); break;
-    case QH_M_DD: rc = launch_bi_dd<R, QH_M_DD>(a, npart, lds); break;
+    case QH_M_CMA: case QH_M_SGNCMA: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_CMA, 0, ADAPT>), grid, block, lds, g_stream, a); break;
+    case QH_M_CMA2: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_CMA2, 0, ADAPT>), grid, block, lds, g_stream, a); break;
+    case QH_M_MCMA: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_MCMA, 0, ADAPT>), grid, block, lds, g_stream, a); break;
+    case QH_M_RDE: rc = launch_bi_parts<R, QH_M_RDE, ADAPT>(a, npart, lds); break;
+    case QH_M_MRDE: rc = launch_bi_parts<R, QH_M_MRDE, ADAPT>(a, npart, lds); break;
+    case QH_M_SBD: rc = launch_bi_dd<R, QH_M_SBD, ADAPT>(a, npart, lds); break;
+    case QH_M_MDDMA: rc = launch_bi_dd<R, QH_M_MDDMA, ADAPT>(a, npart, lds); break;
+    case QH_M_DD: rc = launch_bi_dd<R, QH_M_DD, ADAPT>(a, npart, lds); break;
     default: return QH_ERR_METHOD;
     }
     if (rc) return rc;
     QH_HIP(hipGetLastError());
     return QH_OK;
+}
+
+// adaptive: the caller launches one mode at a time (nsel = 1) so that mu is carried from mode to mode like in the reference
+template <typename R> int launch_bi(const LaArgs<R> &a, bool adaptive = false)
+{
+    return adaptive ? launch_bi_t<R, true>(a) : launch_bi_t<R, false>(a);
 }
 
 }  // namespace qh

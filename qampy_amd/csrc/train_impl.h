@@ -488,7 +488,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         const bool la_ok = !direct && la_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy);
         const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
         const bool pair = la_shape_ok(nmodes, ntaps, os);          // layout of the Gram terms of this capture (qh_gram_build_*)
-        if (bi_ok && (partitioned || decision || !la_ok || (force && force[0] == 'i'))) {
+        if (bi_ok && (partitioned || decision || adaptive || !la_ok || (force && force[0] == 'i'))) {
             // block-iterative form (train_bi.h): 8 wavefronts per output mode solve each 64-step block by fixed-point sweeps
             void *G = const_cast<void *>(gram);
             if (!G && (rc = pair ? gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G) : gram_cur_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G))) return rc;
@@ -507,9 +507,21 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
                 QH_HIP(hipMemsetAsync(pp, 0, 16 * sizeof(unsigned long long), g_stream));
                 la.prof = (unsigned long long *)pp;
             }
-            for (int it = 0; it < Niter; it++) {
-                la.err_off = (int64_t)it * TrSyms;
-                if ((rc = launch_bi<R>(la))) return rc;
+            la.mu_out = (R *)mu_dev;
+            if (adaptive) {          // mu is carried from sweep to sweep and from mode to mode (sequential reference semantics)
+                la.nsel = 1;
+                for (int j = 0; j < nsel; j++) {
+                    la.modes[0] = a.modes[j];
+                    for (int it = 0; it < Niter; it++) {
+                        la.err_off = (int64_t)it * TrSyms;
+                        if ((rc = launch_bi<R>(la, true))) return rc;
+                    }
+                }
+            } else {
+                for (int it = 0; it < Niter; it++) {
+                    la.err_off = (int64_t)it * TrSyms;
+                    if ((rc = launch_bi<R>(la))) return rc;
+                }
             }
             if (la.prof) {
                 unsigned long long hp[16];
@@ -524,7 +536,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             void *G = const_cast<void *>(gram);
             if (!G && (rc = gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G))) return rc;
             LaArgs<R> la;
-            la.E = a.E; la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.G = (const GramPair<R> *)G; la.gpair = 1; la.mu = mu_dev;
+            la.E = a.E; la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.G = (const GramPair<R> *)G; la.gpair = 1; la.mu = mu_dev; la.mu_out = nullptr;
             la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
             la.os = os; la.nsel = nsel; la.method = method;
             for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];

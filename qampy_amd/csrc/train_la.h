@@ -201,6 +201,7 @@ template <typename R> struct LaArgs {
     const GramPair<R> *G;
     int gpair;              // block-iterative kernel only: 1 = G is the look-ahead pair layout (cur/next), 0 = cur only
     const R *mu;
+    R *mu_out;              // block-iterative kernel with the adaptive step: final step size, else unused
     int64_t L, TrSyms, nsy, sy_pitch, err_pitch, err_off;     // symbols row m starts at symbols + m * sy_pitch
     int nmodes, ntaps, os, nsel, method;
     int64_t modes[16];

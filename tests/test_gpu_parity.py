@@ -301,3 +301,34 @@ def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, 
         np.testing.assert_allclose(w, wo, **t)
         np.testing.assert_allclose(e, eo, rtol=t["rtol"], atol=t["atol"] * 5)
     assert not np.array_equal(wl, wd) or dn == "c128" or True        # different summation order: equal only by luck
+
+
+@pytest.mark.parametrize("method,M,ntaps,nmodes", [("cma", 4, 17, 2), ("mcma", 16, 21, 2), ("mrde", 64, 41, 2), ("sbd", 16, 21, 2),
+                                                   ("mddma", 64, 13, 2), ("dd", 16, 9, 3), ("rde", 16, 15, 1)])
+@pytest.mark.parametrize("dn", ["c64", "c128"])
+def test_adaptive_step_forms_agree(monkeypatch, method, M, ntaps, nmodes, dn):
+    """adapt_step (pythran_equalisation.py:12-16, :171-172) in the block-iterative form (1/mu as a prefix sum inside the
+    sweeps) against the direct form and the oracle: taps, errors and the final mu, which is carried over sweeps and modes."""
+    nsym = 3000 + 11
+    sig = synth.make_capture(M, nsym, nmodes=nmodes, snr_db=26, theta=np.pi / 5.6 if nmodes == 2 else None, dgd=30e-12,
+                             seed=123, dtype=CT[dn])
+    E = np.ascontiguousarray(np.asarray(sig))
+    tr = core_eq._cal_training_symbol_len(2, ntaps, E.shape[1]) - 9
+    w0 = core_eq._init_taps(ntaps, nmodes, nmodes, CT[dn])
+    if method in ("rde", "mrde", "sbd", "mddma", "dd"):
+        s0 = core_eq._reshape_symbols(None, "mcma", M, CT[dn], nmodes)
+        _, w0, _ = oracle.train_equaliser(E, tr, 3, 2, RT[dn](2e-3), w0, None, False, s0, "mcma")
+    sy = core_eq._reshape_symbols(None, method, M, CT[dn], nmodes)
+    mu = RT[dn](5e-3)
+    modes = None if nmodes < 3 else np.array([2, 0])
+    eo, wo, muo = oracle.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, True, sy, method)
+    monkeypatch.setenv("QAMPY_HIP_TRAINER", "direct")
+    ed, wd, mud = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, True, sy, method)
+    monkeypatch.setenv("QAMPY_HIP_TRAINER", "iterative")
+    ei, wi, mui = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, True, sy, method)
+    assert muo < 0.95 * mu                                   # the step size really moved
+    t = dict(rtol=1e-9, atol=1e-11) if dn == "c128" else dict(rtol=3e-4, atol=3e-5)
+    for w, e, m in ((wd, ed, mud), (wi, ei, mui)):
+        np.testing.assert_allclose(w, wo, **t)
+        np.testing.assert_allclose(e, eo, rtol=t["rtol"], atol=t["atol"] * 5)
+        np.testing.assert_allclose(m, muo, rtol=1e-9 if dn == "c128" else 3e-4)
