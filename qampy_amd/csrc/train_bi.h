@@ -300,6 +300,11 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
     for (int k = 0; k < nblk; k++) {
         const unsigned long long pt0 = a.prof ? clock64() : 0;
         const int64_t s0 = (int64_t)k * LA_B;
+        Cx<R> sdat{0, 0};                                              // data-aided: the training symbol of this group's step
+        if constexpr (METHOD == QH_M_SBD_DATA) {
+            const int64_t gi = s0 + BI_JW * w + rr;
+            sdat = sy[gi < TrSyms ? gi : TrSyms - 1];
+        }
         load_gram(gn, k + 1 < nblk ? k + 1 : k);                       // next block's rows and the samples of block k+2 arrive during the sweeps
         stage_load(k + 2 < nblk ? k + 2 : k);
         // ---------------------------------------------------------------- fixed-point sweeps
@@ -333,7 +338,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
                     return true;
                 }
                 const Cx<R> eprev0 = w == 0 ? e_carry : Cx<R>{readlane(ax.er, w > 0 ? w - 1 : 0), readlane(ax.ei, w > 0 ? w - 1 : 0)};
-                const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K);
+                const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K, sdat);
                 const Cx<R> ec{bperm(e.re, csrc), bperm(e.im, csrc)};       // compact: lane <-> row cl
                 Cx<R> ep{dpp_mov<DPP_ROW_SHR1>(ec.re), dpp_mov<DPP_ROW_SHR1>(ec.im)};
                 if (cl == 0) ep = eprev0;
@@ -354,7 +359,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
                 S_own = S_new; e_last = el_new;
             } else {
                 if (!__any(got.flag != 0)) return true;                    // nobody's c moved in the last sweep: y is the fixed point
-                c_new = la_errfn<R, METHOD, NPART, true>(y, K);
+                c_new = la_errfn<R, METHOD, NPART, true>(y, K, sdat);
                 const unsigned long long mv = __builtin_amdgcn_ballot_w64(c_new.re != c_old.re || c_new.im != c_old.im);
                 changed = (unsigned)mv | (unsigned)(mv >> 32);             // wave-uniform: non-zero when any own c moved
             }
@@ -373,7 +378,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         }
         // ---------------------------------------------------------------- results of the block
         const unsigned long long pt1 = a.prof ? clock64() : 0;
-        const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K);
+        const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K, sdat);
         if (vv == 0 && s0 + BI_JW * w + rr < TrSyms) eown[s0] = e;
         // taps: this wave's steps into all taps (lane <-> taps lane, lane + 64).  Steps past TrSyms (partial last block) have
         // all-zero Gram rows, so they never touched the sweeps; their c (non-zero for decision-directed functions) is dropped here
@@ -544,6 +549,7 @@ inline bool bi_supported(int method, int adaptive, int nmodes, int ntaps, int os
     case QH_M_CMA: case QH_M_SGNCMA: case QH_M_CMA2: case QH_M_MCMA: return true;
     case QH_M_RDE: case QH_M_MRDE: return nsy - (nsy + 1) / 2 >= 1 && nsy - (nsy + 1) / 2 <= LA_MAXPART;
     case QH_M_SBD: case QH_M_MDDMA: case QH_M_DD: return true;      // if the alphabet is square: slicer_tables() decides
+    case QH_M_SBD_DATA: return true;
     default: return false;
     }
 }
@@ -587,6 +593,7 @@ template <typename R, bool ADAPT> static int launch_bi_t(const LaArgs<R> &a)
     case QH_M_SBD: rc = launch_bi_dd<R, QH_M_SBD, ADAPT>(a, npart, lds); break;
     case QH_M_MDDMA: rc = launch_bi_dd<R, QH_M_MDDMA, ADAPT>(a, npart, lds); break;
     case QH_M_DD: rc = launch_bi_dd<R, QH_M_DD, ADAPT>(a, npart, lds); break;
+    case QH_M_SBD_DATA: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_SBD_DATA, 0, ADAPT>), grid, block, lds, g_stream, a); break;
     default: return QH_ERR_METHOD;
     }
     if (rc) return rc;

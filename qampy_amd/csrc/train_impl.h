@@ -488,7 +488,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         const bool la_ok = !direct && la_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy);
         const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
         const bool pair = la_shape_ok(nmodes, ntaps, os);          // layout of the Gram terms of this capture (qh_gram_build_*)
-        if (bi_ok && (partitioned || decision || adaptive || !la_ok || (force && force[0] == 'i'))) {
+        if (bi_ok && (partitioned || decision || adaptive || method == QH_M_SBD_DATA || !la_ok || (force && force[0] == 'i'))) {
             // block-iterative form (train_bi.h): 8 wavefronts per output mode solve each 64-step block by fixed-point sweeps
             void *G = const_cast<void *>(gram);
             if (!G && (rc = pair ? gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G) : gram_cur_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G))) return rc;

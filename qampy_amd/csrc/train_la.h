@@ -139,7 +139,7 @@ template <typename R, int NPART> struct LaConst {
 template <typename R> struct V2 { typedef R type __attribute__((ext_vector_type(2))); };
 
 template <typename R, int METHOD, int NPART, bool SCALE>
-__device__ __forceinline__ Cx<R> la_errfn(Cx<R> y, const LaConst<R, NPART> &k)
+__device__ __forceinline__ Cx<R> la_errfn(Cx<R> y, const LaConst<R, NPART> &k, Cx<R> sdata = Cx<R>{0, 0})
 {
     using v2 = typename V2<R>::type;
     const v2 yy = {y.re, y.im};
@@ -163,6 +163,11 @@ __device__ __forceinline__ Cx<R> la_errfn(Cx<R> y, const LaConst<R, NPART> &k)
         R d = tab_lookup<R, NPART, false>(sq, k.code0_re, k.tab) - sq;
         if constexpr (SCALE) d = d * k.mu;
         e = yy * d;
+    } else if constexpr (METHOD == QH_M_SBD_DATA) {        // :219-223, the training symbol of this step comes with the call
+        const v2 s = {sdata.re, sdata.im};
+        v2 d = (s - yy) * __builtin_elementwise_abs(s);
+        if constexpr (SCALE) d = d * k.mu;
+        e = d;
     } else if constexpr (METHOD == QH_M_SBD || METHOD == QH_M_MDDMA || METHOD == QH_M_DD) {
         // decision-directed on a square alphabet: the table holds the sorted per-axis levels (codes) and their midpoints
         // (partitions), see slicer_table_kernel in train_bi.h; nearest level per axis == nearest symbol (det_symbol :240-265)
