@@ -88,3 +88,53 @@ def test_window_batch_equals_single_calls(golden, monkeypatch):
         for i, s in enumerate(starts):
             w, e = core_eq.equalise_signal(E[:, s:s + 512], 2, 5e-3, 4, Ntaps=17, Niter=4, method=method, adaptive_stepsize=adaptive)
             assert np.array_equal(w, w_all[i]) and np.array_equal(e, e_all[i])
+
+
+# ------------------------------------------------------------------------------------------------ basic API (signal objects)
+def _pilot_signal(g):
+    from qampy_amd.signals import PilotSignal
+    pilots = np.hstack([g["pilot_seq"], g["ph_pilots"]])
+    sig = PilotSignal(g["rx"].copy(), int(g["M"]), 24e9, 48e9, int(g["frame_len"]), g["pilot_seq"].shape[1], 32, pilots,
+                      coded_symbols=g["alphabet"])
+    assert np.array_equal(sig._idx_pil, g["idx_pil"]) and sig.os == int(g["os"]) and sig.nframes == 3
+    return sig
+
+
+def _run_basic_api(g, rtol):
+    """sync2frame -> corr_foe -> pilot_equaliser -> pilot_cpe on a signal object reproduces the reference's arrays
+    (qampy/signals.py:1709-1750, qampy/equalisation.py:42-87 and :268-338, qampy/phaserec.py:156-192)."""
+    from qampy_amd import equalisation, phaserec
+    sig = _pilot_signal(g)
+    wx1, ok = sig.sync2frame(returntaps=True)
+    assert ok == bool(g["fs_ok"]) and np.array_equal(sig.shiftfctrs, g["shiftfctrs"]) and sig.synctaps == 17
+    np.testing.assert_allclose(wx1, g["fs_wx1"], rtol=rtol, atol=rtol)
+    before, foe_c = np.asarray(sig).copy(), np.mean(sig._foe)
+    sig.corr_foe()                       # = comp_freq_offset with the signal's oversampling (qampy/signals.py:1747-1750)
+    np.testing.assert_allclose(np.asarray(sig), phaserecovery.comp_freq_offset(before, np.ones(2) * foe_c, 2), rtol=0, atol=1e-12)
+    sig[:, :] = g["synced"]              # the captured chain continued from the os=1 variant of that call
+    taps, eq, foe, ntaps = equalisation.pilot_equaliser(sig, (1e-3, 1e-3), 45, foe_comp=False, methods=("cma", "sbd"), verbose=True)
+    assert ntaps == (45, 17) and np.array_equal(foe, g["eq_foe"])
+    np.testing.assert_allclose(taps, g["eq_taps"], rtol=rtol, atol=rtol)
+    assert type(eq) is type(sig) and eq.os == 1 and eq.shape == g["eq_frame"].shape
+    np.testing.assert_allclose(np.asarray(eq), g["eq_frame"], rtol=rtol, atol=10 * rtol)
+    out, ph = phaserec.pilot_cpe(eq, N=5)
+    np.testing.assert_allclose(ph, g["cpe_ph"], rtol=0, atol=100 * rtol)
+    np.testing.assert_allclose(np.asarray(out), g["cpe_out"], rtol=0, atol=100 * rtol)
+    # payload / pilot extraction and the apply_filter(frames=...) path on two consecutive frames
+    assert out.get_data().shape[1] == np.count_nonzero(~g["idx_pil"]) and out.extract_pilots().shape[1] == np.count_nonzero(g["idx_pil"])
+    two = equalisation.apply_filter(sig, taps, frames=[0, 1])
+    assert two.shape == (2, 2 * int(g["frame_len"]))
+    np.testing.assert_allclose(np.asarray(two)[:, :int(g["frame_len"])], g["eq_frame"], rtol=rtol, atol=10 * rtol)
+    one = equalisation.apply_filter(sig, taps, frames=[1])
+    np.testing.assert_allclose(np.asarray(one), np.asarray(two)[:, int(g["frame_len"]):], rtol=rtol, atol=10 * rtol)
+    fo = phaserec.find_freq_offset(eq, fft_size=2 ** 12)
+    assert np.shape(fo) == (2, 1) and np.all(np.abs(fo) < 0.01)          # residual offset after the pilot-based compensation
+
+
+def test_pilot_basic_api_on_oracle_kernels(golden, oracle_kernels):
+    _run_basic_api(golden["pilot"], 1e-9)
+
+
+@pytest.mark.gpu
+def test_pilot_basic_api_on_gpu(golden):
+    _run_basic_api(golden["pilot"], 1e-8)
