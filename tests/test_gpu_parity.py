@@ -332,3 +332,29 @@ def test_adaptive_step_forms_agree(monkeypatch, method, M, ntaps, nmodes, dn):
         np.testing.assert_allclose(w, wo, **t)
         np.testing.assert_allclose(e, eo, rtol=t["rtol"], atol=t["atol"] * 5)
         np.testing.assert_allclose(m, muo, rtol=1e-9 if dn == "c128" else 3e-4)
+
+
+@pytest.mark.parametrize("nmodes,ntaps,os_,tr", [(1, 1, 1, 128), (1, 5, 1, 129), (2, 7, 3, 191), (2, 64, 2, 192), (4, 31, 2, 200), (8, 16, 2, 130),
+                                                (8, 3, 1, 257), (2, 33, 4, 128), (3, 42, 2, 321)])
+@pytest.mark.parametrize("method", ["mcma", "mrde", "sbd"])
+def test_exact_trainer_forms_on_boundary_shapes(monkeypatch, nmodes, ntaps, os_, tr, method):
+    """Smallest captures the block forms take (128 steps), partial / full last blocks, 1 to 8 modes, 1 to 128 taps per output
+    mode, oversampling 1 to 4, adaptive and fixed step: every form the shape admits equals the oracle."""
+    rng = np.random.default_rng(nmodes * 1000 + ntaps * 10 + os_)
+    M = 16
+    L = (tr - 1) * os_ + ntaps + 5
+    alphabet = core_eq._reshape_symbols(None, "sbd", M, np.complex128, 1)[0]
+    tx = alphabet[rng.integers(0, M, (nmodes, L))]
+    E = (tx + 0.05 * (rng.normal(size=tx.shape) + 1j * rng.normal(size=tx.shape))).astype(np.complex128)
+    w0 = core_eq._init_taps(ntaps, nmodes, nmodes, np.complex128)
+    w0 += 0.01 * (rng.normal(size=w0.shape) + 1j * rng.normal(size=w0.shape))
+    sy = core_eq._reshape_symbols(None, method, M, np.complex128, nmodes)
+    modes = np.arange(nmodes)[::-1].copy() if nmodes > 2 else None
+    for adaptive in (False, True):
+        eo, wo, muo = oracle.train_equaliser(E, tr, 2, os_, np.float64(1e-3), w0.copy(), modes, adaptive, sy, method)
+        for form in ("direct", "lookahead", "iterative"):
+            monkeypatch.setenv("QAMPY_HIP_TRAINER", form)
+            e, w, mu = hk.train_equaliser(E, tr, 2, os_, np.float64(1e-3), w0.copy(), modes, adaptive, sy, method)
+            np.testing.assert_allclose(w, wo, rtol=1e-9, atol=1e-11, err_msg="%s adaptive=%s" % (form, adaptive))
+            np.testing.assert_allclose(e, eo, rtol=1e-9, atol=1e-10, err_msg="%s adaptive=%s" % (form, adaptive))
+            np.testing.assert_allclose(mu, muo, rtol=1e-9)
