@@ -86,6 +86,51 @@ def timed_steps(rx, steps, warmup, barrier_sync):
     return elapsed, stage_ms
 
 
+def channel_bank_run(cfg, sig, nch, steps, barrier_sync):
+    """Informational: `nch` independent captures of the workload resident on ONE GPU, all stages for all channels per step.
+    One exact training chain is one workgroup, so channels side by side are how the exact recurrence fills the chip (WDM
+    receivers have them).  Channel c = the capture seen through a different polarisation rotation and time offset (cheap to
+    derive on the host; different channel state, same symbols).  NOT the headline `value` (BASELINE configs are single captures)."""
+    from qampy_amd import _lib
+    from qampy_amd.pipeline import ChannelBank
+    E = np.asarray(sig)
+    bank = ChannelBank(nch, E.shape[0], E.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"],
+                       adaptive_stepsize=cfg["adaptive"], TrSyms=(None,) * len(cfg["methods"]), Mtestangles=cfg["A"], Nbps=cfg["Nbps"],
+                       dtype=np.complex64, alphabet=sig.coded_symbols)
+    for c in range(nch):
+        if E.shape[0] == 2:
+            th = 0.04 * ((c + 1) // 2) * (1 if c % 2 else -1)      # +-0.04 rad steps around the capture's own PMD angle
+            Ec = np.empty_like(E)
+            Ec[0] = np.cos(th) * E[0] - np.sin(th) * E[1]
+            Ec[1] = np.sin(th) * E[0] + np.cos(th) * E[1]
+        else:
+            Ec = E * np.complex64(np.exp(1j * 0.37 * c))
+        bank.load(c, np.roll(Ec, 2 * 37 * c, axis=1))
+    bank.run()
+    ev0, ev1 = _lib.Event(), _lib.Event()
+    barrier_sync()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        bank.run()
+    ev1.record()
+    barrier_sync()
+    el = time.perf_counter() - t0
+    nsym = E.shape[1] // 2
+    sers = {}
+    worst = 0.
+    for c in range(nch):
+        rows = bank.ser(c, sig.symbols, maxlag=4096, window=8192, trim=2000) if cfg["A"] else []
+        ser_c = [r["errors"] / max(r["compared"], 1) for r in rows]
+        worst = max([worst] + ser_c)
+        if c in (0, nch // 2, nch - 1):
+            sers[str(c)] = ser_c
+    return dict(channels=nch, value=round(nch * nsym * steps / el / 1e6, 3), unit="MSym/s", steps=steps, ms_per_step=round(el / steps * 1e3, 2),
+                ms_per_step_events=round(ev1.elapsed_ms(ev0) / steps, 2), ser_of_channels=sers, worst_ser=worst,
+                note="informational: %d independent captures of this workload processed together on one GPU (exact trainers: one "
+                     "workgroup per channel and mode in a single launch per stage); not the headline value" % nch)
+
+
 def symbol_errors(out, sig, trim=2000):
     """(errors, compared) per mode of a recovered signal; alignment on a prefix, decisions counted over the whole run."""
     from qampy_amd import synth
@@ -152,6 +197,8 @@ def main():
                          "segment-parallel continuation (tier B, SER-equivalent, not tap-identical)")
     ap.add_argument("--segments", type=int, default=1024)
     ap.add_argument("--prefix", type=int, default=1 << 16, help="sequential convergence prefix (steps) of the segmented mode")
+    ap.add_argument("--bank", type=int, default=16, help="channels of the informational channel-bank run at N=1 (0 = skip): that many "
+                    "independent captures of the same workload resident on the GPU and processed together")
     ap.add_argument("--tier-b", action="store_true", help="also time the opt-in segmented trainer on the same capture (informational)")
     args = ap.parse_args()
 
@@ -261,6 +308,9 @@ def main():
                                     errors_gpu=[e for e, _ in e_gpu], errors_cpu=[e for e, _ in e_cpu],
                                     max_abs_tap_diff=float(np.max(np.abs(r2["wxy"] - cb["wxy"]))))
         out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+
+    if world == 1 and args.train_mode == "exact" and args.bank > 1:
+        out["channel_bank"] = channel_bank_run(cfg, sig, args.bank, max(1, min(args.steps, 2)), barrier_sync)
 
     if world == 1 and args.train_mode == "exact" and args.tier_b:
         # informational: the opt-in segment-parallel training on the same capture (NOT the headline `value`)

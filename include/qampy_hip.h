@@ -183,6 +183,20 @@ int qh_make_decision_c128_dev(const void *E, int64_t L, const void *symbols, int
 int qh_count_errors_dev(const int32_t *idx_rx, const int32_t *idx_tx, int64_t n, int64_t lag, int64_t ntx,
                         unsigned long long *count_dev);
 
+/* ---- channel bank: nch independent captures of identical shape processed together -------------------------------
+ * (SURVEY.md 8e "within a GPU": one exact training chain occupies one workgroup, so a GPU holds hundreds of channels).
+ * All arrays carry a leading channel dimension and are contiguous: E (nch, nmodes, L), wx (nch, nmodes, nmodes, ntaps),
+ * err (nch, nmodes, TrSyms*Niter), mu_dev (nch,), gram = nch tables from qh_gram_build_*_batch_dev (or NULL: built
+ * internally); symbols and modes are shared.  Semantics per channel: exactly qh_train_equaliser_*_dev. */
+int qh_gram_build_c64_batch_dev(const void *E, int nch, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram);
+int qh_gram_build_c128_batch_dev(const void *E, int nch, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram);
+int qh_train_equaliser_c64_batch_dev(const void *E, int nch, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os,
+                                     float *mu_dev, void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive,
+                                     const void *symbols, int64_t nsy, int method, void *err, int zero_err, const void *gram);
+int qh_train_equaliser_c128_batch_dev(const void *E, int nch, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os,
+                                      double *mu_dev, void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive,
+                                      const void *symbols, int64_t nsy, int method, void *err, int zero_err, const void *gram);
+
 /* On-device SER harness (reference: cal_ser core/signals.py:295-335 = sync_and_adjust /
  * find_sequence_offset_complex core/ber_functions.py:33-160 + make_decision + compare).  E: one recovered row (N,) in
  * HBM; idx_tx: decided indices of the transmitted symbols (nmodes, ntx) int32 in HBM (qh_make_decision_*_dev); symbols

@@ -73,6 +73,10 @@ SIGNATURES = {
     "qh_make_decision_c64": _DECIDE, "qh_make_decision_c128": _DECIDE,
     "qh_make_decision_c64_dev": _DECIDE, "qh_make_decision_c128_dev": _DECIDE,
     "qh_count_errors_dev": [_vp, _vp, _i64, _i64, _i64, _vp],
+    "qh_gram_build_c64_batch_dev": [_vp, _i, _i, _i64, _i, _i, _i64, C.POINTER(_vp)],
+    "qh_gram_build_c128_batch_dev": [_vp, _i, _i, _i64, _i, _i, _i64, C.POINTER(_vp)],
+    "qh_train_equaliser_c64_batch_dev": [_vp, _i] + _train_sig(_pf, dev=True)[1:] + [_vp],
+    "qh_train_equaliser_c128_batch_dev": [_vp, _i] + _train_sig(_pd, dev=True)[1:] + [_vp],
     "qh_ser_c64_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
     "qh_ser_c128_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
 }

@@ -198,6 +198,34 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
         _lib.call(name + "_dev", *args)
 
 
+def gram_build_batch_dev(E, os, ntaps, TrSyms):
+    """Gram terms of a channel bank ``E (nch, nmodes, L)``: one table per channel, one opaque pointer for the bank."""
+    suf, rt, ct = _lib.suffix(E.dtype)
+    nch, nmodes, L = E.shape
+    g = C.c_void_p()
+    _lib.call("qh_gram_build_c" + ("64" if suf == "32" else "128") + "_batch_dev", E.ptr, nch, nmodes, L, int(os), int(ntaps), int(TrSyms),
+              C.byref(g))
+    return g.value
+
+
+def train_equaliser_batch_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method, err, zero_err=False, gram=None):
+    """
+    :func:`train_equaliser_dev` for a bank of independent captures with identical shapes: ``E (nch, nmodes, L)``,
+    ``wx (nch, nmodes, nmodes, ntaps)``, ``err (nch, nmodes, TrSyms*Niter)``, ``mu (nch,)``; ``symbols`` and ``modes`` are
+    shared.  Every channel gets exactly the single-capture result; the exact trainers run all channels concurrently
+    (one workgroup per channel and output mode).
+    """
+    if method not in _lib.METHOD_ID:
+        raise ValueError("Unknown method %s" % method)
+    suf, rt, ct = _lib.suffix(E.dtype)
+    nch, nmodes, L = E.shape
+    ntaps = wx.shape[-1]
+    modes = _as_modes(modes, nmodes)
+    _lib.call("qh_train_equaliser_c" + ("64" if suf == "32" else "128") + "_batch_dev", E.ptr, nch, nmodes, L, int(TrSyms), int(Niter), int(os),
+              mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size, int(bool(adaptive)), symbols.ptr, symbols.shape[1],
+              _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)), gram)
+
+
 def apply_filter_to_signal_dev(E, os, wx, modes, out):
     suf, rt, ct = _lib.suffix(E.dtype)
     nmodes, L = E.shape

@@ -157,6 +157,13 @@ constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114;
 template <typename R, int METHOD, int NPART, bool ADAPT = false>
 __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
 {
+    // independent captures of a channel bank (blockIdx.y): same shapes, own arrays
+    const int64_t ch = blockIdx.y;
+    const Cx<R> *const aE = a.E + ch * a.E_cs;
+    Cx<R> *const awx = a.wx + ch * a.wx_cs;
+    Cx<R> *const aerr = a.err + ch * a.err_cs;
+    const GramPair<R> *const aG = a.G + ch * a.G_cs;
+    const R *const amu = a.mu + ch * a.mu_cs;
     extern __shared__ __attribute__((aligned(16))) char bi_smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -179,7 +186,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
 
     // ---- constants of the error function
     LaConst<R, NPART> K;
-    K.mu = *a.mu;
+    K.mu = *amu;
     {
         const Cx<R> c0 = sy[0];
         K.R_re = c0.re; K.R_im = c0.im;
@@ -191,7 +198,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
     const int tpw = (((ntot + BI_W - 1) / BI_W) + 3) & ~3;              // multiple of 4: the prior dot products run 4 taps at a time
     const int f0 = w * tpw;
     const int nf = f0 < ntot ? ((f0 + tpw) < ntot ? tpw : ntot - f0) : 0;
-    Cx<R> *wrow = a.wx + (size_t)mode * ntot;
+    Cx<R> *wrow = awx + (size_t)mode * ntot;
     for (int f = threadIdx.x; f < BI_MAXTAPS; f += BI_NT) wbuf[f] = f < ntot ? wrow[f] : Cx<R>{0, 0};     // taps >= ntot stay zero
     // tap-update layout: lane <-> taps lane and lane + 64
     int xo[2];
@@ -229,7 +236,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         for (int s = 0; s < 2; s++) {
             int64_t gi = base + st_i[s];
             if (gi > a.L - 1) gi = a.L - 1;
-            stv[s] = a.E[st_src[s] + gi];
+            stv[s] = aE[st_src[s] + gi];
         }
     };
     auto stage_store = [&](int kb) {                                   // ... LDS writes once the window is free
@@ -242,7 +249,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
             const int k2 = e / wpitch, i2 = e - k2 * wpitch;
             int64_t gi = base + i2;
             if (gi > a.L - 1) gi = a.L - 1;
-            dst[e] = a.E[(size_t)k2 * a.L + gi];
+            dst[e] = aE[(size_t)k2 * a.L + gi];
         }
     };
     // own-slice part of the prior outputs of block kb: lane <-> step kb*64 + lane
@@ -264,14 +271,14 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         return acc;
     };
     const int gs = a.gpair ? 2 : 1;                                    // the look-ahead pair layout interleaves cur / next
-    const Cx<R> *gbase = reinterpret_cast<const Cx<R> *>(a.G) + ((size_t)(BI_JW * w) * LA_B + lane) * gs;
+    const Cx<R> *gbase = reinterpret_cast<const Cx<R> *>(aG) + ((size_t)(BI_JW * w) * LA_B + lane) * gs;
     auto load_gram = [&](Cx<R> (&g)[BI_JW], int kb) {
         const Cx<R> *gp = gbase + (size_t)kb * LA_B * LA_B * gs;
 #pragma unroll
         for (int r = 0; r < BI_JW; r++) g[r] = gp[(size_t)r * LA_B * gs];
     };
 
-    Cx<R> *errow = a.err + (size_t)mode * a.err_pitch + a.err_off;
+    Cx<R> *errow = aerr + (size_t)mode * a.err_pitch + a.err_off;
     stage_load(0); stage_store(0);
     if (nblk > 1) { stage_load(1); stage_store(1); }
     __syncthreads();
@@ -428,7 +435,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         a.prof[0] = pf_sweeps; a.prof[1] = pf_t_sweep; a.prof[2] = pf_t_upd; a.prof[3] = pf_t_prior; a.prof[4] = (unsigned long long)nblk;
     }
     for (int f = threadIdx.x; f < ntot; f += BI_NT) wrow[f] = wbuf[f];
-    if constexpr (ADAPT) if (threadIdx.x == 0) *a.mu_out = (R)1 / r_blk;
+    if constexpr (ADAPT) if (threadIdx.x == 0) a.mu_out[ch * a.mu_cs] = (R)1 / r_blk;
 }
 
 // ------------------------------------------------------------------------------------------------ slicer tables
@@ -507,17 +514,19 @@ template <typename R> static size_t gram_cur_bytes(int64_t TrSyms)
     return (size_t)(nblk * LA_B + LA_B) * LA_B * sizeof(Cx<R>);
 }
 
-template <typename R> int gram_cur_build(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
+template <typename R> int gram_cur_build(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram, int nch = 1)
 {
     int rc = ensure_init();
     if (rc) return rc;
     void *G = nullptr;
-    if ((rc = scratch(4, gram_cur_bytes<R>(TrSyms), &G))) return rc;
+    const size_t bytes = gram_cur_bytes<R>(TrSyms);
+    if ((rc = scratch(4, bytes * (size_t)nch, &G))) return rc;
     const int64_t nblk = (TrSyms + LA_B - 1) / LA_B;
     const size_t lds = (size_t)nmodes * ((LA_B - 1) * os + ntaps) * sizeof(Cx<R>);
     QH_REQUIRE(lds <= 64 * 1024, "gram: nmodes*(63*os+ntaps) samples exceed the LDS tile");
-    if (nblk > 0) hipLaunchKernelGGL((gram_cur_kernel<R>), dim3((unsigned)nblk), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps,
-                                     TrSyms, (Cx<R> *)G);
+    for (int c = 0; c < nch && nblk > 0; c++)
+        hipLaunchKernelGGL((gram_cur_kernel<R>), dim3((unsigned)nblk), dim3(256), lds, g_stream, (const Cx<R> *)E + (size_t)c * nmodes * L, nmodes, L,
+                           os, ntaps, TrSyms, (Cx<R> *)((char *)G + bytes * (size_t)c));
     QH_HIP(hipGetLastError());
     *gram = G;
     return QH_OK;
@@ -556,7 +565,7 @@ inline bool bi_supported(int method, int adaptive, int nmodes, int ntaps, int os
 
 template <typename R, int METHOD, bool ADAPT> static int launch_bi_dd(const LaArgs<R> &a, int npart, size_t lds)
 {
-    dim3 grid(a.nsel), block(BI_NT);
+    dim3 grid(a.nsel, a.nch), block(BI_NT);
 #define QH_BI_DD(N) case N: hipLaunchKernelGGL((train_bi_kernel<R, METHOD, N, ADAPT>), grid, block, lds, g_stream, a); break;
     switch (npart) {            // 4-, 16-, 64-, 256-QAM
         QH_BI_DD(1) QH_BI_DD(3) QH_BI_DD(7) QH_BI_DD(15)
@@ -568,7 +577,7 @@ template <typename R, int METHOD, bool ADAPT> static int launch_bi_dd(const LaAr
 
 template <typename R, int METHOD, bool ADAPT> static int launch_bi_parts(const LaArgs<R> &a, int npart, size_t lds)
 {
-    dim3 grid(a.nsel), block(BI_NT);
+    dim3 grid(a.nsel, a.nch), block(BI_NT);
 #define QH_BI_NP(N) case N: hipLaunchKernelGGL((train_bi_kernel<R, METHOD, N, ADAPT>), grid, block, lds, g_stream, a); break;
     switch (npart) {
         QH_BI_NP(1) QH_BI_NP(2) QH_BI_NP(3) QH_BI_NP(4) QH_BI_NP(5) QH_BI_NP(6) QH_BI_NP(7) QH_BI_NP(8)
@@ -580,7 +589,7 @@ template <typename R, int METHOD, bool ADAPT> static int launch_bi_parts(const L
 
 template <typename R, bool ADAPT> static int launch_bi_t(const LaArgs<R> &a)
 {
-    dim3 grid(a.nsel), block(BI_NT);
+    dim3 grid(a.nsel, a.nch), block(BI_NT);
     const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
     const size_t lds = bi_lds_bytes<R>(a.nmodes, a.ntaps, a.os);
     int rc = QH_OK;

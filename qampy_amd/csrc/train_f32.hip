@@ -38,6 +38,17 @@ int qh_train_equaliser_c64_gram_dev(const void *E, int nmodes, int64_t L, int64_
 {
     return qh::train_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, 0, 0, gram);
 }
+int qh_gram_build_c64_batch_dev(const void *E, int nch, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
+{
+    if (!qh::la_shape_ok(nmodes, ntaps, os) && qh::bi_shape_ok(nmodes, ntaps, os, 2 * sizeof(float))) return qh::gram_cur_build<float>(E, nmodes, L, os, ntaps, TrSyms, gram, nch);
+    return qh::gram_build<float>(E, nmodes, L, os, ntaps, TrSyms, gram, nch);
+}
+int qh_train_equaliser_c64_batch_dev(const void *E, int nch, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
+                                      void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
+                                      int64_t nsy, int method, void *err, int zero_err, const void *gram)
+{
+    return qh::train_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, 0, 0, gram, 0, nch);
+}
 int qh_train_equaliser_windows_c64(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len,
                                      int64_t TrSyms, int Niter, int os, float mu, const void *wx0, int ntaps, const int64_t *modes, int nsel,
                                      int adaptive, const void *symbols, int64_t nsy, int method, void *wx_out, void *err, float *mu_out)

@@ -446,11 +446,14 @@ template <typename R> static int launch_any(const TrainArgs<R> &a)
 template <typename R>
 int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu_dev, void *wx, int ntaps,
               const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy, int method, void *err,
-              int zero_err, int nseg = 0, int64_t prefix = 0, const void *gram = nullptr, double prefix_mu = 0)
+              int zero_err, int nseg = 0, int64_t prefix = 0, const void *gram = nullptr, double prefix_mu = 0, int nch = 1)
 {
     int rc = ensure_init();
     if (rc) return rc;
     if (method < 0 || method > QH_M_SBD_DATA) { set_error("unknown equaliser method id"); return QH_ERR_METHOD; }
+    // nch > 1: a bank of independent captures with identical shapes, arrays (nch, ...) contiguous, one mu per channel; the
+    // look-ahead / block-iterative kernels take the channel as blockIdx.y, anything else runs channel after channel
+    QH_REQUIRE(nch >= 1 && nch <= 65535 && (nch == 1 || nseg <= 0), "train_equaliser: bad channel count");
     QH_REQUIRE(nmodes >= 1 && ntaps >= 1 && os >= 1 && Niter >= 0 && TrSyms >= 0, "train_equaliser: bad sizes");
     QH_REQUIRE(nsel >= 1 && nsel <= 16, "train_equaliser: between 1 and 16 modes can be selected");
     QH_REQUIRE(TrSyms == 0 || (TrSyms - 1) * os + ntaps <= L, "train_equaliser: field shorter than TrSyms*os + ntaps");
@@ -459,7 +462,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
     for (int j = 0; j < nsel; j++) QH_REQUIRE(modes[j] >= 0 && modes[j] < nmodes, "train_equaliser: mode number >= nmodes");
     const int ntot = nmodes * ntaps;
     QH_REQUIRE(ntot <= 64 * 16, "train_equaliser: more than 1024 taps per output mode are not supported");
-    if (zero_err) QH_HIP(hipMemsetAsync(err, 0, (size_t)nmodes * TrSyms * Niter * sizeof(Cx<R>), g_stream));
+    if (zero_err) QH_HIP(hipMemsetAsync(err, 0, (size_t)nch * nmodes * TrSyms * Niter * sizeof(Cx<R>), g_stream));
     if (TrSyms == 0 || Niter == 0) return QH_OK;
     TrainArgs<R> a;
     a.E = (const Cx<R> *)E; a.wx = (Cx<R> *)wx; a.symbols = (const Cx<R> *)symbols; a.err = (Cx<R> *)err; a.mu = mu_dev;
@@ -491,11 +494,13 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         if (bi_ok && (partitioned || decision || adaptive || method == QH_M_SBD_DATA || !la_ok || (force && force[0] == 'i'))) {
             // block-iterative form (train_bi.h): 8 wavefronts per output mode solve each 64-step block by fixed-point sweeps
             void *G = const_cast<void *>(gram);
-            if (!G && (rc = pair ? gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G) : gram_cur_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G))) return rc;
+            if (!G && (rc = pair ? gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G, nch) : gram_cur_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G, nch))) return rc;
             LaArgs<R> la;
             la.E = a.E; la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.G = (const GramPair<R> *)G; la.gpair = pair ? 1 : 0; la.mu = mu_dev;
             la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
             la.os = os; la.nsel = nsel; la.method = method;
+            la.nch = nch; la.E_cs = (int64_t)nmodes * L; la.wx_cs = (int64_t)nmodes * ntot; la.err_cs = (int64_t)nmodes * TrSyms * Niter;
+            la.mu_cs = 1; la.G_cs = (int64_t)((pair ? gram_bytes<R>(TrSyms) : gram_cur_bytes<R>(TrSyms)) / sizeof(GramPair<R>));
             for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];
             if (decision) {          // the kernel reads the slicer table like an mrde table: row pitch 2*BI_DD_MAXLEV, 2*npart+1 used
                 la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV;
@@ -534,8 +539,10 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         }
         if (la_ok) {
             void *G = const_cast<void *>(gram);
-            if (!G && (rc = gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G))) return rc;
+            if (!G && (rc = gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G, nch))) return rc;
             LaArgs<R> la;
+            la.nch = nch; la.E_cs = (int64_t)nmodes * L; la.wx_cs = (int64_t)nmodes * ntot; la.err_cs = (int64_t)nmodes * TrSyms * Niter;
+            la.mu_cs = 1; la.G_cs = (int64_t)(gram_bytes<R>(TrSyms) / sizeof(GramPair<R>));
             la.E = a.E; la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.G = (const GramPair<R> *)G; la.gpair = 1; la.mu = mu_dev; la.mu_out = nullptr;
             la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
             la.os = os; la.nsel = nsel; la.method = method;
@@ -561,7 +568,13 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             }
             return QH_OK;
         }
-        return launch_any<R>(a);
+        for (int c = 0; c < nch; c++) {            // direct form: one capture after the other
+            TrainArgs<R> ac = a;
+            ac.E = a.E + (size_t)c * nmodes * L; ac.wx = a.wx + (size_t)c * nmodes * ntot;
+            ac.err = a.err + (size_t)c * nmodes * TrSyms * Niter; ac.mu = mu_dev + c;
+            if ((rc = launch_any<R>(ac))) return rc;
+        }
+        return QH_OK;
     }
     // ---- tier B
     QH_REQUIRE(nseg <= 65535 && prefix >= 0, "train_equaliser: bad segment parameters");

@@ -208,7 +208,9 @@ template <typename R> struct LaArgs {
     const R *mu;
     R *mu_out;              // block-iterative kernel with the adaptive step: final step size, else unused
     int64_t L, TrSyms, nsy, sy_pitch, err_pitch, err_off;     // symbols row m starts at symbols + m * sy_pitch
-    int nmodes, ntaps, os, nsel, method;
+    int nmodes, ntaps, os, nsel, method, nch;
+    // channel batch: blockIdx.y = channel; element strides between the channels' arrays (0 for a single capture)
+    int64_t E_cs, wx_cs, err_cs, G_cs, mu_cs;
     int64_t modes[16];
     unsigned long long *prof;   // optional [4 waves][4] cycle counters of workgroup 0 (qh_la_profile), else nullptr
 };
@@ -222,6 +224,13 @@ template <typename R> struct LaLds {
 template <typename R, int METHOD, int NPART>
 __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
 {
+    // independent captures of a channel bank (blockIdx.y): same shapes, own arrays
+    const int64_t ch = blockIdx.y;
+    const Cx<R> *const aE = a.E + ch * a.E_cs;
+    Cx<R> *const awx = a.wx + ch * a.wx_cs;
+    Cx<R> *const aerr = a.err + ch * a.err_cs;
+    const GramPair<R> *const aG = a.G + ch * a.G_cs;
+    const R *const amu = a.mu + ch * a.mu_cs;
     extern __shared__ __attribute__((aligned(16))) char la_smem[];
     LaLds<R> &lds = *reinterpret_cast<LaLds<R> *>(la_smem);
     Cx<R> *lds_win = reinterpret_cast<Cx<R> *>(la_smem + sizeof(LaLds<R>));   // [LA_NH][2][nmodes][wpitch] helper sample windows
@@ -236,17 +245,17 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
     if (wave == 0) {
         // ============================================================ chain wave: lanes <-> the 64 steps of a block
         LaConst<R, NPART> K;
-        K.mu = *a.mu;
+        K.mu = *amu;
         {
             const Cx<R> c0 = sy[0];
             K.R_re = c0.re; K.R_im = c0.im;
         }
         K.code0_re = K.R_re; K.code0_im = K.R_im;       // np.array_split(symbs, 2): NPART + 1 codes, then NPART partitions
         tab_fill<R, NPART>(K.tab, sy, 0, NPART + 1);
-        Cx<R> *errow = a.err + (size_t)mode * a.err_pitch + a.err_off;
+        Cx<R> *errow = aerr + (size_t)mode * a.err_pitch + a.err_off;
         Cx<R> ynext{0, 0};
         using V4 = typename Cx2T<R>::type;
-        const GramPair<R> *grow = a.G + lane;           // this lane's column of the Gram rows
+        const GramPair<R> *grow = aG + lane;           // this lane's column of the Gram rows
         GramPair<R> ga[LA_PD], gb[LA_PD];               // two register sets: one is consumed while the other one loads
 #pragma unroll
         for (int u = 0; u < LA_PD; u++) ga[u] = grow[(size_t)u * LA_B];
@@ -307,8 +316,8 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
     const bool own = lane < nf;
     const int fl = own ? f0 + lane : 0;
     const int kf = fl / a.ntaps, tf = fl - kf * a.ntaps;
-    const Cx<R> *xl = a.E + (size_t)kf * a.L + tf;                     // x_l[f] = xl[l * os]
-    Cx<R> *wrow = a.wx + (size_t)mode * ntot;
+    const Cx<R> *xl = aE + (size_t)kf * a.L + tf;                     // x_l[f] = xl[l * os]
+    Cx<R> *wrow = awx + (size_t)mode * ntot;
     Cx<R> w = own ? ldg(wrow + fl) : Cx<R>{0, 0};
 
     // Sample windows.  A helper stages, per 64-step block, the (63*os + ntaps) samples of every input mode into its own
@@ -336,7 +345,7 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
     auto stage_load = [&](Cx<R> (&r)[WREG], int kb) {
         const int64_t base = (int64_t)kb * LA_B * os_;
         if (base + wpitch <= a.L) {                                    // whole window inside the capture: no clamping
-            const Cx<R> *pb = a.E + base;
+            const Cx<R> *pb = aE + base;
 #pragma unroll
             for (int q = 0; q < WREG; q++) r[q] = ldg(pb + soff[q]);
         } else {                                                       // the last block may reach past the capture
@@ -345,7 +354,7 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
                 const int64_t row = soff[q] / a.L * a.L;
                 int64_t g = base + (soff[q] - row);
                 if (g > a.L - 1) g = a.L - 1;
-                r[q] = ldg(a.E + row + g);
+                r[q] = ldg(aE + row + g);
             }
         }
     };
@@ -427,22 +436,26 @@ template <typename R> static size_t gram_bytes(int64_t TrSyms)
     return (size_t)(nblk * LA_B + 2 * LA_PD) * LA_B * sizeof(GramPair<R>);
 }
 
-template <typename R> int gram_build(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
+// nch captures (nch, nmodes, L) -> nch Gram tables, gram_bytes() apart, in ONE scratch allocation
+template <typename R> int gram_build(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram, int nch = 1)
 {
     int rc = ensure_init();
     if (rc) return rc;
     const size_t bytes = gram_bytes<R>(TrSyms);
-    void *G = nullptr;
-    if ((rc = scratch(4, bytes, &G))) return rc;
+    void *G0 = nullptr;
+    if ((rc = scratch(4, bytes * (size_t)nch, &G0))) return rc;
     const int64_t nblk = (TrSyms + LA_B - 1) / LA_B;
-    // rows past the last block are read by the prefetch queue only: keep them zero
-    QH_HIP(hipMemsetAsync((char *)G + (size_t)nblk * LA_B * LA_B * sizeof(GramPair<R>), 0, (size_t)2 * LA_PD * LA_B * sizeof(GramPair<R>), g_stream));
     const size_t lds = (size_t)nmodes * ((2 * LA_B - 1) * os + ntaps) * sizeof(Cx<R>);
     QH_REQUIRE(lds <= 64 * 1024, "gram: nmodes*(127*os+ntaps) samples exceed the LDS tile");
-    if (nblk > 0) hipLaunchKernelGGL((gram_kernel<R>), dim3((unsigned)nblk), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps,
-                                     TrSyms, (GramPair<R> *)G);
+    for (int c = 0; c < nch; c++) {
+        char *G = (char *)G0 + bytes * (size_t)c;
+        // rows past the last block are read by the prefetch queue only: keep them zero
+        QH_HIP(hipMemsetAsync(G + (size_t)nblk * LA_B * LA_B * sizeof(GramPair<R>), 0, (size_t)2 * LA_PD * LA_B * sizeof(GramPair<R>), g_stream));
+        if (nblk > 0) hipLaunchKernelGGL((gram_kernel<R>), dim3((unsigned)nblk), dim3(256), lds, g_stream,
+                                         (const Cx<R> *)E + (size_t)c * nmodes * L, nmodes, L, os, ntaps, TrSyms, (GramPair<R> *)G);
+    }
     QH_HIP(hipGetLastError());
-    *gram = G;
+    *gram = G0;
     return QH_OK;
 }
 
@@ -475,7 +488,7 @@ template <typename R> static size_t la_lds_bytes(const LaArgs<R> &a)
 
 template <typename R, int METHOD> static int launch_la_parts(const LaArgs<R> &a, int npart)
 {
-    dim3 grid(a.nsel), block(64 * (1 + LA_NH));
+    dim3 grid(a.nsel, a.nch), block(64 * (1 + LA_NH));
     const size_t lds = la_lds_bytes(a);
 #define QH_LA_NP(N) case N: hipLaunchKernelGGL((train_la_kernel<R, METHOD, N>), grid, block, lds, g_stream, a); break;
     switch (npart) {
@@ -488,7 +501,7 @@ template <typename R, int METHOD> static int launch_la_parts(const LaArgs<R> &a,
 
 template <typename R> int launch_la(const LaArgs<R> &a)
 {
-    dim3 grid(a.nsel), block(64 * (1 + LA_NH));
+    dim3 grid(a.nsel, a.nch), block(64 * (1 + LA_NH));
     const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
     const size_t lds = la_lds_bytes(a);
     int rc = QH_OK;

@@ -150,3 +150,80 @@ class ResidentReceiver:
         apply_ = cs * (self.nmodes * self.os + nsel)
         bps = nsel * (cs + cs + cs // 2) if self.Mtestangles else 0
         return dict(train=train, apply=apply_, bps=bps, total=train + apply_ + bps)
+
+
+class ChannelBank:
+    """
+    ``nch`` independent captures of identical shape (WDM channels) resident on ONE GPU and processed
+    together.  One exact training chain occupies one workgroup, i.e. 1/256 of the chip, so the natural way to fill an
+    MI355X with the exact recurrence is many channels side by side: the trainers take the channel as ``blockIdx.y``
+    (one launch per stage for the whole bank), the Gram tables, the filter and the phase search - already chip-wide per
+    capture - run channel after channel on the same stream.  Per channel the results are bit-identical to a
+    :class:`ResidentReceiver` of that capture.
+
+    HBM per channel (complex64, 2 modes, 2 samples/symbol, N symbols): capture 32 N, Gram table 1024 N, error traces 16 N per
+    stage, outputs 40 N bytes - about 1.1 kB per symbol, so 288 GB hold e.g. 64 channels of 2^22 symbols.
+    """
+
+    def __init__(self, nch, nmodes, L, os, M, Ntaps, mu, **kw):
+        self.nch = int(nch)
+        # one receiver object provides the shared constants and the per-channel views; its own big buffers are replaced
+        self.rx = ResidentReceiver(nmodes, 8 * Ntaps * os, os, M, Ntaps, mu, **kw)       # tiny dummy capture
+        r = self.rx
+        if r.segments:
+            raise ValueError("a channel bank runs the exact recurrence (tier A)")
+        self.nmodes, self.L, self.os, self.Ntaps, self.ct, self.rt = int(nmodes), int(L), int(os), int(Ntaps), r.ct, r.rt
+        TrSyms = kw.get("TrSyms", (None,) * r.nstage)
+        self.TrSyms = tuple(_host._cal_training_symbol_len(os, Ntaps, L) if t is None else int(t) for t in TrSyms[:r.nstage])
+        self.N = (self.L - self.Ntaps + 1) // self.os
+        nsel = r.modes.size
+        self.E = DeviceArray((self.nch, nmodes, L), self.ct)
+        self.wxy = DeviceArray((self.nch, nmodes, nmodes, Ntaps), self.ct)
+        self.wxy0 = DeviceArray.from_host(np.tile(_host._init_taps(Ntaps, nmodes, nmodes, self.ct), (self.nch, 1, 1, 1)))
+        self.mu = [DeviceArray((self.nch,), self.rt) for _ in range(r.nstage)]
+        self.mu_init = [DeviceArray.from_host(np.full(self.nch, m, dtype=self.rt)) for m in r.mu0]
+        self.err = [DeviceArray((self.nch, nmodes, self.TrSyms[s] * r.Niter[s]), self.ct, zero=True) for s in range(r.nstage)]
+        self.eq = DeviceArray((self.nch, nsel, self.N), self.ct)
+        if r.Mtestangles:
+            self.idx = DeviceArray((self.nch, nsel, self.N), np.int32)
+            self.ph = DeviceArray((self.nch, nsel, self.N), self.rt)
+            self.out = DeviceArray((self.nch, nsel, self.N), self.ct)
+        self._gram = None
+        _lib.sync()
+
+    def load(self, ch, E):
+        E = np.ascontiguousarray(np.asarray(E), dtype=self.ct)
+        assert E.shape == (self.nmodes, self.L)
+        self.E.row(ch).set(E)
+
+    def run(self):
+        """One pass of the hot path over all channels; enqueue only."""
+        r = self.rx
+        self.wxy.copy_from(self.wxy0)
+        for m, m0 in zip(self.mu, self.mu_init):
+            m.copy_from(m0)
+        self._gram = _k.gram_build_batch_dev(self.E, self.os, self.Ntaps, self.TrSyms[0]) if len(set(self.TrSyms)) == 1 else None
+        for s in range(r.nstage):
+            _k.train_equaliser_batch_dev(self.E, self.TrSyms[s], r.Niter[s], self.os, self.mu[s], self.wxy, r.modes, r.adaptive[s],
+                                         r.symbols[s], r.methods[s], self.err[s], gram=self._gram)
+        for c in range(self.nch):
+            _k.apply_filter_to_signal_dev(self.E.row(c), self.os, self.wxy.row(c), r.modes, self.eq.row(c))
+            if r.Mtestangles:
+                _dsp.bps_recover_dev(self.eq.row(c), r.Mtestangles, r.alphabet, r.Nbps, self.idx.row(c), self.ph.row(c), self.out.row(c))
+
+    def ser(self, ch, symbols_tx, maxlag=256, window=4096, trim=0):
+        """Per-row symbol errors of channel ``ch`` (device harness, see :meth:`ResidentReceiver.ser`)."""
+        from .core import ber_functions as _ber
+        r = self.rx
+        if getattr(r, "alphabet", None) is None:
+            r.alphabet = DeviceArray.from_host(r.alphabet_host)
+        idx_tx = _ber.tx_indices_dev(np.ascontiguousarray(symbols_tx, dtype=self.ct), r.alphabet)
+        return _ber.cal_ser_dev((self.out if r.Mtestangles else self.eq).row(ch), idx_tx, r.alphabet, maxlag, window, trim)
+
+    def fetch(self, ch):
+        _lib.sync()
+        res = dict(wxy=self.wxy.row(ch).to_host(), err=tuple(e.row(ch).to_host() for e in self.err), eq=self.eq.row(ch).to_host(),
+                   mu=tuple(m.to_host()[ch] for m in self.mu))
+        if self.rx.Mtestangles:
+            res.update(out=self.out.row(ch).to_host(), ph=self.ph.row(ch).to_host(), idx=self.idx.row(ch).to_host())
+        return res

@@ -183,3 +183,33 @@ def test_resident_receiver_device_ser_equals_host_ser():
         nerr, ncmp, mode, rot, lag = synth.count_symbol_errors(row, sig.symbols, sig.coded_symbols, max_lag=256, trim=2000)
         assert (d["tx_mode"], d["rotation"]) == (mode, rot) and d["lag"] == lag + 2000      # host lag is relative to the trimmed row
         assert abs(d["errors"] - nerr) <= 2 and abs(d["compared"] - ncmp) <= 2 * 256 + 4000, (d, nerr, ncmp)
+
+
+# ------------------------------------------------------------------------------------------------ channel bank (8e, within a GPU)
+@pytest.mark.parametrize("methods,adaptive", [(("mcma", "sbd"), (False, False)), (("cma", "mrde"), (False, False)),
+                                              (("mcma", "mddma"), (True, True))])
+def test_channel_bank_equals_single_receivers(methods, adaptive):
+    """A bank of independent captures trained in ONE launch per stage (channel = blockIdx.y) gives bit-identical taps,
+    errors and recovered symbols to one ResidentReceiver per capture."""
+    from qampy_amd.pipeline import ChannelBank, ResidentReceiver
+    nch, M = 3, 16 if "mrde" not in methods else 64
+    sigs = [synth.make_capture(M, 2 ** 13 + 100 * c, nmodes=2, snr_db=24, theta=0.5 + 0.1 * c, dgd=20e-12, linewidth=10e3, seed=50 + c,
+                               dtype=np.complex64)[:, :2 * 2 ** 13] for c in range(nch)]
+    kw = dict(methods=methods, Niter=(2,) * len(methods), adaptive_stepsize=adaptive, TrSyms=(None,) * len(methods), Mtestangles=32,
+              Nbps=10)
+    L = sigs[0].shape[1]
+    bank = ChannelBank(nch, 2, L, 2, M, 15, (2e-3, 5e-4)[:len(methods)], alphabet=sigs[0].coded_symbols, **kw)
+    for c, sg in enumerate(sigs):
+        bank.load(c, sg)
+    bank.run()
+    for c, sg in enumerate(sigs):
+        rx = ResidentReceiver(2, L, 2, M, 15, (2e-3, 5e-4)[:len(methods)], alphabet=sg.coded_symbols, **kw)
+        rx.load(sg)
+        rx.run()
+        one, many = rx.fetch(), bank.fetch(c)
+        for k in ("wxy", "eq", "out", "idx", "ph"):
+            assert np.array_equal(one[k], many[k]), (c, k)
+        for e1, e2 in zip(one["err"], many["err"]):
+            assert np.array_equal(e1, e2)
+        assert one["mu"] == many["mu"]
+        assert np.all(np.isfinite(one["wxy"])) and np.abs(one["err"][-1]).max() > 0
