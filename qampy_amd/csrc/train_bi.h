@@ -25,48 +25,6 @@ constexpr int BI_JW = LA_B / BI_W;       // steps owned by a wave
 constexpr int BI_PAD = BI_W + 1;         // row pitch of the [i][w] exchange buffers (bank-conflict padding)
 constexpr int BI_MAXTAPS = 128;          // taps per output mode (2 per lane in the tap-update layout)
 
-// Gram terms of one block only (lags 1..63 inside the block): G[l][i] = G(l, blk + i) for i > l - blk, else 0
-template <typename R>
-__global__ void __launch_bounds__(256) gram_cur_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, Cx<R> *G)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    Cx<R> *tile = reinterpret_cast<Cx<R> *>(smem);
-    const int64_t blk = (int64_t)blockIdx.x * LA_B;
-    const int span = (LA_B - 1) * os + ntaps;
-    for (int k = 0; k < nmodes; k++) {
-        const int64_t s0 = blk * os;
-        for (int s = threadIdx.x; s < span; s += 256) {
-            const int64_t g = s0 + s;
-            tile[k * span + s] = g < L ? ldg(E + (size_t)k * L + g) : Cx<R>{0, 0};
-        }
-    }
-    __syncthreads();
-    const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const bool t_ok = blk + i < TrSyms;
-    for (int l4 = 0; l4 < 16; l4 += 4) {
-        const int j0 = q * 16 + l4;
-        R cr[4] = {0, 0, 0, 0}, ci[4] = {0, 0, 0, 0};
-        for (int k = 0; k < nmodes; k++) {
-            const Cx<R> *row = tile + k * span;
-            for (int t = 0; t < ntaps; t++) {
-                const Cx<R> b = row[i * os + t];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const Cx<R> a = row[(j0 + u) * os + t];
-                    cr[u] = fma_(a.re, b.re, fma_(a.im, b.im, cr[u]));
-                    ci[u] = fma_(a.re, b.im, fma_(-a.im, b.re, ci[u]));
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = j0 + u;
-            const bool ok = t_ok && i > j && blk + j < TrSyms;
-            stg(G + (size_t)(blk + j) * LA_B + i, ok ? Cx<R>{cr[u], ci[u]} : Cx<R>{0, 0});
-        }
-    }
-}
-
 // sum over groups of BI_W consecutive lanes; every lane of a group gets the group's total (fixed order -> deterministic)
 __device__ __forceinline__ void group_csum(float &re, float &im)
 {
@@ -525,8 +483,8 @@ template <typename R> int gram_cur_build(const void *E, int nmodes, int64_t L, i
     const size_t lds = (size_t)nmodes * ((LA_B - 1) * os + ntaps) * sizeof(Cx<R>);
     QH_REQUIRE(lds <= 64 * 1024, "gram: nmodes*(63*os+ntaps) samples exceed the LDS tile");
     for (int c = 0; c < nch && nblk > 0; c++)
-        hipLaunchKernelGGL((gram_cur_kernel<R>), dim3((unsigned)nblk), dim3(256), lds, g_stream, (const Cx<R> *)E + (size_t)c * nmodes * L, nmodes, L,
-                           os, ntaps, TrSyms, (Cx<R> *)((char *)G + bytes * (size_t)c));
+        hipLaunchKernelGGL((gram_slide_kernel<R, false>), dim3((unsigned)nblk), dim3(256), lds, g_stream, (const Cx<R> *)E + (size_t)c * nmodes * L,
+                           nmodes, L, os, ntaps, TrSyms, (Cx<R> *)((char *)G + bytes * (size_t)c));
     QH_HIP(hipGetLastError());
     *gram = G;
     return QH_OK;

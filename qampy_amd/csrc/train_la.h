@@ -30,16 +30,22 @@ constexpr int LA_MAXPART = 8;     // RDE/MRDE partitions handled by the vector s
 template <typename R> struct GramPair { Cx<R> cur, next; };   // per (step l, lane i): G(l, blk+i) [i > l-blk] and G(l, blk+64+i)
 
 // ------------------------------------------------------------------------------------------------ Gram precompute
-// grid = number of 64-step blocks, 256 threads.  Thread (i = t & 63, q = t >> 6) produces the pairs of lane i for the
-// 16 steps l = blk + 16 q .. +15, four steps at a time so that every LDS sample feeds 8 complex multiply-adds.
-template <typename R>
-__global__ void __launch_bounds__(256) gram_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms,
-                                                   GramPair<R> *G)
+// G(l, l+d) = sum_k sum_t conj(E[k, l os + t]) E[k, (l+d) os + t]  is, along a diagonal (fixed lag d), a SLIDING window sum of
+// the products p_d(n) = sum_k conj(E[k,n]) E[k,n + d os]: one step further drops `os` products and adds `os` new ones.  A
+// thread therefore owns (a half of) one diagonal of a 64-step block: it forms its first window directly and slides 31 times
+// - (ntaps + 31 os) instead of 32 ntaps products per mode, 5x fewer for 41 taps - and stores entry (step j, target j + d)
+// where the trainers expect it.  grid = number of 64-step blocks, 256 threads = 128 lags x 2 halves of the block.
+// Rounding: a slid sum carries at most 31 x 2 os extra additions; the trainers see Gram terms good to a few 1e-7 relative
+// either way (and every form of the trainer is compared with the oracle on its own).
+template <typename R, bool PAIR>
+__global__ void __launch_bounds__(256) gram_slide_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, Cx<R> *G)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Cx<R> *tile = reinterpret_cast<Cx<R> *>(smem);
+    constexpr int NT = PAIR ? 2 * LA_B : LA_B;                    // targets reachable from a block: this block (+ the next one)
+    constexpr int GS = PAIR ? 2 : 1;                              // Cx elements per (step, lane) entry
     const int64_t blk = (int64_t)blockIdx.x * LA_B;
-    const int span = (2 * LA_B - 1) * os + ntaps;                 // samples per mode covering steps blk .. blk+127
+    const int span = (NT - 1) * os + ntaps;                       // samples per mode covering steps blk .. blk + NT - 1
     for (int k = 0; k < nmodes; k++) {
         const int64_t s0 = blk * os;
         for (int s = threadIdx.x; s < span; s += 256) {
@@ -47,41 +53,47 @@ __global__ void __launch_bounds__(256) gram_kernel(const Cx<R> *E, int nmodes, i
             tile[k * span + s] = g < L ? ldg(E + (size_t)k * L + g) : Cx<R>{0, 0};
         }
     }
+    // entries a lane must never see (targets at or before the source step) are zeros
+    for (int e = threadIdx.x; e < LA_B * LA_B; e += 256) {
+        const int j = e >> 6, i = e & 63;
+        if (i <= j) stg(G + ((size_t)(blk + j) * LA_B + i) * GS, Cx<R>{0, 0});
+    }
     __syncthreads();
-    const int i = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const bool cur_ok = blk + i < TrSyms, next_ok = blk + LA_B + i < TrSyms;
-    for (int l4 = 0; l4 < 16; l4 += 4) {
-        const int j0 = q * 16 + l4;                               // first of four source steps (relative to blk)
-        R cr[4] = {0, 0, 0, 0}, ci[4] = {0, 0, 0, 0}, nr[4] = {0, 0, 0, 0}, ni[4] = {0, 0, 0, 0};
-        for (int k = 0; k < nmodes; k++) {
-            const Cx<R> *row = tile + k * span;
-            for (int t = 0; t < ntaps; t++) {
-                const Cx<R> bc = row[i * os + t];                 // x_{blk+i}[f]
-                const Cx<R> bn = row[(i + LA_B) * os + t];        // x_{blk+64+i}[f]
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const Cx<R> a = row[(j0 + u) * os + t];       // x_l[f], wave-uniform address (LDS broadcast)
-                    // conj(a) * b = (ar br + ai bi) + j (ar bi - ai br)
-                    cr[u] = fma_(a.re, bc.re, fma_(a.im, bc.im, cr[u]));
-                    ci[u] = fma_(a.re, bc.im, fma_(-a.im, bc.re, ci[u]));
-                    nr[u] = fma_(a.re, bn.re, fma_(a.im, bn.im, nr[u]));
-                    ni[u] = fma_(a.re, bn.im, fma_(-a.im, bn.re, ni[u]));
+    const int d = threadIdx.x & 127, half = threadIdx.x >> 7;     // lag, half of the block
+    if (d == 0 || d >= NT) {                                       // PAIR = false: lags >= 64 do not exist
+        return;
+    }
+    const int j0 = half * 32;
+    int jend = j0 + 32;                                            // steps j with target j + d < NT
+    if (jend > NT - d) jend = NT - d;
+    if (j0 >= jend) return;
+    // first window, directly
+    R sr = 0, si = 0;
+    for (int k = 0; k < nmodes; k++) {
+        const Cx<R> *ra = tile + k * span + j0 * os, *rb = ra + d * os;
+        for (int t = 0; t < ntaps; t++) {
+            const Cx<R> a = ra[t], b = rb[t];
+            sr = fma_(a.re, b.re, fma_(a.im, b.im, sr));          // conj(a) * b
+            si = fma_(a.re, b.im, fma_(-a.im, b.re, si));
+        }
+    }
+    for (int j = j0; j < jend; j++) {
+        const int it = j + d;                                      // target relative to the block start
+        const bool ok = blk + j < TrSyms && blk + it < TrSyms;
+        const Cx<R> v = ok ? Cx<R>{sr, si} : Cx<R>{0, 0};
+        if (it < LA_B) stg(G + ((size_t)(blk + j) * LA_B + it) * GS, v);
+        else if (PAIR) stg(G + ((size_t)(blk + j) * LA_B + (it - LA_B)) * GS + 1, v);
+        if (j + 1 < jend) {                                        // slide: drop the first `os` products, add the next `os`
+            for (int k = 0; k < nmodes; k++) {
+                const Cx<R> *ra = tile + k * span + j * os, *rb = ra + d * os;
+                for (int t = 0; t < os; t++) {
+                    const Cx<R> a0 = ra[t], b0 = rb[t], a1 = ra[ntaps + t], b1 = rb[ntaps + t];
+                    sr = fma_(a1.re, b1.re, fma_(a1.im, b1.im, sr));
+                    si = fma_(a1.re, b1.im, fma_(-a1.im, b1.re, si));
+                    sr = fma_(-a0.re, b0.re, fma_(-a0.im, b0.im, sr));
+                    si = fma_(-a0.re, b0.im, fma_(a0.im, b0.re, si));
                 }
             }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = j0 + u;
-            const bool l_ok = blk + j < TrSyms;
-            GramPair<R> p;
-            const bool c_ok = l_ok && cur_ok && i > j;            // lanes <= j already hold their final output: add zero
-            p.cur = c_ok ? Cx<R>{cr[u], ci[u]} : Cx<R>{0, 0};
-            p.next = (l_ok && next_ok) ? Cx<R>{nr[u], ni[u]} : Cx<R>{0, 0};
-            using V = typename Cx2T<R>::type;
-            V *dst = reinterpret_cast<V *>(G + (size_t)(blk + j) * LA_B + i);
-            V v0, v1;
-            v0.x = p.cur.re; v0.y = p.cur.im; v1.x = p.next.re; v1.y = p.next.im;
-            dst[0] = v0; dst[1] = v1;
         }
     }
 }
@@ -451,8 +463,8 @@ template <typename R> int gram_build(const void *E, int nmodes, int64_t L, int o
         char *G = (char *)G0 + bytes * (size_t)c;
         // rows past the last block are read by the prefetch queue only: keep them zero
         QH_HIP(hipMemsetAsync(G + (size_t)nblk * LA_B * LA_B * sizeof(GramPair<R>), 0, (size_t)2 * LA_PD * LA_B * sizeof(GramPair<R>), g_stream));
-        if (nblk > 0) hipLaunchKernelGGL((gram_kernel<R>), dim3((unsigned)nblk), dim3(256), lds, g_stream,
-                                         (const Cx<R> *)E + (size_t)c * nmodes * L, nmodes, L, os, ntaps, TrSyms, (GramPair<R> *)G);
+        if (nblk > 0) hipLaunchKernelGGL((gram_slide_kernel<R, true>), dim3((unsigned)nblk), dim3(256), lds, g_stream,
+                                         (const Cx<R> *)E + (size_t)c * nmodes * L, nmodes, L, os, ntaps, TrSyms, (Cx<R> *)G);
     }
     QH_HIP(hipGetLastError());
     *gram = G0;
