@@ -3,8 +3,15 @@
 // Reference behaviour: qampy/core/equalisation/pythran_equalisation.py:128-173 (complex), :78-108 (real),
 // error functions :178-231 / :110-125, adapt_step :12-22, partition_value :4-9, det_symbol :240-265.
 //
-// The recurrence  w[i+1] = w[i] + mu*e(w[i].x[i])*conj(x[i])  is strictly sequential in i, so one output mode is ONE
-// dependent chain and this kernel is latency bound, not HBM or MFMA bound.  Mapping:
+// Three kernel forms of the same recurrence live here and in the two headers below; train_dev() picks one per call:
+//   direct (this file)      every method, adaptive step, real-valued trainer, window batches, tiny captures
+//   look-ahead (train_la.h) cma / cma2 / sgncma / mcma with a fixed step: Gram terms, no reduction on the critical wave
+//   block-iterative (train_bi.h)  rde / mrde / sbd / mddma / dd / sbd_data and every method with the adaptive step:
+//                           fixed-point sweeps over 64-step blocks on 8 wavefronts
+// All three give the reference's numbers up to the order of floating-point additions (tests compare them pairwise).
+//
+// Direct form.  The recurrence  w[i+1] = w[i] + mu*e(w[i].x[i])*conj(x[i])  is strictly sequential in i, so one output mode
+// is ONE dependent chain and this kernel is latency bound, not HBM or MFMA bound.  Mapping:
 //   * one wave64 per chain; the nmodes*ntaps taps are spread round-robin over the 64 lanes (TPL taps per lane) and
 //     live in VGPRs for the whole sweep;
 //   * per step every lane multiplies its taps with its samples, a 6-level DPP butterfly (row_* / row_bcast) sums

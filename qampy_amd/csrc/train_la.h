@@ -7,7 +7,7 @@
 // costs ~360 cycles per step.  Unrolling the tap update gives the algebraically identical
 //        y_i = W . x_i + sum_{l=l0}^{i-1} c_l * G(l, i) ,      G(l, i) = sum_f conj(x_l[f]) * x_i[f]
 // for any earlier tap state W = w_{l0}.  G depends on the capture only (not on the taps, the mode, the stage or the
-// sweep), so it is computed once, chip-wide, by gram_kernel.  With lanes <-> the 64 steps of a block the critical wave
+// sweep), so it is computed once, chip-wide, by gram_slide_kernel.  With lanes <-> the 64 steps of a block the critical wave
 // then needs per step: one 16 B load, the error function on its 64 pending outputs, two v_readlane and two complex
 // multiply-adds - ~11 instructions, no cross-lane reduction, no tap update.  Three helper waves (one per remaining
 // SIMD of the CU) keep the taps one block behind ( W_k = W_{k-1} + sum_{l in block k-1} c_l conj(x_l) ) and produce
