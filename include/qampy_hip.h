@@ -208,6 +208,16 @@ int qh_ser_c64_dev(const void *E, int64_t N, const int32_t *idx_tx, int nmodes, 
 int qh_ser_c128_dev(const void *E, int64_t N, const int32_t *idx_tx, int nmodes, int64_t ntx, const void *symbols, int M,
                     int maxlag, int64_t window, int64_t trim, int64_t *result);
 
+/* On-device synthesis of an impaired capture (the reference builds its test signals with signals.py,
+ * core/resample.py:73-126 and core/impairments.py:94-233): random Gray-labelled M-QAM symbols (Philox, keyed by seed /
+ * mode / symbol index), root-raised-cosine shaping at `os` samples per symbol, optional Wiener phase noise (phase_var =
+ * 2 pi linewidth / fs per sample), first-order PMD (theta, DGD in samples; 2 modes) and AWGN at snr_db (reference
+ * convention sigma = 10^(-snr/20) sqrt(os)).  Outputs in HBM: E (nmodes, nsym*os) complex64, symbols (nmodes, nsym)
+ * complex64, idx_tx (nmodes, nsym) int32 (index into alphabet).  alphabet (M,) complex64 in HBM. */
+int qh_synth_capture_c64_dev(void *E, void *symbols, int32_t *idx_tx, const void *alphabet, int M, int nmodes, int64_t nsym,
+                             int os, double beta, double snr_db, int have_snr, double theta, double dgd_samples, int have_pmd,
+                             double phase_var, uint64_t seed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,8 @@ SIGNATURES = {
     "qh_gram_build_c128_batch_dev": [_vp, _i, _i, _i64, _i, _i, _i64, C.POINTER(_vp)],
     "qh_train_equaliser_c64_batch_dev": [_vp, _i] + _train_sig(_pf, dev=True)[1:] + [_vp],
     "qh_train_equaliser_c128_batch_dev": [_vp, _i] + _train_sig(_pd, dev=True)[1:] + [_vp],
+    "qh_synth_capture_c64_dev": [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, C.c_double, C.c_double, _i, C.c_double, C.c_double, _i, C.c_double,
+                                 C.c_uint64],
     "qh_ser_c64_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
     "qh_ser_c128_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
 }

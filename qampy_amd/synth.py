@@ -32,7 +32,7 @@ def _rrc_frequency_response(n, os, beta):
 
 
 def make_capture(M, nsym, nmodes=2, os=2, snr_db=None, theta=None, dgd=None, linewidth=0., fb=20e9, beta=0.1,
-                 seed=1000, dtype=np.complex64, shift=0):
+                 seed=1000, dtype=np.complex64, shift=0, symbols=None):
     """
     Build one impaired capture.
 
@@ -45,7 +45,7 @@ def make_capture(M, nsym, nmodes=2, os=2, snr_db=None, theta=None, dgd=None, lin
     rng = np.random.default_rng(seed)
     alphabet = theory.coded_symbols_qam(M, dtype=np.complex128)
     idx = rng.integers(0, M, size=(nmodes, nsym))
-    syms = alphabet[idx]
+    syms = alphabet[idx] if symbols is None else np.asarray(symbols, dtype=np.complex128)      # given symbols: cross-checks
     L = nsym * os
     fs = fb * os
     # zero-stuff to os samples/symbol and RRC-shape in the frequency domain (circular)
@@ -81,6 +81,33 @@ def make_capture(M, nsym, nmodes=2, os=2, snr_db=None, theta=None, dgd=None, lin
         x = np.roll(x, shift, axis=1)
     return SignalQAM(np.ascontiguousarray(x.astype(dtype)), M, fb=fb, fs=fs, symbols=syms.astype(dtype),
                      coded_symbols=alphabet.astype(dtype))
+
+
+def make_capture_dev(M, nsym, nmodes=2, os=2, snr_db=None, theta=None, dgd=None, linewidth=0., fb=20e9, beta=0.1, seed=1000, E=None):
+    """
+    :func:`make_capture` on the GPU (``qh_synth_capture_c64_dev``, csrc/synth.hip): the capture never exists on the host.
+    Same impairment conventions; time-domain filters instead of FFTs and a counter-based generator instead of numpy's, so
+    the waveforms agree statistically (and, for given symbols, to the filter truncation error - see the tests), not bit for bit.
+
+    Returns ``dict(E=(nmodes, nsym*os) complex64, symbols=(nmodes, nsym) complex64, idx_tx=(nmodes, nsym) int32, alphabet=(M,))``
+    of :class:`qampy_amd._lib.DeviceArray` plus ``fb, fs, M``.  ``E``: optional preallocated ``(nmodes, nsym*os)`` DeviceArray
+    (e.g. one channel of a :class:`qampy_amd.pipeline.ChannelBank`) to synthesise into.
+    """
+    from . import _lib
+    from ._lib import DeviceArray
+    alphabet = np.ascontiguousarray(theory.coded_symbols_qam(M, dtype=np.complex64))
+    d_al = DeviceArray.from_host(alphabet)
+    if E is None:
+        E = DeviceArray((nmodes, nsym * os), np.complex64)
+    assert tuple(E.shape) == (nmodes, nsym * os) and np.dtype(E.dtype) == np.complex64
+    sy = DeviceArray((nmodes, nsym), np.complex64)
+    idx = DeviceArray((nmodes, nsym), np.int32)
+    fs = fb * os
+    _lib.call("qh_synth_capture_c64_dev", E.ptr, sy.ptr, idx.ptr, d_al.ptr, int(M), int(nmodes), int(nsym), int(os), float(beta),
+              float(snr_db if snr_db is not None else 0.), int(snr_db is not None), float(theta if theta is not None else 0.),
+              float((dgd or 0.) * fs), int(theta is not None and nmodes == 2), float(2 * np.pi * linewidth / fs if linewidth else 0.),
+              int(seed))
+    return dict(E=E, symbols=sy, idx_tx=idx, alphabet=d_al, alphabet_host=alphabet, fb=fb, fs=fs, M=M)
 
 
 # ------------------------------------------------------------------------------------------------- SER harness

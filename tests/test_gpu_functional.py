@@ -213,3 +213,56 @@ def test_channel_bank_equals_single_receivers(methods, adaptive):
             assert np.array_equal(e1, e2)
         assert one["mu"] == many["mu"]
         assert np.all(np.isfinite(one["wxy"])) and np.abs(one["err"][-1]).max() > 0
+
+
+# ------------------------------------------------------------------------------------------------ on-device synthesis (8f.4)
+def test_device_synthesis_matches_host_generator_for_given_symbols():
+    """Shaping + PMD of csrc/synth.hip (time-domain FIRs) against the host generator (frequency domain) on the SAME symbols."""
+    M, nsym = 16, 2 ** 14
+    d = synth.make_capture_dev(M, nsym, nmodes=2, theta=np.pi / 5.6, dgd=30e-12, seed=7)
+    E, sy, idx = d["E"].to_host(), d["symbols"].to_host(), d["idx_tx"].to_host()
+    assert np.array_equal(sy, d["alphabet_host"][idx])
+    counts = np.bincount(idx.ravel(), minlength=M)
+    assert counts.min() > 0.85 * idx.size / M and counts.max() < 1.15 * idx.size / M          # uniform symbols
+    assert abs(np.mean(np.abs(E) ** 2) - 1) < 0.01                                           # unit power
+    ref = np.asarray(synth.make_capture(M, nsym, nmodes=2, theta=np.pi / 5.6, dgd=30e-12, symbols=sy, dtype=np.complex128))
+    err = np.sqrt(np.mean(np.abs(E - ref) ** 2) / np.mean(np.abs(ref) ** 2))
+    assert err < 1e-2, err              # pulse truncated to +-48 symbols, 33-tap fractional delays, analytic power normalisation
+    # without PMD the modes are independent pulse trains
+    d0 = synth.make_capture_dev(M, nsym, nmodes=2, seed=7)
+    ref0 = np.asarray(synth.make_capture(M, nsym, nmodes=2, symbols=d0["symbols"].to_host(), dtype=np.complex128))
+    assert np.sqrt(np.mean(np.abs(d0["E"].to_host() - ref0) ** 2)) < 1e-2
+
+
+def test_device_synthesis_noise_and_phase_noise_statistics():
+    M, nsym, os_ = 4, 2 ** 16, 2
+    clean = synth.make_capture_dev(M, nsym, nmodes=2, seed=3)["E"].to_host()
+    noisy = synth.make_capture_dev(M, nsym, nmodes=2, snr_db=15., seed=3)["E"].to_host()
+    nvar = np.mean(np.abs(noisy - clean) ** 2)
+    assert abs(nvar / (10 ** (-15. / 10) * os_) - 1) < 0.02, nvar                             # sigma^2 = P 10^(-snr/10) os
+    n = noisy - clean
+    assert abs(np.mean(n.real ** 2) / np.mean(n.imag ** 2) - 1) < 0.03 and abs(np.mean(n)) < 3e-3
+    lw, fb = 1e6, 20e9
+    pn = synth.make_capture_dev(M, nsym, nmodes=2, linewidth=lw, fb=fb, seed=3)["E"].to_host()
+    ph = np.unwrap(np.angle(np.sum(pn * np.conj(clean), axis=0) if False else (pn * np.conj(clean))[0][np.abs(clean[0]) > 0.3]))
+    sel = np.nonzero(np.abs(clean[0]) > 0.3)[0]
+    # Wiener process: increments over a gap of g samples have variance g * 2 pi lw / fs; no jumps at the 1024-sample tiles
+    gaps = np.diff(sel)
+    inc = np.diff(ph)
+    var = 2 * np.pi * lw / (fb * os_)
+    assert abs(np.sum(inc ** 2) / (np.sum(gaps) * var) - 1) < 0.05
+    assert np.max(np.abs(inc) / np.sqrt(gaps * var)) < 7
+    assert abs(ph[-1] - ph[0]) > 0.05                                                         # it really drifts
+
+
+def test_receiver_on_device_generated_capture():
+    """A capture synthesised in HBM goes through the resident receiver without ever visiting the host; SER from the device harness."""
+    from qampy_amd.pipeline import ResidentReceiver
+    from qampy_amd.core import ber_functions as ber
+    d = synth.make_capture_dev(16, 2 ** 17, nmodes=2, snr_db=25, theta=np.pi / 5.6, dgd=30e-12, linewidth=50e3, seed=1000)
+    rx = ResidentReceiver(2, 2 ** 18, 2, 16, 21, (1e-3,), methods=("mcma",), Niter=(2,), adaptive_stepsize=(False,), TrSyms=(None,),
+                          Mtestangles=32, Nbps=20, alphabet=d["alphabet_host"])
+    rx.E.copy_from(d["E"])
+    rx.run()
+    res = ber.cal_ser_dev(rx.out, d["idx_tx"], rx.alphabet, maxlag=256, window=4096, trim=20000)
+    assert max(r["ser"] for r in res) < 2e-3 and sorted(r["tx_mode"] for r in res) == [0, 1], res
