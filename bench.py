@@ -50,9 +50,16 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def make_input(cfg, nsym, seed):
+def make_input(cfg, nsym, seed, host=False):
+    """The capture of this rank: synthesised on the GPU (csrc/synth.hip, ~1 ms) and copied to the host once for the CPU legs;
+    --host-synth uses the numpy generator instead (same impairments, frequency-domain filters, ~10 s at 2^22 symbols)."""
     from qampy_amd import synth
+    from qampy_amd.signals import SignalQAM
     nm = cfg.get("nmodes", 2)
+    if not host:
+        d = synth.make_capture_dev(cfg["M"], nsym, nmodes=nm, os=2, snr_db=cfg["snr_db"], theta=np.pi / 5.6 if nm == 2 else None, dgd=30e-12,
+                                   linewidth=cfg["linewidth"], fb=20e9, beta=0.1, seed=seed)
+        return SignalQAM(d["E"].to_host(), cfg["M"], fb=d["fb"], fs=d["fs"], symbols=d["symbols"].to_host(), coded_symbols=d["alphabet_host"])
     return synth.make_capture(cfg["M"], nsym, nmodes=nm, os=2, snr_db=cfg["snr_db"], theta=np.pi / 5.6 if nm == 2 else None, dgd=30e-12,
                               linewidth=cfg["linewidth"], fb=20e9, beta=0.1, seed=seed, dtype=np.complex64)
 
@@ -197,6 +204,7 @@ def main():
                          "segment-parallel continuation (tier B, SER-equivalent, not tap-identical)")
     ap.add_argument("--segments", type=int, default=1024)
     ap.add_argument("--prefix", type=int, default=1 << 16, help="sequential convergence prefix (steps) of the segmented mode")
+    ap.add_argument("--host-synth", action="store_true", help="generate the capture with the host (numpy) generator instead of on the GPU")
     ap.add_argument("--bank", type=int, default=32, help="channels of the informational channel-bank run at N=1 (0 = skip): that many "
                     "independent captures of the same workload resident on the GPU and processed together")
     ap.add_argument("--tier-b", action="store_true", help="also time the opt-in segmented trainer on the same capture (informational)")
@@ -224,8 +232,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # ---- independent channel per rank (seed 1000 + channel), synthesised on the host, then made resident
-    sig = make_input(cfg, nsym, sharding.channel_seed(rank))
+    # ---- independent channel per rank (seed 1000 + channel), synthesised on the GPU (or the host), then made resident
+    sig = make_input(cfg, nsym, sharding.channel_seed(rank), host=args.host_synth)
     seg = dict(segments=args.segments, prefix=args.prefix) if args.train_mode == "segmented" else {}
     rx = make_receiver(cfg, sig, **seg)
     rx.load(sig)

@@ -266,7 +266,6 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
         tab_fill<R, NPART>(K.tab, sy, 0, NPART + 1);
         Cx<R> *errow = aerr + (size_t)mode * a.err_pitch + a.err_off;
         Cx<R> ynext{0, 0};
-        using V4 = typename Cx2T<R>::type;
         const GramPair<R> *grow = aG + lane;           // this lane's column of the Gram rows
         GramPair<R> ga[LA_PD], gb[LA_PD];               // two register sets: one is consumed while the other one loads
 #pragma unroll
@@ -328,7 +327,6 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
     const bool own = lane < nf;
     const int fl = own ? f0 + lane : 0;
     const int kf = fl / a.ntaps, tf = fl - kf * a.ntaps;
-    const Cx<R> *xl = aE + (size_t)kf * a.L + tf;                     // x_l[f] = xl[l * os]
     Cx<R> *wrow = awx + (size_t)mode * ntot;
     Cx<R> w = own ? ldg(wrow + fl) : Cx<R>{0, 0};
 
