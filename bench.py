@@ -93,7 +93,7 @@ def timed_steps(rx, steps, warmup, barrier_sync):
     return elapsed, stage_ms
 
 
-def channel_bank_run(cfg, sig, nch, steps, barrier_sync):
+def channel_bank_run(cfg, sig, nch, steps, barrier_sync, trainer="iterative"):
     """Informational: `nch` independent captures of the workload resident on ONE GPU, all stages for all channels per step.
     One exact training chain is one workgroup, so channels side by side are how the exact recurrence fills the chip (WDM
     receivers have them).  Every channel is an independent capture generated on the device (seed 2000 + c).  NOT the headline
@@ -104,7 +104,7 @@ def channel_bank_run(cfg, sig, nch, steps, barrier_sync):
     E = np.asarray(sig)
     bank = ChannelBank(nch, E.shape[0], E.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"],
                        adaptive_stepsize=cfg["adaptive"], TrSyms=(None,) * len(cfg["methods"]), Mtestangles=cfg["A"], Nbps=cfg["Nbps"],
-                       dtype=np.complex64, alphabet=sig.coded_symbols)
+                       dtype=np.complex64, alphabet=sig.coded_symbols, trainer=trainer)
     # every channel is its own capture, synthesised in HBM (csrc/synth.hip) with the workload's impairments and its own seed
     from qampy_amd import synth
     nsym_c = E.shape[1] // 2
@@ -132,7 +132,7 @@ def channel_bank_run(cfg, sig, nch, steps, barrier_sync):
         worst = max([worst] + ser_c)
         if c in (0, nch // 2, nch - 1):
             sers[str(c)] = ser_c
-    return dict(channels=nch, value=round(nch * nsym * steps / el / 1e6, 3), unit="MSym/s", steps=steps, ms_per_step=round(el / steps * 1e3, 2),
+    return dict(channels=nch, trainer=trainer, value=round(nch * nsym * steps / el / 1e6, 3), unit="MSym/s", steps=steps, ms_per_step=round(el / steps * 1e3, 2),
                 ms_per_step_events=round(ev1.elapsed_ms(ev0) / steps, 2), ser_of_channels=sers, worst_ser=worst,
                 note="informational: %d independent captures of this workload processed together on one GPU (exact trainers: one "
                      "workgroup per channel and mode in a single launch per stage); not the headline value" % nch)
@@ -205,7 +205,10 @@ def main():
     ap.add_argument("--segments", type=int, default=1024)
     ap.add_argument("--prefix", type=int, default=1 << 16, help="sequential convergence prefix (steps) of the segmented mode")
     ap.add_argument("--host-synth", action="store_true", help="generate the capture with the host (numpy) generator instead of on the GPU")
-    ap.add_argument("--bank", type=int, default=32, help="channels of the informational channel-bank run at N=1 (0 = skip): that many "
+    ap.add_argument("--bank-trainer", default="iterative", choices=["auto", "iterative"],
+                    help="trainer forms of the channel bank: auto = as for the single capture, iterative = block-iterative for every stage "
+                         "(half the Gram table: more channels fit)")
+    ap.add_argument("--bank", type=int, default=64, help="channels of the informational channel-bank run at N=1 (0 = skip): that many "
                     "independent captures of the same workload resident on the GPU and processed together")
     ap.add_argument("--tier-b", action="store_true", help="also time the opt-in segmented trainer on the same capture (informational)")
     args = ap.parse_args()
@@ -319,7 +322,7 @@ def main():
 
     if world == 1 and args.train_mode == "exact" and args.bank > 1:
         try:
-            out["channel_bank"] = channel_bank_run(cfg, sig, args.bank, max(1, min(args.steps, 2)), barrier_sync)
+            out["channel_bank"] = channel_bank_run(cfg, sig, args.bank, max(1, min(args.steps, 2)), barrier_sync, args.bank_trainer)
         except Exception as e:                    # informational only: never take the headline line down with it
             out["channel_bank"] = dict(channels=args.bank, error="%s: %s" % (type(e).__name__, e))
 

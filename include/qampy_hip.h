@@ -183,6 +183,11 @@ int qh_make_decision_c128_dev(const void *E, int64_t L, const void *symbols, int
 int qh_count_errors_dev(const int32_t *idx_rx, const int32_t *idx_tx, int64_t n, int64_t lag, int64_t ntx,
                         unsigned long long *count_dev);
 
+/* Form of the exact trainer for subsequent calls: 0 automatic (default; the QAMPY_HIP_TRAINER environment variable, if set
+ * to direct / lookahead / iterative, then decides), 1 direct, 2 look-ahead, 3 block-iterative.  All forms give the
+ * reference's results up to the order of floating-point additions; a form that cannot take a call falls through. */
+int qh_set_trainer(int form);
+
 /* ---- channel bank: nch independent captures of identical shape processed together -------------------------------
  * (SURVEY.md 8e "within a GPU": one exact training chain occupies one workgroup, so a GPU holds hundreds of channels).
  * All arrays carry a leading channel dimension and are contiguous: E (nch, nmodes, L), wx (nch, nmodes, nmodes, ntaps),

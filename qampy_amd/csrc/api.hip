@@ -1,5 +1,6 @@
 // Runtime part of libqampy_hip: device selection, the library stream, device memory, events, error text.
 #include "common.h"
+#include <stdlib.h>
 #include <mutex>
 #include <string.h>
 
@@ -52,6 +53,17 @@ int ensure_init()
 // grow-only scratch slots so that the resident pipeline never allocates (and never synchronises) inside a timed region
 static void *g_scratch[12] = {nullptr};
 static size_t g_scratch_n[12] = {0};
+// form of the exact trainer: 0 = automatic (or the QAMPY_HIP_TRAINER environment variable), 1 direct, 2 look-ahead, 3 block-iterative
+int g_trainer = 0;
+const char *trainer_force()
+{
+    switch (g_trainer) {
+    case 1: return "direct";
+    case 2: return "lookahead";
+    case 3: return "iterative";
+    default: { const char *e = getenv("QAMPY_HIP_TRAINER"); return e ? e : ""; }
+    }
+}
 int scratch(int slot, size_t bytes, void **p)
 {
     if (bytes > g_scratch_n[slot]) {
@@ -67,6 +79,12 @@ int scratch(int slot, size_t bytes, void **p)
 }  // namespace qh
 
 extern "C" {
+int qh_set_trainer(int form)
+{
+    if (form < 0 || form > 3) { qh::set_error("qh_set_trainer: 0 automatic, 1 direct, 2 lookahead, 3 iterative"); return QH_ERR_ARG; }
+    qh::g_trainer = form;
+    return QH_OK;
+}
 
 int qh_device_count(int *count)
 {

@@ -500,8 +500,8 @@ template <typename R> static size_t bi_lds_bytes(int nmodes, int ntaps, int os)
 // sizes the block-iterative kernel can hold (the Gram layout of a capture follows from this alone)
 inline bool bi_shape_ok(int nmodes, int ntaps, int os, size_t elem)
 {
-    const char *force = getenv("QAMPY_HIP_TRAINER");
-    if (force && (force[0] == 'd' || force[0] == 'l')) return false;      // "direct" / "lookahead": A/B measurements, tests
+    const char *force = trainer_force();
+    if ((force[0] == 'd' || force[0] == 'l')) return false;      // "direct" / "lookahead": A/B measurements, tests
     if (nmodes * ntaps > BI_MAXTAPS) return false;
     const int wpitch = ((LA_B - 1) * os + ntaps + 1) & ~1;
     return (size_t)2 * LA_B * BI_PAD * (elem + 16) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch) * elem + 2 * BI_W * 2 * elem <= 64 * 1024;

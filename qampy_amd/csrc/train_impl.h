@@ -485,9 +485,9 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         // Trainer choice.  QAMPY_HIP_TRAINER = direct | lookahead | iterative forces one form (A/B measurements, tests);
         // otherwise the block-iterative form takes the partitioned error functions (rde, mrde: one evaluation per sweep
         // instead of one per step), the look-ahead chain the cheap ones (cma, mcma, cma2), whichever of the two fits.
-        const char *force = getenv("QAMPY_HIP_TRAINER");
-        const bool direct = force && force[0] == 'd';
-        bool bi_ok = !direct && !(force && force[0] == 'l') && bi_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy, sizeof(Cx<R>));
+        const char *force = trainer_force();
+        const bool direct = force[0] == 'd';
+        bool bi_ok = !direct && !(force[0] == 'l') && bi_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy, sizeof(Cx<R>));
         const bool decision = method == QH_M_SBD || method == QH_M_MDDMA || method == QH_M_DD;
         void *dd_table = nullptr;
         int dd_npart = -1;
@@ -498,7 +498,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         const bool la_ok = !direct && la_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy);
         const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
         const bool pair = la_shape_ok(nmodes, ntaps, os);          // layout of the Gram terms of this capture (qh_gram_build_*)
-        if (bi_ok && (partitioned || decision || adaptive || method == QH_M_SBD_DATA || !la_ok || (force && force[0] == 'i'))) {
+        if (bi_ok && (partitioned || decision || adaptive || method == QH_M_SBD_DATA || !la_ok || (force[0] == 'i'))) {
             // block-iterative form (train_bi.h): 8 wavefronts per output mode solve each 64-step block by fixed-point sweeps
             void *G = const_cast<void *>(gram);
             if (!G && (rc = pair ? gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G, nch) : gram_cur_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G, nch))) return rc;

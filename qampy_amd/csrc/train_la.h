@@ -473,8 +473,8 @@ template <typename R> int gram_build(const void *E, int nmodes, int64_t L, int o
 // sizes the look-ahead kernel can hold (this alone decides the Gram layout of a capture: pairs when true)
 inline bool la_shape_ok(int nmodes, int ntaps, int os)
 {
-    const char *force = getenv("QAMPY_HIP_TRAINER");
-    if (force && (force[0] == 'd' || force[0] == 'i')) return false;               // "direct" / "iterative": A/B measurements, tests
+    const char *force = trainer_force();
+    if ((force[0] == 'd' || force[0] == 'i')) return false;               // "direct" / "iterative": A/B measurements, tests
     if (nmodes * (((LA_B - 1) * os + ntaps + 1) & ~1) > 8 * 64) return false;      // helper window: 8 staging registers per lane
     return (nmodes * ntaps + LA_NH - 1) / LA_NH <= LA_MAXSLICE;
 }

@@ -188,7 +188,8 @@ def test_resident_receiver_device_ser_equals_host_ser():
 # ------------------------------------------------------------------------------------------------ channel bank (8e, within a GPU)
 @pytest.mark.parametrize("methods,adaptive", [(("mcma", "sbd"), (False, False)), (("cma", "mrde"), (False, False)),
                                               (("mcma", "mddma"), (True, True))])
-def test_channel_bank_equals_single_receivers(methods, adaptive):
+@pytest.mark.parametrize("trainer", ["auto", "iterative"])
+def test_channel_bank_equals_single_receivers(monkeypatch, methods, adaptive, trainer):
     """A bank of independent captures trained in ONE launch per stage (channel = blockIdx.y) gives bit-identical taps,
     errors and recovered symbols to one ResidentReceiver per capture."""
     from qampy_amd.pipeline import ChannelBank, ResidentReceiver
@@ -198,10 +199,12 @@ def test_channel_bank_equals_single_receivers(methods, adaptive):
     kw = dict(methods=methods, Niter=(2,) * len(methods), adaptive_stepsize=adaptive, TrSyms=(None,) * len(methods), Mtestangles=32,
               Nbps=10)
     L = sigs[0].shape[1]
-    bank = ChannelBank(nch, 2, L, 2, M, 15, (2e-3, 5e-4)[:len(methods)], alphabet=sigs[0].coded_symbols, **kw)
+    bank = ChannelBank(nch, 2, L, 2, M, 15, (2e-3, 5e-4)[:len(methods)], alphabet=sigs[0].coded_symbols, trainer=trainer, **kw)
     for c, sg in enumerate(sigs):
         bank.load(c, sg)
     bank.run()
+    if trainer != "auto":
+        monkeypatch.setenv("QAMPY_HIP_TRAINER", trainer)         # the single receivers in the same form
     for c, sg in enumerate(sigs):
         rx = ResidentReceiver(2, L, 2, M, 15, (2e-3, 5e-4)[:len(methods)], alphabet=sg.coded_symbols, **kw)
         rx.load(sg)
