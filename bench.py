@@ -208,7 +208,7 @@ def main():
     ap.add_argument("--bank-trainer", default="iterative", choices=["auto", "iterative"],
                     help="trainer forms of the channel bank: auto = as for the single capture, iterative = block-iterative for every stage "
                          "(half the Gram table: more channels fit)")
-    ap.add_argument("--bank", type=int, default=64, help="channels of the informational channel-bank run at N=1 (0 = skip): that many "
+    ap.add_argument("--bank", type=int, default=128, help="channels of the informational channel-bank run at N=1 (0 = skip): that many "
                     "independent captures of the same workload resident on the GPU and processed together")
     ap.add_argument("--tier-b", action="store_true", help="also time the opt-in segmented trainer on the same capture (informational)")
     args = ap.parse_args()

@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         const int k2 = ec / wpitch;
         st_dst[s] = e < wsz ? ec : -1;
         st_i[s] = ec - k2 * wpitch;
-        st_src[s] = (int64_t)k2 * a.L;
+        st_src[s] = (int64_t)k2 * a.Lp;
     }
     Cx<R> stv[2];
     auto stage_load = [&](int kb) {                                    // global loads now ...
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
             const int k2 = e / wpitch, i2 = e - k2 * wpitch;
             int64_t gi = base + i2;
             if (gi > a.L - 1) gi = a.L - 1;
-            dst[e] = aE[(size_t)k2 * a.L + gi];
+            dst[e] = aE[(size_t)k2 * a.Lp + gi];
         }
     };
     // own-slice part of the prior outputs of block kb: lane <-> step kb*64 + lane
@@ -472,8 +472,11 @@ template <typename R> static size_t gram_cur_bytes(int64_t TrSyms)
     return (size_t)(nblk * LA_B + LA_B) * LA_B * sizeof(Cx<R>);
 }
 
-template <typename R> int gram_cur_build(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram, int nch = 1)
+template <typename R> int gram_cur_build(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram, int nch = 1,
+                                         int64_t Lp = 0, int64_t ch_stride = 0)
 {
+    if (Lp <= 0) Lp = L;
+    if (ch_stride <= 0) ch_stride = (int64_t)nmodes * Lp;
     int rc = ensure_init();
     if (rc) return rc;
     void *G = nullptr;
@@ -483,8 +486,8 @@ template <typename R> int gram_cur_build(const void *E, int nmodes, int64_t L, i
     const size_t lds = (size_t)nmodes * ((LA_B - 1) * os + ntaps) * sizeof(Cx<R>);
     QH_REQUIRE(lds <= 64 * 1024, "gram: nmodes*(63*os+ntaps) samples exceed the LDS tile");
     for (int c = 0; c < nch && nblk > 0; c++)
-        hipLaunchKernelGGL((gram_slide_kernel<R, false>), dim3((unsigned)nblk), dim3(256), lds, g_stream, (const Cx<R> *)E + (size_t)c * nmodes * L,
-                           nmodes, L, os, ntaps, TrSyms, (Cx<R> *)((char *)G + bytes * (size_t)c));
+        hipLaunchKernelGGL((gram_slide_kernel<R, false>), dim3((unsigned)nblk), dim3(256), lds, g_stream, (const Cx<R> *)E + (size_t)c * ch_stride,
+                           nmodes, L, Lp, os, ntaps, TrSyms, (Cx<R> *)((char *)G + bytes * (size_t)c));
     QH_HIP(hipGetLastError());
     *gram = G;
     return QH_OK;

@@ -447,6 +447,15 @@ template <typename R> static int launch_any(const TrainArgs<R> &a)
     return launch_tpl<R, 16>(a);
 }
 
+// scratch the Gram tables of one call may take: QAMPY_HIP_GRAM_BUDGET_GB (default 160 of the 288 GB); longer captures / larger channel banks
+// are trained in time chunks
+static size_t gram_budget()
+{
+    const char *e = getenv("QAMPY_HIP_GRAM_BUDGET_GB");
+    const double gb = e ? atof(e) : 160.0;
+    return (size_t)((gb > 0.001 ? gb : 0.001) * 1073741824.0);
+}
+
 // nseg == 0: the reference's exact sequential semantics.  nseg > 0: "segment-parallel continuation" (tier B): the first
 // `prefix` steps of sweep 0 are trained sequentially, then every sweep is split into nseg segments that all start from
 // the taps at the end of the previous phase; final taps (and step size) are those of the last segment.
@@ -498,80 +507,72 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         const bool la_ok = !direct && la_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy);
         const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
         const bool pair = la_shape_ok(nmodes, ntaps, os);          // layout of the Gram terms of this capture (qh_gram_build_*)
-        if (bi_ok && (partitioned || decision || adaptive || method == QH_M_SBD_DATA || !la_ok || (force[0] == 'i'))) {
-            // block-iterative form (train_bi.h): 8 wavefronts per output mode solve each 64-step block by fixed-point sweeps
-            void *G = const_cast<void *>(gram);
-            if (!G && (rc = pair ? gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G, nch) : gram_cur_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G, nch))) return rc;
+        const bool use_bi = bi_ok && (partitioned || decision || adaptive || method == QH_M_SBD_DATA || !la_ok || (force[0] == 'i'));
+        if (use_bi || la_ok) {
+            // block-iterative form (train_bi.h): 8 wavefronts per output mode solve each 64-step block by fixed-point sweeps;
+            // look-ahead form (train_la.h): one chain wave + three helper waves per output mode
+            const bool pair_tab = use_bi ? pair : true;                      // layout of the Gram table this call reads
+            const size_t step_bytes = (pair_tab ? sizeof(GramPair<R>) : sizeof(Cx<R>)) * LA_B;     // per step and channel
+            // Time chunks: when the Gram tables of the whole capture (x channels) would not fit the budget, the sweep runs
+            // chunk after chunk - table of the chunk, then the trainers over it, taps handed on through HBM exactly as
+            // between sweeps - which bounds the scratch memory for any capture length and channel count.  Not for the
+            // adaptive step / data-aided training (their state does not live in HBM between launches) nor a caller's table.
+            int64_t CH = TrSyms;
+            if (!gram && !adaptive && method != QH_M_SBD_DATA) {
+                const int64_t fit = (int64_t)(gram_budget() / (step_bytes * (size_t)nch)) / LA_B * LA_B;
+                if (fit < TrSyms) CH = fit > 64 * LA_B ? fit : 64 * LA_B;
+            }
             LaArgs<R> la;
-            la.E = a.E; la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.G = (const GramPair<R> *)G; la.gpair = pair ? 1 : 0; la.mu = mu_dev;
-            la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
+            la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.gpair = pair_tab ? 1 : 0; la.mu = mu_dev; la.mu_out = use_bi ? (R *)mu_dev : nullptr;
+            la.Lp = L; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
             la.os = os; la.nsel = nsel; la.method = method;
-            la.nch = nch; la.E_cs = (int64_t)nmodes * L; la.wx_cs = (int64_t)nmodes * ntot; la.err_cs = (int64_t)nmodes * TrSyms * Niter;
-            la.mu_cs = 1; la.G_cs = (int64_t)((pair ? gram_bytes<R>(TrSyms) : gram_cur_bytes<R>(TrSyms)) / sizeof(GramPair<R>));
+            la.nch = nch; la.E_cs = (int64_t)nmodes * L; la.wx_cs = (int64_t)nmodes * ntot; la.err_cs = (int64_t)nmodes * TrSyms * Niter; la.mu_cs = 1;
             for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];
-            if (decision) {          // the kernel reads the slicer table like an mrde table: row pitch 2*BI_DD_MAXLEV, 2*npart+1 used
+            if (use_bi && decision) {   // the kernel reads the slicer table like an mrde table: row pitch 2*BI_DD_MAXLEV, 2*npart+1 used
                 la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV;
             }
             la.prof = nullptr;
-            if (getenv("QAMPY_HIP_LA_PROFILE")) {                // developer aid: sweep count and cycle split of workgroup 0
+            if (getenv("QAMPY_HIP_LA_PROFILE")) {                // developer aid: cycle split of workgroup 0
                 void *pp = nullptr;
                 if ((rc = scratch(5, 16 * sizeof(unsigned long long), &pp))) return rc;
                 QH_HIP(hipMemsetAsync(pp, 0, 16 * sizeof(unsigned long long), g_stream));
                 la.prof = (unsigned long long *)pp;
             }
-            la.mu_out = (R *)mu_dev;
-            if (adaptive) {          // mu is carried from sweep to sweep and from mode to mode (sequential reference semantics)
-                la.nsel = 1;
-                for (int j = 0; j < nsel; j++) {
-                    la.modes[0] = a.modes[j];
-                    for (int it = 0; it < Niter; it++) {
-                        la.err_off = (int64_t)it * TrSyms;
-                        if ((rc = launch_bi<R>(la, true))) return rc;
+            const int nmode_runs = adaptive ? nsel : 1;          // adaptive: mu is carried from sweep to sweep and from mode to mode
+            if (adaptive) la.nsel = 1;
+            for (int jm = 0; jm < nmode_runs; jm++) {
+                if (adaptive) la.modes[0] = a.modes[jm];
+                for (int it = 0; it < Niter; it++) {             // one launch per sweep (and chunk): taps go through HBM in between
+                    for (int64_t step0 = 0; step0 < TrSyms;) {
+                        int64_t n = TrSyms - step0 < CH ? TrSyms - step0 : CH;
+                        if (TrSyms - (step0 + n) < 2 * LA_B) n = TrSyms - step0;          // never leave a tail the block forms cannot take
+                        const Cx<R> *Ec = a.E + step0 * os;
+                        void *G = const_cast<void *>(gram);
+                        if (!G) {
+                            rc = pair_tab ? gram_build<R>(Ec, nmodes, L - step0 * os, os, ntaps, n, &G, nch, L, (int64_t)nmodes * L)
+                                          : gram_cur_build<R>(Ec, nmodes, L - step0 * os, os, ntaps, n, &G, nch, L, (int64_t)nmodes * L);
+                            if (rc) return rc;
+                        }
+                        la.E = Ec; la.L = L - step0 * os; la.TrSyms = n; la.G = (const GramPair<R> *)G;
+                        la.G_cs = (int64_t)((pair_tab ? gram_bytes<R>(n) : gram_cur_bytes<R>(n)) / sizeof(GramPair<R>));
+                        la.err_off = (int64_t)it * TrSyms + step0;
+                        if ((rc = use_bi ? launch_bi<R>(la, adaptive != 0) : launch_la<R>(la))) return rc;
+                        step0 += n;
                     }
                 }
-            } else {
-                for (int it = 0; it < Niter; it++) {
-                    la.err_off = (int64_t)it * TrSyms;
-                    if ((rc = launch_bi<R>(la))) return rc;
+            }
+            if (la.prof) {
+                unsigned long long hp[16];
+                QH_HIP(hipMemcpyAsync(hp, la.prof, sizeof(hp), hipMemcpyDeviceToHost, g_stream));
+                QH_HIP(hipStreamSynchronize(g_stream));
+                if (use_bi) {
+                    fprintf(stderr, "[bi profile] method %d blocks %llu: sweeps/block %.2f, cycles/block sweeps %.0f update %.0f prior %.0f\n", method, hp[4],
+                            (double)hp[0] / (double)hp[4], (double)hp[1] / (double)hp[4], (double)hp[2] / (double)hp[4], (double)hp[3] / (double)hp[4]);
+                } else {
+                    fprintf(stderr, "[la profile] method %d TrSyms %lld: chain work %llu wait %llu |", method, (long long)TrSyms, hp[0], hp[1]);
+                    for (int h = 1; h <= LA_NH; h++) fprintf(stderr, " helper%d update %llu prior %llu wait %llu |", h, hp[4 * h], hp[4 * h + 1], hp[4 * h + 2]);
+                    fprintf(stderr, "\n");
                 }
-            }
-            if (la.prof) {
-                unsigned long long hp[16];
-                QH_HIP(hipMemcpyAsync(hp, la.prof, sizeof(hp), hipMemcpyDeviceToHost, g_stream));
-                QH_HIP(hipStreamSynchronize(g_stream));
-                fprintf(stderr, "[bi profile] method %d blocks %llu: sweeps/block %.2f, cycles/block sweeps %.0f update %.0f prior %.0f\n", method, hp[4],
-                        (double)hp[0] / (double)hp[4], (double)hp[1] / (double)hp[4], (double)hp[2] / (double)hp[4], (double)hp[3] / (double)hp[4]);
-            }
-            return QH_OK;
-        }
-        if (la_ok) {
-            void *G = const_cast<void *>(gram);
-            if (!G && (rc = gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G, nch))) return rc;
-            LaArgs<R> la;
-            la.nch = nch; la.E_cs = (int64_t)nmodes * L; la.wx_cs = (int64_t)nmodes * ntot; la.err_cs = (int64_t)nmodes * TrSyms * Niter;
-            la.mu_cs = 1; la.G_cs = (int64_t)(gram_bytes<R>(TrSyms) / sizeof(GramPair<R>));
-            la.E = a.E; la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.G = (const GramPair<R> *)G; la.gpair = 1; la.mu = mu_dev; la.mu_out = nullptr;
-            la.L = L; la.TrSyms = TrSyms; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
-            la.os = os; la.nsel = nsel; la.method = method;
-            for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];
-            la.prof = nullptr;
-            if (getenv("QAMPY_HIP_LA_PROFILE")) {                // developer aid: per-wave cycle split of workgroup 0
-                void *pp = nullptr;
-                if ((rc = scratch(5, 16 * sizeof(unsigned long long), &pp))) return rc;
-                QH_HIP(hipMemsetAsync(pp, 0, 16 * sizeof(unsigned long long), g_stream));
-                la.prof = (unsigned long long *)pp;
-            }
-            for (int it = 0; it < Niter; it++) {                 // one launch per sweep: taps go through HBM in between
-                la.err_off = (int64_t)it * TrSyms;
-                if ((rc = launch_la<R>(la))) return rc;
-            }
-            if (la.prof) {
-                unsigned long long hp[16];
-                QH_HIP(hipMemcpyAsync(hp, la.prof, sizeof(hp), hipMemcpyDeviceToHost, g_stream));
-                QH_HIP(hipStreamSynchronize(g_stream));
-                fprintf(stderr, "[la profile] method %d TrSyms %lld: chain work %llu wait %llu |", method, (long long)TrSyms, hp[0], hp[1]);
-                for (int h = 1; h <= LA_NH; h++) fprintf(stderr, " helper%d update %llu prior %llu wait %llu |", h, hp[4 * h], hp[4 * h + 1], hp[4 * h + 2]);
-                fprintf(stderr, "\n");
             }
             return QH_OK;
         }

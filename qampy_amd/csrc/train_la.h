@@ -38,7 +38,7 @@ template <typename R> struct GramPair { Cx<R> cur, next; };   // per (step l, la
 // Rounding: a slid sum carries at most 31 x 2 os extra additions; the trainers see Gram terms good to a few 1e-7 relative
 // either way (and every form of the trainer is compared with the oracle on its own).
 template <typename R, bool PAIR>
-__global__ void __launch_bounds__(256) gram_slide_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, Cx<R> *G)
+__global__ void __launch_bounds__(256) gram_slide_kernel(const Cx<R> *E, int nmodes, int64_t L, int64_t Lp, int os, int ntaps, int64_t TrSyms, Cx<R> *G)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Cx<R> *tile = reinterpret_cast<Cx<R> *>(smem);
@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) gram_slide_kernel(const Cx<R> *E, int nmo
         const int64_t s0 = blk * os;
         for (int s = threadIdx.x; s < span; s += 256) {
             const int64_t g = s0 + s;
-            tile[k * span + s] = g < L ? ldg(E + (size_t)k * L + g) : Cx<R>{0, 0};
+            tile[k * span + s] = g < L ? ldg(E + (size_t)k * Lp + g) : Cx<R>{0, 0};
         }
     }
     // entries a lane must never see (targets at or before the source step) are zeros
@@ -219,7 +219,7 @@ template <typename R> struct LaArgs {
     int gpair;              // block-iterative kernel only: 1 = G is the look-ahead pair layout (cur/next), 0 = cur only
     const R *mu;
     R *mu_out;              // block-iterative kernel with the adaptive step: final step size, else unused
-    int64_t L, TrSyms, nsy, sy_pitch, err_pitch, err_off;     // symbols row m starts at symbols + m * sy_pitch
+    int64_t L, Lp, TrSyms, nsy, sy_pitch, err_pitch, err_off;   // L usable samples per row from E on, Lp row pitch (>= L: time chunks)     // symbols row m starts at symbols + m * sy_pitch
     int nmodes, ntaps, os, nsel, method, nch;
     // channel batch: blockIdx.y = channel; element strides between the channels' arrays (0 for a single capture)
     int64_t E_cs, wx_cs, err_cs, G_cs, mu_cs;
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
         const int e = lane + 64 * q;
         const bool v = e < wtot;
         const int k2 = v ? e / wpitch : 0, i2 = v ? e - k2 * wpitch : 0;
-        soff[q] = (int64_t)k2 * a.L + i2;
+        soff[q] = (int64_t)k2 * a.Lp + i2;
         sdst[q] = v ? e : wtot;
     }
     auto stage_load = [&](Cx<R> (&r)[WREG], int kb) {
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
         } else {                                                       // the last block may reach past the capture
 #pragma unroll
             for (int q = 0; q < WREG; q++) {
-                const int64_t row = soff[q] / a.L * a.L;
+                const int64_t row = soff[q] / a.Lp * a.Lp;
                 int64_t g = base + (soff[q] - row);
                 if (g > a.L - 1) g = a.L - 1;
                 r[q] = ldg(aE + row + g);
@@ -447,8 +447,12 @@ template <typename R> static size_t gram_bytes(int64_t TrSyms)
 }
 
 // nch captures (nch, nmodes, L) -> nch Gram tables, gram_bytes() apart, in ONE scratch allocation
-template <typename R> int gram_build(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram, int nch = 1)
+// L: usable samples per row starting at E, Lp: row pitch (0 = L), ch_stride: samples between channels (0 = nmodes * Lp)
+template <typename R> int gram_build(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram, int nch = 1,
+                                     int64_t Lp = 0, int64_t ch_stride = 0)
 {
+    if (Lp <= 0) Lp = L;
+    if (ch_stride <= 0) ch_stride = (int64_t)nmodes * Lp;
     int rc = ensure_init();
     if (rc) return rc;
     const size_t bytes = gram_bytes<R>(TrSyms);
@@ -462,7 +466,7 @@ template <typename R> int gram_build(const void *E, int nmodes, int64_t L, int o
         // rows past the last block are read by the prefetch queue only: keep them zero
         QH_HIP(hipMemsetAsync(G + (size_t)nblk * LA_B * LA_B * sizeof(GramPair<R>), 0, (size_t)2 * LA_PD * LA_B * sizeof(GramPair<R>), g_stream));
         if (nblk > 0) hipLaunchKernelGGL((gram_slide_kernel<R, true>), dim3((unsigned)nblk), dim3(256), lds, g_stream,
-                                         (const Cx<R> *)E + (size_t)c * nmodes * L, nmodes, L, os, ntaps, TrSyms, (Cx<R> *)G);
+                                         (const Cx<R> *)E + (size_t)c * ch_stride, nmodes, L, Lp, os, ntaps, TrSyms, (Cx<R> *)G);
     }
     QH_HIP(hipGetLastError());
     *gram = G0;

@@ -213,7 +213,13 @@ class ChannelBank:
             _lib.call("qh_set_trainer", 0)
 
     def _run_stages(self, r):
-        self._gram = _k.gram_build_batch_dev(self.E, self.os, self.Ntaps, self.TrSyms[0]) if len(set(self.TrSyms)) == 1 else None
+        # one Gram table per channel shared by the stages when the bank's tables fit the library's scratch budget; otherwise
+        # the trainers build them per time chunk themselves (csrc/train_impl.h: gram_budget)
+        import os as _os
+        budget = float(_os.environ.get("QAMPY_HIP_GRAM_BUDGET_GB", 160.)) * 2 ** 30
+        per_step = (512 if self.trainer == 3 else 1024) * (np.dtype(self.ct).itemsize // 8)
+        fits = self.nch * self.TrSyms[0] * per_step <= budget
+        self._gram = _k.gram_build_batch_dev(self.E, self.os, self.Ntaps, self.TrSyms[0]) if (len(set(self.TrSyms)) == 1 and fits) else None
         for s in range(r.nstage):
             _k.train_equaliser_batch_dev(self.E, self.TrSyms[s], r.Niter[s], self.os, self.mu[s], self.wxy, r.modes, r.adaptive[s],
                                          r.symbols[s], r.methods[s], self.err[s], gram=self._gram)

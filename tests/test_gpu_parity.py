@@ -358,3 +358,29 @@ def test_exact_trainer_forms_on_boundary_shapes(monkeypatch, nmodes, ntaps, os_,
             np.testing.assert_allclose(w, wo, rtol=1e-9, atol=1e-11, err_msg="%s adaptive=%s" % (form, adaptive))
             np.testing.assert_allclose(e, eo, rtol=1e-9, atol=1e-10, err_msg="%s adaptive=%s" % (form, adaptive))
             np.testing.assert_allclose(mu, muo, rtol=1e-9)
+
+
+@pytest.mark.parametrize("method,M", [("cma", 16), ("mcma", 16), ("mrde", 64), ("sbd", 16)])
+def test_time_chunked_training_equals_unchunked(monkeypatch, method, M):
+    """When the Gram tables of a call exceed the scratch budget the sweep runs chunk after chunk (taps handed on through HBM):
+    same results - bit for bit in the block-iterative form (it restarts every block from the taps anyway), to rounding in the
+    look-ahead form - for any capture length."""
+    sig = synth.make_capture(M, 24000, nmodes=2, snr_db=28, theta=np.pi / 5.6, dgd=30e-12, seed=31, dtype=np.complex64)
+    E = np.ascontiguousarray(np.asarray(sig))
+    ntaps = 21
+    tr = core_eq._cal_training_symbol_len(2, ntaps, E.shape[1]) - 3
+    w0 = core_eq._init_taps(ntaps, 2, 2, np.complex64)
+    if method in ("mrde", "sbd"):
+        _, w0, _ = hk.train_equaliser(E, tr, 2, 2, np.float32(2e-3), w0, None, False, core_eq._reshape_symbols(None, "mcma", M, np.complex64, 2), "mcma")
+    sy = core_eq._reshape_symbols(None, method, M, np.complex64, 2)
+    e1, w1, _ = hk.train_equaliser(E, tr, 2, 2, np.float32(3e-4), w0.copy(), None, False, sy, method)
+    monkeypatch.setenv("QAMPY_HIP_GRAM_BUDGET_GB", "0.004")          # 4 MiB: chunks of 4096 steps (the minimum)
+    e2, w2, _ = hk.train_equaliser(E, tr, 2, 2, np.float32(3e-4), w0.copy(), None, False, sy, method)
+    assert np.all(np.isfinite(w2)) and np.abs(e2[:, -1]).min() > 0
+    if method in ("mrde", "sbd"):
+        assert np.array_equal(w1, w2) and np.array_equal(e1, e2)
+    else:
+        np.testing.assert_allclose(w2, w1, rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(e2, e1, rtol=2e-4, atol=1e-4)
+    eo, wo, _ = oracle.train_equaliser(E, tr, 2, 2, np.float32(3e-4), w0.copy(), None, False, sy, method)
+    np.testing.assert_allclose(w2, wo, rtol=2e-4, atol=2e-5)
