@@ -21,7 +21,7 @@
 
 namespace qh {
 
-constexpr int BPS_THREADS = 512;
+constexpr int BPS_THREADS = 1024;
 constexpr size_t BPS_LDS_BUDGET = 120 * 1024;
 
 template <typename R> __device__ __forceinline__ void sincos_(R x, R *s, R *c);
