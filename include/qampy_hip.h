@@ -67,6 +67,10 @@ int qh_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises o
 /* ---- train_equaliser (complex) ----------------------------------------------------------------------------------
  *   E        (nmodes, L)                 input field
  *   mu       in/out step size (the adapted value is returned when adaptive != 0)
+ *   adaptive 0 fixed step; 1 adapt_step with the reference's sequential semantics (mu carried from sweep to sweep and
+ *            from mode to mode, pythran_equalisation.py:162-172 with one thread); 2 (extension) one step size per mode:
+ *            exactly the result of one call per selected mode from the initial mu, modes trained concurrently, mu out =
+ *            the last mode's (the compiled reference's OpenMP threads share and race on mu; 2 is its deterministic stand-in)
  *   wx       (nmodes, nmodes, ntaps)     taps, updated in place
  *   modes    (nsel,) int64               output modes to train, processed in this order
  *   symbols  (nmodes, nsy)               per-method constants / alphabet / training symbols

@@ -21,6 +21,17 @@ def _as_modes(modes, nmax):
     return np.ascontiguousarray(np.atleast_1d(modes), dtype=np.int64)
 
 
+def _adaptive_flag(adaptive, allow_per_mode=True):
+    """0 fixed step, 1 the reference's (sequential) adaptive step, 2 ``"per-mode"``: one adapted step size per mode."""
+    if isinstance(adaptive, str):
+        if adaptive.lower().replace("_", "-") not in ("per-mode", "private"):
+            raise ValueError("adaptive step size must be a bool or 'per-mode'")
+        if not allow_per_mode:
+            raise ValueError("per-mode step sizes are implemented for the complex-valued trainer only")
+        return 2
+    return int(bool(adaptive))
+
+
 def _need(arr, dtype, name):
     if not isinstance(arr, np.ndarray) or arr.dtype != dtype or not arr.flags.c_contiguous:
         raise TypeError("%s must be a C-contiguous %s array (got %s %s)" % (
@@ -31,7 +42,10 @@ def train_equaliser(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, meth
     """
     Stochastic-gradient tap training, complex field.  Returns ``(err, wx, mu)``; ``wx`` is also updated in place
     (pythran_equalisation.py:128-173).  ``modes`` are trained in the given order; with ``adaptive`` the adapted step is
-    carried from one mode to the next (sequential semantics of the reference).
+    carried from one mode to the next (sequential semantics of the reference).  ``adaptive="per-mode"`` (beyond the
+    reference's bool): every mode adapts its own step size from ``mu`` - the result of one call per mode - and the modes
+    train concurrently; ``mu`` out is the last mode's.  (The compiled reference lets its OpenMP threads share and race on
+    one ``mu``; this is the deterministic counterpart of that behaviour.)
     """
     if method not in _lib.METHOD_ID:
         raise ValueError("Unknown method %s" % method)
@@ -53,7 +67,7 @@ def train_equaliser(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, meth
     err = np.zeros((nmodes, int(TrSyms) * int(Niter)), dtype=ct)
     mu_c = (C.c_float if rt is np.float32 else C.c_double)(mu)
     _lib.call("qh_train_equaliser_c" + ("64" if suf == "32" else "128"), _lib.ptr(E), nmodes, L, int(TrSyms), int(Niter),
-              int(os), C.byref(mu_c), _lib.ptr(wx), ntaps, _lib.ptr(modes), modes.size, int(bool(adaptive)),
+              int(os), C.byref(mu_c), _lib.ptr(wx), ntaps, _lib.ptr(modes), modes.size, _adaptive_flag(adaptive),
               _lib.ptr(symbols), symbols.shape[1], _lib.METHOD_ID[method], _lib.ptr(err))
     return err, wx, rt(mu_c.value)
 
@@ -81,7 +95,7 @@ def train_equaliser_windows(E, starts, win_len, TrSyms, Niter, os, mu, wx0, mode
     mu_out = np.zeros(nwin, dtype=rt)
     _lib.call("qh_train_equaliser_windows_c" + ("64" if suf == "32" else "128"), _lib.ptr(E), nmodes, L, _lib.ptr(starts), nwin,
               int(win_len), int(TrSyms), int(Niter), int(os), rt(mu), _lib.ptr(wx0), ntaps, _lib.ptr(modes), modes.size,
-              int(bool(adaptive)), _lib.ptr(symbols), symbols.shape[1], _lib.METHOD_ID[method], _lib.ptr(wx), _lib.ptr(err),
+              _adaptive_flag(adaptive, False), _lib.ptr(symbols), symbols.shape[1], _lib.METHOD_ID[method], _lib.ptr(wx), _lib.ptr(err),
               _lib.ptr(mu_out))
     return err, wx, mu_out
 
@@ -106,7 +120,7 @@ def train_equaliser_realvalued(E, TrSyms, Niter, os, mu, wx, modes, adaptive, sy
     err = np.zeros((nmodes, int(TrSyms) * int(Niter)), dtype=rt)
     mu_c = (C.c_float if rt is np.float32 else C.c_double)(mu)
     _lib.call("qh_train_equaliser_real_f" + suf, _lib.ptr(E), nmodes, L, int(TrSyms), int(Niter), int(os), C.byref(mu_c),
-              _lib.ptr(wx), ntaps, _lib.ptr(modes), modes.size, int(bool(adaptive)), _lib.ptr(symbols), symbols.shape[1],
+              _lib.ptr(wx), ntaps, _lib.ptr(modes), modes.size, _adaptive_flag(adaptive, False), _lib.ptr(symbols), symbols.shape[1],
               _lib.REAL_METHOD_ID[method], _lib.ptr(err))
     return err, wx, rt(mu_c.value)
 
@@ -188,7 +202,7 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
     ntaps = wx.shape[-1]
     modes = _as_modes(modes, nmodes)
     args = (E.ptr, nmodes, L, int(TrSyms), int(Niter), int(os), mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size,
-            int(bool(adaptive)), symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)))
+            _adaptive_flag(adaptive), symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)))
     name = "qh_train_equaliser_c" + ("64" if suf == "32" else "128")
     if segments and segments > 0:
         _lib.call(name + "_seg_dev", *args, int(segments), int(prefix), float(prefix_mu or 0.))
@@ -222,7 +236,7 @@ def train_equaliser_batch_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, sym
     ntaps = wx.shape[-1]
     modes = _as_modes(modes, nmodes)
     _lib.call("qh_train_equaliser_c" + ("64" if suf == "32" else "128") + "_batch_dev", E.ptr, nch, nmodes, L, int(TrSyms), int(Niter), int(os),
-              mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size, int(bool(adaptive)), symbols.ptr, symbols.shape[1],
+              mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size, _adaptive_flag(adaptive), symbols.ptr, symbols.shape[1],
               _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)), gram)
 
 

@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
     Cx<R> *const awx = a.wx + ch * a.wx_cs;
     Cx<R> *const aerr = a.err + ch * a.err_cs;
     const GramPair<R> *const aG = a.G + ch * a.G_cs;
-    const R *const amu = a.mu + ch * a.mu_cs;
+    const R *const amu = a.mu + ch * a.mu_cs + (int64_t)blockIdx.x * a.mu_ms;
     extern __shared__ __attribute__((aligned(16))) char bi_smem[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         a.prof[0] = pf_sweeps; a.prof[1] = pf_t_sweep; a.prof[2] = pf_t_upd; a.prof[3] = pf_t_prior; a.prof[4] = (unsigned long long)nblk;
     }
     for (int f = threadIdx.x; f < ntot; f += BI_NT) wrow[f] = wbuf[f];
-    if constexpr (ADAPT) if (threadIdx.x == 0) a.mu_out[ch * a.mu_cs] = (R)1 / r_blk;
+    if constexpr (ADAPT) if (threadIdx.x == 0) a.mu_out[ch * a.mu_cs + (int64_t)blockIdx.x * a.mu_ms] = (R)1 / r_blk;
 }
 
 // ------------------------------------------------------------------------------------------------ slicer tables

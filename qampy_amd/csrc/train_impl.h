@@ -447,6 +447,18 @@ template <typename R> static int launch_any(const TrainArgs<R> &a)
     return launch_tpl<R, 16>(a);
 }
 
+// dst[i] = src[i / n] (one step size per channel -> one per channel and mode) and back (the last mode's)
+template <typename R> __global__ void spread_kernel(R *dst, const R *src, int n, int total)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) dst[i] = src[i / n];
+}
+template <typename R> __global__ void gather_kernel(R *dst, const R *src, int n, int nch)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nch) dst[c] = src[(size_t)c * n + n - 1];
+}
+
 // scratch the Gram tables of one call may take: QAMPY_HIP_GRAM_BUDGET_GB (default 160 of the 288 GB); longer captures / larger channel banks
 // are trained in time chunks
 static size_t gram_budget()
@@ -470,6 +482,12 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
     // nch > 1: a bank of independent captures with identical shapes, arrays (nch, ...) contiguous, one mu per channel; the
     // look-ahead / block-iterative kernels take the channel as blockIdx.y, anything else runs channel after channel
     QH_REQUIRE(nch >= 1 && nch <= 65535 && (nch == 1 || nseg <= 0), "train_equaliser: bad channel count");
+    // adaptive: 0 fixed step; 1 the reference's sequential semantics (mu carried from sweep to sweep AND from mode to mode,
+    // pythran_equalisation.py:162-172 run with one thread); 2 one step size PER MODE - exactly what one call per selected mode
+    // from the initial mu gives (mu out = the last mode's).  The compiled reference adapts a mu that its OpenMP threads share
+    // without synchronisation; 2 is the deterministic stand-in for that (every mode starts adapting from the full step).
+    QH_REQUIRE(adaptive >= 0 && adaptive <= 2, "train_equaliser: adaptive must be 0, 1 or 2");
+    QH_REQUIRE(adaptive != 2 || nseg <= 0, "train_equaliser: per-mode step sizes are not available in the segmented mode");
     QH_REQUIRE(nmodes >= 1 && ntaps >= 1 && os >= 1 && Niter >= 0 && TrSyms >= 0, "train_equaliser: bad sizes");
     QH_REQUIRE(nsel >= 1 && nsel <= 16, "train_equaliser: between 1 and 16 modes can be selected");
     QH_REQUIRE(TrSyms == 0 || (TrSyms - 1) * os + ntaps <= L, "train_equaliser: field shorter than TrSyms*os + ntaps");
@@ -485,6 +503,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
     a.L = L; a.TrSyms = TrSyms; a.nsy = nsy; a.nmodes = nmodes; a.ntaps = ntaps; a.Niter = Niter; a.os = os;
     a.nsel = nsel; a.adaptive = adaptive ? 1 : 0; a.method = method;
     for (int j = 0; j < 16; j++) a.modes[j] = j < nsel ? modes[j] : 0;
+    const bool per_mode = adaptive == 2 && nsel > 1;
     a.nseg = 0; a.seg_begin = 0; a.seg_len = 0; a.seg_iter = 0; a.wx_out = nullptr;
     a.win_start = nullptr; a.win_len = 0; a.nwin = 0; a.win_mu = nullptr; a.e_off = 0;
     if (nseg <= 0) {
@@ -527,6 +546,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             la.Lp = L; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
             la.os = os; la.nsel = nsel; la.method = method;
             la.nch = nch; la.E_cs = (int64_t)nmodes * L; la.wx_cs = (int64_t)nmodes * ntot; la.err_cs = (int64_t)nmodes * TrSyms * Niter; la.mu_cs = 1;
+            la.mu_ms = 0;
             for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];
             if (use_bi && decision) {   // the kernel reads the slicer table like an mrde table: row pitch 2*BI_DD_MAXLEV, 2*npart+1 used
                 la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV;
@@ -538,10 +558,20 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
                 QH_HIP(hipMemsetAsync(pp, 0, 16 * sizeof(unsigned long long), g_stream));
                 la.prof = (unsigned long long *)pp;
             }
-            const int nmode_runs = adaptive ? nsel : 1;          // adaptive: mu is carried from sweep to sweep and from mode to mode
-            if (adaptive) la.nsel = 1;
+            // adaptive = 1: mu is carried from sweep to sweep and from mode to mode -> one mode after the other;
+            // adaptive = 2: every mode owns a step size (scratch array, seeded with mu) -> all modes concurrently
+            R *mu_modes = nullptr;
+            if (per_mode && use_bi) {
+                void *pm = nullptr;
+                if ((rc = scratch(6, (size_t)nch * nsel * sizeof(R), &pm))) return rc;
+                mu_modes = (R *)pm;
+                hipLaunchKernelGGL((spread_kernel<R>), dim3((unsigned)((nch * nsel + 63) / 64)), dim3(64), 0, g_stream, mu_modes, (const R *)mu_dev, nsel, nch * nsel);
+                la.mu = mu_modes; la.mu_out = mu_modes; la.mu_cs = nsel; la.mu_ms = 1;
+            }
+            const int nmode_runs = (adaptive && !mu_modes) ? nsel : 1;
+            if (adaptive && !mu_modes) la.nsel = 1;
             for (int jm = 0; jm < nmode_runs; jm++) {
-                if (adaptive) la.modes[0] = a.modes[jm];
+                if (adaptive && !mu_modes) la.modes[0] = a.modes[jm];
                 for (int it = 0; it < Niter; it++) {             // one launch per sweep (and chunk): taps go through HBM in between
                     for (int64_t step0 = 0; step0 < TrSyms;) {
                         int64_t n = TrSyms - step0 < CH ? TrSyms - step0 : CH;
@@ -561,6 +591,8 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
                     }
                 }
             }
+            if (mu_modes)        // mu out = the last selected mode's, per channel
+                hipLaunchKernelGGL((gather_kernel<R>), dim3((unsigned)((nch + 63) / 64)), dim3(64), 0, g_stream, (R *)mu_dev, (const R *)mu_modes, nsel, nch);
             if (la.prof) {
                 unsigned long long hp[16];
                 QH_HIP(hipMemcpyAsync(hp, la.prof, sizeof(hp), hipMemcpyDeviceToHost, g_stream));
@@ -573,6 +605,17 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
                     for (int h = 1; h <= LA_NH; h++) fprintf(stderr, " helper%d update %llu prior %llu wait %llu |", h, hp[4 * h], hp[4 * h + 1], hp[4 * h + 2]);
                     fprintf(stderr, "\n");
                 }
+            }
+            return QH_OK;
+        }
+        if (per_mode) {                            // one call per mode, each from the initial step size
+            void *pm = nullptr;
+            if ((rc = scratch(6, (size_t)nch * sizeof(R), &pm))) return rc;
+            QH_HIP(hipMemcpyAsync(pm, mu_dev, (size_t)nch * sizeof(R), hipMemcpyDeviceToDevice, g_stream));
+            for (int j = 0; j < nsel; j++) {
+                QH_HIP(hipMemcpyAsync(mu_dev, pm, (size_t)nch * sizeof(R), hipMemcpyDeviceToDevice, g_stream));
+                if ((rc = train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes + j, 1, 1, symbols, nsy, method, err, 0, 0, 0, gram, 0, nch)))
+                    return rc;
             }
             return QH_OK;
         }

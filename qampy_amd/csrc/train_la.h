@@ -222,7 +222,7 @@ template <typename R> struct LaArgs {
     int64_t L, Lp, TrSyms, nsy, sy_pitch, err_pitch, err_off;   // L usable samples per row from E on, Lp row pitch (>= L: time chunks)     // symbols row m starts at symbols + m * sy_pitch
     int nmodes, ntaps, os, nsel, method, nch;
     // channel batch: blockIdx.y = channel; element strides between the channels' arrays (0 for a single capture)
-    int64_t E_cs, wx_cs, err_cs, G_cs, mu_cs;
+    int64_t E_cs, wx_cs, err_cs, G_cs, mu_cs, mu_ms;     // mu_ms: stride between the step sizes of the selected modes (0: one mu)
     int64_t modes[16];
     unsigned long long *prof;   // optional [4 waves][4] cycle counters of workgroup 0 (qh_la_profile), else nullptr
 };
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
     Cx<R> *const awx = a.wx + ch * a.wx_cs;
     Cx<R> *const aerr = a.err + ch * a.err_cs;
     const GramPair<R> *const aG = a.G + ch * a.G_cs;
-    const R *const amu = a.mu + ch * a.mu_cs;
+    const R *const amu = a.mu + ch * a.mu_cs + (int64_t)blockIdx.x * a.mu_ms;
     extern __shared__ __attribute__((aligned(16))) char la_smem[];
     LaLds<R> &lds = *reinterpret_cast<LaLds<R> *>(la_smem);
     Cx<R> *lds_win = reinterpret_cast<Cx<R> *>(la_smem + sizeof(LaLds<R>));   // [LA_NH][2][nmodes][wpitch] helper sample windows

@@ -384,3 +384,33 @@ def test_time_chunked_training_equals_unchunked(monkeypatch, method, M):
         np.testing.assert_allclose(e2, e1, rtol=2e-4, atol=1e-4)
     eo, wo, _ = oracle.train_equaliser(E, tr, 2, 2, np.float32(3e-4), w0.copy(), None, False, sy, method)
     np.testing.assert_allclose(w2, wo, rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("method,M,ntaps,nmodes", [("mcma", 16, 19, 2), ("sbd", 16, 19, 4), ("cma", 4, 7, 3), ("mrde", 64, 161, 2)])
+@pytest.mark.parametrize("dn", ["c64", "c128"])
+def test_per_mode_adaptive_step_equals_one_call_per_mode(method, M, ntaps, nmodes, dn):
+    """adaptive='per-mode' (C flag 2): every mode adapts its own step size from mu and the modes train concurrently - by
+    definition the result of one reference call per mode from the initial mu (161 taps: no block form, per-mode loop)."""
+    sig = synth.make_capture(M, 6000, nmodes=nmodes, snr_db=26, seed=5, dtype=CT[dn])
+    E = np.ascontiguousarray(np.asarray(sig))
+    tr = core_eq._cal_training_symbol_len(2, ntaps, E.shape[1])
+    w0 = core_eq._init_taps(ntaps, nmodes, nmodes, CT[dn])
+    if method in ("sbd", "mrde"):
+        _, w0, _ = oracle.train_equaliser(E, tr, 2, 2, RT[dn](2e-3), w0, None, False, core_eq._reshape_symbols(None, "mcma", M, CT[dn], nmodes), "mcma")
+    sy = core_eq._reshape_symbols(None, method, M, CT[dn], nmodes)
+    modes = np.arange(nmodes)[::-1].copy()
+    mu0 = RT[dn](4e-3)
+    wo, eo, muo = w0.copy(), np.zeros((nmodes, tr * 2), CT[dn]), None
+    for m in modes:                                   # the definition: one sequential-semantics call per mode
+        e1, wo, muo = oracle.train_equaliser(E, tr, 2, 2, mu0, wo, np.array([m]), True, sy, method)
+        eo[m] = e1[m]
+    e, w, mu = hk.train_equaliser(E, tr, 2, 2, mu0, w0.copy(), modes, "per-mode", sy, method)
+    t = dict(rtol=1e-9, atol=1e-11) if dn == "c128" else dict(rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(w, wo, **t)
+    np.testing.assert_allclose(e, eo, rtol=t["rtol"], atol=t["atol"] * 5)
+    np.testing.assert_allclose(mu, muo, rtol=1e-9 if dn == "c128" else 3e-4)
+    # and it differs from the sequential semantics, where later modes inherit an already reduced step
+    e2, w2, mu2 = hk.train_equaliser(E, tr, 2, 2, mu0, w0.copy(), modes, True, sy, method)
+    assert not np.allclose(w2[modes[-1]], w[modes[-1]], rtol=1e-3, atol=1e-4)
+    with pytest.raises(ValueError):
+        hk.train_equaliser(E, tr, 1, 2, mu0, w0.copy(), modes, "sometimes", sy, method)
