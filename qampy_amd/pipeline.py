@@ -45,7 +45,7 @@ class ResidentReceiver:
             if m not in _host.TRAINING_FCTS:
                 raise ValueError("%s is unknown method" % m)
         self.Niter = tuple(int(n) for n in Niter)
-        self.adaptive = tuple(bool(a) for a in adaptive_stepsize)
+        self.adaptive = tuple(a if isinstance(a, str) else bool(a) for a in adaptive_stepsize)      # True, False or "per-mode"
         self.modes = np.arange(nmodes) if modes is None else np.atleast_1d(modes)
         self.TrSyms = tuple(_host._cal_training_symbol_len(os, Ntaps, L) if t is None else int(t) for t in TrSyms[:self.nstage])
         self.N = (self.L - self.Ntaps + 1) // self.os

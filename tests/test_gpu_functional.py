@@ -187,7 +187,7 @@ def test_resident_receiver_device_ser_equals_host_ser():
 
 # ------------------------------------------------------------------------------------------------ channel bank (8e, within a GPU)
 @pytest.mark.parametrize("methods,adaptive", [(("mcma", "sbd"), (False, False)), (("cma", "mrde"), (False, False)),
-                                              (("mcma", "mddma"), (True, True))])
+                                              (("mcma", "mddma"), (True, True)), (("mcma", "sbd"), ("per-mode", "per-mode"))])
 @pytest.mark.parametrize("trainer", ["auto", "iterative"])
 def test_channel_bank_equals_single_receivers(monkeypatch, methods, adaptive, trainer):
     """A bank of independent captures trained in ONE launch per stage (channel = blockIdx.y) gives bit-identical taps,
