@@ -269,3 +269,22 @@ def test_receiver_on_device_generated_capture():
     rx.run()
     res = ber.cal_ser_dev(rx.out, d["idx_tx"], rx.alphabet, maxlag=256, window=4096, trim=20000)
     assert max(r["ser"] for r in res) < 2e-3 and sorted(r["tx_mode"] for r in res) == [0, 1], res
+
+
+@pytest.mark.parametrize("method", ["cma", "mrde", "sbd"])
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_divergent_training_terminates(method, adaptive):
+    """A step size far beyond stability drives the taps to inf / nan; every trainer form must still return (the block-iterative
+    sweeps are bounded by the block length) and produce non-finite taps like the reference's arithmetic does."""
+    import time
+    from qampy_amd.core.equalisation import equalisation as core_eq
+    from qampy_amd.core.equalisation import hip_equalisation as hk
+    sig = synth.make_capture(64 if method == "mrde" else 16, 2 ** 14, nmodes=2, snr_db=20, seed=2, dtype=np.complex64)
+    E = np.ascontiguousarray(np.asarray(sig))
+    tr = core_eq._cal_training_symbol_len(2, 21, E.shape[1])
+    sy = core_eq._reshape_symbols(None, method, sig.M, np.complex64, 2)
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        e, w, mu = hk.train_equaliser(E, tr, 1, 2, np.float32(50.), core_eq._init_taps(21, 2, 2, np.complex64), None, adaptive, sy, method)
+    assert time.perf_counter() - t0 < 20
+    assert e.shape == (2, tr) and (adaptive or not np.all(np.isfinite(w)))
