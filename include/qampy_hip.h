@@ -58,7 +58,13 @@ int qh_memset(void *dptr, int value, size_t bytes);
 int qh_memcpy_h2d(void *dptr, const void *hptr, size_t bytes);
 int qh_memcpy_d2h(void *hptr, const void *dptr, size_t bytes);
 int qh_memcpy_d2d(void *dst, const void *src, size_t bytes);
-/* HIP events recorded on the library stream (bench.py measures kernel time with these) */
+/* Two library streams.  Every entry point enqueues on the CURRENT one (0 after qh_init); qh_use_stream switches it,
+ * qh_stream_wait_event makes the current stream wait for an event recorded on the other one, qh_sync drains both.
+ * Scratch buffers are per library, not per stream: overlap only stages that use different ones (trainers + Gram tables on
+ * one stream; filter, phase search and SER harness on the other - what ChannelBank.run_pipelined does). */
+int qh_use_stream(int idx);
+int qh_stream_wait_event(void *ev);
+/* HIP events recorded on the current library stream (bench.py measures kernel time with these) */
 int qh_event_create(void **ev);
 int qh_event_destroy(void *ev);
 int qh_event_record(void *ev);

@@ -80,6 +80,8 @@ SIGNATURES = {
     "qh_synth_capture_c64_dev": [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, C.c_double, C.c_double, _i, C.c_double, C.c_double, _i, C.c_double,
                                  C.c_uint64],
     "qh_set_trainer": [_i],
+    "qh_use_stream": [_i],
+    "qh_stream_wait_event": [_vp],
     "qh_ser_c64_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
     "qh_ser_c128_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
 }

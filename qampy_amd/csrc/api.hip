@@ -6,7 +6,8 @@
 
 namespace qh {
 
-hipStream_t g_stream = nullptr;
+hipStream_t g_stream = nullptr;          // the stream every entry point enqueues on: one of g_streams (qh_use_stream)
+static hipStream_t g_streams[2] = {nullptr, nullptr};
 int g_device = -1;
 static thread_local std::string g_err;
 static std::mutex g_mu;
@@ -38,8 +39,11 @@ static int init_device(int device)
         return QH_ERR_NODEVICE;
     }
     QH_HIP(hipSetDevice(device));
-    if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
-    QH_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        if (g_streams[i]) { (void)hipStreamDestroy(g_streams[i]); g_streams[i] = nullptr; }
+        QH_HIP(hipStreamCreateWithFlags(&g_streams[i], hipStreamNonBlocking));
+    }
+    g_stream = g_streams[0];
     g_device = device;
     return QH_OK;
 }
@@ -108,7 +112,23 @@ int qh_sync(void)
 {
     int rc = qh::ensure_init();
     if (rc) return rc;
-    QH_HIP(hipStreamSynchronize(qh::g_stream));
+    QH_HIP(hipStreamSynchronize(qh::g_streams[0]));
+    QH_HIP(hipStreamSynchronize(qh::g_streams[1]));
+    return QH_OK;
+}
+int qh_use_stream(int idx)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    if (idx < 0 || idx > 1) { qh::set_error("qh_use_stream: the library has streams 0 and 1"); return QH_ERR_ARG; }
+    qh::g_stream = qh::g_streams[idx];
+    return QH_OK;
+}
+int qh_stream_wait_event(void *ev)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    QH_HIP(hipStreamWaitEvent(qh::g_stream, (hipEvent_t)ev, 0));
     return QH_OK;
 }
 int qh_malloc(void **dptr, size_t bytes)

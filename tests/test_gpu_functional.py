@@ -288,3 +288,25 @@ def test_divergent_training_terminates(method, adaptive):
         e, w, mu = hk.train_equaliser(E, tr, 1, 2, np.float32(50.), core_eq._init_taps(21, 2, 2, np.complex64), None, adaptive, sy, method)
     assert time.perf_counter() - t0 < 20
     assert e.shape == (2, tr) and (adaptive or not np.all(np.isfinite(w)))
+
+
+def test_channel_bank_pipelined_passes_equal_plain_passes():
+    """Two-stream software pipelining of the bank (trainers of pass k+1 beside filter + phase search of pass k) changes no result."""
+    from qampy_amd import _lib
+    from qampy_amd.pipeline import ChannelBank
+    nch, M = 4, 16
+    sigs = [synth.make_capture(M, 2 ** 13, nmodes=2, snr_db=24, theta=0.5 + 0.1 * c, dgd=20e-12, linewidth=10e3, seed=70 + c, dtype=np.complex64)
+            for c in range(nch)]
+    bank = ChannelBank(nch, 2, sigs[0].shape[1], 2, M, 15, (2e-3, 5e-4), methods=("mcma", "sbd"), Niter=(2, 1), Mtestangles=32, Nbps=10,
+                       alphabet=sigs[0].coded_symbols, trainer="iterative")
+    for c, sg in enumerate(sigs):
+        bank.load(c, sg)
+    bank.run()
+    ref = [bank.fetch(c) for c in range(nch)]
+    bank.eq.zero(); bank.out.zero()
+    bank.run_pipelined(5)
+    _lib.sync()
+    for c in range(nch):
+        got = bank.fetch(c)
+        for k in ("wxy", "eq", "out", "idx", "ph"):
+            assert np.array_equal(ref[c][k], got[k]), (c, k)
