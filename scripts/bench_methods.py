@@ -28,7 +28,7 @@ for method in ("cma", "mcma", "cma2", "rde", "mrde", "sbd", "mddma", "dd"):
         os.environ.pop("QAMPY_HIP_TRAINER", None)
         if form != "default":
             os.environ["QAMPY_HIP_TRAINER"] = form
-        for adaptive in (False, True):
+        for adaptive in (False, True, "per-mode"):
             if adaptive and form != "default":
                 continue
             dw = DeviceArray.from_host(w0.copy())
@@ -41,7 +41,7 @@ for method in ("cma", "mcma", "cma2", "rde", "mrde", "sbd", "mddma", "dd"):
             e1.record()
             ms = e1.elapsed_ms(e0)
             wf = dw.to_host()
-            res["%s/%s%s" % (method, form, "+adaptive" if adaptive else "")] = dict(ms=round(ms, 2), cycles_per_step=round(ms * 1e-3 * 2.4e9 / tr, 1),
+            res["%s/%s%s" % (method, form, "+adaptive" if adaptive is True else ("+adaptive(per-mode)" if adaptive else ""))] = dict(ms=round(ms, 2), cycles_per_step=round(ms * 1e-3 * 2.4e9 / tr, 1),
                                                                                    finite=bool(np.all(np.isfinite(wf))))
 os.environ.pop("QAMPY_HIP_TRAINER", None)
 print(json.dumps(dict(what="%d-QAM 2-pol, %d symbols, %d taps, one sweep, both output modes concurrently (gram build included)" % (M, nsym, ntaps), results=res)))
