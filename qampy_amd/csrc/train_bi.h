@@ -228,14 +228,27 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         if ((int64_t)kb * LA_B + lane >= TrSyms) acc = Cx<R>{0, 0};
         return acc;
     };
-    const int gs = a.gpair ? 2 : 1;                                    // the look-ahead pair layout interleaves cur / next
-    const Cx<R> *gbase = reinterpret_cast<const Cx<R> *>(aG) + ((size_t)(BI_JW * w) * LA_B + lane) * gs;
-    auto load_gram = [&](Cx<R> (&g)[BI_JW], int kb) {
-        const Cx<R> *gp = gbase + (size_t)kb * LA_B * LA_B * gs;
+    // Gram rows of the own steps: either the look-ahead pair layout (cur / next interleaved, zeros where target <= step) or
+    // the triangular cur-only layout (only targets > step are stored: lanes at or before the step load a dummy and are
+    // zeroed when the prefetched rows are taken over - never at load time, that would stall on the load)
+    const int gstride = a.gpair ? LA_B * LA_B * 2 : GRAM_TRI;         // Cx elements per block
+    int goff[BI_JW];
+    bool gok[BI_JW];
 #pragma unroll
-        for (int r = 0; r < BI_JW; r++) g[r] = gp[(size_t)r * LA_B * gs];
+    for (int r = 0; r < BI_JW; r++) {
+        const int j = BI_JW * w + r;
+        gok[r] = a.gpair || lane > j;
+        goff[r] = a.gpair ? (j * LA_B + lane) * 2 : (lane > j ? gram_tri_row(j) + lane - j - 1 : 0);
+    }
+    auto load_gram = [&](Cx<R> (&g)[BI_JW], int kb) {
+        const Cx<R> *gp = reinterpret_cast<const Cx<R> *>(aG) + (size_t)kb * gstride;
+#pragma unroll
+        for (int r = 0; r < BI_JW; r++) g[r] = gp[goff[r]];
     };
-
+    auto mask_gram = [&](Cx<R> (&g)[BI_JW]) {
+#pragma unroll
+        for (int r = 0; r < BI_JW; r++) g[r] = gok[r] ? g[r] : Cx<R>{0, 0};
+    };
     Cx<R> *errow = aerr + (size_t)mode * a.err_pitch + a.err_off;
     stage_load(0); stage_store(0);
     if (nblk > 1) { stage_load(1); stage_store(1); }
@@ -243,6 +256,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
     Cx<R> qpart = prior_part(0);
     Cx<R> g[BI_JW], gn[BI_JW];
     load_gram(g, 0);
+    mask_gram(g);
 
     BiEnt<R> *pw = P + (size_t)lane * BI_PAD + w;                       // this wave's column of the exchange buffer
     const BiEnt<R> *pr = P + (size_t)(BI_JW * w + rr) * BI_PAD + vv;   // the rows it reduces
@@ -382,7 +396,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         const unsigned long long pt2c = a.prof ? clock64() : 0;
         if (k + 1 < nblk) qpart = prior_part(k + 1);                      // reads the own slice of wbuf only: no barrier needed
 #pragma unroll
-        for (int r = 0; r < BI_JW; r++) g[r] = gn[r];
+        for (int r = 0; r < BI_JW; r++) g[r] = gok[r] ? gn[r] : Cx<R>{0, 0};
         if (a.prof) {
             const unsigned long long pt3 = clock64();
             pf_t_sweep += pt1 - pt0; pf_t_upd += pt2c - pt1; pf_t_prior += pt3 - pt2c;
@@ -469,7 +483,7 @@ template <typename R> int slicer_tables(const void *symbols, int nmodes, int64_t
 template <typename R> static size_t gram_cur_bytes(int64_t TrSyms)
 {
     const int64_t nblk = (TrSyms + LA_B - 1) / LA_B;
-    return (size_t)(nblk * LA_B + LA_B) * LA_B * sizeof(Cx<R>);
+    return (size_t)(nblk + 1) * GRAM_TRI * sizeof(Cx<R>);
 }
 
 template <typename R> int gram_cur_build(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram, int nch = 1,

@@ -531,7 +531,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             // block-iterative form (train_bi.h): 8 wavefronts per output mode solve each 64-step block by fixed-point sweeps;
             // look-ahead form (train_la.h): one chain wave + three helper waves per output mode
             const bool pair_tab = use_bi ? pair : true;                      // layout of the Gram table this call reads
-            const size_t step_bytes = (pair_tab ? sizeof(GramPair<R>) : sizeof(Cx<R>)) * LA_B;     // per step and channel
+            const size_t step_bytes = pair_tab ? sizeof(GramPair<R>) * LA_B : sizeof(Cx<R>) * GRAM_TRI / LA_B;     // per step and channel
             // Time chunks: when the Gram tables of the whole capture (x channels) would not fit the budget, the sweep runs
             // chunk after chunk - table of the chunk, then the trainers over it, taps handed on through HBM exactly as
             // between sweeps - which bounds the scratch memory for any capture length and channel count.  Not for the

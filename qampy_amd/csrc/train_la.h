@@ -27,7 +27,10 @@ constexpr int LA_HB = 32;         // helper load batch (tap update)
 constexpr int LA_MAXSLICE = 32;   // taps per helper held in registers by the prior dot products
 constexpr int LA_MAXPART = 8;     // RDE/MRDE partitions handled by the vector select chain
 
-template <typename R> struct GramPair { Cx<R> cur, next; };   // per (step l, lane i): G(l, blk+i) [i > l-blk] and G(l, blk+64+i)
+template <typename R> struct GramPair { Cx<R> cur, next; };
+// cur-only ("triangular") layout: row j of a block holds its 63 - j entries with target > j at gram_tri_row(j)
+constexpr int GRAM_TRI = 2048;     // entries per block slot (2016 used)
+__host__ __device__ constexpr int gram_tri_row(int j) { return j * (LA_B - 1) - j * (j - 1) / 2; }   // per (step l, lane i): G(l, blk+i) [i > l-blk] and G(l, blk+64+i)
 
 // ------------------------------------------------------------------------------------------------ Gram precompute
 // G(l, l+d) = sum_k sum_t conj(E[k, l os + t]) E[k, (l+d) os + t]  is, along a diagonal (fixed lag d), a SLIDING window sum of
@@ -53,10 +56,13 @@ __global__ void __launch_bounds__(256) gram_slide_kernel(const Cx<R> *E, int nmo
             tile[k * span + s] = g < L ? ldg(E + (size_t)k * Lp + g) : Cx<R>{0, 0};
         }
     }
-    // entries a lane must never see (targets at or before the source step) are zeros
-    for (int e = threadIdx.x; e < LA_B * LA_B; e += 256) {
-        const int j = e >> 6, i = e & 63;
-        if (i <= j) stg(G + ((size_t)(blk + j) * LA_B + i) * GS, Cx<R>{0, 0});
+    // pair layout: entries a lane must never see (targets at or before the source step) are zeros.  The cur-only layout
+    // (block-iterative trainer) stores just the 2016 entries with target > step of a block, row after row, in a 2048-entry slot
+    if (PAIR) {
+        for (int e = threadIdx.x; e < LA_B * LA_B; e += 256) {
+            const int j = e >> 6, i = e & 63;
+            if (i <= j) stg(G + ((size_t)(blk + j) * LA_B + i) * GS, Cx<R>{0, 0});
+        }
     }
     __syncthreads();
     const int d = threadIdx.x & 127, half = threadIdx.x >> 7;     // lag, half of the block
@@ -81,8 +87,12 @@ __global__ void __launch_bounds__(256) gram_slide_kernel(const Cx<R> *E, int nmo
         const int it = j + d;                                      // target relative to the block start
         const bool ok = blk + j < TrSyms && blk + it < TrSyms;
         const Cx<R> v = ok ? Cx<R>{sr, si} : Cx<R>{0, 0};
-        if (it < LA_B) stg(G + ((size_t)(blk + j) * LA_B + it) * GS, v);
-        else if (PAIR) stg(G + ((size_t)(blk + j) * LA_B + (it - LA_B)) * GS + 1, v);
+        if (PAIR) {
+            if (it < LA_B) stg(G + ((size_t)(blk + j) * LA_B + it) * GS, v);
+            else stg(G + ((size_t)(blk + j) * LA_B + (it - LA_B)) * GS + 1, v);
+        } else {
+            stg(G + (size_t)blockIdx.x * GRAM_TRI + gram_tri_row(j) + (d - 1), v);
+        }
         if (j + 1 < jend) {                                        // slide: drop the first `os` products, add the next `os`
             for (int k = 0; k < nmodes; k++) {
                 const Cx<R> *ra = tile + k * span + j * os, *rb = ra + d * os;

@@ -258,7 +258,7 @@ class ChannelBank:
         # the trainers build them per time chunk themselves (csrc/train_impl.h: gram_budget)
         import os as _os
         budget = float(_os.environ.get("QAMPY_HIP_GRAM_BUDGET_GB", 160.)) * 2 ** 30
-        per_step = (512 if self.trainer == 3 else 1024) * (np.dtype(self.ct).itemsize // 8)
+        per_step = (256 if self.trainer == 3 else 1024) * (np.dtype(self.ct).itemsize // 8)
         fits = self.nch * self.TrSyms[0] * per_step <= budget
         self._gram = _k.gram_build_batch_dev(self.E, self.os, self.Ntaps, self.TrSyms[0]) if (len(set(self.TrSyms)) == 1 and fits) else None
         for s in range(r.nstage):
