@@ -169,7 +169,7 @@ class ChannelBank:
         self.nch = int(nch)
         # trainer: "auto" = per-method choice of the single-capture path (look-ahead for cma-type stages: lowest latency, but
         # its Gram table is 1 KiB per step); "iterative" = block-iterative form for every stage: 10-25 % longer stages, half
-        # the Gram table (0.5 KiB per step, built 2.7x faster) - more channels fit and aggregate throughput is higher
+        # a quarter of the Gram table (256 B per step, built 2.8x faster) - more channels fit and aggregate throughput is higher
         self.trainer = {"auto": 0, "direct": 1, "lookahead": 2, "iterative": 3}[trainer]
         # one receiver object provides the shared constants and the per-channel views; its own big buffers are replaced
         self.rx = ResidentReceiver(nmodes, 8 * Ntaps * os, os, M, Ntaps, mu, **kw)       # tiny dummy capture
