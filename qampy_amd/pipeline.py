@@ -168,7 +168,7 @@ class ChannelBank:
     def __init__(self, nch, nmodes, L, os, M, Ntaps, mu, trainer="auto", **kw):
         self.nch = int(nch)
         # trainer: "auto" = per-method choice of the single-capture path (look-ahead for cma-type stages: lowest latency, but
-        # its Gram table is 1 KiB per step); "iterative" = block-iterative form for every stage: 10-25 % longer stages, half
+        # its Gram table is 1 KiB per step); "iterative" = block-iterative form for every stage: 10-25 % longer stages,
         # a quarter of the Gram table (256 B per step, built 2.8x faster) - more channels fit and aggregate throughput is higher
         self.trainer = {"auto": 0, "direct": 1, "lookahead": 2, "iterative": 3}[trainer]
         # one receiver object provides the shared constants and the per-channel views; its own big buffers are replaced
