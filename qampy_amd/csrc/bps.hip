@@ -110,14 +110,18 @@ __global__ void __launch_bounds__(BPS_THREADS) bps_kernel(BpsArgs<R> a)
     // ---- phase 1: min-distance of every (symbol, test angle) of tile + halo; lanes <-> consecutive angles.  A thread
     // rotates BPS_EPT elements, then walks the candidates ONCE for all of them (one candidate fetch per 8 updates).
     const int total = rows * A;
+    const int r_step = BPS_THREADS / A, ja_step = BPS_THREADS - r_step * A;      // (row, angle) advance of one thread-block stride
     for (int e0 = threadIdx.x; e0 < total; e0 += BPS_THREADS * BPS_EPT) {
         R tr[BPS_EPT], ti[BPS_EPT];
         bool ok[BPS_EPT];
+        int rq = e0 / A, jq = e0 - rq * A;                 // one division per 8 elements; the rest advance incrementally
 #pragma unroll
         for (int q = 0; q < BPS_EPT; q++) {
             const int e = e0 + q * BPS_THREADS;
-            const int ec = e < total ? e : total - 1;
-            const int r = ec / A, ja = ec - r * A;
+            const bool in = e < total;
+            const int r = in ? rq : rows - 1, ja = in ? jq : A - 1;
+            rq += r_step; jq += ja_step;
+            if (jq >= A) { jq -= A; rq++; }
             const int64_t l = l0 + r;
             ok[q] = e < total && l >= 0 && l < a.L;        // rows outside [0, L) only feed outputs that are forced to 0
             const int64_t lc = l < 0 ? 0 : (l < a.L ? l : a.L - 1);
