@@ -198,6 +198,21 @@ int qh_count_errors_dev(const int32_t *idx_rx, const int32_t *idx_tx, int64_t n,
  * reference's results up to the order of floating-point additions; a form that cannot take a call falls through. */
 int qh_set_trainer(int form);
 
+/* ---- parallel-in-time training (opt-in, NOT the reference's order of evaluation) ---------------------
+ * Waveform relaxation over `nseg` contiguous segments of every sweep: `npass` passes, each training all segments
+ * concurrently with the exact kernels, segment s starting from the taps segment s-1 ended with in the previous pass.
+ * The fixed point is the sequential recurrence (reached exactly after nseg passes); 2-3 passes reproduce outputs, error
+ * trace and decisions, tap components in the null space of the input covariance lag behind.  Fixed step,
+ * blind and decision-directed methods.  pass_change: NULL or `npass` doubles on the HOST receiving, per pass, the largest
+ * change of any segment's end taps against the previous pass (entry 0 = -1); asking for it synchronises every pass.
+ * prefix: steps of the first sweep trained sequentially before the segments start (converged, phase-locked taps). */
+int qh_train_equaliser_c64_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
+                                   void *wx, int ntaps, const int64_t *modes, int nsel, const void *symbols, int64_t nsy,
+                                   int method, void *err, int zero_err, int nseg, int npass, double *pass_change, int64_t prefix);
+int qh_train_equaliser_c128_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev,
+                                    void *wx, int ntaps, const int64_t *modes, int nsel, const void *symbols, int64_t nsy,
+                                    int method, void *err, int zero_err, int nseg, int npass, double *pass_change, int64_t prefix);
+
 /* ---- channel bank: nch independent captures of identical shape processed together -------------------------------
  * (SURVEY.md 8e "within a GPU": one exact training chain occupies one workgroup, so a GPU holds hundreds of channels).
  * All arrays carry a leading channel dimension and are contiguous: E (nch, nmodes, L), wx (nch, nmodes, nmodes, ntaps),

@@ -79,6 +79,8 @@ SIGNATURES = {
     "qh_train_equaliser_c128_batch_dev": [_vp, _i] + _train_sig(_pd, dev=True)[1:] + [_vp],
     "qh_synth_capture_c64_dev": [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, C.c_double, C.c_double, _i, C.c_double, C.c_double, _i, C.c_double,
                                  C.c_uint64],
+    "qh_train_equaliser_c64_pit_dev": [_vp, _i, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64],
+    "qh_train_equaliser_c128_pit_dev": [_vp, _i, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64],
     "qh_set_trainer": [_i],
     "qh_use_stream": [_i],
     "qh_stream_wait_event": [_vp],

@@ -186,14 +186,15 @@ def gram_build_dev(E, os, ntaps, TrSyms):
 
 
 def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method, err, zero_err=False, segments=0,
-                        prefix=0, gram=None, prefix_mu=0.):
+                        prefix=0, gram=None, prefix_mu=0., passes=0, pass_change=None):
     """
     Same as :func:`train_equaliser` with every array (and the scalar ``mu``, a 1-element DeviceArray) already in HBM.
     Only enqueues work on the library stream.
 
-    ``segments > 0`` selects the opt-in segment-parallel continuation (tier B): ``prefix`` sequential steps,
-    then ``segments`` concurrently trained contiguous segments per sweep, all starting from the same taps.  This is NOT
-    the reference's recurrence (results agree statistically, not to rounding).
+    ``segments > 0`` selects an opt-in segment-parallel mode, NOT the reference's order of evaluation:
+    with ``passes > 0`` parallel-in-time relaxation (segment s restarts from the end taps of segment s-1 of the previous
+    pass; converges to the sequential recurrence, 2-3 passes reproduce outputs and decisions), else the one-shot
+    continuation (``prefix`` sequential steps, then all segments from the same taps; statistical agreement only).
     """
     if method not in _lib.METHOD_ID:
         raise ValueError("Unknown method %s" % method)
@@ -204,7 +205,18 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
     args = (E.ptr, nmodes, L, int(TrSyms), int(Niter), int(os), mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size,
             _adaptive_flag(adaptive), symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)))
     name = "qh_train_equaliser_c" + ("64" if suf == "32" else "128")
-    if segments and segments > 0:
+    if segments and segments > 0 and passes and passes > 0:
+        # parallel in time (opt-in): `passes` relaxation passes over `segments` concurrently trained segments per sweep;
+        # pass_change: optional float64 array (passes,) receiving the largest end-tap change per pass
+        if _adaptive_flag(adaptive):
+            raise ValueError("parallel-in-time training needs a fixed step size")
+        pc = None
+        if pass_change is not None:
+            assert pass_change.dtype == np.float64 and pass_change.size >= passes and pass_change.flags.c_contiguous
+            pc = _lib.ptr(pass_change)
+        _lib.call(name + "_pit_dev", E.ptr, nmodes, L, int(TrSyms), int(Niter), int(os), mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size,
+                  symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)), int(segments), int(passes), pc, int(prefix))
+    elif segments and segments > 0:
         _lib.call(name + "_seg_dev", *args, int(segments), int(prefix), float(prefix_mu or 0.))
     elif gram:
         _lib.call(name + "_gram_dev", *args, gram)

@@ -38,6 +38,12 @@ int qh_train_equaliser_c128_gram_dev(const void *E, int nmodes, int64_t L, int64
 {
     return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, 0, 0, gram);
 }
+int qh_train_equaliser_c128_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev, void *wx, int ntaps,
+                                    const int64_t *modes, int nsel, const void *symbols, int64_t nsy, int method, void *err, int zero_err,
+                                    int nseg, int npass, double *pass_change, int64_t prefix)
+{
+    return qh::train_pit_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, symbols, nsy, method, err, zero_err, nseg, npass, pass_change, prefix);
+}
 int qh_gram_build_c128_batch_dev(const void *E, int nch, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
 {
     if (!qh::la_shape_ok(nmodes, ntaps, os) && qh::bi_shape_ok(nmodes, ntaps, os, 2 * sizeof(double))) return qh::gram_cur_build<double>(E, nmodes, L, os, ntaps, TrSyms, gram, nch);

@@ -28,6 +28,8 @@
 #include "common.h"
 #include "train_bi.h"
 #include <stdlib.h>
+#include <vector>
+#include <math.h>
 #include <stdio.h>
 
 namespace qh {
@@ -659,6 +661,147 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         QH_HIP(hipMemcpyAsync(wtmp, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));   // rows of unselected modes stay as they are
         if ((rc = launch_any<R>(s))) return rc;
         QH_HIP(hipMemcpyAsync(wx, wtmp, wbytes, hipMemcpyDeviceToDevice, g_stream));
+    }
+    return QH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Parallel-in-time training (opt-in; DESIGN.md 3.2 tier B+): waveform relaxation over S contiguous segments of a sweep.
+// Pass p trains all segments CONCURRENTLY with the exact kernels (segments = channels of a batch that overlap in the
+// capture), segment s starting from the taps segment s-1 ended with in pass p-1 (segment 0 always from the true initial
+// taps; pass 0: everybody from the initial taps).  The map is triangular in s, so its only fixed point is the sequential
+// recurrence, reached exactly after S passes; because the LMS recursion forgets its initial condition within a few
+// 1/(mu lambda) steps in every direction the signal excites, two or three passes already reproduce outputs and error
+// trace to ~1e-4 and the symbol decisions exactly - what differs from the reference at that point are tap components in
+// the (near-)null space of the input covariance, which move by a slow random walk and are handed on one segment per pass.
+// pass_change (host, npass entries, optional): largest change of a segment's end taps against the previous pass.
+// Blind / decision-directed methods with a fixed step; the TrSyms % (S*64) last steps run sequentially afterwards.
+template <typename R>
+int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu_dev, void *wx, int ntaps,
+                  const int64_t *modes, int nsel, const void *symbols, int64_t nsy, int method, void *err, int zero_err,
+                  int nseg, int npass, double *pass_change, int64_t prefix = 0)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (method < 0 || method > QH_M_SBD_DATA) { set_error("unknown equaliser method id"); return QH_ERR_METHOD; }
+    QH_REQUIRE(nmodes >= 1 && ntaps >= 1 && os >= 1 && Niter >= 0 && TrSyms >= 0 && nsel >= 1 && nsel <= 16 && nsy >= 1, "train_equaliser: bad sizes");
+    QH_REQUIRE(TrSyms == 0 || (TrSyms - 1) * os + ntaps <= L, "train_equaliser: field shorter than TrSyms*os + ntaps");
+    QH_REQUIRE(nseg >= 1 && nseg <= 4096 && npass >= 1 && npass <= 4096, "train_equaliser: bad segment / pass count");
+    QH_REQUIRE(method != QH_M_SBD_DATA, "train_equaliser: parallel-in-time training is not available for data-aided methods");
+    for (int j = 0; j < nsel; j++) QH_REQUIRE(modes[j] >= 0 && modes[j] < nmodes, "train_equaliser: mode number >= nmodes");
+    const int ntot = nmodes * ntaps;
+    if (zero_err) QH_HIP(hipMemsetAsync(err, 0, (size_t)nmodes * TrSyms * Niter * sizeof(Cx<R>), g_stream));
+    if (pass_change) for (int p = 0; p < npass; p++) pass_change[p] = 0;
+    if (TrSyms == 0 || Niter == 0) return QH_OK;
+    // `prefix` steps of the FIRST sweep run sequentially (exact kernels) so that every segment starts from converged,
+    // phase-locked taps; the segments then cover [prefix, TrSyms) in the first sweep and everything in later ones
+    if (prefix < 0) prefix = 0;
+    prefix = prefix / LA_B * LA_B;
+    if (prefix > TrSyms) prefix = TrSyms / LA_B * LA_B;
+    const int64_t seg = (TrSyms - prefix) / nseg / LA_B * LA_B;       // one segment length for all sweeps
+    const int S = nseg;
+    // which exact form takes the segments (same rules as the sequential path, fixed step)
+    const char *force = trainer_force();
+    bool bi_ok = force[0] != 'd' && force[0] != 'l' && seg >= 2 * LA_B && bi_supported(method, 0, nmodes, ntaps, os, seg, nsy, sizeof(Cx<R>));
+    const bool decision = method == QH_M_SBD || method == QH_M_MDDMA || method == QH_M_DD;
+    void *dd_table = nullptr;
+    int dd_npart = -1;
+    if (bi_ok && decision) {
+        if ((rc = slicer_tables<R>(symbols, nmodes, nsy, modes, nsel, &dd_table, &dd_npart))) return rc;
+        bi_ok = dd_npart == 1 || dd_npart == 3 || dd_npart == 7 || dd_npart == 15;
+    }
+    const bool la_ok = force[0] != 'd' && seg >= 2 * LA_B && la_supported(method, 0, nmodes, ntaps, os, seg, nsy);
+    const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
+    const bool use_bi = bi_ok && (partitioned || decision || !la_ok || force[0] == 'i');
+    if (S == 1 || !(use_bi || la_ok))          // nothing to parallelise / no block form for this call: the sequential path
+        return train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, 0, symbols, nsy, method, err, 0);
+    const bool pair_tab = use_bi ? la_shape_ok(nmodes, ntaps, os) : true;
+    const size_t wset = (size_t)nmodes * ntot;                        // one tap set
+    void *wbuf = nullptr;
+    if ((rc = scratch(2, 2 * (size_t)S * wset * sizeof(Cx<R>), &wbuf))) return rc;
+    Cx<R> *wA = (Cx<R> *)wbuf, *wB = wA + (size_t)S * wset;
+    std::vector<Cx<R>> hprev, hcur;
+    if (pass_change) { hprev.resize((size_t)S * wset); hcur.resize((size_t)S * wset); }
+    // Gram tables of the segments: once, shared by passes and sweeps
+    void *G = nullptr;
+    const size_t gbytes = (pair_tab ? gram_bytes<R>(seg) : gram_cur_bytes<R>(seg)) * (size_t)S;
+    auto build_tables = [&](int64_t first, void **Gout) -> int {        // tables of the S segments starting at step `first`
+        const Cx<R> *E0 = (const Cx<R> *)E + first * os;
+        const int64_t Lb = L - first * os - (int64_t)(S - 1) * seg * os;
+        return pair_tab ? gram_build<R>(E0, nmodes, Lb, os, ntaps, seg, Gout, S, L, seg * os)
+                        : gram_cur_build<R>(E0, nmodes, Lb, os, ntaps, seg, Gout, S, L, seg * os);
+    };
+    (void)gbytes;
+    LaArgs<R> la;
+    la.symbols = (const Cx<R> *)symbols; la.err = (Cx<R> *)err; la.gpair = pair_tab ? 1 : 0;
+    la.mu = mu_dev; la.mu_out = nullptr; la.mu_cs = 0; la.mu_ms = 0;
+    la.Lp = L; la.TrSyms = seg; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter;
+    la.nmodes = nmodes; la.ntaps = ntaps; la.os = os; la.nsel = nsel; la.method = method;
+    la.nch = S; la.E_cs = seg * os; la.wx_cs = (int64_t)wset; la.err_cs = seg;
+    la.G_cs = (int64_t)((pair_tab ? gram_bytes<R>(seg) : gram_cur_bytes<R>(seg)) / sizeof(GramPair<R>));
+    for (int j = 0; j < 16; j++) la.modes[j] = j < nsel ? modes[j] : 0;
+    if (use_bi && decision) { la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV; }
+    la.prof = nullptr;
+    const size_t wbytes = wset * sizeof(Cx<R>);
+    int64_t tables_for = -1;
+    for (int it = 0; it < Niter; it++) {
+        const int64_t first = it == 0 ? prefix : 0;                    // the segments of this sweep start here
+        if (first >= 2 * LA_B) {                                        // sequential prefix: the exact kernels on [0, prefix)
+            LaArgs<R> lp = la;
+            void *Gp = nullptr;
+            rc = pair_tab ? gram_build<R>(E, nmodes, L, os, ntaps, first, &Gp, 1, L, 0) : gram_cur_build<R>(E, nmodes, L, os, ntaps, first, &Gp, 1, L, 0);
+            if (rc) return rc;
+            lp.E = (const Cx<R> *)E; lp.L = L; lp.TrSyms = first; lp.nch = 1; lp.wx = (Cx<R> *)wx; lp.G = (const GramPair<R> *)Gp;
+            lp.err_off = (int64_t)it * TrSyms;
+            if ((rc = use_bi ? launch_bi<R>(lp) : launch_la<R>(lp))) return rc;
+            tables_for = -1;                                            // the prefix table replaced the segments' tables
+        }
+        if (tables_for != first) {
+            if ((rc = build_tables(first, &G))) return rc;
+            tables_for = first;
+        }
+        la.E = (const Cx<R> *)E + first * os; la.L = L - first * os - (int64_t)(S - 1) * seg * os; la.G = (const GramPair<R> *)G;
+        // pass 0: every segment from the taps at the start of the segmented part
+        for (int s2 = 0; s2 < S; s2++) QH_HIP(hipMemcpyAsync(wA + (size_t)s2 * wset, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
+        for (int p = 0; p < npass; p++) {
+            la.wx = wA; la.err_off = (int64_t)it * TrSyms + first;
+            if ((rc = use_bi ? launch_bi<R>(la) : launch_la<R>(la))) return rc;
+            if (pass_change) {                       // diagnostic: how far did the segments' end taps move since the last pass?
+                QH_HIP(hipMemcpyAsync(hcur.data(), wA, (size_t)S * wbytes, hipMemcpyDeviceToHost, g_stream));
+                QH_HIP(hipStreamSynchronize(g_stream));
+                if (p > 0) {
+                    double m = 0;
+                    for (size_t q = 0; q < hcur.size(); q++) {
+                        const double d = fabs((double)hcur[q].re - (double)hprev[q].re) + fabs((double)hcur[q].im - (double)hprev[q].im);
+                        if (d > m || d != d) m = d;
+                    }
+                    if (m > pass_change[p] || m != m) pass_change[p] = m;
+                } else if (it == 0) {
+                    pass_change[0] = -1;             // no previous pass to compare with
+                }
+                hprev.swap(hcur);
+            }
+            if (p + 1 < npass) {                     // next pass: segment s starts where segment s-1 just ended
+                QH_HIP(hipMemcpyAsync(wB, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
+                QH_HIP(hipMemcpyAsync(wB + wset, wA, (size_t)(S - 1) * wbytes, hipMemcpyDeviceToDevice, g_stream));
+                Cx<R> *t = wA; wA = wB; wB = t;
+            }
+        }
+        // the last segment's end taps are the sweep's; rows of unselected modes were carried along unchanged
+        QH_HIP(hipMemcpyAsync(wx, wA + (size_t)(S - 1) * wset, wbytes, hipMemcpyDeviceToDevice, g_stream));
+        const int64_t done = first + (int64_t)S * seg;
+        if (done < TrSyms) {                         // remainder of the sweep, sequentially (direct form, one segment per mode)
+            TrainArgs<R> a;
+            a.E = (const Cx<R> *)E; a.wx = (Cx<R> *)wx; a.symbols = (const Cx<R> *)symbols; a.err = (Cx<R> *)err; a.mu = mu_dev;
+            a.L = L; a.TrSyms = TrSyms; a.nsy = nsy; a.nmodes = nmodes; a.ntaps = ntaps; a.Niter = Niter; a.os = os;
+            a.nsel = nsel; a.adaptive = 0; a.method = method;
+            for (int j = 0; j < 16; j++) a.modes[j] = j < nsel ? modes[j] : 0;
+            a.win_start = nullptr; a.win_len = 0; a.nwin = 0; a.win_mu = nullptr; a.e_off = 0;
+            a.nseg = 1; a.seg_begin = done; a.seg_len = TrSyms - done; a.seg_iter = it; a.wx_out = wB;
+            QH_HIP(hipMemcpyAsync(wB, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
+            if ((rc = launch_any<R>(a))) return rc;
+            QH_HIP(hipMemcpyAsync(wx, wB, wbytes, hipMemcpyDeviceToDevice, g_stream));
+        }
     }
     return QH_OK;
 }

@@ -34,7 +34,7 @@ class ResidentReceiver:
 
     def __init__(self, nmodes, L, os, M, Ntaps, mu, methods=("cma", "mrde"), Niter=(1, 1), adaptive_stepsize=(False, False),
                  TrSyms=(None, None), Mtestangles=64, Nbps=20, dtype=np.complex64, alphabet=None, modes=None, segments=0,
-                 prefix=1 << 16, prefix_mu=None):
+                 prefix=1 << 16, prefix_mu=None, passes=0):
         suf, self.rt, self.ct = _lib.suffix(dtype)
         self.nmodes, self.L, self.os, self.M, self.Ntaps = int(nmodes), int(L), int(os), int(M), int(Ntaps)
         self.nstage = len(methods)
@@ -51,10 +51,14 @@ class ResidentReceiver:
         self.N = (self.L - self.Ntaps + 1) // self.os
         self.Mtestangles, self.Nbps = Mtestangles, Nbps
         # segments > 0: opt-in segment-parallel training (tier B); 0 = the reference's exact sequential recurrence
-        self.segments = int(segments)
+        self.segments_stage = tuple(int(x) for x in segments) if isinstance(segments, (tuple, list)) else (int(segments),) * len(methods)
+        self.segments = max(self.segments_stage)
+        self.passes = int(passes)              # > 0 with segments: parallel-in-time relaxation passes (tier B+)
+        self.pass_change = [np.zeros(max(self.passes, 1)) for _ in methods] if passes else None
         self.prefix = tuple(int(p) for p in (prefix if isinstance(prefix, (tuple, list)) else (prefix,) * len(methods)))
         self.prefix_mu = tuple(prefix_mu) if prefix_mu is not None else (0.,) * len(methods)
         self.mu0 = tuple(self.rt(m) for m in mu)
+        self.report_passes = False             # True: fill pass_change (synchronises after every pass)
         if alphabet is None:
             alphabet = _host.generate_symbols_for_eq("sbd", M, self.ct)[0]
         self.alphabet_host = np.ascontiguousarray(alphabet, dtype=self.ct)
@@ -100,8 +104,9 @@ class ResidentReceiver:
     def train(self, stage):
         _k.train_equaliser_dev(self.E, self.TrSyms[stage], self.Niter[stage], self.os, self.mu[stage], self.wxy, self.modes,
                                self.adaptive[stage], self.symbols[stage], self.methods[stage], self.err[stage],
-                               segments=self.segments, prefix=self.prefix[stage], gram=getattr(self, "_gram", None),
-                               prefix_mu=self.prefix_mu[stage])
+                               segments=self.segments_stage[stage], prefix=self.prefix[stage], gram=getattr(self, "_gram", None),
+                               prefix_mu=self.prefix_mu[stage], passes=self.passes,
+                               pass_change=self.pass_change[stage] if (self.pass_change and self.report_passes) else None)
 
     def apply(self):
         _k.apply_filter_to_signal_dev(self.E, self.os, self.wxy, self.modes, self.eq)

@@ -414,3 +414,35 @@ def test_per_mode_adaptive_step_equals_one_call_per_mode(method, M, ntaps, nmode
     assert not np.allclose(w2[modes[-1]], w[modes[-1]], rtol=1e-3, atol=1e-4)
     with pytest.raises(ValueError):
         hk.train_equaliser(E, tr, 1, 2, mu0, w0.copy(), modes, "sometimes", sy, method)
+
+
+@pytest.mark.parametrize("method,M", [("mcma", 16), ("cma", 16), ("mrde", 64), ("sbd", 16)])
+def test_parallel_in_time_relaxation_reaches_the_sequential_recurrence(method, M):
+    """Opt-in parallel-in-time training (qh_train_equaliser_*_pit_dev): S segments trained concurrently per pass, segment s
+    restarting from the end taps of segment s-1 of the previous pass.  The map is triangular in s, so after S passes the result
+    IS the sequential recurrence (to rounding, like every exact form); fewer passes are an approximation whose end-tap motion
+    per pass is reported."""
+    from qampy_amd._lib import DeviceArray
+    sig = synth.make_capture(M, 2 ** 14, nmodes=2, snr_db=28, theta=np.pi / 5.6, dgd=30e-12, seed=41, dtype=np.complex64)
+    E = np.ascontiguousarray(np.asarray(sig))
+    ntaps, S = 15, 4
+    tr = core_eq._cal_training_symbol_len(2, ntaps, E.shape[1]) - 7
+    w0 = core_eq._init_taps(ntaps, 2, 2, np.complex64)
+    if method in ("mrde", "sbd"):
+        _, w0, _ = hk.train_equaliser(E, tr, 2, 2, np.float32(2e-3), w0, None, False, core_eq._reshape_symbols(None, "mcma", M, np.complex64, 2), "mcma")
+    sy = core_eq._reshape_symbols(None, method, M, np.complex64, 2)
+    eo, wo, _ = hk.train_equaliser(E, tr, 2, 2, np.float32(5e-4), w0.copy(), None, False, sy, method)
+    dE, dsy, dmu = DeviceArray.from_host(E), DeviceArray.from_host(np.ascontiguousarray(sy)), DeviceArray.from_host(np.array([5e-4], np.float32))
+    res = {}
+    for P in (1, S):
+        dw, derr = DeviceArray.from_host(w0.copy()), DeviceArray((2, tr * 2), np.complex64, zero=True)
+        pc = np.zeros(P)
+        hk.train_equaliser_dev(dE, tr, 2, 2, dmu, dw, None, False, dsy, method, derr, segments=S, passes=P, pass_change=pc, prefix=512)
+        res[P] = (dw.to_host(), derr.to_host(), pc)
+    w, e, pc = res[S]
+    np.testing.assert_allclose(w, wo, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(e, eo, rtol=2e-4, atol=1e-4)
+    assert pc[0] == -1 and np.all(pc[1:] >= 0) and pc[-1] <= pc[1] + 1e-6          # the end taps settle
+    w1, e1, _ = res[1]
+    assert np.all(np.isfinite(w1)) and np.all(np.abs(e1[:, -1]) > 0)
+    assert np.array_equal(e1[:, :512], e[:, :512])                                 # the sequential prefix is the same in every pass count
