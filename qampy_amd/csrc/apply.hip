@@ -19,6 +19,8 @@ namespace qh {
 constexpr int AP_THREADS = 256;
 constexpr int AP_PER_THREAD = 4;
 constexpr int AP_TILE = AP_THREADS * AP_PER_THREAD;   // output symbols per workgroup
+// LDS row pitch of the complex kernel in samples: the tile's window, one spare sample, rounded up to an even count
+__host__ __device__ constexpr int ap_pitch(int os, int ntaps) { return ((AP_TILE - 1) * os + ntaps + 2) & ~1; }
 
 template <typename T> struct ApplyArgs {
     const T *E;
@@ -38,10 +40,11 @@ __global__ void __launch_bounds__(AP_THREADS) apply_cplx_kernel(ApplyArgs<Cx<R>>
     const int64_t i0 = (int64_t)blockIdx.x * AP_TILE;
     const int nout = (int)((a.N - i0) < AP_TILE ? (a.N - i0) : AP_TILE);
     const int span = (nout - 1) * a.os + a.ntaps;                 // samples per input mode needed by this tile
-    const int stride = (AP_TILE - 1) * a.os + a.ntaps;            // LDS row pitch
+    const int stride = ap_pitch(a.os, a.ntaps);                   // LDS row pitch: even, one spare sample for the paired reads
     for (int k = 0; k < a.nmodes; k++) {
         const Cx<R> *src = a.E + (size_t)k * a.L + i0 * a.os;
         for (int s = threadIdx.x; s < span; s += AP_THREADS) tile[k * stride + s] = ldg(src + s);
+        if (threadIdx.x == 0) tile[k * stride + span] = Cx<R>{0, 0};            // the spare sample (odd tap counts read it with a zero tap)
     }
     __syncthreads();
     const int j0 = blockIdx.y * NJ;
@@ -52,6 +55,59 @@ __global__ void __launch_bounds__(AP_THREADS) apply_cplx_kernel(ApplyArgs<Cx<R>>
     for (int r = 0; r < AP_PER_THREAD; r++)
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[r][j][0] = acc[r][j][1] = 0;
+    if (sizeof(R) == 4 && (a.os & 1) == 0) {
+        // even oversampling, complex64: a lane's window starts on a 16-byte boundary, so two consecutive samples (= two taps)
+        // come with ONE ds_read_b128, conflict-free at the lanes' 16-byte stride; the complex multiply-adds are written on
+        // (re, im) 2-vectors so that they become v_pk_fma_f32 (two per complex MAC instead of four v_fma_f32)
+        typedef R v2 __attribute__((ext_vector_type(2)));
+        struct alignas(16) Pair { Cx<R> a, b; };
+        v2 ac[AP_PER_THREAD][NJ];
+#pragma unroll
+        for (int r = 0; r < AP_PER_THREAD; r++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) ac[r][j] = v2{0, 0};
+        auto cmac = [](v2 &acc, const Cx<R> &x, const Cx<R> &c) {
+            acc = __builtin_elementwise_fma(v2{x.re, x.re}, v2{c.re, c.im}, acc);
+            acc = __builtin_elementwise_fma(v2{x.im, x.im}, v2{-c.im, c.re}, acc);
+        };
+        // taps, paired and zero-padded, behind the sample rows in LDS: read back as wave-uniform (broadcast) 16-byte loads - no
+        // scalar-cache round trip inside the loop, no odd-tap special case
+        const int npair = (a.ntaps + 1) / 2;
+        Pair *wt = reinterpret_cast<Pair *>(tile + (size_t)a.nmodes * stride);                // [NJ][nmodes][npair]
+        for (int e = threadIdx.x; e < NJ * a.nmodes * npair; e += AP_THREADS) {
+            const int j = e / (a.nmodes * npair), q = e - j * a.nmodes * npair, k = q / npair, pp = q - k * npair;
+            const Cx<R> *w = j == 0 ? w0 : w1;
+            Pair v;
+            v.a = w[k * a.ntaps + 2 * pp];
+            v.b = 2 * pp + 1 < a.ntaps ? w[k * a.ntaps + 2 * pp + 1] : Cx<R>{0, 0};
+            wt[e] = v;
+        }
+        __syncthreads();
+        for (int k = 0; k < a.nmodes; k++) {
+            const Cx<R> *row = tile + k * stride + threadIdx.x * a.os;
+            const Pair *wk0 = wt + k * npair, *wk1 = wt + (a.nmodes + k) * npair;
+#pragma unroll 2
+            for (int pp = 0; pp < npair; pp++) {
+                const Pair c0 = wk0[pp];
+                Pair c1 = c0;
+                if constexpr (NJ > 1) c1 = wk1[pp];
+#pragma unroll
+                for (int r = 0; r < AP_PER_THREAD; r++) {
+                    const Pair x = *reinterpret_cast<const Pair *>(row + r * AP_THREADS * a.os + 2 * pp);
+                    cmac(ac[r][0], x.a, c0.a);
+                    cmac(ac[r][0], x.b, c0.b);
+                    if constexpr (NJ > 1) {
+                        cmac(ac[r][1], x.a, c1.a);
+                        cmac(ac[r][1], x.b, c1.b);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < AP_PER_THREAD; r++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) { acc[r][j][0] = ac[r][j].x; acc[r][j][1] = ac[r][j].y; }
+    } else
     for (int k = 0; k < a.nmodes; k++) {
         const Cx<R> *row = tile + k * stride;
         for (int t = 0; t < a.ntaps; t++) {
@@ -124,7 +180,7 @@ template <typename T> static int apply_check(int nmodes, int64_t L, int os, int 
     QH_REQUIRE(nsel >= 1 && nsel <= 16, "apply_filter_to_signal: between 1 and 16 modes can be selected");
     for (int j = 0; j < nsel; j++)
         QH_REQUIRE(modes[j] >= 0 && modes[j] < nrows_w, "apply_filter_to_signal: largest mode number is larger than shape of taps");
-    const size_t lds = (size_t)nmodes * ((size_t)(AP_TILE - 1) * os + ntaps) * sizeof(T);
+    const size_t lds = ((size_t)nmodes * ((size_t)(AP_TILE - 1) * os + ntaps + 2) + (size_t)2 * nmodes * (ntaps + 1)) * sizeof(T);
     QH_REQUIRE(lds <= 160 * 1024, "apply_filter_to_signal: nmodes*(1023*os+ntaps) samples exceed the 160 KiB LDS tile");
     return QH_OK;
 }
@@ -141,7 +197,7 @@ template <typename R> int apply_cplx_dev(const void *E, int nmodes, int64_t L, i
     a.E = (const Cx<R> *)E; a.wx = (const Cx<R> *)wx; a.out = (Cx<R> *)out; a.L = L; a.N = N;
     a.nmodes = nmodes; a.ntaps = ntaps; a.os = os; a.nsel = nsel;
     for (int j = 0; j < 16; j++) a.modes[j] = j < nsel ? modes[j] : 0;
-    const size_t lds = (size_t)nmodes * ((size_t)(AP_TILE - 1) * os + ntaps) * sizeof(Cx<R>);
+    const size_t lds = ((size_t)nmodes * (size_t)ap_pitch(os, ntaps) + (size_t)2 * nmodes * (ntaps + 1)) * sizeof(Cx<R>);   // sample rows + paired taps
     const unsigned ntile = (unsigned)((N + AP_TILE - 1) / AP_TILE);
     if (nsel == 1) {
         if (lds > 64 * 1024) QH_HIP(hipFuncSetAttribute((const void *)apply_cplx_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
