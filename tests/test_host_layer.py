@@ -217,3 +217,32 @@ def test_ser_counter_finds_rotation_lag_and_swap():
     assert mode == 1 and lag == 7 and nerr == 1 and ncmp == 4000 - 7
     nerr, ncmp, mode, rot, lag = synth.count_symbol_errors(rx[1], tx, alphabet)
     assert mode == 0 and lag == -3 and nerr == 0
+
+
+def test_adaptive_flag_and_given_symbols():
+    from qampy_amd.core.equalisation import hip_equalisation as hk
+    assert hk._adaptive_flag(False) == 0 and hk._adaptive_flag(True) == 1 and hk._adaptive_flag(np.bool_(True)) == 1
+    assert hk._adaptive_flag("per-mode") == 2 and hk._adaptive_flag("per_mode") == 2 and hk._adaptive_flag("Private") == 2
+    with pytest.raises(ValueError):
+        hk._adaptive_flag("sometimes")
+    with pytest.raises(ValueError):
+        hk._adaptive_flag("per-mode", allow_per_mode=False)
+    # the host generator takes given symbols (cross-checks of the device generator, pilot frames)
+    a = synth.make_capture(16, 512, nmodes=2, seed=1, dtype=np.complex128)
+    b = synth.make_capture(16, 512, nmodes=2, seed=99, dtype=np.complex128, symbols=a.symbols)
+    assert np.allclose(np.asarray(a), np.asarray(b)) and np.array_equal(b.symbols, a.symbols)
+
+
+def test_pilot_signal_geometry():
+    from qampy_amd.signals import PilotSignal
+    idx, idx_dat, idx_pil = PilotSignal._cal_pilot_idx(256, 32, 8)
+    assert idx_pil[:33].all() and not idx_pil[33] and idx_pil[40] and idx_pil.sum() == 32 + (256 - 32) // 8 and (idx_dat ^ idx_pil).all()
+    with pytest.raises(ValueError):
+        PilotSignal._cal_pilot_idx(256, 32, 5)
+    pilots = np.ones((2, int(idx_pil.sum())), np.complex128)
+    sig = PilotSignal(np.zeros((2, 2 * 256 * 2), np.complex128), 16, 1e9, 2e9, 256, 32, 8, pilots)
+    assert sig.os == 2 and sig.nframes == 2 and sig.pilot_seq.shape == (2, 32) and sig.ph_pilots.shape == (2, 28)
+    one = sig.recreate_from_np_array(np.zeros((2, 256), np.complex128), fs=sig.fb)
+    assert type(one) is PilotSignal and one.os == 1 and one.nframes == 1 and one.get_data().shape == (2, 224) and one.extract_pilots().shape == (2, 32)
+    with pytest.raises(ValueError):
+        PilotSignal(np.zeros((2, 10), np.complex128), 16, 1e9, 2e9, 256, 32, 8, pilots[:, :5])
