@@ -243,6 +243,6 @@ def test_pilot_signal_geometry():
     sig = PilotSignal(np.zeros((2, 2 * 256 * 2), np.complex128), 16, 1e9, 2e9, 256, 32, 8, pilots)
     assert sig.os == 2 and sig.nframes == 2 and sig.pilot_seq.shape == (2, 32) and sig.ph_pilots.shape == (2, 28)
     one = sig.recreate_from_np_array(np.zeros((2, 256), np.complex128), fs=sig.fb)
-    assert type(one) is PilotSignal and one.os == 1 and one.nframes == 1 and one.get_data().shape == (2, 224) and one.extract_pilots().shape == (2, 32)
+    assert type(one) is PilotSignal and one.os == 1 and one.nframes == 1 and one.get_data().shape == (2, 196) and one.extract_pilots().shape == (2, 60)
     with pytest.raises(ValueError):
         PilotSignal(np.zeros((2, 10), np.complex128), 16, 1e9, 2e9, 256, 32, 8, pilots[:, :5])
