@@ -226,7 +226,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(dev)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        # RCCL ("nccl") on the GPUs; QAMPY_BENCH_BACKEND=gloo lets several ranks share ONE GPU (checking the multi-rank flow
+        # on a single-GPU box), the reductions then go through host tensors
+        backend = os.environ.get("QAMPY_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend=backend)
+    red_dev = "cpu" if (world > 1 and os.environ.get("QAMPY_BENCH_BACKEND", "nccl") != "nccl") else "cuda"
     _lib.init(dev)
 
     def barrier_sync():
@@ -244,14 +251,14 @@ def main():
 
     # ---- timed region: exactly K steps, HIP events between the stages (same stream as the kernels)
     elapsed, stage_ms = timed_steps(rx, args.steps, args.warmup, barrier_sync)
-    elapsed = sharding.reduce_max_time(elapsed, dist, device="cuda")
+    elapsed = sharding.reduce_max_time(elapsed, dist, device=red_dev)
 
     # ---- results of the last step: SER against the transmitted symbols
     # (on-device harness: alignment search + decisions + count in HBM, qh_ser_*_dev; nothing but 7 integers per row moves)
     ser_rows = rx.ser(sig.symbols, maxlag=256, window=8192, trim=2000)
     errs = [(d["errors"], d["compared"]) for d in ser_rows]
     res = dict(wxy=rx.wxy.to_host())
-    counts_all = sharding.reduce_sum_counts([[e, n] for e, n in errs], dist, device="cuda")
+    counts_all = sharding.reduce_sum_counts([[e, n] for e, n in errs], dist, device=red_dev)
 
     if rank != 0:
         if dist is not None:
