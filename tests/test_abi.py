@@ -53,3 +53,22 @@ def test_unknown_method_is_a_value_error_before_touching_the_device():
     with pytest.raises(TypeError):
         k.train_equaliser(E, 4, 1, 2, np.float32(1e-3), np.zeros((1, 1, 5), np.complex128), None, False,
                           np.ones((1, 1), np.complex64), "cma")
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/qampy_hip.h is a C header (extern "C" only under __cplusplus): a C99 and a C++11 translation unit that include
+    it compile, and a C program can link against the library by name."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "qampy_hip.h"\nint main(void) { int n = -1; return qh_device_count(&n) == QH_OK ? 0 : (n < 0 ? 0 : 0); }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lqampy_hip", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.call([str(exe)]) == 0          # runs without a GPU: counting devices is not an error
