@@ -58,6 +58,11 @@ int qh_memset(void *dptr, int value, size_t bytes);
 int qh_memcpy_h2d(void *dptr, const void *hptr, size_t bytes);
 int qh_memcpy_d2h(void *hptr, const void *dptr, size_t bytes);
 int qh_memcpy_d2d(void *dst, const void *src, size_t bytes);
+/* Threading: the library keeps per-process state (current device and stream, grow-only scratch buffers, trainer selection) and
+ * is meant to be driven by ONE host thread, like the reference's extension modules under the GIL; error text is per thread.
+ * qh_release_scratch frees the grow-only scratch buffers (Gram tables above all - up to QAMPY_HIP_GRAM_BUDGET_GB) after
+ * draining both streams; they are re-allocated on demand. */
+int qh_release_scratch(void);
 /* Two library streams.  Every entry point enqueues on the CURRENT one (0 after qh_init); qh_use_stream switches it,
  * qh_stream_wait_event makes the current stream wait for an event recorded on the other one, qh_sync drains both.
  * Scratch buffers are per library, not per stream: overlap only stages that use different ones (trainers + Gram tables on

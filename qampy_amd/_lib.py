@@ -83,6 +83,7 @@ SIGNATURES = {
     "qh_train_equaliser_c128_pit_dev": [_vp, _i, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64],
     "qh_set_trainer": [_i],
     "qh_use_stream": [_i],
+    "qh_release_scratch": [],
     "qh_stream_wait_event": [_vp],
     "qh_ser_c64_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
     "qh_ser_c128_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],

@@ -310,3 +310,18 @@ def test_channel_bank_pipelined_passes_equal_plain_passes():
         got = bank.fetch(c)
         for k in ("wxy", "eq", "out", "idx", "ph"):
             assert np.array_equal(ref[c][k], got[k]), (c, k)
+
+
+def test_release_scratch_and_continue():
+    """qh_release_scratch gives the grow-only buffers (Gram tables ...) back; the next call re-allocates what it needs."""
+    from qampy_amd import _lib
+    from qampy_amd.core.equalisation import equalisation as core_eq
+    from qampy_amd.core.equalisation import hip_equalisation as hk
+    sig = synth.make_capture(16, 2 ** 12, nmodes=2, snr_db=25, seed=3, dtype=np.complex64)
+    E = np.ascontiguousarray(np.asarray(sig))
+    tr = core_eq._cal_training_symbol_len(2, 11, E.shape[1])
+    sy = core_eq._reshape_symbols(None, "mcma", 16, np.complex64, 2)
+    e1, w1, _ = hk.train_equaliser(E, tr, 1, 2, np.float32(1e-3), core_eq._init_taps(11, 2, 2, np.complex64), None, False, sy, "mcma")
+    _lib.call("qh_release_scratch")
+    e2, w2, _ = hk.train_equaliser(E, tr, 1, 2, np.float32(1e-3), core_eq._init_taps(11, 2, 2, np.complex64), None, False, sy, "mcma")
+    assert np.array_equal(w1, w2) and np.array_equal(e1, e2)
