@@ -72,3 +72,16 @@ def test_header_is_plain_c(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lqampy_hip", "-Wl,-rpath," + libdir,
                            "-Wl,-rpath,/opt/rocm/lib"])
     assert subprocess.call([str(exe)]) == 0          # runs without a GPU: counting devices is not an error
+
+
+@pytest.mark.gpu
+def test_c_program_drives_the_hot_path(tmp_path):
+    """examples/c_abi_demo.c: training, filter and blind phase search through the C ABI from plain C, no Python in the loop."""
+    import subprocess
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "c_abi_demo"
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "c_abi_demo.c"),
+                           "-o", str(exe), "-L", libdir, "-lqampy_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("symbol errors") == 2
