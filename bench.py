@@ -302,6 +302,10 @@ def main():
                roofline=roofline,
                stages_ms={n: round(t, 3) for n, t in zip(stage_names, stage_ms)},
                stages_GBps={n: round(b / (t * 1e-3) / 1e9, 2) for n, b, t in zip(stage_names, stage_bytes, stage_ms)},
+               # what actually bounds the exact trainers: shader cycles per recurrence step of the critical workgroup (2.4 GHz
+               # clock; a lone wavefront issues one instruction per ~8.3 cycles)
+               train_cycles_per_step={stage_names[1 + s2]: round(stage_ms[1 + s2] * 1e-3 * 2.4e9 / (rx.TrSyms[s2] * rx.Niter[s2]), 1)
+                                      for s2 in range(rx.nstage)},
                ser=dict(per_mode_rank0=[e / max(n, 1) for e, n in errs], errors_all=int(counts_all[:, 0].sum()),
                         symbols_all=int(counts_all[:, 1].sum())),
                device=_lib.device_name())
