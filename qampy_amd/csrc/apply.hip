@@ -17,10 +17,12 @@
 namespace qh {
 
 constexpr int AP_THREADS = 256;
+// P output symbols per thread: 4 by default (1024 per workgroup), 1 when many modes x a large oversampling would not fit the LDS
 constexpr int AP_PER_THREAD = 4;
-constexpr int AP_TILE = AP_THREADS * AP_PER_THREAD;   // output symbols per workgroup
-// LDS row pitch of the complex kernel in samples: the tile's window, one spare sample, rounded up to an even count
-__host__ __device__ constexpr int ap_pitch(int os, int ntaps) { return ((AP_TILE - 1) * os + ntaps + 2) & ~1; }
+__host__ __device__ constexpr int ap_tile(int P) { return AP_THREADS * P; }
+// LDS row pitch in samples: the tile's window, one spare sample, rounded up to an even count
+__host__ __device__ constexpr int ap_pitch(int os, int ntaps, int P) { return ((ap_tile(P) - 1) * os + ntaps + 2) & ~1; }
+constexpr size_t AP_LDS_MAX = 160 * 1024;
 
 template <typename T> struct ApplyArgs {
     const T *E;
@@ -32,15 +34,15 @@ template <typename T> struct ApplyArgs {
 };
 
 // ---- complex
-template <typename R, int NJ>
+template <typename R, int NJ, int AP_P>
 __global__ void __launch_bounds__(AP_THREADS) apply_cplx_kernel(ApplyArgs<Cx<R>> a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Cx<R> *tile = reinterpret_cast<Cx<R> *>(smem);
-    const int64_t i0 = (int64_t)blockIdx.x * AP_TILE;
-    const int nout = (int)((a.N - i0) < AP_TILE ? (a.N - i0) : AP_TILE);
+    const int64_t i0 = (int64_t)blockIdx.x * ap_tile(AP_P);
+    const int nout = (int)((a.N - i0) < ap_tile(AP_P) ? (a.N - i0) : ap_tile(AP_P));
     const int span = (nout - 1) * a.os + a.ntaps;                 // samples per input mode needed by this tile
-    const int stride = ap_pitch(a.os, a.ntaps);                   // LDS row pitch: even, one spare sample for the paired reads
+    const int stride = ap_pitch(a.os, a.ntaps, AP_P);                   // LDS row pitch: even, one spare sample for the paired reads
     for (int k = 0; k < a.nmodes; k++) {
         const Cx<R> *src = a.E + (size_t)k * a.L + i0 * a.os;
         for (int s = threadIdx.x; s < span; s += AP_THREADS) tile[k * stride + s] = ldg(src + s);
@@ -50,9 +52,9 @@ __global__ void __launch_bounds__(AP_THREADS) apply_cplx_kernel(ApplyArgs<Cx<R>>
     const int j0 = blockIdx.y * NJ;
     const Cx<R> *w0 = a.wx + (size_t)a.modes[j0] * a.nmodes * a.ntaps;
     const Cx<R> *w1 = (NJ > 1 && j0 + 1 < a.nsel) ? a.wx + (size_t)a.modes[j0 + 1] * a.nmodes * a.ntaps : w0;
-    R acc[AP_PER_THREAD][NJ][2];
+    R acc[AP_P][NJ][2];
 #pragma unroll
-    for (int r = 0; r < AP_PER_THREAD; r++)
+    for (int r = 0; r < AP_P; r++)
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[r][j][0] = acc[r][j][1] = 0;
     if (sizeof(R) == 4 && (a.os & 1) == 0) {
@@ -61,9 +63,9 @@ __global__ void __launch_bounds__(AP_THREADS) apply_cplx_kernel(ApplyArgs<Cx<R>>
         // (re, im) 2-vectors so that they become v_pk_fma_f32 (two per complex MAC instead of four v_fma_f32)
         typedef R v2 __attribute__((ext_vector_type(2)));
         struct alignas(16) Pair { Cx<R> a, b; };
-        v2 ac[AP_PER_THREAD][NJ];
+        v2 ac[AP_P][NJ];
 #pragma unroll
-        for (int r = 0; r < AP_PER_THREAD; r++)
+        for (int r = 0; r < AP_P; r++)
 #pragma unroll
             for (int j = 0; j < NJ; j++) ac[r][j] = v2{0, 0};
         auto cmac = [](v2 &acc, const Cx<R> &x, const Cx<R> &c) {
@@ -92,7 +94,7 @@ __global__ void __launch_bounds__(AP_THREADS) apply_cplx_kernel(ApplyArgs<Cx<R>>
                 Pair c1 = c0;
                 if constexpr (NJ > 1) c1 = wk1[pp];
 #pragma unroll
-                for (int r = 0; r < AP_PER_THREAD; r++) {
+                for (int r = 0; r < AP_P; r++) {
                     const Pair x = *reinterpret_cast<const Pair *>(row + r * AP_THREADS * a.os + 2 * pp);
                     cmac(ac[r][0], x.a, c0.a);
                     cmac(ac[r][0], x.b, c0.b);
@@ -104,7 +106,7 @@ __global__ void __launch_bounds__(AP_THREADS) apply_cplx_kernel(ApplyArgs<Cx<R>>
             }
         }
 #pragma unroll
-        for (int r = 0; r < AP_PER_THREAD; r++)
+        for (int r = 0; r < AP_P; r++)
 #pragma unroll
             for (int j = 0; j < NJ; j++) { acc[r][j][0] = ac[r][j].x; acc[r][j][1] = ac[r][j].y; }
     } else
@@ -114,7 +116,7 @@ __global__ void __launch_bounds__(AP_THREADS) apply_cplx_kernel(ApplyArgs<Cx<R>>
             const Cx<R> c0 = w0[k * a.ntaps + t];                 // wave-uniform -> scalar loads
             const Cx<R> c1 = w1[k * a.ntaps + t];
 #pragma unroll
-            for (int r = 0; r < AP_PER_THREAD; r++) {
+            for (int r = 0; r < AP_P; r++) {
                 const int il = threadIdx.x + r * AP_THREADS;
                 // rows past `nout` read stale-but-in-bounds LDS (stride covers the full tile); they are never stored
                 const Cx<R> x = row[il * a.os + t];
@@ -128,7 +130,7 @@ __global__ void __launch_bounds__(AP_THREADS) apply_cplx_kernel(ApplyArgs<Cx<R>>
         }
     }
 #pragma unroll
-    for (int r = 0; r < AP_PER_THREAD; r++) {
+    for (int r = 0; r < AP_P; r++) {
         const int il = threadIdx.x + r * AP_THREADS;
         if (il < nout) {
             stg(a.out + (size_t)j0 * a.N + i0 + il, Cx<R>{acc[r][0][0], acc[r][0][1]});
@@ -139,15 +141,15 @@ __global__ void __launch_bounds__(AP_THREADS) apply_cplx_kernel(ApplyArgs<Cx<R>>
 }
 
 // ---- real (the real-valued equaliser path, equalisation.py:178-184)
-template <typename R>
+template <typename R, int AP_P>
 __global__ void __launch_bounds__(AP_THREADS) apply_real_kernel(ApplyArgs<R> a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     R *tile = reinterpret_cast<R *>(smem);
-    const int64_t i0 = (int64_t)blockIdx.x * AP_TILE;
-    const int nout = (int)((a.N - i0) < AP_TILE ? (a.N - i0) : AP_TILE);
+    const int64_t i0 = (int64_t)blockIdx.x * ap_tile(AP_P);
+    const int nout = (int)((a.N - i0) < ap_tile(AP_P) ? (a.N - i0) : ap_tile(AP_P));
     const int span = (nout - 1) * a.os + a.ntaps;
-    const int stride = (AP_TILE - 1) * a.os + a.ntaps;
+    const int stride = (ap_tile(AP_P) - 1) * a.os + a.ntaps;
     for (int k = 0; k < a.nmodes; k++) {
         const R *src = a.E + (size_t)k * a.L + i0 * a.os;
         for (int s = threadIdx.x; s < span; s += AP_THREADS) tile[k * stride + s] = src[s];
@@ -155,19 +157,19 @@ __global__ void __launch_bounds__(AP_THREADS) apply_real_kernel(ApplyArgs<R> a)
     __syncthreads();
     const int j = blockIdx.y;
     const R *w = a.wx + (size_t)a.modes[j] * a.nmodes * a.ntaps;
-    R acc[AP_PER_THREAD];
+    R acc[AP_P];
 #pragma unroll
-    for (int r = 0; r < AP_PER_THREAD; r++) acc[r] = 0;
+    for (int r = 0; r < AP_P; r++) acc[r] = 0;
     for (int k = 0; k < a.nmodes; k++) {
         const R *row = tile + k * stride;
         for (int t = 0; t < a.ntaps; t++) {
             const R c = w[k * a.ntaps + t];
 #pragma unroll
-            for (int r = 0; r < AP_PER_THREAD; r++) acc[r] = fma_(row[(threadIdx.x + r * AP_THREADS) * a.os + t], c, acc[r]);
+            for (int r = 0; r < AP_P; r++) acc[r] = fma_(row[(threadIdx.x + r * AP_THREADS) * a.os + t], c, acc[r]);
         }
     }
 #pragma unroll
-    for (int r = 0; r < AP_PER_THREAD; r++) {
+    for (int r = 0; r < AP_P; r++) {
         const int il = threadIdx.x + r * AP_THREADS;
         if (il < nout) a.out[(size_t)j * a.N + i0 + il] = acc[r];
     }
@@ -180,8 +182,8 @@ template <typename T> static int apply_check(int nmodes, int64_t L, int os, int 
     QH_REQUIRE(nsel >= 1 && nsel <= 16, "apply_filter_to_signal: between 1 and 16 modes can be selected");
     for (int j = 0; j < nsel; j++)
         QH_REQUIRE(modes[j] >= 0 && modes[j] < nrows_w, "apply_filter_to_signal: largest mode number is larger than shape of taps");
-    const size_t lds = ((size_t)nmodes * ((size_t)(AP_TILE - 1) * os + ntaps + 2) + (size_t)2 * nmodes * (ntaps + 1)) * sizeof(T);
-    QH_REQUIRE(lds <= 160 * 1024, "apply_filter_to_signal: nmodes*(1023*os+ntaps) samples exceed the 160 KiB LDS tile");
+    const size_t lds = ((size_t)nmodes * ((size_t)(ap_tile(1) - 1) * os + ntaps + 2) + (size_t)2 * nmodes * (ntaps + 1)) * sizeof(T);
+    QH_REQUIRE(lds <= AP_LDS_MAX, "apply_filter_to_signal: nmodes*(255*os+ntaps) samples exceed the 160 KiB LDS tile");
     return QH_OK;
 }
 
@@ -197,15 +199,18 @@ template <typename R> int apply_cplx_dev(const void *E, int nmodes, int64_t L, i
     a.E = (const Cx<R> *)E; a.wx = (const Cx<R> *)wx; a.out = (Cx<R> *)out; a.L = L; a.N = N;
     a.nmodes = nmodes; a.ntaps = ntaps; a.os = os; a.nsel = nsel;
     for (int j = 0; j < 16; j++) a.modes[j] = j < nsel ? modes[j] : 0;
-    const size_t lds = ((size_t)nmodes * (size_t)ap_pitch(os, ntaps) + (size_t)2 * nmodes * (ntaps + 1)) * sizeof(Cx<R>);   // sample rows + paired taps
-    const unsigned ntile = (unsigned)((N + AP_TILE - 1) / AP_TILE);
-    if (nsel == 1) {
-        if (lds > 64 * 1024) QH_HIP(hipFuncSetAttribute((const void *)apply_cplx_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((apply_cplx_kernel<R, 1>), dim3(ntile, 1), dim3(AP_THREADS), lds, g_stream, a);
-    } else {
-        if (lds > 64 * 1024) QH_HIP(hipFuncSetAttribute((const void *)apply_cplx_kernel<R, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((apply_cplx_kernel<R, 2>), dim3(ntile, (nsel + 1) / 2), dim3(AP_THREADS), lds, g_stream, a);
-    }
+    auto lds_for = [&](int P) { return ((size_t)nmodes * (size_t)ap_pitch(os, ntaps, P) + (size_t)2 * nmodes * (ntaps + 1)) * sizeof(Cx<R>); };   // sample rows + paired taps
+    const int P = lds_for(AP_PER_THREAD) <= AP_LDS_MAX ? AP_PER_THREAD : 1;
+    const size_t lds = lds_for(P);
+    const unsigned ntile = (unsigned)((N + ap_tile(P) - 1) / ap_tile(P));
+#define QH_AP_LAUNCH(NJ, PP, GY)                                                                                                     \
+    do {                                                                                                                             \
+        if (lds > 64 * 1024) QH_HIP(hipFuncSetAttribute((const void *)apply_cplx_kernel<R, NJ, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((apply_cplx_kernel<R, NJ, PP>), dim3(ntile, GY), dim3(AP_THREADS), lds, g_stream, a);                      \
+    } while (0)
+    if (nsel == 1) { if (P == 1) QH_AP_LAUNCH(1, 1, 1); else QH_AP_LAUNCH(1, AP_PER_THREAD, 1); }
+    else { if (P == 1) QH_AP_LAUNCH(2, 1, (nsel + 1) / 2); else QH_AP_LAUNCH(2, AP_PER_THREAD, (nsel + 1) / 2); }
+#undef QH_AP_LAUNCH
     QH_HIP(hipGetLastError());
     return QH_OK;
 }
@@ -222,10 +227,17 @@ template <typename R> int apply_real_dev(const void *E, int nmodes, int64_t L, i
     a.E = (const R *)E; a.wx = (const R *)wx; a.out = (R *)out; a.L = L; a.N = N;
     a.nmodes = nmodes; a.ntaps = ntaps; a.os = os; a.nsel = nsel;
     for (int j = 0; j < 16; j++) a.modes[j] = j < nsel ? modes[j] : 0;
-    const size_t lds = (size_t)nmodes * ((size_t)(AP_TILE - 1) * os + ntaps) * sizeof(R);
-    const unsigned ntile = (unsigned)((N + AP_TILE - 1) / AP_TILE);
-    if (lds > 64 * 1024) QH_HIP(hipFuncSetAttribute((const void *)apply_real_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((apply_real_kernel<R>), dim3(ntile, nsel), dim3(AP_THREADS), lds, g_stream, a);
+    auto lds_for = [&](int P) { return (size_t)nmodes * ((size_t)(ap_tile(P) - 1) * os + ntaps) * sizeof(R); };
+    const int P = lds_for(AP_PER_THREAD) <= AP_LDS_MAX ? AP_PER_THREAD : 1;
+    const size_t lds = lds_for(P);
+    const unsigned ntile = (unsigned)((N + ap_tile(P) - 1) / ap_tile(P));
+    if (P == 1) {
+        if (lds > 64 * 1024) QH_HIP(hipFuncSetAttribute((const void *)apply_real_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((apply_real_kernel<R, 1>), dim3(ntile, nsel), dim3(AP_THREADS), lds, g_stream, a);
+    } else {
+        if (lds > 64 * 1024) QH_HIP(hipFuncSetAttribute((const void *)apply_real_kernel<R, AP_PER_THREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((apply_real_kernel<R, AP_PER_THREAD>), dim3(ntile, nsel), dim3(AP_THREADS), lds, g_stream, a);
+    }
     QH_HIP(hipGetLastError());
     return QH_OK;
 }

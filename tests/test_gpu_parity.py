@@ -456,3 +456,12 @@ def test_trainer_fuzz_against_oracle():
     out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_trainer.py"),
                           "250", "11"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "250 cases, 0 failures" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_dsp_fuzz_against_oracle():
+    """scripts/fuzz_dsp.py: random shapes / dtypes / alphabets for the filter (complex and real taps, up to 4 modes x os 3 x 69
+    taps), blind phase search (one and per-symbol grids), angle selection and decisions against the oracle."""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_dsp.py"),
+                          "300", "7"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "300 cases, 0 failures" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
