@@ -51,8 +51,12 @@ for case in range(n_cases):
     if not np.array_equal(sa, so):
         fails.append(("select_angles", case))
     d1, d2 = hk.make_decision(sig, alphabet), oracle.make_decision(sig, alphabet)
-    if not (np.array_equal(d1[2], d2[2]) and np.array_equal(d1[0], d2[0]) and np.allclose(d1[1], d2[1], rtol=1e-5 if ct is np.complex64 else 1e-12)):
-        fails.append(("make_decision", case, M, Lb, str(ct)))
+    dm = np.nonzero(d1[2] != d2[2])[0]
+    # a different index is only acceptable for a tie within the rounding of the distance (hypot on the device vs libm)
+    tie = all(abs(abs(sig[i] - alphabet[d1[2][i]]) - abs(sig[i] - alphabet[d2[2][i]])) <= 4 * np.finfo(rt).eps * abs(sig[i] - alphabet[d2[2][i]]) for i in dm)
+    same = np.ones(Lb, bool); same[dm] = False
+    if not (tie and dm.size <= 1 and np.array_equal(d1[0][same], d2[0][same]) and np.allclose(d1[1], d2[1], rtol=1e-5 if ct is np.complex64 else 1e-12)):
+        fails.append(("make_decision", case, M, Lb, str(ct), int(dm.size)))
 for f in fails[:20]:
     print("FAIL", f)
 print("fuzz-dsp: %d cases, %d failures, worst bps mismatch fraction %.2e, %.1f s" % (n_cases, len(fails), worst_bps, time.time() - t0))
