@@ -2,25 +2,34 @@
 """
 bench.py - equalised MSym/s of the adaptive-equaliser + carrier-recovery hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|ns] [--nsym S] [--no-cpu-baseline]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|ns] [--tier b|a] [--nsym S] [--no-cpu-baseline]
 
-One "step" = one pass of the hot path (dual-mode tap training -> filter application -> blind phase search, unwrap and
-de-rotation of every mode) over one synthetic dual-polarisation 2 SPS capture that is already resident in HBM.  With N
-GPUs every rank processes its own independent channel (seed 1000 + rank, BASELINE.json config 4): weak scaling, no
-collective on the data path; torch.distributed (RCCL) is used only for the barriers, the max-over-ranks of the elapsed
-time and the sum of the symbol-error counters.
+One "step" = one pass of the hot path (Gram terms -> dual-mode tap training -> filter application -> blind phase search,
+unwrap and de-rotation of every mode) over one synthetic dual-polarisation 2 SPS capture that is already resident in HBM.
+With N GPUs every rank processes its own independent channel (seed 1000 + rank, BASELINE.json config 4): weak scaling, no
+collective on the data path; torch.distributed (RCCL) carries only the barriers, the max-over-ranks of the elapsed time,
+the sum of the symbol-error counters and the count of ranks.  `--gpus N` with N > 1 launches the N ranks itself (re-exec
+under torch.distributed.run, 127.0.0.1 rendezvous) unless it already runs inside such a launch.
+
+Trainer tiers.  The timed pipeline uses tier "b", the parallel-in-time solver of the equaliser recurrence
+(concurrently trained segments + waveform relaxation + linearised coarse correction, stopped by a device-side boundary
+defect below `tol`) - provided its own certificate holds in this very run: every stage reports `converged` and the symbol
+errors per mode are within +-3 of the exact sequential path (tier "a") run beside it on the same capture.  If either check
+fails, or with `--tier a`, the headline `value` is the exact path's.  Both numbers are always in the line (`tier_a`, `tier_b`).
 
 The JSON line carries, besides the driver's contract fields:
-  roofline      for the dominant kernel (the stage with the largest share of the step): algorithmic bytes per launch /
-                average launch duration measured with HIP events on the library stream inside the timed region
-  cpu_baseline  the oracle's reference-flag OpenMP build ("port" of the pythran loops) timed on a bounded sample of the
-                same workload on this box's host cores (rank 0, N = 1 only)
-  stages_ms, ser, parity_vs_cpu  supporting numbers
+  roofline      dominant kernel of the step (largest total kernel time): algorithmic bytes per launch / mean launch duration
+                from HIP events on the library stream inside the timed region; plus `pipeline`: 88 B per symbol period (fully
+                fused lower bound) x symbol periods / step time
+  cpu_baseline  the oracle's reference-flag OpenMP build ("port" of the pythran loops) on this box's host cores: the whole
+                capture with all threads (3 runs), a bounded sample with one thread, CPU model, H2D / D2H times
+  tier_a, tier_b, parity_vs_cpu, channel_bank (+ its own CPU leg), stages_ms, ser
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,8 +41,9 @@ if ROOT not in sys.path:
 
 # SURVEY.md §8d / BASELINE.md configs.  Step sizes / linewidth of c3 and ns: MRDE is phase sensitive and false-locks when the
 # CMA stage leaves a rotated constellation (its phase diffuses ~ mu^2 * N); mu = (2e-4, 2e-4) with a 100 Hz source
-# converges on both modes over 2^22 symbols (verified with the CPU oracle, seeds 1000-1001).  c3 is the 2^22-symbol variant of the north-star configuration (64-QAM, 41 taps,
-# CMA -> MRDE, 64-angle BPS) and the largest single-GPU configuration in BASELINE.json's `configs`.
+# converges on both modes over 2^22 symbols (verified with the CPU oracle, seeds 1000-1001).  c3 is the 2^22-symbol variant of
+# the north-star configuration (64-QAM, 41 taps, CMA -> MRDE, 64-angle BPS) and the largest single-GPU configuration in
+# BASELINE.json's `configs`.
 WORKLOADS = {
     # configs[0]: the reference's own CPU-runnable plumbing case (Scripts/cma_equaliser.py): a parity-test case, not a bench line
     "c1": dict(M=4, nsym=2 ** 16, nmodes=1, ntaps=11, methods=("cma",), mu=(1e-3,), niter=(1,), adaptive=(False,), A=None, Nbps=0,
@@ -48,8 +58,25 @@ WORKLOADS = {
                label="64-QAM 2-pol 2 SPS 10^7 sym, 41-tap dual-mode CMA->MRDE + 64-angle BPS (north star)"),
 }
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FUSED_BYTES_PER_SYM = 88   # read E once, write err1, err2, out, ph (complex64, 2 modes, 2 samples/symbol)
+SER_TOL_ERRORS = 3         # tier b counts as SER-equivalent when every mode is within this many symbol errors of tier a
 
 
+# ------------------------------------------------------------------------------------------------------------ launcher
+def self_launch(argv, gpus):
+    """`python bench.py --gpus N` outside a torchrun environment: start the N ranks (one per GPU) and relay their output."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------------------ workload
 def make_input(cfg, nsym, seed, host=False):
     """The capture of this rank: synthesised on the GPU (csrc/synth.hip, ~1 ms) and copied to the host once for the CPU legs;
     --host-synth uses the numpy generator instead (same impairments, frequency-domain filters, ~10 s at 2^22 symbols)."""
@@ -64,40 +91,67 @@ def make_input(cfg, nsym, seed, host=False):
                               linewidth=cfg["linewidth"], fb=20e9, beta=0.1, seed=seed, dtype=np.complex64)
 
 
-def make_receiver(cfg, sig, segments=0, prefix=0, prefix_mu=None):
+def make_receiver(cfg, sig, tier="a", pit=None):
     from qampy_amd.pipeline import ResidentReceiver
     return ResidentReceiver(sig.shape[0], sig.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"],
                             adaptive_stepsize=cfg["adaptive"], TrSyms=(None,) * len(cfg["methods"]), Mtestangles=cfg["A"],
-                            Nbps=cfg["Nbps"], dtype=np.complex64, alphabet=sig.coded_symbols, segments=segments, prefix=prefix,
-                            prefix_mu=prefix_mu)
+                            Nbps=cfg["Nbps"], dtype=np.complex64, alphabet=sig.coded_symbols, tier=tier, pit=pit)
+
+
+class DryReceiver:
+    """--dry-run: stands in for the ResidentReceiver where there is no GPU, so that the launcher, the rank bookkeeping and
+    the reductions of the N > 1 path can be exercised on CPU (tests/test_distributed.py).  Kernels are replaced by a sleep."""
+
+    def __init__(self, cfg, nsym, tier):
+        self.nstage, self.tier, self.nmodes = len(cfg["methods"]), tier, cfg.get("nmodes", 2)
+        self.Mtestangles = cfg["A"]
+        self.N = nsym
+
+    def run(self):
+        time.sleep(0.002)
+
+    def ser(self, *a, **k):
+        return [dict(errors=0, compared=self.N) for _ in range(self.nmodes)]
+
+
+def stage_list(rx):
+    names = ["gram"] + ["train%d:%s" % (s + 1, m) for s, m in enumerate(rx.methods)] + ["apply"] + (["bps_recover"] if rx.Mtestangles else [])
+    fns = [rx.build_gram] + [lambda s=s: rx.train(s) for s in range(rx.nstage)] + [rx.apply] + ([rx.recover] if rx.Mtestangles else [])
+    return names, fns
 
 
 def timed_steps(rx, steps, warmup, barrier_sync):
-    """W warm-up passes, then exactly K passes bracketed by barrier + device sync; HIP events between the stages."""
+    """W warm-up passes, then exactly K passes bracketed by barrier + device sync; HIP events between the stages.  Returns
+    (elapsed s, mean stage ms, per-step pass kernel ms of tier b)."""
     from qampy_amd import _lib
-    stage_fns = [rx.build_gram] + [lambda s=s: rx.train(s) for s in range(rx.nstage)] + [rx.apply] + ([rx.recover] if rx.Mtestangles else [])
+    names, fns = stage_list(rx)
     for _ in range(warmup):
         rx.run()
-    ev = [[_lib.Event() for _ in range(len(stage_fns) + 1)] for _ in range(steps)]
+    ev = [[_lib.Event() for _ in range(len(fns) + 1)] for _ in range(steps)]
+    pass_ms = [[] for _ in range(rx.nstage)]
+    acq_ms = [[] for _ in range(rx.nstage)]
     barrier_sync()
     t0 = time.perf_counter()
     for k in range(steps):
         rx.reset()
         ev[k][0].record()
-        for j, fn in enumerate(stage_fns):
+        for j, fn in enumerate(fns):
             fn()
             ev[k][j + 1].record()
+            if rx.tier == "b" and 1 <= j <= rx.nstage:
+                p, a = rx.pit_timing[j - 1]
+                pass_ms[j - 1].append(list(p))
+                acq_ms[j - 1].append(a)
     barrier_sync()
     elapsed = time.perf_counter() - t0
-    stage_ms = [float(np.mean([ev[k][j + 1].elapsed_ms(ev[k][j]) for k in range(steps)])) for j in range(len(stage_fns))]
-    return elapsed, stage_ms
+    stage_ms = [float(np.mean([ev[k][j + 1].elapsed_ms(ev[k][j]) for k in range(steps)])) for j in range(len(fns))]
+    return elapsed, stage_ms, pass_ms, acq_ms
 
 
 def channel_bank_run(cfg, sig, nch, steps, barrier_sync, trainer="iterative"):
-    """Informational: `nch` independent captures of the workload resident on ONE GPU, all stages for all channels per step.
-    One exact training chain is one workgroup, so channels side by side are how the exact recurrence fills the chip (WDM
-    receivers have them).  Every channel is an independent capture generated on the device (seed 2000 + c).  NOT the headline
-    `value` (BASELINE configs are single captures)."""
+    """Informational: `nch` independent captures of the workload resident on ONE GPU, all stages for all channels per step,
+    exact trainers (one workgroup per channel and mode).  Every channel is an independent capture generated on the device
+    (seed 2000 + c).  NOT the headline `value` (BASELINE configs are single captures)."""
     from qampy_amd import _lib
     from qampy_amd.core import ber_functions as ber
     from qampy_amd.pipeline import ChannelBank
@@ -105,7 +159,6 @@ def channel_bank_run(cfg, sig, nch, steps, barrier_sync, trainer="iterative"):
     bank = ChannelBank(nch, E.shape[0], E.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"],
                        adaptive_stepsize=cfg["adaptive"], TrSyms=(None,) * len(cfg["methods"]), Mtestangles=cfg["A"], Nbps=cfg["Nbps"],
                        dtype=np.complex64, alphabet=sig.coded_symbols, trainer=trainer)
-    # every channel is its own capture, synthesised in HBM (csrc/synth.hip) with the workload's impairments and its own seed
     from qampy_amd import synth
     nsym_c = E.shape[1] // 2
     idx_tx = []
@@ -139,7 +192,7 @@ def channel_bank_run(cfg, sig, nch, steps, barrier_sync, trainer="iterative"):
 
 
 def symbol_errors(out, sig, trim=2000):
-    """(errors, compared) per mode of a recovered signal; alignment on a prefix, decisions counted over the whole run."""
+    """(errors, compared) per mode of a recovered signal (host arrays); alignment on a prefix, decisions over the whole run."""
     from qampy_amd import synth
     from qampy_amd.core.equalisation import hip_equalisation as hk
     res = []
@@ -157,21 +210,35 @@ def symbol_errors(out, sig, trim=2000):
     return res
 
 
-def cpu_baseline(cfg, sig, sample_sym):
-    """Oracle (reference-flag OpenMP build) on a bounded prefix of the same capture; returns timing + results."""
+# ------------------------------------------------------------------------------------------------------------ CPU legs
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _omp_threads(n):
+    """Set the OpenMP team size of the already loaded oracle (libgomp), returns the previous maximum."""
+    import ctypes
+    g = ctypes.CDLL("libgomp.so.1")
+    prev = g.omp_get_max_threads()
+    g.omp_set_num_threads(int(n))
+    return prev
+
+
+def cpu_pipeline(cfg, E, coded_symbols):
+    """One pass of the hot path through the oracle (reference-flag OpenMP build) on host arrays; returns times + results."""
     from oracle import oracle
     from qampy_amd.core.equalisation import equalisation as host
-    try:
-        oracle.build(fast_native=True)       # -march=native for THIS host
-    except Exception as e:                   # fall back to the prebuilt library
-        print("cpu_baseline: native rebuild failed (%s), using the prebuilt oracle" % e, file=sys.stderr)
-    E = np.ascontiguousarray(np.asarray(sig)[:, :2 * sample_sym])
     ntaps = cfg["ntaps"]
-    w = host._init_taps(ntaps, E.shape[0], E.shape[0], np.complex64)
-    tr = host._cal_training_symbol_len(2, ntaps, E.shape[1])
     nm = E.shape[0]
-    syms = [host._reshape_symbols(sig.coded_symbols if m in host.DECISION_BASED else None, m, cfg["M"], np.complex64, nm)
-            for m in cfg["methods"]]
+    w = host._init_taps(ntaps, nm, nm, np.complex64)
+    tr = host._cal_training_symbol_len(2, ntaps, E.shape[1])
+    syms = [host._reshape_symbols(coded_symbols if m in host.DECISION_BASED else None, m, cfg["M"], np.complex64, nm) for m in cfg["methods"]]
     angles = np.linspace(-np.pi / 4, np.pi / 4, cfg["A"] or 1, endpoint=False, dtype=np.float32).reshape(1, -1)
     t0 = time.perf_counter()
     for s, m in enumerate(cfg["methods"]):
@@ -181,7 +248,7 @@ def cpu_baseline(cfg, sig, sample_sym):
     t2 = time.perf_counter()
     N = cfg["Nbps"]
     if cfg["A"]:
-        ph = np.array([oracle.select_angles(angles, oracle.bps(eq[m], angles, sig.coded_symbols, N, fast=True)) for m in range(nm)])
+        ph = np.array([oracle.select_angles(angles, oracle.bps(eq[m], angles, coded_symbols, N, fast=True)) for m in range(nm)])
         ph[:, N:-N] = np.unwrap(ph[:, N:-N] * 4) / 4
         out = eq * np.exp(1j * ph)
     else:
@@ -190,6 +257,89 @@ def cpu_baseline(cfg, sig, sample_sym):
     return dict(seconds=t3 - t0, train_s=t1 - t0, apply_s=t2 - t1, bps_s=t3 - t2, wxy=w, out=out.astype(np.complex64))
 
 
+def cpu_baseline(cfg, sig, nsym, sample_1t, runs=3):
+    """the whole capture with all host threads (`runs` runs -> spread) and a bounded sample with ONE thread."""
+    from oracle import oracle
+    try:
+        oracle.build(fast_native=True)       # -march=native for THIS host
+    except Exception as e:                   # fall back to the prebuilt library
+        print("cpu_baseline: native rebuild failed (%s), using the prebuilt oracle" % e, file=sys.stderr)
+    E = np.ascontiguousarray(np.asarray(sig)[:, :2 * nsym])
+    ncores = os.cpu_count()
+    res = [cpu_pipeline(cfg, E, sig.coded_symbols) for _ in range(runs)]
+    secs = [r["seconds"] for r in res]
+    best = res[int(np.argmin(secs))]
+    prev = _omp_threads(1)
+    try:
+        one = cpu_pipeline(cfg, np.ascontiguousarray(E[:, :2 * sample_1t]), sig.coded_symbols)
+    finally:
+        _omp_threads(prev)
+    return dict(all=dict(value=nsym / min(secs) / 1e6, runs_s=[round(s, 3) for s in secs], cores=ncores,
+                         stages_s=dict(train=round(best["train_s"], 3), apply=round(best["apply_s"], 3), bps=round(best["bps_s"], 3))),
+                one=dict(value=sample_1t / one["seconds"] / 1e6, sample=sample_1t, seconds=round(one["seconds"], 3),
+                         stages_s=dict(train=round(one["train_s"], 3), apply=round(one["apply_s"], 3), bps=round(one["bps_s"], 3))),
+                result=best)
+
+
+CPU_BANK_WORKER = r"""
+import sys, time, json, numpy as np
+sys.path.insert(0, %(root)r)
+import bench
+cfg = dict(bench.WORKLOADS[%(workload)r])
+d = np.load(%(path)r)
+E, coded = d["E"], d["coded"]
+bench.cpu_pipeline(cfg, np.ascontiguousarray(E[:, :8192]), coded)            # load + warm the library
+t0 = time.perf_counter()
+for _ in range(%(reps)d):
+    bench.cpu_pipeline(cfg, E, coded)
+print(json.dumps(dict(seconds=time.perf_counter() - t0)))
+"""
+
+
+def cpu_channel_bank(cfg, workload, sig, sample, workers, reps=1):
+    """CPU counterpart of the channel bank: `workers` independent captures processed concurrently, one single-threaded
+    oracle pipeline per capture (one process each, OMP_NUM_THREADS=1) - how a many-core host would run a WDM bank."""
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), "qampy_cpu_bank_%d.npz" % os.getpid())
+    np.savez(path, E=np.ascontiguousarray(np.asarray(sig)[:, :2 * sample]), coded=np.asarray(sig.coded_symbols))
+    code = CPU_BANK_WORKER % dict(root=ROOT, workload=workload, path=path, reps=reps)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True) for _ in range(workers)]
+    secs, last_err = [], ""
+    for p in procs:
+        out, err = p.communicate(timeout=600)
+        try:
+            secs.append(json.loads(out.strip().splitlines()[-1])["seconds"])
+        except (ValueError, IndexError):
+            last_err = err[-300:]
+    wall = time.perf_counter() - t0
+    try:
+        os.remove(path)
+    except OSError:
+        pass
+    if not secs:
+        return dict(error="no worker finished: " + last_err)
+    return dict(value=round(len(secs) * sample * reps / max(secs) / 1e6, 3), unit="MSym/s", workers=len(secs), threads_per_worker=1, sample=sample,
+                reps=reps, slowest_worker_s=round(max(secs), 2), wall_s_incl_startup=round(wall, 1),
+                note="aggregate of %d concurrent single-threaded oracle pipelines, each on its own copy of a %d-symbol capture" % (len(secs), sample))
+
+
+def transfer_times(sig, rx):
+    """Host <-> HBM copies the host-array entry points pay per capture (not part of `value`)."""
+    from qampy_amd import _lib
+    E = np.ascontiguousarray(np.asarray(sig))
+    _lib.sync()
+    t0 = time.perf_counter(); rx.E.set(E); _lib.sync(); h2d = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    o = (rx.out if rx.Mtestangles else rx.eq).to_host(); w = rx.wxy.to_host(); e = [x.to_host() for x in rx.err]
+    d2h = time.perf_counter() - t0
+    nb = o.nbytes + w.nbytes + sum(x.nbytes for x in e)
+    return dict(h2d_ms=round(h2d * 1e3, 2), h2d_GBps=round(E.nbytes / h2d / 1e9, 1), d2h_ms=round(d2h * 1e3, 2), d2h_GBps=round(nb / d2h / 1e9, 1),
+                bytes_in=int(E.nbytes), bytes_out=int(nb), note="pageable numpy arrays through hipMemcpy; outputs = recovered signal + taps + both error traces")
+
+
+# ------------------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,67 +347,102 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--nsym", type=int, default=None, help="override the number of symbol periods per capture")
+    ap.add_argument("--tier", default="b", choices=["a", "b"],
+                    help="trainer of the timed pipeline: b = parallel-in-time solver of the recurrence, used for the headline only if it certifies "
+                         "itself in this run (converged + SER within +-3 errors of the exact path); a = the exact sequential recurrence")
+    ap.add_argument("--tol", type=float, default=0., help="boundary-defect tolerance of tier b (0 = library default 0.02)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 20, help="symbol periods of the capture the CPU baseline processes")
-    ap.add_argument("--train-mode", default="exact", choices=["exact", "segmented"],
-                    help="exact = the reference's sequential recurrence (default, parity tier A); segmented = opt-in "
-                         "segment-parallel continuation (tier B, SER-equivalent, not tap-identical)")
-    ap.add_argument("--segments", type=int, default=1024)
-    ap.add_argument("--prefix", type=int, default=1 << 16, help="sequential convergence prefix (steps) of the segmented mode")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="symbol periods the all-thread CPU baseline processes (default: the whole capture)")
+    ap.add_argument("--cpu-sample-1t", type=int, default=1 << 19, help="symbol periods of the one-thread CPU run")
+    ap.add_argument("--exact-steps", type=int, default=2, help="timed passes of the exact path beside tier b (N = 1)")
     ap.add_argument("--host-synth", action="store_true", help="generate the capture with the host (numpy) generator instead of on the GPU")
-    ap.add_argument("--bank-trainer", default="iterative", choices=["auto", "iterative"],
-                    help="trainer forms of the channel bank: auto = as for the single capture, iterative = block-iterative for every stage "
-                         "(half the Gram table: more channels fit)")
-    ap.add_argument("--bank", type=int, default=128, help="channels of the informational channel-bank run at N=1 (0 = skip): that many "
-                    "independent captures of the same workload resident on the GPU and processed together")
-    ap.add_argument("--tier-b", action="store_true", help="also time the opt-in segmented trainer on the same capture (informational)")
+    ap.add_argument("--bank-trainer", default="iterative", choices=["auto", "iterative"])
+    ap.add_argument("--bank", type=int, default=128, help="channels of the informational channel-bank run at N=1 (0 = skip)")
+    ap.add_argument("--cpu-bank-workers", type=int, default=-1, help="concurrent single-threaded CPU pipelines of the bank's CPU leg (-1: min(cores, 128), 0: skip)")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: kernels replaced by a sleep, gloo backend - exercises launcher + reductions")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     from qampy_amd import sharding
     rank, local_rank, world = sharding.rank_info()
+    if world != args.gpus:
+        if rank == 0:
+            print(json.dumps(dict(error="launched with WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))))
+        sys.exit(2)
     cfg = dict(WORKLOADS[args.workload])
     nsym = args.nsym or cfg["nsym"]
 
     import torch                                     # plumbing only: barriers / reductions / device sync
-    from qampy_amd import _lib
-    ndev = max(_lib.device_count(), 1)
-    dev = local_rank % ndev                          # a launcher may expose a single device per rank
     dist = None
+    backend = "gloo" if args.dry_run else os.environ.get("QAMPY_BENCH_BACKEND", "nccl")
+    if args.dry_run:
+        dev = 0
+        _lib = None
+    else:
+        from qampy_amd import _lib
+        ndev = max(_lib.device_count(), 1)
+        dev = local_rank % ndev                      # a launcher may expose a single device per rank
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(dev)
-        # RCCL ("nccl") on the GPUs; QAMPY_BENCH_BACKEND=gloo lets several ranks share ONE GPU (checking the multi-rank flow
-        # on a single-GPU box), the reductions then go through host tensors
-        backend = os.environ.get("QAMPY_BENCH_BACKEND", "nccl")
         if backend == "nccl":
+            torch.cuda.set_device(dev)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend=backend)
-    red_dev = "cpu" if (world > 1 and os.environ.get("QAMPY_BENCH_BACKEND", "nccl") != "nccl") else "cuda"
-    _lib.init(dev)
+    red_dev = "cuda" if (backend == "nccl" and not args.dry_run) else "cpu"
+    if not args.dry_run:
+        _lib.init(dev)
+    ranks_seen = int(round(sharding.reduce_sum_counts([[1.0]], dist, device=red_dev)[0, 0]))
 
     def barrier_sync():
-        _lib.sync()
-        torch.cuda.synchronize()
+        if not args.dry_run:
+            _lib.sync()
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
+    pit = dict(tol=args.tol) if args.tol > 0 else {}
+    if args.dry_run:
+        rx = DryReceiver(cfg, nsym, args.tier)
+        for _ in range(args.warmup):
+            rx.run()
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rx.run()
+        barrier_sync()
+        elapsed = sharding.reduce_max_time(time.perf_counter() - t0, dist, device=red_dev)
+        counts_all = sharding.reduce_sum_counts([[d["errors"], d["compared"]] for d in rx.ser()], dist, device=red_dev)
+        if rank == 0:
+            print(json.dumps(dict(metric="equalised MSym/s (2-pol, 2 SPS)", value=round(sharding.aggregate_throughput(nsym, world, args.steps, elapsed), 4),
+                                  unit="MSym/s", n_gpus=world, ranks_seen=ranks_seen, steps=args.steps, warmup=args.warmup,
+                                  ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                                  data="synthetic", dry_run=True, config=dict(workload=cfg["label"], key=args.workload, channels=world),
+                                  ser=dict(errors_all=int(counts_all[:, 0].sum()), symbols_all=int(counts_all[:, 1].sum())))))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # ---- independent channel per rank (seed 1000 + channel), synthesised on the GPU (or the host), then made resident
     sig = make_input(cfg, nsym, sharding.channel_seed(rank), host=args.host_synth)
-    seg = dict(segments=args.segments, prefix=args.prefix) if args.train_mode == "segmented" else {}
-    rx = make_receiver(cfg, sig, **seg)
+    rx = make_receiver(cfg, sig, tier=args.tier, pit=pit)
     rx.load(sig)
-    stage_names = ["gram"] + ["train%d:%s" % (s + 1, m) for s, m in enumerate(cfg["methods"])] + ["apply"] + (["bps_recover"] if cfg["A"] else [])
+    stage_names, _ = stage_list(rx)
 
     # ---- timed region: exactly K steps, HIP events between the stages (same stream as the kernels)
-    elapsed, stage_ms = timed_steps(rx, args.steps, args.warmup, barrier_sync)
+    elapsed, stage_ms, pass_ms, acq_ms = timed_steps(rx, args.steps, args.warmup, barrier_sync)
     elapsed = sharding.reduce_max_time(elapsed, dist, device=red_dev)
+    reports = rx.pit_reports()
+    certified_local = 1.0 if (args.tier == "a" or all(r["converged"] for r in reports)) else 0.0
+    certified_all = int(round(sharding.reduce_sum_counts([[certified_local]], dist, device=red_dev)[0, 0])) == world
 
     # ---- results of the last step: SER against the transmitted symbols
     # (on-device harness: alignment search + decisions + count in HBM, qh_ser_*_dev; nothing but 7 integers per row moves)
     ser_rows = rx.ser(sig.symbols, maxlag=256, window=8192, trim=2000)
     errs = [(d["errors"], d["compared"]) for d in ser_rows]
-    res = dict(wxy=rx.wxy.to_host())
     counts_all = sharding.reduce_sum_counts([[e, n] for e, n in errs], dist, device=red_dev)
 
     if rank != 0:
@@ -266,96 +451,195 @@ def main():
             dist.destroy_process_group()
         return
 
-    value = sharding.aggregate_throughput(nsym, world, args.steps, elapsed)
-    # ---- roofline of the dominant kernel
+    value_timed = sharding.aggregate_throughput(nsym, world, args.steps, elapsed)
+    ms_timed = elapsed / args.steps * 1e3
+    nsel = rx.modes.size
+    # ---- algorithmic bytes per launch of every stage / kernel (SURVEY.md 8d general formula)
     bps_b = rx.bytes_per_symbol()
-    stage_bytes = [rx.TrSyms[0] * (8 * 2 * rx.nmodes + 64 * 16)]     # gram: read the capture once, write 1 KiB per step
-    for s in range(rx.nstage):
-        stage_bytes.append(rx.Niter[s] * rx.TrSyms[s] * 8 * (rx.nmodes * 2 + rx.modes.size))
+    train_bytes = [rx.TrSyms[s] * 8 * (rx.nmodes * 2 + nsel) for s in range(rx.nstage)]          # one sweep = one relaxation pass
+    stage_bytes = [rx.TrSyms[0] * (8 * 2 * rx.nmodes + 64 * 16)] + [rx.Niter[s] * train_bytes[s] for s in range(rx.nstage)]
     stage_bytes += [rx.N * bps_b["apply"]] + ([rx.N * bps_b["bps"]] if cfg["A"] else [])
-    dom = int(np.argmax(stage_ms))
-    achieved = stage_bytes[dom] / (stage_ms[dom] * 1e-3) / 1e9
-    # HBM bytes per launch of the dominant kernel from the committed PMC pass of the same workload (scripts/gpu_pmc.sh);
-    # counters need their own rocprofv3 run, so they cannot be collected inside this process
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.workload)))
-        if args.train_mode == "exact" and args.nsym is None and 1 <= dom <= rx.nstage:
-            mid = _lib.METHOD_ID[cfg["methods"][dom - 1]]
-            kname = [k for k in pmc["kernels"] if k.startswith("qh::train_la_kernel<float, %d," % mid)
-                     or k.startswith("qh::train_bi_kernel<float, %d," % mid)]
-            traffic = pmc["kernels"][kname[0]]["hbm_bytes"] if kname else None
-    except (OSError, KeyError, ValueError, IndexError):
-        traffic = None
-    roofline = dict(bound="hbm", kernel=stage_names[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, algorithmic_bytes=int(stage_bytes[dom]),
-                    note=("exact sequential LMS recurrence: dependent-issue / barrier-latency bound, one workgroup per output mode (DESIGN.md 3.1)"
-                          if args.train_mode == "exact" and 1 <= dom <= rx.nstage else "see DESIGN.md"))
 
-    out = dict(metric="equalised MSym/s (2-pol, 2 SPS)", value=round(value, 4), unit="MSym/s", n_gpus=world, steps=args.steps,
-               warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak",
-               vs_baseline=None, dtype="f32", data="synthetic",
+    out = dict(metric="equalised MSym/s (2-pol, 2 SPS)", value=round(value_timed, 4), unit="MSym/s", n_gpus=world, ranks_seen=ranks_seen,
+               steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_timed, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f32", data="synthetic",
                config=dict(workload=cfg["label"], key=args.workload, nsym_per_channel=nsym, channels=world, ntaps=cfg["ntaps"],
                            methods=list(cfg["methods"]), niter=list(cfg["niter"]), test_angles=cfg["A"], bps_N=cfg["Nbps"],
-                           complex_dtype="complex64", parallelism="1 independent channel per GPU", train_mode=args.train_mode,
-                           **({"segments": args.segments, "prefix": args.prefix} if args.train_mode == "segmented" else {})),
-               roofline=roofline,
+                           complex_dtype="complex64", parallelism="1 independent channel per GPU", train_mode=None),
                stages_ms={n: round(t, 3) for n, t in zip(stage_names, stage_ms)},
-               stages_GBps={n: round(b / (t * 1e-3) / 1e9, 2) for n, b, t in zip(stage_names, stage_bytes, stage_ms)},
-               # what actually bounds the exact trainers: shader cycles per recurrence step of the critical workgroup (2.4 GHz
-               # clock; a lone wavefront issues one instruction per ~8.3 cycles)
-               train_cycles_per_step={stage_names[1 + s2]: round(stage_ms[1 + s2] * 1e-3 * 2.4e9 / (rx.TrSyms[s2] * rx.Niter[s2]), 1)
-                                      for s2 in range(rx.nstage)},
-               ser=dict(per_mode_rank0=[e / max(n, 1) for e, n in errs], errors_all=int(counts_all[:, 0].sum()),
+               ser=dict(per_mode_rank0=[e / max(n, 1) for e, n in errs], errors_rank0=[e for e, _ in errs], errors_all=int(counts_all[:, 0].sum()),
                         symbols_all=int(counts_all[:, 1].sum())),
                device=_lib.device_name())
 
+    # ---- tier blocks
+    tier_b = None
+    if args.tier == "b":
+        kern = []
+        for s in range(rx.nstage):
+            flat = [p for step in pass_ms[s] for p in step]
+            kern.append(dict(stage=stage_names[1 + s], kernel="relaxation pass (all segments, one launch)", launches_per_step=len(flat) / max(len(pass_ms[s]), 1),
+                             mean_ms=float(np.mean(flat)) if flat else 0., acquisition_ms=float(np.mean(acq_ms[s])) if acq_ms[s] else 0.))
+        tier_b = dict(method="parallel in time: %s; segments trained concurrently by the exact kernels, waveform relaxation + linearised "
+                             "coarse correction until every boundary defect < tol" % " -> ".join(cfg["methods"]),
+                      value=round(value_timed, 4), unit="MSym/s", ms_per_step=round(ms_timed, 3),
+                      stages=[dict(stage=stage_names[1 + s], S=r["segments"], seg_len=r["seg_len"], P=r["passes"], converged=r["converged"], tol=r["tol"],
+                                   defect=[float("%.3g" % d) for d in r["defect"]], prefix=r["acquisition"]["steps"],
+                                   acquisition=dict(steps=r["acquisition"]["steps"], mu=r["acquisition"]["mu"], diverged=r["acquisition"]["diverged"]),
+                                   coarse_correction=r["correction"], gain=round(r["gain"], 4),
+                                   pass_ms=round(kern[s]["mean_ms"], 3), acquisition_ms=round(kern[s]["acquisition_ms"], 3))
+                              for s, r in enumerate(reports)],
+                      errors=[e for e, _ in errs], certified=bool(certified_all),
+                      roofline=dict(bound="hbm", achieved=round(FUSED_BYTES_PER_SYM * nsym / (ms_timed * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                    frac=round(FUSED_BYTES_PER_SYM * nsym / (ms_timed * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                    note="whole step against the fully fused lower bound of 88 B per symbol period"))
+        out["tier_b"] = tier_b
+
+    tier_a = None
+    res_a = None
+    if world == 1 and (args.tier == "a" or args.exact_steps > 0):
+        if args.tier == "a":
+            rxa, el_a, ms_a = rx, elapsed, stage_ms
+            steps_a = args.steps
+        else:
+            rxa = make_receiver(cfg, sig, tier="a")
+            rxa.load(sig)
+            steps_a = args.exact_steps
+            el_a, ms_a, _, _ = timed_steps(rxa, steps_a, 1, barrier_sync)
+        ser_a = rxa.ser(sig.symbols, maxlag=256, window=8192, trim=2000)
+        errs_a = [d["errors"] for d in ser_a]
+        names_a, _ = stage_list(rxa)
+        tier_a = dict(method="exact sequential recurrence (reference order of evaluation)", value=round(nsym * steps_a / el_a / 1e6, 4), unit="MSym/s",
+                      steps=steps_a, ms_per_step=round(el_a / steps_a * 1e3, 3), stages_ms={n: round(t, 3) for n, t in zip(names_a, ms_a)},
+                      errors=errs_a,
+                      train_cycles_per_step={names_a[1 + s2]: round(ms_a[1 + s2] * 1e-3 * 2.4e9 / (rxa.TrSyms[s2] * rxa.Niter[s2]), 1) for s2 in range(rxa.nstage)})
+        out["tier_a"] = tier_a
+        if args.tier == "b":
+            wa, wb = rxa.wxy.to_host(), rx.wxy.to_host()
+            ea = (rxa.out if cfg["A"] else rxa.eq).to_host()
+            eb = (rx.out if cfg["A"] else rx.eq).to_host()
+            dev_t, dev_o, dev_omax = [], [], []
+            for m in range(wa.shape[0]):                       # modulo a common quarter turn per output mode (symmetry of the error functions)
+                g = 1j ** int(np.rint(np.angle(np.vdot(wb[m].ravel(), wa[m].ravel())) / (np.pi / 2)))
+                dev_t.append(float(np.max(np.abs(wa[m] - g * wb[m]))))
+                dd = np.abs(ea[m] - g * eb[m])
+                dev_o.append(float(np.sqrt(np.mean(dd ** 2))))
+                dev_omax.append(float(dd.max()))
+            ser_ok = all(abs(a - b) <= SER_TOL_ERRORS for a, b in zip(errs_a, [e for e, _ in errs]))
+            tier_b.update(errors_exact=errs_a, ser_equivalent=bool(ser_ok), max_abs_tap_dev_vs_exact=dev_t, out_rms_dev_vs_exact=dev_o,
+                          out_max_dev_vs_exact=dev_omax, speedup_vs_exact=round(tier_b["value"] / tier_a["value"], 2))
+            tier_b["certified"] = bool(certified_all and ser_ok)
+            res_a = dict(value=tier_a["value"], ms=el_a / steps_a * 1e3, stage_ms=ms_a, names=names_a)
+
+    # ---- headline: tier b only with its certificate; else the exact path
+    use_b = args.tier == "b" and tier_b is not None and tier_b["certified"]
+    if args.tier == "b" and not use_b and res_a is not None:
+        out["value"] = round(res_a["value"], 4)
+        out["ms_per_step"] = round(res_a["ms"], 3)
+        out["stages_ms"] = {n: round(t, 3) for n, t in zip(res_a["names"], res_a["stage_ms"])}
+        out["steps"] = args.exact_steps
+        out["note"] = "tier b did not certify itself in this run: headline = exact path"
+    out["config"]["train_mode"] = ("parallel-in-time (tier b), certified in-run: converged + SER within +-%d errors of the exact path" % SER_TOL_ERRORS) if use_b \
+        else "exact sequential recurrence (tier a)"
+    head_ms = stage_ms if (use_b or args.tier == "a") else res_a["stage_ms"]
+
+    # ---- roofline of the dominant kernel (largest total kernel time per step)
+    if use_b:
+        cands = [(tier_b["stages"][s]["pass_ms"] * tier_b["stages"][s]["P"], "train%d:%s relaxation pass" % (s + 1, cfg["methods"][s]),
+                  train_bytes[s], tier_b["stages"][s]["pass_ms"]) for s in range(rx.nstage)]
+        cands.append((stage_ms[0], "gram", stage_bytes[0], stage_ms[0]))
+        if cfg["A"]:
+            cands.append((stage_ms[-1], "bps_recover", stage_bytes[-1], stage_ms[-1]))
+        tot, kname, kbytes, kms = max(cands)
+        roofline = dict(bound="hbm", kernel=kname, achieved=round(kbytes / (kms * 1e-3) / 1e9, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), traffic=None, algorithmic_bytes=int(kbytes), launch_ms=round(kms, 3),
+                        note="one launch trains all segments of the sweep; algorithmic bytes = one sweep (read E, write err); the look-ahead form "
+                             "additionally streams the Gram table (1 KiB per step) - see profiles/ for the PMC traffic",
+                        pipeline=tier_b["roofline"])
+    else:
+        dom = int(np.argmax(head_ms))
+        achieved = stage_bytes[dom] / (head_ms[dom] * 1e-3) / 1e9
+        roofline = dict(bound="valu-issue" if 1 <= dom <= rx.nstage else "hbm", kernel=stage_names[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None, algorithmic_bytes=int(stage_bytes[dom]),
+                        note="exact sequential LMS recurrence: dependent-issue bound, one workgroup per output mode (DESIGN.md 3.1); HBM figure for reference")
+    # measured HBM traffic of the dominant kernel: from the PMC pass of the same workload IF it was taken at this commit
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)))
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+        key = roofline["kernel"]
+        if pmc.get("kernels_by_stage", {}).get(key) and (not head or pmc.get("kernel_sources_sha") == kernel_sources_sha()):
+            roofline["traffic"] = pmc["kernels_by_stage"][key]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        pass
+    out["roofline"] = roofline
+
     if world == 1 and not args.no_cpu_baseline:
-        sample = min(nsym, args.cpu_sample)
-        cb = cpu_baseline(cfg, sig, sample)
-        # GPU on the identical sample -> SER / tap parity against the CPU path
-        rx2 = make_receiver(cfg, sig[:, :2 * sample])
-        rx2.load(np.asarray(sig)[:, :2 * sample])
-        rx2.run()
-        r2 = rx2.fetch()
+        sample = min(nsym, args.cpu_sample or nsym)
+        cb = cpu_baseline(cfg, sig, sample, min(sample, args.cpu_sample_1t))
+        r_cpu = cb["result"]
         sig_s = sig.recreate_from_np_array(np.asarray(sig)[:, :2 * sample])
         sig_s._symbols = sig.symbols[:, :sample]
-        e_gpu = symbol_errors(r2["out"] if cfg["A"] else r2["eq"], sig_s)
-        e_cpu = symbol_errors(cb["out"], sig_s)
-        out["cpu_baseline"] = dict(value=round(sample / cb["seconds"] / 1e6, 4), unit="MSym/s", cores=os.cpu_count(), kind="port",
-                                   sample="first %d symbol periods of the same capture (all stages); oracle built with the "
-                                          "reference's flags + OpenMP placement" % sample,
-                                   stages_s=dict(train=round(cb["train_s"], 3), apply=round(cb["apply_s"], 3), bps=round(cb["bps_s"], 3)))
-        out["parity_vs_cpu"] = dict(sample=sample, ser_gpu=[e / n for e, n in e_gpu], ser_cpu=[e / n for e, n in e_cpu],
-                                    errors_gpu=[e for e, _ in e_gpu], errors_cpu=[e for e, _ in e_cpu],
-                                    max_abs_tap_diff=float(np.max(np.abs(r2["wxy"] - cb["wxy"]))))
-        out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 2)
+        e_cpu = symbol_errors(r_cpu["out"], sig_s)
+        out["cpu_baseline"] = dict(value=round(cb["all"]["value"], 4), unit="MSym/s", cores=cb["all"]["cores"], kind="port",
+                                   sample="%s symbol periods of the same capture, all stages, %d OpenMP threads (placement as in the reference: "
+                                          "modes-parallel train, collapse(2) apply, L-parallel BPS distances)" % ("all %d" % sample if sample == nsym else "first %d" % sample, cb["all"]["cores"]),
+                                   runs_s=cb["all"]["runs_s"], stages_s=cb["all"]["stages_s"], cpu_model=cpu_model(),
+                                   one_thread=dict(value=round(cb["one"]["value"], 4), sample=cb["one"]["sample"], seconds=cb["one"]["seconds"], stages_s=cb["one"]["stages_s"]),
+                                   transfers=transfer_times(sig, rx))
+        # GPU vs CPU on the identical sample: SER / taps
+        if sample == nsym:
+            e_gpu = errs
+            w_gpu = rx.wxy.to_host()
+            e_gpu_a = [(e, None) for e in tier_a["errors"]] if tier_a else None
+        else:
+            rx2 = make_receiver(cfg, sig_s, tier=args.tier, pit=pit)
+            rx2.load(np.asarray(sig)[:, :2 * sample])
+            rx2.run()
+            r2 = rx2.fetch()
+            e_gpu = symbol_errors(r2["out"] if cfg["A"] else r2["eq"], sig_s)
+            w_gpu = r2["wxy"]
+            e_gpu_a = None
+        tapd = []
+        for m in range(w_gpu.shape[0]):
+            g = 1j ** int(np.rint(np.angle(np.vdot(w_gpu[m].ravel(), r_cpu["wxy"][m].ravel())) / (np.pi / 2)))
+            tapd.append(float(np.max(np.abs(r_cpu["wxy"][m] - g * w_gpu[m]))))
+        out["parity_vs_cpu"] = dict(sample=sample, errors_gpu=[e for e, _ in e_gpu], errors_cpu=[e for e, _ in e_cpu],
+                                    errors_gpu_exact=[e for e, _ in e_gpu_a] if e_gpu_a else None,
+                                    ser_gpu=[e / max(n, 1) for e, n in e_gpu] if sample != nsym else out["ser"]["per_mode_rank0"],
+                                    ser_cpu=[e / n for e, n in e_cpu], max_abs_tap_diff=tapd)
+        out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
+        if tier_a:
+            tier_a["speedup_vs_cpu"] = round(tier_a["value"] / out["cpu_baseline"]["value"], 2)
+        if tier_b:
+            tier_b["speedup_vs_cpu"] = round(tier_b["value"] / out["cpu_baseline"]["value"], 2)
 
-    if world == 1 and args.train_mode == "exact" and args.bank > 1:
+    if world == 1 and args.bank > 1:
+        del rx
         try:
             out["channel_bank"] = channel_bank_run(cfg, sig, args.bank, max(1, min(args.steps, 2)), barrier_sync, args.bank_trainer)
+            _lib.call("qh_release_scratch")
+            workers = min(os.cpu_count() or 1, 128) if args.cpu_bank_workers < 0 else args.cpu_bank_workers
+            if workers > 0 and not args.no_cpu_baseline:
+                out["channel_bank"]["cpu_baseline"] = cpu_channel_bank(cfg, args.workload, sig, min(nsym, 1 << 17), workers)
+                if "value" in out["channel_bank"]["cpu_baseline"]:
+                    out["channel_bank"]["speedup_vs_cpu_bank"] = round(out["channel_bank"]["value"] / out["channel_bank"]["cpu_baseline"]["value"], 2)
         except Exception as e:                    # informational only: never take the headline line down with it
             out["channel_bank"] = dict(channels=args.bank, error="%s: %s" % (type(e).__name__, e))
 
-    if world == 1 and args.train_mode == "exact" and args.tier_b:
-        # informational: the opt-in segment-parallel training on the same capture (NOT the headline `value`)
-        rxb = make_receiver(cfg, sig, segments=args.segments, prefix=args.prefix)
-        rxb.load(sig)
-        el_b, ms_b = timed_steps(rxb, args.steps, 1, barrier_sync)
-        rb = rxb.fetch()
-        e_b = symbol_errors(rb["out"], sig)
-        out["tier_b_segmented"] = dict(value=round(nsym * args.steps / el_b / 1e6, 3), unit="MSym/s", segments=args.segments,
-                                       prefix=args.prefix, stages_ms={n: round(t, 3) for n, t in zip(stage_names, ms_b)},
-                                       ser=[e / max(n, 1) for e, n in e_b], errors=[e for e, _ in e_b],
-                                       max_abs_tap_diff_vs_exact=float(np.max(np.abs(rb["wxy"] - res["wxy"]))),
-                                       note="opt-in; same per-symbol work, different dependency structure; only meaningful when the "
-                                            "taps converge within the sequential prefix (DESIGN.md tiers)")
-        if "cpu_baseline" in out:
-            out["tier_b_segmented"]["speedup_vs_cpu"] = round(out["tier_b_segmented"]["value"] / out["cpu_baseline"]["value"], 2)
     print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_sources_sha():
+    """Fingerprint of the kernel sources a PMC profile belongs to (profiles/pmc_traffic_*.json carry it)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "qampy_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 if __name__ == "__main__":

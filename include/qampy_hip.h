@@ -115,18 +115,6 @@ int qh_train_equaliser_c128_gram_dev(const void *E, int nmodes, int64_t L, int64
                                      void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
                                      int64_t nsy, int method, void *err, int zero_err, const void *gram);
 
-/* Segment-parallel continuation ("tier B", NOT the reference's semantics - DESIGN.md §tiers): the first `prefix` steps
- * are trained sequentially (with step size `prefix_mu` if it is > 0: "gear shifting" while the taps converge), then each
- * sweep is cut into `nseg` contiguous segments that are trained concurrently, every segment starting from the taps the
- * previous phase ended with; err is complete, the returned taps are those of the last segment.  Only meaningful when the
- * taps have converged by the end of the prefix.  Opt-in, never used by the drop-in entry points above. */
-int qh_train_equaliser_c64_seg_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
-                                   void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
-                                   int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix, double prefix_mu);
-int qh_train_equaliser_c128_seg_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev,
-                                    void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
-                                    int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix, double prefix_mu);
-
 /* Batch of independent equaliser runs on `nwin` windows E[:, win_start[v] : win_start[v] + win_len] of one capture, all from
  * the same initial taps wx0 and step size mu - what the frame synchronisation of the pilot receiver does in a Python loop
  * (qampy/core/pilotbased_receiver.py:395-400).  Results are those of nwin separate qh_train_equaliser_* calls; the windows
@@ -203,20 +191,69 @@ int qh_count_errors_dev(const int32_t *idx_rx, const int32_t *idx_tx, int64_t n,
  * reference's results up to the order of floating-point additions; a form that cannot take a call falls through. */
 int qh_set_trainer(int form);
 
-/* ---- parallel-in-time training (opt-in, NOT the reference's order of evaluation) ---------------------
- * Waveform relaxation over `nseg` contiguous segments of every sweep: `npass` passes, each training all segments
- * concurrently with the exact kernels, segment s starting from the taps segment s-1 ended with in the previous pass.
- * The fixed point is the sequential recurrence (reached exactly after nseg passes); 2-3 passes reproduce outputs, error
- * trace and decisions, tap components in the null space of the input covariance lag behind.  Fixed step,
- * blind and decision-directed methods.  pass_change: NULL or `npass` doubles on the HOST receiving, per pass, the largest
- * change of any segment's end taps against the previous pass (entry 0 = -1); asking for it synchronises every pass.
- * prefix: steps of the first sweep trained sequentially before the segments start (converged, phase-locked taps). */
+/* ---- parallel-in-time training ("tier B": opt-in, NOT the reference's order of evaluation) -----------
+ * The sweep of TrSyms steps is cut into S contiguous segments that are trained CONCURRENTLY with the exact kernels
+ * (segments = the channels of a batch that happen to be adjacent in one capture) and made consistent by waveform
+ * relaxation: in pass p segment s starts from the taps segment s-1 ended with in pass p-1 (segment 0 always from the start
+ * taps).  The map is triangular in s, its only fixed point is the sequential recurrence, reached exactly after S passes;
+ * in practice the LMS recursion forgets its start within a few 1/(mu lambda) steps and the passes stop as soon as the
+ * boundary DEFECT - the relative rms difference, on a probe window of the capture, between the outputs of the taps a
+ * segment started from and the taps its left neighbour ended with, modulo the symmetry of the error function (common
+ * phase for cma / rde, quarter turns for the square-grid functions) - is below `tol` for every boundary.  Everything is
+ * decided on the device (skip flags): the call only enqueues, nothing synchronises.
+ *   acquire != 0 (cold start, e.g. centre-spike taps): a sequential "acquisition" first trains a prefix of the capture with
+ *     a gear-shifted step size mu_acq = clamp(gear * mu, mu, acq_bound / (nmodes ntaps <|x|^2>)) in chunks until the mean
+ *     squared error stops improving (or acq_max steps); the sweep proper then runs from the acquired taps.  The result
+ *     is therefore the recurrence WARM-STARTED from the acquired taps, not the trajectory from the initial taps.
+ *   phase_seed: for the phase-sensitive functions (mcma, mrde, sbd, mddma, dd) the pass-0 start taps of segment s are the
+ *     start taps rotated by an unwrapped 4th-power phase estimate of their output at the head of the segment, so that
+ *     every segment starts phase-locked however far the carrier has drifted (-1: by method, 0 off, 1 on).
+ *   correction: plain relaxation hands information on by ONE segment per pass, which is fine for the tap directions the
+ *     signal excites (they forget within a segment) but not for the weakly excited ones (out-of-band directions, time
+ *     constants 1/(mu g lambda) of millions of steps), whose state depends on the whole history.  Between the passes
+ *     the boundary defects d[s] are therefore propagated through the LINEARISED segment map J = exp(-mu g T Rc), Rc the
+ *     input covariance <conj(x) x^T> and g the mean gain of the error function: D[s+1] = d[s+1] + J D[s] (a parallel
+ *     scan with the powers of J), start taps += D.  With J = 0 this is plain relaxation; J only preconditions the
+ *     iteration - at the fixed point all defects vanish and the result is the sequential recurrence either way.
+ * Fixed step only (adaptive = 0), no data-aided methods.  gram: table from qh_gram_build_*_dev for this (E, os, ntaps,
+ * TrSyms), or NULL.  report_dev: device memory for one qh_pit_report (read it after qh_sync), or NULL. */
+#define QH_PIT_MAXPASS 16
+#define QH_PIT_MAXCHUNK 32
+typedef struct qh_pit_opts {
+    int32_t segments;       /* 0 = automatic: segments of about 1.6 / mu steps, qh_pit_auto_segments */
+    int32_t max_passes;     /* 0 = 8 (at most QH_PIT_MAXPASS) */
+    int32_t acquire;        /* 0 warm start, 1 cold start: gear-shifted sequential acquisition first */
+    int32_t phase_seed;     /* -1 by method, 0 off, 1 on */
+    double tol;             /* 0 = 0.02 */
+    double gear;            /* 0 = 8 */
+    double acq_bound;       /* 0 = 0.08 */
+    double acq_plateau;     /* 0 = 0.9: a chunk whose mean |err|^2 exceeds this fraction of the previous one's ends the acquisition */
+    int64_t acq_chunk;      /* 0 = automatic (>= 4096 steps) */
+    int64_t acq_max;        /* 0 = min(TrSyms / 2, 2^17) steps */
+    int32_t correction;     /* -1 / 1: linearised coarse correction between the passes (see below), 0: plain relaxation */
+    int32_t pad;
+} qh_pit_opts;
+typedef struct qh_pit_report {
+    int32_t segments, passes, converged, acq_chunks;
+    int64_t seg_len, acq_steps;
+    double mu, mu_acq, power, tol;
+    double defect[QH_PIT_MAXPASS];      /* largest boundary defect after pass p of the last sweep; -1 = pass not run */
+    double acq_err[QH_PIT_MAXCHUNK];    /* mean |err|^2 of the acquisition chunks */
+    double gain, out_power;             /* linearised error-function gain g and mean output power used by the correction */
+    int32_t acq_done, done, diverged, corr_on;   /* device-side flags */
+} qh_pit_report;
+int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int *segments);
+/* kernel time (HIP events on the library stream) of the trainer launches of the most recent qh_train_equaliser_*_pit_dev call:
+ * the relaxation passes in order (all sweeps) and the sum of the acquisition chunks */
+int qh_pit_last_timing(float *pass_ms, int max_passes, int *npass, float *acq_ms);
 int qh_train_equaliser_c64_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
                                    void *wx, int ntaps, const int64_t *modes, int nsel, const void *symbols, int64_t nsy,
-                                   int method, void *err, int zero_err, int nseg, int npass, double *pass_change, int64_t prefix);
+                                   int method, void *err, int zero_err, const void *gram, const qh_pit_opts *opts,
+                                   void *report_dev);
 int qh_train_equaliser_c128_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev,
                                     void *wx, int ntaps, const int64_t *modes, int nsel, const void *symbols, int64_t nsy,
-                                    int method, void *err, int zero_err, int nseg, int npass, double *pass_change, int64_t prefix);
+                                    int method, void *err, int zero_err, const void *gram, const qh_pit_opts *opts,
+                                    void *report_dev);
 
 /* ---- channel bank: nch independent captures of identical shape processed together -------------------------------
  * (SURVEY.md 8e "within a GPU": one exact training chain occupies one workgroup, so a GPU holds hundreds of channels).

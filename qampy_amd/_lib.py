@@ -55,8 +55,6 @@ SIGNATURES = {
     "qh_train_equaliser_c128": _train_sig(_pd),
     "qh_train_equaliser_c64_dev": _train_sig(_pf, dev=True),
     "qh_train_equaliser_c128_dev": _train_sig(_pd, dev=True),
-    "qh_train_equaliser_c64_seg_dev": _train_sig(_pf, dev=True) + [_i, _i64, C.c_double],
-    "qh_train_equaliser_c128_seg_dev": _train_sig(_pd, dev=True) + [_i, _i64, C.c_double],
     "qh_gram_build_c64_dev": [_vp, _i, _i64, _i, _i, _i64, C.POINTER(_vp)],
     "qh_gram_build_c128_dev": [_vp, _i, _i64, _i, _i, _i64, C.POINTER(_vp)],
     "qh_train_equaliser_c64_gram_dev": _train_sig(_pf, dev=True) + [_vp],
@@ -79,8 +77,10 @@ SIGNATURES = {
     "qh_train_equaliser_c128_batch_dev": [_vp, _i] + _train_sig(_pd, dev=True)[1:] + [_vp],
     "qh_synth_capture_c64_dev": [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, C.c_double, C.c_double, _i, C.c_double, C.c_double, _i, C.c_double,
                                  C.c_uint64],
-    "qh_train_equaliser_c64_pit_dev": [_vp, _i, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64],
-    "qh_train_equaliser_c128_pit_dev": [_vp, _i, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64],
+    "qh_train_equaliser_c64_pit_dev": [_vp, _i, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp],
+    "qh_train_equaliser_c128_pit_dev": [_vp, _i, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp],
+    "qh_pit_auto_segments": [_i64, C.c_double, _i, C.POINTER(_i)],
+    "qh_pit_last_timing": [_pf, _i, C.POINTER(_i), _pf],
     "qh_set_trainer": [_i],
     "qh_use_stream": [_i],
     "qh_release_scratch": [],
@@ -88,6 +88,34 @@ SIGNATURES = {
     "qh_ser_c64_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
     "qh_ser_c128_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
 }
+
+PIT_MAXPASS, PIT_MAXCHUNK = 16, 32
+
+
+class PitOpts(C.Structure):
+    """``qh_pit_opts`` of include/qampy_hip.h (zeros = the library's defaults)."""
+    _fields_ = [("segments", C.c_int32), ("max_passes", C.c_int32), ("acquire", C.c_int32), ("phase_seed", C.c_int32),
+                ("tol", C.c_double), ("gear", C.c_double), ("acq_bound", C.c_double), ("acq_plateau", C.c_double),
+                ("acq_chunk", C.c_int64), ("acq_max", C.c_int64), ("correction", C.c_int32), ("pad", C.c_int32)]
+
+
+class PitReport(C.Structure):
+    """``qh_pit_report`` of include/qampy_hip.h."""
+    _fields_ = [("segments", C.c_int32), ("passes", C.c_int32), ("converged", C.c_int32), ("acq_chunks", C.c_int32),
+                ("seg_len", C.c_int64), ("acq_steps", C.c_int64),
+                ("mu", C.c_double), ("mu_acq", C.c_double), ("power", C.c_double), ("tol", C.c_double),
+                ("defect", C.c_double * PIT_MAXPASS), ("acq_err", C.c_double * PIT_MAXCHUNK),
+                ("gain", C.c_double), ("out_power", C.c_double),
+                ("acq_done", C.c_int32), ("done", C.c_int32), ("diverged", C.c_int32), ("corr_on", C.c_int32)]
+
+    def as_dict(self):
+        return dict(segments=int(self.segments), seg_len=int(self.seg_len), passes=int(self.passes), converged=bool(self.converged),
+                    tol=float(self.tol), defect=[float(d) for d in self.defect if d >= 0],
+                    acquisition=dict(steps=int(self.acq_steps), chunks=int(self.acq_chunks), mu=float(self.mu_acq),
+                                     diverged=bool(self.diverged), mean_sq_err=[float(v) for v in self.acq_err if v >= 0]),
+                    mu=float(self.mu), power=float(self.power), gain=float(self.gain), out_power=float(self.out_power),
+                    correction=bool(self.corr_on))
+
 
 _lib = None
 

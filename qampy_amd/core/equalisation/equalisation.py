@@ -49,34 +49,41 @@ def generate_symbols_for_eq(method, M, dtype):
     raise ValueError("%s is unknown method" % method)
 
 
+def _rows_complex(arr, nmodes):
+    """One row of constants / alphabet / training symbols per mode for the complex trainers."""
+    if arr.ndim <= 1 or arr.shape[0] == 1:
+        return np.broadcast_to(arr.reshape(1, -1), (nmodes, arr.size)).copy()          # shared by all modes
+    if arr.shape[0] == nmodes:
+        return arr
+    raise ValueError("symbols of shape %s do not fit %d modes: pass one row (shared) or one row per mode" % (arr.shape, nmodes))
+
+
+def _rows_real(arr, nrows):
+    """Rows for the real-stacked trainers: the first half of the rows belongs to the in-phase, the second to the quadrature
+    parts of the modes (packing of _convert_sig_to_real)."""
+    half = nrows // 2
+    if np.iscomplexobj(arr):
+        if arr.ndim <= 1 or arr.shape[0] == 1:
+            flat = arr.reshape(-1)
+            return np.concatenate([np.broadcast_to(flat.real, (half, flat.size)), np.broadcast_to(flat.imag, (half, flat.size))])
+        if arr.shape[0] == half:
+            return np.concatenate([arr.real, arr.imag])
+        raise ValueError("complex symbols with %d rows do not fit %d complex modes: pass one row or one per mode" % (arr.shape[0], half))
+    if arr.shape[0] == 2 and nrows > 2:                                                   # (in-phase row, quadrature row) for all modes
+        return np.concatenate([np.broadcast_to(arr[0], (half,) + arr[0].shape), np.broadcast_to(arr[1], (half,) + arr[1].shape)])
+    if arr.shape[0] == nrows:
+        return arr
+    raise ValueError("real symbols of shape %s do not fit the %d rows of the real-stacked field" % (arr.shape, nrows))
+
+
 def _reshape_symbols(symbols, method, M, dtype, nmodes):
-    """Bring ``symbols`` into the ``(nmodes, K)`` layout of the trainer (equalisation.py:568-594)."""
-    if symbols is None or method in NONDECISION_BASED:      # caller-supplied arrays are ignored for blind methods (:569)
+    """``symbols`` in the ``(rows of the field, K)`` layout the trainer indexes (behaviour of equalisation.py:568-594;
+    a caller-supplied array is ignored for the blind methods, :569)."""
+    if symbols is None or method in NONDECISION_BASED:
         symbols = generate_symbols_for_eq(method, M, dtype)
-    symbols = np.asarray(symbols)
-    if method not in REAL_VALUED:
-        if symbols.ndim == 1 or symbols.shape[0] == 1:
-            symbols = np.tile(symbols, (nmodes, 1))
-        elif symbols.shape[0] != nmodes:
-            raise ValueError("Symbols array is shape {} but signal has {} modes, symbols must be 1d or of shape (1, N) "
-                             "or ({}, N)".format(symbols.shape, nmodes, nmodes))
-        return np.atleast_2d(symbols.astype(dtype))
-    half = nmodes // 2
-    if np.iscomplexobj(symbols):
-        if symbols.ndim == 1 or symbols.shape[0] == 1:
-            symbols = np.repeat([symbols.real, symbols.imag], half, axis=0).squeeze().reshape(nmodes, -1)
-        elif symbols.shape[0] == half:
-            symbols = np.vstack([symbols.real, symbols.imag])
-        else:
-            raise ValueError("Symbols array is  complex and has {} modes, but needs to either have one mode or the same "
-                             "modes as the signal ({})".format(symbols.shape[0], half))
-    else:
-        if symbols.shape[0] == 2 and nmodes > 2:
-            symbols = np.repeat([symbols[0], symbols[1]], half, axis=0).squeeze().reshape(nmodes, -1)
-        elif symbols.shape[0] != nmodes:
-            raise ValueError("Symbols array is shape {} but signal has {} modes, symbols must be 1d or of shape (1, N) "
-                             "or ({}, N)".format(symbols.shape, nmodes, nmodes))
-    return symbols.astype(dtype)
+    arr = np.asarray(symbols)
+    rows = _rows_real(arr, nmodes) if method in REAL_VALUED else _rows_complex(arr, nmodes)
+    return np.atleast_2d(rows).astype(dtype)
 
 
 def _cal_training_symbol_len(os, ntaps, L):
@@ -124,73 +131,120 @@ def apply_filter(E, os, wxy, method="pyt", modes=None):
     raise ValueError("The field has an unknown data type")
 
 
+class _Field:
+    """
+    The capture of one equaliser call, prepared once: a private C-ordered copy (real-stacked for the real-valued
+    trainers), uploaded to HBM once for the complex trainers (:class:`hip_equalisation.ResidentField`) so that every stage
+    of a multi-stage call and the final filter run on the same resident array.  The reference copies the field anew for
+    each of its compiled calls (equalisation.py:166, :532, three times per dual-mode call).
+    """
+
+    def __init__(self, E, real):
+        E = np.asarray(E)
+        self.real = real
+        self.host = _convert_sig_to_real(E) if real else np.array(E, copy=True, order="C", subok=False)
+        self.rows, self.L = self.host.shape
+        self.dtype = self.host.dtype
+        self.dev = None if real else _kernels.ResidentField(self.host)
+
+    def mode_rows(self, modes):
+        """Rows of the field the call trains: the modes, plus their quadrature rows in the real-stacked layout."""
+        if modes is None:
+            return np.arange(self.rows)
+        modes = np.atleast_1d(modes)
+        if self.real:
+            modes = np.concatenate([modes, modes + self.rows // 2])
+        if modes.size and modes.max() >= self.rows:
+            raise AssertionError("largest mode number is larger than shape of signal")
+        return modes
+
+    def taps(self, wxy, Ntaps):
+        """Initial taps: centre spike unless given; given taps are used (and updated) in place when they already have the
+        field's dtype and layout."""
+        if wxy is None:
+            return _init_taps(Ntaps, self.rows, self.rows, self.dtype)
+        wxy = np.ascontiguousarray(wxy, dtype=self.dtype)
+        if wxy.ndim != 3:
+            raise AssertionError("wxy needs to be three dimensional")
+        if wxy.shape[:2] != (self.rows, self.rows):
+            raise AssertionError("The first 2 dimensions of wxy need to be the same shape as E")
+        return wxy
+
+    def train(self, os, mu, M, wxy, TrSyms, Niter, method, adaptive, symbols, rows):
+        """One training stage on the prepared field; returns ``(taps, err)``."""
+        n = wxy.shape[-1]
+        if TrSyms is None:
+            TrSyms = _cal_training_symbol_len(os, n, self.L)
+        sy = _reshape_symbols(symbols, method, M, self.dtype, self.rows).copy()
+        mu = self.dtype.type(0).real.dtype.type(mu)
+        if self.real:
+            err, wxy, _ = _kernels.train_equaliser_realvalued(self.host, TrSyms, Niter, os, mu, wxy, rows, adaptive, sy, method[:-len("_real")])
+        else:
+            err, wxy, _ = self.dev.train(TrSyms, Niter, os, mu, wxy, rows, adaptive, sy, method)
+        return wxy, err
+
+    def filtered(self, os, wxy, rows):
+        """The field through the taps, selected rows only; complex result."""
+        if not self.real:
+            return self.dev.apply(os, wxy, rows)
+        out = _kernels.apply_filter_to_signal(self.host, os, np.array(wxy, copy=True, order="C"), rows)
+        return _convert_sig_to_cmplx(out, rows.shape[0], (np.complex64 if self.dtype.itemsize == 4 else np.complex128)(1j))
+
+
+def _method_name(method):
+    method = method.lower()
+    if method not in TRAINING_FCTS:
+        raise ValueError("%s is unknown method" % method)
+    return method
+
+
 def equalise_signal(E, os, mu, M, wxy=None, Ntaps=None, TrSyms=None, Niter=1, method="mcma", adaptive_stepsize=False,
                     symbols=None, modes=None, apply=False, **kwargs):
     """
-    Blind / decision-directed / data-aided equaliser training (equalisation.py:468-566).
+    Blind / decision-directed / data-aided equaliser training (behaviour of equalisation.py:468-566).
 
     Returns ``(wxy, err)`` or, with ``apply=True``, ``(E_equalised, wxy, err)``.  Unknown keyword arguments are
     swallowed like in the reference.
     """
-    method = method.lower()
-    E = np.asarray(E)
-    if method in REAL_VALUED:
-        E = _convert_sig_to_real(E)
-    else:
-        E = np.array(E, copy=True, order="C", subok=False)
-    mu = E.real.dtype.type(mu)
-    nmodes = E.shape[0]
-    if modes is None:
-        modes = np.arange(nmodes)
-    else:
-        modes = np.atleast_1d(modes)
-        if method in REAL_VALUED:
-            modes = np.hstack([modes, modes + nmodes // 2])
-        assert np.max(modes) < nmodes, "largest mode number is larger than shape of signal"
-    if wxy is None:
-        wxy = _init_taps(Ntaps, nmodes, nmodes, E.dtype)
-    else:
-        wxy = np.ascontiguousarray(wxy, dtype=E.dtype)      # no copy when possible: taps are updated in place (:547)
-        Ntaps = wxy.shape[-1]
-        assert wxy.ndim == 3, "wxy needs to be three dimensional"
-        assert wxy.shape[:2] == (nmodes, nmodes), "The first 2 dimensions of wxy need to be the same shape as E"
-    if TrSyms is None:
-        TrSyms = _cal_training_symbol_len(os, Ntaps, E.shape[-1])
-    symbols = _reshape_symbols(symbols, method, M, E.dtype, nmodes)
-    if method in REAL_VALUED:
-        err, wxy, mu = _kernels.train_equaliser_realvalued(E, TrSyms, Niter, os, mu, wxy, modes, adaptive_stepsize,
-                                                            symbols.copy(), method[:-5])
-    else:
-        err, wxy, mu = _kernels.train_equaliser(E, TrSyms, Niter, os, mu, wxy, modes, adaptive_stepsize, symbols.copy(),
-                                                method)
+    method = _method_name(method)
+    field = _Field(E, method in REAL_VALUED)
+    rows = field.mode_rows(modes)
+    taps, err = field.train(os, mu, M, field.taps(wxy, Ntaps), TrSyms, Niter, method, adaptive_stepsize, symbols, rows)
     if apply:
-        return apply_filter(E, os, wxy, modes=modes), wxy, err
-    return wxy, err
+        return field.filtered(os, taps, rows), taps, err
+    return taps, err
 
 
 def dual_mode_equalisation(E, os, mu, M, wxy=None, Ntaps=None, TrSyms=(None, None), Niter=(1, 1), methods=("mcma", "sbd"),
                            adaptive_stepsize=(False, False), symbols=None, modes=None, apply=True, **kwargs):
     """
-    Two-stage equalisation: stage 2 continues from the taps of stage 1 on the SAME input from sample 0
-    (equalisation.py:400-466).  Returns ``(E_eq, wxy, (err1, err2))`` or ``(wxy, (err1, err2))``.
+    Two training stages on the same field, the second continuing from the taps of the first, from sample 0 both times
+    (behaviour of equalisation.py:400-466).  Returns ``(E_eq, wxy, (err1, err2))`` or ``(wxy, (err1, err2))``.
+    The field is prepared and uploaded once for both stages and the filter.
 
-    Deviation: with ``symbols=None`` the reference's ``np.atleast_1d(None)`` turns into a NaN alphabet for
-    decision-directed stages; here ``None`` generates the alphabet like ``equalise_signal`` does.
+    ``symbols``: ``None``, one array for both stages, or an array whose leading axis of length 2 selects the stage (3-d).
+    Deviation: with ``symbols=None`` the reference hands decision-directed stages a NaN alphabet; here
+    ``None`` generates the alphabet like ``equalise_signal`` does.
     """
+    stages = [_method_name(m) for m in methods]
+    real = [m in REAL_VALUED for m in stages]
+    if real[0] != real[1]:
+        raise ValueError("the two stages must both be complex-valued or both real-valued methods")
     if symbols is None:
-        per_stage = (None, None)
+        sy = (None, None)
     else:
-        symbols = np.atleast_1d(symbols)
-        if symbols.ndim < 3:
-            symbols = np.tile(symbols, (2, 1, 1))
-        per_stage = (symbols[0], symbols[1])
-    wxy, err1 = equalise_signal(E, os, mu[0], M, wxy=wxy, Ntaps=Ntaps, TrSyms=TrSyms[0], Niter=Niter[0], method=methods[0],
-                                adaptive_stepsize=adaptive_stepsize[0], symbols=per_stage[0], modes=modes, **kwargs)
-    wxy2, err2 = equalise_signal(E, os, mu[1], M, wxy=wxy, TrSyms=TrSyms[1], Niter=Niter[1], method=methods[1],
-                                 adaptive_stepsize=adaptive_stepsize[1], symbols=per_stage[1], modes=modes, **kwargs)
+        s3 = np.asarray(symbols)
+        sy = (s3[0], s3[1]) if s3.ndim == 3 else (s3, s3)
+    field = _Field(E, real[0])
+    rows = field.mode_rows(modes)
+    taps = field.taps(wxy, Ntaps)
+    errs = []
+    for k in range(2):
+        taps, err = field.train(os, mu[k], M, taps, TrSyms[k], Niter[k], stages[k], adaptive_stepsize[k], sy[k], rows)
+        errs.append(err)
     if apply:
-        return apply_filter(E, os, wxy2, modes=modes), wxy2, (err1, err2)
-    return wxy2, (err1, err2)
+        return field.filtered(os, taps, rows), taps, tuple(errs)
+    return taps, tuple(errs)
 
 
 def equalise_signal_windows(E, os, mu, M, starts, win_len, Ntaps=None, TrSyms=None, Niter=1, method="mcma",

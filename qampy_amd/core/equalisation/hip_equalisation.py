@@ -170,6 +170,60 @@ def det_symbol(X, symbs):
     return det[0], dist[0] ** 2
 
 
+class ResidentField:
+    """
+    A complex capture uploaded to HBM once; trainer stages and the filter of one host-level call run on it there
+    (``equalise_signal(apply=True)``: 2 kernels, ``dual_mode_equalisation``: 3 - the reference hands the field to each of its
+    compiled calls separately).  ``train`` / ``apply`` keep the contracts of :func:`train_equaliser` /
+    :func:`apply_filter_to_signal` minus the field argument: host arrays in and out, ``wx`` updated in place.
+    """
+
+    def __init__(self, E):
+        suf, rt, ct = _lib.suffix(E.dtype)
+        if not np.iscomplexobj(E):
+            raise TypeError("ResidentField holds a complex field")
+        _need(E, ct, "E")
+        if E.ndim != 2:
+            raise TypeError("E must be 2-d")
+        self.shape, self.ct, self.rt = E.shape, ct, rt
+        self.dev = DeviceArray.from_host(E)
+
+    def train(self, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method):
+        if method not in _lib.METHOD_ID:
+            raise ValueError("Unknown method %s" % method)
+        nmodes, L = self.shape
+        _need(wx, self.ct, "wx")
+        symbols = np.ascontiguousarray(symbols)
+        _need(symbols, self.ct, "symbols")
+        if wx.ndim != 3 or symbols.ndim != 2:
+            raise TypeError("wx must be 3-d and symbols 2-d")
+        if wx.shape[:2] != (nmodes, nmodes):
+            raise ValueError("wx needs to have at least as many dimensions as the maximum mode")
+        if symbols.shape[0] != nmodes:
+            raise ValueError("symbols must be at least size of modes")
+        dw, dsy = DeviceArray.from_host(wx), DeviceArray.from_host(symbols)
+        dmu = DeviceArray.from_host(np.array([mu], dtype=self.rt))
+        derr = DeviceArray((nmodes, int(TrSyms) * int(Niter)), self.ct)
+        train_equaliser_dev(self.dev, TrSyms, Niter, os, dmu, dw, modes, adaptive, dsy, method, derr, zero_err=True)
+        wx[...] = dw.to_host()
+        return derr.to_host(), wx, self.rt(dmu.to_host()[0])
+
+    def apply(self, os, wx, modes=None):
+        if os <= 0:
+            raise ValueError("oversampling factor must be larger than 0")
+        nmodes, L = self.shape
+        wx = np.ascontiguousarray(wx, dtype=self.ct)
+        if wx.ndim != 3 or wx.shape[0] != nmodes or wx.shape[1] != nmodes:
+            raise ValueError("wx must be (nmodes, nmodes, ntaps)")
+        modes = _as_modes(modes, nmodes)
+        if modes.size and modes.max() >= nmodes:
+            raise ValueError("largest mode number is larger than shape of signal")
+        N = max((L - wx.shape[-1] + 1) // os, 0)
+        out = DeviceArray((modes.size, N), self.ct)
+        apply_filter_to_signal_dev(self.dev, os, DeviceArray.from_host(wx), modes, out)
+        return out.to_host()
+
+
 # ------------------------------------------------------------------------------------------------ device-resident forms
 def gram_build_dev(E, os, ntaps, TrSyms):
     """
@@ -185,16 +239,17 @@ def gram_build_dev(E, os, ntaps, TrSyms):
     return g.value
 
 
-def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method, err, zero_err=False, segments=0,
-                        prefix=0, gram=None, prefix_mu=0., passes=0, pass_change=None):
+def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method, err, zero_err=False, gram=None, pit=None,
+                        report=None):
     """
     Same as :func:`train_equaliser` with every array (and the scalar ``mu``, a 1-element DeviceArray) already in HBM.
     Only enqueues work on the library stream.
 
-    ``segments > 0`` selects an opt-in segment-parallel mode, NOT the reference's order of evaluation:
-    with ``passes > 0`` parallel-in-time relaxation (segment s restarts from the end taps of segment s-1 of the previous
-    pass; converges to the sequential recurrence, 2-3 passes reproduce outputs and decisions), else the one-shot
-    continuation (``prefix`` sequential steps, then all segments from the same taps; statistical agreement only).
+    ``pit`` (a dict, default ``None`` = the reference's exact sequential recurrence) selects the opt-in parallel-in-time
+    trainer (``qh_train_equaliser_*_pit_dev``): concurrently trained segments made consistent by waveform
+    relaxation until the boundary defect is below ``tol``.  Keys (all optional): ``segments`` (0 = automatic),
+    ``max_passes``, ``tol``, ``acquire`` (cold start: gear-shifted acquisition first), ``phase_seed``, ``gear``,
+    ``acq_bound``, ``acq_plateau``, ``acq_chunk``, ``acq_max``.  ``report``: a :class:`PitReportBuffer` the device fills.
     """
     if method not in _lib.METHOD_ID:
         raise ValueError("Unknown method %s" % method)
@@ -205,23 +260,50 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
     args = (E.ptr, nmodes, L, int(TrSyms), int(Niter), int(os), mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size,
             _adaptive_flag(adaptive), symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)))
     name = "qh_train_equaliser_c" + ("64" if suf == "32" else "128")
-    if segments and segments > 0 and passes and passes > 0:
-        # parallel in time (opt-in): `passes` relaxation passes over `segments` concurrently trained segments per sweep;
-        # pass_change: optional float64 array (passes,) receiving the largest end-tap change per pass
+    if pit is not None:
         if _adaptive_flag(adaptive):
             raise ValueError("parallel-in-time training needs a fixed step size")
-        pc = None
-        if pass_change is not None:
-            assert pass_change.dtype == np.float64 and pass_change.size >= passes and pass_change.flags.c_contiguous
-            pc = _lib.ptr(pass_change)
+        o = _lib.PitOpts()
+        o.phase_seed = -1
+        o.correction = -1
+        for k, v in pit.items():
+            if not hasattr(o, k):
+                raise ValueError("unknown parallel-in-time option %s" % k)
+            setattr(o, k, v)
         _lib.call(name + "_pit_dev", E.ptr, nmodes, L, int(TrSyms), int(Niter), int(os), mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size,
-                  symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)), int(segments), int(passes), pc, int(prefix))
-    elif segments and segments > 0:
-        _lib.call(name + "_seg_dev", *args, int(segments), int(prefix), float(prefix_mu or 0.))
+                  symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)), gram, C.byref(o),
+                  report.ptr if report is not None else None)
     elif gram:
         _lib.call(name + "_gram_dev", *args, gram)
     else:
         _lib.call(name + "_dev", *args)
+
+
+class PitReportBuffer(DeviceArray):
+    """Device memory for one ``qh_pit_report``; :meth:`read` synchronises and returns it as a dict."""
+
+    def __init__(self):
+        super().__init__((C.sizeof(_lib.PitReport),), np.uint8, zero=True)
+
+    def read(self):
+        _lib.sync()
+        raw = self.to_host()
+        return _lib.PitReport.from_buffer_copy(raw.tobytes()).as_dict()
+
+
+def pit_last_timing():
+    """Kernel time of the trainer launches of the most recent parallel-in-time call: ``(pass_ms list, acquisition ms)``."""
+    buf = (C.c_float * _lib.PIT_MAXPASS)()
+    n, acq = C.c_int(0), C.c_float(0)
+    _lib.call("qh_pit_last_timing", buf, _lib.PIT_MAXPASS, C.byref(n), C.byref(acq))
+    return [float(buf[i]) for i in range(n.value)], float(acq.value)
+
+
+def pit_auto_segments(TrSyms, mu, nsel=1):
+    """The library's automatic segment count for a sweep of ``TrSyms`` steps at step size ``mu`` (1 = sequential)."""
+    n = C.c_int(0)
+    _lib.call("qh_pit_auto_segments", int(TrSyms), float(mu), int(nsel), C.byref(n))
+    return n.value
 
 
 def gram_build_batch_dev(E, os, ntaps, TrSyms):

@@ -115,12 +115,15 @@ constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114;
 template <typename R, int METHOD, int NPART, bool ADAPT = false>
 __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
 {
-    // independent captures of a channel bank (blockIdx.y): same shapes, own arrays
+    if (a.skip && *a.skip) return;
+    // independent captures of a channel bank / segments of a sweep (blockIdx.y): same shapes, own arrays
     const int64_t ch = blockIdx.y;
-    const Cx<R> *const aE = a.E + ch * a.E_cs;
-    Cx<R> *const awx = a.wx + ch * a.wx_cs;
-    Cx<R> *const aerr = a.err + ch * a.err_cs;
-    const GramPair<R> *const aG = a.G + ch * a.G_cs;
+    const LaView<R> vw = la_view(a, ch);
+    const Cx<R> *const aE = vw.E;
+    Cx<R> *const awx = vw.wx;
+    Cx<R> *const aerr = vw.err;
+    const GramPair<R> *const aG = vw.G;
+    const int64_t aL = vw.L;
     const R *const amu = a.mu + ch * a.mu_cs + (int64_t)blockIdx.x * a.mu_ms;
     extern __shared__ __attribute__((aligned(16))) char bi_smem[];
     const int lane = threadIdx.x & 63;
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
     const int mode = (int)a.modes[blockIdx.x];
     const int ntot = a.nmodes * a.ntaps;
     const int os_ = a.os;
-    const int64_t TrSyms = a.TrSyms;
+    const int64_t TrSyms = vw.TrSyms;
     const int nblk = (int)((TrSyms + LA_B - 1) / LA_B);
     const Cx<R> *sy = a.symbols + (size_t)mode * a.sy_pitch;
 
@@ -193,7 +196,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             int64_t gi = base + st_i[s];
-            if (gi > a.L - 1) gi = a.L - 1;
+            if (gi > aL - 1) gi = aL - 1;
             stv[s] = aE[st_src[s] + gi];
         }
     };
@@ -206,7 +209,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         for (int e = threadIdx.x + 2 * BI_NT; e < wsz; e += BI_NT) {      // very long windows only
             const int k2 = e / wpitch, i2 = e - k2 * wpitch;
             int64_t gi = base + i2;
-            if (gi > a.L - 1) gi = a.L - 1;
+            if (gi > aL - 1) gi = aL - 1;
             dst[e] = aE[(size_t)k2 * a.Lp + gi];
         }
     };

@@ -1,5 +1,5 @@
 // C ABI of the trainers, single precision (complex64 / float32).  Kernels: train_impl.h
-#include "train_impl.h"
+#include "train_pit.h"
 
 extern "C" {
 int qh_train_equaliser_c64(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu, void *wx,
@@ -20,12 +20,6 @@ int qh_train_equaliser_real_f32(const void *E, int nmodes, int64_t L, int64_t Tr
 {
     return qh::train_real_host<float>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err);
 }
-int qh_train_equaliser_c64_seg_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
-                                   void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
-                                   int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix, double prefix_mu)
-{
-    return qh::train_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, nseg, prefix, nullptr, prefix_mu);
-}
 int qh_gram_build_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
 {
     // pairs (look-ahead layout, also read by the block-iterative kernel) whenever the look-ahead kernel fits the shape
@@ -36,13 +30,26 @@ int qh_train_equaliser_c64_gram_dev(const void *E, int nmodes, int64_t L, int64_
                                     void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
                                     int64_t nsy, int method, void *err, int zero_err, const void *gram)
 {
-    return qh::train_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, 0, 0, gram);
+    return qh::train_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, gram);
 }
 int qh_train_equaliser_c64_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev, void *wx, int ntaps,
                                     const int64_t *modes, int nsel, const void *symbols, int64_t nsy, int method, void *err, int zero_err,
-                                    int nseg, int npass, double *pass_change, int64_t prefix)
+                                    const void *gram, const qh_pit_opts *opts, void *report_dev)
 {
-    return qh::train_pit_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, symbols, nsy, method, err, zero_err, nseg, npass, pass_change, prefix);
+    return qh::train_pit_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, symbols, nsy, method, err, zero_err, gram, opts, report_dev);
+}
+int qh_pit_last_timing(float *pass_ms, int max_passes, int *npass, float *acq_ms)
+{
+    const qh::PitTiming &t = qh::pit_timing();
+    for (int i = 0; i < t.npass && i < max_passes; i++) pass_ms[i] = t.pass_ms[i];
+    *npass = t.npass < max_passes ? t.npass : max_passes;
+    *acq_ms = t.acq_ms;
+    return QH_OK;
+}
+int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int *segments)
+{
+    *segments = qh::pit_auto_segments(TrSyms, mu, nsel);
+    return QH_OK;
 }
 int qh_gram_build_c64_batch_dev(const void *E, int nch, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
 {
@@ -53,7 +60,7 @@ int qh_train_equaliser_c64_batch_dev(const void *E, int nch, int nmodes, int64_t
                                       void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
                                       int64_t nsy, int method, void *err, int zero_err, const void *gram)
 {
-    return qh::train_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, 0, 0, gram, 0, nch);
+    return qh::train_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, gram, nch);
 }
 int qh_train_equaliser_windows_c64(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len,
                                      int64_t TrSyms, int Niter, int os, float mu, const void *wx0, int ntaps, const int64_t *modes, int nsel,

@@ -1,5 +1,5 @@
 // C ABI of the trainers, double precision (complex128 / float64).  Kernels: train_impl.h
-#include "train_impl.h"
+#include "train_pit.h"
 
 extern "C" {
 int qh_train_equaliser_c128(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu, void *wx,
@@ -20,12 +20,6 @@ int qh_train_equaliser_real_f64(const void *E, int nmodes, int64_t L, int64_t Tr
 {
     return qh::train_real_host<double>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err);
 }
-int qh_train_equaliser_c128_seg_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev,
-                                   void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
-                                   int64_t nsy, int method, void *err, int zero_err, int nseg, int64_t prefix, double prefix_mu)
-{
-    return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, nseg, prefix, nullptr, prefix_mu);
-}
 int qh_gram_build_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
 {
     // pairs (look-ahead layout, also read by the block-iterative kernel) whenever the look-ahead kernel fits the shape
@@ -36,13 +30,13 @@ int qh_train_equaliser_c128_gram_dev(const void *E, int nmodes, int64_t L, int64
                                     void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
                                     int64_t nsy, int method, void *err, int zero_err, const void *gram)
 {
-    return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, 0, 0, gram);
+    return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, gram);
 }
 int qh_train_equaliser_c128_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev, void *wx, int ntaps,
                                     const int64_t *modes, int nsel, const void *symbols, int64_t nsy, int method, void *err, int zero_err,
-                                    int nseg, int npass, double *pass_change, int64_t prefix)
+                                    const void *gram, const qh_pit_opts *opts, void *report_dev)
 {
-    return qh::train_pit_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, symbols, nsy, method, err, zero_err, nseg, npass, pass_change, prefix);
+    return qh::train_pit_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, symbols, nsy, method, err, zero_err, gram, opts, report_dev);
 }
 int qh_gram_build_c128_batch_dev(const void *E, int nch, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
 {
@@ -53,7 +47,7 @@ int qh_train_equaliser_c128_batch_dev(const void *E, int nch, int nmodes, int64_
                                       void *wx, int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols,
                                       int64_t nsy, int method, void *err, int zero_err, const void *gram)
 {
-    return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, 0, 0, gram, 0, nch);
+    return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, gram, nch);
 }
 int qh_train_equaliser_windows_c128(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len,
                                      int64_t TrSyms, int Niter, int os, double mu, const void *wx0, int ntaps, const int64_t *modes, int nsel,

@@ -31,6 +31,7 @@
 #include <vector>
 #include <math.h>
 #include <stdio.h>
+#include <string.h>
 
 namespace qh {
 
@@ -45,12 +46,13 @@ template <typename R> struct TrainArgs {
     int64_t L, TrSyms, nsy;
     int nmodes, ntaps, Niter, os, nsel, adaptive, method;
     int64_t modes[16];
-    // segment-parallel continuation (tier B, NOT the reference's semantics):
-    // blockIdx.y = segment; segment s trains steps [seg_begin + s*seg_len, min(seg_begin + (s+1)*seg_len, TrSyms))
-    // of sweep `seg_iter`, every segment starting from the same taps `wx`; the last segment's taps go to `wx_out`.
-    int64_t seg_begin, seg_len;
+    // segments of one sweep trained concurrently (parallel-in-time training, train_pit.h): blockIdx.y = segment; segment s
+    // covers seg_len steps (one 64-step block more for the first seg_extra segments, seg_tail more for the last one) of
+    // sweep seg_iter, starts from ITS taps wx + s * nmodes * nmodes * ntaps and leaves its end taps there
+    int64_t seg_begin, seg_len, seg_extra, seg_tail;     // seg_begin: first step of segment 0
     int nseg, seg_iter;
-    Cx<R> *wx_out;
+    const int *skip;        // optional device flag: non-zero -> the launch does nothing
+    Cx<R> *wx_out;          // window batches: (nwin, nmodes, nmodes, ntaps) result taps
     // batch of independent windows (frame synchronisation, qampy/core/pilotbased_receiver.py:395-400): blockIdx.y = window;
     // window v trains on E[:, win_start[v] : win_start[v] + win_len] from the shared initial taps `wx` and step size `mu`
     // and writes its own taps / error trace / final step size
@@ -376,6 +378,7 @@ __global__ void __launch_bounds__(64) train_kernel(TrainArgs<R> a, int CH, int p
     lds.pitch = pitch;
     lds.CH = CH;
     lds.zero_off = 2 * a.nmodes * pitch;
+    if (a.skip && *a.skip) return;
     for (int j = lane; j < TR_SLACK + 64; j += 64) lds.buf[lds.zero_off + j] = Cx<R>{0, 0};
     R mu = *a.mu;
     // adaptive: sequential semantics, ONE wave walks the modes in order and carries mu;
@@ -395,18 +398,14 @@ __global__ void __launch_bounds__(64) train_kernel(TrainArgs<R> a, int CH, int p
         return;
     }
     if (a.nseg > 0) {
-        // tier B: one workgroup per (mode, segment); every segment starts from the same taps and step size
-        const int64_t b = a.seg_begin + (int64_t)blockIdx.y * a.seg_len;
-        int64_t e = b + a.seg_len;
-        if (e > a.TrSyms) e = a.TrSyms;
-        const bool last = (int)blockIdx.y == a.nseg - 1;
-        if (b < e) {
-            mu = run_chain<R, TPL, METHOD>(a, lds, (int)a.modes[blockIdx.x], mu, lane, b, e, a.seg_iter, a.seg_iter + 1,
-                                           last ? a.wx_out : nullptr);
-            // the adapted step size is only handed on by the sequential prefix (nseg == 1); parallel segments keep
-            // theirs private, so a late-starting workgroup can never observe another segment's value
-            if (a.nseg == 1 && a.adaptive && blockIdx.x == a.nsel - 1 && lane == 0) *a.mu = mu;
-        }
+        // one workgroup per (mode, segment); fixed step size
+        const int64_t sgi = blockIdx.y;
+        const int64_t nx = sgi < a.seg_extra ? sgi : a.seg_extra;
+        const int64_t b = a.seg_begin + sgi * a.seg_len + nx * 64;
+        const int64_t e = b + a.seg_len + (sgi < a.seg_extra ? 64 : 0) + ((int)sgi == a.nseg - 1 ? a.seg_tail : 0);
+        TrainArgs<R> sa = a;
+        sa.wx = a.wx + (size_t)sgi * a.nmodes * a.nmodes * a.ntaps;
+        if (b < e) run_chain<R, TPL, METHOD>(sa, lds, (int)a.modes[blockIdx.x], mu, lane, b, e, a.seg_iter, a.seg_iter + 1, sa.wx);
         return;
     }
     const int jbeg = a.adaptive ? 0 : blockIdx.x, jend = a.adaptive ? a.nsel : blockIdx.x + 1;
@@ -470,26 +469,23 @@ static size_t gram_budget()
     return (size_t)((gb > 0.001 ? gb : 0.001) * 1073741824.0);
 }
 
-// nseg == 0: the reference's exact sequential semantics.  nseg > 0: "segment-parallel continuation" (tier B): the first
-// `prefix` steps of sweep 0 are trained sequentially, then every sweep is split into nseg segments that all start from
-// the taps at the end of the previous phase; final taps (and step size) are those of the last segment.
+// The reference's exact sequential semantics, in whichever of the three kernel forms is fastest for the call.
 template <typename R>
 int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu_dev, void *wx, int ntaps,
               const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy, int method, void *err,
-              int zero_err, int nseg = 0, int64_t prefix = 0, const void *gram = nullptr, double prefix_mu = 0, int nch = 1)
+              int zero_err, const void *gram = nullptr, int nch = 1)
 {
     int rc = ensure_init();
     if (rc) return rc;
     if (method < 0 || method > QH_M_SBD_DATA) { set_error("unknown equaliser method id"); return QH_ERR_METHOD; }
     // nch > 1: a bank of independent captures with identical shapes, arrays (nch, ...) contiguous, one mu per channel; the
     // look-ahead / block-iterative kernels take the channel as blockIdx.y, anything else runs channel after channel
-    QH_REQUIRE(nch >= 1 && nch <= 65535 && (nch == 1 || nseg <= 0), "train_equaliser: bad channel count");
+    QH_REQUIRE(nch >= 1 && nch <= 65535, "train_equaliser: bad channel count");
     // adaptive: 0 fixed step; 1 the reference's sequential semantics (mu carried from sweep to sweep AND from mode to mode,
     // pythran_equalisation.py:162-172 run with one thread); 2 one step size PER MODE - exactly what one call per selected mode
     // from the initial mu gives (mu out = the last mode's).  The compiled reference adapts a mu that its OpenMP threads share
     // without synchronisation; 2 is the deterministic stand-in for that (every mode starts adapting from the full step).
     QH_REQUIRE(adaptive >= 0 && adaptive <= 2, "train_equaliser: adaptive must be 0, 1 or 2");
-    QH_REQUIRE(adaptive != 2 || nseg <= 0, "train_equaliser: per-mode step sizes are not available in the segmented mode");
     QH_REQUIRE(nmodes >= 1 && ntaps >= 1 && os >= 1 && Niter >= 0 && TrSyms >= 0, "train_equaliser: bad sizes");
     QH_REQUIRE(nsel >= 1 && nsel <= 16, "train_equaliser: between 1 and 16 modes can be selected");
     QH_REQUIRE(TrSyms == 0 || (TrSyms - 1) * os + ntaps <= L, "train_equaliser: field shorter than TrSyms*os + ntaps");
@@ -506,9 +502,9 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
     a.nsel = nsel; a.adaptive = adaptive ? 1 : 0; a.method = method;
     for (int j = 0; j < 16; j++) a.modes[j] = j < nsel ? modes[j] : 0;
     const bool per_mode = adaptive == 2 && nsel > 1;
-    a.nseg = 0; a.seg_begin = 0; a.seg_len = 0; a.seg_iter = 0; a.wx_out = nullptr;
+    a.nseg = 0; a.seg_begin = 0; a.seg_len = 0; a.seg_extra = 0; a.seg_tail = 0; a.seg_iter = 0; a.skip = nullptr; a.wx_out = nullptr;
     a.win_start = nullptr; a.win_len = 0; a.nwin = 0; a.win_mu = nullptr; a.e_off = 0;
-    if (nseg <= 0) {
+    {
         // exact semantics.  Blind methods with a fixed step run in the look-ahead (train_la.h) or block-iterative
         // (train_bi.h) form, everything else (decision-directed, data-aided, adaptive step, tiny captures) in the direct
         // form below.  Same results up to the order of additions.
@@ -553,7 +549,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             if (use_bi && decision) {   // the kernel reads the slicer table like an mrde table: row pitch 2*BI_DD_MAXLEV, 2*npart+1 used
                 la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV;
             }
-            la.prof = nullptr;
+            la.prof = nullptr; la.seg = 0; la.seg_extra = 0; la.seg_tail = 0; la.skip = nullptr;
             if (getenv("QAMPY_HIP_LA_PROFILE")) {                // developer aid: cycle split of workgroup 0
                 void *pp = nullptr;
                 if ((rc = scratch(5, 16 * sizeof(unsigned long long), &pp))) return rc;
@@ -616,7 +612,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             QH_HIP(hipMemcpyAsync(pm, mu_dev, (size_t)nch * sizeof(R), hipMemcpyDeviceToDevice, g_stream));
             for (int j = 0; j < nsel; j++) {
                 QH_HIP(hipMemcpyAsync(mu_dev, pm, (size_t)nch * sizeof(R), hipMemcpyDeviceToDevice, g_stream));
-                if ((rc = train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes + j, 1, 1, symbols, nsy, method, err, 0, 0, 0, gram, 0, nch)))
+                if ((rc = train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes + j, 1, 1, symbols, nsy, method, err, 0, gram, nch)))
                     return rc;
             }
             return QH_OK;
@@ -629,181 +625,6 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         }
         return QH_OK;
     }
-    // ---- tier B
-    QH_REQUIRE(nseg <= 65535 && prefix >= 0, "train_equaliser: bad segment parameters");
-    if (prefix > TrSyms) prefix = TrSyms;
-    void *wtmp = nullptr;
-    if ((rc = scratch(2, (size_t)nmodes * ntot * sizeof(Cx<R>), &wtmp))) return rc;
-    const size_t wbytes = (size_t)nmodes * ntot * sizeof(Cx<R>);
-    for (int it = 0; it < Niter; it++) {
-        int64_t begin = 0;
-        if (it == 0 && prefix > 0) {                         // sequential convergence prefix
-            TrainArgs<R> p = a;       // one "segment" [0, prefix) per mode == the exact chain on the prefix
-            p.nseg = 1; p.seg_begin = 0; p.seg_len = prefix; p.seg_iter = 0; p.wx_out = (Cx<R> *)wtmp;
-            if (prefix_mu > 0) {      // "gear shifting": a larger step size while the taps converge
-                void *pm = nullptr;
-                if ((rc = scratch(6, sizeof(R), &pm))) return rc;
-                const R v = (R)prefix_mu;
-                QH_HIP(hipMemcpyAsync(pm, &v, sizeof(R), hipMemcpyHostToDevice, g_stream));
-                QH_HIP(hipStreamSynchronize(g_stream));     // `v` lives on this stack frame
-                p.mu = (R *)pm;
-            }
-            QH_HIP(hipMemcpyAsync(wtmp, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
-            if ((rc = launch_any<R>(p))) return rc;
-            QH_HIP(hipMemcpyAsync(wx, wtmp, wbytes, hipMemcpyDeviceToDevice, g_stream));
-            begin = prefix;
-        }
-        if (begin >= TrSyms) continue;
-        TrainArgs<R> s = a;
-        s.nseg = nseg; s.seg_begin = begin; s.seg_len = (TrSyms - begin + nseg - 1) / nseg; s.seg_iter = it;
-        s.nseg = (int)((TrSyms - begin + s.seg_len - 1) / s.seg_len);     // drop empty trailing segments
-        s.wx_out = (Cx<R> *)wtmp;
-        QH_HIP(hipMemcpyAsync(wtmp, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));   // rows of unselected modes stay as they are
-        if ((rc = launch_any<R>(s))) return rc;
-        QH_HIP(hipMemcpyAsync(wx, wtmp, wbytes, hipMemcpyDeviceToDevice, g_stream));
-    }
-    return QH_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Parallel-in-time training (opt-in; DESIGN.md 3.2 tier B+): waveform relaxation over S contiguous segments of a sweep.
-// Pass p trains all segments CONCURRENTLY with the exact kernels (segments = channels of a batch that overlap in the
-// capture), segment s starting from the taps segment s-1 ended with in pass p-1 (segment 0 always from the true initial
-// taps; pass 0: everybody from the initial taps).  The map is triangular in s, so its only fixed point is the sequential
-// recurrence, reached exactly after S passes; because the LMS recursion forgets its initial condition within a few
-// 1/(mu lambda) steps in every direction the signal excites, two or three passes already reproduce outputs and error
-// trace to ~1e-4 and the symbol decisions exactly - what differs from the reference at that point are tap components in
-// the (near-)null space of the input covariance, which move by a slow random walk and are handed on one segment per pass.
-// pass_change (host, npass entries, optional): largest change of a segment's end taps against the previous pass.
-// Blind / decision-directed methods with a fixed step; the TrSyms % (S*64) last steps run sequentially afterwards.
-template <typename R>
-int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu_dev, void *wx, int ntaps,
-                  const int64_t *modes, int nsel, const void *symbols, int64_t nsy, int method, void *err, int zero_err,
-                  int nseg, int npass, double *pass_change, int64_t prefix = 0)
-{
-    int rc = ensure_init();
-    if (rc) return rc;
-    if (method < 0 || method > QH_M_SBD_DATA) { set_error("unknown equaliser method id"); return QH_ERR_METHOD; }
-    QH_REQUIRE(nmodes >= 1 && ntaps >= 1 && os >= 1 && Niter >= 0 && TrSyms >= 0 && nsel >= 1 && nsel <= 16 && nsy >= 1, "train_equaliser: bad sizes");
-    QH_REQUIRE(TrSyms == 0 || (TrSyms - 1) * os + ntaps <= L, "train_equaliser: field shorter than TrSyms*os + ntaps");
-    QH_REQUIRE(nseg >= 1 && nseg <= 4096 && npass >= 1 && npass <= 4096, "train_equaliser: bad segment / pass count");
-    QH_REQUIRE(method != QH_M_SBD_DATA, "train_equaliser: parallel-in-time training is not available for data-aided methods");
-    for (int j = 0; j < nsel; j++) QH_REQUIRE(modes[j] >= 0 && modes[j] < nmodes, "train_equaliser: mode number >= nmodes");
-    const int ntot = nmodes * ntaps;
-    if (zero_err) QH_HIP(hipMemsetAsync(err, 0, (size_t)nmodes * TrSyms * Niter * sizeof(Cx<R>), g_stream));
-    if (pass_change) for (int p = 0; p < npass; p++) pass_change[p] = 0;
-    if (TrSyms == 0 || Niter == 0) return QH_OK;
-    // `prefix` steps of the FIRST sweep run sequentially (exact kernels) so that every segment starts from converged,
-    // phase-locked taps; the segments then cover [prefix, TrSyms) in the first sweep and everything in later ones
-    if (prefix < 0) prefix = 0;
-    prefix = prefix / LA_B * LA_B;
-    if (prefix > TrSyms) prefix = TrSyms / LA_B * LA_B;
-    const int64_t seg = (TrSyms - prefix) / nseg / LA_B * LA_B;       // one segment length for all sweeps
-    const int S = nseg;
-    // which exact form takes the segments (same rules as the sequential path, fixed step)
-    const char *force = trainer_force();
-    bool bi_ok = force[0] != 'd' && force[0] != 'l' && seg >= 2 * LA_B && bi_supported(method, 0, nmodes, ntaps, os, seg, nsy, sizeof(Cx<R>));
-    const bool decision = method == QH_M_SBD || method == QH_M_MDDMA || method == QH_M_DD;
-    void *dd_table = nullptr;
-    int dd_npart = -1;
-    if (bi_ok && decision) {
-        if ((rc = slicer_tables<R>(symbols, nmodes, nsy, modes, nsel, &dd_table, &dd_npart))) return rc;
-        bi_ok = dd_npart == 1 || dd_npart == 3 || dd_npart == 7 || dd_npart == 15;
-    }
-    const bool la_ok = force[0] != 'd' && seg >= 2 * LA_B && la_supported(method, 0, nmodes, ntaps, os, seg, nsy);
-    const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
-    const bool use_bi = bi_ok && (partitioned || decision || !la_ok || force[0] == 'i');
-    if (S == 1 || !(use_bi || la_ok))          // nothing to parallelise / no block form for this call: the sequential path
-        return train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, 0, symbols, nsy, method, err, 0);
-    const bool pair_tab = use_bi ? la_shape_ok(nmodes, ntaps, os) : true;
-    const size_t wset = (size_t)nmodes * ntot;                        // one tap set
-    void *wbuf = nullptr;
-    if ((rc = scratch(2, 2 * (size_t)S * wset * sizeof(Cx<R>), &wbuf))) return rc;
-    Cx<R> *wA = (Cx<R> *)wbuf, *wB = wA + (size_t)S * wset;
-    std::vector<Cx<R>> hprev, hcur;
-    if (pass_change) { hprev.resize((size_t)S * wset); hcur.resize((size_t)S * wset); }
-    // Gram tables of the segments: once, shared by passes and sweeps
-    void *G = nullptr;
-    const size_t gbytes = (pair_tab ? gram_bytes<R>(seg) : gram_cur_bytes<R>(seg)) * (size_t)S;
-    auto build_tables = [&](int64_t first, void **Gout) -> int {        // tables of the S segments starting at step `first`
-        const Cx<R> *E0 = (const Cx<R> *)E + first * os;
-        const int64_t Lb = L - first * os - (int64_t)(S - 1) * seg * os;
-        return pair_tab ? gram_build<R>(E0, nmodes, Lb, os, ntaps, seg, Gout, S, L, seg * os)
-                        : gram_cur_build<R>(E0, nmodes, Lb, os, ntaps, seg, Gout, S, L, seg * os);
-    };
-    (void)gbytes;
-    LaArgs<R> la;
-    la.symbols = (const Cx<R> *)symbols; la.err = (Cx<R> *)err; la.gpair = pair_tab ? 1 : 0;
-    la.mu = mu_dev; la.mu_out = nullptr; la.mu_cs = 0; la.mu_ms = 0;
-    la.Lp = L; la.TrSyms = seg; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter;
-    la.nmodes = nmodes; la.ntaps = ntaps; la.os = os; la.nsel = nsel; la.method = method;
-    la.nch = S; la.E_cs = seg * os; la.wx_cs = (int64_t)wset; la.err_cs = seg;
-    la.G_cs = (int64_t)((pair_tab ? gram_bytes<R>(seg) : gram_cur_bytes<R>(seg)) / sizeof(GramPair<R>));
-    for (int j = 0; j < 16; j++) la.modes[j] = j < nsel ? modes[j] : 0;
-    if (use_bi && decision) { la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV; }
-    la.prof = nullptr;
-    const size_t wbytes = wset * sizeof(Cx<R>);
-    int64_t tables_for = -1;
-    for (int it = 0; it < Niter; it++) {
-        const int64_t first = it == 0 ? prefix : 0;                    // the segments of this sweep start here
-        if (first >= 2 * LA_B) {                                        // sequential prefix: the exact kernels on [0, prefix)
-            LaArgs<R> lp = la;
-            void *Gp = nullptr;
-            rc = pair_tab ? gram_build<R>(E, nmodes, L, os, ntaps, first, &Gp, 1, L, 0) : gram_cur_build<R>(E, nmodes, L, os, ntaps, first, &Gp, 1, L, 0);
-            if (rc) return rc;
-            lp.E = (const Cx<R> *)E; lp.L = L; lp.TrSyms = first; lp.nch = 1; lp.wx = (Cx<R> *)wx; lp.G = (const GramPair<R> *)Gp;
-            lp.err_off = (int64_t)it * TrSyms;
-            if ((rc = use_bi ? launch_bi<R>(lp) : launch_la<R>(lp))) return rc;
-            tables_for = -1;                                            // the prefix table replaced the segments' tables
-        }
-        if (tables_for != first) {
-            if ((rc = build_tables(first, &G))) return rc;
-            tables_for = first;
-        }
-        la.E = (const Cx<R> *)E + first * os; la.L = L - first * os - (int64_t)(S - 1) * seg * os; la.G = (const GramPair<R> *)G;
-        // pass 0: every segment from the taps at the start of the segmented part
-        for (int s2 = 0; s2 < S; s2++) QH_HIP(hipMemcpyAsync(wA + (size_t)s2 * wset, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
-        for (int p = 0; p < npass; p++) {
-            la.wx = wA; la.err_off = (int64_t)it * TrSyms + first;
-            if ((rc = use_bi ? launch_bi<R>(la) : launch_la<R>(la))) return rc;
-            if (pass_change) {                       // diagnostic: how far did the segments' end taps move since the last pass?
-                QH_HIP(hipMemcpyAsync(hcur.data(), wA, (size_t)S * wbytes, hipMemcpyDeviceToHost, g_stream));
-                QH_HIP(hipStreamSynchronize(g_stream));
-                if (p > 0) {
-                    double m = 0;
-                    for (size_t q = 0; q < hcur.size(); q++) {
-                        const double d = fabs((double)hcur[q].re - (double)hprev[q].re) + fabs((double)hcur[q].im - (double)hprev[q].im);
-                        if (d > m || d != d) m = d;
-                    }
-                    if (m > pass_change[p] || m != m) pass_change[p] = m;
-                } else if (it == 0) {
-                    pass_change[0] = -1;             // no previous pass to compare with
-                }
-                hprev.swap(hcur);
-            }
-            if (p + 1 < npass) {                     // next pass: segment s starts where segment s-1 just ended
-                QH_HIP(hipMemcpyAsync(wB, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
-                QH_HIP(hipMemcpyAsync(wB + wset, wA, (size_t)(S - 1) * wbytes, hipMemcpyDeviceToDevice, g_stream));
-                Cx<R> *t = wA; wA = wB; wB = t;
-            }
-        }
-        // the last segment's end taps are the sweep's; rows of unselected modes were carried along unchanged
-        QH_HIP(hipMemcpyAsync(wx, wA + (size_t)(S - 1) * wset, wbytes, hipMemcpyDeviceToDevice, g_stream));
-        const int64_t done = first + (int64_t)S * seg;
-        if (done < TrSyms) {                         // remainder of the sweep, sequentially (direct form, one segment per mode)
-            TrainArgs<R> a;
-            a.E = (const Cx<R> *)E; a.wx = (Cx<R> *)wx; a.symbols = (const Cx<R> *)symbols; a.err = (Cx<R> *)err; a.mu = mu_dev;
-            a.L = L; a.TrSyms = TrSyms; a.nsy = nsy; a.nmodes = nmodes; a.ntaps = ntaps; a.Niter = Niter; a.os = os;
-            a.nsel = nsel; a.adaptive = 0; a.method = method;
-            for (int j = 0; j < 16; j++) a.modes[j] = j < nsel ? modes[j] : 0;
-            a.win_start = nullptr; a.win_len = 0; a.nwin = 0; a.win_mu = nullptr; a.e_off = 0;
-            a.nseg = 1; a.seg_begin = done; a.seg_len = TrSyms - done; a.seg_iter = it; a.wx_out = wB;
-            QH_HIP(hipMemcpyAsync(wB, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
-            if ((rc = launch_any<R>(a))) return rc;
-            QH_HIP(hipMemcpyAsync(wx, wB, wbytes, hipMemcpyDeviceToDevice, g_stream));
-        }
-    }
-    return QH_OK;
 }
 
 // Batch of independent equaliser runs on windows of one capture (host pointers).  Equivalent to calling train_host once per
@@ -846,7 +667,7 @@ int train_windows_host(const void *E, int nmodes, int64_t L, const int64_t *win_
         a.L = L; a.TrSyms = TrSyms; a.nsy = nsy; a.nmodes = nmodes; a.ntaps = ntaps; a.Niter = Niter; a.os = os;
         a.nsel = nsel; a.adaptive = adaptive ? 1 : 0; a.method = method;
         for (int j = 0; j < 16; j++) a.modes[j] = j < nsel ? modes[j] : 0;
-        a.nseg = 0; a.seg_begin = 0; a.seg_len = 0; a.seg_iter = 0; a.wx_out = (Cx<R> *)dwo.p;
+        a.nseg = 0; a.seg_begin = 0; a.seg_len = 0; a.seg_extra = 0; a.seg_tail = 0; a.seg_iter = 0; a.skip = nullptr; a.wx_out = (Cx<R> *)dwo.p;
         a.win_start = (const int64_t *)dst.p; a.win_len = win_len; a.nwin = nwin; a.win_mu = (R *)dmo.p; a.e_off = 0;
         if ((rc = launch_any<R>(a))) return rc;
     }

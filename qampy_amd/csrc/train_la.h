@@ -235,7 +235,42 @@ template <typename R> struct LaArgs {
     int64_t E_cs, wx_cs, err_cs, G_cs, mu_cs, mu_ms;     // mu_ms: stride between the step sizes of the selected modes (0: one mu)
     int64_t modes[16];
     unsigned long long *prof;   // optional [4 waves][4] cycle counters of workgroup 0 (qh_la_profile), else nullptr
+    // segments of ONE sweep as the channels of a batch (parallel-in-time training, train_pit.h): seg != 0 -> channel c
+    // trains the steps [c TrSyms + 64 min(c, seg_extra), ...) of the capture at E: TrSyms steps, one block more for the first
+    // seg_extra segments, seg_tail (< 64) more for the last one; E, err and G are the whole sweep's arrays, wx per segment
+    int seg;
+    int64_t seg_extra, seg_tail;
+    const int *skip;            // optional device flag: non-zero -> the launch does nothing (device-side early termination)
 };
+
+// per-channel view of the arrays of a launch (channel bank: fixed strides; segmented sweep: see LaArgs::seg)
+template <typename R> struct LaView {
+    const Cx<R> *E;
+    Cx<R> *wx, *err;
+    const GramPair<R> *G;
+    int64_t L, TrSyms;
+};
+template <typename R> __device__ __forceinline__ LaView<R> la_view(const LaArgs<R> &a, int64_t ch)
+{
+    LaView<R> v;
+    v.wx = a.wx + ch * a.wx_cs;
+    if (a.seg) {
+        const int64_t nx = ch < a.seg_extra ? ch : a.seg_extra;
+        const int64_t start = ch * a.TrSyms + nx * LA_B;
+        v.TrSyms = a.TrSyms + (ch < a.seg_extra ? LA_B : 0) + (ch == a.nch - 1 ? a.seg_tail : 0);
+        v.E = a.E + start * a.os;
+        v.err = a.err + start;
+        v.G = a.G + start * (a.gpair ? LA_B : GRAM_TRI / 2 / LA_B);
+        v.L = a.L - start * a.os;
+    } else {
+        v.TrSyms = a.TrSyms;
+        v.E = a.E + ch * a.E_cs;
+        v.err = a.err + ch * a.err_cs;
+        v.G = a.G + ch * a.G_cs;
+        v.L = a.L;
+    }
+    return v;
+}
 
 template <typename R> struct LaLds {
     Cx<R> cbuf[2][LA_B];             // chain -> helpers: c_l of the block just finished
@@ -246,21 +281,27 @@ template <typename R> struct LaLds {
 template <typename R, int METHOD, int NPART>
 __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
 {
-    // independent captures of a channel bank (blockIdx.y): same shapes, own arrays
+    if (a.skip && *a.skip) return;
+    // independent captures of a channel bank / segments of a sweep (blockIdx.y): same shapes, own arrays
     const int64_t ch = blockIdx.y;
-    const Cx<R> *const aE = a.E + ch * a.E_cs;
-    Cx<R> *const awx = a.wx + ch * a.wx_cs;
-    Cx<R> *const aerr = a.err + ch * a.err_cs;
-    const GramPair<R> *const aG = a.G + ch * a.G_cs;
+    const LaView<R> vw = la_view(a, ch);
+    const Cx<R> *const aE = vw.E;
+    Cx<R> *const awx = vw.wx;
+    Cx<R> *const aerr = vw.err;
+    const GramPair<R> *const aG = vw.G;
+    const int64_t aL = vw.L;
     const R *const amu = a.mu + ch * a.mu_cs + (int64_t)blockIdx.x * a.mu_ms;
     extern __shared__ __attribute__((aligned(16))) char la_smem[];
     LaLds<R> &lds = *reinterpret_cast<LaLds<R> *>(la_smem);
     Cx<R> *lds_win = reinterpret_cast<Cx<R> *>(la_smem + sizeof(LaLds<R>));   // [LA_NH][2][nmodes][wpitch] helper sample windows
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Roles: 0 = chain, 1..3 = helpers.  The chain wave issues ~4x the instructions of a helper; when several workgroups
+    // share a CU (segment / channel batches) the roles are rotated with the workgroup index so that the chain waves of
+    // co-resident workgroups land on different SIMDs instead of all on the one that hosts wave 0.
+    const int wave = __builtin_amdgcn_readfirstlane(((threadIdx.x >> 6) + blockIdx.x + blockIdx.y) & 3);
     const int mode = (int)a.modes[blockIdx.x];
     const int ntot = a.nmodes * a.ntaps;
-    const int64_t TrSyms = a.TrSyms;
+    const int64_t TrSyms = vw.TrSyms;
     const int nblk = (int)((TrSyms + LA_B - 1) / LA_B);
     const Cx<R> *sy = a.symbols + (size_t)mode * a.sy_pitch;
 
@@ -364,7 +405,7 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
     }
     auto stage_load = [&](Cx<R> (&r)[WREG], int kb) {
         const int64_t base = (int64_t)kb * LA_B * os_;
-        if (base + wpitch <= a.L) {                                    // whole window inside the capture: no clamping
+        if (base + wpitch <= aL) {                                    // whole window inside the capture: no clamping
             const Cx<R> *pb = aE + base;
 #pragma unroll
             for (int q = 0; q < WREG; q++) r[q] = ldg(pb + soff[q]);
@@ -373,7 +414,7 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
             for (int q = 0; q < WREG; q++) {
                 const int64_t row = soff[q] / a.Lp * a.Lp;
                 int64_t g = base + (soff[q] - row);
-                if (g > a.L - 1) g = a.L - 1;
+                if (g > aL - 1) g = aL - 1;
                 r[q] = ldg(aE + row + g);
             }
         }

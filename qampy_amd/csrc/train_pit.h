@@ -1,0 +1,779 @@
+// Parallel-in-time training ("tier B", opt-in; include/qampy_hip.h): the sweep
+//        w_{i+1} = w_i + mu errfn(w_i . x_i) conj(x_i) ,   i = 0 .. TrSyms-1     (pythran_equalisation.py:165-172)
+// is cut into S contiguous segments that the exact kernels train concurrently (one workgroup per segment and output
+// mode: the segments are the channels of a batch that happen to be adjacent in one capture) and that waveform relaxation
+// makes consistent: pass p starts segment s from the end taps of segment s-1 in pass p-1.  What is sequential is
+//   * a gear-shifted acquisition on a prefix when the start taps are not converged (cold start), and
+//   * the number of passes (each costs one segment length of dependent steps),
+// and both end on device-side criteria (error plateau; boundary defect), so the host only enqueues.
+//
+// Buffers per call (scratch slot 2):  X (S tap sets) start taps of the current pass,  Y (S tap sets) trained in place,
+// rot (S x nsel) pass-0 phase rotations, z (S x nsel) 4th-power sums, dfc (S x nsel) boundary defects.
+#pragma once
+#include "train_impl.h"
+
+namespace qh {
+
+typedef qh_pit_report PitCtrl;
+
+constexpr int PIT_PROBE = 128;      // symbol periods of the capture a boundary defect is measured on
+constexpr int PIT_SEEDWIN = 1024;   // symbol periods of a segment's head the phase seed is estimated on
+
+// symmetry group of an error function: errfn(g y) = g errfn(y).  0: every phase (cma, rde); n: the n-th roots of unity
+__host__ __device__ inline int pit_symmetry(int method)
+{
+    switch (method) {
+    case QH_M_CMA: case QH_M_SGNCMA: case QH_M_RDE: return 0;
+    case QH_M_CMA2: return 2;
+    default: return 4;               // mcma, mrde, sbd, mddma, dd on the 4-fold symmetric QAM alphabets
+    }
+}
+
+struct PitSeg {                      // segment grid of a sweep: see LaArgs::seg
+    int S;
+    int64_t len, extra, tail;
+    __host__ __device__ int64_t start(int64_t s) const { return s * len + (s < extra ? s : extra) * 64; }
+    __host__ __device__ int64_t steps(int64_t s) const { return len + (s < extra ? 64 : 0) + (s == S - 1 ? tail : 0); }
+};
+
+// ------------------------------------------------------------------------------------------------ control kernels
+// power of the capture, gear-shifted step size, report header
+template <typename R>
+__global__ void __launch_bounds__(256) pit_setup_kernel(const Cx<R> *E, int nmodes, int64_t L, int64_t npow, int ntot, const R *mu, double gear,
+                                                        double bound, double tol, PitSeg sg, PitCtrl *c, R *mu_acq)
+{
+    __shared__ double red[256];
+    double acc = 0;
+    for (int k = 0; k < nmodes; k++)
+        for (int64_t i = threadIdx.x; i < npow; i += 256) {
+            const Cx<R> v = E[(size_t)k * L + i];
+            acc += (double)v.re * v.re + (double)v.im * v.im;
+        }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double p = red[0] / ((double)nmodes * (double)npow);
+        const double m = (double)*mu;
+        double ma = gear * m;
+        const double cap = bound / ((double)ntot * (p > 1e-30 ? p : 1e-30));
+        if (ma > cap) ma = cap;
+        if (!(ma > m)) ma = m;
+        c->segments = sg.S; c->seg_len = sg.len; c->mu = m; c->mu_acq = ma; c->power = p; c->tol = tol;
+        c->passes = 0; c->converged = 0; c->acq_chunks = 0; c->acq_steps = 0; c->acq_done = 0; c->done = 0; c->diverged = 0; c->corr_on = 0; c->gain = 0; c->out_power = 0;
+        for (int i = 0; i < QH_PIT_MAXPASS; i++) c->defect[i] = -1;
+        for (int i = 0; i < QH_PIT_MAXCHUNK; i++) c->acq_err[i] = -1;
+        *mu_acq = (R)ma;
+    }
+}
+
+// start of a sweep's relaxation: passes of this sweep count from zero
+static __global__ void pit_sweep_kernel(PitCtrl *c)
+{
+    c->done = 0; c->converged = 0; c->passes = 0;
+    for (int i = 0; i < QH_PIT_MAXPASS; i++) c->defect[i] = -1;
+}
+
+// after an acquisition chunk: mean |err|^2 over the chunk -> plateau / divergence test
+template <typename R>
+__global__ void __launch_bounds__(256) pit_acq_monitor_kernel(const Cx<R> *err, int64_t err_pitch, int64_t step0, int64_t n, int nsel,
+                                                              const int64_t *modes_dev, double plateau, PitCtrl *c)
+{
+    if (c->acq_done) return;
+    __shared__ double red[256];
+    double acc = 0;
+    for (int j = 0; j < nsel; j++) {
+        const Cx<R> *row = err + (size_t)modes_dev[j] * err_pitch + step0;
+        for (int64_t i = threadIdx.x; i < n; i += 256) {
+            const Cx<R> v = row[i];
+            acc += (double)v.re * v.re + (double)v.im * v.im;
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double v = red[0] / ((double)n * nsel);
+        const int k = c->acq_chunks;
+        if (k < QH_PIT_MAXCHUNK) c->acq_err[k] = v;
+        c->acq_chunks = k + 1;
+        c->acq_steps = step0 + n;
+        if (!(v == v) || v > 1e30) { c->diverged = 1; c->acq_done = 1; return; }
+        if (k >= 1) {
+            const double prev = c->acq_err[k - 1 < QH_PIT_MAXCHUNK ? k - 1 : QH_PIT_MAXCHUNK - 1];
+            if (v > 100 * c->acq_err[0]) { c->diverged = 1; c->acq_done = 1; return; }
+            if (v > plateau * prev) c->acq_done = 1;
+        }
+    }
+}
+
+// a diverged acquisition (step size too bold for this capture) is undone: the sweep then starts from the original taps
+template <typename R> __global__ void pit_acq_finish_kernel(Cx<R> *wx, const Cx<R> *w_start, int n, PitCtrl *c)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c->diverged && i < n) wx[i] = w_start[i];
+}
+
+// z[s, j] = sum over the head of segment s of (w[mode_j] . x_i)^4
+template <typename R>
+__global__ void __launch_bounds__(256) pit_phase_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, const Cx<R> *wx, int ntaps, PitSeg sg,
+                                                        const int64_t *modes_dev, int nwin, double *z)
+{
+    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
+    Cx<R> *w = reinterpret_cast<Cx<R> *>(pit_smem);
+    __shared__ double rr[256], ri[256];
+    const int s = blockIdx.x, j = blockIdx.y;
+    const int mode = (int)modes_dev[j];
+    const int ntot = nmodes * ntaps;
+    for (int f = threadIdx.x; f < ntot; f += 256) w[f] = wx[(size_t)mode * ntot + f];
+    __syncthreads();
+    const int64_t st = sg.start(s);
+    int64_t n = sg.steps(s);
+    if (n > nwin) n = nwin;
+    double zr = 0, zi = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        R yr = 0, yi = 0;
+        for (int k = 0; k < nmodes; k++) {
+            const Cx<R> *x = E + (size_t)k * L + (st + i) * os;
+            const Cx<R> *wk = w + k * ntaps;
+            for (int t = 0; t < ntaps; t++) {
+                const Cx<R> a = x[t], b = wk[t];
+                yr = fma_(a.re, b.re, fma_(-a.im, b.im, yr));
+                yi = fma_(a.re, b.im, fma_(a.im, b.re, yi));
+            }
+        }
+        const double y2r = (double)yr * yr - (double)yi * yi, y2i = 2.0 * yr * yi;
+        zr += y2r * y2r - y2i * y2i;
+        zi += 2.0 * y2r * y2i;
+    }
+    rr[threadIdx.x] = zr; ri[threadIdx.x] = zi;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (threadIdx.x < q) { rr[threadIdx.x] += rr[threadIdx.x + q]; ri[threadIdx.x] += ri[threadIdx.x + q]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { z[2 * ((size_t)s * gridDim.y + j)] = rr[0]; z[2 * ((size_t)s * gridDim.y + j) + 1] = ri[0]; }
+}
+
+// rot[s, j] = exp(-i phi_s): phi = arg(-z)/4 (E[s^4] is negative real for the QAM alphabets), unwrapped along the segments
+static __global__ void __launch_bounds__(256) pit_unwrap_kernel(const double *z, int S, int nsel, double *rot)
+{
+    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
+    double *phi = reinterpret_cast<double *>(pit_smem);       // [S]
+    int *jump = reinterpret_cast<int *>(phi + S);            // [S]
+    const double q = 1.5707963267948966;
+    for (int j = 0; j < nsel; j++) {
+        for (int s = threadIdx.x; s < S; s += 256) {
+            const double zr = z[2 * ((size_t)s * nsel + j)], zi = z[2 * ((size_t)s * nsel + j) + 1];
+            phi[s] = (zr == 0 && zi == 0) ? 0.0 : atan2(-zi, -zr) / 4;
+        }
+        __syncthreads();
+        for (int s = threadIdx.x; s < S; s += 256) jump[s] = s == 0 ? 0 : (int)rint((phi[s - 1] - phi[s]) / q);
+        __syncthreads();
+        if (threadIdx.x == 0) { int a = 0; for (int s = 0; s < S; s++) { a += jump[s]; jump[s] = a; } }
+        __syncthreads();
+        for (int s = threadIdx.x; s < S; s += 256) {
+            const double p = phi[s] + q * jump[s];
+            rot[2 * ((size_t)s * nsel + j)] = cos(p);
+            rot[2 * ((size_t)s * nsel + j) + 1] = -sin(p);
+        }
+        __syncthreads();
+    }
+}
+
+// X[s] = wx with the rows of the selected modes rotated by rot[s, j] (rot == nullptr: plain copies)
+template <typename R>
+__global__ void __launch_bounds__(256) pit_seed_kernel(const Cx<R> *wx, int nmodes, int ntot, const int64_t *modes_dev, int nsel, const double *rot, Cx<R> *X)
+{
+    const int s = blockIdx.x;
+    const int n = nmodes * ntot;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int row = e / ntot;
+        Cx<R> v = wx[e];
+        if (rot) {
+            for (int j = 0; j < nsel; j++)
+                if ((int)modes_dev[j] == row) {
+                    const double c = rot[2 * ((size_t)s * nsel + j)], d = rot[2 * ((size_t)s * nsel + j) + 1];
+                    const double vr = (double)v.re * c - (double)v.im * d, vi = (double)v.re * d + (double)v.im * c;
+                    v = Cx<R>{(R)vr, (R)vi};
+                    break;
+                }
+        }
+        X[(size_t)s * n + e] = v;
+    }
+}
+
+// defect of boundary b = blockIdx.x + 1: outputs of the start taps X[b] against the end taps Y[b-1] of the left neighbour
+// on PIT_PROBE symbol periods from the boundary on, modulo the symmetry of the error function
+template <typename R>
+__global__ void __launch_bounds__(PIT_PROBE) pit_defect_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, int ntaps, PitSeg sg, int64_t TrSyms,
+                                                                const int64_t *modes_dev, const Cx<R> *X, const Cx<R> *Y, int sym, const PitCtrl *c, double *dfc, double *pw, double *gph)
+{
+    if (c->done) return;
+    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
+    Cx<R> *wa = reinterpret_cast<Cx<R> *>(pit_smem);
+    const int ntot = nmodes * ntaps;
+    Cx<R> *wb = wa + ntot;
+    __shared__ double red[4][PIT_PROBE];
+    const int b = blockIdx.x + 1, j = blockIdx.y;
+    const int mode = (int)modes_dev[j];
+    const size_t wset = (size_t)nmodes * ntot;
+    for (int f = threadIdx.x; f < ntot; f += PIT_PROBE) {
+        wa[f] = X[(size_t)b * wset + (size_t)mode * ntot + f];
+        wb[f] = Y[(size_t)(b - 1) * wset + (size_t)mode * ntot + f];
+    }
+    __syncthreads();
+    const int64_t st = sg.start(b) + threadIdx.x;
+    double aa = 0, bb = 0, cr = 0, ci = 0;
+    if (st < TrSyms) {
+        R ar = 0, ai = 0, br = 0, bi = 0;
+        for (int k = 0; k < nmodes; k++) {
+            const Cx<R> *x = E + (size_t)k * L + st * os;
+            for (int t = 0; t < ntaps; t++) {
+                const Cx<R> v = x[t], p = wa[k * ntaps + t], q = wb[k * ntaps + t];
+                ar = fma_(v.re, p.re, fma_(-v.im, p.im, ar)); ai = fma_(v.re, p.im, fma_(v.im, p.re, ai));
+                br = fma_(v.re, q.re, fma_(-v.im, q.im, br)); bi = fma_(v.re, q.im, fma_(v.im, q.re, bi));
+            }
+        }
+        aa = (double)ar * ar + (double)ai * ai;
+        bb = (double)br * br + (double)bi * bi;
+        cr = (double)br * ar + (double)bi * ai;          // yB conj(yA)
+        ci = (double)bi * ar - (double)br * ai;
+    }
+    red[0][threadIdx.x] = aa; red[1][threadIdx.x] = bb; red[2][threadIdx.x] = cr; red[3][threadIdx.x] = ci;
+    __syncthreads();
+    for (int q = PIT_PROBE / 2; q > 0; q >>= 1) {
+        if (threadIdx.x < q)
+            for (int u = 0; u < 4; u++) red[u][threadIdx.x] += red[u][threadIdx.x + q];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double A = red[0][0], B = red[1][0], Cr = red[2][0], Ci = red[3][0];
+        double proj, gr = 1, gi = 0;                         // best group element g (yB ~ g yA) and Re(conj(g) c)
+        if (sym == 0) {
+            proj = sqrt(Cr * Cr + Ci * Ci);
+            if (proj > 0) { gr = Cr / proj; gi = Ci / proj; }
+        } else {
+            const double step = 6.283185307179586 / sym;
+            const double k = rint(atan2(Ci, Cr) / step) * step;
+            gr = cos(k); gi = sin(k);
+            proj = Cr * gr + Ci * gi;
+        }
+        gph[2 * ((size_t)blockIdx.x * gridDim.y + j)] = gr; gph[2 * ((size_t)blockIdx.x * gridDim.y + j) + 1] = gi;
+        double d2 = (A + B - 2 * proj) / (B > 1e-300 ? B : 1e-300);
+        if (d2 < 0) d2 = 0;
+        dfc[(size_t)blockIdx.x * gridDim.y + j] = (A == A && B == B) ? sqrt(d2) : 1e30;
+        pw[(size_t)blockIdx.x * gridDim.y + j] = B / PIT_PROBE;
+    }
+}
+
+// mean gain g of the error function around a converged output of power Py: d errfn / dy ~ -g (holomorphic part, decisions
+// held), so that a tap perturbation decays like exp(-mu g Rc t).  cma / mcma from their constants; the radius- and decision-
+// directed functions behave like (s - y) |s|^2 resp. (s - y) around the decided point.  0: no usable linearisation.
+template <typename R> __device__ inline double pit_gain(int method, double Py, Cx<R> c0)
+{
+    switch (method) {
+    case QH_M_CMA: case QH_M_SGNCMA: return 2 * Py - (double)c0.re;
+    case QH_M_MCMA: return 1.5 * Py - 0.5 * ((double)c0.re + (double)c0.im);
+    case QH_M_RDE: case QH_M_MRDE: case QH_M_MDDMA: return Py;
+    case QH_M_DD: return 1.0;
+    case QH_M_SBD: return 0.866 * sqrt(Py / 2);
+    default: return 0.0;
+    }
+}
+
+// end of a pass: largest boundary defect -> report; the pass's end taps become the sweep's result; converged -> later passes skip
+template <typename R>
+__global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, const double *pw, int nb, const Cx<R> *Ylast, int n, Cx<R> *wx, int method,
+                                                         const Cx<R> *sy0, int want_corr, PitCtrl *c)
+{
+    if (c->done) return;
+    __shared__ double red[256], redp[256];
+    double m = 0, ps = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        const double v = dfc[i];
+        m = (v > m || !(v == v)) ? (v == v ? v : 1e30) : m;
+        ps += pw[i];
+    }
+    red[threadIdx.x] = m; redp[threadIdx.x] = ps;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
+            redp[threadIdx.x] += redp[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < n; e += 256) wx[e] = Ylast[e];
+    if (threadIdx.x == 0) {
+        const int p = c->passes;
+        if (p < QH_PIT_MAXPASS) c->defect[p] = red[0];
+        c->passes = p + 1;
+        if (p == 0) {
+            const double Py = redp[0] / nb;
+            const double g = pit_gain<R>(method, Py, sy0[0]);
+            c->out_power = Py; c->gain = g;
+            c->corr_on = (want_corr && g > 0 && g == g) ? 1 : 0;
+        } else if (!(red[0] < c->defect[p - 1 < QH_PIT_MAXPASS ? p - 1 : QH_PIT_MAXPASS - 1])) {
+            c->corr_on = 0;            // the correction did not help: plain relaxation from here on
+        }
+        if (red[0] < c->tol) { c->converged = 1; c->done = 1; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ coarse correction
+typedef double2 Z;
+__device__ __forceinline__ Z zmul(Z a, Z b) { return Z{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+
+// Rc[f][f'] = sum over a subsample of the training windows of conj(x_i[f]) x_i[f'],  x_i[f = k ntaps + t] = E[k, i os + t].
+// Block b stages PIT_COVW windows in LDS and writes its partial sums to part[b]; pit_cov_reduce_kernel adds the blocks up.
+constexpr int PIT_COVW = 64, PIT_COVB = 128;                       // windows per block, blocks
+template <typename R, int EPT>
+__global__ void __launch_bounds__(256) pit_cov_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, int nwin, Z *part)
+{
+    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
+    Cx<R> *x = reinterpret_cast<Cx<R> *>(pit_smem);               // [PIT_COVW][ntot]
+    const int ntot = nmodes * ntaps;
+    const int nent = ntot * ntot;
+    const int64_t stride = TrSyms / nwin > 0 ? TrSyms / nwin : 1;
+    for (int e = threadIdx.x; e < PIT_COVW * ntot; e += 256) {
+        const int w = e / ntot, f = e - w * ntot;
+        const int k = f / ntaps, t = f - k * ntaps;
+        const int64_t i = ((int64_t)blockIdx.x * PIT_COVW + w) * stride;
+        x[e] = (i < TrSyms && (int64_t)blockIdx.x * PIT_COVW + w < nwin) ? E[(size_t)k * L + i * os + t] : Cx<R>{0, 0};
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int q = 0; q < EPT; q++) {
+        const int e = threadIdx.x + 256 * q;
+        if (e >= nent) break;
+        const int fa = e / ntot, fb = e - fa * ntot;
+        float ar = 0, ai = 0;
+#pragma unroll 8
+        for (int w = 0; w < PIT_COVW; w++) {
+            const Cx<R> u = x[w * ntot + fa], v = x[w * ntot + fb];
+            ar += (float)(u.re * v.re + u.im * v.im);
+            ai += (float)(u.re * v.im - u.im * v.re);
+        }
+        part[(size_t)blockIdx.x * nent + e] = Z{(double)ar, (double)ai};
+    }
+}
+static __global__ void __launch_bounds__(256) pit_cov_reduce_kernel(const Z *part, int nent, int nblk, Z *Rc)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nent) return;
+    double ar = 0, ai = 0;
+    for (int b = 0; b < nblk; b++) { const Z v = part[(size_t)b * nent + e]; ar += v.x; ai += v.y; }
+    Rc[e] = Z{ar, ai};
+}
+
+// B = -(mu g T / (nwin 2^PIT_SCALE)) Rc;  the 4th-order Taylor polynomial needs |B| <~ 1: checked with the trace
+constexpr int PIT_SCALE = 12;
+template <typename R>
+__global__ void __launch_bounds__(256) pit_expm_scale_kernel(const Z *Rc, int ntot, int nwin, int64_t T, const R *mu, PitCtrl *c, Z *B)
+{
+    if (c->done || !c->corr_on) return;
+    __shared__ double tr[256];
+    double t = 0;
+    for (int f = threadIdx.x; f < ntot; f += 256) t += Rc[(size_t)f * ntot + f].x;
+    tr[threadIdx.x] = t;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) tr[threadIdx.x] += tr[threadIdx.x + s]; __syncthreads(); }
+    const double a = (double)*mu * c->gain * (double)T / ((double)nwin * (double)(1 << PIT_SCALE));
+    if (!(a * tr[0] < 1.0)) { if (threadIdx.x == 0) c->corr_on = 0; return; }
+    for (int e = threadIdx.x; e < ntot * ntot; e += 256) B[e] = Z{-a * Rc[e].x, -a * Rc[e].y};
+}
+// T1 = B/6 + B2/24 ;  P0 = I + B + B2/2
+static __global__ void __launch_bounds__(256) pit_expm_poly_kernel(const Z *B, const Z *B2, int ntot, const PitCtrl *c, Z *T1, Z *P0)
+{
+    if (c->done || !c->corr_on) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= ntot * ntot) return;
+    const Z b = B[e], b2 = B2[e];
+    const double id = (e / ntot == e % ntot) ? 1.0 : 0.0;
+    T1[e] = Z{b.x / 6 + b2.x / 24, b.y / 6 + b2.y / 24};
+    P0[e] = Z{id + b.x + b2.x / 2, b.y + b2.y / 2};
+}
+// C[i][c] = (Cadd ? Cadd[i][c] : 0) + sum_k A[i][k] Bm[k][c - shift]   (columns c < shift take no product), row-major
+static __global__ void __launch_bounds__(256) pit_zgemm_kernel(const Z *A, const Z *Bm, const Z *Cadd, Z *Cm, int M, int N, int K, int shift, const PitCtrl *c)
+{
+    if (c->done) return;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
+    if (!c->corr_on) {                                          // correction off: D = d (plain relaxation)
+        if (Cadd && row < M && col < N) Cm[(size_t)row * N + col] = Cadd[(size_t)row * N + col];
+        return;
+    }
+    __shared__ Z ta[16][17], tb[16][17];
+    Z acc{0, 0};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const int ka = k0 + tx, kb = k0 + ty;
+        ta[ty][tx] = (row < M && ka < K) ? A[(size_t)row * K + ka] : Z{0, 0};
+        tb[ty][tx] = (kb < K && col < N && col >= shift) ? Bm[(size_t)kb * N + (col - shift)] : Z{0, 0};
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const Z p = zmul(ta[ty][k], tb[k][tx]); acc.x += p.x; acc.y += p.y; }
+        __syncthreads();
+    }
+    if (row < M && col < N) {
+        if (Cadd) { const Z a = Cadd[(size_t)row * N + col]; acc.x += a.x; acc.y += a.y; }
+        Cm[(size_t)row * N + col] = acc;
+    }
+}
+// Gauge fixing.  The error functions are equivariant under their symmetry group (errfn(g y) = g errfn(y)), so the trajectory
+// from rotated start taps is the rotated trajectory and a relative rotation g_s between the start taps of segment s and the
+// end taps of segment s-1 (yB ~ g_s yA, from the defect kernel) is not an error: theta_s = g_1 ... g_s brings every segment
+// into the frame of segment 0, where the boundary defects are formed and corrected (a rotation treated as an additive
+// defect would be wrong in second order and keep the iteration from converging below ~theta^2).
+static __global__ void __launch_bounds__(64) pit_gauge_kernel(const double *gph, int S, int nsel, const PitCtrl *c, double *theta)
+{
+    if (c->done) return;
+    const int j = threadIdx.x;
+    if (j >= nsel) return;
+    double tr = 1, ti = 0;
+    theta[2 * (size_t)j] = 1; theta[2 * (size_t)j + 1] = 0;
+    for (int s = 1; s < S; s++) {
+        const double gr = gph[2 * ((size_t)(s - 1) * nsel + j)], gi = gph[2 * ((size_t)(s - 1) * nsel + j) + 1];
+        const double nr = tr * gr - ti * gi, ni = tr * gi + ti * gr;
+        const double nn = sqrt(nr * nr + ni * ni);
+        tr = nr / nn; ti = ni / nn;
+        theta[2 * ((size_t)s * nsel + j)] = tr; theta[2 * ((size_t)s * nsel + j) + 1] = ti;
+    }
+}
+// D[f][s nsel + j] = theta_{s-1} Y[s-1][mode_j][f] - theta_s X[s][mode_j][f]  (s >= 1), 0 for s = 0
+template <typename R>
+__global__ void __launch_bounds__(256) pit_dvec_kernel(const Cx<R> *X, const Cx<R> *Y, int nmodes, int ntot, const int64_t *modes_dev, int nsel, int S, const PitCtrl *c,
+                                                       const double *theta, Z *D)
+{
+    if (c->done) return;
+    const int col = blockIdx.x, s = col / nsel, j = col - s * nsel;
+    const size_t wset = (size_t)nmodes * ntot, ro = (size_t)modes_dev[j] * ntot;
+    const int ncol = S * nsel;
+    for (int f = threadIdx.x; f < ntot; f += 256) {
+        Z v{0, 0};
+        if (s > 0) {
+            const Cx<R> b = Y[(size_t)(s - 1) * wset + ro + f], a = X[(size_t)s * wset + ro + f];
+            const double pr = theta[2 * (size_t)(col - nsel)], pi = theta[2 * (size_t)(col - nsel) + 1], qr = theta[2 * (size_t)col], qi = theta[2 * (size_t)col + 1];
+            v = Z{(pr * b.re - pi * b.im) - (qr * a.re - qi * a.im), (pr * b.im + pi * b.re) - (qr * a.im + qi * a.re)};
+        }
+        D[(size_t)f * ncol + col] = v;
+    }
+}
+// X[s][mode_j][f] = theta_s X[s][mode_j][f] + D[f][s nsel + j]
+template <typename R>
+__global__ void __launch_bounds__(256) pit_dapply_kernel(Cx<R> *X, int nmodes, int ntot, const int64_t *modes_dev, int nsel, int S, const PitCtrl *c,
+                                                         const double *theta, const Z *D)
+{
+    if (c->done) return;
+    const int col = blockIdx.x, s = col / nsel, j = col - s * nsel;
+    const size_t wset = (size_t)nmodes * ntot, ro = (size_t)modes_dev[j] * ntot;
+    const int ncol = S * nsel;
+    for (int f = threadIdx.x; f < ntot; f += 256) {
+        const Z d = D[(size_t)f * ncol + col];
+        const double qr = theta[2 * (size_t)col], qi = theta[2 * (size_t)col + 1];
+        Cx<R> &x = X[(size_t)s * wset + ro + f];
+        x = Cx<R>{(R)(qr * x.re - qi * x.im + d.x), (R)(qr * x.im + qi * x.re + d.y)};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+// kernel time of the most recent call (HIP events around the trainer launches; the host synchronises after each anyway)
+struct PitTiming { int npass; float pass_ms[QH_PIT_MAXPASS]; float acq_ms; };
+inline PitTiming &pit_timing() { static PitTiming t; return t; }
+inline hipEvent_t *pit_events()
+{
+    static hipEvent_t ev[2] = {nullptr, nullptr};
+    if (!ev[0]) { (void)hipEventCreate(&ev[0]); (void)hipEventCreate(&ev[1]); }
+    return ev;
+}
+
+inline int pit_auto_segments(int64_t TrSyms, double mu, int nsel)
+{
+    double target = 1.6 / (mu > 1e-12 ? mu : 1e-12);           // ~1.5-3 time constants 1/(mu_eff lambda) of the in-band directions
+    if (target < 1024) target = 1024;
+    if (target > 1048576) target = 1048576;
+    const int64_t seg = ((int64_t)target + 63) / 64 * 64;
+    int64_t S = TrSyms / seg;
+    if (S > 4096) S = 4096;
+    const int64_t ncu = 256;                                   // MI355X: whole rounds of workgroups (one per segment and mode)
+    if (S * nsel > ncu && nsel <= ncu) S = S * nsel / ncu * ncu / nsel;
+    if (S < 4) S = 1;
+    return (int)S;
+}
+
+template <typename R>
+int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu_dev, void *wx, int ntaps,
+                  const int64_t *modes, int nsel, const void *symbols, int64_t nsy, int method, void *err, int zero_err,
+                  const void *gram, const qh_pit_opts *opts, void *report_dev)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (method < 0 || method > QH_M_SBD_DATA) { set_error("unknown equaliser method id"); return QH_ERR_METHOD; }
+    QH_REQUIRE(nmodes >= 1 && ntaps >= 1 && os >= 1 && Niter >= 0 && TrSyms >= 0 && nsel >= 1 && nsel <= 16 && nsy >= 1, "train_equaliser: bad sizes");
+    QH_REQUIRE(TrSyms == 0 || (TrSyms - 1) * os + ntaps <= L, "train_equaliser: field shorter than TrSyms*os + ntaps");
+    QH_REQUIRE(method != QH_M_SBD_DATA, "train_equaliser: parallel-in-time training is not available for data-aided methods");
+    for (int j = 0; j < nsel; j++) QH_REQUIRE(modes[j] >= 0 && modes[j] < nmodes, "train_equaliser: mode number >= nmodes");
+    qh_pit_opts o;
+    memset(&o, 0, sizeof(o));
+    o.phase_seed = -1;
+    if (opts) o = *opts;
+    QH_REQUIRE(o.segments >= 0 && o.segments <= 4096 && o.max_passes >= 0 && o.max_passes <= QH_PIT_MAXPASS, "train_equaliser: bad segment / pass count");
+    const int ntot = nmodes * ntaps;
+    QH_REQUIRE(ntot <= 64 * 16, "train_equaliser: more than 1024 taps per output mode are not supported");
+    const int npass = o.max_passes > 0 ? o.max_passes : 8;
+    const double tol = o.tol > 0 ? o.tol : 0.02;
+    const double gear = o.gear > 0 ? o.gear : 8.0;
+    const double bound = o.acq_bound > 0 ? o.acq_bound : 0.08;
+    const double plateau = o.acq_plateau > 0 ? o.acq_plateau : 0.9;
+    const int sym = pit_symmetry(method);
+    const bool seed_phase = o.phase_seed < 0 ? sym == 4 : o.phase_seed != 0;
+    const bool want_corr = o.correction != 0 && ntot <= 128 && (size_t)PIT_COVW * ntot * sizeof(Cx<R>) <= 64 * 1024;
+
+    // ---- control block / report
+    void *cbuf = nullptr;
+    if ((rc = scratch(8, sizeof(PitCtrl) + 64, &cbuf))) return rc;
+    PitCtrl *ctrl = report_dev ? (PitCtrl *)report_dev : (PitCtrl *)cbuf;
+    R *mu_acq = (R *)((char *)cbuf + sizeof(PitCtrl));            // 8-byte aligned: sizeof(PitCtrl) is a multiple of 8
+
+    // the device decides (error plateau, boundary defect); the host reads the flag after each chunk / pass instead of
+    // enqueueing work that would only be skipped
+    auto poll = [&](const int32_t *flag, int *val) -> int {
+        int32_t v = 0;
+        QH_HIP(hipMemcpyAsync(&v, flag, sizeof(v), hipMemcpyDeviceToHost, g_stream));
+        QH_HIP(hipStreamSynchronize(g_stream));
+        *val = v;
+        return QH_OK;
+    };
+
+    // ---- segment grid
+    int S = o.segments;
+    if (S == 0) {
+        R mu_h = 0;
+        QH_HIP(hipMemcpyAsync(&mu_h, mu_dev, sizeof(R), hipMemcpyDeviceToHost, g_stream));
+        QH_HIP(hipStreamSynchronize(g_stream));
+        S = pit_auto_segments(TrSyms, (double)mu_h, nsel);
+    }
+    const int64_t nblk_all = TrSyms / LA_B;
+    if ((int64_t)S * 4 > nblk_all) S = (int)(nblk_all / 4);       // at least 4 blocks per segment
+    PitSeg sg;
+    sg.S = S > 1 ? S : 1;
+    sg.len = sg.S > 0 ? nblk_all / sg.S * LA_B : 0;
+    sg.extra = nblk_all - (sg.len / LA_B) * sg.S;
+    sg.tail = TrSyms - nblk_all * LA_B;
+    if (zero_err) QH_HIP(hipMemsetAsync(err, 0, (size_t)nmodes * TrSyms * Niter * sizeof(Cx<R>), g_stream));
+    const int64_t npow = L < 4096 ? L : 4096;
+    hipLaunchKernelGGL((pit_setup_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const Cx<R> *)E, nmodes, L, npow, ntot, (const R *)mu_dev, gear, bound, tol, sg, ctrl, mu_acq);
+    QH_HIP(hipGetLastError());
+    if (TrSyms == 0 || Niter == 0) return QH_OK;
+    if (sg.S < 2) {                 // nothing to parallelise: the sequential path (report: one segment, one pass, defect 0)
+        if ((rc = train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, 0, symbols, nsy, method, err, 0, gram))) return rc;
+        const double zero = 0;
+        const int32_t hdr[3] = {1, 1, 1};                          // segments, passes, converged
+        QH_HIP(hipMemcpyAsync(&ctrl->segments, hdr, sizeof(hdr), hipMemcpyHostToDevice, g_stream));
+        QH_HIP(hipMemcpyAsync(&ctrl->defect[0], &zero, sizeof(double), hipMemcpyHostToDevice, g_stream));
+        QH_HIP(hipStreamSynchronize(g_stream));
+        return QH_OK;
+    }
+
+    // ---- which exact form takes the segments (same rules as the sequential path, fixed step)
+    const char *force = trainer_force();
+    bool bi_ok = force[0] != 'd' && force[0] != 'l' && bi_supported(method, 0, nmodes, ntaps, os, sg.len, nsy, sizeof(Cx<R>));
+    const bool decision = method == QH_M_SBD || method == QH_M_MDDMA || method == QH_M_DD;
+    void *dd_table = nullptr;
+    int dd_npart = -1;
+    if (bi_ok && decision) {
+        if ((rc = slicer_tables<R>(symbols, nmodes, nsy, modes, nsel, &dd_table, &dd_npart))) return rc;
+        bi_ok = dd_npart == 1 || dd_npart == 3 || dd_npart == 7 || dd_npart == 15;
+    }
+    const bool la_ok = force[0] != 'd' && la_supported(method, 0, nmodes, ntaps, os, sg.len, nsy);
+    const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
+    (void)partitioned;
+    // With the chip full the stage is bound by instruction issue, not by one chain's latency: the look-ahead form (~25
+    // instructions per step and mode over its 4 waves) beats the block-iterative one (~125: every block is swept ~8 times),
+    // so it takes whatever it can (cma-type AND rde / mrde); block-iterative for the decision-directed functions.
+    const bool use_bi = bi_ok && (decision || !la_ok || force[0] == 'i');
+    const bool block_form = use_bi || la_ok;
+    const bool pair_tab = use_bi ? la_shape_ok(nmodes, ntaps, os) : true;
+
+    // ---- buffers
+    const size_t wset = (size_t)nmodes * ntot;
+    const size_t wbytes = wset * sizeof(Cx<R>);
+    void *wbuf = nullptr;
+    const size_t nsj = (size_t)sg.S * nsel;
+    const size_t bytes_w = ((2 * (size_t)sg.S + 1) * wbytes + 63) / 64 * 64;
+    if ((rc = scratch(2, bytes_w + 10 * nsj * sizeof(double) + (size_t)nsel * sizeof(int64_t) + 64, &wbuf))) return rc;
+    Cx<R> *X = (Cx<R> *)wbuf, *Y = X + (size_t)sg.S * wset, *w_start = Y + (size_t)sg.S * wset;
+    double *z = (double *)((char *)wbuf + bytes_w), *rot = z + 2 * nsj, *dfc = rot + 2 * nsj, *pw = dfc + nsj, *gph = pw + nsj, *theta = gph + 2 * nsj;
+    int64_t *modes_dev = (int64_t *)(theta + 2 * nsj);
+    QH_HIP(hipMemcpyAsync(modes_dev, modes, (size_t)nsel * sizeof(int64_t), hipMemcpyHostToDevice, g_stream));
+    QH_HIP(hipStreamSynchronize(g_stream));                       // `modes` is the caller's memory
+
+    // ---- Gram table of the whole sweep: acquisition chunks and segments index into it
+    void *G = const_cast<void *>(gram);
+    if (block_form && !G) {
+        rc = pair_tab ? gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G) : gram_cur_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G);
+        if (rc) return rc;
+    }
+    const int64_t g_per_step = pair_tab ? LA_B : GRAM_TRI / 2 / LA_B;      // GramPair elements per step
+
+    // ---- coarse correction: covariance of the training windows, room for the powers of the linearised segment map
+    int nround = 0;
+    while ((1 << nround) < sg.S) nround++;
+    const int ncol = sg.S * nsel;
+    const size_t msz = (size_t)ntot * ntot;
+    Z *Rc = nullptr, *Mw[2] = {nullptr, nullptr}, *Mr = nullptr, *Dz[2] = {nullptr, nullptr};
+    const int ncov = (int)(TrSyms < PIT_COVW * PIT_COVB ? TrSyms : PIT_COVW * PIT_COVB);
+    if (want_corr) {
+        void *cb = nullptr;
+        if ((rc = scratch(9, ((5 + (size_t)nround + PIT_COVB) * msz + 2 * (size_t)ntot * ncol) * sizeof(Z), &cb))) return rc;
+        Rc = (Z *)cb; Mw[0] = Rc + msz; Mw[1] = Mw[0] + msz; Mr = Mw[1] + msz; Dz[0] = Mr + ((size_t)nround + 2) * msz; Dz[1] = Dz[0] + (size_t)ntot * ncol;
+        Z *part = Dz[1] + (size_t)ntot * ncol;
+        const int ept = (int)((msz + 255) / 256);
+        const size_t lds = (size_t)PIT_COVW * ntot * sizeof(Cx<R>);
+        if (ept <= 8) hipLaunchKernelGGL((pit_cov_kernel<R, 8>), dim3(PIT_COVB), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
+        else if (ept <= 32) hipLaunchKernelGGL((pit_cov_kernel<R, 32>), dim3(PIT_COVB), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
+        else hipLaunchKernelGGL((pit_cov_kernel<R, 64>), dim3(PIT_COVB), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
+        hipLaunchKernelGGL(pit_cov_reduce_kernel, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, g_stream, (const Z *)part, (int)msz, PIT_COVB, Rc);
+        QH_HIP(hipGetLastError());
+    }
+    const dim3 gsq((ntot + 15) / 16, (ntot + 15) / 16), gsc((ncol + 15) / 16, (ntot + 15) / 16);
+    // powers of J = exp(-mu g T Rc): Mr[r] = J^(2^r); needs the gain, i.e. runs after the first pass of the call
+    auto build_powers = [&]() -> int {
+        hipLaunchKernelGGL((pit_expm_scale_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const Z *)Rc, ntot, ncov, sg.len, (const R *)mu_dev, ctrl, Mw[0]);   // B
+        hipLaunchKernelGGL(pit_zgemm_kernel, gsq, dim3(256), 0, g_stream, (const Z *)Mw[0], (const Z *)Mw[0], (const Z *)nullptr, Mw[1], ntot, ntot, ntot, 0, (const PitCtrl *)ctrl);   // B2
+        Z *T1 = Mr, *P0 = Mr + msz;                                  // temporaries in the (not yet used) power slots; nround >= 2 since S >= 4
+        hipLaunchKernelGGL(pit_expm_poly_kernel, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, g_stream, (const Z *)Mw[0], (const Z *)Mw[1], ntot, (const PitCtrl *)ctrl, T1, P0);
+        hipLaunchKernelGGL(pit_zgemm_kernel, gsq, dim3(256), 0, g_stream, (const Z *)Mw[1], (const Z *)T1, (const Z *)P0, Mw[0], ntot, ntot, ntot, 0, (const PitCtrl *)ctrl);       // exp(B)
+        int cur = 0;
+        for (int q = 0; q < PIT_SCALE; q++) {                        // undo the scaling: the last squaring lands in Mr[0]
+            Z *dst = q == PIT_SCALE - 1 ? Mr : Mw[cur ^ 1];
+            hipLaunchKernelGGL(pit_zgemm_kernel, gsq, dim3(256), 0, g_stream, (const Z *)Mw[cur], (const Z *)Mw[cur], (const Z *)nullptr, dst, ntot, ntot, ntot, 0, (const PitCtrl *)ctrl);
+            cur ^= 1;
+        }
+        for (int r = 1; r < nround; r++)
+            hipLaunchKernelGGL(pit_zgemm_kernel, gsq, dim3(256), 0, g_stream, (const Z *)(Mr + (size_t)(r - 1) * msz), (const Z *)(Mr + (size_t)(r - 1) * msz), (const Z *)nullptr,
+                               Mr + (size_t)r * msz, ntot, ntot, ntot, 0, (const PitCtrl *)ctrl);
+        QH_HIP(hipGetLastError());
+        return QH_OK;
+    };
+    bool have_powers = false;
+
+    LaArgs<R> la;
+    la.E = (const Cx<R> *)E; la.symbols = (const Cx<R> *)symbols; la.err = (Cx<R> *)err; la.G = (const GramPair<R> *)G; la.gpair = pair_tab ? 1 : 0;
+    la.mu = mu_dev; la.mu_out = nullptr; la.mu_cs = 0; la.mu_ms = 0;
+    la.L = L; la.Lp = L; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter;
+    la.nmodes = nmodes; la.ntaps = ntaps; la.os = os; la.nsel = nsel; la.method = method;
+    la.E_cs = 0; la.err_cs = 0; la.G_cs = 0; la.wx_cs = (int64_t)wset;
+    for (int j = 0; j < 16; j++) la.modes[j] = j < nsel ? modes[j] : 0;
+    if (use_bi && decision) { la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV; }
+    la.prof = nullptr; la.seg = 0; la.seg_extra = 0; la.seg_tail = 0; la.skip = nullptr;
+    TrainArgs<R> ta;
+    ta.E = (const Cx<R> *)E; ta.symbols = (const Cx<R> *)symbols; ta.err = (Cx<R> *)err; ta.mu = mu_dev;
+    ta.L = L; ta.TrSyms = TrSyms; ta.nsy = nsy; ta.nmodes = nmodes; ta.ntaps = ntaps; ta.Niter = Niter; ta.os = os;
+    ta.nsel = nsel; ta.adaptive = 0; ta.method = method;
+    for (int j = 0; j < 16; j++) ta.modes[j] = j < nsel ? modes[j] : 0;
+    ta.win_start = nullptr; ta.win_len = 0; ta.nwin = 0; ta.win_mu = nullptr; ta.e_off = 0; ta.wx_out = nullptr;
+    ta.nseg = 0; ta.seg_begin = 0; ta.seg_len = 0; ta.seg_extra = 0; ta.seg_tail = 0; ta.seg_iter = 0; ta.skip = nullptr;
+
+    PitTiming &tm = pit_timing();
+    tm.npass = 0; tm.acq_ms = 0;
+    hipEvent_t *ev = pit_events();
+    for (int it = 0; it < Niter; it++) {
+        // ================================================================ acquisition (first sweep of a cold start)
+        if (it == 0 && o.acquire) {
+            int64_t amax = o.acq_max > 0 ? o.acq_max : (TrSyms / 2 < 131072 ? TrSyms / 2 : 131072);
+            if (amax > TrSyms) amax = TrSyms;
+            int64_t CH = o.acq_chunk > 0 ? o.acq_chunk : 4096;
+            if (CH * QH_PIT_MAXCHUNK < amax) CH = (amax + QH_PIT_MAXCHUNK - 1) / QH_PIT_MAXCHUNK;
+            CH = (CH + LA_B - 1) / LA_B * LA_B;
+            if (CH < 4 * LA_B) CH = 4 * LA_B;
+            QH_HIP(hipMemcpyAsync(w_start, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
+            for (int64_t step0 = 0; step0 + CH <= amax; step0 += CH) {
+                QH_HIP(hipEventRecord(ev[0], g_stream));
+                if (block_form) {
+                    LaArgs<R> lp = la;
+                    lp.E = (const Cx<R> *)E + step0 * os; lp.L = L - step0 * os; lp.TrSyms = CH; lp.nch = 1; lp.wx = (Cx<R> *)wx; lp.wx_cs = 0;
+                    lp.G = (const GramPair<R> *)G + step0 * g_per_step; lp.err_off = step0; lp.mu = mu_acq; lp.skip = &ctrl->acq_done;
+                    if ((rc = use_bi ? launch_bi<R>(lp) : launch_la<R>(lp))) return rc;
+                } else {
+                    TrainArgs<R> tp = ta;
+                    tp.wx = (Cx<R> *)wx; tp.mu = mu_acq; tp.nseg = 1; tp.seg_begin = step0; tp.seg_len = CH; tp.seg_iter = 0; tp.skip = &ctrl->acq_done;
+                    if ((rc = launch_any<R>(tp))) return rc;
+                }
+                QH_HIP(hipEventRecord(ev[1], g_stream));
+                hipLaunchKernelGGL((pit_acq_monitor_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const Cx<R> *)err, (int64_t)(TrSyms * Niter), step0, CH,
+                                   nsel, (const int64_t *)modes_dev, plateau, ctrl);
+                int fin = 0;
+                if ((rc = poll(&ctrl->acq_done, &fin))) return rc;
+                { float ms = 0; QH_HIP(hipEventElapsedTime(&ms, ev[0], ev[1])); tm.acq_ms += ms; }
+                if (fin) break;
+            }
+            hipLaunchKernelGGL((pit_acq_finish_kernel<R>), dim3((unsigned)((wset + 255) / 256)), dim3(256), 0, g_stream, (Cx<R> *)wx, (const Cx<R> *)w_start, (int)wset, ctrl);
+            QH_HIP(hipGetLastError());
+        }
+        // ================================================================ pass-0 start taps
+        hipLaunchKernelGGL(pit_sweep_kernel, dim3(1), dim3(1), 0, g_stream, ctrl);
+        const double *rot_use = nullptr;
+        if (seed_phase) {
+            hipLaunchKernelGGL((pit_phase_kernel<R>), dim3(sg.S, nsel), dim3(256), (size_t)ntot * sizeof(Cx<R>), g_stream, (const Cx<R> *)E, nmodes, L, os,
+                               (const Cx<R> *)wx, ntaps, sg, (const int64_t *)modes_dev, PIT_SEEDWIN, z);
+            hipLaunchKernelGGL(pit_unwrap_kernel, dim3(1), dim3(256), (size_t)sg.S * (sizeof(double) + sizeof(int)), g_stream, (const double *)z, sg.S, nsel, rot);
+            rot_use = rot;
+        }
+        hipLaunchKernelGGL((pit_seed_kernel<R>), dim3(sg.S), dim3(256), 0, g_stream, (const Cx<R> *)wx, nmodes, ntot, (const int64_t *)modes_dev, nsel, rot_use, X);
+        QH_HIP(hipGetLastError());
+        // ================================================================ relaxation passes
+        for (int p = 0; p < npass; p++) {
+            if (p > 0 && want_corr) {
+                // start taps += D,  D[s+1] = d[s+1] + J D[s]  (d = boundary defects): a parallel scan over the segments.  With the
+                // correction switched off on the device (corr_on = 0) the products are skipped and D = d: plain relaxation.
+                if (!have_powers) { if ((rc = build_powers())) return rc; have_powers = true; }
+                hipLaunchKernelGGL(pit_gauge_kernel, dim3(1), dim3(64), 0, g_stream, (const double *)gph, sg.S, nsel, (const PitCtrl *)ctrl, theta);
+                hipLaunchKernelGGL((pit_dvec_kernel<R>), dim3(ncol), dim3(256), 0, g_stream, (const Cx<R> *)X, (const Cx<R> *)Y, nmodes, ntot, (const int64_t *)modes_dev, nsel, sg.S,
+                                   (const PitCtrl *)ctrl, (const double *)theta, Dz[0]);
+                int cur = 0;
+                for (int r = 0; r < nround; r++) {
+                    hipLaunchKernelGGL(pit_zgemm_kernel, gsc, dim3(256), 0, g_stream, (const Z *)(Mr + (size_t)r * msz), (const Z *)Dz[cur], (const Z *)Dz[cur], Dz[cur ^ 1],
+                                       ntot, ncol, ntot, (1 << r) * nsel, (const PitCtrl *)ctrl);
+                    cur ^= 1;
+                }
+                hipLaunchKernelGGL((pit_dapply_kernel<R>), dim3(ncol), dim3(256), 0, g_stream, X, nmodes, ntot, (const int64_t *)modes_dev, nsel, sg.S, (const PitCtrl *)ctrl, (const double *)theta, (const Z *)Dz[cur]);
+                QH_HIP(hipGetLastError());
+            } else if (p > 0) {
+                QH_HIP(hipMemcpyAsync(X + wset, Y, (size_t)(sg.S - 1) * wbytes, hipMemcpyDeviceToDevice, g_stream));   // X[s] = end taps of s-1
+            }
+            QH_HIP(hipMemcpyAsync(Y, X, (size_t)sg.S * wbytes, hipMemcpyDeviceToDevice, g_stream));
+            QH_HIP(hipEventRecord(ev[0], g_stream));
+            if (block_form) {
+                LaArgs<R> ls = la;
+                ls.TrSyms = sg.len; ls.nch = sg.S; ls.wx = Y; ls.err_off = (int64_t)it * TrSyms; ls.seg = 1; ls.seg_extra = sg.extra; ls.seg_tail = sg.tail;
+                ls.skip = &ctrl->done;
+                if ((rc = use_bi ? launch_bi<R>(ls) : launch_la<R>(ls))) return rc;
+            } else {
+                TrainArgs<R> ts = ta;
+                ts.wx = Y; ts.nseg = sg.S; ts.seg_begin = 0; ts.seg_len = sg.len; ts.seg_extra = sg.extra; ts.seg_tail = sg.tail; ts.seg_iter = it; ts.skip = &ctrl->done;
+                if ((rc = launch_any<R>(ts))) return rc;
+            }
+            QH_HIP(hipEventRecord(ev[1], g_stream));
+            hipLaunchKernelGGL((pit_defect_kernel<R>), dim3(sg.S - 1, nsel), dim3(PIT_PROBE), 2 * (size_t)ntot * sizeof(Cx<R>), g_stream, (const Cx<R> *)E, nmodes, L, os,
+                               ntaps, sg, TrSyms, (const int64_t *)modes_dev, (const Cx<R> *)X, (const Cx<R> *)Y, sym, (const PitCtrl *)ctrl, dfc, pw, gph);
+            hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, (int)((sg.S - 1) * nsel),
+                               (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, method,
+                               (const Cx<R> *)symbols + (size_t)modes[0] * nsy, want_corr ? 1 : 0, ctrl);
+            QH_HIP(hipGetLastError());
+            int fin = 0;
+            if ((rc = poll(&ctrl->done, &fin))) return rc;
+            if (tm.npass < QH_PIT_MAXPASS) { float ms = 0; QH_HIP(hipEventElapsedTime(&ms, ev[0], ev[1])); tm.pass_ms[tm.npass++] = ms; }
+            if (fin) break;
+        }
+    }
+    return QH_OK;
+}
+
+}  // namespace qh

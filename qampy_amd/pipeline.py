@@ -33,8 +33,7 @@ class ResidentReceiver:
     """
 
     def __init__(self, nmodes, L, os, M, Ntaps, mu, methods=("cma", "mrde"), Niter=(1, 1), adaptive_stepsize=(False, False),
-                 TrSyms=(None, None), Mtestangles=64, Nbps=20, dtype=np.complex64, alphabet=None, modes=None, segments=0,
-                 prefix=1 << 16, prefix_mu=None, passes=0):
+                 TrSyms=(None, None), Mtestangles=64, Nbps=20, dtype=np.complex64, alphabet=None, modes=None, tier="a", pit=None):
         suf, self.rt, self.ct = _lib.suffix(dtype)
         self.nmodes, self.L, self.os, self.M, self.Ntaps = int(nmodes), int(L), int(os), int(M), int(Ntaps)
         self.nstage = len(methods)
@@ -50,15 +49,18 @@ class ResidentReceiver:
         self.TrSyms = tuple(_host._cal_training_symbol_len(os, Ntaps, L) if t is None else int(t) for t in TrSyms[:self.nstage])
         self.N = (self.L - self.Ntaps + 1) // self.os
         self.Mtestangles, self.Nbps = Mtestangles, Nbps
-        # segments > 0: opt-in segment-parallel training (tier B); 0 = the reference's exact sequential recurrence
-        self.segments_stage = tuple(int(x) for x in segments) if isinstance(segments, (tuple, list)) else (int(segments),) * len(methods)
-        self.segments = max(self.segments_stage)
-        self.passes = int(passes)              # > 0 with segments: parallel-in-time relaxation passes (tier B+)
-        self.pass_change = [np.zeros(max(self.passes, 1)) for _ in methods] if passes else None
-        self.prefix = tuple(int(p) for p in (prefix if isinstance(prefix, (tuple, list)) else (prefix,) * len(methods)))
-        self.prefix_mu = tuple(prefix_mu) if prefix_mu is not None else (0.,) * len(methods)
+        # tier "a" (default): the reference's exact sequential recurrence.  tier "b" (opt-in): parallel-in-time training
+        #  - concurrently trained segments + waveform relaxation until the boundary defect is below `tol`; the
+        # first stage is a cold start (gear-shifted acquisition), later stages start from the previous stage's taps.
+        # `pit`: options of hip_equalisation.train_equaliser_dev(pit=...), one dict for all stages or one per stage
+        if tier not in ("a", "b"):
+            raise ValueError("tier must be 'a' (exact) or 'b' (parallel in time)")
+        self.tier = tier
+        pit = pit or {}
+        self.pit = [dict(p) for p in pit] if isinstance(pit, (tuple, list)) else [dict(pit) for _ in methods]
+        self.pit_report = None
+        self.pit_timing = [([], 0.) for _ in methods]
         self.mu0 = tuple(self.rt(m) for m in mu)
-        self.report_passes = False             # True: fill pass_change (synchronises after every pass)
         if alphabet is None:
             alphabet = _host.generate_symbols_for_eq("sbd", M, self.ct)[0]
         self.alphabet_host = np.ascontiguousarray(alphabet, dtype=self.ct)
@@ -79,6 +81,13 @@ class ResidentReceiver:
             self.idx = DeviceArray((self.modes.size, self.N), np.int32)
             self.ph = DeviceArray((self.modes.size, self.N), self.rt)
             self.out = DeviceArray((self.modes.size, self.N), self.ct)
+        if tier == "b":
+            if any(self.adaptive):
+                raise ValueError("parallel-in-time training needs fixed step sizes")
+            self.pit_report = [_k.PitReportBuffer() for _ in methods]
+            for s_, o in enumerate(self.pit):          # segment grid from the host copy of mu: the call then never synchronises
+                o.setdefault("segments", _k.pit_auto_segments(self.TrSyms[s_], float(self.mu0[s_]), self.modes.size))
+                o.setdefault("acquire", 1 if s_ == 0 else 0)
         _lib.sync()
 
     # ------------------------------------------------------------------------------------------ data movement
@@ -98,15 +107,22 @@ class ResidentReceiver:
     def build_gram(self):
         """Gram terms of the look-ahead trainer: once per capture, shared by all modes, stages and sweeps."""
         self._gram = None
-        if self.segments == 0 and len(set(self.TrSyms)) == 1:
+        if len(set(self.TrSyms)) == 1:
             self._gram = _k.gram_build_dev(self.E, self.os, self.Ntaps, self.TrSyms[0])
 
     def train(self, stage):
+        tb = self.tier == "b"
         _k.train_equaliser_dev(self.E, self.TrSyms[stage], self.Niter[stage], self.os, self.mu[stage], self.wxy, self.modes,
                                self.adaptive[stage], self.symbols[stage], self.methods[stage], self.err[stage],
-                               segments=self.segments_stage[stage], prefix=self.prefix[stage], gram=getattr(self, "_gram", None),
-                               prefix_mu=self.prefix_mu[stage], passes=self.passes,
-                               pass_change=self.pass_change[stage] if (self.pass_change and self.report_passes) else None)
+                               gram=getattr(self, "_gram", None), pit=self.pit[stage] if tb else None,
+                               report=self.pit_report[stage] if tb else None)
+        if tb:
+            self.pit_timing[stage] = _k.pit_last_timing()      # host-side copy of the HIP-event times: no synchronisation
+
+    def pit_reports(self):
+        """Tier b: what the device decided in the last run, one dict per stage (segments, passes, boundary defects,
+        acquisition); synchronises."""
+        return [r.read() for r in self.pit_report] if self.pit_report else None
 
     def apply(self):
         _k.apply_filter_to_signal_dev(self.E, self.os, self.wxy, self.modes, self.eq)
@@ -179,7 +195,7 @@ class ChannelBank:
         # one receiver object provides the shared constants and the per-channel views; its own big buffers are replaced
         self.rx = ResidentReceiver(nmodes, 8 * Ntaps * os, os, M, Ntaps, mu, **kw)       # tiny dummy capture
         r = self.rx
-        if r.segments:
+        if r.tier != "a":
             raise ValueError("a channel bank runs the exact recurrence (tier A)")
         self.nmodes, self.L, self.os, self.Ntaps, self.ct, self.rt = int(nmodes), int(L), int(os), int(Ntaps), r.ct, r.rt
         TrSyms = kw.get("TrSyms", (None,) * r.nstage)

@@ -1,42 +1,100 @@
 #!/usr/bin/env python3
-"""Parallel-in-time training (tier B+) against the exact path on the C3 capture: time, SER, tap / output deviation per (S, P)."""
-import json, os, sys, time
+"""Parallel-in-time training (tier b) against the exact path (tier a): time, SER, tap / output deviation, device report.
+
+    python scripts/pit_exp.py [--workload c3|ns|c2] [--nsym N] [--seeds 1000,1001] [--linewidth Hz] [--variants default,...]
+"""
+import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import bench
 from qampy_amd import synth, _lib
 from qampy_amd.pipeline import ResidentReceiver
 from qampy_amd.core import ber_functions as ber
 
-wl = dict(M=64, nsym=int(os.environ.get("PIT_NSYM", 2 ** 22)), ntaps=41, methods=("cma", "mrde"), mu=(2e-4, 2e-4))
+VARIANTS = {
+    "default": {},
+    "tol1e-2": dict(tol=1e-2),
+    "tol5e-2": dict(tol=5e-2),
+    "noseed": dict(phase_seed=0),
+    "gear4": dict(gear=4.),
+    "gear16": dict(gear=16., acq_bound=0.16),
+    "S256": dict(segments=256),
+    "S1024": dict(segments=1024),
+    "S2048": dict(segments=2048),
+    "plateau.8": dict(acq_plateau=0.8),
+    "plateau.95": dict(acq_plateau=0.95),
+    "noacq": dict(acquire=0),
+    "nocorr": dict(correction=0),
+    "nocorr8": dict(correction=0, max_passes=8, tol=1e-3),
+    "corr8": dict(max_passes=8, tol=1e-3),
+}
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="c3")
+ap.add_argument("--nsym", type=int, default=None)
+ap.add_argument("--seeds", default="1000")
+ap.add_argument("--linewidth", type=float, default=None)
+ap.add_argument("--variants", default="default")
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--no-exact", action="store_true")
+args = ap.parse_args()
+cfg = dict(bench.WORKLOADS[args.workload])
+if args.linewidth is not None:
+    cfg["linewidth"] = args.linewidth
+nsym = args.nsym or cfg["nsym"]
 _lib.init(0)
-d = synth.make_capture_dev(wl["M"], wl["nsym"], nmodes=2, snr_db=30, theta=np.pi / 5.6, dgd=30e-12, linewidth=100., seed=int(os.environ.get("PIT_SEED", 1000)))
-kw = dict(methods=wl["methods"], Niter=(1, 1), Mtestangles=64, Nbps=20, alphabet=d["alphabet_host"])
+out = []
+for seed in [int(s) for s in args.seeds.split(",")]:
+    d = synth.make_capture_dev(cfg["M"], nsym, nmodes=2, snr_db=cfg["snr_db"], theta=np.pi / 5.6, dgd=30e-12, linewidth=cfg["linewidth"], seed=seed)
+    kw = dict(methods=cfg["methods"], Niter=cfg["niter"], Mtestangles=cfg["A"], Nbps=cfg["Nbps"], alphabet=d["alphabet_host"])
 
+    def run(tier, pit=None):
+        rx = ResidentReceiver(2, nsym * 2, 2, cfg["M"], cfg["ntaps"], cfg["mu"], tier=tier, pit=pit, **kw)
+        rx.E.copy_from(d["E"])
+        rx.run(); _lib.sync()
+        ts = []
+        for _ in range(args.reps):
+            t0 = time.perf_counter(); rx.run(); _lib.sync(); ts.append(time.perf_counter() - t0)
+        # per-stage times
+        names = ["gram"] + ["train%d" % (s + 1) for s in range(rx.nstage)] + ["apply", "recover"]
+        fns = [rx.build_gram] + [lambda s=s: rx.train(s) for s in range(rx.nstage)] + [rx.apply, rx.recover]
+        ev = [_lib.Event() for _ in range(len(fns) + 1)]
+        rx.reset(); ev[0].record()
+        for j, f in enumerate(fns):
+            f(); ev[j + 1].record()
+        _lib.sync()
+        st = {n: round(ev[j + 1].elapsed_ms(ev[j]), 3) for j, n in enumerate(names)}
+        ser = ber.cal_ser_dev(rx.out, d["idx_tx"], rx.alphabet, 256, 8192, 2000)
+        return rx, min(ts), st, ser
 
-def run(S, P, prefix=(0, 1 << 17)):
-    rx = ResidentReceiver(2, wl["nsym"] * 2, 2, wl["M"], wl["ntaps"], wl["mu"], segments=S, passes=P, prefix=prefix, **kw)
-    rx.E.copy_from(d["E"])
-    rx.run(); _lib.sync()
-    t0 = time.perf_counter(); rx.run(); _lib.sync(); t = time.perf_counter() - t0
-    rx.report_passes = True
-    rx.run(); _lib.sync()
-    ser = ber.cal_ser_dev(rx.out, d["idx_tx"], rx.alphabet, 256, 8192, 2000)
-    return rx, t, ser
-
-
-ref, t_ref, ser_ref = run(0, 0)
-w_ref, out_ref, eq_ref = ref.wxy.to_host(), ref.out.to_host(), ref.eq.to_host()
-e_ref = [e.to_host() for e in ref.err]
-res = [dict(S=0, P=0, ms=round(t_ref * 1e3, 2), MSym_s=round(wl["nsym"] / t_ref / 1e6, 2), errors=[r["errors"] for r in ser_ref])]
-for S, P, pre in [((0, 64), 1, (0, 1 << 17)), ((0, 64), 2, (0, 1 << 17)), ((0, 64), 3, (0, 1 << 17)), ((0, 64), 2, (0, 1 << 16)), ((0, 64), 2, (0, 0)),
-                  ((0, 128), 2, (0, 1 << 17)), ((0, 32), 2, (0, 1 << 17)), ((64, 64), 3, (1 << 18, 1 << 17))]:
-    rx, t, ser = run(S, P, pre)
-    w, eq = rx.wxy.to_host(), rx.eq.to_host()
-    e2 = rx.err[1].to_host()
-    res.append(dict(S=S, P=P, prefix=pre, ms=round(t * 1e3, 2), MSym_s=round(wl["nsym"] / t / 1e6, 2), errors=[r["errors"] for r in ser],
-                    tap_diff_max=float(np.max(np.abs(w - w_ref))), tap_diff_rel=float(np.linalg.norm(w - w_ref) / np.linalg.norm(w_ref)),
-                    eq_rms_diff=float(np.sqrt(np.mean(np.abs(eq - eq_ref) ** 2))), eq_max_diff=float(np.max(np.abs(eq - eq_ref))),
-                    err2_rms_diff=float(np.sqrt(np.mean(np.abs(e2 - e_ref[1]) ** 2))),
-                    pass_change=[[float("%.3g" % v) for v in pc] for pc in rx.pass_change]))
-    del rx
-print(json.dumps(dict(what="C3 capture, exact vs parallel-in-time (S segments, P passes)", results=res)))
+    ref = None
+    if not args.no_exact:
+        ref, t_ref, st_ref, ser_ref = run("a")
+        w_ref, eq_ref = ref.wxy.to_host(), ref.eq.to_host()
+        e_ref = [e.to_host() for e in ref.err]
+        out.append(dict(seed=seed, tier="a", ms=round(t_ref * 1e3, 2), MSym_s=round(nsym / t_ref / 1e6, 2), stages_ms=st_ref,
+                        errors=[r["errors"] for r in ser_ref], rot=[r["rotation"] for r in ser_ref]))
+        print(json.dumps(out[-1]), flush=True)
+    for v in args.variants.split(","):
+        rx, t, st, ser = run("b", VARIANTS[v])
+        rec = dict(seed=seed, tier="b", variant=v, ms=round(t * 1e3, 2), MSym_s=round(nsym / t / 1e6, 2), stages_ms=st,
+                   errors=[r["errors"] for r in ser], rot=[r["rotation"] for r in ser], report=rx.pit_reports())
+        if ref is not None:
+            w, eq = rx.wxy.to_host(), rx.eq.to_host()
+            # deviation modulo a common quarter turn per output mode (the error functions' symmetry)
+            dev_t, dev_o = [], []
+            for m in range(w.shape[0]):
+                c = np.vdot(w[m].ravel(), w_ref[m].ravel())
+                g = 1j ** int(np.rint(np.angle(c) / (np.pi / 2)))
+                dev_t.append(float(np.linalg.norm(w_ref[m] - g * w[m]) / np.linalg.norm(w_ref[m])))
+                dev_o.append(float(np.sqrt(np.mean(np.abs(eq_ref[m] - g * eq[m]) ** 2))))
+            n8 = rx.err[0].shape[1] // 8
+            rec.update(tap_dev_rel=dev_t, eq_rms_dev=dev_o,
+                       err_pow_by_eighth=[[[round(float(np.mean(np.abs(e[m, i * n8:(i + 1) * n8]) ** 2)), 5) for i in range(8)] for m in range(2)]
+                                          for e in (x.to_host() for x in rx.err)],
+                       err_pow_exact=[[[round(float(np.mean(np.abs(e[m, i * n8:(i + 1) * n8]) ** 2)), 5) for i in range(8)] for m in range(2)] for e in e_ref])
+        out.append(rec)
+        print(json.dumps(rec), flush=True)
+        del rx
+    del ref
+print(json.dumps(dict(what="exact (tier a) vs parallel-in-time (tier b)", workload=args.workload, nsym=nsym, results=out)))

@@ -7,6 +7,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 from qampy_amd import sharding, synth
@@ -60,3 +61,22 @@ def test_world_size_two_gloo(tmp_path):
     assert res["tmax"] == 2.0                                  # MAX over ranks
     assert res["counts"] == [[3.0, 200.0], [0.0, 200.0]]       # SUM over ranks
     assert res["value"] == 1000 * 2 * 2 / 2.0 / 1e6
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it) starts two ranks itself, checks WORLD_SIZE == --gpus and reports
+    ranks_seen from an all-reduce of ones; --dry-run replaces the kernels by a sleep (gloo), so this runs without a GPU."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["steps"] == 3 and res["dry_run"] is True
+    assert res["ser"]["symbols_all"] == 2 * 2 * 2 ** 22            # both ranks' counters were summed
+    assert res["value"] == pytest.approx(2 * 2 ** 22 * 3 / (res["ms_per_step"] * 3e-3) / 1e6, rel=1e-3)
+    # a launch whose world size contradicts --gpus is refused
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120, env=env2)
+    assert bad.returncode == 2 and "WORLD_SIZE=1" in bad.stdout

@@ -233,35 +233,6 @@ def test_edge_cases():
     assert idx.shape == (15,) and np.all(idx == 0)
 
 
-# ------------------------------------------------------------------------------------------------ tier B (opt-in)
-def test_segment_parallel_training_is_consistent(monkeypatch):
-    """The opt-in segment-parallel continuation: one segment == the exact chain bit for bit; many segments stay
-    statistically equivalent (same SER, taps within the LMS misadjustment) and never touch the default path."""
-    from qampy_amd.pipeline import ResidentReceiver
-    sig = synth.make_capture(16, 2 ** 16, nmodes=2, snr_db=25, theta=np.pi / 5.6, dgd=30e-12, linewidth=20e3, seed=77,
-                             dtype=np.complex64)
-    kw = dict(methods=("mcma", "sbd"), Niter=(1, 1), Mtestangles=32, Nbps=20, alphabet=sig.coded_symbols)
-    monkeypatch.setenv("QAMPY_HIP_TRAINER", "direct")      # tier B runs the direct-form kernel: compare like with like
-    exact = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (2e-3, 5e-4), **kw)
-    one = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (2e-3, 5e-4), segments=1, prefix=0, **kw)
-    many = ResidentReceiver(2, sig.shape[1], 2, 16, 21, (2e-3, 5e-4), segments=8, prefix=(16384, 4096), **kw)
-    res = []
-    for rx in (exact, one, many):
-        rx.load(sig)
-        rx.run()
-        res.append(rx.fetch())
-    assert np.array_equal(res[0]["wxy"], res[1]["wxy"]) and np.array_equal(res[0]["err"][0], res[1]["err"][0])
-    assert np.array_equal(res[0]["out"], res[1]["out"])
-    # 16 segments: every error sample is produced, the converged taps agree within the gradient-noise misadjustment
-    assert np.all(np.abs(res[2]["err"][1][:, -100:]) > 0) and np.all(np.isfinite(res[2]["wxy"]))
-    assert np.max(np.abs(res[2]["wxy"] - res[0]["wxy"])) < 0.25
-    # the first `prefix` errors of stage 1 come from the same sequential recurrence
-    assert np.array_equal(res[2]["err"][0][:, :16384], res[0]["err"][0][:, :16384])
-    ser = [synth.cal_ser(r["out"], sig.symbols, sig.coded_symbols, trim=500) for r in res]
-    n = res[0]["out"].shape[1] - 1000
-    assert np.all(np.abs(ser[2] - ser[0]) * n <= 5), ser
-
-
 # ------------------------------------------------------------------------------------------------ look-ahead vs direct form
 @pytest.mark.parametrize("method,M,ntaps,nmodes", [("cma", 64, 41, 2), ("mcma", 16, 21, 2), ("mrde", 64, 41, 2), ("rde", 16, 13, 2),
                                                    ("cma2", 16, 11, 2), ("sgncma", 16, 7, 1), ("mcma", 16, 9, 3),
@@ -415,38 +386,6 @@ def test_per_mode_adaptive_step_equals_one_call_per_mode(method, M, ntaps, nmode
     assert not np.allclose(w2[modes[-1]], w[modes[-1]], rtol=1e-3, atol=1e-4)
     with pytest.raises(ValueError):
         hk.train_equaliser(E, tr, 1, 2, mu0, w0.copy(), modes, "sometimes", sy, method)
-
-
-@pytest.mark.parametrize("method,M", [("mcma", 16), ("cma", 16), ("mrde", 64), ("sbd", 16)])
-def test_parallel_in_time_relaxation_reaches_the_sequential_recurrence(method, M):
-    """Opt-in parallel-in-time training (qh_train_equaliser_*_pit_dev): S segments trained concurrently per pass, segment s
-    restarting from the end taps of segment s-1 of the previous pass.  The map is triangular in s, so after S passes the result
-    IS the sequential recurrence (to rounding, like every exact form); fewer passes are an approximation whose end-tap motion
-    per pass is reported."""
-    from qampy_amd._lib import DeviceArray
-    sig = synth.make_capture(M, 2 ** 14, nmodes=2, snr_db=28, theta=np.pi / 5.6, dgd=30e-12, seed=41, dtype=np.complex64)
-    E = np.ascontiguousarray(np.asarray(sig))
-    ntaps, S = 15, 4
-    tr = core_eq._cal_training_symbol_len(2, ntaps, E.shape[1]) - 7
-    w0 = core_eq._init_taps(ntaps, 2, 2, np.complex64)
-    if method in ("mrde", "sbd"):
-        _, w0, _ = hk.train_equaliser(E, tr, 2, 2, np.float32(2e-3), w0, None, False, core_eq._reshape_symbols(None, "mcma", M, np.complex64, 2), "mcma")
-    sy = core_eq._reshape_symbols(None, method, M, np.complex64, 2)
-    eo, wo, _ = hk.train_equaliser(E, tr, 2, 2, np.float32(5e-4), w0.copy(), None, False, sy, method)
-    dE, dsy, dmu = DeviceArray.from_host(E), DeviceArray.from_host(np.ascontiguousarray(sy)), DeviceArray.from_host(np.array([5e-4], np.float32))
-    res = {}
-    for P in (1, S):
-        dw, derr = DeviceArray.from_host(w0.copy()), DeviceArray((2, tr * 2), np.complex64, zero=True)
-        pc = np.zeros(P)
-        hk.train_equaliser_dev(dE, tr, 2, 2, dmu, dw, None, False, dsy, method, derr, segments=S, passes=P, pass_change=pc, prefix=512)
-        res[P] = (dw.to_host(), derr.to_host(), pc)
-    w, e, pc = res[S]
-    np.testing.assert_allclose(w, wo, rtol=2e-4, atol=2e-5)
-    np.testing.assert_allclose(e, eo, rtol=2e-4, atol=1e-4)
-    assert pc[0] == -1 and np.all(pc[1:] >= 0) and pc[-1] <= pc[1] + 1e-6          # the end taps settle
-    w1, e1, _ = res[1]
-    assert np.all(np.isfinite(w1)) and np.all(np.abs(e1[:, -1]) > 0)
-    assert np.array_equal(e1[:, :512], e[:, :512])                                 # the sequential prefix is the same in every pass count
 
 
 def test_trainer_fuzz_against_oracle():

@@ -18,6 +18,18 @@ from qampy_amd.core import phaserecovery as core_ph
 @pytest.fixture
 def oracle_kernels(monkeypatch):
     k = core_eq._kernels
+
+    class OracleField:                      # stands in for hip_equalisation.ResidentField (the capture resident in HBM)
+        def __init__(self, E):
+            self.E = E
+
+        def train(self, *a):
+            return oracle.train_equaliser(self.E, *a)
+
+        def apply(self, os, wx, modes=None):
+            return oracle.apply_filter_to_signal(self.E, os, np.ascontiguousarray(wx), modes)
+
+    monkeypatch.setattr(k, "ResidentField", OracleField)
     monkeypatch.setattr(k, "train_equaliser", oracle.train_equaliser)
     monkeypatch.setattr(k, "train_equaliser_realvalued", oracle.train_equaliser_realvalued)
     monkeypatch.setattr(k, "apply_filter_to_signal", oracle.apply_filter_to_signal)
