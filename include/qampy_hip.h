@@ -126,6 +126,16 @@ int qh_train_equaliser_windows_c128(const void *E, int nmodes, int64_t L, const 
                                     int64_t TrSyms, int Niter, int os, double mu, const void *wx0, int ntaps, const int64_t *modes, int nsel,
                                     int adaptive, const void *symbols, int64_t nsy, int method, void *wx_out, void *err, double *mu_out);
 
+/* Search form of the window batch: the error traces stay in HBM; out come var (nmodes, nwin) = variance of every window's
+ * error trace per mode (np.var of the complex row), best (nmodes) = window with the smallest variance per mode (first
+ * minimum) and wx_best (nmodes, nmodes, nmodes, ntaps) = the tap sets of those windows. */
+int qh_train_equaliser_windows_search_c64(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len,
+                                          int64_t TrSyms, int Niter, int os, float mu, const void *wx0, int ntaps, const int64_t *modes, int nsel,
+                                          int adaptive, const void *symbols, int64_t nsy, int method, double *var, int32_t *best, void *wx_best);
+int qh_train_equaliser_windows_search_c128(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len,
+                                           int64_t TrSyms, int Niter, int os, double mu, const void *wx0, int ntaps, const int64_t *modes, int nsel,
+                                           int adaptive, const void *symbols, int64_t nsy, int method, double *var, int32_t *best, void *wx_best);
+
 /* ---- train_equaliser_realvalued: same layout with real arrays, update without conjugate ---------------------- */
 int qh_train_equaliser_real_f32(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu, void *wx,
                                 int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
@@ -164,11 +174,14 @@ int qh_bps_c128_dev(const void *E, int64_t L, const void *testangles, int64_t p,
                     int32_t *idx);
 
 /* device-resident carrier recovery of the host layer qampy/core/phaserecovery.py:145-159 for `nm` modes at once:
- *   grid = linspace(-pi/4, pi/4, A, endpoint=False); idx = bps(E[m]); ph = grid[idx]; ph[N:-N] = unwrap(4 ph)/4;
- *   Eout = E * exp(1j ph).   E, Eout (nm, L) complex; ph (nm, L) real; idx (nm, L) int32 scratch/out. */
-int qh_bps_recover_c64_dev(const void *E, int nm, int64_t L, int A, const void *symbols, int M, int N, int32_t *idx,
+ *   idx = bps(E[m], grid); ph = grid[idx]; ph[N:-N] = unwrap(4 ph)/4; Eout = E * exp(1j ph).
+ * angles: the grid (A,) real in HBM, as the host builds it (np.linspace(-pi/4, pi/4, A, endpoint=False) in double, cast to
+ * the signal's precision), or NULL for a grid formed on the device.  np.unwrap's jump decisions are evaluated with numpy's own
+ * operations on the grid values (a jump of exactly half the range depends on their rounding), the running correction is an
+ * exact integer prefix sum.  E, Eout (nm, L) complex; ph (nm, L) real; idx (nm, L) int32 scratch/out. */
+int qh_bps_recover_c64_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *symbols, int M, int N, int32_t *idx,
                            void *ph, void *Eout);
-int qh_bps_recover_c128_dev(const void *E, int nm, int64_t L, int A, const void *symbols, int M, int N, int32_t *idx,
+int qh_bps_recover_c128_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *symbols, int M, int N, int32_t *idx,
                             void *ph, void *Eout);
 
 /* ---- select_angles: out[i] = angles[(p > 1 ? i : 0), idx[i]] ;  idx int64 (L,) ------------------------------- */

@@ -25,7 +25,7 @@ _pf, _pd = C.POINTER(C.c_float), C.POINTER(C.c_double)
 _TRAIN = [_vp, _i, _i64, _i64, _i, _i, None, _vp, _i, _vp, _i, _i, _vp, _i64, _i, _vp]      # [6] = mu pointer
 _APPLY = [_vp, _i, _i64, _i, _vp, _i, _vp, _i, _vp]
 _BPS = [_vp, _i64, _vp, _i64, _i, _vp, _i, _i, _vp]
-_RECOVER = [_vp, _i, _i64, _i, _vp, _i, _i, _vp, _vp, _vp]
+_RECOVER = [_vp, _i, _i64, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]
 _SELECT = [_vp, _i64, _i, _vp, _i64, _vp]
 _DECIDE = [_vp, _i64, _vp, _i, _vp, _vp, _vp]
 
@@ -61,6 +61,8 @@ SIGNATURES = {
     "qh_train_equaliser_c128_gram_dev": _train_sig(_pd, dev=True) + [_vp],
     "qh_train_equaliser_windows_c64": [_vp, _i, _i64, _vp, _i, _i64, _i64, _i, _i, C.c_float, _vp, _i, _vp, _i, _i, _vp, _i64, _i, _vp, _vp, _vp],
     "qh_train_equaliser_windows_c128": [_vp, _i, _i64, _vp, _i, _i64, _i64, _i, _i, C.c_double, _vp, _i, _vp, _i, _i, _vp, _i64, _i, _vp, _vp, _vp],
+    "qh_train_equaliser_windows_search_c64": [_vp, _i, _i64, _vp, _i, _i64, _i64, _i, _i, C.c_float, _vp, _i, _vp, _i, _i, _vp, _i64, _i, _vp, _vp, _vp],
+    "qh_train_equaliser_windows_search_c128": [_vp, _i, _i64, _vp, _i, _i64, _i64, _i, _i, C.c_double, _vp, _i, _vp, _i, _i, _vp, _i64, _i, _vp, _vp, _vp],
     "qh_train_equaliser_real_f32": _train_sig(_pf),
     "qh_train_equaliser_real_f64": _train_sig(_pd),
     "qh_apply_filter_c64": _APPLY, "qh_apply_filter_c128": _APPLY, "qh_apply_filter_f32": _APPLY, "qh_apply_filter_f64": _APPLY,

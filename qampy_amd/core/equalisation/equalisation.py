@@ -269,3 +269,23 @@ def equalise_signal_windows(E, os, mu, M, starts, win_len, Ntaps=None, TrSyms=No
     err, wxy, _ = _kernels.train_equaliser_windows(E, starts, win_len, TrSyms, Niter, os, mu, wxy0, modes, adaptive_stepsize,
                                                    symbols.copy(), method)
     return wxy, err
+
+
+def search_windows(E, os, mu, M, starts, win_len, Ntaps=None, TrSyms=None, Niter=1, method="mcma", adaptive_stepsize=False,
+                   symbols=None, modes=None, **kwargs):
+    """
+    The blind search of the frame synchronisation: an independent equaliser run from centre-spike taps on every window
+    ``E[:, s:s + win_len]``, ``s`` in ``starts``, all in one launch, of which only the summary comes back - ``(var (nmodes,
+    nwin), best (nmodes,), taps (nmodes, nmodes, nmodes, Ntaps))``: the variance of every window's error trace per mode, the
+    index (into ``starts``) of the window with the smallest variance per mode, and the taps that window ended with.
+    """
+    method = _method_name(method)
+    if method in REAL_VALUED or method in DATA_AIDED:
+        raise ValueError("window batches support the complex blind / decision-directed methods, not %s" % method)
+    E = np.array(np.asarray(E), copy=True, order="C", subok=False)
+    nmodes = E.shape[0]
+    if TrSyms is None:
+        TrSyms = _cal_training_symbol_len(os, Ntaps, win_len)
+    return _kernels.train_equaliser_windows_search(E, starts, win_len, TrSyms, Niter, os, E.real.dtype.type(mu), _init_taps(Ntaps, nmodes, nmodes, E.dtype),
+                                                   np.arange(nmodes) if modes is None else np.atleast_1d(modes), adaptive_stepsize,
+                                                   _reshape_symbols(symbols, method, M, E.dtype, nmodes).copy(), method)

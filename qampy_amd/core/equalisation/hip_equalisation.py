@@ -100,6 +100,30 @@ def train_equaliser_windows(E, starts, win_len, TrSyms, Niter, os, mu, wx0, mode
     return err, wx, mu_out
 
 
+def train_equaliser_windows_search(E, starts, win_len, TrSyms, Niter, os, mu, wx0, modes, adaptive, symbols, method):
+    """
+    :func:`train_equaliser_windows` for a search: the error traces never leave HBM.  Returns ``(var (nmodes, nwin), best
+    (nmodes,), wx_best (nmodes, nmodes, nmodes, ntaps))`` - the variance of every window's error trace per mode, the window
+    with the smallest one per mode (first minimum) and the taps those windows ended with.
+    """
+    if method not in _lib.METHOD_ID:
+        raise ValueError("Unknown method %s" % method)
+    suf, rt, ct = _lib.suffix(E.dtype)
+    _need(E, ct, "E"); _need(wx0, ct, "wx0")
+    symbols = np.ascontiguousarray(symbols)
+    _need(symbols, ct, "symbols")
+    nmodes, L = E.shape
+    modes = _as_modes(modes, nmodes)
+    starts = np.ascontiguousarray(starts, dtype=np.int64)
+    var = np.zeros((nmodes, starts.size), dtype=np.float64)
+    best = np.zeros(nmodes, dtype=np.int32)
+    wx = np.zeros((nmodes,) + wx0.shape, dtype=ct)
+    _lib.call("qh_train_equaliser_windows_search_c" + ("64" if suf == "32" else "128"), _lib.ptr(E), nmodes, L, _lib.ptr(starts), starts.size,
+              int(win_len), int(TrSyms), int(Niter), int(os), rt(mu), _lib.ptr(wx0), wx0.shape[-1], _lib.ptr(modes), modes.size,
+              _adaptive_flag(adaptive, False), _lib.ptr(symbols), symbols.shape[1], _lib.METHOD_ID[method], _lib.ptr(var), _lib.ptr(best), _lib.ptr(wx))
+    return var, best, wx
+
+
 def train_equaliser_realvalued(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method):
     """Real-valued trainer (pythran_equalisation.py:78-108); ``method`` without the ``_real`` suffix."""
     if method not in _lib.REAL_METHOD_ID:

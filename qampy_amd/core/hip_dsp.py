@@ -43,6 +43,8 @@ def select_angles(angles, idx):
     idx = np.ascontiguousarray(idx, dtype=np.int64)
     p, A = angles.shape
     L = idx.shape[0] if p <= 1 else p
+    if idx.shape[0] < L:
+        raise ValueError("a per-symbol grid of %d rows needs as many indices (got %d)" % (p, idx.shape[0]))
     if idx.size and (idx.max() >= A or idx.min() < 0):
         raise ValueError("angle index out of range")
     out = np.zeros(L, dtype=rt)
@@ -50,13 +52,41 @@ def select_angles(angles, idx):
     return out
 
 
-def bps_recover_dev(E, Mtestangles, symbols, N, idx, ph, Eout):
+def test_angle_grid(Mtestangles, rt):
+    """The ``(1, A)`` grid of the host layer: ``np.linspace(-pi/4, pi/4, A, endpoint=False)`` formed in double and cast
+    (qampy/core/phaserecovery.py:145)."""
+    return np.linspace(-np.pi / 4, np.pi / 4, int(Mtestangles), endpoint=False, dtype=rt).reshape(1, -1)
+
+
+def bps_recover_dev(E, Mtestangles, symbols, N, idx, ph, Eout, angles=None):
     """
-    Device-resident carrier recovery of all modes at once: BPS index, linspace grid look-up, unwrap of the interior
-    and de-rotation (host layer qampy/core/phaserecovery.py:145-159) without leaving HBM.  All arguments except the
-    integers are DeviceArrays: E, Eout (nmodes, L) complex; ph (nmodes, L) real; idx (nmodes, L) int32.
+    Device-resident carrier recovery of all modes at once: BPS index, grid look-up, ``np.unwrap`` of the interior and
+    de-rotation (host layer qampy/core/phaserecovery.py:145-159) without leaving HBM.  All arguments except the integers
+    are DeviceArrays: E, Eout (nmodes, L) complex; ph (nmodes, L) real; idx (nmodes, L) int32; ``angles`` the (A,) grid of
+    :func:`test_angle_grid` (``None``: formed on the device in the signal's precision).
     """
     suf, rt, ct = _lib.suffix(E.dtype)
     nm, L = E.shape
-    _lib.call("qh_bps_recover_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, nm, L, int(Mtestangles), symbols.ptr,
-              int(np.prod(symbols.shape)), int(N), idx.ptr, ph.ptr, Eout.ptr)
+    _lib.call("qh_bps_recover_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, nm, L, angles.ptr if angles is not None else None,
+              int(Mtestangles), symbols.ptr, int(np.prod(symbols.shape)), int(N), idx.ptr, ph.ptr, Eout.ptr)
+
+
+def bps_recover(E, Mtestangles, symbols, N):
+    """
+    Carrier recovery of every row of ``E (nmodes, L)`` in one go: upload once, blind phase search + unwrap + de-rotation in
+    HBM, ``(Eout, ph)`` back.  What the host layer of the reference does mode by mode with three compiled / numpy passes.
+    """
+    suf, rt, ct = _lib.suffix(E.dtype)
+    if E.ndim != 2 or not np.iscomplexobj(E):
+        raise TypeError("bps_recover works on a 2-d complex array")
+    symbols = np.ascontiguousarray(symbols)
+    if symbols.dtype != ct:
+        raise TypeError("symbols must be %s" % np.dtype(ct).name)
+    nm, L = E.shape
+    if L == 0:
+        return np.zeros((nm, 0), ct), np.zeros((nm, 0), rt)
+    D = _lib.DeviceArray
+    dE, dsy, dang = D.from_host(np.ascontiguousarray(E)), D.from_host(symbols), D.from_host(test_angle_grid(Mtestangles, rt))
+    idx, ph, out = D((nm, L), np.int32), D((nm, L), rt), D((nm, L), ct)
+    bps_recover_dev(dE, Mtestangles, dsy, N, idx, ph, out, angles=dang)
+    return out.to_host(), ph.to_host()

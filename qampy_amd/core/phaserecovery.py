@@ -5,38 +5,30 @@ The index search (one grid or a per-symbol grid) and the angle gather are the HI
 """
 import numpy as np
 
+from . import hip_dsp as _dsp
 from .hip_dsp import bps as _bps_idx_hip
 from .hip_dsp import select_angles
 
 
 def bps(E, Mtestangles, symbols, N, method="pyt", **kwargs):
     """
-    Blind phase search (Pfau et al. 2009), same contract as phaserecovery.py:93-159.
+    Blind phase search (Pfau et al. 2009), contract of qampy/core/phaserecovery.py:93-159: ``(Eout, ph)`` - the de-rotated
+    signal and the applied phase, unwrapped on ``[N, -N)`` (the first and last ``N`` symbols keep the first grid angle).
 
-    E : 1-d (one mode) or 2-d (modes x symbols) complex array at 1 sample/symbol
-    Mtestangles : number of test angles on [-pi/4, pi/4)
-    symbols : alphabet
-    N : half width of the averaging window (2N symbols are averaged)
-    method : kept for signature compatibility; "pyt" and "hip" both run the HIP kernel
+    E : 1-d (one mode) or 2-d (modes x symbols) complex array at 1 sample/symbol;  Mtestangles : angles on [-pi/4, pi/4);
+    symbols : alphabet;  N : half width of the averaging window (2N symbols);  method : "pyt" / "hip" (same kernels).
 
-    Returns ``(Eout, ph)``: de-rotated signal and the applied (unwrapped) phase.
+    All modes go through one fused device pass (index search, grid look-up, unwrap, de-rotation: ``hip_dsp.bps_recover``).
     """
     if method.lower() not in ("pyt", "hip"):
         raise ValueError("Method needs to be 'pyt' or 'hip' (the py/pyx/af back-ends of the reference are not provided)")
-    dtype = np.float32 if E.dtype is np.dtype(np.complex64) else np.float64
-    angles = np.linspace(-np.pi / 4, np.pi / 4, Mtestangles, endpoint=False, dtype=dtype).reshape(1, -1)
-    Ew = np.atleast_2d(E).astype(E.dtype)
-    symbols = np.asarray(symbols).astype(E.dtype, copy=False)
-    ph = []
-    for i in range(Ew.shape[0]):
-        idx = _bps_idx_hip(np.ascontiguousarray(np.asarray(Ew[i])), angles, symbols, N)
-        ph.append(select_angles(np.copy(angles), idx.astype(int)))
-    ph = np.asarray(ph, dtype=dtype)
-    # only the interior is unwrapped; the first and last N symbols keep angles[0] (phaserecovery.py:155)
-    ph[:, N:-N] = np.unwrap(ph[:, N:-N] * 4) / 4
+    rows = np.atleast_2d(E)
+    out, ph = _dsp.bps_recover(np.ascontiguousarray(rows), Mtestangles, np.asarray(symbols).astype(rows.dtype, copy=False), N)
     if E.ndim == 1:
-        return (Ew * np.exp(1.j * ph)).flatten(), ph.flatten()
-    return Ew * np.exp(1.j * ph), ph
+        return out.reshape(-1), ph.reshape(-1)
+    if type(E) is not np.ndarray and hasattr(E, "recreate_from_np_array"):        # keep the signal subclass like E * exp(..) does
+        out = E.recreate_from_np_array(out)
+    return out, ph
 
 
 def bps_twostage(E, Mtestangles, symbols, N, B=4, method="pyt", **kwargs):

@@ -283,13 +283,29 @@ constexpr int UW_THREADS = 256;
 constexpr int UW_PER_THREAD = 4;
 constexpr int UW_CHUNK = UW_THREADS * UW_PER_THREAD;
 
-__device__ __forceinline__ int unwrap_jump(int kprev, int kcur, int A)
+// np.unwrap's decision for the step from grid entry kprev to kcur of 4 * ph, evaluated with the operations numpy applies to
+// the array (numpy/lib/_function_base_impl.py unwrap: dd = diff(p); ddmod = mod(dd + pi, 2 pi) - pi; ddmod = pi where it is
+// -pi and dd > 0; correction = ddmod - dd, forced to 0 where |dd| < pi) in the precision of the phase array, on the values
+// of the grid the host built - a jump of exactly half the range sits on the edge of that rule and its outcome depends on the
+// rounding of the grid.  Returns the correction in units of 2 pi.
+template <typename R> __device__ __forceinline__ R fmod_(R a, R b);
+template <> __device__ __forceinline__ float fmod_<float>(float a, float b) { return fmodf(a, b); }
+template <> __device__ __forceinline__ double fmod_<double>(double a, double b) { return fmod(a, b); }
+template <typename R> __device__ __forceinline__ int unwrap_jump(const R *angles, int kprev, int kcur)
 {
-    const int d = kcur - kprev;
-    return (2 * d > A) ? -1 : ((2 * d < -A) ? 1 : 0);
+    const R pi = (R)3.14159265358979323846, twopi = (R)6.28318530717958647692;
+    const R dd = (R)4 * angles[kcur] - (R)4 * angles[kprev];
+    if (abs_(dd) < pi) return 0;
+    R m = fmod_<R>(dd + pi, twopi);
+    if (m != 0 && m < 0) m += twopi;
+    R ddmod = m - pi;
+    if (ddmod == -pi && dd > 0) ddmod = pi;
+    const R corr = ddmod - dd;
+    return (int)rint((double)corr / 6.28318530717958647692);
 }
 
-__global__ void __launch_bounds__(UW_THREADS) unwrap_partial_kernel(const int32_t *idx, int64_t L, int N, int A, int *chunk_sum,
+template <typename R>
+__global__ void __launch_bounds__(UW_THREADS) unwrap_partial_kernel(const int32_t *idx, int64_t L, int N, const R *angles, int *chunk_sum,
                                                                      int64_t nchunk)
 {
     // sums of the jump indicators of one chunk of one mode; interior = [N, L-N), the first interior element has no jump
@@ -300,7 +316,7 @@ __global__ void __launch_bounds__(UW_THREADS) unwrap_partial_kernel(const int32_
     int s = 0;
     for (int r = 0; r < UW_PER_THREAD; r++) {
         const int64_t i = base + threadIdx.x + (int64_t)r * UW_THREADS;
-        if (i > N && i < L - N) s += unwrap_jump(ix[i - 1], ix[i], A);
+        if (i > N && i < L - N) s += unwrap_jump<R>(angles, ix[i - 1], ix[i]);
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -332,7 +348,7 @@ __global__ void __launch_bounds__(64) unwrap_scan_kernel(int *chunk_sum, int64_t
 
 template <typename R>
 __global__ void __launch_bounds__(UW_THREADS) unwrap_apply_kernel(const Cx<R> *E, const int32_t *idx, const int *chunk_off,
-                                                                   int64_t L, int N, int A, int64_t nchunk, R *ph, Cx<R> *Eout)
+                                                                   int64_t L, int N, const R *angles, int64_t nchunk, R *ph, Cx<R> *Eout)
 {
     __shared__ int wsum[UW_THREADS / 64];
     __shared__ int tsum[UW_THREADS];
@@ -347,7 +363,7 @@ __global__ void __launch_bounds__(UW_THREADS) unwrap_apply_kernel(const Cx<R> *E
     for (int r = 0; r < UW_PER_THREAD; r++) {
         const int64_t i = t0 + r;
         int j = 0;
-        if (i > N && i < L - N) j = unwrap_jump(ix[i - 1], ix[i], A);
+        if (i > N && i < L - N) j = unwrap_jump<R>(angles, ix[i - 1], ix[i]);
         local += j;
         jmp[r] = local;                       // inclusive within the thread
     }
@@ -364,15 +380,14 @@ __global__ void __launch_bounds__(UW_THREADS) unwrap_apply_kernel(const Cx<R> *E
     for (int w = 0; w < (int)(threadIdx.x >> 6); w++) woff += wsum[w];
     const int off = chunk_off[mode * nchunk + blockIdx.x] + woff + tsum[threadIdx.x];
     const R pi = (R)3.14159265358979323846;
-    const R step = (pi / 2) / (R)A;            // linspace(-pi/4, pi/4, A, endpoint=False) spacing
 #pragma unroll
     for (int r = 0; r < UW_PER_THREAD; r++) {
         const int64_t i = t0 + r;
         if (i < L) {
             const bool interior = (i >= N && i < L - N);
             const int k = ix[i];
-            // edges keep the raw grid value of idx = 0, i.e. -pi/4 (phaserecovery.py:155 unwraps the interior only)
-            R p = -pi / 4 + step * (R)k;
+            // edges keep the raw grid value of idx = 0, i.e. angles[0] (phaserecovery.py:155 unwraps the interior only)
+            R p = angles[k];
             if (interior) p += (pi / 2) * (R)(off + jmp[r]);
             ph[mode * L + i] = p;
             R sn, cs;
@@ -390,24 +405,28 @@ template <typename R> __global__ void linspace_kernel(R *angles, int A)
     if (j < A) angles[j] = -pi / 4 + ((pi / 2) / (R)A) * (R)j;
 }
 
+// angles: the (A,) test-angle grid in HBM as the host layer builds it (np.linspace in double, cast to the signal's precision,
+// phaserecovery.py:145), or nullptr for a grid formed on the device in the signal's precision
 template <typename R>
-int bps_recover_dev(const void *E, int nm, int64_t L, int A, const void *symbols, int M, int N, int32_t *idx, void *ph, void *Eout)
+int bps_recover_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *symbols, int M, int N, int32_t *idx, void *ph, void *Eout)
 {
     int rc = ensure_init();
     if (rc) return rc;
     QH_REQUIRE(nm >= 1 && L >= 1 && A >= 1, "bps_recover: bad sizes");
     const int64_t nchunk = (L + UW_CHUNK - 1) / UW_CHUNK;
-    void *dang = nullptr, *dchunk = nullptr;     // grow-only library scratch: no allocation / sync in the steady state
-    if ((rc = scratch(0, (size_t)A * sizeof(R), &dang))) return rc;
+    void *dang = const_cast<void *>(angles), *dchunk = nullptr;     // grow-only library scratch: no allocation / sync in the steady state
     if ((rc = scratch(1, (size_t)nm * nchunk * sizeof(int), &dchunk))) return rc;
-    hipLaunchKernelGGL((linspace_kernel<R>), dim3((A + 63) / 64), dim3(64), 0, g_stream, (R *)dang, A);
+    if (!dang) {
+        if ((rc = scratch(0, (size_t)A * sizeof(R), &dang))) return rc;
+        hipLaunchKernelGGL((linspace_kernel<R>), dim3((A + 63) / 64), dim3(64), 0, g_stream, (R *)dang, A);
+    }
     for (int m = 0; m < nm; m++)
         if ((rc = bps_dev<R>((const Cx<R> *)E + (size_t)m * L, L, dang, 1, A, symbols, M, N, idx + (size_t)m * L))) return rc;
-    hipLaunchKernelGGL(unwrap_partial_kernel, dim3((unsigned)nchunk, nm), dim3(UW_THREADS), 0, g_stream, idx, L, N, A,
+    hipLaunchKernelGGL((unwrap_partial_kernel<R>), dim3((unsigned)nchunk, nm), dim3(UW_THREADS), 0, g_stream, idx, L, N, (const R *)dang,
                        (int *)dchunk, nchunk);
     hipLaunchKernelGGL(unwrap_scan_kernel, dim3(nm), dim3(64), 0, g_stream, (int *)dchunk, nchunk);
     hipLaunchKernelGGL((unwrap_apply_kernel<R>), dim3((unsigned)nchunk, nm), dim3(UW_THREADS), 0, g_stream, (const Cx<R> *)E, idx,
-                       (const int *)dchunk, L, N, A, nchunk, (R *)ph, (Cx<R> *)Eout);
+                       (const int *)dchunk, L, N, (const R *)dang, nchunk, (R *)ph, (Cx<R> *)Eout);
     QH_HIP(hipGetLastError());
     return QH_OK;
 }
@@ -521,10 +540,10 @@ int qh_bps_c64_dev(const void *E, int64_t L, const void *t, int64_t p, int A, co
 { return qh::bps_dev<float>(E, L, t, p, A, s, M, N, idx); }
 int qh_bps_c128_dev(const void *E, int64_t L, const void *t, int64_t p, int A, const void *s, int M, int N, int32_t *idx)
 { return qh::bps_dev<double>(E, L, t, p, A, s, M, N, idx); }
-int qh_bps_recover_c64_dev(const void *E, int nm, int64_t L, int A, const void *s, int M, int N, int32_t *idx, void *ph, void *Eout)
-{ return qh::bps_recover_dev<float>(E, nm, L, A, s, M, N, idx, ph, Eout); }
-int qh_bps_recover_c128_dev(const void *E, int nm, int64_t L, int A, const void *s, int M, int N, int32_t *idx, void *ph, void *Eout)
-{ return qh::bps_recover_dev<double>(E, nm, L, A, s, M, N, idx, ph, Eout); }
+int qh_bps_recover_c64_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *s, int M, int N, int32_t *idx, void *ph, void *Eout)
+{ return qh::bps_recover_dev<float>(E, nm, L, angles, A, s, M, N, idx, ph, Eout); }
+int qh_bps_recover_c128_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *s, int M, int N, int32_t *idx, void *ph, void *Eout)
+{ return qh::bps_recover_dev<double>(E, nm, L, angles, A, s, M, N, idx, ph, Eout); }
 int qh_select_angles_f32(const void *angles, int64_t p, int A, const int64_t *idx, int64_t L, void *out)
 { return qh::select_angles_host<float>(angles, p, A, idx, L, out); }
 int qh_select_angles_f64(const void *angles, int64_t p, int A, const int64_t *idx, int64_t L, void *out)

@@ -49,6 +49,13 @@ int qh_train_equaliser_c128_batch_dev(const void *E, int nch, int nmodes, int64_
 {
     return qh::train_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, zero_err, gram, nch);
 }
+int qh_train_equaliser_windows_search_c128(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len,
+                                            int64_t TrSyms, int Niter, int os, double mu, const void *wx0, int ntaps, const int64_t *modes, int nsel,
+                                            int adaptive, const void *symbols, int64_t nsy, int method, double *var, int32_t *best, void *wx_best)
+{
+    return qh::train_windows_host<double>(E, nmodes, L, win_start, nwin, win_len, TrSyms, Niter, os, mu, wx0, ntaps, modes, nsel, adaptive,
+                                      symbols, nsy, method, nullptr, nullptr, nullptr, var, best, wx_best);
+}
 int qh_train_equaliser_windows_c128(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len,
                                      int64_t TrSyms, int Niter, int os, double mu, const void *wx0, int ntaps, const int64_t *modes, int nsel,
                                      int adaptive, const void *symbols, int64_t nsy, int method, void *wx_out, void *err, double *mu_out)

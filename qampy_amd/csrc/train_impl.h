@@ -627,13 +627,53 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
     }
 }
 
+// variance of the error trace of every (window, mode): var[m * nwin + v] = mean |e - mean(e)|^2  (np.var of a complex row)
+template <typename R>
+__global__ void __launch_bounds__(256) win_var_kernel(const Cx<R> *err, int nmodes, int64_t n, double *var)
+{
+    __shared__ double r0[256], r1[256];
+    const int v = blockIdx.x, m = blockIdx.y, nwin = gridDim.x;
+    const Cx<R> *row = err + ((size_t)v * nmodes + m) * n;
+    double sr = 0, si = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) { const Cx<R> e = row[i]; sr += e.re; si += e.im; }
+    r0[threadIdx.x] = sr; r1[threadIdx.x] = si;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) { r0[threadIdx.x] += r0[threadIdx.x + s]; r1[threadIdx.x] += r1[threadIdx.x + s]; } __syncthreads(); }
+    const double mr = r0[0] / (double)n, mi = r1[0] / (double)n;
+    __syncthreads();
+    double q = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) { const Cx<R> e = row[i]; const double dr = e.re - mr, di = e.im - mi; q += dr * dr + di * di; }
+    r0[threadIdx.x] = q;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) r0[threadIdx.x] += r0[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) var[(size_t)m * nwin + v] = r0[0] / (double)n;
+}
+// first minimum of every mode's row of `var`; its window's tap set goes to wx_best[m]
+template <typename R>
+__global__ void __launch_bounds__(64) win_best_kernel(const double *var, int nwin, const Cx<R> *wx_all, int wset, int *best, Cx<R> *wx_best)
+{
+    const int m = blockIdx.x;
+    __shared__ int bi;
+    if (threadIdx.x == 0) {
+        int b = 0; double bv = var[(size_t)m * nwin];
+        for (int v = 1; v < nwin; v++) { const double x = var[(size_t)m * nwin + v]; if (x < bv) { bv = x; b = v; } }
+        bi = b; best[m] = b;
+    }
+    __syncthreads();
+    for (int f = threadIdx.x; f < wset; f += 64) wx_best[(size_t)m * wset + f] = wx_all[(size_t)bi * wset + f];
+}
+
 // Batch of independent equaliser runs on windows of one capture (host pointers).  Equivalent to calling train_host once per
 // window with E[:, start : start + win_len], the same initial taps and step size; all windows run concurrently.
 //   wx0 (nmodes, nmodes, ntaps) in;  wx_out (nwin, nmodes, nmodes, ntaps), err (nwin, nmodes, TrSyms*Niter), mu_out (nwin) out
+// Search form (var_out != nullptr; wx_out / err / mu_out may then be nullptr): the error traces stay in HBM, only their
+// variances var_out (nmodes, nwin), the window with the smallest variance per mode best (nmodes) and the tap sets of those
+// windows wx_best (nmodes, nmodes, nmodes, ntaps) come back - what the frame synchronisation needs (pilotbased_receiver.py:395-405).
 template <typename R>
 int train_windows_host(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len, int64_t TrSyms,
                        int Niter, int os, R mu, const void *wx0, int ntaps, const int64_t *modes, int nsel, int adaptive,
-                       const void *symbols, int64_t nsy, int method, void *wx_out, void *err, R *mu_out)
+                       const void *symbols, int64_t nsy, int method, void *wx_out, void *err, R *mu_out,
+                       double *var_out = nullptr, int *best = nullptr, void *wx_best = nullptr)
 {
     int rc = ensure_init();
     if (rc) return rc;
@@ -671,9 +711,24 @@ int train_windows_host(const void *E, int nmodes, int64_t L, const int64_t *win_
         a.win_start = (const int64_t *)dst.p; a.win_len = win_len; a.nwin = nwin; a.win_mu = (R *)dmo.p; a.e_off = 0;
         if ((rc = launch_any<R>(a))) return rc;
     }
-    if ((rc = dwo.to_host(wx_out, dwo.n))) return rc;
-    if ((rc = de.to_host(err, de.n))) return rc;
-    if ((rc = dmo.to_host(mu_out, dmo.n))) return rc;
+    if (wx_out && (rc = dwo.to_host(wx_out, dwo.n))) return rc;
+    if (err && (rc = de.to_host(err, de.n))) return rc;
+    if (mu_out && (rc = dmo.to_host(mu_out, dmo.n))) return rc;
+    if (var_out) {
+        QH_REQUIRE(best && wx_best, "train_equaliser_windows: the search form needs best and wx_best");
+        DevBuf dv, db, dwb;
+        if ((rc = dv.alloc((size_t)nmodes * nwin * sizeof(double)))) return rc;
+        if ((rc = db.alloc((size_t)nmodes * sizeof(int)))) return rc;
+        if ((rc = dwb.alloc((size_t)nmodes * wsz * cs))) return rc;
+        hipLaunchKernelGGL((win_var_kernel<R>), dim3(nwin, nmodes), dim3(256), 0, g_stream, (const Cx<R> *)de.p, nmodes, (int64_t)(TrSyms * Niter), (double *)dv.p);
+        hipLaunchKernelGGL((win_best_kernel<R>), dim3(nmodes), dim3(64), 0, g_stream, (const double *)dv.p, nwin, (const Cx<R> *)dwo.p, (int)wsz, (int *)db.p, (Cx<R> *)dwb.p);
+        QH_HIP(hipGetLastError());
+        if ((rc = dv.to_host(var_out, dv.n))) return rc;
+        if ((rc = db.to_host(best, db.n))) return rc;
+        if ((rc = dwb.to_host(wx_best, dwb.n))) return rc;
+        QH_HIP(hipStreamSynchronize(g_stream));
+        return QH_OK;
+    }
     QH_HIP(hipStreamSynchronize(g_stream));
     return QH_OK;
 }

@@ -78,6 +78,7 @@ class ResidentReceiver:
         self.eq = DeviceArray((self.modes.size, self.N), self.ct)
         if Mtestangles:
             self.alphabet = DeviceArray.from_host(self.alphabet_host)
+            self.angles = DeviceArray.from_host(_dsp.test_angle_grid(Mtestangles, self.rt))
             self.idx = DeviceArray((self.modes.size, self.N), np.int32)
             self.ph = DeviceArray((self.modes.size, self.N), self.rt)
             self.out = DeviceArray((self.modes.size, self.N), self.ct)
@@ -128,7 +129,7 @@ class ResidentReceiver:
         _k.apply_filter_to_signal_dev(self.E, self.os, self.wxy, self.modes, self.eq)
 
     def recover(self):
-        _dsp.bps_recover_dev(self.eq, self.Mtestangles, self.alphabet, self.Nbps, self.idx, self.ph, self.out)
+        _dsp.bps_recover_dev(self.eq, self.Mtestangles, self.alphabet, self.Nbps, self.idx, self.ph, self.out, angles=self.angles)
 
     def run(self):
         """One pass of the hot path over the resident capture; returns without synchronising."""
@@ -290,7 +291,7 @@ class ChannelBank:
         for c in range(self.nch):
             _k.apply_filter_to_signal_dev(self.E.row(c), self.os, wxy.row(c), r.modes, self.eq.row(c))
             if r.Mtestangles:
-                _dsp.bps_recover_dev(self.eq.row(c), r.Mtestangles, r.alphabet, r.Nbps, self.idx.row(c), self.ph.row(c), self.out.row(c))
+                _dsp.bps_recover_dev(self.eq.row(c), r.Mtestangles, r.alphabet, r.Nbps, self.idx.row(c), self.ph.row(c), self.out.row(c), angles=r.angles)
 
     def ser(self, ch, symbols_tx, maxlag=256, window=4096, trim=0):
         """Per-row symbol errors of channel ``ch`` (device harness, see :meth:`ResidentReceiver.ser`)."""

@@ -478,7 +478,66 @@ def gen_e2e(inp, meta):
     return cases
 
 
+# ------------------------------------------------------------------------------------------------ harness (rows f2, f4)
+def gen_harness():
+    """
+    Vectors that pin the measurement harness to the reference:
+      * SER: SignalQAMGrayCoded.cal_ser (qampy/signals.py:295-335 -> _sync_and_adjust :246-267 -> core/ber_functions.py:108-160
+        sync_and_adjust / find_sequence_offset_complex, + make_decision) on received versions of known symbols (noise, quarter
+        turns, delays, swapped modes);
+      * synthesis: pulse shaping to 2 samples/symbol (core/resample.py:73-126 rrcos_resample through Signal.resample),
+        first-order PMD (core/impairments.py:94-131 apply_PMD_to_field), the AWGN scaling of change_snr (:188-233) and the
+        Wiener phase-noise variance of phase_noise (:133-160), all on given symbols / seeded generators.
+    """
+    from qampy.core import impairments as ref_imp
+    arr = {}
+    # ---- SER
+    M, N = 64, 4096
+    s = ref_signals.SignalQAMGrayCoded(M, N, nmodes=2, fb=20e9, seed=[11, 12], dtype=np.complex128)
+    tx = np.asarray(s).copy()
+    arr["ser_tx"] = tx
+    arr["ser_alphabet"] = np.asarray(s.coded_symbols)
+    rng = np.random.default_rng(5)
+    cases = []
+    for name, rots, lags, swap, snr in (("clean", (0, 0), (0, 0), False, 40.), ("noisy", (0, 0), (0, 0), False, 19.),
+                                        ("rot_lag", (1, 3), (37, -12), False, 19.), ("swapped", (2, 1), (5, 200), True, 21.)):
+        rx = np.array([np.roll(tx[m] * 1j ** rots[m], lags[m]) for m in range(2)])
+        rx = rx + 10 ** (-snr / 20) * (rng.standard_normal(rx.shape) + 1j * rng.standard_normal(rx.shape)) / np.sqrt(2)
+        if swap:
+            rx = rx[::-1].copy()
+        ser, errs, tx_sync = s.cal_ser(signal_rx=s.recreate_from_np_array(rx), verbose=True)
+        arr["ser_%s_rx" % name] = rx
+        arr["ser_%s_ser" % name] = np.asarray(ser)
+        arr["ser_%s_errmask" % name] = np.asarray(errs) != 0            # per received symbol, in rx order
+        arr["ser_%s_txsync" % name] = np.asarray(tx_sync)
+        cases.append(dict(name=name, rots=list(rots), lags=list(lags), swap=swap, snr=snr))
+    # ---- synthesis
+    sy = ref_signals.SignalQAMGrayCoded(16, 4096, nmodes=2, fb=20e9, seed=[3, 5], dtype=np.complex128)
+    arr["syn_symbols"] = np.asarray(sy).copy()
+    up = sy.resample(2 * sy.fb, beta=0.1, renormalise=True)
+    arr["syn_shaped"] = np.asarray(up).copy()
+    arr["syn_pmd"] = np.asarray(ref_imp.apply_PMD_to_field(np.asarray(up), np.pi / 5.6, 30e-12, up.fs))
+    np.random.seed(7)
+    big = ref_signals.SignalQAMGrayCoded(16, 2 ** 15, nmodes=2, fb=20e9, seed=[1, 2], dtype=np.complex128).resample(40e9, beta=0.1, renormalise=True)
+    noisy = ref_imp.change_snr(big, 20., big.fb, big.fs)
+    arr["syn_noise_std"] = np.float64(np.std(np.asarray(noisy) - np.asarray(big)))
+    arr["syn_noise_power_in"] = np.float64(np.mean(np.abs(np.asarray(big)) ** 2))
+    np.random.seed(8)
+    ph = ref_imp.phase_noise((2, 2 ** 16), 100e3, 40e9)
+    arr["syn_pn_step_var"] = np.float64(np.var(np.diff(ph, axis=1)))
+    arr["syn_pn_params"] = np.array([100e3, 40e9])
+    save("harness.npz", arr)
+    return cases
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "harness":          # only this group (the others are unchanged)
+        path = os.path.join(OUT, "cases.json")
+        cases = json.load(open(path))
+        cases["harness"] = gen_harness()
+        with open(path, "w") as f:
+            json.dump(cases, f, indent=1, default=float)
+        return
     gen_constants()
     inp, meta = gen_inputs()
     cases = {"inputs": meta}
@@ -489,6 +548,7 @@ def main():
     gen_pilot()
     gen_decision()
     cases["e2e"] = gen_e2e(inp, meta)
+    cases["harness"] = gen_harness()
     cases["versions"] = dict(numpy=np.__version__, python=sys.version.split()[0], reference="QAMpy v0.5.1 (/root/reference)")
     with open(os.path.join(OUT, "cases.json"), "w") as f:
         json.dump(cases, f, indent=1, default=float)

@@ -33,6 +33,14 @@ def oracle_kernels(monkeypatch):
     monkeypatch.setattr(k, "train_equaliser", oracle.train_equaliser)
     monkeypatch.setattr(k, "train_equaliser_realvalued", oracle.train_equaliser_realvalued)
     monkeypatch.setattr(k, "apply_filter_to_signal", oracle.apply_filter_to_signal)
+    def oracle_recover(E, Mtestangles, symbols, N):          # what hip_dsp.bps_recover fuses on the device, from the oracle's parts
+        rt = E.real.dtype.type
+        angles = np.linspace(-np.pi / 4, np.pi / 4, Mtestangles, endpoint=False, dtype=rt).reshape(1, -1)
+        ph = np.array([oracle.select_angles(angles, oracle.bps(np.ascontiguousarray(r), angles, symbols, N)) for r in E], dtype=rt)
+        ph[:, N:-N] = np.unwrap(ph[:, N:-N] * 4) / 4
+        return E * np.exp(1j * ph), ph
+
+    monkeypatch.setattr(core_ph._dsp, "bps_recover", oracle_recover)
     monkeypatch.setattr(core_ph, "_bps_idx_hip", oracle.bps)
     monkeypatch.setattr(core_ph, "select_angles", oracle.select_angles)
 

@@ -22,13 +22,33 @@ def _oracle_windows(E, starts, win_len, TrSyms, Niter, os_, mu, wx0, modes, adap
     return np.array(errs), np.array(wxs), np.array(mus)
 
 
+def _oracle_search(E, starts, win_len, *a):
+    err, wx, _ = _oracle_windows(E, starts, win_len, *a)
+    var = np.var(err, axis=-1).T                       # (nmodes, nwin)
+    best = np.argmin(var, axis=-1)
+    return var, best, wx[best]
+
+
 @pytest.fixture
 def oracle_kernels(monkeypatch):
     k = core_eq._kernels
+
+    class OracleField:                      # stands in for hip_equalisation.ResidentField (the capture resident in HBM)
+        def __init__(self, E):
+            self.E = E
+
+        def train(self, *a):
+            return oracle.train_equaliser(self.E, *a)
+
+        def apply(self, os, wx, modes=None):
+            return oracle.apply_filter_to_signal(self.E, os, np.ascontiguousarray(wx), modes)
+
+    monkeypatch.setattr(k, "ResidentField", OracleField)
     monkeypatch.setattr(k, "train_equaliser", oracle.train_equaliser)
     monkeypatch.setattr(k, "train_equaliser_realvalued", oracle.train_equaliser_realvalued)
     monkeypatch.setattr(k, "apply_filter_to_signal", oracle.apply_filter_to_signal)
     monkeypatch.setattr(k, "train_equaliser_windows", _oracle_windows)
+    monkeypatch.setattr(k, "train_equaliser_windows_search", _oracle_search)
 
 
 def test_helpers_match_reference(golden):
