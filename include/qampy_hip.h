@@ -225,8 +225,8 @@ int qh_set_trainer(int form);
  *     signal excites (they forget within a segment) but not for the weakly excited ones (out-of-band directions, time
  *     constants 1/(mu g lambda) of millions of steps), whose state depends on the whole history.  Between the passes
  *     the boundary defects d[s] are therefore propagated through the LINEARISED segment map J = exp(-mu g T Rc), Rc the
- *     input covariance <conj(x) x^T> and g the mean gain of the error function: D[s+1] = d[s+1] + J D[s] (a parallel
- *     scan with the powers of J), start taps += D.  With J = 0 this is plain relaxation; J only preconditions the
+ *     input covariance <conj(x) x^T> and g the mean gain of the error function: D[s+1] = d[s+1] + J D[s] (in the
+ *     eigenbasis of Rc: one scalar first-order recurrence per direction, run as a parallel scan), start taps += D.  With J = 0 this is plain relaxation; J only preconditions the
  *     iteration - at the fixed point all defects vanish and the result is the sequential recurrence either way.
  * Fixed step only (adaptive = 0), no data-aided methods.  gram: table from qh_gram_build_*_dev for this (E, os, ntaps,
  * TrSyms), or NULL.  report_dev: device memory for one qh_pit_report (read it after qh_sync), or NULL. */
@@ -245,6 +245,7 @@ typedef struct qh_pit_opts {
     int64_t acq_max;        /* 0 = min(TrSyms / 2, 2^17) steps */
     int32_t correction;     /* -1 / 1: linearised coarse correction between the passes (see below), 0: plain relaxation */
     int32_t pad;
+    void *basis;            /* NULL, or the eigenbasis of this capture's input covariance from qh_pit_basis_*_dev (device memory) */
 } qh_pit_opts;
 typedef struct qh_pit_report {
     int32_t segments, passes, converged, acq_chunks;
@@ -256,6 +257,12 @@ typedef struct qh_pit_report {
     int32_t acq_done, done, diverged, corr_on;   /* device-side flags */
 } qh_pit_report;
 int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int *segments);
+/* Eigenbasis of the input covariance <conj(x) x^T> of the training windows of a capture, for the coarse correction: depends
+ * on (E, os, ntaps, TrSyms) only, so one build serves every stage and sweep over the same capture.  basis: device memory of
+ * qh_pit_basis_bytes(nmodes*ntaps) bytes.  nmodes*ntaps <= 96. */
+int qh_pit_basis_bytes(int ntot, size_t *bytes);
+int qh_pit_basis_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis);
+int qh_pit_basis_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis);
 /* kernel time (HIP events on the library stream) of the trainer launches of the most recent qh_train_equaliser_*_pit_dev call:
  * the relaxation passes in order (all sweeps) and the sum of the acquisition chunks */
 int qh_pit_last_timing(float *pass_ms, int max_passes, int *npass, float *acq_ms);

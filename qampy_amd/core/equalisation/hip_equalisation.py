@@ -315,6 +315,22 @@ class PitReportBuffer(DeviceArray):
         return _lib.PitReport.from_buffer_copy(raw.tobytes()).as_dict()
 
 
+def pit_basis_dev(E, os, ntaps, TrSyms, basis=None):
+    """
+    Eigenbasis of the input covariance of a resident capture for the coarse correction of the parallel-in-time trainer
+    (``qh_pit_basis_*_dev``); depends on ``E, os, ntaps, TrSyms`` only, so one build serves every stage.  Returns the
+    DeviceArray holding it (pass ``basis`` to reuse an allocation); hand its ``ptr`` to ``pit=dict(basis=...)``.
+    """
+    suf, rt, ct = _lib.suffix(E.dtype)
+    nmodes, L = E.shape
+    if basis is None:
+        n = C.c_size_t(0)
+        _lib.call("qh_pit_basis_bytes", nmodes * int(ntaps), C.byref(n))
+        basis = DeviceArray((n.value,), np.uint8)
+    _lib.call("qh_pit_basis_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, nmodes, L, int(os), int(ntaps), int(TrSyms), basis.ptr)
+    return basis
+
+
 def pit_last_timing():
     """Kernel time of the trainer launches of the most recent parallel-in-time call: ``(pass_ms list, acquisition ms)``."""
     buf = (C.c_float * _lib.PIT_MAXPASS)()

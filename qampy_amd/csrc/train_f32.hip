@@ -51,6 +51,15 @@ int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int *segments)
     *segments = qh::pit_auto_segments(TrSyms, mu, nsel);
     return QH_OK;
 }
+int qh_pit_basis_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis)
+{
+    return qh::pit_basis<float>(E, nmodes, L, os, ntaps, TrSyms, basis);
+}
+int qh_pit_basis_bytes(int ntot, size_t *bytes)
+{
+    *bytes = qh::pit_basis_bytes(ntot);
+    return QH_OK;
+}
 int qh_gram_build_c64_batch_dev(const void *E, int nch, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
 {
     if (!qh::la_shape_ok(nmodes, ntaps, os) && qh::bi_shape_ok(nmodes, ntaps, os, 2 * sizeof(float))) return qh::gram_cur_build<float>(E, nmodes, L, os, ntaps, TrSyms, gram, nch);

@@ -38,6 +38,10 @@ int qh_train_equaliser_c128_pit_dev(const void *E, int nmodes, int64_t L, int64_
 {
     return qh::train_pit_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, symbols, nsy, method, err, zero_err, gram, opts, report_dev);
 }
+int qh_pit_basis_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis)
+{
+    return qh::pit_basis<double>(E, nmodes, L, os, ntaps, TrSyms, basis);
+}
 int qh_gram_build_c128_batch_dev(const void *E, int nch, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
 {
     if (!qh::la_shape_ok(nmodes, ntaps, os) && qh::bi_shape_ok(nmodes, ntaps, os, 2 * sizeof(double))) return qh::gram_cur_build<double>(E, nmodes, L, os, ntaps, TrSyms, gram, nch);

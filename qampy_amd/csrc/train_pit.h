@@ -11,6 +11,7 @@
 // rot (S x nsel) pass-0 phase rotations, z (S x nsel) 4th-power sums, dfc (S x nsel) boundary defects.
 #pragma once
 #include "train_impl.h"
+#include "train_seg.h"
 
 namespace qh {
 
@@ -373,109 +374,239 @@ static __global__ void __launch_bounds__(256) pit_cov_reduce_kernel(const Z *par
     Rc[e] = Z{ar, ai};
 }
 
-// B = -(mu g T / (nwin 2^PIT_SCALE)) Rc;  the 4th-order Taylor polynomial needs |B| <~ 1: checked with the trace
-constexpr int PIT_SCALE = 12;
-template <typename R>
-__global__ void __launch_bounds__(256) pit_expm_scale_kernel(const Z *Rc, int ntot, int nwin, int64_t T, const R *mu, PitCtrl *c, Z *B)
+// Eigenbasis of the covariance: cyclic Jacobi (parallel round-robin ordering, n/2 disjoint rotations per round) on the
+// Hermitian matrix Rc / nwin, whole problem in the LDS of ONE workgroup, single precision (the basis only preconditions the
+// relaxation).  Out: lam[n] eigenvalues, V[i][k] = component i of eigenvector k.  n <= PIT_EIGMAX.
+typedef float2 Zf;
+constexpr int PIT_EIGMAX = 96, PIT_EIGSWEEPS = 7;        // 7 sweeps: off-diagonal 1e-5, smallest eigenvalues good to 0.2 % (float)
+__device__ __forceinline__ Zf cmulf(Zf a, Zf b) { return Zf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, int n, double norm, double *lam, Zf *Vout)
 {
-    if (c->done || !c->corr_on) return;
-    __shared__ double tr[256];
-    double t = 0;
-    for (int f = threadIdx.x; f < ntot; f += 256) t += Rc[(size_t)f * ntot + f].x;
-    tr[threadIdx.x] = t;
+    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
+    const int ld = n + 1;
+    Zf *A = reinterpret_cast<Zf *>(pit_smem);                 // [n][ld]
+    Zf *V = A + (size_t)n * ld;                               // [n][ld]
+    float4 *rot = reinterpret_cast<float4 *>(V + (size_t)n * ld);   // [npair]: c, s, e.re, e.im
+    int2 *pq = reinterpret_cast<int2 *>(rot + (PIT_EIGMAX + 2) / 2);   // [npair]: the pair's indices, p < q (q >= n: idle)
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int i = wave; i < n; i += 16)
+        for (int j = lane; j < n; j += 64) {
+            const Z v = Rc[(size_t)i * n + j];
+            A[i * ld + j] = Zf{(float)(v.x * norm), (float)(v.y * norm)};
+            V[i * ld + j] = Zf{i == j ? 1.f : 0.f, 0.f};
+        }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) tr[threadIdx.x] += tr[threadIdx.x + s]; __syncthreads(); }
-    const double a = (double)*mu * c->gain * (double)T / ((double)nwin * (double)(1 << PIT_SCALE));
-    if (!(a * tr[0] < 1.0)) { if (threadIdx.x == 0) c->corr_on = 0; return; }
-    for (int e = threadIdx.x; e < ntot * ntot; e += 256) B[e] = Z{-a * Rc[e].x, -a * Rc[e].y};
+    const int m = (n + 1) & ~1;                               // players of the round-robin (a dummy when n is odd)
+    const int npair = m / 2;
+    for (int sweep = 0; sweep < PIT_EIGSWEEPS; sweep++) {
+        for (int r = 0; r < m - 1; r++) {
+            if (tid < npair) {
+                // pair `tid` of round r (circle method): player m-1 stays, the others rotate
+                int a, b;
+                if (tid == 0) { a = m - 1; b = r; }
+                else {
+                    a = r + tid; if (a >= m - 1) a -= m - 1;
+                    b = r - tid; if (b < 0) b += m - 1;
+                }
+                const int p = a < b ? a : b, q = a < b ? b : a;
+                float4 g = {1.f, 0.f, 1.f, 0.f};
+                if (q < n) {
+                    const Zf apq = A[p * ld + q];
+                    const float app = A[p * ld + p].x, aqq = A[q * ld + q].x;
+                    const float mag = sqrtf(apq.x * apq.x + apq.y * apq.y);
+                    if (mag > 1e-30f) {
+                        const float tau = (aqq - app) / (2.f * mag);
+                        const float t = (tau >= 0 ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
+                        const float c = 1.f / sqrtf(1.f + t * t);
+                        g = float4{c, t * c, apq.x / mag, apq.y / mag};
+                    }
+                }
+                rot[tid] = g;
+                pq[tid] = int2{p, q};
+            }
+            __syncthreads();
+            // columns p, q of A and V:  col_p' = c col_p - s conj(e) col_q ;  col_q' = s col_p + c conj(e) col_q
+            for (int i = wave; i < npair; i += 16) {
+                const int2 ix = pq[i];
+                if (ix.y >= n) continue;
+                const float4 g = rot[i];
+                for (int row = lane; row < n; row += 64) {
+#pragma unroll
+                    for (int which = 0; which < 2; which++) {
+                        Zf *Mx = which ? V : A;
+                        const Zf xp = Mx[row * ld + ix.x], xq = Mx[row * ld + ix.y];
+                        const Zf xqe = cmulf(Zf{g.z, -g.w}, xq);        // conj(e) x_q
+                        Mx[row * ld + ix.x] = Zf{g.x * xp.x - g.y * xqe.x, g.x * xp.y - g.y * xqe.y};
+                        Mx[row * ld + ix.y] = Zf{g.y * xp.x + g.x * xqe.x, g.y * xp.y + g.x * xqe.y};
+                    }
+                }
+            }
+            __syncthreads();
+            // rows p, q of A:  row_p' = c row_p - s e row_q ;  row_q' = s row_p + c e row_q
+            for (int i = wave; i < npair; i += 16) {
+                const int2 ix = pq[i];
+                if (ix.y >= n) continue;
+                const float4 g = rot[i];
+                for (int col = lane; col < n; col += 64) {
+                    const Zf xp = A[ix.x * ld + col], xq = A[ix.y * ld + col];
+                    const Zf xqe = cmulf(Zf{g.z, g.w}, xq);
+                    A[ix.x * ld + col] = Zf{g.x * xp.x - g.y * xqe.x, g.x * xp.y - g.y * xqe.y};
+                    A[ix.y * ld + col] = Zf{g.y * xp.x + g.x * xqe.x, g.y * xp.y + g.x * xqe.y};
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int k = tid; k < n; k += 1024) lam[k] = (double)A[k * ld + k].x;
+    for (int i = wave; i < n; i += 16)
+        for (int k = lane; k < n; k += 64) Vout[(size_t)i * n + k] = V[i * ld + k];
 }
-// T1 = B/6 + B2/24 ;  P0 = I + B + B2/2
-static __global__ void __launch_bounds__(256) pit_expm_poly_kernel(const Z *B, const Z *B2, int ntot, const PitCtrl *c, Z *T1, Z *P0)
-{
-    if (c->done || !c->corr_on) return;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= ntot * ntot) return;
-    const Z b = B[e], b2 = B2[e];
-    const double id = (e / ntot == e % ntot) ? 1.0 : 0.0;
-    T1[e] = Z{b.x / 6 + b2.x / 24, b.y / 6 + b2.y / 24};
-    P0[e] = Z{id + b.x + b2.x / 2, b.y + b2.y / 2};
-}
-// C[i][c] = (Cadd ? Cadd[i][c] : 0) + sum_k A[i][k] Bm[k][c - shift]   (columns c < shift take no product), row-major
-static __global__ void __launch_bounds__(256) pit_zgemm_kernel(const Z *A, const Z *Bm, const Z *Cadd, Z *Cm, int M, int N, int K, int shift, const PitCtrl *c)
+
+// C[m][c] = sum_k op(A)[m][k] B[k][c],  op(A) = A (CONJT = false) or A^H; A is n x n, B and C are n x ncol (row-major)
+template <bool CONJT>
+__global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B, Zf *C, int n, int ncol, const PitCtrl *c)
 {
     if (c->done) return;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
-    if (!c->corr_on) {                                          // correction off: D = d (plain relaxation)
-        if (Cadd && row < M && col < N) Cm[(size_t)row * N + col] = Cadd[(size_t)row * N + col];
-        return;
+    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
+    Zf *As = reinterpret_cast<Zf *>(pit_smem);                // [n][n]  op(A)
+    Zf *Bs = As + (size_t)n * n;                               // [n][64]
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col0 = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int i = e / n, k = e - i * n;
+        Zf v = CONJT ? A[(size_t)k * n + i] : A[e];
+        if (CONJT) v.y = -v.y;
+        As[e] = v;
     }
-    __shared__ Z ta[16][17], tb[16][17];
-    Z acc{0, 0};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        const int ka = k0 + tx, kb = k0 + ty;
-        ta[ty][tx] = (row < M && ka < K) ? A[(size_t)row * K + ka] : Z{0, 0};
-        tb[ty][tx] = (kb < K && col < N && col >= shift) ? Bm[(size_t)kb * N + (col - shift)] : Z{0, 0};
-        __syncthreads();
+    for (int e = threadIdx.x; e < n * 64; e += 256) {
+        const int k = e >> 6, cc = e & 63;
+        Bs[e] = col0 + cc < ncol ? B[(size_t)k * ncol + col0 + cc] : Zf{0.f, 0.f};
+    }
+    __syncthreads();
+    if (col0 + tx >= ncol) return;
+    for (int m0 = ty; m0 < n; m0 += 4 * 8) {                   // 8 rows per trip: m0, m0+4, ...
+        Zf acc[8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) { const Z p = zmul(ta[ty][k], tb[k][tx]); acc.x += p.x; acc.y += p.y; }
-        __syncthreads();
-    }
-    if (row < M && col < N) {
-        if (Cadd) { const Z a = Cadd[(size_t)row * N + col]; acc.x += a.x; acc.y += a.y; }
-        Cm[(size_t)row * N + col] = acc;
+        for (int u = 0; u < 8; u++) acc[u] = Zf{0.f, 0.f};
+        for (int k = 0; k < n; k++) {
+            const Zf b = Bs[k * 64 + tx];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int mm = m0 + 4 * u;
+                if (mm < n) {
+                    const Zf a = As[mm * n + k];
+                    acc[u].x += a.x * b.x - a.y * b.y;
+                    acc[u].y += a.x * b.y + a.y * b.x;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int mm = m0 + 4 * u;
+            if (mm < n) C[(size_t)mm * ncol + col0 + tx] = acc[u];
+        }
     }
 }
+
+// In the eigenbasis the linearised segment map is diagonal, J = diag(exp(-mu g T lam_k)), and D[s] = d[s] + J D[s-1] is one
+// first-order recurrence with a constant coefficient per (eigen-direction k, mode j): block (k, j) runs it over the S
+// segments (chunks per thread, then the carries).  Correction off -> coefficient 0 (D = d: plain relaxation).
+template <typename R>
+__global__ void __launch_bounds__(256) pit_recur_kernel(Zf *D, const double *lam, int nsel, int S, int64_t T, const R *mu, const PitCtrl *c)
+{
+    if (c->done) return;
+    __shared__ Zf tot[256];
+    __shared__ Zf car[256];
+    const int k = blockIdx.x, j = blockIdx.y;
+    const int ncol = S * nsel;
+    Zf *row = D + (size_t)k * ncol + j;
+    double a = (double)*mu * c->gain * (double)T * lam[k];
+    if (a < 0) a = 0;
+    const float coef = c->corr_on ? (float)exp(-a) : 0.f;
+    const int len = (S + 255) / 256;
+    const int s0 = threadIdx.x * len, s1 = s0 + len < S ? s0 + len : S;
+    Zf run{0.f, 0.f};
+    for (int s = s0; s < s1; s++) {
+        const Zf d = row[(size_t)s * nsel];
+        run = Zf{d.x + coef * run.x, d.y + coef * run.y};
+        row[(size_t)s * nsel] = run;
+    }
+    tot[threadIdx.x] = run;
+    __syncthreads();
+    const float clen = powf(coef, (float)len);
+    if (threadIdx.x == 0) {
+        Zf cin{0.f, 0.f};
+        for (int t = 0; t < 256; t++) { car[t] = cin; cin = Zf{tot[t].x + clen * cin.x, tot[t].y + clen * cin.y}; }
+    }
+    __syncthreads();
+    const Zf cin = car[threadIdx.x];
+    float pw = coef;
+    for (int s = s0; s < s1; s++) {
+        Zf v = row[(size_t)s * nsel];
+        v.x += pw * cin.x; v.y += pw * cin.y;
+        row[(size_t)s * nsel] = v;
+        pw *= coef;
+    }
+}
+
 // Gauge fixing.  The error functions are equivariant under their symmetry group (errfn(g y) = g errfn(y)), so the trajectory
 // from rotated start taps is the rotated trajectory and a relative rotation g_s between the start taps of segment s and the
 // end taps of segment s-1 (yB ~ g_s yA, from the defect kernel) is not an error: theta_s = g_1 ... g_s brings every segment
 // into the frame of segment 0, where the boundary defects are formed and corrected (a rotation treated as an additive
 // defect would be wrong in second order and keep the iteration from converging below ~theta^2).
-static __global__ void __launch_bounds__(64) pit_gauge_kernel(const double *gph, int S, int nsel, const PitCtrl *c, double *theta)
+static __global__ void __launch_bounds__(256) pit_gauge_kernel(const double *gph, int S, int nsel, const PitCtrl *c, double *theta)
 {
     if (c->done) return;
-    const int j = threadIdx.x;
-    if (j >= nsel) return;
-    double tr = 1, ti = 0;
-    theta[2 * (size_t)j] = 1; theta[2 * (size_t)j + 1] = 0;
-    for (int s = 1; s < S; s++) {
-        const double gr = gph[2 * ((size_t)(s - 1) * nsel + j)], gi = gph[2 * ((size_t)(s - 1) * nsel + j) + 1];
-        const double nr = tr * gr - ti * gi, ni = tr * gi + ti * gr;
-        const double nn = sqrt(nr * nr + ni * ni);
-        tr = nr / nn; ti = ni / nn;
-        theta[2 * ((size_t)s * nsel + j)] = tr; theta[2 * ((size_t)s * nsel + j) + 1] = ti;
+    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
+    double *ang = reinterpret_cast<double *>(pit_smem);         // [nsel][S] angles of g_s, then their running sums
+    for (int e = threadIdx.x; e < S * nsel; e += 256) {
+        const int s = e / nsel, j = e - s * nsel;
+        ang[(size_t)j * S + s] = s == 0 ? 0.0 : atan2(gph[2 * ((size_t)(s - 1) * nsel + j) + 1], gph[2 * ((size_t)(s - 1) * nsel + j)]);
+    }
+    __syncthreads();
+    if (threadIdx.x < nsel) {
+        double *a = ang + (size_t)threadIdx.x * S;
+        double acc = 0;
+        for (int s = 0; s < S; s++) { acc += a[s]; a[s] = acc; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < S * nsel; e += 256) {
+        const int s = e / nsel, j = e - s * nsel;
+        const double t = ang[(size_t)j * S + s];
+        theta[2 * (size_t)e] = cos(t); theta[2 * (size_t)e + 1] = sin(t);
     }
 }
 // D[f][s nsel + j] = theta_{s-1} Y[s-1][mode_j][f] - theta_s X[s][mode_j][f]  (s >= 1), 0 for s = 0
 template <typename R>
-__global__ void __launch_bounds__(256) pit_dvec_kernel(const Cx<R> *X, const Cx<R> *Y, int nmodes, int ntot, const int64_t *modes_dev, int nsel, int S, const PitCtrl *c,
-                                                       const double *theta, Z *D)
+__global__ void __launch_bounds__(128) pit_dvec_kernel(const Cx<R> *X, const Cx<R> *Y, int nmodes, int ntot, const int64_t *modes_dev, int nsel, int S, const PitCtrl *c,
+                                                       const double *theta, Zf *D)
 {
     if (c->done) return;
     const int col = blockIdx.x, s = col / nsel, j = col - s * nsel;
     const size_t wset = (size_t)nmodes * ntot, ro = (size_t)modes_dev[j] * ntot;
     const int ncol = S * nsel;
-    for (int f = threadIdx.x; f < ntot; f += 256) {
-        Z v{0, 0};
+    for (int f = threadIdx.x; f < ntot; f += 128) {
+        Zf v{0.f, 0.f};
         if (s > 0) {
             const Cx<R> b = Y[(size_t)(s - 1) * wset + ro + f], a = X[(size_t)s * wset + ro + f];
             const double pr = theta[2 * (size_t)(col - nsel)], pi = theta[2 * (size_t)(col - nsel) + 1], qr = theta[2 * (size_t)col], qi = theta[2 * (size_t)col + 1];
-            v = Z{(pr * b.re - pi * b.im) - (qr * a.re - qi * a.im), (pr * b.im + pi * b.re) - (qr * a.im + qi * a.re)};
+            v = Zf{(float)((pr * b.re - pi * b.im) - (qr * a.re - qi * a.im)), (float)((pr * b.im + pi * b.re) - (qr * a.im + qi * a.re))};
         }
         D[(size_t)f * ncol + col] = v;
     }
 }
 // X[s][mode_j][f] = theta_s X[s][mode_j][f] + D[f][s nsel + j]
 template <typename R>
-__global__ void __launch_bounds__(256) pit_dapply_kernel(Cx<R> *X, int nmodes, int ntot, const int64_t *modes_dev, int nsel, int S, const PitCtrl *c,
-                                                         const double *theta, const Z *D)
+__global__ void __launch_bounds__(128) pit_dapply_kernel(Cx<R> *X, int nmodes, int ntot, const int64_t *modes_dev, int nsel, int S, const PitCtrl *c,
+                                                         const double *theta, const Zf *D)
 {
     if (c->done) return;
     const int col = blockIdx.x, s = col / nsel, j = col - s * nsel;
     const size_t wset = (size_t)nmodes * ntot, ro = (size_t)modes_dev[j] * ntot;
     const int ncol = S * nsel;
-    for (int f = threadIdx.x; f < ntot; f += 256) {
-        const Z d = D[(size_t)f * ncol + col];
+    for (int f = threadIdx.x; f < ntot; f += 128) {
+        const Zf d = D[(size_t)f * ncol + col];
         const double qr = theta[2 * (size_t)col], qi = theta[2 * (size_t)col + 1];
         Cx<R> &x = X[(size_t)s * wset + ro + f];
         x = Cx<R>{(R)(qr * x.re - qi * x.im + d.x), (R)(qr * x.im + qi * x.re + d.y)};
@@ -507,6 +638,38 @@ inline int pit_auto_segments(int64_t TrSyms, double mu, int nsel)
     return (int)S;
 }
 
+// Eigenbasis of the input covariance of a capture (depends on E, os, ntaps, TrSyms only - one build serves every stage):
+// basis = [ntot eigenvalues (double)][ntot x ntot eigenvectors (float complex, V[i][k])] in device memory.
+inline size_t pit_basis_bytes(int ntot) { return (size_t)ntot * sizeof(double) + (size_t)ntot * ntot * sizeof(Zf); }
+inline bool pit_basis_ok(int ntot, size_t elem) { return ntot <= PIT_EIGMAX && (size_t)PIT_COVW * ntot * elem <= 64 * 1024; }
+template <typename R>
+int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    const int ntot = nmodes * ntaps;
+    QH_REQUIRE(pit_basis_ok(ntot, sizeof(Cx<R>)), "pit basis: nmodes*ntaps too large for the eigen-solver");
+    QH_REQUIRE(TrSyms >= 1 && (TrSyms - 1) * os + ntaps <= L, "pit basis: field shorter than TrSyms*os + ntaps");
+    const size_t msz = (size_t)ntot * ntot;
+    void *cb = nullptr;
+    if ((rc = scratch(9, (1 + (size_t)PIT_COVB) * msz * sizeof(Z), &cb))) return rc;
+    Z *Rc = (Z *)cb, *part = Rc + msz;
+    const int ncov = (int)(TrSyms < PIT_COVW * PIT_COVB ? TrSyms : PIT_COVW * PIT_COVB);
+    const int ept = (int)((msz + 255) / 256);
+    const size_t lds = (size_t)PIT_COVW * ntot * sizeof(Cx<R>);
+    if (ept <= 8) hipLaunchKernelGGL((pit_cov_kernel<R, 8>), dim3(PIT_COVB), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
+    else if (ept <= 32) hipLaunchKernelGGL((pit_cov_kernel<R, 32>), dim3(PIT_COVB), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
+    else hipLaunchKernelGGL((pit_cov_kernel<R, 64>), dim3(PIT_COVB), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
+    hipLaunchKernelGGL(pit_cov_reduce_kernel, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, g_stream, (const Z *)part, (int)msz, PIT_COVB, Rc);
+    static bool attr_set = false;
+    const size_t jlds = 2 * (size_t)ntot * (ntot + 1) * sizeof(Zf) + (size_t)((PIT_EIGMAX + 2) / 2) * (sizeof(float4) + sizeof(int2));
+    if (!attr_set) { QH_HIP(hipFuncSetAttribute((const void *)pit_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); attr_set = true; }
+    hipLaunchKernelGGL(pit_jacobi_kernel, dim3(1), dim3(1024), jlds, g_stream, (const Z *)Rc, ntot, 1.0 / (double)ncov, (double *)basis,
+                       (Zf *)((char *)basis + (size_t)ntot * sizeof(double)));
+    QH_HIP(hipGetLastError());
+    return QH_OK;
+}
+
 template <typename R>
 int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu_dev, void *wx, int ntaps,
                   const int64_t *modes, int nsel, const void *symbols, int64_t nsy, int method, void *err, int zero_err,
@@ -533,7 +696,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     const double plateau = o.acq_plateau > 0 ? o.acq_plateau : 0.9;
     const int sym = pit_symmetry(method);
     const bool seed_phase = o.phase_seed < 0 ? sym == 4 : o.phase_seed != 0;
-    const bool want_corr = o.correction != 0 && ntot <= 128 && (size_t)PIT_COVW * ntot * sizeof(Cx<R>) <= 64 * 1024;
+    const bool want_corr = o.correction != 0 && pit_basis_ok(ntot, sizeof(Cx<R>));
 
     // ---- control block / report
     void *cbuf = nullptr;
@@ -587,10 +750,20 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     const bool decision = method == QH_M_SBD || method == QH_M_MDDMA || method == QH_M_DD;
     void *dd_table = nullptr;
     int dd_npart = -1;
-    if (bi_ok && decision) {
+    bool seg_ok = force[0] == 0 && seg_supported(method, nmodes, ntaps, os, nsy, sizeof(Cx<R>), nsel);
+    if ((bi_ok || seg_ok) && decision) {
         if ((rc = slicer_tables<R>(symbols, nmodes, nsy, modes, nsel, &dd_table, &dd_npart))) return rc;
-        bi_ok = dd_npart == 1 || dd_npart == 3 || dd_npart == 7 || dd_npart == 15;
+        const bool sq = dd_npart == 1 || dd_npart == 3 || dd_npart == 7 || dd_npart == 15;
+        bi_ok = bi_ok && sq; seg_ok = seg_ok && sq;
     }
+    // Form of the passes.  Few chains: the latency forms (look-ahead / block-iterative, one workgroup per chain).  Many
+    // chains: the throughput form (train_seg.h: 16 lanes per chain, no Gram table).  QAMPY_HIP_PIT_FORM = segment | block forces.
+    {
+        const char *pf = getenv("QAMPY_HIP_PIT_FORM");
+        if (pf && pf[0] == 'b') seg_ok = false;
+        else if (!(pf && pf[0] == 's') && (int64_t)sg.S * nsel < 512) seg_ok = false;
+    }
+    const bool seg_form = seg_ok;
     const bool la_ok = force[0] != 'd' && la_supported(method, 0, nmodes, ntaps, os, sg.len, nsy);
     const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
     (void)partitioned;
@@ -614,55 +787,42 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     QH_HIP(hipMemcpyAsync(modes_dev, modes, (size_t)nsel * sizeof(int64_t), hipMemcpyHostToDevice, g_stream));
     QH_HIP(hipStreamSynchronize(g_stream));                       // `modes` is the caller's memory
 
-    // ---- Gram table of the whole sweep: acquisition chunks and segments index into it
+    // ---- Gram table: of the whole sweep when the passes run in a block form (acquisition chunks and segments index into
+    // it), of the acquisition range only when they run in the throughput form
+    int64_t amax = 0;
+    if (o.acquire) {
+        amax = o.acq_max > 0 ? o.acq_max : (TrSyms / 2 < 131072 ? TrSyms / 2 : 131072);
+        if (amax > TrSyms) amax = TrSyms;
+    }
     void *G = const_cast<void *>(gram);
-    if (block_form && !G) {
-        rc = pair_tab ? gram_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G) : gram_cur_build<R>(E, nmodes, L, os, ntaps, TrSyms, &G);
+    if (block_form && !G && (!seg_form || amax > 0)) {
+        const int64_t n = seg_form ? (amax / LA_B + 1) * LA_B < TrSyms ? (amax / LA_B + 1) * LA_B : TrSyms : TrSyms;
+        rc = pair_tab ? gram_build<R>(E, nmodes, L, os, ntaps, n, &G) : gram_cur_build<R>(E, nmodes, L, os, ntaps, n, &G);
         if (rc) return rc;
     }
     const int64_t g_per_step = pair_tab ? LA_B : GRAM_TRI / 2 / LA_B;      // GramPair elements per step
 
-    // ---- coarse correction: covariance of the training windows, room for the powers of the linearised segment map
-    int nround = 0;
-    while ((1 << nround) < sg.S) nround++;
+    // ---- coarse correction: eigenbasis of the input covariance (the caller's, or built here), defect vectors in that basis
     const int ncol = sg.S * nsel;
-    const size_t msz = (size_t)ntot * ntot;
-    Z *Rc = nullptr, *Mw[2] = {nullptr, nullptr}, *Mr = nullptr, *Dz[2] = {nullptr, nullptr};
-    const int ncov = (int)(TrSyms < PIT_COVW * PIT_COVB ? TrSyms : PIT_COVW * PIT_COVB);
+    const double *lam = nullptr;
+    const Zf *Vb = nullptr;
+    Zf *Dz[2] = {nullptr, nullptr};
     if (want_corr) {
         void *cb = nullptr;
-        if ((rc = scratch(9, ((5 + (size_t)nround + PIT_COVB) * msz + 2 * (size_t)ntot * ncol) * sizeof(Z), &cb))) return rc;
-        Rc = (Z *)cb; Mw[0] = Rc + msz; Mw[1] = Mw[0] + msz; Mr = Mw[1] + msz; Dz[0] = Mr + ((size_t)nround + 2) * msz; Dz[1] = Dz[0] + (size_t)ntot * ncol;
-        Z *part = Dz[1] + (size_t)ntot * ncol;
-        const int ept = (int)((msz + 255) / 256);
-        const size_t lds = (size_t)PIT_COVW * ntot * sizeof(Cx<R>);
-        if (ept <= 8) hipLaunchKernelGGL((pit_cov_kernel<R, 8>), dim3(PIT_COVB), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
-        else if (ept <= 32) hipLaunchKernelGGL((pit_cov_kernel<R, 32>), dim3(PIT_COVB), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
-        else hipLaunchKernelGGL((pit_cov_kernel<R, 64>), dim3(PIT_COVB), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
-        hipLaunchKernelGGL(pit_cov_reduce_kernel, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, g_stream, (const Z *)part, (int)msz, PIT_COVB, Rc);
-        QH_HIP(hipGetLastError());
+        if ((rc = scratch(10, pit_basis_bytes(ntot) + 2 * (size_t)ntot * ncol * sizeof(Zf) + 64, &cb))) return rc;
+        void *basis = o.basis ? o.basis : cb;
+        if (!o.basis && (rc = pit_basis<R>(E, nmodes, L, os, ntaps, TrSyms, basis))) return rc;
+        lam = (const double *)basis; Vb = (const Zf *)((const char *)basis + (size_t)ntot * sizeof(double));
+        Dz[0] = (Zf *)((char *)cb + (pit_basis_bytes(ntot) + 63) / 64 * 64); Dz[1] = Dz[0] + (size_t)ntot * ncol;
     }
-    const dim3 gsq((ntot + 15) / 16, (ntot + 15) / 16), gsc((ncol + 15) / 16, (ntot + 15) / 16);
-    // powers of J = exp(-mu g T Rc): Mr[r] = J^(2^r); needs the gain, i.e. runs after the first pass of the call
-    auto build_powers = [&]() -> int {
-        hipLaunchKernelGGL((pit_expm_scale_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const Z *)Rc, ntot, ncov, sg.len, (const R *)mu_dev, ctrl, Mw[0]);   // B
-        hipLaunchKernelGGL(pit_zgemm_kernel, gsq, dim3(256), 0, g_stream, (const Z *)Mw[0], (const Z *)Mw[0], (const Z *)nullptr, Mw[1], ntot, ntot, ntot, 0, (const PitCtrl *)ctrl);   // B2
-        Z *T1 = Mr, *P0 = Mr + msz;                                  // temporaries in the (not yet used) power slots; nround >= 2 since S >= 4
-        hipLaunchKernelGGL(pit_expm_poly_kernel, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, g_stream, (const Z *)Mw[0], (const Z *)Mw[1], ntot, (const PitCtrl *)ctrl, T1, P0);
-        hipLaunchKernelGGL(pit_zgemm_kernel, gsq, dim3(256), 0, g_stream, (const Z *)Mw[1], (const Z *)T1, (const Z *)P0, Mw[0], ntot, ntot, ntot, 0, (const PitCtrl *)ctrl);       // exp(B)
-        int cur = 0;
-        for (int q = 0; q < PIT_SCALE; q++) {                        // undo the scaling: the last squaring lands in Mr[0]
-            Z *dst = q == PIT_SCALE - 1 ? Mr : Mw[cur ^ 1];
-            hipLaunchKernelGGL(pit_zgemm_kernel, gsq, dim3(256), 0, g_stream, (const Z *)Mw[cur], (const Z *)Mw[cur], (const Z *)nullptr, dst, ntot, ntot, ntot, 0, (const PitCtrl *)ctrl);
-            cur ^= 1;
-        }
-        for (int r = 1; r < nround; r++)
-            hipLaunchKernelGGL(pit_zgemm_kernel, gsq, dim3(256), 0, g_stream, (const Z *)(Mr + (size_t)(r - 1) * msz), (const Z *)(Mr + (size_t)(r - 1) * msz), (const Z *)nullptr,
-                               Mr + (size_t)r * msz, ntot, ntot, ntot, 0, (const PitCtrl *)ctrl);
-        QH_HIP(hipGetLastError());
-        return QH_OK;
-    };
-    bool have_powers = false;
+    const size_t glds = ((size_t)ntot * ntot + (size_t)ntot * 64) * sizeof(Zf);
+    static bool gemm_attr = false;
+    if (want_corr && !gemm_attr) {
+        QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        QH_HIP(hipFuncSetAttribute((const void *)pit_gauge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        gemm_attr = true;
+    }
 
     LaArgs<R> la;
     la.E = (const Cx<R> *)E; la.symbols = (const Cx<R> *)symbols; la.err = (Cx<R> *)err; la.G = (const GramPair<R> *)G; la.gpair = pair_tab ? 1 : 0;
@@ -671,7 +831,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     la.nmodes = nmodes; la.ntaps = ntaps; la.os = os; la.nsel = nsel; la.method = method;
     la.E_cs = 0; la.err_cs = 0; la.G_cs = 0; la.wx_cs = (int64_t)wset;
     for (int j = 0; j < 16; j++) la.modes[j] = j < nsel ? modes[j] : 0;
-    if (use_bi && decision) { la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV; }
+    if ((use_bi || seg_form) && decision) { la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV; }
     la.prof = nullptr; la.seg = 0; la.seg_extra = 0; la.seg_tail = 0; la.skip = nullptr;
     TrainArgs<R> ta;
     ta.E = (const Cx<R> *)E; ta.symbols = (const Cx<R> *)symbols; ta.err = (Cx<R> *)err; ta.mu = mu_dev;
@@ -687,8 +847,6 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     for (int it = 0; it < Niter; it++) {
         // ================================================================ acquisition (first sweep of a cold start)
         if (it == 0 && o.acquire) {
-            int64_t amax = o.acq_max > 0 ? o.acq_max : (TrSyms / 2 < 131072 ? TrSyms / 2 : 131072);
-            if (amax > TrSyms) amax = TrSyms;
             int64_t CH = o.acq_chunk > 0 ? o.acq_chunk : 4096;
             if (CH * QH_PIT_MAXCHUNK < amax) CH = (amax + QH_PIT_MAXCHUNK - 1) / QH_PIT_MAXCHUNK;
             CH = (CH + LA_B - 1) / LA_B * LA_B;
@@ -733,24 +891,30 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             if (p > 0 && want_corr) {
                 // start taps += D,  D[s+1] = d[s+1] + J D[s]  (d = boundary defects): a parallel scan over the segments.  With the
                 // correction switched off on the device (corr_on = 0) the products are skipped and D = d: plain relaxation.
-                if (!have_powers) { if ((rc = build_powers())) return rc; have_powers = true; }
-                hipLaunchKernelGGL(pit_gauge_kernel, dim3(1), dim3(64), 0, g_stream, (const double *)gph, sg.S, nsel, (const PitCtrl *)ctrl, theta);
-                hipLaunchKernelGGL((pit_dvec_kernel<R>), dim3(ncol), dim3(256), 0, g_stream, (const Cx<R> *)X, (const Cx<R> *)Y, nmodes, ntot, (const int64_t *)modes_dev, nsel, sg.S,
+                hipLaunchKernelGGL(pit_gauge_kernel, dim3(1), dim3(256), (size_t)ncol * sizeof(double), g_stream, (const double *)gph, sg.S, nsel, (const PitCtrl *)ctrl, theta);
+                hipLaunchKernelGGL((pit_dvec_kernel<R>), dim3(ncol), dim3(128), 0, g_stream, (const Cx<R> *)X, (const Cx<R> *)Y, nmodes, ntot, (const int64_t *)modes_dev, nsel, sg.S,
                                    (const PitCtrl *)ctrl, (const double *)theta, Dz[0]);
-                int cur = 0;
-                for (int r = 0; r < nround; r++) {
-                    hipLaunchKernelGGL(pit_zgemm_kernel, gsc, dim3(256), 0, g_stream, (const Z *)(Mr + (size_t)r * msz), (const Z *)Dz[cur], (const Z *)Dz[cur], Dz[cur ^ 1],
-                                       ntot, ncol, ntot, (1 << r) * nsel, (const PitCtrl *)ctrl);
-                    cur ^= 1;
-                }
-                hipLaunchKernelGGL((pit_dapply_kernel<R>), dim3(ncol), dim3(256), 0, g_stream, X, nmodes, ntot, (const int64_t *)modes_dev, nsel, sg.S, (const PitCtrl *)ctrl, (const double *)theta, (const Z *)Dz[cur]);
+                hipLaunchKernelGGL((pit_cgemm_kernel<true>), dim3((ncol + 63) / 64), dim3(256), glds, g_stream, Vb, (const Zf *)Dz[0], Dz[1], ntot, ncol, (const PitCtrl *)ctrl);
+                hipLaunchKernelGGL((pit_recur_kernel<R>), dim3(ntot, nsel), dim3(256), 0, g_stream, Dz[1], lam, nsel, sg.S, sg.len, (const R *)mu_dev, (const PitCtrl *)ctrl);
+                hipLaunchKernelGGL((pit_cgemm_kernel<false>), dim3((ncol + 63) / 64), dim3(256), glds, g_stream, Vb, (const Zf *)Dz[1], Dz[0], ntot, ncol, (const PitCtrl *)ctrl);
+                hipLaunchKernelGGL((pit_dapply_kernel<R>), dim3(ncol), dim3(128), 0, g_stream, X, nmodes, ntot, (const int64_t *)modes_dev, nsel, sg.S, (const PitCtrl *)ctrl,
+                                   (const double *)theta, (const Zf *)Dz[0]);
                 QH_HIP(hipGetLastError());
             } else if (p > 0) {
                 QH_HIP(hipMemcpyAsync(X + wset, Y, (size_t)(sg.S - 1) * wbytes, hipMemcpyDeviceToDevice, g_stream));   // X[s] = end taps of s-1
             }
             QH_HIP(hipMemcpyAsync(Y, X, (size_t)sg.S * wbytes, hipMemcpyDeviceToDevice, g_stream));
             QH_HIP(hipEventRecord(ev[0], g_stream));
-            if (block_form) {
+            if (seg_form) {
+                SegArgs<R> sa;
+                sa.E = (const Cx<R> *)E; sa.wx = Y; sa.symbols = la.symbols; sa.err = (Cx<R> *)err; sa.mu = mu_dev;
+                sa.L = L; sa.TrSyms = TrSyms; sa.nsy = la.nsy; sa.sy_pitch = la.sy_pitch; sa.err_pitch = TrSyms * Niter; sa.err_off = (int64_t)it * TrSyms;
+                sa.nmodes = nmodes; sa.ntaps = ntaps; sa.os = os; sa.nsel = nsel; sa.S = sg.S;
+                sa.seg_len = sg.len; sa.seg_extra = sg.extra; sa.seg_tail = sg.tail; sa.seg_begin = 0;
+                for (int j = 0; j < 16; j++) sa.modes[j] = j < nsel ? modes[j] : 0;
+                sa.skip = &ctrl->done;
+                if ((rc = launch_seg<R>(sa, method))) return rc;
+            } else if (block_form) {
                 LaArgs<R> ls = la;
                 ls.TrSyms = sg.len; ls.nch = sg.S; ls.wx = Y; ls.err_off = (int64_t)it * TrSyms; ls.seg = 1; ls.seg_extra = sg.extra; ls.seg_tail = sg.tail;
                 ls.skip = &ctrl->done;

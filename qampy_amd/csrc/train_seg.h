@@ -1,0 +1,324 @@
+// Throughput form of the equaliser recurrence for MANY concurrent chains (segments of a sweep, train_pit.h).
+//
+// The exact-path kernels minimise the latency of ONE chain (look-ahead: 13 instructions per step on the critical wave, paid
+// for with a 1 KiB-per-step Gram table; block-iterative: 8 waves per chain).  With thousands of chains in flight the stage is
+// bound by instruction issue (and the look-ahead form by streaming its table: 4.3 GB per pass at C3), so this kernel spends
+// as few instructions per chain and step as the recurrence allows and reads nothing but the capture:
+//   * 16 lanes per chain, 4 chains per wave64 (one wave per workgroup, no workgroup barrier anywhere);
+//   * the nmodes*ntaps taps of a chain are spread over its 16 lanes, TPL consecutive taps of one input mode per lane, and live
+//     in registers for the whole segment; per step a lane reads its TPL samples from an LDS window (staged chunk-wise with
+//     coalesced loads, double buffered; chains of the same segment - its output modes - share the window);
+//   * the dot product is reduced over the 16 lanes with 4 DPP steps (quad_perm, row_half_mirror, row_mirror: every lane ends
+//     up with the total), the error function is evaluated redundantly in all lanes, every lane updates its own taps;
+//   * ~45 instructions per step for 4 chains (~11 per chain and step, against ~25 of the look-ahead form over its 4 waves and
+//     ~125 of the block-iterative one).
+// Same recurrence, same error functions (la_errfn); results equal the other forms up to the order of the additions in the dot
+// product (16-lane tree instead of 64-lane tree / look-ahead identity).
+#pragma once
+#include "train_bi.h"
+
+namespace qh {
+
+constexpr int SG_CH = 64;          // steps per staged chunk
+
+template <typename R> struct SegArgs {
+    const Cx<R> *E;
+    Cx<R> *wx;                // (S, nmodes, nmodes*ntaps) tap sets, trained in place
+    const Cx<R> *symbols;
+    Cx<R> *err;               // rows of err_pitch, this sweep starts at column err_off
+    const R *mu;
+    int64_t L, TrSyms, nsy, sy_pitch, err_pitch, err_off;
+    int nmodes, ntaps, os, nsel, S;
+    int64_t seg_len, seg_extra, seg_tail, seg_begin;
+    int64_t modes[16];
+    const int *skip;
+    int lpm, pitch, rag, nslots;   // lanes per input mode, LDS row pitch (samples), padding taps in the last lane of a mode, segment windows per wave
+};
+
+// sum over the 16 lanes of a row; every lane gets the total
+__device__ __forceinline__ void row16_csum(float &re, float &im)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        : "+v"(re), "+v"(im));
+}
+__device__ __forceinline__ void row16_csum(double &re, double &im)
+{
+    re += dpp_mov<DPP_QUAD_1032>(re);       im += dpp_mov<DPP_QUAD_1032>(im);
+    re += dpp_mov<DPP_QUAD_2301>(re);       im += dpp_mov<DPP_QUAD_2301>(im);
+    re += dpp_mov<DPP_ROW_HALF_MIRROR>(re); im += dpp_mov<DPP_ROW_HALF_MIRROR>(im);
+    re += dpp_mov<DPP_ROW_MIRROR>(re);      im += dpp_mov<DPP_ROW_MIRROR>(im);
+}
+
+constexpr int SG_PITCH = 192;      // samples per LDS row (one segment window of one input mode): 3 pieces of 64
+constexpr int SG_PIECES = SG_PITCH / 64;
+constexpr int SG_ROWS = 4;         // rows per buffer: segment windows of the wave x input modes
+constexpr int SG_NSTG = SG_ROWS * SG_PIECES;      // staging registers per lane
+constexpr int SG_MAXRAG = 3;       // padding taps a lane may hold (handled by selects on its last three tap slots)
+
+template <typename R, int METHOD, int NPART, int TPL>
+__global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
+{
+    if (a.skip && *a.skip) return;
+    extern __shared__ __attribute__((aligned(16))) char sg_smem[];
+    Cx<R> *lds = reinterpret_cast<Cx<R> *>(sg_smem);          // [2 buffers][SG_ROWS][SG_PITCH] + zero row [SG_PITCH]
+    using v2 = typename V2<R>::type;
+    const int lane = threadIdx.x;
+    const int l16 = lane & 15;
+    const int nq = a.S * a.nsel;                               // chains of the launch
+    const int q0 = blockIdx.x * 4;
+    const int q = q0 + (lane >> 4);
+    const bool alive = q < nq;
+    const int qc = alive ? q : nq - 1;
+    const int seg = qc / a.nsel, jsel = qc - seg * a.nsel;
+    const int seg0 = q0 / a.nsel;                              // first segment of this wave
+    const int segl = ((q0 + 3 < nq ? q0 + 3 : nq - 1)) / a.nsel;
+    const int nslot = segl - seg0 + 1;
+    const int slot = seg - seg0;
+    const int mode = (int)a.modes[jsel];
+    const int ntot = a.nmodes * a.ntaps;
+    const int os_ = a.os;
+    auto seg_start = [&](int64_t s) { return a.seg_begin + s * a.seg_len + (s < a.seg_extra ? s : a.seg_extra) * LA_B; };
+    auto seg_steps = [&](int64_t s) { return (int)(a.seg_len + (s < a.seg_extra ? LA_B : 0) + (s == a.S - 1 ? a.seg_tail : 0)); };
+    const int64_t my_start = seg_start(seg);
+    const int my_steps = alive ? seg_steps(seg) : 0;
+    int max_steps = 0;
+    for (int s = seg0; s <= segl; s++) { const int n = seg_steps(s); max_steps = n > max_steps ? n : max_steps; }
+
+    // ---- taps: lane <-> TPL consecutive taps of input mode kin
+    const int kin = l16 / a.lpm, t0 = (l16 - kin * a.lpm) * TPL;
+    const bool has = kin < a.nmodes;
+    Cx<R> *wrow = a.wx + ((size_t)seg * a.nmodes + mode) * ntot;
+    v2 w[TPL];
+#pragma unroll
+    for (int j = 0; j < TPL; j++) {
+        const bool ok = has && t0 + j < a.ntaps;
+        const Cx<R> v = ok ? wrow[kin * a.ntaps + t0 + j] : Cx<R>{0, 0};
+        w[j] = v2{v.re, v.im};
+    }
+    // ---- error-function constants
+    const Cx<R> *sy = a.symbols + (size_t)mode * a.sy_pitch;
+    LaConst<R, NPART> K;
+    K.mu = *a.mu;
+    { const Cx<R> c0 = sy[0]; K.R_re = c0.re; K.R_im = c0.im; }
+    K.code0_re = K.R_re; K.code0_im = K.R_im;
+    tab_fill<R, NPART>(K.tab, sy, 0, NPART + 1);
+
+    // ---- LDS windows: SG_ROWS rows of SG_PITCH samples per buffer, one per (segment window, input mode)
+    constexpr int rowsz = SG_PITCH;
+    constexpr int bufsz = SG_ROWS * SG_PITCH;
+    const int nrow = nslot * a.nmodes;                          // <= SG_ROWS (checked on the host)
+    Cx<R> *zero_row = lds + 2 * bufsz;
+    for (int e = lane; e < rowsz; e += 64) zero_row[e] = Cx<R>{0, 0};
+    int64_t rowbase[SG_ROWS], rowlim[SG_ROWS];                  // sample offset of row r at chunk 0, last sample of its capture row (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < SG_ROWS; r++) {
+        const int rc = r < nrow ? r : 0;
+        const int sl = rc / a.nmodes, k = rc - sl * a.nmodes;
+        rowbase[r] = (int64_t)k * a.L + seg_start(seg0 + sl) * os_;
+        rowlim[r] = (int64_t)k * a.L + a.L - 1;
+    }
+    Cx<R> stg_r[SG_NSTG];
+    // global loads of chunk `chunk` into registers (no wait) ...
+    auto stage_load = [&](int chunk) {
+        const int64_t adv = (int64_t)chunk * SG_CH * os_;
+#pragma unroll
+        for (int u = 0; u < SG_NSTG; u++) {
+            const int row = u / SG_PIECES, piece = u % SG_PIECES;
+            if (row < nrow) {
+                int64_t g = rowbase[row] + adv + piece * 64 + lane;
+                if (g > rowlim[row]) g = rowlim[row];           // reads stay inside their row of the capture
+                stg_r[u] = ldg(a.E + g);
+            }
+        }
+    };
+    // ... and from there into the buffer of that chunk once the previous user of the buffer is done
+    auto stage_store = [&](int chunk) {
+        Cx<R> *dst = lds + (chunk & 1) * bufsz;
+#pragma unroll
+        for (int u = 0; u < SG_NSTG; u++)
+            if (u / SG_PIECES < nrow) dst[u * 64 + lane] = stg_r[u];
+    };
+    Cx<R> *errow = a.err + (size_t)mode * a.err_pitch + a.err_off + my_start;
+    R ebr = 0, ebi = 0;                                        // error of step i waits in lane (i & 15) of the chain for a 16-step store
+    // padding taps (the last lane of an input mode may hold up to SG_MAXRAG): their samples are replaced by zeros, so they stay zero
+    bool padj[SG_MAXRAG];
+#pragma unroll
+    for (int r = 0; r < SG_MAXRAG; r++) padj[r] = has && (TPL - SG_MAXRAG + r >= 0) && (t0 + TPL - SG_MAXRAG + r >= a.ntaps);
+    const bool ragged = a.rag != 0;
+
+    auto load_x = [&](v2 (&x)[TPL], const Cx<R> *p) {
+#pragma unroll
+        for (int j = 0; j < TPL; j++) { const Cx<R> v = p[j]; x[j] = v2{v.re, v.im}; }
+    };
+    auto step = [&](v2 (&x)[TPL], int i, int gstep) {
+        if (ragged) {                                          // wave-uniform
+#pragma unroll
+            for (int r = 0; r < SG_MAXRAG; r++)
+                if (TPL - SG_MAXRAG + r >= 0 && padj[r]) x[TPL - SG_MAXRAG + r < 0 ? 0 : TPL - SG_MAXRAG + r] = v2{0, 0};
+        }
+        // y = sum w x  (no conjugate, pythran_equalisation.py:24-31): two accumulators, combined before the reduction
+        v2 p = {0, 0}, r = {0, 0};
+#pragma unroll
+        for (int j = 0; j < TPL; j++) {
+            p = __builtin_elementwise_fma(v2{x[j].x, x[j].x}, w[j], p);      // x.re * (w.re, w.im)
+            r = __builtin_elementwise_fma(v2{x[j].y, x[j].y}, w[j], r);      // x.im * (w.re, w.im)
+        }
+        R yr = p.x - r.y, yi = p.y + r.x;
+        row16_csum(yr, yi);
+        const Cx<R> y{yr, yi};
+        const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K);
+        Cx<R> cc = la_errfn<R, METHOD, NPART, true>(y, K);     // mu * e with mu folded in
+        if (gstep >= my_steps) cc = Cx<R>{0, 0};               // past the end of this chain's segment: nothing moves
+        const bool mine = l16 == (i & 15);
+        ebr = mine ? e.re : ebr;
+        ebi = mine ? e.im : ebi;
+        // w += c conj(x):  (re, im) += x.re (c.re, c.im) + x.im (c.im, -c.re)
+        const v2 c1 = {cc.re, cc.im}, c2 = {cc.im, -cc.re};
+#pragma unroll
+        for (int j = 0; j < TPL; j++) {
+            w[j] = __builtin_elementwise_fma(v2{x[j].x, x[j].x}, c1, w[j]);
+            w[j] = __builtin_elementwise_fma(v2{x[j].y, x[j].y}, c2, w[j]);
+        }
+    };
+
+    const int nchunk = (max_steps + SG_CH - 1) / SG_CH;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; c++) {
+        if (c + 1 < nchunk) stage_load(c + 1);                  // in flight while this chunk computes
+        const Cx<R> *xs = has ? lds + (c & 1) * bufsz + (slot * a.nmodes + kin) * rowsz + t0 : zero_row;
+        const int xstep = has ? os_ : 0;
+        const int ibase = c * SG_CH;
+        const int nst = (max_steps - ibase) < SG_CH ? (max_steps - ibase) : SG_CH;
+        v2 xa[TPL], xb[TPL];
+        load_x(xa, xs);
+        int i = 0;
+        for (; i + 2 <= nst; i += 2) {                          // the samples of step i+1 are read while step i computes
+            load_x(xb, xs + (i + 1) * xstep);
+            step(xa, i, ibase + i);
+            load_x(xa, xs + (i + 2) * xstep);                   // may look one step past the chunk: inside the row's slack
+            step(xb, i + 1, ibase + i + 1);
+            if (((i + 1) & 15) == 15) {                         // 16 errors per chain staged: one store per chain
+                const int gi = ibase + i + 1 - 15 + l16;
+                if (gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
+            }
+        }
+        if (i < nst) { step(xa, i, ibase + i); i++; }
+        if ((nst & 15) != 0) {                                   // ragged end of the last chunk
+            const int gi = ibase + (nst & ~15) + l16;
+            if (l16 < (nst & 15) && gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
+        }
+        if (c + 1 < nchunk) stage_store(c + 1);                  // the other buffer: its last readers finished a chunk ago
+        __syncthreads();
+    }
+    if (alive) {
+#pragma unroll
+        for (int j = 0; j < TPL; j++)
+            if (has && t0 + j < a.ntaps) stg(wrow + kin * a.ntaps + t0 + j, Cx<R>{w[j].x, w[j].y});
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+inline int seg_tpl(int nmodes, int ntaps)
+{
+    for (int tpl : {2, 4, 6, 8}) {
+        const int lpm = (ntaps + tpl - 1) / tpl;
+        if (nmodes * lpm <= 16 && lpm * tpl - ntaps <= SG_MAXRAG && lpm * tpl - ntaps < tpl) return tpl;
+    }
+    return 0;
+}
+inline int seg_slots(int nsel)                                      // distinct segments among the 4 chains of a wave
+{
+    int n = 1;
+    for (int q0 = 0; q0 <= 4 * nsel; q0 += 4) { const int m = (q0 + 3) / nsel - q0 / nsel + 1; n = m > n ? m : n; }
+    return n;
+}
+inline bool seg_supported(int method, int nmodes, int ntaps, int os, int64_t nsy, size_t elem, int nsel = 1)
+{
+    (void)elem;
+    if (seg_tpl(nmodes, ntaps) == 0) return false;
+    if ((SG_CH + 1) * os + ntaps + 8 > SG_PITCH) return false;      // chunk + one step of look-ahead + padding taps fit a row
+    if (seg_slots(nsel) * nmodes > SG_ROWS) return false;
+    switch (method) {
+    case QH_M_CMA: case QH_M_SGNCMA: case QH_M_CMA2: case QH_M_MCMA: return true;
+    case QH_M_RDE: case QH_M_MRDE: return nsy - (nsy + 1) / 2 >= 1 && nsy - (nsy + 1) / 2 <= LA_MAXPART;
+    case QH_M_SBD: case QH_M_MDDMA: case QH_M_DD: return true;      // square alphabets through slicer tables (caller checks)
+    default: return false;
+    }
+}
+
+template <typename R, int METHOD, int NPART> static int launch_seg_tpl(const SegArgs<R> &a, int tpl, dim3 grid, size_t lds)
+{
+    switch (tpl) {
+    case 2: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 2>), grid, dim3(64), lds, g_stream, a); break;
+    case 4: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 4>), grid, dim3(64), lds, g_stream, a); break;
+    case 6: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 6>), grid, dim3(64), lds, g_stream, a); break;
+    case 8: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 8>), grid, dim3(64), lds, g_stream, a); break;
+    default: set_error("segment trainer: unsupported tap layout"); return QH_ERR_ARG;
+    }
+    return QH_OK;
+}
+template <typename R, int METHOD> static int launch_seg_parts(const SegArgs<R> &a, int npart, int tpl, dim3 grid, size_t lds)
+{
+#define QH_SG_NP(N) case N: return launch_seg_tpl<R, METHOD, N>(a, tpl, grid, lds);
+    switch (npart) {
+        QH_SG_NP(1) QH_SG_NP(2) QH_SG_NP(3) QH_SG_NP(4) QH_SG_NP(5) QH_SG_NP(6) QH_SG_NP(7) QH_SG_NP(8)
+    default: set_error("segment trainer: unsupported partition count"); return QH_ERR_ARG;
+    }
+#undef QH_SG_NP
+}
+template <typename R, int METHOD> static int launch_seg_dd(const SegArgs<R> &a, int npart, int tpl, dim3 grid, size_t lds)
+{
+    switch (npart) {            // 4-, 16-, 64-, 256-QAM
+    case 1: return launch_seg_tpl<R, METHOD, 1>(a, tpl, grid, lds);
+    case 3: return launch_seg_tpl<R, METHOD, 3>(a, tpl, grid, lds);
+    case 7: return launch_seg_tpl<R, METHOD, 7>(a, tpl, grid, lds);
+    case 15: return launch_seg_tpl<R, METHOD, 15>(a, tpl, grid, lds);
+    default: set_error("segment trainer: unsupported slicer size"); return QH_ERR_ARG;
+    }
+}
+
+// `a` complete except lpm / pitch / rag; method-specific table layout as for launch_bi (slicer tables for sbd / mddma / dd)
+template <typename R> int launch_seg(SegArgs<R> a, int method)
+{
+    const int tpl = seg_tpl(a.nmodes, a.ntaps);
+    a.lpm = (a.ntaps + tpl - 1) / tpl;
+    a.rag = a.lpm * tpl - a.ntaps;
+    a.pitch = SG_PITCH;
+    a.nslots = seg_slots(a.nsel);
+    const size_t lds = (size_t)(2 * SG_ROWS + 1) * SG_PITCH * sizeof(Cx<R>);
+    const int nq = a.S * a.nsel;
+    dim3 grid((nq + 3) / 4);
+    const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
+    int rc = QH_OK;
+    switch (method) {
+    case QH_M_CMA: case QH_M_SGNCMA: rc = launch_seg_tpl<R, QH_M_CMA, 0>(a, tpl, grid, lds); break;
+    case QH_M_CMA2: rc = launch_seg_tpl<R, QH_M_CMA2, 0>(a, tpl, grid, lds); break;
+    case QH_M_MCMA: rc = launch_seg_tpl<R, QH_M_MCMA, 0>(a, tpl, grid, lds); break;
+    case QH_M_RDE: rc = launch_seg_parts<R, QH_M_RDE>(a, npart, tpl, grid, lds); break;
+    case QH_M_MRDE: rc = launch_seg_parts<R, QH_M_MRDE>(a, npart, tpl, grid, lds); break;
+    case QH_M_SBD: rc = launch_seg_dd<R, QH_M_SBD>(a, npart, tpl, grid, lds); break;
+    case QH_M_MDDMA: rc = launch_seg_dd<R, QH_M_MDDMA>(a, npart, tpl, grid, lds); break;
+    case QH_M_DD: rc = launch_seg_dd<R, QH_M_DD>(a, npart, tpl, grid, lds); break;
+    default: return QH_ERR_METHOD;
+    }
+    if (rc) return rc;
+    QH_HIP(hipGetLastError());
+    return QH_OK;
+}
+
+}  // namespace qh

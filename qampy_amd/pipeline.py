@@ -108,8 +108,15 @@ class ResidentReceiver:
     def build_gram(self):
         """Gram terms of the look-ahead trainer: once per capture, shared by all modes, stages and sweeps."""
         self._gram = None
-        if len(set(self.TrSyms)) == 1:
-            self._gram = _k.gram_build_dev(self.E, self.os, self.Ntaps, self.TrSyms[0])
+        if self.tier == "a":
+            if len(set(self.TrSyms)) == 1:
+                self._gram = _k.gram_build_dev(self.E, self.os, self.Ntaps, self.TrSyms[0])
+        elif len(set(self.TrSyms)) == 1 and self.nmodes * self.Ntaps <= 96:
+            # tier b builds what its passes need itself (no Gram table in the throughput form, csrc/train_seg.h); what the stages
+            # share is the eigenbasis of the capture's input covariance for the coarse correction
+            self._basis = _k.pit_basis_dev(self.E, self.os, self.Ntaps, self.TrSyms[0], getattr(self, "_basis", None))
+            for o in self.pit:
+                o["basis"] = self._basis.ptr
 
     def train(self, stage):
         tb = self.tier == "b"

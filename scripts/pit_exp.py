@@ -21,6 +21,8 @@ VARIANTS = {
     "S256": dict(segments=256),
     "S1024": dict(segments=1024),
     "S2048": dict(segments=2048),
+    "S4096": dict(segments=4096),
+    "S2048/4096": (dict(segments=2048), dict(segments=4096)),
     "plateau.8": dict(acq_plateau=0.8),
     "plateau.95": dict(acq_plateau=0.95),
     "noacq": dict(acquire=0),
