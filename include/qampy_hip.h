@@ -233,7 +233,7 @@ int qh_set_trainer(int form);
 #define QH_PIT_MAXPASS 16
 #define QH_PIT_MAXCHUNK 32
 typedef struct qh_pit_opts {
-    int32_t segments;       /* 0 = automatic: segments of about 1.6 / mu steps, qh_pit_auto_segments */
+    int32_t segments;       /* 0 = automatic: segments of about 0.2 / mu (warm) or 0.4 / mu (cold start) steps, qh_pit_auto_segments */
     int32_t max_passes;     /* 0 = 8 (at most QH_PIT_MAXPASS) */
     int32_t acquire;        /* 0 warm start, 1 cold start: gear-shifted sequential acquisition first */
     int32_t phase_seed;     /* -1 by method, 0 off, 1 on */
@@ -246,6 +246,7 @@ typedef struct qh_pit_opts {
     int32_t correction;     /* -1 / 1: linearised coarse correction between the passes (see below), 0: plain relaxation */
     int32_t pad;
     void *basis;            /* NULL, or the eigenbasis of this capture's input covariance from qh_pit_basis_*_dev (device memory) */
+    double corr_beta;       /* extra damping of the well-excited directions in the coarse map, exp(-a (1 + beta a)); < 0: by method */
 } qh_pit_opts;
 typedef struct qh_pit_report {
     int32_t segments, passes, converged, acq_chunks;
@@ -256,13 +257,14 @@ typedef struct qh_pit_report {
     double gain, out_power;             /* linearised error-function gain g and mean output power used by the correction */
     int32_t acq_done, done, diverged, corr_on;   /* device-side flags */
 } qh_pit_report;
-int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int *segments);
+int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold, int *segments);   /* cold: the sweep starts from unconverged taps (acquire) */
 /* Eigenbasis of the input covariance <conj(x) x^T> of the training windows of a capture, for the coarse correction: depends
  * on (E, os, ntaps, TrSyms) only, so one build serves every stage and sweep over the same capture.  basis: device memory of
- * qh_pit_basis_bytes(nmodes*ntaps) bytes.  nmodes*ntaps <= 96. */
+ * qh_pit_basis_bytes(nmodes*ntaps) bytes.  nmodes*ntaps <= 96.  overlap != 0: built on the library's other stream while the
+ * current stream goes on (the trainer waits for it before its first correction; qh_sync waits for both streams). */
 int qh_pit_basis_bytes(int ntot, size_t *bytes);
-int qh_pit_basis_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis);
-int qh_pit_basis_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis);
+int qh_pit_basis_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis, int overlap);
+int qh_pit_basis_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis, int overlap);
 /* kernel time (HIP events on the library stream) of the trainer launches of the most recent qh_train_equaliser_*_pit_dev call:
  * the relaxation passes in order (all sweeps) and the sum of the acquisition chunks */
 int qh_pit_last_timing(float *pass_ms, int max_passes, int *npass, float *acq_ms);

@@ -81,11 +81,11 @@ SIGNATURES = {
                                  C.c_uint64],
     "qh_train_equaliser_c64_pit_dev": [_vp, _i, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp],
     "qh_train_equaliser_c128_pit_dev": [_vp, _i, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp],
-    "qh_pit_auto_segments": [_i64, C.c_double, _i, C.POINTER(_i)],
+    "qh_pit_auto_segments": [_i64, C.c_double, _i, _i, C.POINTER(_i)],
     "qh_pit_last_timing": [_pf, _i, C.POINTER(_i), _pf],
     "qh_pit_basis_bytes": [_i, C.POINTER(_sz)],
-    "qh_pit_basis_c64_dev": [_vp, _i, _i64, _i, _i, _i64, _vp],
-    "qh_pit_basis_c128_dev": [_vp, _i, _i64, _i, _i, _i64, _vp],
+    "qh_pit_basis_c64_dev": [_vp, _i, _i64, _i, _i, _i64, _vp, _i],
+    "qh_pit_basis_c128_dev": [_vp, _i, _i64, _i, _i, _i64, _vp, _i],
     "qh_set_trainer": [_i],
     "qh_use_stream": [_i],
     "qh_release_scratch": [],
@@ -101,7 +101,7 @@ class PitOpts(C.Structure):
     """``qh_pit_opts`` of include/qampy_hip.h (zeros = the library's defaults)."""
     _fields_ = [("segments", C.c_int32), ("max_passes", C.c_int32), ("acquire", C.c_int32), ("phase_seed", C.c_int32),
                 ("tol", C.c_double), ("gear", C.c_double), ("acq_bound", C.c_double), ("acq_plateau", C.c_double),
-                ("acq_chunk", C.c_int64), ("acq_max", C.c_int64), ("correction", C.c_int32), ("pad", C.c_int32), ("basis", C.c_void_p)]
+                ("acq_chunk", C.c_int64), ("acq_max", C.c_int64), ("correction", C.c_int32), ("pad", C.c_int32), ("basis", C.c_void_p), ("corr_beta", C.c_double)]
 
 
 class PitReport(C.Structure):

@@ -290,6 +290,7 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
         o = _lib.PitOpts()
         o.phase_seed = -1
         o.correction = -1
+        o.corr_beta = -1.
         for k, v in pit.items():
             if not hasattr(o, k):
                 raise ValueError("unknown parallel-in-time option %s" % k)
@@ -315,11 +316,12 @@ class PitReportBuffer(DeviceArray):
         return _lib.PitReport.from_buffer_copy(raw.tobytes()).as_dict()
 
 
-def pit_basis_dev(E, os, ntaps, TrSyms, basis=None):
+def pit_basis_dev(E, os, ntaps, TrSyms, basis=None, overlap=False):
     """
     Eigenbasis of the input covariance of a resident capture for the coarse correction of the parallel-in-time trainer
     (``qh_pit_basis_*_dev``); depends on ``E, os, ntaps, TrSyms`` only, so one build serves every stage.  Returns the
     DeviceArray holding it (pass ``basis`` to reuse an allocation); hand its ``ptr`` to ``pit=dict(basis=...)``.
+    ``overlap``: build it on the library's other stream while the current one goes on (the trainer waits where it needs it).
     """
     suf, rt, ct = _lib.suffix(E.dtype)
     nmodes, L = E.shape
@@ -327,7 +329,7 @@ def pit_basis_dev(E, os, ntaps, TrSyms, basis=None):
         n = C.c_size_t(0)
         _lib.call("qh_pit_basis_bytes", nmodes * int(ntaps), C.byref(n))
         basis = DeviceArray((n.value,), np.uint8)
-    _lib.call("qh_pit_basis_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, nmodes, L, int(os), int(ntaps), int(TrSyms), basis.ptr)
+    _lib.call("qh_pit_basis_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, nmodes, L, int(os), int(ntaps), int(TrSyms), basis.ptr, int(bool(overlap)))
     return basis
 
 
@@ -339,10 +341,11 @@ def pit_last_timing():
     return [float(buf[i]) for i in range(n.value)], float(acq.value)
 
 
-def pit_auto_segments(TrSyms, mu, nsel=1):
-    """The library's automatic segment count for a sweep of ``TrSyms`` steps at step size ``mu`` (1 = sequential)."""
+def pit_auto_segments(TrSyms, mu, nsel=1, cold=False):
+    """The library's automatic segment count for a sweep of ``TrSyms`` steps at step size ``mu`` (1 = sequential); ``cold``:
+    the sweep starts from unconverged taps (acquisition first)."""
     n = C.c_int(0)
-    _lib.call("qh_pit_auto_segments", int(TrSyms), float(mu), int(nsel), C.byref(n))
+    _lib.call("qh_pit_auto_segments", int(TrSyms), float(mu), int(nsel), int(bool(cold)), C.byref(n))
     return n.value
 
 

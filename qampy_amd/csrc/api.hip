@@ -48,6 +48,8 @@ static int init_device(int device)
     return QH_OK;
 }
 
+hipStream_t side_stream() { return g_stream == g_streams[0] ? g_streams[1] : g_streams[0]; }
+
 int ensure_init()
 {
     if (g_stream) return QH_OK;

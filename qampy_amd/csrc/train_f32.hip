@@ -46,14 +46,14 @@ int qh_pit_last_timing(float *pass_ms, int max_passes, int *npass, float *acq_ms
     *acq_ms = t.acq_ms;
     return QH_OK;
 }
-int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int *segments)
+int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold, int *segments)
 {
-    *segments = qh::pit_auto_segments(TrSyms, mu, nsel);
+    *segments = qh::pit_auto_segments(TrSyms, mu, nsel, cold);
     return QH_OK;
 }
-int qh_pit_basis_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis)
+int qh_pit_basis_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis, int overlap)
 {
-    return qh::pit_basis<float>(E, nmodes, L, os, ntaps, TrSyms, basis);
+    return qh::pit_basis<float>(E, nmodes, L, os, ntaps, TrSyms, basis, overlap);
 }
 int qh_pit_basis_bytes(int ntot, size_t *bytes)
 {

@@ -38,9 +38,9 @@ int qh_train_equaliser_c128_pit_dev(const void *E, int nmodes, int64_t L, int64_
 {
     return qh::train_pit_dev<double>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, symbols, nsy, method, err, zero_err, gram, opts, report_dev);
 }
-int qh_pit_basis_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis)
+int qh_pit_basis_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis, int overlap)
 {
-    return qh::pit_basis<double>(E, nmodes, L, os, ntaps, TrSyms, basis);
+    return qh::pit_basis<double>(E, nmodes, L, os, ntaps, TrSyms, basis, overlap);
 }
 int qh_gram_build_c128_batch_dev(const void *E, int nch, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram)
 {

@@ -18,7 +18,7 @@ namespace qh {
 typedef qh_pit_report PitCtrl;
 
 constexpr int PIT_PROBE = 128;      // symbol periods of the capture a boundary defect is measured on
-constexpr int PIT_SEEDWIN = 1024;   // symbol periods of a segment's head the phase seed is estimated on
+constexpr int PIT_SEEDWIN = 512;    // symbol periods of a segment's head the phase seed is estimated on
 
 // symmetry group of an error function: errfn(g y) = g errfn(y).  0: every phase (cma, rde); n: the n-th roots of unity
 __host__ __device__ inline int pit_symmetry(int method)
@@ -36,6 +36,23 @@ struct PitSeg {                      // segment grid of a sweep: see LaArgs::seg
     __host__ __device__ int64_t start(int64_t s) const { return s * len + (s < extra ? s : extra) * 64; }
     __host__ __device__ int64_t steps(int64_t s) const { return len + (s < extra ? 64 : 0) + (s == S - 1 ? tail : 0); }
 };
+
+// in-place inclusive prefix sum of a[0..n) in LDS by a 256-thread block: chunk sums, one serial pass over the 256 chunk
+// totals, chunk-local prefixes (n is a few thousand: ~1 us instead of a serial loop over n)
+template <typename T> __device__ __forceinline__ void block_prefix_sum(T *a, int n, T *tot)
+{
+    const int len = (n + 255) / 256;
+    const int i0 = threadIdx.x * len, i1 = i0 + len < n ? i0 + len : n;
+    T s = 0;
+    for (int i = i0; i < i1; i++) s += a[i];
+    tot[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { T acc = 0; for (int t = 0; t < 256; t++) { const T v = tot[t]; tot[t] = acc; acc += v; } }
+    __syncthreads();
+    T run = tot[threadIdx.x];
+    for (int i = i0; i < i1; i++) { run += a[i]; a[i] = run; }
+    __syncthreads();
+}
 
 // ------------------------------------------------------------------------------------------------ control kernels
 // power of the capture, gear-shifted step size, report header
@@ -168,6 +185,7 @@ static __global__ void __launch_bounds__(256) pit_unwrap_kernel(const double *z,
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     double *phi = reinterpret_cast<double *>(pit_smem);       // [S]
     int *jump = reinterpret_cast<int *>(phi + S);            // [S]
+    __shared__ int ptot[256];
     const double q = 1.5707963267948966;
     for (int j = 0; j < nsel; j++) {
         for (int s = threadIdx.x; s < S; s += 256) {
@@ -177,8 +195,7 @@ static __global__ void __launch_bounds__(256) pit_unwrap_kernel(const double *z,
         __syncthreads();
         for (int s = threadIdx.x; s < S; s += 256) jump[s] = s == 0 ? 0 : (int)rint((phi[s - 1] - phi[s]) / q);
         __syncthreads();
-        if (threadIdx.x == 0) { int a = 0; for (int s = 0; s < S; s++) { a += jump[s]; jump[s] = a; } }
-        __syncthreads();
+        block_prefix_sum<int>(jump, S, ptot);
         for (int s = threadIdx.x; s < S; s += 256) {
             const double p = phi[s] + q * jump[s];
             rot[2 * ((size_t)s * nsel + j)] = cos(p);
@@ -378,7 +395,7 @@ static __global__ void __launch_bounds__(256) pit_cov_reduce_kernel(const Z *par
 // Hermitian matrix Rc / nwin, whole problem in the LDS of ONE workgroup, single precision (the basis only preconditions the
 // relaxation).  Out: lam[n] eigenvalues, V[i][k] = component i of eigenvector k.  n <= PIT_EIGMAX.
 typedef float2 Zf;
-constexpr int PIT_EIGMAX = 96, PIT_EIGSWEEPS = 7;        // 7 sweeps: off-diagonal 1e-5, smallest eigenvalues good to 0.2 % (float)
+constexpr int PIT_EIGMAX = 96, PIT_EIGSWEEPS = 5;        // 5 sweeps: off-diagonal norm 2e-3, smallest eigenvalues good to 2 % - a preconditioner
 __device__ __forceinline__ Zf cmulf(Zf a, Zf b) { return Zf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, int n, double norm, double *lam, Zf *Vout)
 {
@@ -427,32 +444,74 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
             }
             __syncthreads();
             // columns p, q of A and V:  col_p' = c col_p - s conj(e) col_q ;  col_q' = s col_p + c conj(e) col_q
-            for (int i = wave; i < npair; i += 16) {
-                const int2 ix = pq[i];
-                if (ix.y >= n) continue;
-                const float4 g = rot[i];
-                for (int row = lane; row < n; row += 64) {
+            // (a thread's items - up to 3 pairs x 2 rows x 2 matrices - are all read before any is rotated: one LDS latency)
+            {
+                constexpr int NP = (PIT_EIGMAX / 2 + 15) / 16, NR = (PIT_EIGMAX + 63) / 64;
+                Zf xp[NP][NR][2], xq[NP][NR][2];
 #pragma unroll
-                    for (int which = 0; which < 2; which++) {
-                        Zf *Mx = which ? V : A;
-                        const Zf xp = Mx[row * ld + ix.x], xq = Mx[row * ld + ix.y];
-                        const Zf xqe = cmulf(Zf{g.z, -g.w}, xq);        // conj(e) x_q
-                        Mx[row * ld + ix.x] = Zf{g.x * xp.x - g.y * xqe.x, g.x * xp.y - g.y * xqe.y};
-                        Mx[row * ld + ix.y] = Zf{g.y * xp.x + g.x * xqe.x, g.y * xp.y + g.x * xqe.y};
+                for (int a = 0; a < NP; a++) {
+                    const int i = wave + 16 * a;
+                    const int2 ix = i < npair ? pq[i] : int2{0, n};
+#pragma unroll
+                    for (int b = 0; b < NR; b++) {
+                        const int row = lane + 64 * b;
+                        if (ix.y < n && row < n) {
+                            xp[a][b][0] = A[row * ld + ix.x]; xq[a][b][0] = A[row * ld + ix.y];
+                            xp[a][b][1] = V[row * ld + ix.x]; xq[a][b][1] = V[row * ld + ix.y];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < NP; a++) {
+                    const int i = wave + 16 * a;
+                    const int2 ix = i < npair ? pq[i] : int2{0, n};
+                    const float4 g = i < npair ? rot[i] : float4{1.f, 0.f, 1.f, 0.f};
+#pragma unroll
+                    for (int b = 0; b < NR; b++) {
+                        const int row = lane + 64 * b;
+                        if (ix.y < n && row < n) {
+#pragma unroll
+                            for (int which = 0; which < 2; which++) {
+                                Zf *Mx = which ? V : A;
+                                const Zf up = xp[a][b][which];
+                                const Zf xqe = cmulf(Zf{g.z, -g.w}, xq[a][b][which]);        // conj(e) x_q
+                                Mx[row * ld + ix.x] = Zf{g.x * up.x - g.y * xqe.x, g.x * up.y - g.y * xqe.y};
+                                Mx[row * ld + ix.y] = Zf{g.y * up.x + g.x * xqe.x, g.y * up.y + g.x * xqe.y};
+                            }
+                        }
                     }
                 }
             }
             __syncthreads();
             // rows p, q of A:  row_p' = c row_p - s e row_q ;  row_q' = s row_p + c e row_q
-            for (int i = wave; i < npair; i += 16) {
-                const int2 ix = pq[i];
-                if (ix.y >= n) continue;
-                const float4 g = rot[i];
-                for (int col = lane; col < n; col += 64) {
-                    const Zf xp = A[ix.x * ld + col], xq = A[ix.y * ld + col];
-                    const Zf xqe = cmulf(Zf{g.z, g.w}, xq);
-                    A[ix.x * ld + col] = Zf{g.x * xp.x - g.y * xqe.x, g.x * xp.y - g.y * xqe.y};
-                    A[ix.y * ld + col] = Zf{g.y * xp.x + g.x * xqe.x, g.y * xp.y + g.x * xqe.y};
+            {
+                constexpr int NP = (PIT_EIGMAX / 2 + 15) / 16, NR = (PIT_EIGMAX + 63) / 64;
+                Zf xp[NP][NR], xq[NP][NR];
+#pragma unroll
+                for (int a = 0; a < NP; a++) {
+                    const int i = wave + 16 * a;
+                    const int2 ix = i < npair ? pq[i] : int2{0, n};
+#pragma unroll
+                    for (int b = 0; b < NR; b++) {
+                        const int col = lane + 64 * b;
+                        if (ix.y < n && col < n) { xp[a][b] = A[ix.x * ld + col]; xq[a][b] = A[ix.y * ld + col]; }
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < NP; a++) {
+                    const int i = wave + 16 * a;
+                    const int2 ix = i < npair ? pq[i] : int2{0, n};
+                    const float4 g = i < npair ? rot[i] : float4{1.f, 0.f, 1.f, 0.f};
+#pragma unroll
+                    for (int b = 0; b < NR; b++) {
+                        const int col = lane + 64 * b;
+                        if (ix.y < n && col < n) {
+                            const Zf up = xp[a][b];
+                            const Zf xqe = cmulf(Zf{g.z, g.w}, xq[a][b]);
+                            A[ix.x * ld + col] = Zf{g.x * up.x - g.y * xqe.x, g.x * up.y - g.y * xqe.y};
+                            A[ix.y * ld + col] = Zf{g.y * up.x + g.x * xqe.x, g.y * up.y + g.x * xqe.y};
+                        }
+                    }
                 }
             }
             __syncthreads();
@@ -463,49 +522,57 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
         for (int k = lane; k < n; k += 64) Vout[(size_t)i * n + k] = V[i * ld + k];
 }
 
-// C[m][c] = sum_k op(A)[m][k] B[k][c],  op(A) = A (CONJT = false) or A^H; A is n x n, B and C are n x ncol (row-major)
+// C[m][c] = sum_k op(A)[m][k] B[k][c],  op(A) = A (CONJT = false) or A^H; A is n x n (n <= PIT_EIGMAX), B and C are n x ncol
+// (row-major).  A block takes 64 columns: op(A) and the B tile are staged in LDS, a thread accumulates 6 rows x 4 columns in
+// registers (16 x 16 threads), so one k step costs 10 LDS reads for 24 complex multiply-adds.
+constexpr int PIT_GT = 64;
 template <bool CONJT>
 __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B, Zf *C, int n, int ncol, const PitCtrl *c)
 {
     if (c->done) return;
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
-    Zf *As = reinterpret_cast<Zf *>(pit_smem);                // [n][n]  op(A)
-    Zf *Bs = As + (size_t)n * n;                               // [n][64]
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int col0 = blockIdx.x * 64;
-    for (int e = threadIdx.x; e < n * n; e += 256) {
-        const int i = e / n, k = e - i * n;
-        Zf v = CONJT ? A[(size_t)k * n + i] : A[e];
-        if (CONJT) v.y = -v.y;
+    Zf *As = reinterpret_cast<Zf *>(pit_smem);                // [k][PIT_EIGMAX]  op(A)[m][k] stored k-major: rows m contiguous
+    Zf *Bs = As + (size_t)PIT_EIGMAX * PIT_EIGMAX;            // [k][PIT_GT]
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // columns 4 tx .. 4 tx + 3, rows ty + 16 u
+    const int col0 = blockIdx.x * PIT_GT;
+    for (int e = threadIdx.x; e < PIT_EIGMAX * n; e += 256) {
+        const int k = e / PIT_EIGMAX, m = e - k * PIT_EIGMAX;
+        Zf v{0.f, 0.f};
+        if (m < n) { v = CONJT ? A[(size_t)k * n + m] : A[(size_t)m * n + k]; if (CONJT) v.y = -v.y; }
         As[e] = v;
     }
-    for (int e = threadIdx.x; e < n * 64; e += 256) {
-        const int k = e >> 6, cc = e & 63;
+    for (int e = threadIdx.x; e < n * PIT_GT; e += 256) {
+        const int k = e / PIT_GT, cc = e - k * PIT_GT;
         Bs[e] = col0 + cc < ncol ? B[(size_t)k * ncol + col0 + cc] : Zf{0.f, 0.f};
     }
     __syncthreads();
-    if (col0 + tx >= ncol) return;
-    for (int m0 = ty; m0 < n; m0 += 4 * 8) {                   // 8 rows per trip: m0, m0+4, ...
-        Zf acc[8];
+    constexpr int RU = PIT_EIGMAX / 16;                       // 6 rows per thread
+    Zf acc[RU][4];
 #pragma unroll
-        for (int u = 0; u < 8; u++) acc[u] = Zf{0.f, 0.f};
-        for (int k = 0; k < n; k++) {
-            const Zf b = Bs[k * 64 + tx];
+    for (int u = 0; u < RU; u++)
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int mm = m0 + 4 * u;
-                if (mm < n) {
-                    const Zf a = As[mm * n + k];
-                    acc[u].x += a.x * b.x - a.y * b.y;
-                    acc[u].y += a.x * b.y + a.y * b.x;
-                }
+        for (int v = 0; v < 4; v++) acc[u][v] = Zf{0.f, 0.f};
+    for (int k = 0; k < n; k++) {
+        Zf b[4], a[RU];
+#pragma unroll
+        for (int v = 0; v < 4; v++) b[v] = Bs[k * PIT_GT + 4 * tx + v];
+#pragma unroll
+        for (int u = 0; u < RU; u++) a[u] = As[k * PIT_EIGMAX + ty + 16 * u];
+#pragma unroll
+        for (int u = 0; u < RU; u++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                acc[u][v].x += a[u].x * b[v].x - a[u].y * b[v].y;
+                acc[u][v].y += a[u].x * b[v].y + a[u].y * b[v].x;
             }
-        }
+    }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int mm = m0 + 4 * u;
-            if (mm < n) C[(size_t)mm * ncol + col0 + tx] = acc[u];
-        }
+    for (int u = 0; u < RU; u++) {
+        const int m = ty + 16 * u;
+        if (m < n)
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+                if (col0 + 4 * tx + v < ncol) C[(size_t)m * ncol + col0 + 4 * tx + v] = acc[u][v];
     }
 }
 
@@ -513,7 +580,7 @@ __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B
 // first-order recurrence with a constant coefficient per (eigen-direction k, mode j): block (k, j) runs it over the S
 // segments (chunks per thread, then the carries).  Correction off -> coefficient 0 (D = d: plain relaxation).
 template <typename R>
-__global__ void __launch_bounds__(256) pit_recur_kernel(Zf *D, const double *lam, int nsel, int S, int64_t T, const R *mu, const PitCtrl *c)
+__global__ void __launch_bounds__(256) pit_recur_kernel(Zf *D, const double *lam, int nsel, int S, int64_t T, const R *mu, double beta, const PitCtrl *c)
 {
     if (c->done) return;
     __shared__ Zf tot[256];
@@ -523,7 +590,12 @@ __global__ void __launch_bounds__(256) pit_recur_kernel(Zf *D, const double *lam
     Zf *row = D + (size_t)k * ncol + j;
     double a = (double)*mu * c->gain * (double)T * lam[k];
     if (a < 0) a = 0;
-    const float coef = c->corr_on ? (float)exp(-a) : 0.f;
+    // beta > 0: stronger damping of the well-excited directions than the mean gain gives.  The error functions pull several
+    // times harder on the output's amplitude than on anything else (cma: 2 <|s|^4>/<|s|^2> = 2.76 against g = 0.62); that
+    // direction lives in the strongly excited part of the spectrum, and a map that damps it too LITTLE makes the iteration
+    // stall (error factor |J - J'| / (1 - J')), one that damps the rest a little too much only slows it down.  The weakly
+    // excited directions (a << 1), which are the ones that need the propagation, are unaffected.
+    const float coef = c->corr_on ? (float)exp(-a * (1 + beta * a)) : 0.f;
     const int len = (S + 255) / 256;
     const int s0 = threadIdx.x * len, s1 = s0 + len < S ? s0 + len : S;
     Zf run{0.f, 0.f};
@@ -565,12 +637,8 @@ static __global__ void __launch_bounds__(256) pit_gauge_kernel(const double *gph
         ang[(size_t)j * S + s] = s == 0 ? 0.0 : atan2(gph[2 * ((size_t)(s - 1) * nsel + j) + 1], gph[2 * ((size_t)(s - 1) * nsel + j)]);
     }
     __syncthreads();
-    if (threadIdx.x < nsel) {
-        double *a = ang + (size_t)threadIdx.x * S;
-        double acc = 0;
-        for (int s = 0; s < S; s++) { acc += a[s]; a[s] = acc; }
-    }
-    __syncthreads();
+    __shared__ double gtot[256];
+    for (int j = 0; j < nsel; j++) block_prefix_sum<double>(ang + (size_t)j * S, S, gtot);
     for (int e = threadIdx.x; e < S * nsel; e += 256) {
         const int s = e / nsel, j = e - s * nsel;
         const double t = ang[(size_t)j * S + s];
@@ -596,9 +664,9 @@ __global__ void __launch_bounds__(128) pit_dvec_kernel(const Cx<R> *X, const Cx<
         D[(size_t)f * ncol + col] = v;
     }
 }
-// X[s][mode_j][f] = theta_s X[s][mode_j][f] + D[f][s nsel + j]
+// X[s][mode_j][f] = Y[s][mode_j][f] = theta_s X[s][mode_j][f] + D[f][s nsel + j]   (Y: the copy the next pass trains in place)
 template <typename R>
-__global__ void __launch_bounds__(128) pit_dapply_kernel(Cx<R> *X, int nmodes, int ntot, const int64_t *modes_dev, int nsel, int S, const PitCtrl *c,
+__global__ void __launch_bounds__(128) pit_dapply_kernel(Cx<R> *X, Cx<R> *Y, int nmodes, int ntot, const int64_t *modes_dev, int nsel, int S, const PitCtrl *c,
                                                          const double *theta, const Zf *D)
 {
     if (c->done) return;
@@ -608,8 +676,10 @@ __global__ void __launch_bounds__(128) pit_dapply_kernel(Cx<R> *X, int nmodes, i
     for (int f = threadIdx.x; f < ntot; f += 128) {
         const Zf d = D[(size_t)f * ncol + col];
         const double qr = theta[2 * (size_t)col], qi = theta[2 * (size_t)col + 1];
-        Cx<R> &x = X[(size_t)s * wset + ro + f];
-        x = Cx<R>{(R)(qr * x.re - qi * x.im + d.x), (R)(qr * x.im + qi * x.re + d.y)};
+        const Cx<R> x = X[(size_t)s * wset + ro + f];
+        const Cx<R> v{(R)(qr * x.re - qi * x.im + d.x), (R)(qr * x.im + qi * x.re + d.y)};
+        X[(size_t)s * wset + ro + f] = v;
+        Y[(size_t)s * wset + ro + f] = v;
     }
 }
 
@@ -624,15 +694,19 @@ inline hipEvent_t *pit_events()
     return ev;
 }
 
-inline int pit_auto_segments(int64_t TrSyms, double mu, int nsel)
+// Automatic segment grid.  A segment should be a fraction of the time constant 1/(mu g lambda) of the well-excited tap
+// directions - short enough for thousands of chains (the throughput form wants >= 2 waves per SIMD: 8192 chains), long enough
+// for the linearised coarse correction to describe what a segment does to its start taps: ~0.2/mu steps when the sweep
+// starts from converged taps (2 passes at C3), ~0.4/mu when it starts cold, i.e. from the taps of the acquisition (3-4).
+inline int pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold)
 {
-    double target = 1.6 / (mu > 1e-12 ? mu : 1e-12);           // ~1.5-3 time constants 1/(mu_eff lambda) of the in-band directions
-    if (target < 1024) target = 1024;
+    double target = (cold ? 0.4 : 0.2) / (mu > 1e-12 ? mu : 1e-12);
+    if (target < 256) target = 256;
     if (target > 1048576) target = 1048576;
     const int64_t seg = ((int64_t)target + 63) / 64 * 64;
     int64_t S = TrSyms / seg;
     if (S > 4096) S = 4096;
-    const int64_t ncu = 256;                                   // MI355X: whole rounds of workgroups (one per segment and mode)
+    const int64_t ncu = 256;                                   // MI355X: whole rounds of workgroups
     if (S * nsel > ncu && nsel <= ncu) S = S * nsel / ncu * ncu / nsel;
     if (S < 4) S = 1;
     return (int)S;
@@ -642,11 +716,24 @@ inline int pit_auto_segments(int64_t TrSyms, double mu, int nsel)
 // basis = [ntot eigenvalues (double)][ntot x ntot eigenvectors (float complex, V[i][k])] in device memory.
 inline size_t pit_basis_bytes(int ntot) { return (size_t)ntot * sizeof(double) + (size_t)ntot * ntot * sizeof(Zf); }
 inline bool pit_basis_ok(int ntot, size_t elem) { return ntot <= PIT_EIGMAX && (size_t)PIT_COVW * ntot * elem <= 64 * 1024; }
+// overlap != 0: the build runs on the library's other stream (one workgroup grinding through the Jacobi sweeps next to
+// whatever the current stream does next - the acquisition and the first pass do not need the basis); the trainer waits for
+// it right before its first correction.
+struct PitBasisSync { hipEvent_t in = nullptr, out = nullptr; bool pending = false; };
+inline PitBasisSync &pit_basis_sync() { static PitBasisSync b; return b; }
 template <typename R>
-int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis)
+int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis, int overlap = 0)
 {
     int rc = ensure_init();
     if (rc) return rc;
+    hipStream_t st = g_stream;
+    PitBasisSync &bs = pit_basis_sync();
+    if (overlap) {
+        if (!bs.in) { QH_HIP(hipEventCreateWithFlags(&bs.in, hipEventDisableTiming)); QH_HIP(hipEventCreateWithFlags(&bs.out, hipEventDisableTiming)); }
+        st = side_stream();
+        QH_HIP(hipEventRecord(bs.in, g_stream));                 // the capture is complete on the current stream
+        QH_HIP(hipStreamWaitEvent(st, bs.in, 0));
+    }
     const int ntot = nmodes * ntaps;
     QH_REQUIRE(pit_basis_ok(ntot, sizeof(Cx<R>)), "pit basis: nmodes*ntaps too large for the eigen-solver");
     QH_REQUIRE(TrSyms >= 1 && (TrSyms - 1) * os + ntaps <= L, "pit basis: field shorter than TrSyms*os + ntaps");
@@ -657,16 +744,17 @@ int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t T
     const int ncov = (int)(TrSyms < PIT_COVW * PIT_COVB ? TrSyms : PIT_COVW * PIT_COVB);
     const int ept = (int)((msz + 255) / 256);
     const size_t lds = (size_t)PIT_COVW * ntot * sizeof(Cx<R>);
-    if (ept <= 8) hipLaunchKernelGGL((pit_cov_kernel<R, 8>), dim3(PIT_COVB), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
-    else if (ept <= 32) hipLaunchKernelGGL((pit_cov_kernel<R, 32>), dim3(PIT_COVB), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
-    else hipLaunchKernelGGL((pit_cov_kernel<R, 64>), dim3(PIT_COVB), dim3(256), lds, g_stream, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
-    hipLaunchKernelGGL(pit_cov_reduce_kernel, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, g_stream, (const Z *)part, (int)msz, PIT_COVB, Rc);
+    if (ept <= 8) hipLaunchKernelGGL((pit_cov_kernel<R, 8>), dim3(PIT_COVB), dim3(256), lds, st, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
+    else if (ept <= 32) hipLaunchKernelGGL((pit_cov_kernel<R, 32>), dim3(PIT_COVB), dim3(256), lds, st, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
+    else hipLaunchKernelGGL((pit_cov_kernel<R, 64>), dim3(PIT_COVB), dim3(256), lds, st, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
+    hipLaunchKernelGGL(pit_cov_reduce_kernel, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, st, (const Z *)part, (int)msz, PIT_COVB, Rc);
     static bool attr_set = false;
     const size_t jlds = 2 * (size_t)ntot * (ntot + 1) * sizeof(Zf) + (size_t)((PIT_EIGMAX + 2) / 2) * (sizeof(float4) + sizeof(int2));
     if (!attr_set) { QH_HIP(hipFuncSetAttribute((const void *)pit_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); attr_set = true; }
-    hipLaunchKernelGGL(pit_jacobi_kernel, dim3(1), dim3(1024), jlds, g_stream, (const Z *)Rc, ntot, 1.0 / (double)ncov, (double *)basis,
+    hipLaunchKernelGGL(pit_jacobi_kernel, dim3(1), dim3(1024), jlds, st, (const Z *)Rc, ntot, 1.0 / (double)ncov, (double *)basis,
                        (Zf *)((char *)basis + (size_t)ntot * sizeof(double)));
     QH_HIP(hipGetLastError());
+    if (overlap) { QH_HIP(hipEventRecord(bs.out, st)); bs.pending = true; }
     return QH_OK;
 }
 
@@ -684,7 +772,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     for (int j = 0; j < nsel; j++) QH_REQUIRE(modes[j] >= 0 && modes[j] < nmodes, "train_equaliser: mode number >= nmodes");
     qh_pit_opts o;
     memset(&o, 0, sizeof(o));
-    o.phase_seed = -1;
+    o.phase_seed = -1; o.corr_beta = -1;
     if (opts) o = *opts;
     QH_REQUIRE(o.segments >= 0 && o.segments <= 4096 && o.max_passes >= 0 && o.max_passes <= QH_PIT_MAXPASS, "train_equaliser: bad segment / pass count");
     const int ntot = nmodes * ntaps;
@@ -697,6 +785,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     const int sym = pit_symmetry(method);
     const bool seed_phase = o.phase_seed < 0 ? sym == 4 : o.phase_seed != 0;
     const bool want_corr = o.correction != 0 && pit_basis_ok(ntot, sizeof(Cx<R>));
+    const double beta = o.corr_beta >= 0 ? o.corr_beta : (sym == 0 ? 1.5 : 0.0);
 
     // ---- control block / report
     void *cbuf = nullptr;
@@ -720,7 +809,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         R mu_h = 0;
         QH_HIP(hipMemcpyAsync(&mu_h, mu_dev, sizeof(R), hipMemcpyDeviceToHost, g_stream));
         QH_HIP(hipStreamSynchronize(g_stream));
-        S = pit_auto_segments(TrSyms, (double)mu_h, nsel);
+        S = pit_auto_segments(TrSyms, (double)mu_h, nsel, o.acquire);
     }
     const int64_t nblk_all = TrSyms / LA_B;
     if ((int64_t)S * 4 > nblk_all) S = (int)(nblk_all / 4);       // at least 4 blocks per segment
@@ -815,7 +904,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         lam = (const double *)basis; Vb = (const Zf *)((const char *)basis + (size_t)ntot * sizeof(double));
         Dz[0] = (Zf *)((char *)cb + (pit_basis_bytes(ntot) + 63) / 64 * 64); Dz[1] = Dz[0] + (size_t)ntot * ncol;
     }
-    const size_t glds = ((size_t)ntot * ntot + (size_t)ntot * 64) * sizeof(Zf);
+    const size_t glds = ((size_t)PIT_EIGMAX * PIT_EIGMAX + (size_t)PIT_EIGMAX * PIT_GT) * sizeof(Zf);
     static bool gemm_attr = false;
     if (want_corr && !gemm_attr) {
         QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
@@ -891,19 +980,25 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             if (p > 0 && want_corr) {
                 // start taps += D,  D[s+1] = d[s+1] + J D[s]  (d = boundary defects): a parallel scan over the segments.  With the
                 // correction switched off on the device (corr_on = 0) the products are skipped and D = d: plain relaxation.
+                if (o.basis && pit_basis_sync().pending) {           // a basis still being built on the other stream
+                    QH_HIP(hipStreamWaitEvent(g_stream, pit_basis_sync().out, 0));
+                    pit_basis_sync().pending = false;
+                }
                 hipLaunchKernelGGL(pit_gauge_kernel, dim3(1), dim3(256), (size_t)ncol * sizeof(double), g_stream, (const double *)gph, sg.S, nsel, (const PitCtrl *)ctrl, theta);
                 hipLaunchKernelGGL((pit_dvec_kernel<R>), dim3(ncol), dim3(128), 0, g_stream, (const Cx<R> *)X, (const Cx<R> *)Y, nmodes, ntot, (const int64_t *)modes_dev, nsel, sg.S,
                                    (const PitCtrl *)ctrl, (const double *)theta, Dz[0]);
-                hipLaunchKernelGGL((pit_cgemm_kernel<true>), dim3((ncol + 63) / 64), dim3(256), glds, g_stream, Vb, (const Zf *)Dz[0], Dz[1], ntot, ncol, (const PitCtrl *)ctrl);
-                hipLaunchKernelGGL((pit_recur_kernel<R>), dim3(ntot, nsel), dim3(256), 0, g_stream, Dz[1], lam, nsel, sg.S, sg.len, (const R *)mu_dev, (const PitCtrl *)ctrl);
-                hipLaunchKernelGGL((pit_cgemm_kernel<false>), dim3((ncol + 63) / 64), dim3(256), glds, g_stream, Vb, (const Zf *)Dz[1], Dz[0], ntot, ncol, (const PitCtrl *)ctrl);
-                hipLaunchKernelGGL((pit_dapply_kernel<R>), dim3(ncol), dim3(128), 0, g_stream, X, nmodes, ntot, (const int64_t *)modes_dev, nsel, sg.S, (const PitCtrl *)ctrl,
+                hipLaunchKernelGGL((pit_cgemm_kernel<true>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb, (const Zf *)Dz[0], Dz[1], ntot, ncol, (const PitCtrl *)ctrl);
+                hipLaunchKernelGGL((pit_recur_kernel<R>), dim3(ntot, nsel), dim3(256), 0, g_stream, Dz[1], lam, nsel, sg.S, sg.len, (const R *)mu_dev, beta, (const PitCtrl *)ctrl);
+                hipLaunchKernelGGL((pit_cgemm_kernel<false>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb, (const Zf *)Dz[1], Dz[0], ntot, ncol, (const PitCtrl *)ctrl);
+                hipLaunchKernelGGL((pit_dapply_kernel<R>), dim3(ncol), dim3(128), 0, g_stream, X, Y, nmodes, ntot, (const int64_t *)modes_dev, nsel, sg.S, (const PitCtrl *)ctrl,
                                    (const double *)theta, (const Zf *)Dz[0]);
                 QH_HIP(hipGetLastError());
             } else if (p > 0) {
                 QH_HIP(hipMemcpyAsync(X + wset, Y, (size_t)(sg.S - 1) * wbytes, hipMemcpyDeviceToDevice, g_stream));   // X[s] = end taps of s-1
+                QH_HIP(hipMemcpyAsync(Y, X, (size_t)sg.S * wbytes, hipMemcpyDeviceToDevice, g_stream));
+            } else {
+                QH_HIP(hipMemcpyAsync(Y, X, (size_t)sg.S * wbytes, hipMemcpyDeviceToDevice, g_stream));
             }
-            QH_HIP(hipMemcpyAsync(Y, X, (size_t)sg.S * wbytes, hipMemcpyDeviceToDevice, g_stream));
             QH_HIP(hipEventRecord(ev[0], g_stream));
             if (seg_form) {
                 SegArgs<R> sa;

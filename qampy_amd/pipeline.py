@@ -87,8 +87,8 @@ class ResidentReceiver:
                 raise ValueError("parallel-in-time training needs fixed step sizes")
             self.pit_report = [_k.PitReportBuffer() for _ in methods]
             for s_, o in enumerate(self.pit):          # segment grid from the host copy of mu: the call then never synchronises
-                o.setdefault("segments", _k.pit_auto_segments(self.TrSyms[s_], float(self.mu0[s_]), self.modes.size))
                 o.setdefault("acquire", 1 if s_ == 0 else 0)
+                o.setdefault("segments", _k.pit_auto_segments(self.TrSyms[s_], float(self.mu0[s_]), self.modes.size, cold=bool(o["acquire"])))
         _lib.sync()
 
     # ------------------------------------------------------------------------------------------ data movement
@@ -114,7 +114,7 @@ class ResidentReceiver:
         elif len(set(self.TrSyms)) == 1 and self.nmodes * self.Ntaps <= 96:
             # tier b builds what its passes need itself (no Gram table in the throughput form, csrc/train_seg.h); what the stages
             # share is the eigenbasis of the capture's input covariance for the coarse correction
-            self._basis = _k.pit_basis_dev(self.E, self.os, self.Ntaps, self.TrSyms[0], getattr(self, "_basis", None))
+            self._basis = _k.pit_basis_dev(self.E, self.os, self.Ntaps, self.TrSyms[0], getattr(self, "_basis", None), overlap=True)
             for o in self.pit:
                 o["basis"] = self._basis.ptr
 

@@ -27,6 +27,10 @@ VARIANTS = {
     "plateau.95": dict(acq_plateau=0.95),
     "noacq": dict(acquire=0),
     "nocorr": dict(correction=0),
+    "beta0": dict(corr_beta=0.),
+    "beta1": dict(corr_beta=1.),
+    "beta3": dict(corr_beta=3.),
+    "beta6": dict(corr_beta=6.),
     "nocorr8": dict(correction=0, max_passes=8, tol=1e-3),
     "corr8": dict(max_passes=8, tol=1e-3),
 }

@@ -87,7 +87,7 @@ def test_complex128_and_oracle():
 
 
 def test_small_sweeps_fall_through_and_bad_calls_raise():
-    sig, E, tr, w0, sy, rt = _setup("mcma", 16, nsym=2 ** 11)
+    sig, E, tr, w0, sy, rt = _setup("mcma", 16, nsym=2 ** 10)
     eo, wo, _ = hk.train_equaliser(E, tr, 1, 2, rt(1e-3), w0.copy(), None, False, sy, "mcma")
     w, e, rep = _run_pit(E, tr, 1, 1e-3, w0, sy, "mcma", {}, rt)        # automatic segment count: too short to cut -> exact path
     assert rep["segments"] == 1 and rep["converged"]
@@ -136,7 +136,7 @@ def test_ser_equivalence_at_scale():
                         np.sqrt(np.mean(np.abs(res["a"]["eq"][m] - g * r["eq"][m]) ** 2))))
         return np.array(out)
     d_b, d_t = dev(res["b"]), dev(res["b_tight"])
-    assert d_b[:, 1].max() < 1e-2 and d_t[:, 1].max() < 1e-3 and d_t[:, 0].max() < 2e-2, (d_b, d_t)
+    assert d_b[:, 1].max() < 1e-2 and d_t[:, 1].max() < 1e-3 and d_t[:, 0].max() < 2e-2, (d_b.tolist(), d_t.tolist(), [r["rep"] for r in res.values()])
     # the CPU oracle (reference-flag build) on the same capture
     E = d["E"].to_host()
     w = core_eq._init_taps(ntaps, 2, 2, np.complex64)
