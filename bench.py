@@ -57,6 +57,9 @@ WORKLOADS = {
                A=64, Nbps=20, snr_db=30, linewidth=100.,
                label="64-QAM 2-pol 2 SPS 10^7 sym, 41-tap dual-mode CMA->MRDE + 64-angle BPS (north star)"),
 }
+WORKLOADS["c5"] = dict(M=256, nsym=2 ** 16, ntaps=45, methods=("cma", "sbd_data"), mu=(1e-3, 1e-3), niter=(30, 30), adaptive=(True, True), A=None, Nbps=0,
+                       snr_db=35, linewidth=10e3,
+                       label="pilot-based 256-QAM 2-pol 2 SPS, 2^16-symbol frames: frame sync + data-aided pilot equaliser + filter + pilot phase recovery")
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FUSED_BYTES_PER_SYM = 88   # read E once, write err1, err2, out, ph (complex64, 2 modes, 2 samples/symbol)
 SER_TOL_ERRORS = 3         # tier b counts as SER-equivalent when every mode is within this many symbol errors of tier a
@@ -339,6 +342,101 @@ def transfer_times(sig, rx):
                 bytes_in=int(E.nbytes), bytes_out=int(nb), note="pageable numpy arrays through hipMemcpy; outputs = recovered signal + taps + both error traces")
 
 
+# ------------------------------------------------------------------------------------------------------------ config 5
+def pilot_chain(cap, dtype=np.complex64):
+    """BASELINE config 5 through the basic API (host arrays in and out): sync2frame -> corr_foe -> pilot_equaliser (data-aided
+    second stage, filter over the frame) -> pilot_cpe; returns stage times and results."""
+    from qampy_amd import equalisation, phaserec
+    from qampy_amd.signals import PilotSignal
+    sig = PilotSignal(cap["E"].astype(dtype), cap["M"], cap["fb"], cap["fs"], cap["frame_len"], cap["seq_len"], cap["ins_rat"], cap["pilots"],
+                      symbols=cap["payload"], coded_symbols=cap["alphabet"])
+    t = [time.perf_counter()]
+    ok = sig.sync2frame()
+    t.append(time.perf_counter())
+    sig.corr_foe()
+    t.append(time.perf_counter())
+    taps, eq = equalisation.pilot_equaliser(sig, (1e-3, 1e-3), 45, foe_comp=False, methods=("cma", "sbd_data"))
+    t.append(time.perf_counter())
+    out, ph = phaserec.pilot_cpe(eq, N=5, use_seq=False)
+    t.append(time.perf_counter())
+    d = np.diff(t)
+    return dict(ok=bool(ok), seconds=t[-1] - t[0], stages_ms=dict(frame_sync=d[0] * 1e3, foe=d[1] * 1e3, pilot_equaliser_and_filter=d[2] * 1e3, pilot_cpe=d[3] * 1e3),
+                ser=[float(v) for v in out.cal_ser(frames=[0])], taps=taps)
+
+
+class _OracleKernels:
+    """cpu_baseline leg of config 5: the same host layer on the oracle's kernels (reference-flag build)."""
+
+    def __enter__(self):
+        from oracle import oracle
+        from qampy_amd.core.equalisation import equalisation as core_eq
+        k = core_eq._kernels
+        self.k, self.saved = k, {n: getattr(k, n) for n in ("ResidentField", "train_equaliser", "apply_filter_to_signal", "train_equaliser_windows_search")}
+
+        class OracleField:
+            def __init__(self, E):
+                self.E = E
+
+            def train(self, *a):
+                return oracle.train_equaliser(self.E, *a, fast=True)
+
+            def apply(self, os_, wx, modes=None):
+                return oracle.apply_filter_to_signal(self.E, os_, np.ascontiguousarray(wx), modes, fast=True)
+
+        def search(E, starts, win_len, TrSyms, Niter, os_, mu, wx0, modes, adaptive, symbols, method):
+            res = [oracle.train_equaliser(np.ascontiguousarray(E[:, s0:s0 + win_len]), TrSyms, Niter, os_, mu, wx0.copy(), modes, adaptive, symbols, method, fast=True)
+                   for s0 in np.asarray(starts)]
+            var = np.array([np.var(r[0], axis=-1) for r in res]).T
+            best = np.argmin(var, axis=-1)
+            return var, best, np.array([res[b][1] for b in best])
+
+        k.ResidentField = OracleField
+        k.train_equaliser = lambda *a: oracle.train_equaliser(*a, fast=True)
+        k.apply_filter_to_signal = lambda *a, **kw: oracle.apply_filter_to_signal(*a, fast=True, **kw)
+        k.train_equaliser_windows_search = search
+        return self
+
+    def __exit__(self, *exc):
+        for n, v in self.saved.items():
+            setattr(self.k, n, v)
+
+
+def run_c5(args, cfg):
+    """`--workload c5`: the pilot receiver is a CALLER of the hot path; single GPU, host arrays in and out
+    (so `value` includes the PCIe copies of the basic API - noted in the line)."""
+    from qampy_amd import synth, _lib
+    _lib.init(0)
+    cap = synth.make_pilot_capture(M=cfg["M"], frame_len=cfg["nsym"])
+    for _ in range(max(args.warmup, 1)):
+        pilot_chain(cap)
+    runs = [pilot_chain(cap) for _ in range(args.steps)]
+    el = sum(r["seconds"] for r in runs)
+    best = runs[-1]
+    out = dict(metric="equalised MSym/s (2-pol, 2 SPS)", value=round(cfg["nsym"] * args.steps / el / 1e6, 4), unit="MSym/s", n_gpus=1, ranks_seen=1, steps=args.steps,
+               warmup=args.warmup, ms_per_step=round(el / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload=cfg["label"], key="c5", frame_len=cfg["nsym"], frames_captured=3, frames_recovered=1, ntaps=[17, 45],
+                           methods=list(cfg["methods"]), niter=[10, 30], boundary="basic API: host arrays in and out (PCIe inside the timed region)"),
+               stages_ms={k: round(float(np.mean([r["stages_ms"][k] for r in runs])), 3) for k in best["stages_ms"]},
+               ser=dict(payload_per_mode=best["ser"], sync_ok=best["ok"]), device=_lib.device_name(),
+               roofline=dict(bound="valu-issue", kernel="data-aided pilot-sequence training (30 sweeps, adaptive step: sequential chains)", achieved=None, peak=HBM_PEAK_GBS,
+                             unit="GB/s", frac=None, traffic=None, note="a few thousand sequential steps per stage: latency-bound, no roofline applies"))
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        try:
+            oracle.build(fast_native=True)
+        except Exception:
+            pass
+        with _OracleKernels():
+            pilot_chain(cap, np.complex64)
+            cpu = pilot_chain(cap, np.complex64)
+        out["cpu_baseline"] = dict(value=round(cfg["nsym"] / cpu["seconds"] / 1e6, 4), unit="MSym/s", cores=os.cpu_count(), kind="port",
+                                   sample="the same capture through the same host layer on the oracle's kernels (one run)", cpu_model=cpu_model(),
+                                   stages_ms={k: round(v, 2) for k, v in cpu["stages_ms"].items()})
+        out["parity_vs_cpu"] = dict(ser_gpu=best["ser"], ser_cpu=cpu["ser"], max_abs_tap_diff=float(np.max(np.abs(best["taps"] - cpu["taps"]))))
+        out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
+    print(json.dumps(out))
+
+
 # ------------------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -373,6 +471,11 @@ def main():
         sys.exit(2)
     cfg = dict(WORKLOADS[args.workload])
     nsym = args.nsym or cfg["nsym"]
+    if args.workload == "c5":
+        if world > 1 or args.dry_run:
+            print(json.dumps(dict(error="workload c5 runs on one GPU")))
+            sys.exit(2)
+        return run_c5(args, cfg)
 
     import torch                                     # plumbing only: barriers / reductions / device sync
     dist = None

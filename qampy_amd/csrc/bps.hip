@@ -35,6 +35,7 @@ template <> __device__ __forceinline__ void sincos_<double>(double x, double *s,
 constexpr int BPS_MAX_LEVELS = 32;
 template <typename R> struct AlphabetDesc {
     int product;            // 1: cartesian product detected
+    int symmetric;          // 1: product alphabet whose sorted levels are mirror images on both axes (l_k == -l_{n-1-k}, n even)
     int nre, nim;
     R re[BPS_MAX_LEVELS], im[BPS_MAX_LEVELS];
 };
@@ -62,8 +63,17 @@ __global__ void __launch_bounds__(64) analyse_alphabet_kernel(const Cx<R> *symbo
         if (ok) { if (seen[r * BPS_MAX_LEVELS + i]) ok = false; else seen[r * BPS_MAX_LEVELS + i] = 1; }
     }
     ok = ok && (long)nre * nim == M;
+    // sorted levels; mirror symmetry lets the search run on |t| against the positive half only (|(-t) - (-l)| == |t - l| exactly)
+    bool sym = ok && (nre % 2 == 0) && (nim % 2 == 0);
+    if (ok) {
+        for (int a = 1; a < nre; a++) { R v = lre[a]; int b = a - 1; while (b >= 0 && lre[b] > v) { lre[b + 1] = lre[b]; b--; } lre[b + 1] = v; }
+        for (int a = 1; a < nim; a++) { R v = lim[a]; int b = a - 1; while (b >= 0 && lim[b] > v) { lim[b + 1] = lim[b]; b--; } lim[b + 1] = v; }
+        for (int a = 0; a < nre / 2 && sym; a++) sym = lre[a] == -lre[nre - 1 - a];
+        for (int a = 0; a < nim / 2 && sym; a++) sym = lim[a] == -lim[nim - 1 - a];
+    }
     for (int r = 0; r < BPS_MAX_LEVELS; r++) { d->re[r] = r < nre ? lre[r] : (R)0; d->im[r] = r < nim ? lim[r] : (R)0; }
     d->product = ok ? 1 : 0;
+    d->symmetric = sym ? 1 : 0;
     d->nre = nre; d->nim = nim;
 }
 
@@ -93,6 +103,7 @@ __global__ void __launch_bounds__(BPS_THREADS) bps_kernel(BpsArgs<R> a)
     const int64_t l0 = i0 - N + 1;                         // symbol index of dist row 0
     const bool per_symbol = a.p > 1;
     const bool product = a.desc->product != 0;
+    const bool symmetric = a.desc->symmetric != 0;
     const int nre = product ? a.desc->nre : 0, nim = product ? a.desc->nim : 0;
 
     if (!per_symbol) {                                     // exp(j*theta_a) once per tile instead of once per (symbol, angle)
@@ -138,7 +149,25 @@ __global__ void __launch_bounds__(BPS_THREADS) bps_kernel(BpsArgs<R> a)
             ti[q] = fma_(x.re, c.im, x.im * c.re);
         }
         R d0[BPS_EPT];
-        if (product) {
+        if (symmetric) {
+            // mirror-symmetric levels: the nearest level of t is the mirror image of the nearest POSITIVE level of |t|, at exactly
+            // the same distance - half the candidates, and |t|, |d| are source modifiers: two instructions per level pair
+            R mr[BPS_EPT], mi[BPS_EPT];
+#pragma unroll
+            for (int q = 0; q < BPS_EPT; q++) mr[q] = mi[q] = (R)3.0e38;
+            for (int r = nre / 2; r < nre; r += 2) {
+                const R l0 = lev[r], l1 = lev[r + 1 < nre ? r + 1 : r];
+#pragma unroll
+                for (int q = 0; q < BPS_EPT; q++) mr[q] = min_(min_(mr[q], abs_(abs_(tr[q]) - l0)), abs_(abs_(tr[q]) - l1));
+            }
+            for (int r = nim / 2; r < nim; r += 2) {
+                const R l0 = lev[BPS_MAX_LEVELS + r], l1 = lev[BPS_MAX_LEVELS + (r + 1 < nim ? r + 1 : r)];
+#pragma unroll
+                for (int q = 0; q < BPS_EPT; q++) mi[q] = min_(min_(mi[q], abs_(abs_(ti[q]) - l0)), abs_(abs_(ti[q]) - l1));
+            }
+#pragma unroll
+            for (int q = 0; q < BPS_EPT; q++) d0[q] = fma_(mr[q], mr[q], mi[q] * mi[q]);
+        } else if (product) {
             R mr[BPS_EPT], mi[BPS_EPT];
 #pragma unroll
             for (int q = 0; q < BPS_EPT; q++) mr[q] = mi[q] = (R)3.0e38;

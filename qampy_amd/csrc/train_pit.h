@@ -523,9 +523,9 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
 }
 
 // C[m][c] = sum_k op(A)[m][k] B[k][c],  op(A) = A (CONJT = false) or A^H; A is n x n (n <= PIT_EIGMAX), B and C are n x ncol
-// (row-major).  A block takes 64 columns: op(A) and the B tile are staged in LDS, a thread accumulates 6 rows x 4 columns in
-// registers (16 x 16 threads), so one k step costs 10 LDS reads for 24 complex multiply-adds.
-constexpr int PIT_GT = 64;
+// (row-major).  A block takes 32 columns: op(A) and the B tile are staged in LDS, a thread accumulates 3 rows x 4 columns in
+// registers (8 x 32 threads), so one k step costs 7 LDS reads for 12 complex multiply-adds.
+constexpr int PIT_GT = 32;
 template <bool CONJT>
 __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B, Zf *C, int n, int ncol, const PitCtrl *c)
 {
@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     Zf *As = reinterpret_cast<Zf *>(pit_smem);                // [k][PIT_EIGMAX]  op(A)[m][k] stored k-major: rows m contiguous
     Zf *Bs = As + (size_t)PIT_EIGMAX * PIT_EIGMAX;            // [k][PIT_GT]
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // columns 4 tx .. 4 tx + 3, rows ty + 16 u
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;    // columns 4 tx .. 4 tx + 3, rows ty + 32 u
     const int col0 = blockIdx.x * PIT_GT;
     for (int e = threadIdx.x; e < PIT_EIGMAX * n; e += 256) {
         const int k = e / PIT_EIGMAX, m = e - k * PIT_EIGMAX;
@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B
         Bs[e] = col0 + cc < ncol ? B[(size_t)k * ncol + col0 + cc] : Zf{0.f, 0.f};
     }
     __syncthreads();
-    constexpr int RU = PIT_EIGMAX / 16;                       // 6 rows per thread
+    constexpr int RU = PIT_EIGMAX / 32;                       // 3 rows per thread
     Zf acc[RU][4];
 #pragma unroll
     for (int u = 0; u < RU; u++)
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B
 #pragma unroll
         for (int v = 0; v < 4; v++) b[v] = Bs[k * PIT_GT + 4 * tx + v];
 #pragma unroll
-        for (int u = 0; u < RU; u++) a[u] = As[k * PIT_EIGMAX + ty + 16 * u];
+        for (int u = 0; u < RU; u++) a[u] = As[k * PIT_EIGMAX + ty + 32 * u];
 #pragma unroll
         for (int u = 0; u < RU; u++)
 #pragma unroll
@@ -568,7 +568,7 @@ __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B
     }
 #pragma unroll
     for (int u = 0; u < RU; u++) {
-        const int m = ty + 16 * u;
+        const int m = ty + 32 * u;
         if (m < n)
 #pragma unroll
             for (int v = 0; v < 4; v++)

@@ -83,6 +83,36 @@ def make_capture(M, nsym, nmodes=2, os=2, snr_db=None, theta=None, dgd=None, lin
                      coded_symbols=alphabet.astype(dtype))
 
 
+def make_pilot_capture(M=256, frame_len=2 ** 16, seq_len=2 ** 10, ins_rat=32, nframes=3, nmodes=2, os=2, fb=24e9, snr_db=35, theta=np.pi / 5.6,
+                       dgd=10e-12, linewidth=10e3, freq_off=40e6, modal_delay=700, frame_offset=12345, seed=9, dtype=np.complex128):
+    """
+    A capture for the pilot-based receiver (BASELINE config 5 shape): frames of ``frame_len`` symbols that start with a QPSK
+    pilot sequence of ``seq_len`` symbols, then one QPSK phase pilot every ``ins_rat`` symbols among the M-QAM payload; the
+    second mode is delayed by ``modal_delay`` symbols, the frame starts ``frame_offset`` symbols into the capture, a carrier
+    frequency offset is applied after the usual impairments (:func:`make_capture`).  Returns a dict: ``E`` (nmodes, nframes *
+    frame_len * os), ``pilots`` (nmodes, pilots per frame: sequence first), ``payload`` (nmodes, payload symbols per frame),
+    ``alphabet``, geometry and rates - what :class:`qampy_amd.signals.PilotSignal` takes.
+    """
+    from .signals import PilotSignal
+    rng = np.random.default_rng(seed)
+    _, idx_dat, idx_pil = PilotSignal._cal_pilot_idx(frame_len, seq_len, ins_rat)
+    pil_alpha, dat_alpha = theory.coded_symbols_qam(4, dtype=np.complex128), theory.coded_symbols_qam(M, dtype=np.complex128)
+    pilots = pil_alpha[rng.integers(0, 4, (nmodes, int(idx_pil.sum())))]
+    payload = dat_alpha[rng.integers(0, M, (nmodes, int(idx_dat.sum())))]
+    frame = np.empty((nmodes, frame_len), np.complex128)
+    frame[:, idx_pil] = pilots
+    frame[:, idx_dat] = payload
+    tx = np.tile(frame, nframes)
+    for m in range(1, nmodes):
+        tx[m] = np.roll(tx[m], m * modal_delay)
+    cap = make_capture(M, tx.shape[1], nmodes=nmodes, os=os, snr_db=snr_db, theta=theta if nmodes == 2 else None, dgd=dgd, linewidth=linewidth,
+                       fb=fb, beta=0.1, seed=seed, dtype=np.complex128, symbols=tx)
+    E = np.roll(np.asarray(cap), os * frame_offset, axis=1)
+    E = E * np.exp(2j * np.pi * freq_off / (fb * os) * np.arange(E.shape[1]))
+    return dict(E=np.ascontiguousarray(E.astype(dtype)), pilots=pilots, payload=payload, alphabet=dat_alpha, M=M, fb=fb, fs=fb * os,
+                frame_len=frame_len, seq_len=seq_len, ins_rat=ins_rat, nframes=nframes)
+
+
 def make_capture_dev(M, nsym, nmodes=2, os=2, snr_db=None, theta=None, dgd=None, linewidth=0., fb=20e9, beta=0.1, seed=1000, E=None):
     """
     :func:`make_capture` on the GPU (``qh_synth_capture_c64_dev``, csrc/synth.hip): the capture never exists on the host.

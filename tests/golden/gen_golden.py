@@ -396,6 +396,36 @@ def gen_pilot():
     save("pilot.npz", arr)
 
 
+def gen_pilot_frames():
+    """
+    Frame-by-frame pilot equalisation and the constant-phase helpers through the reference's BASIC API on its own signal
+    object (qampy/equalisation.py:340-397 pilot_equaliser_nframes -> :268-338 pilot_equaliser -> :42-87 _apply_to_pilotsignal;
+    qampy/phaserec.py:194-238 find_pilot_const_phase / correct_pilot_const_phase), on the SAME seeded capture as gen_pilot
+    (checked against pilot.npz), so that the tests can feed the stored arrays to the build's PilotSignal.
+    """
+    from qampy import impairments as ref_imp
+    np.random.seed(20240928)
+    frame_len, seq_len, ins_rat, M = 2 ** 12, 2 ** 8, 32, 64
+    sig = ref_signals.SignalWithPilots(M, frame_len, seq_len, ins_rat, nmodes=2, Mpilots=4, nframes=3, fb=24e9)
+    sig2 = sig.resample(sig.fb * 2, beta=0.1)
+    rx = ref_imp.simulate_transmission(sig2, snr=27, dgd=10e-12, freq_off=40e6, lwdth=50e3, roll_frame_sync=True, modal_delay=(700, 500))
+    stored = np.load(os.path.join(OUT, "pilot.npz"))
+    assert np.array_equal(np.asarray(rx), stored["rx"]), "the seeded capture differs from the one in pilot.npz"
+    rx.sync2frame(Ntaps=17)
+    rx.corr_foe()
+    arr = dict(synced=np.array(rx, copy=True), shiftfctrs=np.asarray(rx.shiftfctrs).copy())
+    taps, sout, rest = ref_basic_eq.pilot_equaliser_nframes(rx, (1e-3, 1e-3), 45, foe_comp=False, frames=[0, 1], methods=("cma", "sbd"))
+    arr.update(nf_taps=np.array(taps), nf_out=np.asarray(sout).copy(), nf_foe=np.array(rest[0]), nf_ntaps=np.array(rest[1]))
+    # (apply=False cannot be captured: the reference's pilot_equaliser forgets the `return` of its verbose no-apply branch, :335-336,
+    # and its frame loop indexes a bare taps array otherwise)
+    # constant pilot phase on the pilot sequence of the first equalised frame
+    rec = np.asarray(sout)[:, :seq_len]
+    ref = np.asarray(sig.pilot_seq)
+    ph = ref_basic_ph.find_pilot_const_phase(rec, ref)
+    arr.update(cp_rec=rec.copy(), cp_ref=ref.copy(), cp_phase=ph, cp_out=np.asarray(ref_basic_ph.correct_pilot_const_phase(rec, ph)))
+    save("pilot_frames.npz", arr)
+
+
 # ------------------------------------------------------------------------------------------------ make_decision (row I)
 def gen_decision():
     arr = {}
@@ -531,6 +561,9 @@ def gen_harness():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "pilot_frames":
+        gen_pilot_frames()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "harness":          # only this group (the others are unchanged)
         path = os.path.join(OUT, "cases.json")
         cases = json.load(open(path))
@@ -546,6 +579,7 @@ def main():
     cases["bps"] = gen_bps()
     cases["twostage"] = gen_twostage()
     gen_pilot()
+    gen_pilot_frames()
     gen_decision()
     cases["e2e"] = gen_e2e(inp, meta)
     cases["harness"] = gen_harness()

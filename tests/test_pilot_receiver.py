@@ -158,3 +158,85 @@ def test_pilot_basic_api_on_oracle_kernels(golden, oracle_kernels):
 @pytest.mark.gpu
 def test_pilot_basic_api_on_gpu(golden):
     _run_basic_api(golden["pilot"], 1e-8)
+
+
+# ------------------------------------------------------------------------------------------------ frames / constant phase
+def _run_frames(g, gf, rtol):
+    """pilot_equaliser_nframes and the constant-phase helpers against the reference's basic API on its own signal object
+    (tests/golden/pilot_frames.npz: qampy/equalisation.py:340-397, qampy/phaserec.py:194-238)."""
+    from qampy_amd import equalisation, phaserec
+    sig = _pilot_signal(g)
+    sig[:, :] = gf["synced"]
+    sig.shiftfctrs, sig.synctaps = gf["shiftfctrs"].copy(), 17
+    taps, sout, rest = equalisation.pilot_equaliser_nframes(sig, (1e-3, 1e-3), 45, foe_comp=False, frames=[0, 1], methods=("cma", "sbd"))
+    np.testing.assert_allclose(np.array(taps), gf["nf_taps"], rtol=rtol, atol=rtol)
+    assert type(sout) is type(sig) and sout.shape == gf["nf_out"].shape
+    np.testing.assert_allclose(np.asarray(sout), gf["nf_out"], rtol=rtol, atol=10 * rtol)
+    assert np.array_equal(np.array(rest[0]), gf["nf_foe"]) and np.array_equal(np.array(rest[1]), gf["nf_ntaps"])
+    # (the taps of frame 0 initialise frame 1 and are trained on IN PLACE by its pre-convergence stage, in the reference as here:
+    # entry 0 of the returned list is therefore not what frame 0 alone returns)
+    # without applying the filter the reference returns nothing usable (missing `return`, qampy/equalisation.py:335-336); here: the taps
+    only = equalisation.pilot_equaliser_nframes(sig, (1e-3, 1e-3), 45, apply=False, foe_comp=False, frames=[0, 1], verbose=False, methods=("cma", "sbd"))
+    np.testing.assert_allclose(np.array(only[0]), gf["nf_taps"], rtol=rtol, atol=rtol)
+    with pytest.raises(ValueError):
+        equalisation.pilot_equaliser_nframes(sig, (1e-3, 1e-3), 45, frames=[5], methods=("cma", "sbd"))      # incomplete frame
+    ph = phaserec.find_pilot_const_phase(gf["cp_rec"], gf["cp_ref"])
+    assert ph.shape == (2, 1)
+    np.testing.assert_allclose(ph, gf["cp_phase"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(phaserec.correct_pilot_const_phase(gf["cp_rec"], ph), gf["cp_out"], rtol=0, atol=1e-12)
+    with pytest.raises(ValueError):
+        phaserec.correct_pilot_const_phase(gf["cp_rec"], np.zeros(3))
+
+
+def test_pilot_frames_on_oracle_kernels(golden, oracle_kernels):
+    _run_frames(golden["pilot"], golden["pilot_frames"], 1e-9)
+
+
+@pytest.mark.gpu
+def test_pilot_frames_on_gpu(golden):
+    _run_frames(golden["pilot"], golden["pilot_frames"], 1e-8)
+
+
+# ------------------------------------------------------------------------------------------------ config 5 shape
+def _config5_chain(cap, dtype):
+    from qampy_amd import equalisation, phaserec
+    from qampy_amd.signals import PilotSignal
+    sig = PilotSignal(cap["E"].astype(dtype), cap["M"], cap["fb"], cap["fs"], cap["frame_len"], cap["seq_len"], cap["ins_rat"], cap["pilots"],
+                      symbols=cap["payload"], coded_symbols=cap["alphabet"])
+    ok = sig.sync2frame()
+    shifts = np.array(sig.shiftfctrs)
+    sig.corr_foe()
+    taps, eq = equalisation.pilot_equaliser(sig, (1e-3, 1e-3), 45, foe_comp=False, methods=("cma", "sbd_data"))
+    out, ph = phaserec.pilot_cpe(eq, N=5, use_seq=False)
+    return dict(ok=ok, shifts=shifts, taps=taps, eq=np.asarray(eq), out=np.asarray(out), ser=out.cal_ser(frames=[0]))
+
+
+@pytest.mark.gpu
+def test_config5_256qam_against_oracle_kernel_chain(monkeypatch):
+    """BASELINE config 5 as stated: 256-QAM payload, 2^16-symbol frames, 2 modes, 2 SPS, frequency offset and modal delay -
+    frame sync, pilot-sequence equaliser (data-aided second stage), filter over the frame and pilot phase recovery on the HIP
+    kernels against the same host layer running on the oracle's kernels."""
+    from qampy_amd import synth
+    cap = synth.make_pilot_capture()
+    hip = _config5_chain(cap, np.complex128)
+    k = core_eq._kernels
+
+    class OracleField:
+        def __init__(self, E):
+            self.E = E
+
+        def train(self, *a):
+            return oracle.train_equaliser(self.E, *a)
+
+        def apply(self, os, wx, modes=None):
+            return oracle.apply_filter_to_signal(self.E, os, np.ascontiguousarray(wx), modes)
+
+    monkeypatch.setattr(k, "ResidentField", OracleField)
+    monkeypatch.setattr(k, "train_equaliser", oracle.train_equaliser)
+    monkeypatch.setattr(k, "apply_filter_to_signal", oracle.apply_filter_to_signal)
+    monkeypatch.setattr(k, "train_equaliser_windows_search", _oracle_search)
+    cpu = _config5_chain(cap, np.complex128)
+    assert hip["ok"] and cpu["ok"] and np.array_equal(hip["shifts"], cpu["shifts"])
+    np.testing.assert_allclose(hip["taps"], cpu["taps"], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(hip["out"], cpu["out"], rtol=0, atol=1e-6)
+    assert np.array_equal(hip["ser"], cpu["ser"]) and hip["ser"].max() < 5e-2
