@@ -394,11 +394,16 @@ class _OracleKernels:
         k.train_equaliser = lambda *a: oracle.train_equaliser(*a, fast=True)
         k.apply_filter_to_signal = lambda *a, **kw: oracle.apply_filter_to_signal(*a, fast=True, **kw)
         k.train_equaliser_windows_search = search
+        from qampy_amd.core import phaserecovery
+        self.dsp, self.cfo = phaserecovery._dsp, phaserecovery._dsp.comp_freq_offset
+        t_exp = lambda E, fo, os_=1: (E * np.exp(-2j * np.pi * np.arange(1, E.shape[1] + 1, dtype=float) * np.asarray(fo, dtype=float).reshape(-1, 1) / os_)).astype(E.dtype)
+        self.dsp.comp_freq_offset = t_exp
         return self
 
     def __exit__(self, *exc):
         for n, v in self.saved.items():
             setattr(self.k, n, v)
+        self.dsp.comp_freq_offset = self.cfo
 
 
 def run_c5(args, cfg):
@@ -664,14 +669,29 @@ def main():
         roofline = dict(bound="valu-issue" if 1 <= dom <= rx.nstage else "hbm", kernel=stage_names[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None, algorithmic_bytes=int(stage_bytes[dom]),
                         note="exact sequential LMS recurrence: dependent-issue bound, one workgroup per output mode (DESIGN.md 3.1); HBM figure for reference")
-    # measured HBM traffic of the dominant kernel: from the PMC pass of the same workload IF it was taken at this commit
+    # measured HBM traffic of the dominant kernel: from the PMC passes of the same workload (scripts/gpu_pmc.sh ->
+    # profiles/pmc_traffic_<workload>.json), quoted only while the kernel sources are the ones that were profiled
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)))
-        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
-        key = roofline["kernel"]
-        if pmc.get("kernels_by_stage", {}).get(key) and (not head or pmc.get("kernel_sources_sha") == kernel_sources_sha()):
-            roofline["traffic"] = pmc["kernels_by_stage"][key]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
+        if pmc.get("kernel_sources_sha") == kernel_sources_sha():
+            kern = roofline["kernel"]
+            pat = None
+            if "relaxation pass" in kern:
+                stage = int(kern[5]) - 1
+                pat = "qh::train_seg_kernel<float, %d," % _lib.METHOD_ID[cfg["methods"][stage]]
+            elif kern.startswith("train"):
+                mid = _lib.METHOD_ID[cfg["methods"][int(kern[5]) - 1]]
+                pat = ("qh::train_la_kernel<float, %d," % mid, "qh::train_bi_kernel<float, %d," % mid)
+            elif kern == "bps_recover":
+                pat = "qh::bps_kernel<float>"
+            elif kern == "gram":
+                pat = "qh::gram_slide_kernel<float"
+            hit = [v for k, v in pmc["kernels"].items() if pat and k.startswith(pat)]
+            if hit:
+                roofline["traffic"] = hit[0]["hbm_bytes"]
+        else:
+            roofline["traffic_note"] = "profiles/pmc_traffic_%s.json belongs to other kernel sources: not quoted" % args.workload
+    except (OSError, KeyError, ValueError, IndexError):
         pass
     out["roofline"] = roofline
 
@@ -718,7 +738,9 @@ def main():
     if world == 1 and args.bank > 1:
         del rx
         try:
-            out["channel_bank"] = channel_bank_run(cfg, sig, args.bank, max(1, min(args.steps, 2)), barrier_sync, args.bank_trainer)
+            # channels x symbol periods bounded to what 128 captures of 2^22 periods take (bank buffers + block-iterative scratch)
+            nbank = max(2, min(args.bank, (args.bank << 22) // max(nsym, 1)))
+            out["channel_bank"] = channel_bank_run(cfg, sig, nbank, max(1, min(args.steps, 2)), barrier_sync, args.bank_trainer)
             _lib.call("qh_release_scratch")
             workers = min(os.cpu_count() or 1, 128) if args.cpu_bank_workers < 0 else args.cpu_bank_workers
             if workers > 0 and not args.no_cpu_baseline:

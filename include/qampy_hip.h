@@ -48,7 +48,8 @@ enum { QH_RM_CMA = 0, QH_RM_SGNCMA, QH_RM_DD, QH_RM_DD_DATA };
 
 /* ---- device / runtime --------------------------------------------------------------------------------------- */
 int qh_device_count(int *count);
-int qh_init(int device);                       /* select device, create the library stream; idempotent per device */
+int qh_init(int device);                       /* select the device and create the library streams; idempotent for the same device; ONE device
+                                                * per process: a second call with another index fails with QH_ERR_ARG (run one process per GPU) */
 int qh_device_name(char *buf, size_t n);
 const char *qh_last_error(void);
 int qh_sync(void);                             /* wait for the library stream */
@@ -183,6 +184,11 @@ int qh_bps_recover_c64_dev(const void *E, int nm, int64_t L, const void *angles,
                            void *ph, void *Eout);
 int qh_bps_recover_c128_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *symbols, int M, int N, int32_t *idx,
                             void *ph, void *Eout);
+
+/* ---- comp_freq_offset (pilot receiver; qampy/core/phaserecovery.py:435-473): out[k, n] = E[k, n] exp(-2 pi i (n + 1) fo[k] / os),
+ * fo (nmodes,) in units of the symbol rate, E / out (nmodes, L) host arrays */
+int qh_comp_freq_offset_c64(const void *E, int nmodes, int64_t L, const double *fo, int os, void *out);
+int qh_comp_freq_offset_c128(const void *E, int nmodes, int64_t L, const double *fo, int os, void *out);
 
 /* ---- select_angles: out[i] = angles[(p > 1 ? i : 0), idx[i]] ;  idx int64 (L,) ------------------------------- */
 int qh_select_angles_f32(const void *angles, int64_t p, int A, const int64_t *idx, int64_t L, void *out);

@@ -90,3 +90,18 @@ def bps_recover(E, Mtestangles, symbols, N):
     idx, ph, out = D((nm, L), np.int32), D((nm, L), rt), D((nm, L), ct)
     bps_recover_dev(dE, Mtestangles, dsy, N, idx, ph, out, angles=dang)
     return out.to_host(), ph.to_host()
+
+
+def comp_freq_offset(E, freq_offset, os=1):
+    """``E[k, n] * exp(-2j pi (n + 1) freq_offset[k] / os)`` for every row (qampy/core/phaserecovery.py:435-473) on the device."""
+    suf, rt, ct = _lib.suffix(E.dtype)
+    E = np.ascontiguousarray(E)
+    if E.ndim != 2 or not np.iscomplexobj(E):
+        raise TypeError("comp_freq_offset works on a 2-d complex array")
+    fo = np.ascontiguousarray(np.broadcast_to(np.asarray(freq_offset, dtype=np.float64).reshape(-1), (E.shape[0],)) if np.size(freq_offset) == 1
+                              else np.asarray(freq_offset, dtype=np.float64).reshape(-1))
+    if fo.size != E.shape[0]:
+        raise ValueError("one frequency offset per mode (or one for all)")
+    out = np.empty_like(E)
+    _lib.call("qh_comp_freq_offset_c" + ("64" if suf == "32" else "128"), _lib.ptr(E), E.shape[0], E.shape[1], _lib.ptr(fo), int(os), _lib.ptr(out))
+    return out

@@ -80,11 +80,8 @@ def find_freq_offset(sig, os=1, average_over_modes=True, fft_size=2 ** 16):
 
 
 def comp_freq_offset(sig, freq_offset, os=1):
-    """Remove a frequency offset given in units of the symbol rate (qampy/core/phaserecovery.py:435-473)."""
-    ndim = sig.ndim
-    sig = np.atleast_2d(sig)
-    out = np.zeros(sig.shape, dtype=sig.dtype)
-    t = np.arange(1, sig.shape[1] + 1, dtype=float)
-    for k in range(sig.shape[0]):
-        out[k, :] = sig[k, :] * np.exp(-1j * (2 * np.pi * t * freq_offset[k] / os))
-    return out.flatten() if ndim == 1 else out
+    """Remove a frequency offset given in units of the symbol rate, per mode (contract of qampy/core/phaserecovery.py:435-473:
+    ``sig[k] * exp(-2j pi t freq_offset[k] / os)`` with ``t = 1 .. L``); one elementwise device pass over all modes."""
+    rows = np.atleast_2d(sig)
+    out = _dsp.comp_freq_offset(np.ascontiguousarray(rows), np.asarray(freq_offset, dtype=np.float64).reshape(-1)[:rows.shape[0]], os)
+    return out.reshape(-1) if np.ndim(sig) == 1 else out

@@ -2,6 +2,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <mutex>
+#include <vector>
 #include <string.h>
 
 namespace qh {
@@ -25,6 +26,12 @@ static int init_device(int device)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_stream && device == g_device) return QH_OK;
+    if (g_stream) {
+        // One device per process: scratch buffers, streams, events and the kernels' per-device attributes belong to the device
+        // the library was initialised on; run one process per GPU (bench.py --gpus N does).
+        set_error("libqampy_hip is already initialised on device " + std::to_string(g_device) + ": one device per process");
+        return QH_ERR_ARG;
+    }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         (void)hipGetLastError();
@@ -70,6 +77,39 @@ const char *trainer_force()
     default: { const char *e = getenv("QAMPY_HIP_TRAINER"); return e ? e : ""; }
     }
 }
+// ---- pool of staging buffers (DevBuf): size classes 2^k bytes, at most POOL_KEEP idle buffers per class and POOL_BYTES in total
+static constexpr int POOL_CLASSES = 48, POOL_KEEP = 8;
+static constexpr size_t POOL_BYTES = (size_t)24 << 30;
+static std::vector<void *> g_pool[POOL_CLASSES];
+static size_t g_pool_bytes = 0;
+static int pool_class(size_t bytes) { int k = 8; while (((size_t)1 << k) < bytes && k < POOL_CLASSES - 1) k++; return k; }
+int pool_alloc(size_t bytes, void **p, size_t *cap)
+{
+    const int k = pool_class(bytes);
+    *cap = (size_t)1 << k;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_pool[k].empty()) { *p = g_pool[k].back(); g_pool[k].pop_back(); g_pool_bytes -= *cap; return QH_OK; }
+    }
+    QH_HIP(hipMalloc(p, *cap));
+    return QH_OK;
+}
+void pool_free(void *p, size_t cap)
+{
+    const int k = pool_class(cap);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if ((int)g_pool[k].size() < POOL_KEEP && g_pool_bytes + cap <= POOL_BYTES) { g_pool[k].push_back(p); g_pool_bytes += cap; return; }
+    }
+    (void)hipFree(p);
+}
+static void pool_release()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &v : g_pool) { for (void *p : v) (void)hipFree(p); v.clear(); }
+    g_pool_bytes = 0;
+}
+
 int scratch(int slot, size_t bytes, void **p)
 {
     if (bytes > g_scratch_n[slot]) {
@@ -128,6 +168,7 @@ int qh_release_scratch(void)
         if (qh::g_scratch[i]) QH_HIP(hipFree(qh::g_scratch[i]));
         qh::g_scratch[i] = nullptr; qh::g_scratch_n[i] = 0;
     }
+    qh::pool_release();
     return QH_OK;
 }
 int qh_use_stream(int idx)

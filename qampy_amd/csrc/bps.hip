@@ -545,6 +545,40 @@ template <typename R> int make_decision_host(const void *E, int64_t L, const voi
     return QH_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ frequency-offset removal
+// out[k, n] = E[k, n] * exp(-1j * 2 pi (n + 1) fo[k] / os)   (qampy/core/phaserecovery.py:435-473: t = arange(1, L + 1)); the phase is
+// formed in double and reduced modulo one turn before the sine / cosine, whatever the precision of the signal
+template <typename R>
+__global__ void __launch_bounds__(256) comp_freq_offset_kernel(const Cx<R> *E, int64_t L, const double *fo, int os, Cx<R> *out)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (n >= L) return;
+    double turns = (double)(n + 1) * fo[k] / (double)os;
+    turns -= rint(turns);
+    double sn, cs;
+    sincos(-6.283185307179586476925 * turns, &sn, &cs);
+    const Cx<R> x = ldg(E + (size_t)k * L + n);
+    stg(out + (size_t)k * L + n, Cx<R>{(R)((double)x.re * cs - (double)x.im * sn), (R)((double)x.re * sn + (double)x.im * cs)});
+}
+template <typename R> int comp_freq_offset_host(const void *E, int nmodes, int64_t L, const double *fo, int os, void *out)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    QH_REQUIRE(nmodes >= 1 && L >= 0 && os >= 1, "comp_freq_offset: bad sizes");
+    if (L == 0) return QH_OK;
+    DevBuf dE, df, dout;
+    if ((rc = dE.from_host(E, (size_t)nmodes * L * sizeof(Cx<R>)))) return rc;
+    if ((rc = df.from_host(fo, (size_t)nmodes * sizeof(double)))) return rc;
+    if ((rc = dout.alloc((size_t)nmodes * L * sizeof(Cx<R>)))) return rc;
+    hipLaunchKernelGGL((comp_freq_offset_kernel<R>), dim3((unsigned)((L + 255) / 256), nmodes), dim3(256), 0, g_stream, (const Cx<R> *)dE.p, L, (const double *)df.p, os,
+                       (Cx<R> *)dout.p);
+    QH_HIP(hipGetLastError());
+    if ((rc = dout.to_host(out, dout.n))) return rc;
+    QH_HIP(hipStreamSynchronize(g_stream));
+    return QH_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ error counter
 __global__ void __launch_bounds__(256) count_errors_kernel(const int32_t *rx, const int32_t *tx, int64_t n, int64_t lag, int64_t ntx,
                                                            unsigned long long *count)
@@ -585,6 +619,10 @@ int qh_make_decision_c64_dev(const void *E, int64_t L, const void *s, int M, voi
 { return qh::make_decision_dev<float>(E, L, s, M, det, dist, idx); }
 int qh_make_decision_c128_dev(const void *E, int64_t L, const void *s, int M, void *det, void *dist, int32_t *idx)
 { return qh::make_decision_dev<double>(E, L, s, M, det, dist, idx); }
+int qh_comp_freq_offset_c64(const void *E, int nmodes, int64_t L, const double *fo, int os, void *out)
+{ return qh::comp_freq_offset_host<float>(E, nmodes, L, fo, os, out); }
+int qh_comp_freq_offset_c128(const void *E, int nmodes, int64_t L, const double *fo, int os, void *out)
+{ return qh::comp_freq_offset_host<double>(E, nmodes, L, fo, os, out); }
 int qh_count_errors_dev(const int32_t *rx, const int32_t *tx, int64_t n, int64_t lag, int64_t ntx, unsigned long long *count_dev)
 {
     int rc = qh::ensure_init();

@@ -29,15 +29,20 @@ hipStream_t side_stream();       // the library stream that is NOT the current o
 const char *trainer_force();   // "" (automatic) or "direct" / "lookahead" / "iterative": qh_set_trainer(), else QAMPY_HIP_TRAINER
 int scratch(int slot, size_t bytes, void **p);   // grow-only device scratch, slots 0..11
 
+// Staging memory of the host-pointer entry points: power-of-two size classes kept in a small pool (api.hip) instead of a
+// hipMalloc / hipFree pair per call - hipFree synchronises the device, and the pilot receiver makes dozens of small calls.
+// The entry points synchronise their stream before they return, so a buffer is idle when it goes back to the pool.
+int pool_alloc(size_t bytes, void **p, size_t *cap);
+void pool_free(void *p, size_t cap);
+
 // RAII device scratch used by the host-pointer entry points
 struct DevBuf {
     void *p = nullptr;
-    size_t n = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    size_t n = 0, cap = 0;
+    ~DevBuf() { if (p) pool_free(p, cap); }
     int alloc(size_t bytes) {
         n = bytes;
-        QH_HIP(hipMalloc(&p, bytes ? bytes : 1));
-        return QH_OK;
+        return pool_alloc(bytes ? bytes : 1, &p, &cap);
     }
     int from_host(const void *h, size_t bytes) {
         int rc = alloc(bytes);

@@ -6,13 +6,13 @@
 // substitution - 64 dependent steps, each paying the ~8 cycles a lone wavefront needs per instruction.  Here it is
 // solved by fixed-point sweeps  c <- mu errfn(q + L c)  instead: because L is strictly lower triangular, entry i is
 // final once entries < i are, so the sweeps reach the exact fixed point (bit for bit, the reduction order is fixed) after
-// at most 64 and in practice 4-8 of them, and every sweep is a 64x64 complex matrix-vector product that 16 wavefronts
-// share: wave w owns the steps j = 4w..4w+3 (its c_j and Gram rows) and the taps of slice w.  The error function is
-// evaluated once per sweep instead of once per step.  Per block:
+// at most 64 and in practice 4-8 of them, and every sweep is a 64x64 complex matrix-vector product that BI_W = 8 wavefronts
+// share (2 per SIMD): wave w owns the steps j = 8w..8w+7 (its c_j and Gram rows) and the taps of slice w.  The error
+// function is evaluated once per sweep instead of once per step.  Per block:
 //        q      prior outputs W . x_i, every wave contributes its tap slice
 //        sweeps partial_w[i] = q_w[i] + sum_{j in own} c_j G(j, i)  ->  LDS [i][w]  ->  barrier  ->  wave w reduces rows
-//               i = 4w..4w+3 over the 16 contributions (one ds_read + a 16-lane DPP tree)  ->  c_i = mu errfn(y_i)
-//        taps   W += sum_j c_j conj(x_j): every wave adds its 4 steps to all taps, slice owners reduce over the waves
+//               i = 8w..8w+7 over the 8 contributions (one ds_read + an 8-lane DPP tree)  ->  c_i = mu errfn(y_i)
+//        taps   W += sum_j c_j conj(x_j): every wave adds its 8 steps to all taps, slice owners reduce over the waves
 // The result is the sequential recurrence's result up to the order of floating-point additions (like train_la.h).
 #pragma once
 #include <stdlib.h>

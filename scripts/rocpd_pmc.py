@@ -39,4 +39,12 @@ if json_out:
             "gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128 B request for coalesced streams -> x2; "
             "confirmed here on apply/bps/make_decision/gram whose known read volume is exactly 2x the counter); WRITE_SIZE "
             "matched the known 4 GiB of gram_kernel 1:1.")
-    json.dump(dict(workload=workload, note=note, kernels=kern), open(json_out, "w"), indent=1)
+    import os, hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    d = os.path.join(root, "qampy_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    # kernel_sources_sha: bench.py only quotes these numbers while the kernel sources are the ones that were profiled
+    json.dump(dict(workload=workload, note=note, kernel_sources_sha=h.hexdigest()[:16], kernels=kern), open(json_out, "w"), indent=1)

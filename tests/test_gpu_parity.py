@@ -272,7 +272,10 @@ def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, 
     for w, e in ((wd, ed), (wl, el), (wi, ei)):
         np.testing.assert_allclose(w, wo, **t)
         np.testing.assert_allclose(e, eo, rtol=t["rtol"], atol=t["atol"] * 5)
-    assert not np.array_equal(wl, wd) or dn == "c128" or True        # different summation order: equal only by luck
+    # the three forms really are different computations (different summation orders): their error traces agree to the
+    # tolerance above but not bit for bit
+    if not (method in ("sbd", "mddma", "dd") and M == 32):       # cross alphabets: every request runs the direct form
+        assert not (np.array_equal(el, ed) and np.array_equal(ei, ed))
 
 
 @pytest.mark.parametrize("method,M,ntaps,nmodes", [("cma", 4, 17, 2), ("mcma", 16, 21, 2), ("mrde", 64, 41, 2), ("sbd", 16, 21, 2),

@@ -22,6 +22,12 @@ def _oracle_windows(E, starts, win_len, TrSyms, Niter, os_, mu, wx0, modes, adap
     return np.array(errs), np.array(wxs), np.array(mus)
 
 
+def _numpy_cfo(E, fo, os=1):
+    """What hip_dsp.comp_freq_offset computes on the device (qampy/core/phaserecovery.py:435-473)."""
+    t = np.arange(1, E.shape[1] + 1, dtype=float)
+    return (E * np.exp(-2j * np.pi * t * np.asarray(fo, dtype=float).reshape(-1, 1) / os)).astype(E.dtype)
+
+
 def _oracle_search(E, starts, win_len, *a):
     err, wx, _ = _oracle_windows(E, starts, win_len, *a)
     var = np.var(err, axis=-1).T                       # (nmodes, nwin)
@@ -49,9 +55,10 @@ def oracle_kernels(monkeypatch):
     monkeypatch.setattr(k, "apply_filter_to_signal", oracle.apply_filter_to_signal)
     monkeypatch.setattr(k, "train_equaliser_windows", _oracle_windows)
     monkeypatch.setattr(k, "train_equaliser_windows_search", _oracle_search)
+    monkeypatch.setattr(phaserecovery._dsp, "comp_freq_offset", _numpy_cfo)
 
 
-def test_helpers_match_reference(golden):
+def test_helpers_match_reference(golden, oracle_kernels):
     g = golden["pilot"]
     ix, y2, ii, acm = ber_functions.find_sequence_offset_complex(g["fso_x"], g["fso_y"])
     assert ix == g["fso_ix"] and ii == g["fso_ii"] and np.isclose(acm, g["fso_acm"])
@@ -235,6 +242,7 @@ def test_config5_256qam_against_oracle_kernel_chain(monkeypatch):
     monkeypatch.setattr(k, "train_equaliser", oracle.train_equaliser)
     monkeypatch.setattr(k, "apply_filter_to_signal", oracle.apply_filter_to_signal)
     monkeypatch.setattr(k, "train_equaliser_windows_search", _oracle_search)
+    monkeypatch.setattr(phaserecovery._dsp, "comp_freq_offset", _numpy_cfo)
     cpu = _config5_chain(cap, np.complex128)
     assert hip["ok"] and cpu["ok"] and np.array_equal(hip["shifts"], cpu["shifts"])
     np.testing.assert_allclose(hip["taps"], cpu["taps"], rtol=1e-8, atol=1e-8)
