@@ -18,6 +18,8 @@
 //     short run, sliding for the rest, written to a padded LDS plane;
 //   * one thread per symbol scans the A sums for the first strict minimum (tie -> lowest angle, like the reference).
 #include "common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace qh {
 
@@ -40,41 +42,56 @@ template <typename R> struct AlphabetDesc {
     R re[BPS_MAX_LEVELS], im[BPS_MAX_LEVELS];
 };
 
+// One wave.  Lanes 0..31 hold the distinct real parts found so far, lanes 32..63 the distinct imaginary parts; a symbol is
+// matched against all of them with one ballot, so the pass over the alphabet costs a few instructions per symbol (the former
+// single-thread version with private level arrays took 40 us per call - as long as a quarter of the search it prepares).
 template <typename R>
 __global__ void __launch_bounds__(64) analyse_alphabet_kernel(const Cx<R> *symbols, int M, AlphabetDesc<R> *d)
 {
-    __shared__ R sre[1024], sim[1024];
     __shared__ unsigned char seen[BPS_MAX_LEVELS * BPS_MAX_LEVELS];
-    if (M > 1024) { if (threadIdx.x == 0) d->product = 0; return; }
-    for (int k = threadIdx.x; k < M; k += 64) { const Cx<R> s = symbols[k]; sre[k] = s.re; sim[k] = s.im; }
-    for (int k = threadIdx.x; k < BPS_MAX_LEVELS * BPS_MAX_LEVELS; k += 64) seen[k] = 0;
+    __shared__ R sorted[2 * BPS_MAX_LEVELS];
+    const int lane = threadIdx.x;
+    const bool imside = lane >= BPS_MAX_LEVELS;
+    const int slot = lane & (BPS_MAX_LEVELS - 1);
+    if (M > 1024) { if (lane == 0) { d->product = 0; d->symmetric = 0; d->nre = d->nim = 0; } return; }
+    for (int k = lane; k < BPS_MAX_LEVELS * BPS_MAX_LEVELS; k += 64) seen[k] = 0;
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    R lre[BPS_MAX_LEVELS], lim[BPS_MAX_LEVELS];
+    R mine = 0;
     int nre = 0, nim = 0;
     bool ok = true;
     for (int k = 0; k < M && ok; k++) {
-        int r = 0, i = 0;
-        while (r < nre && lre[r] != sre[k]) r++;
-        if (r == nre) { if (nre < BPS_MAX_LEVELS) lre[nre++] = sre[k]; else ok = false; }
-        while (i < nim && lim[i] != sim[k]) i++;
-        if (i == nim) { if (nim < BPS_MAX_LEVELS) lim[nim++] = sim[k]; else ok = false; }
+        const Cx<R> sk = symbols[k];                                    // wave-uniform
+        const R v = imside ? sk.im : sk.re;
+        const unsigned long long hit = __ballot(slot < (imside ? nim : nre) && mine == v);
+        int r = __ffsll((unsigned long long)(hit & 0xffffffffull)) - 1, i = __ffsll((unsigned long long)(hit >> 32)) - 1;
+        if (r < 0) { if (nre < BPS_MAX_LEVELS) { if (!imside && slot == nre) mine = v; r = nre++; } else ok = false; }
+        if (i < 0) { if (nim < BPS_MAX_LEVELS) { if (imside && slot == nim) mine = v; i = nim++; } else ok = false; }
         // every (re, im) combination must occur exactly once: M distinct points on an nre x nim grid with M == nre*nim
-        if (ok) { if (seen[r * BPS_MAX_LEVELS + i]) ok = false; else seen[r * BPS_MAX_LEVELS + i] = 1; }
+        if (ok) {
+            const bool dup = seen[r * BPS_MAX_LEVELS + i] != 0;       // same address in every lane
+            __syncthreads();
+            if (dup) ok = false; else if (lane == 0) seen[r * BPS_MAX_LEVELS + i] = 1;
+            __syncthreads();
+        }
     }
     ok = ok && (long)nre * nim == M;
-    // sorted levels; mirror symmetry lets the search run on |t| against the positive half only (|(-t) - (-l)| == |t - l| exactly)
-    bool sym = ok && (nre % 2 == 0) && (nim % 2 == 0);
-    if (ok) {
-        for (int a = 1; a < nre; a++) { R v = lre[a]; int b = a - 1; while (b >= 0 && lre[b] > v) { lre[b + 1] = lre[b]; b--; } lre[b + 1] = v; }
-        for (int a = 1; a < nim; a++) { R v = lim[a]; int b = a - 1; while (b >= 0 && lim[b] > v) { lim[b + 1] = lim[b]; b--; } lim[b + 1] = v; }
-        for (int a = 0; a < nre / 2 && sym; a++) sym = lre[a] == -lre[nre - 1 - a];
-        for (int a = 0; a < nim / 2 && sym; a++) sym = lim[a] == -lim[nim - 1 - a];
+    // sorted levels (rank = number of smaller levels of the same axis; levels are distinct)
+    const int nmine = imside ? nim : nre;
+    int rank = 0;
+    for (int j = 0; j < BPS_MAX_LEVELS; j++) {
+        const R other = __shfl(mine, (imside ? BPS_MAX_LEVELS : 0) + j);
+        if (j < nmine && other < mine) rank++;
     }
-    for (int r = 0; r < BPS_MAX_LEVELS; r++) { d->re[r] = r < nre ? lre[r] : (R)0; d->im[r] = r < nim ? lim[r] : (R)0; }
-    d->product = ok ? 1 : 0;
-    d->symmetric = sym ? 1 : 0;
-    d->nre = nre; d->nim = nim;
+    sorted[lane] = 0;
+    __syncthreads();
+    if (ok && slot < nmine) sorted[(imside ? BPS_MAX_LEVELS : 0) + rank] = mine;
+    __syncthreads();
+    // mirror symmetry lets the search run on |t| against the positive half only (|(-t) - (-l)| == |t - l| exactly)
+    bool symlane = true;
+    if (ok && slot < nmine) symlane = sorted[lane] == -sorted[(imside ? BPS_MAX_LEVELS : 0) + nmine - 1 - slot];
+    const bool sym = ok && (nre % 2 == 0) && (nim % 2 == 0) && __all(symlane);
+    if (imside) d->im[slot] = ok && slot < nim ? sorted[lane] : (R)0; else d->re[slot] = ok && slot < nre ? sorted[lane] : (R)0;
+    if (lane == 0) { d->product = ok ? 1 : 0; d->symmetric = sym ? 1 : 0; d->nre = nre; d->nim = nim; }
 }
 
 template <typename R> struct BpsArgs {
@@ -239,6 +256,173 @@ __global__ void __launch_bounds__(BPS_THREADS) bps_kernel(BpsArgs<R> a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------ streaming form (complex64)
+// The tile kernel above keeps one workgroup per CU busy with three phases separated by barriers; 2/3 of its time is spent in
+// the window sums and the arg-min, with a quarter of the threads idle.  The streaming form removes the phases:
+//   * one wave per chunk of C output symbols (one wave per workgroup: no workgroup barrier), lane <-> test angle; the rotator
+//     of a lane stays in registers, the symbol of a step is wave-uniform (read once per 16 steps, broadcast with v_readlane);
+//   * the distances of the last 2N symbols live in an LDS ring of the wave (2N x 64 floats): per symbol one read (the value
+//     leaving the window), one write, s += entering, s -= leaving - the same sliding order as the tile kernel; every 128
+//     symbols s is re-formed as the direct 2N-term sum of the ring (oldest to newest);
+//   * the arg-min over the angles is taken 16 symbols at a time on a transposed 16 x 64 block in LDS: lane <-> (symbol,
+//     quarter of the angles), 16 strided reads (conflict free at pitch 65), then two exchange steps over the quarters;
+//   * all three alphabet kinds (mirror-symmetric product / product / anything) are handled in the kernel from the device-side
+//     descriptor, so the host never waits for the analysis.
+// ~35 wave instructions per symbol against ~75 (and no idle threads): bound by VALU issue, not by HBM (16 B per symbol).
+constexpr int BS_G = 16;                 // symbols per arg-min block
+constexpr int BS_TP = 65;                // pitch of the transposed block
+constexpr int BS_REANCHOR = 8;           // groups between direct re-summations of the window
+constexpr int BS_MAXRING = 192;          // rows (2N) the ring may take: 48 KiB
+
+struct BpsStreamArgs {
+    const Cx<float> *E;          // (nm, L)
+    const float *angles;         // (A,)
+    const Cx<float> *symbols;    // (M,)
+    const AlphabetDesc<float> *desc;
+    int32_t *idx;                // (nm, L)
+    int64_t L;
+    int A, M, N, C, alpha_lds;
+};
+
+template <int K> struct BsKind { static constexpr int value = K; };
+__device__ __forceinline__ float bs_axis_sym(float t, const float (&lv)[16], int nl)
+{
+    const float u = abs_(t);
+    float m = min_(min_(abs_(u - lv[0]), abs_(u - lv[1])), min_(abs_(u - lv[2]), abs_(u - lv[3])));   // padding levels are 3e38: never the minimum
+    if (nl > 4) {                                                                                   // wave-uniform
+        m = min_(m, min_(min_(abs_(u - lv[4]), abs_(u - lv[5])), min_(abs_(u - lv[6]), abs_(u - lv[7]))));
+        if (nl > 8) {
+#pragma unroll
+            for (int k = 8; k < 16; k += 2) m = min_(m, min_(abs_(u - lv[k]), abs_(u - lv[k + 1])));
+        }
+    }
+    return m;
+}
+
+__global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char bs_smem[];
+    const int lane = threadIdx.x;
+    const int W = 2 * a.N;
+    float *ring = reinterpret_cast<float *>(bs_smem);                 // [W][64]
+    float *tb = ring + (size_t)W * 64;                                // [BS_G][BS_TP]
+    float *plev = tb + BS_G * BS_TP + 1;                              // [2][BPS_MAX_LEVELS] levels of a product alphabet
+    Cx<float> *alpha = reinterpret_cast<Cx<float> *>(plev + 2 * BPS_MAX_LEVELS + 1);   // [M] any other alphabet (if it fits)
+    const int64_t L = a.L;
+    const Cx<float> *E = a.E + (size_t)blockIdx.y * L;
+    int32_t *idx = a.idx + (size_t)blockIdx.y * L;
+    const int64_t c0 = (int64_t)blockIdx.x * a.C;
+    const int64_t c1 = c0 + a.C < L ? c0 + a.C : L;                   // outputs [c0, c1)
+    const int ngroups = (a.C + W - 1 + BS_G - 1) / BS_G;
+    const int64_t lstart = c0 + a.C - 1 + a.N - (int64_t)ngroups * BS_G + 1;   // first distance row; row l completes the window of output l - N
+
+    // ---- alphabet
+    const int product = a.desc->product, symmetric = a.desc->symmetric;
+    const int nre = a.desc->nre, nim = a.desc->nim;
+    float lre[16], lim[16];                                           // positive halves, in SGPRs
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        lre[k] = symmetric && k < nre / 2 ? a.desc->re[nre / 2 + k] : 3.0e38f;
+        lim[k] = symmetric && k < nim / 2 ? a.desc->im[nim / 2 + k] : 3.0e38f;
+    }
+    if (product && !symmetric) {
+        if (lane < BPS_MAX_LEVELS) { plev[lane] = a.desc->re[lane]; plev[BPS_MAX_LEVELS + lane] = a.desc->im[lane]; }
+    } else if (!product && a.alpha_lds) {
+        for (int k = lane; k < a.M; k += 64) alpha[k] = a.symbols[k];
+    }
+    for (int r = 0; r < W; r++) ring[r * 64 + lane] = 0.f;
+    float cs = 1.f, sn = 0.f;
+    if (lane < a.A) sincosf(a.angles[lane], &sn, &cs);
+    const float bias = lane < a.A ? 0.f : 2000.f;                     // lanes without an angle never win (dmin starts at 1000)
+    __syncthreads();
+
+    auto distance = [&](float tr, float ti, auto KIND) -> float {
+        constexpr int kind = decltype(KIND)::value;
+        float d0;
+        if (kind == 0) {
+            const float mr = bs_axis_sym(tr, lre, nre / 2), mi = bs_axis_sym(ti, lim, nim / 2);
+            d0 = fma_(mr, mr, mi * mi);
+        } else if (kind == 1) {
+            float mr = 3.0e38f, mi = 3.0e38f;
+            for (int r = 0; r < nre; r++) mr = min_(mr, abs_(tr - plev[r]));
+            for (int r = 0; r < nim; r++) mi = min_(mi, abs_(ti - plev[BPS_MAX_LEVELS + r]));
+            d0 = fma_(mr, mr, mi * mi);
+        } else {
+            d0 = 1000.f;                                              // det_symbol: strict `<` from d0 = 1000 (:17-22)
+            for (int k = 0; k < a.M; k++) {
+                const Cx<float> sk = a.alpha_lds ? alpha[k] : a.symbols[k];
+                const float dr = tr - sk.re, di = ti - sk.im;
+                const float d = fma_(dr, dr, di * di);
+                d0 = d < d0 ? d : d0;
+            }
+        }
+        return d0 < 100.f ? d0 : 100.f;                               // dists start at 100 (:73, :83)
+    };
+    auto load_group = [&](int64_t lg) -> Cx<float> {
+        int64_t l = lg + (lane & (BS_G - 1));
+        l = l < 0 ? 0 : (l < L ? l : L - 1);
+        return ldg(E + l);
+    };
+
+    float s = 0.f;
+    int slot = 0;                                                     // ring row of the oldest distance = the next one written
+    const int sym = lane & (BS_G - 1), quarter = lane >> 4;
+    Cx<float> xnext = load_group(lstart);
+    auto run = [&](auto KIND) {
+    for (int g = 0; g < ngroups; g++) {
+        const int64_t lg = lstart + (int64_t)g * BS_G;
+        const Cx<float> xg = xnext;
+        if (g + 1 < ngroups) xnext = load_group(lg + BS_G);
+        if (g > 0 && (g % BS_REANCHOR) == 0) {                        // direct 2N-term sum, oldest to newest
+            float t = 0.f;
+            int r = slot;
+            for (int k = 0; k < W; k++) { t += ring[r * 64 + lane]; r = r + 1 == W ? 0 : r + 1; }
+            s = t;
+        }
+        auto rows = [&](auto EDGE) {
+#pragma unroll
+            for (int k = 0; k < BS_G; k++) {
+                const float xr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xg.re), k));
+                const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xg.im), k));
+                const float tr = fma_(xr, cs, -(xi * sn));
+                const float ti = fma_(xr, sn, xi * cs);
+                float d = distance(tr, ti, KIND);
+                if (decltype(EDGE)::value && (lg + k < 0 || lg + k >= L)) d = 0.f;   // rows outside the capture only feed outputs that are forced to 0
+                float *cell = ring + slot * 64 + lane;
+                const float old = *cell;
+                *cell = d;
+                s += d;
+                s -= old;
+                slot = slot + 1 == W ? 0 : slot + 1;
+                tb[k * BS_TP + lane] = s + bias;
+            }
+        };
+        if (lg >= 0 && lg + BS_G <= L) rows(BsKind<0>{}); else rows(BsKind<1>{});        // wave-uniform
+        __syncthreads();
+        // ---- first arg-min over the angles for the 16 symbols of the block (dmin starts at 1000, strict `<`, :31-41)
+        float m = 1000.f;
+        int best = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float v = tb[sym * BS_TP + quarter * 16 + k];
+            if (v < m) { m = v; best = quarter * 16 + k; }
+        }
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float m2 = __shfl_xor(m, o);
+            const int b2 = __shfl_xor(best, o);
+            if (m2 < m || (m2 == m && b2 < best)) { m = m2; best = b2; }
+        }
+        const int64_t i = lg + sym - a.N;
+        if (quarter == 0 && i >= c0 && i < c1) idx[i] = (i >= a.N && i < L - a.N) ? best : 0;
+        __syncthreads();
+    }
+    };
+    if (symmetric) run(BsKind<0>{});                                  // wave-uniform: the loop exists once per alphabet kind
+    else if (product) run(BsKind<1>{});
+    else run(BsKind<2>{});
+}
+
 template <typename R> static int bps_tile(int A, int N, size_t *lds)
 {
     // largest T with (T + 2N - 1)*A + T*(A + 1) elements (+ the rotator table) inside the LDS budget
@@ -250,37 +434,63 @@ template <typename R> static int bps_tile(int A, int N, size_t *lds)
     return (int)T;
 }
 
+template <typename R> inline bool bps_stream_ok(int64_t, int, int, int) { return false; }
+template <> inline bool bps_stream_ok<float>(int64_t p, int A, int N, int M)
+{
+    static int off = -1;
+    if (off < 0) { const char *e = getenv("QAMPY_HIP_BPS"); off = e && !strcmp(e, "tile") ? 1 : 0; }
+    return !off && p == 1 && A <= 64 && 2 * N <= BS_MAXRING && M >= 1;
+}
+
+// nm rows of length L (consecutive in memory) against one angle grid; idx likewise
 template <typename R>
-int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, const void *symbols, int M, int N, int32_t *idx)
+int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, const void *symbols, int M, int N, int32_t *idx, int nm = 1)
 {
     int rc = ensure_init();
     if (rc) return rc;
-    QH_REQUIRE(L >= 0 && A >= 1 && M >= 1 && N >= 1, "bps: bad sizes");
+    QH_REQUIRE(L >= 0 && A >= 1 && M >= 1 && N >= 1 && nm >= 1, "bps: bad sizes");
     QH_REQUIRE(p == 1 || p == L, "bps: p must be either 1 or the length of the input signal");
+    QH_REQUIRE(p == 1 || nm == 1, "bps: a per-symbol angle grid goes with a single row");
     if (L == 0) return QH_OK;
-    size_t lds = 0;
-    const int T = bps_tile<R>(A, N, &lds);
-    QH_REQUIRE(T >= 8, "bps: averaging window 2N x test angles does not fit the LDS tile");
     void *desc = nullptr;
     if ((rc = scratch(3, sizeof(AlphabetDesc<R>), &desc))) return rc;
     hipLaunchKernelGGL((analyse_alphabet_kernel<R>), dim3(1), dim3(64), 0, g_stream, (const Cx<R> *)symbols, M, (AlphabetDesc<R> *)desc);
-    BpsArgs<R> a;
-    a.E = (const Cx<R> *)E; a.angles = (const R *)angles; a.symbols = (const Cx<R> *)symbols; a.idx = idx;
-    a.desc = (const AlphabetDesc<R> *)desc;
-    a.L = L; a.p = p; a.A = A; a.M = M; a.N = N; a.T = T;
-    // run length of the sliding window sums: enough runs to keep every thread busy, at least 8 symbols each
-    int run = (int)(((int64_t)T * A + BPS_THREADS - 1) / BPS_THREADS);
-    if (run < 8) run = 8;
-    if (run > T) run = T;
-    a.RUN = run;
+    if (bps_stream_ok<R>(p, A, N, M)) {
+        BpsStreamArgs s;
+        s.E = (const Cx<float> *)E; s.angles = (const float *)angles; s.symbols = (const Cx<float> *)symbols;
+        s.desc = (const AlphabetDesc<float> *)desc; s.idx = idx; s.L = L; s.A = A; s.M = M; s.N = N;
+        s.alpha_lds = M <= 1024 ? 1 : 0;
+        int C = 1024;                                            // longer chunks: less halo (2N - 1 rows each); shorter: more waves
+        while (C > 128 && ((L + C - 1) / C) * nm < 4096) C /= 2;
+        s.C = C;
+        const size_t lds = ((size_t)2 * N * 64 + BS_G * BS_TP + 1 + 2 * BPS_MAX_LEVELS + 1) * sizeof(float) + (s.alpha_lds ? (size_t)M * sizeof(Cx<float>) : 0) + 16;
+        static bool sattr = false;
+        if (!sattr) { QH_HIP(hipFuncSetAttribute((const void *)bps_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); sattr = true; }
+        hipLaunchKernelGGL(bps_stream_kernel, dim3((unsigned)((L + C - 1) / C), nm), dim3(64), lds, g_stream, s);
+        QH_HIP(hipGetLastError());
+        return QH_OK;
+    }
+    size_t lds = 0;
+    const int T = bps_tile<R>(A, N, &lds);
+    QH_REQUIRE(T >= 8, "bps: averaging window 2N x test angles does not fit the LDS tile");
     static bool attr_set = false;
     if (!attr_set) {
         QH_HIP(hipFuncSetAttribute((const void *)bps_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BPS_LDS_BUDGET));
         QH_HIP(hipFuncSetAttribute((const void *)bps_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BPS_LDS_BUDGET));
         attr_set = true;
     }
-    const unsigned nblk = (unsigned)((L + T - 1) / T);
-    hipLaunchKernelGGL((bps_kernel<R>), dim3(nblk), dim3(BPS_THREADS), lds, g_stream, a);
+    // run length of the sliding window sums: enough runs to keep every thread busy, at least 8 symbols each
+    int run = (int)(((int64_t)T * A + BPS_THREADS - 1) / BPS_THREADS);
+    if (run < 8) run = 8;
+    if (run > T) run = T;
+    for (int m = 0; m < nm; m++) {
+        BpsArgs<R> a;
+        a.E = (const Cx<R> *)E + (size_t)m * L; a.angles = (const R *)angles; a.symbols = (const Cx<R> *)symbols; a.idx = idx + (size_t)m * L;
+        a.desc = (const AlphabetDesc<R> *)desc;
+        a.L = L; a.p = p; a.A = A; a.M = M; a.N = N; a.T = T; a.RUN = run;
+        const unsigned nblk = (unsigned)((L + T - 1) / T);
+        hipLaunchKernelGGL((bps_kernel<R>), dim3(nblk), dim3(BPS_THREADS), lds, g_stream, a);
+    }
     QH_HIP(hipGetLastError());
     return QH_OK;
 }
@@ -449,8 +659,7 @@ int bps_recover_dev(const void *E, int nm, int64_t L, const void *angles, int A,
         if ((rc = scratch(0, (size_t)A * sizeof(R), &dang))) return rc;
         hipLaunchKernelGGL((linspace_kernel<R>), dim3((A + 63) / 64), dim3(64), 0, g_stream, (R *)dang, A);
     }
-    for (int m = 0; m < nm; m++)
-        if ((rc = bps_dev<R>((const Cx<R> *)E + (size_t)m * L, L, dang, 1, A, symbols, M, N, idx + (size_t)m * L))) return rc;
+    if ((rc = bps_dev<R>(E, L, dang, 1, A, symbols, M, N, idx, nm))) return rc;
     hipLaunchKernelGGL((unwrap_partial_kernel<R>), dim3((unsigned)nchunk, nm), dim3(UW_THREADS), 0, g_stream, idx, L, N, (const R *)dang,
                        (int *)dchunk, nchunk);
     hipLaunchKernelGGL(unwrap_scan_kernel, dim3(nm), dim3(64), 0, g_stream, (int *)dchunk, nchunk);

@@ -7,7 +7,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 mkdir -p build
 pids=()
 for f in api train_f32 train_f64 apply bps ser synth; do
-    if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ train_impl.h -nt build/$f.o ] || [ train_la.h -nt build/$f.o ] || [ train_bi.h -nt build/$f.o ] || [ train_pit.h -nt build/$f.o ] || [ ../../include/qampy_hip.h -nt build/$f.o ]; then
+    if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ train_impl.h -nt build/$f.o ] || [ train_la.h -nt build/$f.o ] || [ train_bi.h -nt build/$f.o ] || [ train_pit.h -nt build/$f.o ] || [ train_seg.h -nt build/$f.o ] || [ ../../include/qampy_hip.h -nt build/$f.o ]; then
         $HIPCC $FLAGS "$@" -c $f.hip -o build/$f.o &
         pids+=($!)
     fi

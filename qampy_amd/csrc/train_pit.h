@@ -138,32 +138,46 @@ template <typename R> __global__ void pit_acq_finish_kernel(Cx<R> *wx, const Cx<
     if (c->diverged && i < n) wx[i] = w_start[i];
 }
 
-// z[s, j] = sum over the head of segment s of (w[mode_j] . x_i)^4
+// z[s, j] = sum over the head of segment s of (w[mode_j] . x_i)^4.  The head's samples are staged in LDS once, split into the
+// `os` sampling phases (plane r holds x[j os + r]), so that for a fixed tap the lanes - consecutive outputs - read consecutive
+// words; the taps are broadcast reads.  (The former version fetched every operand of every product from global memory: 2 x the
+// time of the full-capture filter for half its outputs.)
+inline size_t pit_phase_pitch(int ntaps, int os, int nwin) { return (size_t)nwin + (size_t)(ntaps + os - 1) / os + 1; }
 template <typename R>
 __global__ void __launch_bounds__(256) pit_phase_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, const Cx<R> *wx, int ntaps, PitSeg sg,
                                                         const int64_t *modes_dev, int nwin, double *z)
 {
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     Cx<R> *w = reinterpret_cast<Cx<R> *>(pit_smem);
+    const int ntot = nmodes * ntaps;
+    const int pitch = nwin + (ntaps + os - 1) / os + 1;
+    Cx<R> *xs = w + ntot;                                         // [nmodes][os][pitch]
     __shared__ double rr[256], ri[256];
     const int s = blockIdx.x, j = blockIdx.y;
     const int mode = (int)modes_dev[j];
-    const int ntot = nmodes * ntaps;
     for (int f = threadIdx.x; f < ntot; f += 256) w[f] = wx[(size_t)mode * ntot + f];
-    __syncthreads();
     const int64_t st = sg.start(s);
     int64_t n = sg.steps(s);
     if (n > nwin) n = nwin;
+    const int ns = n > 0 ? (int)(n - 1) * os + ntaps : 0;         // samples of the head per input mode
+    for (int k = 0; k < nmodes; k++) {
+        const Cx<R> *x = E + (size_t)k * L + st * os;
+        for (int g = threadIdx.x; g < ns; g += 256) xs[((size_t)k * os + g % os) * pitch + g / os] = x[g];
+    }
+    __syncthreads();
     double zr = 0, zi = 0;
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
+    for (int i = threadIdx.x; i < n; i += 256) {
         R yr = 0, yi = 0;
         for (int k = 0; k < nmodes; k++) {
-            const Cx<R> *x = E + (size_t)k * L + (st + i) * os;
             const Cx<R> *wk = w + k * ntaps;
-            for (int t = 0; t < ntaps; t++) {
-                const Cx<R> a = x[t], b = wk[t];
-                yr = fma_(a.re, b.re, fma_(-a.im, b.im, yr));
-                yi = fma_(a.re, b.im, fma_(a.im, b.re, yi));
+            for (int r = 0; r < os; r++) {
+                const Cx<R> *xp = xs + ((size_t)k * os + r) * pitch + i;
+                int u = 0;
+                for (int t = r; t < ntaps; t += os, u++) {
+                    const Cx<R> a = xp[u], b = wk[t];
+                    yr = fma_(a.re, b.re, fma_(-a.im, b.im, yr));
+                    yi = fma_(a.re, b.im, fma_(a.im, b.re, yi));
+                }
             }
         }
         const double y2r = (double)yr * yr - (double)yi * yi, y2i = 2.0 * yr * yi;
@@ -351,7 +365,7 @@ __device__ __forceinline__ Z zmul(Z a, Z b) { return Z{a.x * b.x - a.y * b.y, a.
 
 // Rc[f][f'] = sum over a subsample of the training windows of conj(x_i[f]) x_i[f'],  x_i[f = k ntaps + t] = E[k, i os + t].
 // Block b stages PIT_COVW windows in LDS and writes its partial sums to part[b]; pit_cov_reduce_kernel adds the blocks up.
-constexpr int PIT_COVW = 64, PIT_COVB = 128;                       // windows per block, blocks
+constexpr int PIT_COVW = 32, PIT_COVB = 256;                       // windows per block, blocks (one per CU: the eigensolver waits for this)
 template <typename R, int EPT>
 __global__ void __launch_bounds__(256) pit_cov_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, int nwin, Z *part)
 {
@@ -382,29 +396,36 @@ __global__ void __launch_bounds__(256) pit_cov_kernel(const Cx<R> *E, int nmodes
         part[(size_t)blockIdx.x * nent + e] = Z{(double)ar, (double)ai};
     }
 }
+// 64 entries per block, 4 threads per entry (each a quarter of the partial sums, loads unrolled so that they overlap)
 static __global__ void __launch_bounds__(256) pit_cov_reduce_kernel(const Z *part, int nent, int nblk, Z *Rc)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= nent) return;
+    __shared__ double sr[256], si[256];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     double ar = 0, ai = 0;
-    for (int b = 0; b < nblk; b++) { const Z v = part[(size_t)b * nent + e]; ar += v.x; ai += v.y; }
-    Rc[e] = Z{ar, ai};
+    if (e < nent) {
+#pragma unroll 16
+        for (int b = grp; b < nblk; b += 4) { const Z v = part[(size_t)b * nent + e]; ar += v.x; ai += v.y; }
+    }
+    sr[threadIdx.x] = ar; si[threadIdx.x] = ai;
+    __syncthreads();
+    if (grp == 0 && e < nent) {
+        const int t = threadIdx.x;
+        Rc[e] = Z{(sr[t] + sr[t + 64]) + (sr[t + 128] + sr[t + 192]), (si[t] + si[t + 64]) + (si[t + 128] + si[t + 192])};
+    }
 }
 
 // Eigenbasis of the covariance: cyclic Jacobi (parallel round-robin ordering, n/2 disjoint rotations per round) on the
 // Hermitian matrix Rc / nwin, whole problem in the LDS of ONE workgroup, single precision (the basis only preconditions the
 // relaxation).  Out: lam[n] eigenvalues, V[i][k] = component i of eigenvector k.  n <= PIT_EIGMAX.
 typedef float2 Zf;
-constexpr int PIT_EIGMAX = 96, PIT_EIGSWEEPS = 5;        // 5 sweeps: off-diagonal norm 2e-3, smallest eigenvalues good to 2 % - a preconditioner
+constexpr int PIT_EIGMAX = 96, PIT_EIGSWEEPS = 5;        // 5 sweeps: off-diagonal norm 2e-3, smallest eigenvalues good to 2 % - a preconditioner (3 sweeps: twice the passes on some captures)
 __device__ __forceinline__ Zf cmulf(Zf a, Zf b) { return Zf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, int n, double norm, double *lam, Zf *Vout)
+static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, int n, double norm, double *lam, Zf *Vout, int nsweep)
 {
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     const int ld = n + 1;
     Zf *A = reinterpret_cast<Zf *>(pit_smem);                 // [n][ld]
     Zf *V = A + (size_t)n * ld;                               // [n][ld]
-    float4 *rot = reinterpret_cast<float4 *>(V + (size_t)n * ld);   // [npair]: c, s, e.re, e.im
-    int2 *pq = reinterpret_cast<int2 *>(rot + (PIT_EIGMAX + 2) / 2);   // [npair]: the pair's indices, p < q (q >= n: idle)
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     for (int i = wave; i < n; i += 16)
@@ -416,68 +437,81 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
     __syncthreads();
     const int m = (n + 1) & ~1;                               // players of the round-robin (a dummy when n is odd)
     const int npair = m / 2;
-    for (int sweep = 0; sweep < PIT_EIGSWEEPS; sweep++) {
+    constexpr int NP = (PIT_EIGMAX / 2 + 15) / 16, NR = (PIT_EIGMAX + 63) / 64;
+    for (int sweep = 0; sweep < nsweep; sweep++) {
         for (int r = 0; r < m - 1; r++) {
-            if (tid < npair) {
-                // pair `tid` of round r (circle method): player m-1 stays, the others rotate
-                int a, b;
-                if (tid == 0) { a = m - 1; b = r; }
+            // A wave owns pairs wave, wave + 16, ... of the round (circle method: player m-1 stays, the others rotate) in BOTH
+            // phases, so it works out their rotations itself (one lane per pair, broadcast) instead of waiting for a few threads
+            // to do it for the whole workgroup behind one more barrier.
+            int2 ixs[NP];
+            float4 gs[NP];
+            auto pair_of = [&](int i) -> int2 {
+                int pa, pb;
+                if (i == 0) { pa = m - 1; pb = r; }
                 else {
-                    a = r + tid; if (a >= m - 1) a -= m - 1;
-                    b = r - tid; if (b < 0) b += m - 1;
+                    pa = r + i; if (pa >= m - 1) pa -= m - 1;
+                    pb = r - i; if (pb < 0) pb += m - 1;
                 }
-                const int p = a < b ? a : b, q = a < b ? b : a;
-                float4 g = {1.f, 0.f, 1.f, 0.f};
-                if (q < n) {
-                    const Zf apq = A[p * ld + q];
-                    const float app = A[p * ld + p].x, aqq = A[q * ld + q].x;
-                    const float mag = sqrtf(apq.x * apq.x + apq.y * apq.y);
-                    if (mag > 1e-30f) {
-                        const float tau = (aqq - app) / (2.f * mag);
-                        const float t = (tau >= 0 ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
-                        const float c = 1.f / sqrtf(1.f + t * t);
-                        g = float4{c, t * c, apq.x / mag, apq.y / mag};
+                const int p = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
+                return (i < npair && q < n) ? int2{p, q} : int2{0, n};
+            };
+            float4 gl = {1.f, 0.f, 1.f, 0.f};                     // lane a < NP works out the rotation of the wave's pair a
+            {
+                const int2 ix = pair_of(wave + 16 * (lane < NP ? lane : 0));
+                if (lane < NP && ix.y < n) {
+                    const Zf apq = A[ix.x * ld + ix.y];
+                    const float app = A[ix.x * ld + ix.x].x, aqq = A[ix.y * ld + ix.y].x;
+                    const float m2 = apq.x * apq.x + apq.y * apq.y;
+                    if (m2 > 1e-36f) {                                // hardware reciprocals (1 ulp): the basis is a preconditioner
+                        const float rmag = __builtin_amdgcn_rsqf(m2);
+                        const float tau = (aqq - app) * 0.5f * rmag;
+                        const float t = (tau >= 0 ? 1.f : -1.f) * __builtin_amdgcn_rcpf(fabsf(tau) + __builtin_amdgcn_sqrtf(1.f + tau * tau));
+                        const float c = __builtin_amdgcn_rsqf(1.f + t * t);
+                        gl = float4{c, t * c, apq.x * rmag, apq.y * rmag};
                     }
                 }
-                rot[tid] = g;
-                pq[tid] = int2{p, q};
             }
-            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < NP; a++) {
+                ixs[a] = pair_of(wave + 16 * a);
+                gs[a] = float4{__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl.x), a)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl.y), a)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl.z), a)),
+                               __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl.w), a))};
+            }
+            // (no barrier here: the pivots of a pair sit in its own rows / columns, which only its own wave rotates)
             // columns p, q of A and V:  col_p' = c col_p - s conj(e) col_q ;  col_q' = s col_p + c conj(e) col_q
             // (a thread's items - up to 3 pairs x 2 rows x 2 matrices - are all read before any is rotated: one LDS latency)
             {
-                constexpr int NP = (PIT_EIGMAX / 2 + 15) / 16, NR = (PIT_EIGMAX + 63) / 64;
                 Zf xp[NP][NR][2], xq[NP][NR][2];
 #pragma unroll
                 for (int a = 0; a < NP; a++) {
-                    const int i = wave + 16 * a;
-                    const int2 ix = i < npair ? pq[i] : int2{0, n};
+                    const int2 ix = ixs[a];
+                    if (ix.y >= n) continue;                      // wave-uniform
 #pragma unroll
                     for (int b = 0; b < NR; b++) {
-                        const int row = lane + 64 * b;
-                        if (ix.y < n && row < n) {
-                            xp[a][b][0] = A[row * ld + ix.x]; xq[a][b][0] = A[row * ld + ix.y];
-                            xp[a][b][1] = V[row * ld + ix.x]; xq[a][b][1] = V[row * ld + ix.y];
-                        }
+                        if (64 * b >= n) continue;                    // wave-uniform; lanes past the last row redo row n-1 (same inputs, same result)
+                        const int row = lane + 64 * b < n ? lane + 64 * b : n - 1;
+                        xp[a][b][0] = A[row * ld + ix.x]; xq[a][b][0] = A[row * ld + ix.y];
+                        xp[a][b][1] = V[row * ld + ix.x]; xq[a][b][1] = V[row * ld + ix.y];
                     }
                 }
 #pragma unroll
                 for (int a = 0; a < NP; a++) {
-                    const int i = wave + 16 * a;
-                    const int2 ix = i < npair ? pq[i] : int2{0, n};
-                    const float4 g = i < npair ? rot[i] : float4{1.f, 0.f, 1.f, 0.f};
+                    const int2 ix = ixs[a];
+                    const float4 g = gs[a];
+                    if (ix.y >= n) continue;
 #pragma unroll
                     for (int b = 0; b < NR; b++) {
-                        const int row = lane + 64 * b;
-                        if (ix.y < n && row < n) {
+                        if (64 * b >= n) continue;
+                        const int row = lane + 64 * b < n ? lane + 64 * b : n - 1;
 #pragma unroll
-                            for (int which = 0; which < 2; which++) {
-                                Zf *Mx = which ? V : A;
-                                const Zf up = xp[a][b][which];
-                                const Zf xqe = cmulf(Zf{g.z, -g.w}, xq[a][b][which]);        // conj(e) x_q
-                                Mx[row * ld + ix.x] = Zf{g.x * up.x - g.y * xqe.x, g.x * up.y - g.y * xqe.y};
-                                Mx[row * ld + ix.y] = Zf{g.y * up.x + g.x * xqe.x, g.y * up.y + g.x * xqe.y};
-                            }
+                        for (int which = 0; which < 2; which++) {
+                            Zf *Mx = which ? V : A;
+                            const Zf up = xp[a][b][which];
+                            const Zf xqe = cmulf(Zf{g.z, -g.w}, xq[a][b][which]);        // conj(e) x_q
+                            Mx[row * ld + ix.x] = Zf{g.x * up.x - g.y * xqe.x, g.x * up.y - g.y * xqe.y};
+                            Mx[row * ld + ix.y] = Zf{g.y * up.x + g.x * xqe.x, g.y * up.y + g.x * xqe.y};
                         }
                     }
                 }
@@ -485,32 +519,31 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
             __syncthreads();
             // rows p, q of A:  row_p' = c row_p - s e row_q ;  row_q' = s row_p + c e row_q
             {
-                constexpr int NP = (PIT_EIGMAX / 2 + 15) / 16, NR = (PIT_EIGMAX + 63) / 64;
                 Zf xp[NP][NR], xq[NP][NR];
 #pragma unroll
                 for (int a = 0; a < NP; a++) {
-                    const int i = wave + 16 * a;
-                    const int2 ix = i < npair ? pq[i] : int2{0, n};
+                    const int2 ix = ixs[a];
+                    if (ix.y >= n) continue;
 #pragma unroll
                     for (int b = 0; b < NR; b++) {
-                        const int col = lane + 64 * b;
-                        if (ix.y < n && col < n) { xp[a][b] = A[ix.x * ld + col]; xq[a][b] = A[ix.y * ld + col]; }
+                        if (64 * b >= n) continue;
+                        const int col = lane + 64 * b < n ? lane + 64 * b : n - 1;
+                        xp[a][b] = A[ix.x * ld + col]; xq[a][b] = A[ix.y * ld + col];
                     }
                 }
 #pragma unroll
                 for (int a = 0; a < NP; a++) {
-                    const int i = wave + 16 * a;
-                    const int2 ix = i < npair ? pq[i] : int2{0, n};
-                    const float4 g = i < npair ? rot[i] : float4{1.f, 0.f, 1.f, 0.f};
+                    const int2 ix = ixs[a];
+                    const float4 g = gs[a];
+                    if (ix.y >= n) continue;
 #pragma unroll
                     for (int b = 0; b < NR; b++) {
-                        const int col = lane + 64 * b;
-                        if (ix.y < n && col < n) {
-                            const Zf up = xp[a][b];
-                            const Zf xqe = cmulf(Zf{g.z, g.w}, xq[a][b]);
-                            A[ix.x * ld + col] = Zf{g.x * up.x - g.y * xqe.x, g.x * up.y - g.y * xqe.y};
-                            A[ix.y * ld + col] = Zf{g.y * up.x + g.x * xqe.x, g.y * up.y + g.x * xqe.y};
-                        }
+                        if (64 * b >= n) continue;
+                        const int col = lane + 64 * b < n ? lane + 64 * b : n - 1;
+                        const Zf up = xp[a][b];
+                        const Zf xqe = cmulf(Zf{g.z, g.w}, xq[a][b]);
+                        A[ix.x * ld + col] = Zf{g.x * up.x - g.y * xqe.x, g.x * up.y - g.y * xqe.y};
+                        A[ix.y * ld + col] = Zf{g.y * up.x + g.x * xqe.x, g.y * up.y + g.x * xqe.y};
                     }
                 }
             }
@@ -687,11 +720,20 @@ __global__ void __launch_bounds__(128) pit_dapply_kernel(Cx<R> *X, Cx<R> *Y, int
 // kernel time of the most recent call (HIP events around the trainer launches; the host synchronises after each anyway)
 struct PitTiming { int npass; float pass_ms[QH_PIT_MAXPASS]; float acq_ms; };
 inline PitTiming &pit_timing() { static PitTiming t; return t; }
-inline hipEvent_t *pit_events()
+// Events and a pinned landing area for the flags the host reads: one set per pass / acquisition chunk, because the work of
+// pass p + 1 is enqueued BEFORE the host looks at the flag of pass p (every kernel of a pass starts with `if (done) return`,
+// so a pass enqueued in vain costs a few empty launches instead of an idle GPU during every host round trip).
+constexpr int PIT_NEV = (QH_PIT_MAXPASS > QH_PIT_MAXCHUNK ? QH_PIT_MAXPASS : QH_PIT_MAXCHUNK) + 1;
+struct PitEvents { hipEvent_t t0[PIT_NEV], t1[PIT_NEV], flag[PIT_NEV]; int32_t *hflag; bool ok; };
+inline PitEvents &pit_events()
 {
-    static hipEvent_t ev[2] = {nullptr, nullptr};
-    if (!ev[0]) { (void)hipEventCreate(&ev[0]); (void)hipEventCreate(&ev[1]); }
-    return ev;
+    static PitEvents e = {{nullptr}, {nullptr}, {nullptr}, nullptr, false};
+    if (!e.ok) {
+        for (int i = 0; i < PIT_NEV; i++) { (void)hipEventCreate(&e.t0[i]); (void)hipEventCreate(&e.t1[i]); (void)hipEventCreateWithFlags(&e.flag[i], hipEventDisableTiming); }
+        (void)hipHostMalloc((void **)&e.hflag, PIT_NEV * sizeof(int32_t), hipHostMallocDefault);
+        e.ok = e.hflag != nullptr;
+    }
+    return e;
 }
 
 // Automatic segment grid.  A segment should be a fraction of the time constant 1/(mu g lambda) of the well-excited tap
@@ -747,12 +789,14 @@ int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t T
     if (ept <= 8) hipLaunchKernelGGL((pit_cov_kernel<R, 8>), dim3(PIT_COVB), dim3(256), lds, st, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
     else if (ept <= 32) hipLaunchKernelGGL((pit_cov_kernel<R, 32>), dim3(PIT_COVB), dim3(256), lds, st, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
     else hipLaunchKernelGGL((pit_cov_kernel<R, 64>), dim3(PIT_COVB), dim3(256), lds, st, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
-    hipLaunchKernelGGL(pit_cov_reduce_kernel, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, st, (const Z *)part, (int)msz, PIT_COVB, Rc);
+    hipLaunchKernelGGL(pit_cov_reduce_kernel, dim3((unsigned)((msz + 63) / 64)), dim3(256), 0, st, (const Z *)part, (int)msz, PIT_COVB, Rc);
     static bool attr_set = false;
     const size_t jlds = 2 * (size_t)ntot * (ntot + 1) * sizeof(Zf) + (size_t)((PIT_EIGMAX + 2) / 2) * (sizeof(float4) + sizeof(int2));
     if (!attr_set) { QH_HIP(hipFuncSetAttribute((const void *)pit_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); attr_set = true; }
+    static int nsweep = 0;
+    if (!nsweep) { const char *e = getenv("QAMPY_HIP_PIT_EIGSWEEPS"); nsweep = e && atoi(e) > 0 ? atoi(e) : PIT_EIGSWEEPS; }
     hipLaunchKernelGGL(pit_jacobi_kernel, dim3(1), dim3(1024), jlds, st, (const Z *)Rc, ntot, 1.0 / (double)ncov, (double *)basis,
-                       (Zf *)((char *)basis + (size_t)ntot * sizeof(double)));
+                       (Zf *)((char *)basis + (size_t)ntot * sizeof(double)), nsweep);
     QH_HIP(hipGetLastError());
     if (overlap) { QH_HIP(hipEventRecord(bs.out, st)); bs.pending = true; }
     return QH_OK;
@@ -792,16 +836,6 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     if ((rc = scratch(8, sizeof(PitCtrl) + 64, &cbuf))) return rc;
     PitCtrl *ctrl = report_dev ? (PitCtrl *)report_dev : (PitCtrl *)cbuf;
     R *mu_acq = (R *)((char *)cbuf + sizeof(PitCtrl));            // 8-byte aligned: sizeof(PitCtrl) is a multiple of 8
-
-    // the device decides (error plateau, boundary defect); the host reads the flag after each chunk / pass instead of
-    // enqueueing work that would only be skipped
-    auto poll = [&](const int32_t *flag, int *val) -> int {
-        int32_t v = 0;
-        QH_HIP(hipMemcpyAsync(&v, flag, sizeof(v), hipMemcpyDeviceToHost, g_stream));
-        QH_HIP(hipStreamSynchronize(g_stream));
-        *val = v;
-        return QH_OK;
-    };
 
     // ---- segment grid
     int S = o.segments;
@@ -932,7 +966,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
 
     PitTiming &tm = pit_timing();
     tm.npass = 0; tm.acq_ms = 0;
-    hipEvent_t *ev = pit_events();
+    PitEvents &ev = pit_events();
+    QH_REQUIRE(ev.ok, "train_equaliser: no pinned memory for the pass flags");
     for (int it = 0; it < Niter; it++) {
         // ================================================================ acquisition (first sweep of a cold start)
         if (it == 0 && o.acquire) {
@@ -941,25 +976,35 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             CH = (CH + LA_B - 1) / LA_B * LA_B;
             if (CH < 4 * LA_B) CH = 4 * LA_B;
             QH_HIP(hipMemcpyAsync(w_start, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
-            for (int64_t step0 = 0; step0 + CH <= amax; step0 += CH) {
-                QH_HIP(hipEventRecord(ev[0], g_stream));
+            const int nchunks = (int)(amax / CH);
+            auto enqueue_chunk = [&](int c) -> int {
+                const int64_t step0 = (int64_t)c * CH;
+                QH_HIP(hipEventRecord(ev.t0[c], g_stream));
                 if (block_form) {
                     LaArgs<R> lp = la;
                     lp.E = (const Cx<R> *)E + step0 * os; lp.L = L - step0 * os; lp.TrSyms = CH; lp.nch = 1; lp.wx = (Cx<R> *)wx; lp.wx_cs = 0;
                     lp.G = (const GramPair<R> *)G + step0 * g_per_step; lp.err_off = step0; lp.mu = mu_acq; lp.skip = &ctrl->acq_done;
-                    if ((rc = use_bi ? launch_bi<R>(lp) : launch_la<R>(lp))) return rc;
+                    int r = use_bi ? launch_bi<R>(lp) : launch_la<R>(lp);
+                    if (r) return r;
                 } else {
                     TrainArgs<R> tp = ta;
                     tp.wx = (Cx<R> *)wx; tp.mu = mu_acq; tp.nseg = 1; tp.seg_begin = step0; tp.seg_len = CH; tp.seg_iter = 0; tp.skip = &ctrl->acq_done;
-                    if ((rc = launch_any<R>(tp))) return rc;
+                    int r = launch_any<R>(tp);
+                    if (r) return r;
                 }
-                QH_HIP(hipEventRecord(ev[1], g_stream));
+                QH_HIP(hipEventRecord(ev.t1[c], g_stream));
                 hipLaunchKernelGGL((pit_acq_monitor_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const Cx<R> *)err, (int64_t)(TrSyms * Niter), step0, CH,
                                    nsel, (const int64_t *)modes_dev, plateau, ctrl);
-                int fin = 0;
-                if ((rc = poll(&ctrl->acq_done, &fin))) return rc;
-                { float ms = 0; QH_HIP(hipEventElapsedTime(&ms, ev[0], ev[1])); tm.acq_ms += ms; }
-                if (fin) break;
+                QH_HIP(hipMemcpyAsync(&ev.hflag[c], &ctrl->acq_done, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
+                QH_HIP(hipEventRecord(ev.flag[c], g_stream));
+                return QH_OK;
+            };
+            if (nchunks > 0 && (rc = enqueue_chunk(0))) return rc;
+            for (int c = 0; c < nchunks; c++) {
+                if (c + 1 < nchunks && (rc = enqueue_chunk(c + 1))) return rc;     // skipped on the device once the plateau is reached
+                QH_HIP(hipEventSynchronize(ev.flag[c]));
+                { float ms = 0; QH_HIP(hipEventElapsedTime(&ms, ev.t0[c], ev.t1[c])); tm.acq_ms += ms; }
+                if (ev.hflag[c]) break;
             }
             hipLaunchKernelGGL((pit_acq_finish_kernel<R>), dim3((unsigned)((wset + 255) / 256)), dim3(256), 0, g_stream, (Cx<R> *)wx, (const Cx<R> *)w_start, (int)wset, ctrl);
             QH_HIP(hipGetLastError());
@@ -968,15 +1013,19 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         hipLaunchKernelGGL(pit_sweep_kernel, dim3(1), dim3(1), 0, g_stream, ctrl);
         const double *rot_use = nullptr;
         if (seed_phase) {
-            hipLaunchKernelGGL((pit_phase_kernel<R>), dim3(sg.S, nsel), dim3(256), (size_t)ntot * sizeof(Cx<R>), g_stream, (const Cx<R> *)E, nmodes, L, os,
-                               (const Cx<R> *)wx, ntaps, sg, (const int64_t *)modes_dev, PIT_SEEDWIN, z);
+            int nwin = PIT_SEEDWIN;                                   // head staged in LDS: shortened until it fits the default 64 KiB
+            auto phase_lds = [&](int nw) { return ((size_t)ntot + (size_t)nmodes * os * pit_phase_pitch(ntaps, os, nw)) * sizeof(Cx<R>); };
+            while (nwin > 32 && phase_lds(nwin) > 60 * 1024) nwin /= 2;
+            QH_REQUIRE(phase_lds(nwin) <= 60 * 1024, "train_equaliser: phase seeding does not fit the LDS for this filter shape (pass phase_seed = 0)");
+            hipLaunchKernelGGL((pit_phase_kernel<R>), dim3(sg.S, nsel), dim3(256), phase_lds(nwin), g_stream, (const Cx<R> *)E, nmodes, L, os,
+                               (const Cx<R> *)wx, ntaps, sg, (const int64_t *)modes_dev, nwin, z);
             hipLaunchKernelGGL(pit_unwrap_kernel, dim3(1), dim3(256), (size_t)sg.S * (sizeof(double) + sizeof(int)), g_stream, (const double *)z, sg.S, nsel, rot);
             rot_use = rot;
         }
         hipLaunchKernelGGL((pit_seed_kernel<R>), dim3(sg.S), dim3(256), 0, g_stream, (const Cx<R> *)wx, nmodes, ntot, (const int64_t *)modes_dev, nsel, rot_use, X);
         QH_HIP(hipGetLastError());
         // ================================================================ relaxation passes
-        for (int p = 0; p < npass; p++) {
+        auto enqueue_pass = [&](int p) -> int {
             if (p > 0 && want_corr) {
                 // start taps += D,  D[s+1] = d[s+1] + J D[s]  (d = boundary defects): a parallel scan over the segments.  With the
                 // correction switched off on the device (corr_on = 0) the products are skipped and D = d: plain relaxation.
@@ -999,7 +1048,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             } else {
                 QH_HIP(hipMemcpyAsync(Y, X, (size_t)sg.S * wbytes, hipMemcpyDeviceToDevice, g_stream));
             }
-            QH_HIP(hipEventRecord(ev[0], g_stream));
+            QH_HIP(hipEventRecord(ev.t0[p], g_stream));
             if (seg_form) {
                 SegArgs<R> sa;
                 sa.E = (const Cx<R> *)E; sa.wx = Y; sa.symbols = la.symbols; sa.err = (Cx<R> *)err; sa.mu = mu_dev;
@@ -1008,28 +1057,34 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 sa.seg_len = sg.len; sa.seg_extra = sg.extra; sa.seg_tail = sg.tail; sa.seg_begin = 0;
                 for (int j = 0; j < 16; j++) sa.modes[j] = j < nsel ? modes[j] : 0;
                 sa.skip = &ctrl->done;
-                if ((rc = launch_seg<R>(sa, method))) return rc;
+                { int r = launch_seg<R>(sa, method); if (r) return r; }
             } else if (block_form) {
                 LaArgs<R> ls = la;
                 ls.TrSyms = sg.len; ls.nch = sg.S; ls.wx = Y; ls.err_off = (int64_t)it * TrSyms; ls.seg = 1; ls.seg_extra = sg.extra; ls.seg_tail = sg.tail;
                 ls.skip = &ctrl->done;
-                if ((rc = use_bi ? launch_bi<R>(ls) : launch_la<R>(ls))) return rc;
+                { int r = use_bi ? launch_bi<R>(ls) : launch_la<R>(ls); if (r) return r; }
             } else {
                 TrainArgs<R> ts = ta;
                 ts.wx = Y; ts.nseg = sg.S; ts.seg_begin = 0; ts.seg_len = sg.len; ts.seg_extra = sg.extra; ts.seg_tail = sg.tail; ts.seg_iter = it; ts.skip = &ctrl->done;
-                if ((rc = launch_any<R>(ts))) return rc;
+                { int r = launch_any<R>(ts); if (r) return r; }
             }
-            QH_HIP(hipEventRecord(ev[1], g_stream));
+            QH_HIP(hipEventRecord(ev.t1[p], g_stream));
             hipLaunchKernelGGL((pit_defect_kernel<R>), dim3(sg.S - 1, nsel), dim3(PIT_PROBE), 2 * (size_t)ntot * sizeof(Cx<R>), g_stream, (const Cx<R> *)E, nmodes, L, os,
                                ntaps, sg, TrSyms, (const int64_t *)modes_dev, (const Cx<R> *)X, (const Cx<R> *)Y, sym, (const PitCtrl *)ctrl, dfc, pw, gph);
             hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, (int)((sg.S - 1) * nsel),
                                (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, method,
                                (const Cx<R> *)symbols + (size_t)modes[0] * nsy, want_corr ? 1 : 0, ctrl);
             QH_HIP(hipGetLastError());
-            int fin = 0;
-            if ((rc = poll(&ctrl->done, &fin))) return rc;
-            if (tm.npass < QH_PIT_MAXPASS) { float ms = 0; QH_HIP(hipEventElapsedTime(&ms, ev[0], ev[1])); tm.pass_ms[tm.npass++] = ms; }
-            if (fin) break;
+            QH_HIP(hipMemcpyAsync(&ev.hflag[p], &ctrl->done, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
+            QH_HIP(hipEventRecord(ev.flag[p], g_stream));
+            return QH_OK;
+        };
+        if ((rc = enqueue_pass(0))) return rc;
+        for (int p = 0; p < npass; p++) {
+            if (p + 1 < npass && (rc = enqueue_pass(p + 1))) return rc;          // skipped on the device if pass p converges
+            QH_HIP(hipEventSynchronize(ev.flag[p]));
+            if (tm.npass < QH_PIT_MAXPASS) { float ms = 0; QH_HIP(hipEventElapsedTime(&ms, ev.t0[p], ev.t1[p])); tm.pass_ms[tm.npass++] = ms; }
+            if (ev.hflag[p]) break;
         }
     }
     return QH_OK;

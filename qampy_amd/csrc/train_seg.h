@@ -51,7 +51,6 @@ __device__ __forceinline__ void row16_csum(float &re, float &im)
         "s_nop 0\n\t"
         "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
         : "+v"(re), "+v"(im));
 }
 __device__ __forceinline__ void row16_csum(double &re, double &im)
@@ -61,6 +60,34 @@ __device__ __forceinline__ void row16_csum(double &re, double &im)
     re += dpp_mov<DPP_ROW_HALF_MIRROR>(re); im += dpp_mov<DPP_ROW_HALF_MIRROR>(im);
     re += dpp_mov<DPP_ROW_MIRROR>(re);      im += dpp_mov<DPP_ROW_MIRROR>(im);
 }
+
+// acc + x.re * (b.re, b.im) / acc + x.im * (b.re, b.im) / acc + x.im * (b.im, -b.re): ONE packed instruction each - the halves of
+// the operands are picked with op_sel / neg_hi instead of being copied into place (the compiler materialises the broadcasts
+// with v_mov: 24 of them per step)
+typedef float sg_f2 __attribute__((ext_vector_type(2)));
+typedef double sg_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ sg_f2 pk_re(sg_f2 x, sg_f2 b, sg_f2 acc)
+{
+    sg_f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(x), "v"(b), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ sg_f2 pk_im(sg_f2 x, sg_f2 b, sg_f2 acc)
+{
+    sg_f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(x), "v"(b), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ sg_f2 pk_im_rot(sg_f2 x, sg_f2 b, sg_f2 acc)
+{
+    sg_f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(x), "v"(b), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ sg_d2 pk_re(sg_d2 x, sg_d2 b, sg_d2 acc) { return __builtin_elementwise_fma(sg_d2{x.x, x.x}, b, acc); }
+__device__ __forceinline__ sg_d2 pk_im(sg_d2 x, sg_d2 b, sg_d2 acc) { return __builtin_elementwise_fma(sg_d2{x.y, x.y}, b, acc); }
+__device__ __forceinline__ sg_d2 pk_im_rot(sg_d2 x, sg_d2 b, sg_d2 acc) { return __builtin_elementwise_fma(sg_d2{x.y, x.y}, sg_d2{b.y, -b.x}, acc); }
+template <int N> struct SgInt { static constexpr int value = N; };
 
 constexpr int SG_PITCH = 192;      // samples per LDS row (one segment window of one input mode): 3 pieces of 64
 constexpr int SG_PIECES = SG_PITCH / 64;
@@ -94,8 +121,9 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     auto seg_steps = [&](int64_t s) { return (int)(a.seg_len + (s < a.seg_extra ? LA_B : 0) + (s == a.S - 1 ? a.seg_tail : 0)); };
     const int64_t my_start = seg_start(seg);
     const int my_steps = alive ? seg_steps(seg) : 0;
-    int max_steps = 0;
-    for (int s = seg0; s <= segl; s++) { const int n = seg_steps(s); max_steps = n > max_steps ? n : max_steps; }
+    int max_steps = 0, min_steps = 0x7fffffff;                  // over the chains of the wave (a wave with a dead chain checks every step)
+    for (int s = seg0; s <= segl; s++) { const int n = seg_steps(s); max_steps = n > max_steps ? n : max_steps; min_steps = n < min_steps ? n : min_steps; }
+    if (q0 + 3 >= nq) min_steps = 0;
 
     // ---- taps: lane <-> TPL consecutive taps of input mode kin
     const int kin = l16 / a.lpm, t0 = (l16 - kin * a.lpm) * TPL;
@@ -153,44 +181,61 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     };
     Cx<R> *errow = a.err + (size_t)mode * a.err_pitch + a.err_off + my_start;
     R ebr = 0, ebi = 0;                                        // error of step i waits in lane (i & 15) of the chain for a 16-step store
-    // padding taps (the last lane of an input mode may hold up to SG_MAXRAG): their samples are replaced by zeros, so they stay zero
-    bool padj[SG_MAXRAG];
-#pragma unroll
-    for (int r = 0; r < SG_MAXRAG; r++) padj[r] = has && (TPL - SG_MAXRAG + r >= 0) && (t0 + TPL - SG_MAXRAG + r >= a.ntaps);
-    const bool ragged = a.rag != 0;
+    // padding taps: the last lane of an input mode may hold up to SG_MAXRAG of them, in its last slots.  They start as zeros and
+    // stay zeros because that lane's update of those slots is multiplied by 0 (tailmask; 1 in every other lane).
+    const bool lastlane = has && (l16 - kin * a.lpm) == a.lpm - 1;
+    const v2 tailmask = lastlane ? v2{0, 0} : v2{1, 1};
+    const int rag = a.rag;
 
     auto load_x = [&](v2 (&x)[TPL], const Cx<R> *p) {
 #pragma unroll
         for (int j = 0; j < TPL; j++) { const Cx<R> v = p[j]; x[j] = v2{v.re, v.im}; }
     };
-    auto step = [&](v2 (&x)[TPL], int i, int gstep) {
-        if (ragged) {                                          // wave-uniform
-#pragma unroll
-            for (int r = 0; r < SG_MAXRAG; r++)
-                if (TPL - SG_MAXRAG + r >= 0 && padj[r]) x[TPL - SG_MAXRAG + r < 0 ? 0 : TPL - SG_MAXRAG + r] = v2{0, 0};
-        }
+    auto step = [&](v2 (&x)[TPL], int i, int gstep, auto CHK, auto RG) {
         // y = sum w x  (no conjugate, pythran_equalisation.py:24-31): two accumulators, combined before the reduction
         v2 p = {0, 0}, r = {0, 0};
 #pragma unroll
         for (int j = 0; j < TPL; j++) {
-            p = __builtin_elementwise_fma(v2{x[j].x, x[j].x}, w[j], p);      // x.re * (w.re, w.im)
-            r = __builtin_elementwise_fma(v2{x[j].y, x[j].y}, w[j], r);      // x.im * (w.re, w.im)
+            p = pk_re(x[j], w[j], p);                          // x.re * (w.re, w.im)
+            r = pk_im(x[j], w[j], r);                          // x.im * (w.re, w.im)
         }
         R yr = p.x - r.y, yi = p.y + r.x;
         row16_csum(yr, yi);
         const Cx<R> y{yr, yi};
         const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K);
         Cx<R> cc = la_errfn<R, METHOD, NPART, true>(y, K);     // mu * e with mu folded in
-        if (gstep >= my_steps) cc = Cx<R>{0, 0};               // past the end of this chain's segment: nothing moves
+        if (decltype(CHK)::value && gstep >= my_steps) cc = Cx<R>{0, 0};   // past the end of this chain's segment: nothing moves
         const bool mine = l16 == (i & 15);
         ebr = mine ? e.re : ebr;
         ebi = mine ? e.im : ebi;
         // w += c conj(x):  (re, im) += x.re (c.re, c.im) + x.im (c.im, -c.re)
-        const v2 c1 = {cc.re, cc.im}, c2 = {cc.im, -cc.re};
+        const v2 c1 = {cc.re, cc.im};
+        constexpr int NR = decltype(RG)::value;
+        v2 ct = c1;
+        if (NR > 0) ct = c1 * tailmask;
 #pragma unroll
-        for (int j = 0; j < TPL; j++) {
-            w[j] = __builtin_elementwise_fma(v2{x[j].x, x[j].x}, c1, w[j]);
-            w[j] = __builtin_elementwise_fma(v2{x[j].y, x[j].y}, c2, w[j]);
+        for (int j = 0; j < TPL; j++) w[j] = pk_re(x[j], j >= TPL - NR ? ct : c1, w[j]);        // two rounds: no instruction waits
+#pragma unroll
+        for (int j = 0; j < TPL; j++) w[j] = pk_im_rot(x[j], j >= TPL - NR ? ct : c1, w[j]);    // for the one right before it
+    };
+    auto run_chunk = [&](const Cx<R> *xs, int xstep, int ibase, int nst, auto CHK, auto RG) {
+        v2 xa[TPL], xb[TPL];
+        load_x(xa, xs);
+        int i = 0;
+        for (; i + 2 <= nst; i += 2) {                          // the samples of step i+1 are read while step i computes
+            load_x(xb, xs + (i + 1) * xstep);
+            step(xa, i, ibase + i, CHK, RG);
+            load_x(xa, xs + (i + 2) * xstep);                   // may look one step past the chunk: inside the row's slack
+            step(xb, i + 1, ibase + i + 1, CHK, RG);
+            if (((i + 1) & 15) == 15) {                         // 16 errors per chain staged: one store per chain
+                const int gi = ibase + i + 1 - 15 + l16;
+                if (gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
+            }
+        }
+        if (i < nst) { step(xa, i, ibase + i, CHK, RG); i++; }
+        if ((nst & 15) != 0) {                                   // ragged end of the last chunk
+            const int gi = ibase + (nst & ~15) + l16;
+            if (l16 < (nst & 15) && gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
         }
     };
 
@@ -204,23 +249,15 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         const int xstep = has ? os_ : 0;
         const int ibase = c * SG_CH;
         const int nst = (max_steps - ibase) < SG_CH ? (max_steps - ibase) : SG_CH;
-        v2 xa[TPL], xb[TPL];
-        load_x(xa, xs);
-        int i = 0;
-        for (; i + 2 <= nst; i += 2) {                          // the samples of step i+1 are read while step i computes
-            load_x(xb, xs + (i + 1) * xstep);
-            step(xa, i, ibase + i);
-            load_x(xa, xs + (i + 2) * xstep);                   // may look one step past the chunk: inside the row's slack
-            step(xb, i + 1, ibase + i + 1);
-            if (((i + 1) & 15) == 15) {                         // 16 errors per chain staged: one store per chain
-                const int gi = ibase + i + 1 - 15 + l16;
-                if (gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
-            }
-        }
-        if (i < nst) { step(xa, i, ibase + i); i++; }
-        if ((nst & 15) != 0) {                                   // ragged end of the last chunk
-            const int gi = ibase + (nst & ~15) + l16;
-            if (l16 < (nst & 15) && gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
+        auto run = [&](auto RG) {
+            if (ibase + nst <= min_steps) run_chunk(xs, xstep, ibase, nst, SgInt<0>{}, RG);
+            else run_chunk(xs, xstep, ibase, nst, SgInt<1>{}, RG);
+        };
+        switch (rag) {                                         // wave-uniform: the loops exist once per padding count
+        case 0: run(SgInt<0>{}); break;
+        case 1: run(SgInt<1>{}); break;
+        case 2: run(SgInt<(TPL > 2 ? 2 : 0)>{}); break;
+        default: run(SgInt<(TPL > 3 ? 3 : 0)>{}); break;
         }
         if (c + 1 < nchunk) stage_store(c + 1);                  // the other buffer: its last readers finished a chunk ago
         __syncthreads();

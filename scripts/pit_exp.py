@@ -33,6 +33,12 @@ VARIANTS = {
     "beta6": dict(corr_beta=6.),
     "nocorr8": dict(correction=0, max_passes=8, tol=1e-3),
     "corr8": dict(max_passes=8, tol=1e-3),
+    "tol1=.05": (dict(tol=0.05), {}),
+    "tol1=.035": (dict(tol=0.035), {}),
+    "tol1=.1": (dict(tol=0.1), {}),
+    "S1=2816": (dict(segments=2816), {}),
+    "S1=3840": (dict(segments=3840), {}),
+    "chunk2048": (dict(acq_chunk=2048), {}),
 }
 
 ap = argparse.ArgumentParser()
@@ -101,6 +107,8 @@ for seed in [int(s) for s in args.seeds.split(",")]:
                        err_pow_exact=[[[round(float(np.mean(np.abs(e[m, i * n8:(i + 1) * n8]) ** 2)), 5) for i in range(8)] for m in range(2)] for e in e_ref])
         out.append(rec)
         print(json.dumps(rec), flush=True)
+        print("##", v, seed, rec["ms"], st, rec["errors"], [(r["segments"], r["passes"], [round(x, 4) for x in r["defect"]], r["acquisition"]["steps"]) for r in rec["report"]],
+              [round(x, 5) for x in rec.get("eq_rms_dev", [])], flush=True)
         del rx
     del ref
 print(json.dumps(dict(what="exact (tier a) vs parallel-in-time (tier b)", workload=args.workload, nsym=nsym, results=out)))

@@ -274,7 +274,7 @@ def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, 
         np.testing.assert_allclose(e, eo, rtol=t["rtol"], atol=t["atol"] * 5)
     # the three forms really are different computations (different summation orders): their error traces agree to the
     # tolerance above but not bit for bit
-    if not (method in ("sbd", "mddma", "dd") and M == 32):       # cross alphabets: every request runs the direct form
+    if dn == "c64" and ntaps <= 41 and method in ("cma", "mcma", "mrde"):      # shapes every form takes (others may fall through to the direct form)
         assert not (np.array_equal(el, ed) and np.array_equal(ei, ed))
 
 
