@@ -17,6 +17,7 @@ namespace qh {
 
 typedef qh_pit_report PitCtrl;
 
+constexpr double PIT_CONTRACT = 0.2; // expected defect ratio of consecutive passes with the coarse correction (measured 0.1 .. 0.4)
 constexpr int PIT_PROBE = 128;      // symbol periods of the capture a boundary defect is measured on
 constexpr int PIT_SEEDWIN = 512;    // symbol periods of a segment's head the phase seed is estimated on
 
@@ -39,17 +40,35 @@ struct PitSeg {                      // segment grid of a sweep: see LaArgs::seg
 
 // in-place inclusive prefix sum of a[0..n) in LDS by a 256-thread block: chunk sums, one serial pass over the 256 chunk
 // totals, chunk-local prefixes (n is a few thousand: ~1 us instead of a serial loop over n)
+// Exclusive scan over the 256 threads of a block (thread order) with an associative op(earlier, later); buf: [512] of T in LDS.
+// (Hillis-Steele on ping-pong buffers, 8 barriers - the scans here used to end in ONE thread walking all 256 partial results,
+// 256 dependent LDS round trips = 10-15 us per call.)
+template <typename T, typename Op> __device__ __forceinline__ T block_scan_excl(T v, Op op, T ident, T *buf)
+{
+    const int t = threadIdx.x;
+    int cur = 0;
+    buf[t] = v;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        T x = buf[cur * 256 + t];
+        if (t >= o) x = op(buf[cur * 256 + t - o], x);
+        buf[(cur ^ 1) * 256 + t] = x;
+        cur ^= 1;
+        __syncthreads();
+    }
+    const T r = t > 0 ? buf[cur * 256 + t - 1] : ident;
+    __syncthreads();
+    return r;
+}
+
+// inclusive prefix sums of a[0..n) in place (a in LDS, 256 threads, tot: [512] scratch in LDS)
 template <typename T> __device__ __forceinline__ void block_prefix_sum(T *a, int n, T *tot)
 {
     const int len = (n + 255) / 256;
     const int i0 = threadIdx.x * len, i1 = i0 + len < n ? i0 + len : n;
     T s = 0;
     for (int i = i0; i < i1; i++) s += a[i];
-    tot[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) { T acc = 0; for (int t = 0; t < 256; t++) { const T v = tot[t]; tot[t] = acc; acc += v; } }
-    __syncthreads();
-    T run = tot[threadIdx.x];
+    T run = block_scan_excl<T>(s, [](T x, T y) { return x + y; }, (T)0, tot);
     for (int i = i0; i < i1; i++) { run += a[i]; a[i] = run; }
     __syncthreads();
 }
@@ -199,21 +218,23 @@ static __global__ void __launch_bounds__(256) pit_unwrap_kernel(const double *z,
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     double *phi = reinterpret_cast<double *>(pit_smem);       // [S]
     int *jump = reinterpret_cast<int *>(phi + S);            // [S]
-    __shared__ int ptot[256];
+    __shared__ int ptot[512];
     const double q = 1.5707963267948966;
     for (int j = 0; j < nsel; j++) {
         for (int s = threadIdx.x; s < S; s += 256) {
             const double zr = z[2 * ((size_t)s * nsel + j)], zi = z[2 * ((size_t)s * nsel + j) + 1];
-            phi[s] = (zr == 0 && zi == 0) ? 0.0 : atan2(-zi, -zr) / 4;
+            phi[s] = (zr == 0 && zi == 0) ? 0.0 : (double)atan2f((float)-zi, (float)-zr) / 4;     // a seed: single precision is plenty
         }
         __syncthreads();
         for (int s = threadIdx.x; s < S; s += 256) jump[s] = s == 0 ? 0 : (int)rint((phi[s - 1] - phi[s]) / q);
         __syncthreads();
         block_prefix_sum<int>(jump, S, ptot);
         for (int s = threadIdx.x; s < S; s += 256) {
-            const double p = phi[s] + q * jump[s];
-            rot[2 * ((size_t)s * nsel + j)] = cos(p);
-            rot[2 * ((size_t)s * nsel + j) + 1] = -sin(p);
+            const double p = phi[s] + q * (jump[s] & 3);
+            float sn, cs;
+            sincosf((float)p, &sn, &cs);
+            rot[2 * ((size_t)s * nsel + j)] = cs;
+            rot[2 * ((size_t)s * nsel + j) + 1] = -sn;
         }
         __syncthreads();
     }
@@ -252,6 +273,8 @@ __global__ void __launch_bounds__(PIT_PROBE) pit_defect_kernel(const Cx<R> *E, i
     Cx<R> *wa = reinterpret_cast<Cx<R> *>(pit_smem);
     const int ntot = nmodes * ntaps;
     Cx<R> *wb = wa + ntot;
+    const int pitch = PIT_PROBE + (ntaps + os - 1) / os + 1;
+    Cx<R> *xs = wb + ntot;                                        // [nmodes][os][pitch]: the probe's samples by sampling phase (as in pit_phase_kernel)
     __shared__ double red[4][PIT_PROBE];
     const int b = blockIdx.x + 1, j = blockIdx.y;
     const int mode = (int)modes_dev[j];
@@ -260,19 +283,28 @@ __global__ void __launch_bounds__(PIT_PROBE) pit_defect_kernel(const Cx<R> *E, i
         wa[f] = X[(size_t)b * wset + (size_t)mode * ntot + f];
         wb[f] = Y[(size_t)(b - 1) * wset + (size_t)mode * ntot + f];
     }
+    const int64_t st0 = sg.start(b);
+    int64_t nout = TrSyms - st0;
+    if (nout > PIT_PROBE) nout = PIT_PROBE;
+    const int ns = nout > 0 ? (int)(nout - 1) * os + ntaps : 0;
+    for (int k = 0; k < nmodes; k++) {
+        const Cx<R> *x = E + (size_t)k * L + st0 * os;
+        for (int g = threadIdx.x; g < ns; g += PIT_PROBE) xs[((size_t)k * os + g % os) * pitch + g / os] = x[g];
+    }
     __syncthreads();
-    const int64_t st = sg.start(b) + threadIdx.x;
     double aa = 0, bb = 0, cr = 0, ci = 0;
-    if (st < TrSyms) {
+    if (threadIdx.x < nout) {
         R ar = 0, ai = 0, br = 0, bi = 0;
-        for (int k = 0; k < nmodes; k++) {
-            const Cx<R> *x = E + (size_t)k * L + st * os;
-            for (int t = 0; t < ntaps; t++) {
-                const Cx<R> v = x[t], p = wa[k * ntaps + t], q = wb[k * ntaps + t];
-                ar = fma_(v.re, p.re, fma_(-v.im, p.im, ar)); ai = fma_(v.re, p.im, fma_(v.im, p.re, ai));
-                br = fma_(v.re, q.re, fma_(-v.im, q.im, br)); bi = fma_(v.re, q.im, fma_(v.im, q.re, bi));
+        for (int k = 0; k < nmodes; k++)
+            for (int r = 0; r < os; r++) {
+                const Cx<R> *xp = xs + ((size_t)k * os + r) * pitch + threadIdx.x;
+                int u = 0;
+                for (int t = r; t < ntaps; t += os, u++) {
+                    const Cx<R> v = xp[u], p = wa[k * ntaps + t], q = wb[k * ntaps + t];
+                    ar = fma_(v.re, p.re, fma_(-v.im, p.im, ar)); ai = fma_(v.re, p.im, fma_(v.im, p.re, ai));
+                    br = fma_(v.re, q.re, fma_(-v.im, q.im, br)); bi = fma_(v.re, q.im, fma_(v.im, q.re, bi));
+                }
             }
-        }
         aa = (double)ar * ar + (double)ai * ai;
         bb = (double)br * br + (double)bi * bi;
         cr = (double)br * ar + (double)bi * ai;          // yB conj(yA)
@@ -291,6 +323,10 @@ __global__ void __launch_bounds__(PIT_PROBE) pit_defect_kernel(const Cx<R> *E, i
         if (sym == 0) {
             proj = sqrt(Cr * Cr + Ci * Ci);
             if (proj > 0) { gr = Cr / proj; gi = Ci / proj; }
+        } else if (sym == 4 || sym == 2 || sym == 1) {          // nearest of +-1 (, +-i): signs and one comparison, no trigonometry
+            if (sym == 4 && fabs(Ci) > fabs(Cr)) { gr = 0; gi = Ci >= 0 ? 1 : -1; proj = fabs(Ci); }
+            else if (sym == 1) { gr = 1; proj = Cr; }
+            else { gr = Cr >= 0 ? 1 : -1; proj = fabs(Cr); }
         } else {
             const double step = 6.283185307179586 / sym;
             const double k = rint(atan2(Ci, Cr) / step) * step;
@@ -323,7 +359,7 @@ template <typename R> __device__ inline double pit_gain(int method, double Py, C
 // end of a pass: largest boundary defect -> report; the pass's end taps become the sweep's result; converged -> later passes skip
 template <typename R>
 __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, const double *pw, int nb, const Cx<R> *Ylast, int n, Cx<R> *wx, int method,
-                                                         const Cx<R> *sy0, int want_corr, PitCtrl *c)
+                                                         const Cx<R> *sy0, int want_corr, PitCtrl *c, float *host_view)
 {
     if (c->done) return;
     __shared__ double red[256], redp[256];
@@ -356,6 +392,8 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
             c->corr_on = 0;            // the correction did not help: plain relaxation from here on
         }
         if (red[0] < c->tol) { c->converged = 1; c->done = 1; }
+        host_view[0] = c->done ? 1.f : 0.f;                   // what the host reads after the pass: flag + defect (to decide
+        host_view[1] = (float)red[0];                         // whether the pass after the next one is worth enqueueing early)
     }
 }
 
@@ -556,9 +594,9 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
 }
 
 // C[m][c] = sum_k op(A)[m][k] B[k][c],  op(A) = A (CONJT = false) or A^H; A is n x n (n <= PIT_EIGMAX), B and C are n x ncol
-// (row-major).  A block takes 32 columns: op(A) and the B tile are staged in LDS, a thread accumulates 3 rows x 4 columns in
-// registers (8 x 32 threads), so one k step costs 7 LDS reads for 12 complex multiply-adds.
-constexpr int PIT_GT = 32;
+// (row-major).  A block takes 16 columns (a few thousand columns in all: twice as many blocks as CUs rather than half as many):
+// op(A) and the B tile are staged in LDS, a thread accumulates 3 rows x 2 columns in registers (8 x 32 threads).
+constexpr int PIT_GT = 16, PIT_GC = PIT_GT / 8;
 template <bool CONJT>
 __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B, Zf *C, int n, int ncol, const PitCtrl *c)
 {
@@ -566,7 +604,7 @@ __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     Zf *As = reinterpret_cast<Zf *>(pit_smem);                // [k][PIT_EIGMAX]  op(A)[m][k] stored k-major: rows m contiguous
     Zf *Bs = As + (size_t)PIT_EIGMAX * PIT_EIGMAX;            // [k][PIT_GT]
-    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;    // columns 4 tx .. 4 tx + 3, rows ty + 32 u
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;    // columns PIT_GC tx .., rows ty + 32 u
     const int col0 = blockIdx.x * PIT_GT;
     for (int e = threadIdx.x; e < PIT_EIGMAX * n; e += 256) {
         const int k = e / PIT_EIGMAX, m = e - k * PIT_EIGMAX;
@@ -580,21 +618,21 @@ __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B
     }
     __syncthreads();
     constexpr int RU = PIT_EIGMAX / 32;                       // 3 rows per thread
-    Zf acc[RU][4];
+    Zf acc[RU][PIT_GC];
 #pragma unroll
     for (int u = 0; u < RU; u++)
 #pragma unroll
-        for (int v = 0; v < 4; v++) acc[u][v] = Zf{0.f, 0.f};
+        for (int v = 0; v < PIT_GC; v++) acc[u][v] = Zf{0.f, 0.f};
     for (int k = 0; k < n; k++) {
-        Zf b[4], a[RU];
+        Zf b[PIT_GC], a[RU];
 #pragma unroll
-        for (int v = 0; v < 4; v++) b[v] = Bs[k * PIT_GT + 4 * tx + v];
+        for (int v = 0; v < PIT_GC; v++) b[v] = Bs[k * PIT_GT + PIT_GC * tx + v];
 #pragma unroll
         for (int u = 0; u < RU; u++) a[u] = As[k * PIT_EIGMAX + ty + 32 * u];
 #pragma unroll
         for (int u = 0; u < RU; u++)
 #pragma unroll
-            for (int v = 0; v < 4; v++) {
+            for (int v = 0; v < PIT_GC; v++) {
                 acc[u][v].x += a[u].x * b[v].x - a[u].y * b[v].y;
                 acc[u][v].y += a[u].x * b[v].y + a[u].y * b[v].x;
             }
@@ -604,8 +642,8 @@ __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B
         const int m = ty + 32 * u;
         if (m < n)
 #pragma unroll
-            for (int v = 0; v < 4; v++)
-                if (col0 + 4 * tx + v < ncol) C[(size_t)m * ncol + col0 + 4 * tx + v] = acc[u][v];
+            for (int v = 0; v < PIT_GC; v++)
+                if (col0 + PIT_GC * tx + v < ncol) C[(size_t)m * ncol + col0 + PIT_GC * tx + v] = acc[u][v];
     }
 }
 
@@ -616,8 +654,7 @@ template <typename R>
 __global__ void __launch_bounds__(256) pit_recur_kernel(Zf *D, const double *lam, int nsel, int S, int64_t T, const R *mu, double beta, const PitCtrl *c)
 {
     if (c->done) return;
-    __shared__ Zf tot[256];
-    __shared__ Zf car[256];
+    __shared__ float4 aff[512];
     const int k = blockIdx.x, j = blockIdx.y;
     const int ncol = S * nsel;
     Zf *row = D + (size_t)k * ncol + j;
@@ -637,15 +674,12 @@ __global__ void __launch_bounds__(256) pit_recur_kernel(Zf *D, const double *lam
         run = Zf{d.x + coef * run.x, d.y + coef * run.y};
         row[(size_t)s * nsel] = run;
     }
-    tot[threadIdx.x] = run;
-    __syncthreads();
+    // carry into chunk t: the maps x -> clen x + tot[t] of the chunks before it, composed (a scan of affine maps (A, B))
     const float clen = powf(coef, (float)len);
-    if (threadIdx.x == 0) {
-        Zf cin{0.f, 0.f};
-        for (int t = 0; t < 256; t++) { car[t] = cin; cin = Zf{tot[t].x + clen * cin.x, tot[t].y + clen * cin.y}; }
-    }
-    __syncthreads();
-    const Zf cin = car[threadIdx.x];
+    const float4 comp = block_scan_excl<float4>(float4{clen, run.x, run.y, 0.f},
+                                                [](float4 e, float4 l) { return float4{l.x * e.x, l.x * e.y + l.y, l.x * e.z + l.z, 0.f}; },
+                                                float4{1.f, 0.f, 0.f, 0.f}, aff);
+    const Zf cin{comp.y, comp.z};
     float pw = coef;
     for (int s = s0; s < s1; s++) {
         Zf v = row[(size_t)s * nsel];
@@ -663,19 +697,22 @@ __global__ void __launch_bounds__(256) pit_recur_kernel(Zf *D, const double *lam
 static __global__ void __launch_bounds__(256) pit_gauge_kernel(const double *gph, int S, int nsel, const PitCtrl *c, double *theta)
 {
     if (c->done) return;
-    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
-    double *ang = reinterpret_cast<double *>(pit_smem);         // [nsel][S] angles of g_s, then their running sums
-    for (int e = threadIdx.x; e < S * nsel; e += 256) {
-        const int s = e / nsel, j = e - s * nsel;
-        ang[(size_t)j * S + s] = s == 0 ? 0.0 : atan2(gph[2 * ((size_t)(s - 1) * nsel + j) + 1], gph[2 * ((size_t)(s - 1) * nsel + j)]);
-    }
-    __syncthreads();
-    __shared__ double gtot[256];
-    for (int j = 0; j < nsel; j++) block_prefix_sum<double>(ang + (size_t)j * S, S, gtot);
-    for (int e = threadIdx.x; e < S * nsel; e += 256) {
-        const int s = e / nsel, j = e - s * nsel;
-        const double t = ang[(size_t)j * S + s];
-        theta[2 * (size_t)e] = cos(t); theta[2 * (size_t)e + 1] = sin(t);
+    // theta_s = g_1 ... g_s as a running PRODUCT of unit complex numbers (chunk per thread, scan of the chunk products):
+    // no angles, no trigonometry; renormalised on output
+    __shared__ double2 gbuf[512];
+    const int len = (S + 255) / 256;
+    const int s0 = threadIdx.x * len, s1 = s0 + len < S ? s0 + len : S;
+    auto cm = [](double2 x, double2 y) { return double2{x.x * y.x - x.y * y.y, x.x * y.y + x.y * y.x}; };
+    for (int j = 0; j < nsel; j++) {
+        double2 prod{1.0, 0.0};
+        for (int s = s0; s < s1; s++)
+            if (s > 0) prod = cm(prod, double2{gph[2 * ((size_t)(s - 1) * nsel + j)], gph[2 * ((size_t)(s - 1) * nsel + j) + 1]});
+        double2 run = block_scan_excl<double2>(prod, cm, double2{1.0, 0.0}, gbuf);
+        for (int s = s0; s < s1; s++) {
+            if (s > 0) run = cm(run, double2{gph[2 * ((size_t)(s - 1) * nsel + j)], gph[2 * ((size_t)(s - 1) * nsel + j) + 1]});
+            const double r = rsqrt(run.x * run.x + run.y * run.y);
+            theta[2 * ((size_t)s * nsel + j)] = run.x * r; theta[2 * ((size_t)s * nsel + j) + 1] = run.y * r;
+        }
     }
 }
 // D[f][s nsel + j] = theta_{s-1} Y[s-1][mode_j][f] - theta_s X[s][mode_j][f]  (s >= 1), 0 for s = 0
@@ -724,14 +761,15 @@ inline PitTiming &pit_timing() { static PitTiming t; return t; }
 // pass p + 1 is enqueued BEFORE the host looks at the flag of pass p (every kernel of a pass starts with `if (done) return`,
 // so a pass enqueued in vain costs a few empty launches instead of an idle GPU during every host round trip).
 constexpr int PIT_NEV = (QH_PIT_MAXPASS > QH_PIT_MAXCHUNK ? QH_PIT_MAXPASS : QH_PIT_MAXCHUNK) + 1;
-struct PitEvents { hipEvent_t t0[PIT_NEV], t1[PIT_NEV], flag[PIT_NEV]; int32_t *hflag; bool ok; };
+struct PitEvents { hipEvent_t t0[PIT_NEV], t1[PIT_NEV], flag[PIT_NEV]; int32_t *hflag; float *hview; bool ok; };
 inline PitEvents &pit_events()
 {
-    static PitEvents e = {{nullptr}, {nullptr}, {nullptr}, nullptr, false};
+    static PitEvents e = {{nullptr}, {nullptr}, {nullptr}, nullptr, nullptr, false};
     if (!e.ok) {
         for (int i = 0; i < PIT_NEV; i++) { (void)hipEventCreate(&e.t0[i]); (void)hipEventCreate(&e.t1[i]); (void)hipEventCreateWithFlags(&e.flag[i], hipEventDisableTiming); }
         (void)hipHostMalloc((void **)&e.hflag, PIT_NEV * sizeof(int32_t), hipHostMallocDefault);
-        e.ok = e.hflag != nullptr;
+        (void)hipHostMalloc((void **)&e.hview, 2 * PIT_NEV * sizeof(float), hipHostMallocDefault);
+        e.ok = e.hflag != nullptr && e.hview != nullptr;
     }
     return e;
 }
@@ -836,6 +874,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     if ((rc = scratch(8, sizeof(PitCtrl) + 64, &cbuf))) return rc;
     PitCtrl *ctrl = report_dev ? (PitCtrl *)report_dev : (PitCtrl *)cbuf;
     R *mu_acq = (R *)((char *)cbuf + sizeof(PitCtrl));            // 8-byte aligned: sizeof(PitCtrl) is a multiple of 8
+    float *host_view = (float *)((char *)cbuf + sizeof(PitCtrl) + 16);
 
     // ---- segment grid
     int S = o.segments;
@@ -1033,7 +1072,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                     QH_HIP(hipStreamWaitEvent(g_stream, pit_basis_sync().out, 0));
                     pit_basis_sync().pending = false;
                 }
-                hipLaunchKernelGGL(pit_gauge_kernel, dim3(1), dim3(256), (size_t)ncol * sizeof(double), g_stream, (const double *)gph, sg.S, nsel, (const PitCtrl *)ctrl, theta);
+                hipLaunchKernelGGL(pit_gauge_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)gph, sg.S, nsel, (const PitCtrl *)ctrl, theta);
                 hipLaunchKernelGGL((pit_dvec_kernel<R>), dim3(ncol), dim3(128), 0, g_stream, (const Cx<R> *)X, (const Cx<R> *)Y, nmodes, ntot, (const int64_t *)modes_dev, nsel, sg.S,
                                    (const PitCtrl *)ctrl, (const double *)theta, Dz[0]);
                 hipLaunchKernelGGL((pit_cgemm_kernel<true>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb, (const Zf *)Dz[0], Dz[1], ntot, ncol, (const PitCtrl *)ctrl);
@@ -1069,22 +1108,31 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 { int r = launch_any<R>(ts); if (r) return r; }
             }
             QH_HIP(hipEventRecord(ev.t1[p], g_stream));
-            hipLaunchKernelGGL((pit_defect_kernel<R>), dim3(sg.S - 1, nsel), dim3(PIT_PROBE), 2 * (size_t)ntot * sizeof(Cx<R>), g_stream, (const Cx<R> *)E, nmodes, L, os,
+            const size_t dlds = (2 * (size_t)ntot + (size_t)nmodes * os * pit_phase_pitch(ntaps, os, PIT_PROBE)) * sizeof(Cx<R>);
+            QH_REQUIRE(dlds <= 60 * 1024, "train_equaliser: boundary probe does not fit the LDS for this filter shape");
+            hipLaunchKernelGGL((pit_defect_kernel<R>), dim3(sg.S - 1, nsel), dim3(PIT_PROBE), dlds, g_stream, (const Cx<R> *)E, nmodes, L, os,
                                ntaps, sg, TrSyms, (const int64_t *)modes_dev, (const Cx<R> *)X, (const Cx<R> *)Y, sym, (const PitCtrl *)ctrl, dfc, pw, gph);
             hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, (int)((sg.S - 1) * nsel),
                                (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, method,
-                               (const Cx<R> *)symbols + (size_t)modes[0] * nsy, want_corr ? 1 : 0, ctrl);
+                               (const Cx<R> *)symbols + (size_t)modes[0] * nsy, want_corr ? 1 : 0, ctrl, host_view);
             QH_HIP(hipGetLastError());
-            QH_HIP(hipMemcpyAsync(&ev.hflag[p], &ctrl->done, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
+            QH_HIP(hipMemcpyAsync(&ev.hview[2 * p], host_view, 2 * sizeof(float), hipMemcpyDeviceToHost, g_stream));
             QH_HIP(hipEventRecord(ev.flag[p], g_stream));
             return QH_OK;
         };
+        // Pass p + 1 is enqueued BEFORE the host has seen the flag of pass p - unless pass p is expected to be the last one, since
+        // a pass enqueued in vain costs a dozen empty launches (~55 us), about as much as the idle round trip it would save:
+        // expected defect of pass p = PIT_CONTRACT x the defect of pass p - 1 (the first pass never converges from seeds).
         if ((rc = enqueue_pass(0))) return rc;
+        bool ahead = false;                                       // pass p + 1 already in the stream
         for (int p = 0; p < npass; p++) {
-            if (p + 1 < npass && (rc = enqueue_pass(p + 1))) return rc;          // skipped on the device if pass p converges
+            const bool expect_last = p > 0 && PIT_CONTRACT * (double)ev.hview[2 * (p - 1) + 1] < tol;
+            ahead = false;
+            if (p + 1 < npass && !expect_last) { if ((rc = enqueue_pass(p + 1))) return rc; ahead = true; }
             QH_HIP(hipEventSynchronize(ev.flag[p]));
             if (tm.npass < QH_PIT_MAXPASS) { float ms = 0; QH_HIP(hipEventElapsedTime(&ms, ev.t0[p], ev.t1[p])); tm.pass_ms[tm.npass++] = ms; }
-            if (ev.hflag[p]) break;
+            if (ev.hview[2 * p] != 0.f) break;
+            if (p + 1 < npass && !ahead && (rc = enqueue_pass(p + 1))) return rc;
         }
     }
     return QH_OK;

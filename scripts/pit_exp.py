@@ -39,6 +39,10 @@ VARIANTS = {
     "S1=2816": (dict(segments=2816), {}),
     "S1=3840": (dict(segments=3840), {}),
     "chunk2048": (dict(acq_chunk=2048), {}),
+    "gear16c2048": (dict(gear=16., acq_bound=0.16, acq_chunk=2048), {}),
+    "gear12c2048": (dict(gear=12., acq_bound=0.12, acq_chunk=2048), {}),
+    "gear16c1024": (dict(gear=16., acq_bound=0.16, acq_chunk=1024), {}),
+    "c1024": (dict(acq_chunk=1024), {}),
 }
 
 ap = argparse.ArgumentParser()
