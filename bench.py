@@ -374,7 +374,7 @@ class _OracleKernels:
         from oracle import oracle
         from qampy_amd.core.equalisation import equalisation as core_eq
         k = core_eq._kernels
-        self.k, self.saved = k, {n: getattr(k, n) for n in ("ResidentField", "train_equaliser", "apply_filter_to_signal", "train_equaliser_windows_search")}
+        self.k, self.saved = k, {n: getattr(k, n) for n in ("ResidentField", "ResidentJobs", "train_equaliser", "apply_filter_to_signal", "train_equaliser_windows_search")}
 
         class OracleField:
             def __init__(self, E):
@@ -386,6 +386,18 @@ class _OracleKernels:
             def apply(self, os_, wx, modes=None):
                 return oracle.apply_filter_to_signal(self.E, os_, np.ascontiguousarray(wx), modes, fast=True)
 
+        class OracleJobs:
+            def __init__(self, slices, job_modes):
+                self.slices, self.job_modes = [np.ascontiguousarray(x) for x in slices], [int(m) for m in job_modes]
+
+            def train(self, TrSyms, Niter, os_, mu, wx, adaptive, symbols, method):
+                for E, m in zip(self.slices, self.job_modes):
+                    _, wx, _ = oracle.train_equaliser(E, TrSyms, Niter, os_, mu, wx, np.array([m]), adaptive, symbols, method, fast=True)
+                return wx
+
+            def apply(self, os_, wx):
+                return np.array([oracle.apply_filter_to_signal(E, os_, np.ascontiguousarray(wx), np.array([m]), fast=True)[0] for E, m in zip(self.slices, self.job_modes)])
+
         def search(E, starts, win_len, TrSyms, Niter, os_, mu, wx0, modes, adaptive, symbols, method):
             res = [oracle.train_equaliser(np.ascontiguousarray(E[:, s0:s0 + win_len]), TrSyms, Niter, os_, mu, wx0.copy(), modes, adaptive, symbols, method, fast=True)
                    for s0 in np.asarray(starts)]
@@ -394,6 +406,7 @@ class _OracleKernels:
             return var, best, np.array([res[b][1] for b in best])
 
         k.ResidentField = OracleField
+        k.ResidentJobs = OracleJobs
         k.train_equaliser = lambda *a: oracle.train_equaliser(*a, fast=True)
         k.apply_filter_to_signal = lambda *a, **kw: oracle.apply_filter_to_signal(*a, fast=True, **kw)
         k.train_equaliser_windows_search = search
@@ -666,6 +679,19 @@ def main():
                         note="one launch trains all segments of the sweep; algorithmic bytes = one sweep (read E, write err); the look-ahead form "
                              "additionally streams the Gram table (1 KiB per step) - see profiles/ for the PMC traffic",
                         pipeline=tier_b["roofline"])
+        if kname == "bps_recover" and rx.ct == np.complex64 and cfg["A"] <= 64:
+            # streaming phase search: VALU instructions per symbol and wave counted in the ISA of bps_stream_kernel
+            # for a mirror-symmetric square alphabet with NL = sqrt(M)/2 positive levels per axis: 17.4 + 3 NL (29.4 at 64-QAM)
+            NL = max(1, int(round(np.sqrt(cfg["M"]))) // 2)
+            per_sym = 17.4 + 3 * NL
+            C, W = 1024, 2 * cfg["Nbps"]
+            rows = -(-nsym // C) * (-(-(C + W - 1) // 16) * 16) * rx.modes.size          # distance rows incl. the 2N-1 halo of every chunk
+            winstr = rows * per_sym
+            roofline["valu"] = dict(bound="valu-issue", symbol_angle_pairs=int(nsym * rx.modes.size * cfg["A"]), valu_instr_per_symbol=round(per_sym, 1),
+                                    achieved_ginstr_s=round(winstr / (kms * 1e-3) / 1e9, 1), peak_ginstr_s=VALU_PEAK_GINSTR,
+                                    issue_frac=round(winstr / (kms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4),
+                                    note="lane <-> test angle, one wave per 1024 symbols; the stage time also holds alphabet analysis, unwrap scan and "
+                                         "de-rotation (3 small launches, ~0.2 ms at C3), so the kernel's own fraction is higher")
         # what actually bounds the pass kernel: instruction issue of the fp32 vector units, not HBM
         if "relaxation pass" in kname:
             st = tier_b["stages"][int(kname[5]) - 1]

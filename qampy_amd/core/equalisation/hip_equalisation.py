@@ -248,6 +248,55 @@ class ResidentField:
         return out.to_host()
 
 
+class ResidentJobs:
+    """
+    Independent training jobs of identical shape - slices of one capture that start at different samples, ONE output mode
+    each (``equalize_pilot_sequence`` with unequal shifts, qampy/core/pilotbased_receiver.py:497-547) - resident together and
+    trained together: one launch per stage over all jobs through the channel-bank entry points, instead of one chain after
+    the other.  Job ``j`` trains row ``job_modes[j]`` of the taps on ``slices[j]``; rows of different output modes do not
+    interact, so the result is what one :func:`train_equaliser` call per job with ``modes=[job_modes[j]]`` returns (the
+    adaptive step is therefore run with one step size per chain, each from the initial ``mu``).
+    """
+
+    def __init__(self, slices, job_modes):
+        host = np.ascontiguousarray(np.stack([np.asarray(x) for x in slices]))
+        suf, rt, ct = _lib.suffix(host.dtype)
+        if host.ndim != 3 or not np.iscomplexobj(host):
+            raise TypeError("ResidentJobs holds complex slices of identical shape")
+        self.shape, self.ct, self.rt = host.shape, ct, rt
+        self.job_modes = [int(m) for m in job_modes]
+        self.dev = DeviceArray.from_host(host)
+
+    def train(self, TrSyms, Niter, os, mu, wx, adaptive, symbols, method):
+        if method not in _lib.METHOD_ID:
+            raise ValueError("Unknown method %s" % method)
+        nj, nmodes, L = self.shape
+        _need(wx, self.ct, "wx")
+        symbols = np.ascontiguousarray(symbols)
+        _need(symbols, self.ct, "symbols")
+        bank = np.ascontiguousarray(np.broadcast_to(wx, (nj,) + wx.shape))
+        dw, dsy = DeviceArray.from_host(bank), DeviceArray.from_host(symbols)
+        dmu = DeviceArray.from_host(np.full(nj, mu, dtype=self.rt))
+        derr = DeviceArray((nj, nmodes, int(TrSyms) * int(Niter)), self.ct)
+        train_equaliser_batch_dev(self.dev, TrSyms, Niter, os, dmu, dw, None, "per-mode" if adaptive else False, dsy, method, derr, zero_err=True)
+        out = dw.to_host()
+        for j, m in enumerate(self.job_modes):
+            wx[m] = out[j, m]
+        return wx
+
+    def apply(self, os, wx):
+        """Row ``job_modes[j]`` of slice ``j`` through the taps, stacked."""
+        nj, nmodes, L = self.shape
+        N = max((L - wx.shape[-1] + 1) // os, 0)
+        dw = DeviceArray.from_host(np.ascontiguousarray(wx, dtype=self.ct))
+        rows = []
+        for j, m in enumerate(self.job_modes):
+            out = DeviceArray((1, N), self.ct)
+            apply_filter_to_signal_dev(self.dev.row(j), os, dw, np.array([m]), out)
+            rows.append(out.to_host()[0])
+        return np.array(rows)
+
+
 # ------------------------------------------------------------------------------------------------ device-resident forms
 def gram_build_dev(E, os, ntaps, TrSyms):
     """

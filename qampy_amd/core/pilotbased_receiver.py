@@ -167,6 +167,41 @@ def pilot_based_cpe_new(signal, pilot_symbs, pilot_idx, frame_len, seq_len=None,
     return out[:, :nframes * frame_len], trace[:, :nframes * frame_len]
 
 
+def _equalize_pilot_jobs(rx, refs, starts, span, os, foe_comp, mu, M_pilot, Ntaps, Niter, adaptive, methods, wxinit):
+    """``equalize_pilot_sequence`` when every mode has its own start sample: the per-mode trainings are independent chains
+    (an output mode's taps only see their own error), so the slices are uploaded together and every stage trains all of
+    them in ONE launch (:class:`hip_equalisation.ResidentJobs`) - the reference, and the joint path below, run them one after
+    the other."""
+    nmodes = rx.shape[0]
+    m0, m1 = methods
+    dtype = np.asarray(rx).dtype
+
+    def bank(pieces):
+        return _eq._kernels.ResidentJobs(pieces, range(nmodes))
+
+    pieces = [rx[:, s:s + span] for s in starts]
+
+    def stage(jobs, mu_s, M, taps, method, symbols):
+        n = taps.shape[-1]
+        TrSyms = _eq._cal_training_symbol_len(os, n, span)
+        sy = _eq._reshape_symbols(symbols, method, M, dtype, nmodes).copy()
+        return jobs.train(TrSyms, Niter, os, dtype.type(0).real.dtype.type(mu_s), taps, adaptive, sy, method)
+
+    # given taps are pre-converged IN PLACE and copied afterwards, like the reference (and the joint path below) do
+    taps = _eq._init_taps(Ntaps, nmodes, nmodes, dtype) if wxinit is None else np.ascontiguousarray(wxinit, dtype=dtype)
+    jobs = bank(pieces)
+    taps = stage(jobs, mu[0], M_pilot, taps, m0, None).copy()
+    if foe_comp:
+        foe, foe_modes, _ = pilot_based_foe(jobs.apply(os, taps), refs)
+        offsets = np.ones(foe_modes.shape) * foe
+        jobs = bank([phaserecovery.comp_freq_offset(p, offsets, os=os) for p in pieces])      # per slice, as the reference does (:527)
+    else:
+        offsets = np.zeros([nmodes, 1])
+    taps = stage(jobs, mu[0], M_pilot, taps, m0, refs)
+    taps = stage(jobs, mu[1], 4, taps, m1, refs)              # the reference hard-codes QPSK pilots here when it trains mode by mode (:540)
+    return np.array(taps), offsets
+
+
 def equalize_pilot_sequence(rx_signal, ref_symbs, shift_fctrs, os, foe_comp=False, mu=(1e-4, 1e-4), M_pilot=4, Ntaps=45,
                             Niter=30, adaptive_stepsize=True, methods=('cma', 'cma'), wxinit=None):
     """
@@ -186,6 +221,9 @@ def equalize_pilot_sequence(rx_signal, ref_symbs, shift_fctrs, os, foe_comp=Fals
     jobs = [(int(shift_fctrs[m]), [m]) for m in range(nmodes)] if split else [(int(shift_fctrs[0]), None)]
     m0, m1 = _eq._method_name(methods[0]), _eq._method_name(methods[1])
 
+    if split and not real:
+        return _equalize_pilot_jobs(rx, refs, [j[0] for j in jobs], span, os, foe_comp, mu, M_pilot, Ntaps, Niter, adaptive_stepsize, (m0, m1), wxinit)
+
     # ---- pre-convergence; the equalised pilot sequence is only needed for the frequency-offset estimate
     taps = wxinit
     seen = np.zeros_like(refs)
@@ -194,11 +232,12 @@ def equalize_pilot_sequence(rx_signal, ref_symbs, shift_fctrs, os, foe_comp=Fals
         rows = field.mode_rows(modes)
         taps, _ = field.train(os, mu[0], M_pilot, field.taps(taps, Ntaps), None, Niter, m0,
                               adaptive_stepsize, None, rows)
-        eq = field.filtered(os, taps, rows)
-        if modes is None:
-            seen = eq
-        else:
-            seen[modes[0]] = eq
+        if foe_comp or modes is None:
+            eq = field.filtered(os, taps, rows)
+            if modes is None:
+                seen = eq
+            else:
+                seen[modes[0]] = eq
     if foe_comp:
         foe, foe_modes, _ = pilot_based_foe(seen, refs)
         offsets = np.ones(foe_modes.shape) * foe

@@ -566,6 +566,8 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
                 hipLaunchKernelGGL((spread_kernel<R>), dim3((unsigned)((nch * nsel + 63) / 64)), dim3(64), 0, g_stream, mu_modes, (const R *)mu_dev, nsel, nch * nsel);
                 la.mu = mu_modes; la.mu_out = mu_modes; la.mu_cs = nsel; la.mu_ms = 1;
             }
+            void *built = nullptr;                              // Gram terms depend on the capture only: built once per chunk, not once per sweep
+            int64_t built_step0 = -1, built_n = -1;
             const int nmode_runs = (adaptive && !mu_modes) ? nsel : 1;
             if (adaptive && !mu_modes) la.nsel = 1;
             for (int jm = 0; jm < nmode_runs; jm++) {
@@ -576,10 +578,13 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
                         if (TrSyms - (step0 + n) < 2 * LA_B) n = TrSyms - step0;          // never leave a tail the block forms cannot take
                         const Cx<R> *Ec = a.E + step0 * os;
                         void *G = const_cast<void *>(gram);
-                        if (!G) {
+                        if (!G && built_step0 == step0 && built_n == n) {
+                            G = built;                              // same chunk as the last launch (every sweep of an unchunked call): the table is still there
+                        } else if (!G) {
                             rc = pair_tab ? gram_build<R>(Ec, nmodes, L - step0 * os, os, ntaps, n, &G, nch, L, (int64_t)nmodes * L)
                                           : gram_cur_build<R>(Ec, nmodes, L - step0 * os, os, ntaps, n, &G, nch, L, (int64_t)nmodes * L);
                             if (rc) return rc;
+                            built = G; built_step0 = step0; built_n = n;
                         }
                         la.E = Ec; la.L = L - step0 * os; la.TrSyms = n; la.G = (const GramPair<R> *)G;
                         la.G_cs = (int64_t)((pair_tab ? gram_bytes<R>(n) : gram_cur_bytes<R>(n)) / sizeof(GramPair<R>));

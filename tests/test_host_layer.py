@@ -8,6 +8,7 @@ import pytest
 
 from conftest import CT, RT
 from oracle import oracle
+from oracle_kernels import OracleJobs
 import qampy_amd
 from qampy_amd import theory, synth
 from qampy_amd.signals import SignalQAM
@@ -30,6 +31,7 @@ def oracle_kernels(monkeypatch):
             return oracle.apply_filter_to_signal(self.E, os, np.ascontiguousarray(wx), modes)
 
     monkeypatch.setattr(k, "ResidentField", OracleField)
+    monkeypatch.setattr(k, "ResidentJobs", OracleJobs)
     monkeypatch.setattr(k, "train_equaliser", oracle.train_equaliser)
     monkeypatch.setattr(k, "train_equaliser_realvalued", oracle.train_equaliser_realvalued)
     monkeypatch.setattr(k, "apply_filter_to_signal", oracle.apply_filter_to_signal)

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
+from oracle_kernels import OracleJobs
 from qampy_amd.core import pilotbased_receiver as pil
 from qampy_amd.core import ber_functions, phaserecovery
 from qampy_amd.core.filter import moving_average
@@ -50,6 +51,7 @@ def oracle_kernels(monkeypatch):
             return oracle.apply_filter_to_signal(self.E, os, np.ascontiguousarray(wx), modes)
 
     monkeypatch.setattr(k, "ResidentField", OracleField)
+    monkeypatch.setattr(k, "ResidentJobs", OracleJobs)
     monkeypatch.setattr(k, "train_equaliser", oracle.train_equaliser)
     monkeypatch.setattr(k, "train_equaliser_realvalued", oracle.train_equaliser_realvalued)
     monkeypatch.setattr(k, "apply_filter_to_signal", oracle.apply_filter_to_signal)
@@ -239,6 +241,7 @@ def test_config5_256qam_against_oracle_kernel_chain(monkeypatch):
             return oracle.apply_filter_to_signal(self.E, os, np.ascontiguousarray(wx), modes)
 
     monkeypatch.setattr(k, "ResidentField", OracleField)
+    monkeypatch.setattr(k, "ResidentJobs", OracleJobs)
     monkeypatch.setattr(k, "train_equaliser", oracle.train_equaliser)
     monkeypatch.setattr(k, "apply_filter_to_signal", oracle.apply_filter_to_signal)
     monkeypatch.setattr(k, "train_equaliser_windows_search", _oracle_search)
