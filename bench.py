@@ -469,7 +469,7 @@ def main():
     ap.add_argument("--tier", default="b", choices=["a", "b"],
                     help="trainer of the timed pipeline: b = parallel-in-time solver of the recurrence, used for the headline only if it certifies "
                          "itself in this run (converged + SER within +-3 errors of the exact path); a = the exact sequential recurrence")
-    ap.add_argument("--tol", type=float, default=0., help="boundary-defect tolerance of tier b (0 = library default 0.02)")
+    ap.add_argument("--tol", type=float, default=0., help="boundary-defect tolerance of tier b (0 = library default 0.01; stages that only seed the next one 0.05)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=None, help="symbol periods the all-thread CPU baseline processes (default: the whole capture)")
     ap.add_argument("--cpu-sample-1t", type=int, default=1 << 19, help="symbol periods of the one-thread CPU run")
@@ -681,9 +681,9 @@ def main():
                         pipeline=tier_b["roofline"])
         if kname == "bps_recover" and rx.ct == np.complex64 and cfg["A"] <= 64:
             # streaming phase search: VALU instructions per symbol and wave counted in the ISA of bps_stream_kernel
-            # for a mirror-symmetric square alphabet with NL = sqrt(M)/2 positive levels per axis: 17.4 + 3 NL (29.4 at 64-QAM)
+            # for a mirror-symmetric square alphabet with NL = sqrt(M)/2 positive levels per axis: 16.4 + 2 NL (24.4 at 64-QAM)
             NL = max(1, int(round(np.sqrt(cfg["M"]))) // 2)
-            per_sym = 17.4 + 3 * NL
+            per_sym = 16.4 + 2 * NL
             C, W = 1024, 2 * cfg["Nbps"]
             rows = -(-nsym // C) * (-(-(C + W - 1) // 16) * 16) * rx.modes.size          # distance rows incl. the 2N-1 halo of every chunk
             winstr = rows * per_sym

@@ -243,7 +243,7 @@ typedef struct qh_pit_opts {
     int32_t max_passes;     /* 0 = 8 (at most QH_PIT_MAXPASS) */
     int32_t acquire;        /* 0 warm start, 1 cold start: gear-shifted sequential acquisition first */
     int32_t phase_seed;     /* -1 by method, 0 off, 1 on */
-    double tol;             /* 0 = 0.02 */
+    double tol;             /* 0 = 0.01: largest boundary defect accepted (output deviation from the sequential result ~ 0.6 tol) */
     double gear;            /* 0 = 8 */
     double acq_bound;       /* 0 = 0.08 */
     double acq_plateau;     /* 0 = 0.9: a chunk whose mean |err|^2 exceeds this fraction of the previous one's ends the acquisition */

@@ -285,15 +285,25 @@ struct BpsStreamArgs {
 };
 
 template <int K> struct BsKind { static constexpr int value = K; };
-__device__ __forceinline__ float bs_axis_sym(float t, const float (&lv)[16], int nl)
+typedef float bs_f2 __attribute__((ext_vector_type(2)));
+// both axes at once: u = (|t.re|, |t.im|), d_k = u - (l_re[k], l_im[k]) is ONE packed subtraction per level pair; the minima are
+// per axis (no packed min).  The same values as the scalar form: subtraction and |.| are exact per component.
+template <bool SMALL> __device__ __forceinline__ bs_f2 bs_axes_sym(bs_f2 t, const bs_f2 (&lv)[16], int nl)
 {
-    const float u = abs_(t);
-    float m = min_(min_(abs_(u - lv[0]), abs_(u - lv[1])), min_(abs_(u - lv[2]), abs_(u - lv[3])));   // padding levels are 3e38: never the minimum
-    if (nl > 4) {                                                                                   // wave-uniform
-        m = min_(m, min_(min_(abs_(u - lv[4]), abs_(u - lv[5])), min_(abs_(u - lv[6]), abs_(u - lv[7]))));
+    const bs_f2 u = {abs_(t.x), abs_(t.y)};
+    const bs_f2 d0 = u - lv[0], d1 = u - lv[1], d2 = u - lv[2], d3 = u - lv[3];      // padding levels are 3e38: never the minimum
+    bs_f2 m = {min_(min_(abs_(d0.x), abs_(d1.x)), min_(abs_(d2.x), abs_(d3.x))), min_(min_(abs_(d0.y), abs_(d1.y)), min_(abs_(d2.y), abs_(d3.y)))};
+    if (!SMALL && nl > 4) {                                                           // wave-uniform
+        const bs_f2 d4 = u - lv[4], d5 = u - lv[5], d6 = u - lv[6], d7 = u - lv[7];
+        m.x = min_(m.x, min_(min_(abs_(d4.x), abs_(d5.x)), min_(abs_(d6.x), abs_(d7.x))));
+        m.y = min_(m.y, min_(min_(abs_(d4.y), abs_(d5.y)), min_(abs_(d6.y), abs_(d7.y))));
         if (nl > 8) {
 #pragma unroll
-            for (int k = 8; k < 16; k += 2) m = min_(m, min_(abs_(u - lv[k]), abs_(u - lv[k + 1])));
+            for (int k = 8; k < 16; k += 2) {
+                const bs_f2 da = u - lv[k], db = u - lv[k + 1];
+                m.x = min_(m.x, min_(abs_(da.x), abs_(db.x)));
+                m.y = min_(m.y, min_(abs_(da.y), abs_(db.y)));
+            }
         }
     }
     return m;
@@ -319,12 +329,13 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
     // ---- alphabet
     const int product = a.desc->product, symmetric = a.desc->symmetric;
     const int nre = a.desc->nre, nim = a.desc->nim;
-    float lre[16], lim[16];                                           // positive halves, in SGPRs
+    bs_f2 lev2[16];                                                   // positive halves (re, im), in SGPRs
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        lre[k] = symmetric && k < nre / 2 ? a.desc->re[nre / 2 + k] : 3.0e38f;
-        lim[k] = symmetric && k < nim / 2 ? a.desc->im[nim / 2 + k] : 3.0e38f;
+        lev2[k].x = symmetric && k < nre / 2 ? a.desc->re[nre / 2 + k] : 3.0e38f;
+        lev2[k].y = symmetric && k < nim / 2 ? a.desc->im[nim / 2 + k] : 3.0e38f;
     }
+    const int nlmax = nre > nim ? nre / 2 : nim / 2;
     if (product && !symmetric) {
         if (lane < BPS_MAX_LEVELS) { plev[lane] = a.desc->re[lane]; plev[BPS_MAX_LEVELS + lane] = a.desc->im[lane]; }
     } else if (!product && a.alpha_lds) {
@@ -334,14 +345,16 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
     float cs = 1.f, sn = 0.f;
     if (lane < a.A) sincosf(a.angles[lane], &sn, &cs);
     const float bias = lane < a.A ? 0.f : 2000.f;                     // lanes without an angle never win (dmin starts at 1000)
+    const bool full = a.A == 64;
+    const bs_f2 rot_cs = {cs, sn}, rot_ns = {-sn, cs};
     __syncthreads();
 
     auto distance = [&](float tr, float ti, auto KIND) -> float {
         constexpr int kind = decltype(KIND)::value;
         float d0;
-        if (kind == 0) {
-            const float mr = bs_axis_sym(tr, lre, nre / 2), mi = bs_axis_sym(ti, lim, nim / 2);
-            d0 = fma_(mr, mr, mi * mi);
+        if (kind == 0 || kind == 3) {                                 // 3: at most 4 positive levels per axis (up to 64-QAM), no branch at all
+            const bs_f2 mm = bs_axes_sym<kind == 3>(bs_f2{tr, ti}, lev2, nlmax);
+            d0 = fma_(mm.x, mm.x, mm.y * mm.y);
         } else if (kind == 1) {
             float mr = 3.0e38f, mi = 3.0e38f;
             for (int r = 0; r < nre; r++) mr = min_(mr, abs_(tr - plev[r]));
@@ -384,17 +397,18 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
             for (int k = 0; k < BS_G; k++) {
                 const float xr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xg.re), k));
                 const float xi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, xg.im), k));
-                const float tr = fma_(xr, cs, -(xi * sn));
-                const float ti = fma_(xr, sn, xi * cs);
+                // (tr, ti) = xr (cs, sn) + xi (-sn, cs): a packed multiply and a packed fma with the roundings of the scalar form
+                float *cell = ring + slot * 64 + lane;
+                const float old = *cell;                                                 // the value leaving the window: read before the distance work, used after it
+                const bs_f2 tt = __builtin_elementwise_fma(bs_f2{xr, xr}, rot_cs, bs_f2{xi, xi} * rot_ns);
+                const float tr = tt.x, ti = tt.y;
                 float d = distance(tr, ti, KIND);
                 if (decltype(EDGE)::value && (lg + k < 0 || lg + k >= L)) d = 0.f;   // rows outside the capture only feed outputs that are forced to 0
-                float *cell = ring + slot * 64 + lane;
-                const float old = *cell;
                 *cell = d;
                 s += d;
                 s -= old;
                 slot = slot + 1 == W ? 0 : slot + 1;
-                tb[k * BS_TP + lane] = s + bias;
+                tb[k * BS_TP + lane] = full ? s : s + bias;
             }
         };
         if (lg >= 0 && lg + BS_G <= L) rows(BsKind<0>{}); else rows(BsKind<1>{});        // wave-uniform
@@ -418,7 +432,8 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
         __syncthreads();
     }
     };
-    if (symmetric) run(BsKind<0>{});                                  // wave-uniform: the loop exists once per alphabet kind
+    if (symmetric && nlmax <= 4) run(BsKind<3>{});                    // wave-uniform: the loop exists once per alphabet kind
+    else if (symmetric) run(BsKind<0>{});
     else if (product) run(BsKind<1>{});
     else run(BsKind<2>{});
 }
@@ -618,16 +633,24 @@ __global__ void __launch_bounds__(UW_THREADS) unwrap_apply_kernel(const Cx<R> *E
     int woff = 0;
     for (int w = 0; w < (int)(threadIdx.x >> 6); w++) woff += wsum[w];
     const int off = chunk_off[mode * nchunk + blockIdx.x] + woff + tsum[threadIdx.x];
+    // the scan wants consecutive symbols per thread, the memory system consecutive symbols per LANE: the running correction of
+    // every symbol goes through LDS and the de-rotation walks the chunk in coalesced order (PMC: the per-thread-consecutive
+    // form wrote 3.7 x the algorithmic bytes in partial lines)
+    __shared__ int corr[UW_CHUNK];
+#pragma unroll
+    for (int r = 0; r < UW_PER_THREAD; r++) corr[threadIdx.x * UW_PER_THREAD + r] = off + jmp[r];
+    __syncthreads();
     const R pi = (R)3.14159265358979323846;
 #pragma unroll
     for (int r = 0; r < UW_PER_THREAD; r++) {
-        const int64_t i = t0 + r;
+        const int e = r * UW_THREADS + threadIdx.x;
+        const int64_t i = base + e;
         if (i < L) {
             const bool interior = (i >= N && i < L - N);
             const int k = ix[i];
             // edges keep the raw grid value of idx = 0, i.e. angles[0] (phaserecovery.py:155 unwraps the interior only)
             R p = angles[k];
-            if (interior) p += (pi / 2) * (R)(off + jmp[r]);
+            if (interior) p += (pi / 2) * (R)corr[e];
             ph[mode * L + i] = p;
             R sn, cs;
             sincos_<R>(p, &sn, &cs);

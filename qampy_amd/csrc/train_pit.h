@@ -860,7 +860,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     const int ntot = nmodes * ntaps;
     QH_REQUIRE(ntot <= 64 * 16, "train_equaliser: more than 1024 taps per output mode are not supported");
     const int npass = o.max_passes > 0 ? o.max_passes : 8;
-    const double tol = o.tol > 0 ? o.tol : 0.02;
+    const double tol = o.tol > 0 ? o.tol : 0.01;
     const double gear = o.gear > 0 ? o.gear : 8.0;
     const double bound = o.acq_bound > 0 ? o.acq_bound : 0.08;
     const double plateau = o.acq_plateau > 0 ? o.acq_plateau : 0.9;

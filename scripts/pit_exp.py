@@ -43,6 +43,11 @@ VARIANTS = {
     "gear12c2048": (dict(gear=12., acq_bound=0.12, acq_chunk=2048), {}),
     "gear16c1024": (dict(gear=16., acq_bound=0.16, acq_chunk=1024), {}),
     "c1024": (dict(acq_chunk=1024), {}),
+    "tolF=.01": ({}, dict(tol=0.01)),
+    "tolF=.005": ({}, dict(tol=0.005)),
+    "tolF=.0025": ({}, dict(tol=0.0025)),
+    "tol1=.02,F=.005": (dict(tol=0.02), dict(tol=0.005)),
+    "tol1=.1,F=.005": (dict(tol=0.1), dict(tol=0.005)),
 }
 
 ap = argparse.ArgumentParser()
@@ -50,6 +55,7 @@ ap.add_argument("--workload", default="c3")
 ap.add_argument("--nsym", type=int, default=None)
 ap.add_argument("--seeds", default="1000")
 ap.add_argument("--linewidth", type=float, default=None)
+ap.add_argument("--snr", type=float, default=None)
 ap.add_argument("--variants", default="default")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--no-exact", action="store_true")
@@ -57,6 +63,8 @@ args = ap.parse_args()
 cfg = dict(bench.WORKLOADS[args.workload])
 if args.linewidth is not None:
     cfg["linewidth"] = args.linewidth
+if args.snr is not None:
+    cfg["snr_db"] = args.snr
 nsym = args.nsym or cfg["nsym"]
 _lib.init(0)
 out = []

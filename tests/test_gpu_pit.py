@@ -126,8 +126,8 @@ def test_ser_equivalence_at_scale():
         assert all(st["segments"] >= 64 for st in res[k]["rep"])
         assert all(abs(a - b) <= 3 for a, b in zip(errs["a"], errs[k])), errs
     assert all(st["passes"] <= 4 for st in res["b"]["rep"]), res["b"]["rep"]
-    # deviation from the exact path (modulo a common quarter turn per mode): default tolerance ~1e-3 rms at the output,
-    # tight tolerance an order of magnitude below
+    # deviation from the exact path (modulo a common quarter turn per mode): ~0.6 x the last boundary defect, i.e. 2e-3 rms at
+    # the default tolerance (0.01) and an order of magnitude below at 1e-3
     def dev(r):
         out = []
         for m in range(2):
@@ -136,7 +136,7 @@ def test_ser_equivalence_at_scale():
                         np.sqrt(np.mean(np.abs(res["a"]["eq"][m] - g * r["eq"][m]) ** 2))))
         return np.array(out)
     d_b, d_t = dev(res["b"]), dev(res["b_tight"])
-    assert d_b[:, 1].max() < 1.5e-2 and d_t[:, 1].max() < 1e-3 and d_t[:, 0].max() < 2e-2, (d_b.tolist(), d_t.tolist(), [r["rep"] for r in res.values()])
+    assert d_b[:, 1].max() < 8e-3 and d_t[:, 1].max() < 1e-3 and d_t[:, 0].max() < 2e-2, (d_b.tolist(), d_t.tolist(), [r["rep"] for r in res.values()])
     # the CPU oracle (reference-flag build) on the same capture
     E = d["E"].to_host()
     w = core_eq._init_taps(ntaps, 2, 2, np.complex64)
@@ -151,3 +151,25 @@ def test_ser_equivalence_at_scale():
     from qampy_amd.core import ber_functions as ber
     e_cpu = [s["errors"] for s in ber.cal_ser_dev(rx.out, d["idx_tx"], rx.alphabet, 256, 8192, 2000)]
     assert all(abs(a - b) <= 3 for a, b in zip(e_cpu, errs["b"])), (e_cpu, errs)
+
+
+def test_ser_equivalence_with_symbol_errors():
+    """24 dB SNR: ~1.2e-3 symbol error rate, where an output deviation of 1 % rms from the sequential result would already cost
+    15 % more errors (the error rate moves with (d/sigma)^2 ~ 10 times the relative change of sigma).  Default tolerances:
+    error counts within 4 standard deviations of the exact path's (the residual difference flips borderline decisions both ways)."""
+    nsym, M, ntaps, mu = 2 ** 21, 64, 41, (2e-4, 2e-4)
+    d = synth.make_capture_dev(M, nsym, nmodes=2, snr_db=24, theta=np.pi / 5.6, dgd=30e-12, linewidth=100., seed=1001)
+    kw = dict(methods=("cma", "mrde"), Niter=(1, 1), Mtestangles=64, Nbps=20, alphabet=d["alphabet_host"])
+    from qampy_amd.core import ber_functions as ber
+    errs, reps = {}, {}
+    for tier in ("a", "b"):
+        rx = ResidentReceiver(2, 2 * nsym, 2, M, ntaps, mu, tier=tier, **kw)
+        rx.E.copy_from(d["E"])
+        rx.run()
+        errs[tier] = [s["errors"] for s in ber.cal_ser_dev(rx.out, d["idx_tx"], rx.alphabet, 256, 8192, 2000)]
+        reps[tier] = rx.pit_reports()
+        del rx
+    assert all(st["converged"] for st in reps["b"]), reps["b"]
+    assert min(errs["a"]) > 500, errs                                   # the capture does have symbol errors
+    for a, b in zip(errs["a"], errs["b"]):
+        assert abs(a - b) <= 4 * np.sqrt(a), (errs, reps["b"])
