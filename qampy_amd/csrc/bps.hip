@@ -452,8 +452,8 @@ template <typename R> static int bps_tile(int A, int N, size_t *lds)
 template <typename R> inline bool bps_stream_ok(int64_t, int, int, int) { return false; }
 template <> inline bool bps_stream_ok<float>(int64_t p, int A, int N, int M)
 {
-    static int off = -1;
-    if (off < 0) { const char *e = getenv("QAMPY_HIP_BPS"); off = e && !strcmp(e, "tile") ? 1 : 0; }
+    const char *e = getenv("QAMPY_HIP_BPS");                           // "tile": force the tile kernel (tests compare the two)
+    const bool off = e && !strcmp(e, "tile");
     return !off && p == 1 && A <= 64 && 2 * N <= BS_MAXRING && M >= 1;
 }
 

@@ -12,7 +12,7 @@ import pytest
 from conftest import CT, RT, TOL, golden_cases
 from oracle import oracle
 import qampy_amd
-from qampy_amd import synth
+from qampy_amd import synth, theory
 from qampy_amd.signals import SignalQAM
 from qampy_amd.core.equalisation import hip_equalisation as hk
 from qampy_amd.core.equalisation import equalisation as core_eq
@@ -407,3 +407,46 @@ def test_dsp_fuzz_against_oracle():
     out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "fuzz_dsp.py"),
                           "300", "7"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "300 cases, 0 failures" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------ phase search: streaming vs tile kernel
+def _alphabets():
+    q16, q64 = theory.coded_symbols_qam(16, dtype=np.complex64), theory.coded_symbols_qam(64, dtype=np.complex64)
+    jit = np.random.default_rng(5).normal(size=(16, 2)) * 0.04                                # 16 points off the grid: not a product of levels
+    irregular = (q16 + jit[:, 0] + 1j * jit[:, 1]).astype(np.complex64)
+    return {"qam4": theory.coded_symbols_qam(4, dtype=np.complex64), "qam16": q16, "qam64": q64, "qam256": theory.coded_symbols_qam(256, dtype=np.complex64),
+            "qam1024": theory.coded_symbols_qam(1024, dtype=np.complex64),
+            "qam16_shifted": (q16 + np.complex64(0.11 - 0.07j)).astype(np.complex64),            # a product of levels, not mirror symmetric
+            "qam32_cross": theory.coded_symbols_qam(32, dtype=np.complex64), "irregular16": irregular,   # not products
+            "qam64_rect": (q64.real * 1.0 + 1j * q64.imag * 0.5).astype(np.complex64)}         # symmetric product with different levels per axis
+
+
+@pytest.mark.parametrize("name", ["qam4", "qam16", "qam64", "qam256", "qam1024", "qam16_shifted", "qam32_cross", "irregular16", "qam64_rect"])
+@pytest.mark.parametrize("L,A,N", [(1, 64, 3), (39, 64, 20), (40, 64, 20), (41, 33, 20), (1000, 64, 20), (3 * 1024 + 17, 64, 20), (5000, 5, 1), (4097, 64, 96),
+                                   (2500, 17, 33)])
+def test_bps_stream_kernel_equals_tile_kernel_and_double_oracle(monkeypatch, name, L, A, N):
+    """complex64, one grid of <= 64 angles: the streaming kernel (lane <-> angle, LDS ring, every alphabet kind handled in the
+    kernel) against the tile kernel on the same data and against the oracle run in double precision on the same values (the
+    'true' arg-min: no running-sum drift).  Edges: capture shorter than / equal to / one longer than the window, ragged chunks,
+    the longest ring, grids that leave lanes without an angle."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(repr((name, L, A, N)).encode()))
+    alphabet = _alphabets()[name]
+    scale = np.sqrt(np.mean(np.abs(alphabet) ** 2))
+    sig = (alphabet[rng.integers(0, alphabet.size, L)] * np.exp(1j * (0.2 + 0.002 * np.cumsum(rng.normal(size=L)))) +
+           0.04 * scale * (rng.normal(size=L) + 1j * rng.normal(size=L))).astype(np.complex64)
+    ang = np.linspace(-np.pi / 4, np.pi / 4, A, endpoint=False, dtype=np.float32).reshape(1, -1)
+    monkeypatch.delenv("QAMPY_HIP_BPS", raising=False)
+    i_s = hip_dsp.bps(sig, ang, alphabet, N)
+    monkeypatch.setenv("QAMPY_HIP_BPS", "tile")
+    i_t = hip_dsp.bps(sig, ang, alphabet, N)
+    monkeypatch.delenv("QAMPY_HIP_BPS", raising=False)
+    i_o = oracle.bps(sig.astype(np.complex128), ang.astype(np.float64), alphabet.astype(np.complex128), N)
+    assert i_s.shape == i_t.shape == (L,) and i_s.dtype == np.int32
+    assert np.all(i_s[:N] == 0) and np.all(i_s[max(L - N, 0):] == 0)
+    for other, bar in ((i_t, 2e-3), (i_o, 5e-3)):
+        mism = np.nonzero(i_s != other)[0]
+        assert mism.size <= max(1, int(bar * L)), (mism.size, L)
+        if mism.size:                                  # a flipped near-tie goes to a neighbouring angle
+            d = np.abs(i_s[mism].astype(int) - other[mism])
+            assert np.all(np.minimum(d, A - d) <= 1)
