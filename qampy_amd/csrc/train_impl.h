@@ -473,11 +473,14 @@ static size_t gram_budget()
 template <typename R>
 int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu_dev, void *wx, int ntaps,
               const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy, int method, void *err,
-              int zero_err, const void *gram = nullptr, int nch = 1)
+              int zero_err, const void *gram = nullptr, int nch = 1, int64_t chan_stride = 0, int64_t row_pitch = 0)
 {
     int rc = ensure_init();
     if (rc) return rc;
     if (method < 0 || method > QH_M_SBD_DATA) { set_error("unknown equaliser method id"); return QH_ERR_METHOD; }
+    // chan_stride / row_pitch (elements; 0: contiguous captures): "channels" that are equally spaced, overlapping windows of
+    // ONE capture whose rows are row_pitch apart (the window batch of frame_sync) - block forms only
+    const int64_t Lp = row_pitch ? row_pitch : L, Ecs = chan_stride ? chan_stride : (int64_t)nmodes * L;
     // nch > 1: a bank of independent captures with identical shapes, arrays (nch, ...) contiguous, one mu per channel; the
     // look-ahead / block-iterative kernels take the channel as blockIdx.y, anything else runs channel after channel
     QH_REQUIRE(nch >= 1 && nch <= 65535, "train_equaliser: bad channel count");
@@ -541,9 +544,9 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             }
             LaArgs<R> la;
             la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.gpair = pair_tab ? 1 : 0; la.mu = mu_dev; la.mu_out = use_bi ? (R *)mu_dev : nullptr;
-            la.Lp = L; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
+            la.Lp = Lp; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
             la.os = os; la.nsel = nsel; la.method = method;
-            la.nch = nch; la.E_cs = (int64_t)nmodes * L; la.wx_cs = (int64_t)nmodes * ntot; la.err_cs = (int64_t)nmodes * TrSyms * Niter; la.mu_cs = 1;
+            la.nch = nch; la.E_cs = Ecs; la.wx_cs = (int64_t)nmodes * ntot; la.err_cs = (int64_t)nmodes * TrSyms * Niter; la.mu_cs = 1;
             la.mu_ms = 0;
             for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];
             if (use_bi && decision) {   // the kernel reads the slicer table like an mrde table: row pitch 2*BI_DD_MAXLEV, 2*npart+1 used
@@ -581,8 +584,8 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
                         if (!G && built_step0 == step0 && built_n == n) {
                             G = built;                              // same chunk as the last launch (every sweep of an unchunked call): the table is still there
                         } else if (!G) {
-                            rc = pair_tab ? gram_build<R>(Ec, nmodes, L - step0 * os, os, ntaps, n, &G, nch, L, (int64_t)nmodes * L)
-                                          : gram_cur_build<R>(Ec, nmodes, L - step0 * os, os, ntaps, n, &G, nch, L, (int64_t)nmodes * L);
+                            rc = pair_tab ? gram_build<R>(Ec, nmodes, L - step0 * os, os, ntaps, n, &G, nch, Lp, Ecs)
+                                          : gram_cur_build<R>(Ec, nmodes, L - step0 * os, os, ntaps, n, &G, nch, Lp, Ecs);
                             if (rc) return rc;
                             built = G; built_step0 = step0; built_n = n;
                         }
@@ -611,6 +614,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             }
             return QH_OK;
         }
+        QH_REQUIRE(!chan_stride && !row_pitch, "train_equaliser: strided channels need a block form of the trainer");
         if (per_mode) {                            // one call per mode, each from the initial step size
             void *pm = nullptr;
             if ((rc = scratch(6, (size_t)nch * sizeof(R), &pm))) return rc;
@@ -674,6 +678,15 @@ __global__ void __launch_bounds__(64) win_best_kernel(const double *var, int nwi
 // Search form (var_out != nullptr; wx_out / err / mu_out may then be nullptr): the error traces stay in HBM, only their
 // variances var_out (nmodes, nwin), the window with the smallest variance per mode best (nmodes) and the tap sets of those
 // windows wx_best (nmodes, nmodes, nmodes, ntaps) come back - what the frame synchronisation needs (pilotbased_receiver.py:395-405).
+// can the look-ahead / block-iterative kernels take this call (without slicer tables)?  (the window batch asks before it
+// hands its windows over as strided channels)
+template <typename R> static bool block_forms_ok(int method, int adaptive, int nmodes, int ntaps, int os, int64_t TrSyms, int64_t nsy)
+{
+    if (trainer_force()[0] == 'd') return false;
+    if (method == QH_M_SBD || method == QH_M_MDDMA || method == QH_M_DD || method == QH_M_SBD_DATA) return false;
+    return la_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy) || bi_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy, sizeof(Cx<R>));
+}
+
 template <typename R>
 int train_windows_host(const void *E, int nmodes, int64_t L, const int64_t *win_start, int nwin, int64_t win_len, int64_t TrSyms,
                        int Niter, int os, R mu, const void *wx0, int ntaps, const int64_t *modes, int nsel, int adaptive,
@@ -706,7 +719,18 @@ int train_windows_host(const void *E, int nmodes, int64_t L, const int64_t *win_
     QH_HIP(hipMemsetAsync(de.p, 0, de.n ? de.n : 1, g_stream));
     for (int v = 0; v < nwin; v++)                       // every window starts from (and keeps, for unselected modes) the initial taps
         QH_HIP(hipMemcpyAsync((char *)dwo.p + (size_t)v * wsz * cs, dw.p, wsz * cs, hipMemcpyDeviceToDevice, g_stream));
-    if (TrSyms > 0 && Niter > 0) {
+    // equally spaced windows are the channels of a bank whose captures overlap: a FEW of them go to the latency forms of the
+    // trainer (3 x fewer cycles per step on the critical path).  Hundreds of windows fill the chip either way, and then the direct
+    // form - one wave per chain instead of four or eight - is the cheaper one: 260 windows x 2 modes of the config-5 frame search
+    // take 3.4 ms direct, 5.6 ms block-iterative (measured), so it keeps them, as it does irregular starts and the other methods.
+    bool strided = (int64_t)nwin * nsel <= 64 && (nwin == 1 || win_start[1] > win_start[0]);
+    for (int v = 2; v < nwin && strided; v++) strided = win_start[v] - win_start[v - 1] == win_start[1] - win_start[0];
+    if (TrSyms > 0 && Niter > 0 && strided && block_forms_ok<R>(method, adaptive ? 1 : 0, nmodes, ntaps, os, TrSyms, nsy)) {
+        hipLaunchKernelGGL((spread_kernel<R>), dim3((unsigned)((nwin + 63) / 64)), dim3(64), 0, g_stream, (R *)dmo.p, (const R *)dmu.p, nwin, nwin);
+        rc = train_dev<R>((const Cx<R> *)dE.p + win_start[0], nmodes, win_len, TrSyms, Niter, os, (R *)dmo.p, dwo.p, ntaps, modes, nsel, adaptive ? 1 : 0, ds.p, nsy,
+                          method, de.p, 0, nullptr, nwin, nwin > 1 ? win_start[1] - win_start[0] : L, L);
+        if (rc) return rc;
+    } else if (TrSyms > 0 && Niter > 0) {
         TrainArgs<R> a;
         a.E = (const Cx<R> *)dE.p; a.wx = (Cx<R> *)dw.p; a.symbols = (const Cx<R> *)ds.p; a.err = (Cx<R> *)de.p; a.mu = (R *)dmu.p;
         a.L = L; a.TrSyms = TrSyms; a.nsy = nsy; a.nmodes = nmodes; a.ntaps = ntaps; a.Niter = Niter; a.os = os;

@@ -450,3 +450,38 @@ def test_bps_stream_kernel_equals_tile_kernel_and_double_oracle(monkeypatch, nam
         if mism.size:                                  # a flipped near-tie goes to a neighbouring angle
             d = np.abs(i_s[mism].astype(int) - other[mism])
             assert np.all(np.minimum(d, A - d) <= 1)
+
+
+# ------------------------------------------------------------------------------------------------ window batch
+@pytest.mark.parametrize("nwin,hop,method,adaptive", [(6, 700, "cma", False), (5, 512, "cma", True), (4, 900, "mrde", False), (7, None, "cma", False),
+                                                      (48, 128, "mcma", False)])
+@pytest.mark.parametrize("dn", ["c64", "c128"])
+def test_window_batch_equals_one_call_per_window(nwin, hop, method, adaptive, dn):
+    """qh_train_equaliser_windows_*: a few equally spaced windows run as strided channels of the latency forms, many windows or
+    irregular starts (hop None) in the direct form - every window must be what a call on that slice returns (oracle), and the
+    search form must pick the window with the smallest error variance."""
+    M = 64 if method == "mrde" else 16
+    sig = synth.make_capture(M, 6000, nmodes=2, snr_db=27, theta=np.pi / 5.6, dgd=30e-12, seed=77, dtype=CT[dn])
+    E = np.ascontiguousarray(np.asarray(sig))
+    ntaps, win_len, Niter = 13, 2048, 2
+    starts = (np.arange(nwin) * hop if hop else np.array([0, 300, 1111, 1500, 2900, 4000, 5100][:nwin])).astype(np.int64)
+    tr = core_eq._cal_training_symbol_len(2, ntaps, win_len)
+    w0 = core_eq._init_taps(ntaps, 2, 2, CT[dn])
+    if method == "mrde":
+        _, w0, _ = oracle.train_equaliser(E, core_eq._cal_training_symbol_len(2, ntaps, E.shape[1]), 2, 2, RT[dn](2e-3), w0, None, False,
+                                          core_eq._reshape_symbols(None, "mcma", M, CT[dn], 2), "mcma")
+    sy = core_eq._reshape_symbols(None, method, M, CT[dn], 2)
+    mu = RT[dn](1e-3)
+    err, wx, mus = hk.train_equaliser_windows(E, starts, win_len, tr, Niter, 2, mu, w0, None, adaptive, sy, method)
+    t = dict(rtol=1e-9, atol=1e-11) if dn == "c128" else dict(rtol=3e-4, atol=3e-5)
+    for v, s0 in enumerate(starts):
+        eo, wo, mo = oracle.train_equaliser(np.ascontiguousarray(E[:, s0:s0 + win_len]), tr, Niter, 2, mu, w0.copy(), None, adaptive, sy, method)
+        np.testing.assert_allclose(wx[v], wo, **t)
+        np.testing.assert_allclose(err[v], eo, rtol=t["rtol"], atol=t["atol"] * 5)
+        np.testing.assert_allclose(mus[v], mo, rtol=1e-9 if dn == "c128" else 2e-4)
+    var, best, wbest = hk.train_equaliser_windows_search(E, starts, win_len, tr, Niter, 2, mu, w0, None, adaptive, sy, method)
+    ref_var = np.var(err, axis=-1).T
+    np.testing.assert_allclose(var, ref_var, rtol=1e-6 if dn == "c128" else 2e-3)
+    assert np.array_equal(best, np.argmin(ref_var, axis=-1)) or np.allclose(np.sort(ref_var, axis=-1)[:, 0], np.sort(ref_var, axis=-1)[:, 1], rtol=1e-3)
+    for m in range(2):
+        np.testing.assert_allclose(wbest[m], wx[best[m]], **t)
