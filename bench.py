@@ -62,7 +62,7 @@ WORKLOADS["c5"] = dict(M=256, nsym=2 ** 16, ntaps=45, methods=("cma", "sbd_data"
                        label="pilot-based 256-QAM 2-pol 2 SPS, 2^16-symbol frames: frame sync + data-aided pilot equaliser + filter + pilot phase recovery")
 VALU_PEAK_TFLOPS = 157.3        # fp32 vector (packed FMA), MI355X_MICROARCH.md
 VALU_PEAK_GINSTR = 614.4        # wave64 fp32 instructions per second, nominal: 1024 SIMDs x 2.4 GHz / 4 cycles (measured, clock-throttled ceilings: 697 plain v_fma, 537 v_pk_fma - profiles/r02_ubench_issue.txt)
-SEG_INSTR_PER_WAVE_STEP = 68    # train_seg_kernel main loop (ISA count)
+SEG_INSTR_PER_WAVE_STEP = {16: 68, 8: 94}    # train_seg_kernel main loop per wave and step by lanes per chain (ISA count at 41 taps x 2 modes)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FUSED_BYTES_PER_SYM = 88   # read E once, write err1, err2, out, ph (complex64, 2 modes, 2 samples/symbol)
 SER_TOL_ERRORS = 3         # tier b counts as SER-equivalent when every mode is within this many symbol errors of tier a
@@ -698,15 +698,18 @@ def main():
             chains = st["S"] * rx.modes.size
             ntot = rx.nmodes * rx.Ntaps
             flops = chains * st["seg_len"] * (2 * ntot) * 8.0           # filter + update: 2 x ntot complex multiply-adds per chain and step
-            waves = (chains + 3) // 4
-            winstr = waves * st["seg_len"] * SEG_INSTR_PER_WAVE_STEP
+            tpl8 = 11 if rx.nmodes * -(-rx.Ntaps // 11) <= 8 and 11 * -(-rx.Ntaps // 11) - rx.Ntaps <= 3 else (6 if rx.nmodes * -(-rx.Ntaps // 6) <= 8 and 6 * -(-rx.Ntaps // 6) - rx.Ntaps <= 3 else 0)
+            lpc = 8 if chains >= 3000 and tpl8 else 16                  # launch_seg's rule (train_seg.h)
+            ipw = SEG_INSTR_PER_WAVE_STEP[lpc]
+            waves = -(-chains // (64 // lpc))
+            winstr = waves * st["seg_len"] * ipw
             roofline["valu"] = dict(bound="valu-issue", flops_per_launch=int(flops), achieved_tflops=round(flops / (kms * 1e-3) / 1e12, 2), peak_tflops=VALU_PEAK_TFLOPS,
-                                    frac=round(flops / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4), chains=int(chains), waves=int(waves), steps_per_chain=int(st["seg_len"]),
-                                    instr_per_wave_step=SEG_INSTR_PER_WAVE_STEP, achieved_ginstr_s=round(winstr / (kms * 1e-3) / 1e9, 1), peak_ginstr_s=VALU_PEAK_GINSTR,
-                                    issue_frac=round(winstr / (kms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4),
-                                    note="16 lanes per chain, 4 chains per wave; 68 instructions per wave and step of which 24 are packed FMAs (the recurrence's "
-                                         "arithmetic) - counted in the ISA of train_seg_kernel<float, cma, 0, 6>; peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 "
-                                         "instruction; with one wave per SIMD (stage 1) a wave issues one instruction per ~8 cycles (profiles/r02_ubench_*.txt)")
+                                    frac=round(flops / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4), chains=int(chains), lanes_per_chain=lpc, waves=int(waves),
+                                    steps_per_chain=int(st["seg_len"]), instr_per_wave_step=ipw, achieved_ginstr_s=round(winstr / (kms * 1e-3) / 1e9, 1),
+                                    peak_ginstr_s=VALU_PEAK_GINSTR, issue_frac=round(winstr / (kms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4),
+                                    note="8 (16) lanes per chain, 8 (4) chains per wave; 94 (68) instructions per wave and step, 44 (24) of them the packed FMAs of "
+                                         "the recurrence - counted in the ISA of train_seg_kernel<float, cma, 0, 11, 8> (<.., 6, 16>) at 41 taps x 2 modes; peak = 1024 SIMDs "
+                                         "x 2.4 GHz / 4 cycles per wave64 instruction; a lone wave on a SIMD issues one instruction per ~8 cycles (profiles/r02_ubench_*.txt)")
     else:
         dom = int(np.argmax(head_ms))
         achieved = stage_bytes[dom] / (head_ms[dom] * 1e-3) / 1e9

@@ -4,16 +4,18 @@
 // for with a 1 KiB-per-step Gram table; block-iterative: 8 waves per chain).  With thousands of chains in flight the stage is
 // bound by instruction issue (and the look-ahead form by streaming its table: 4.3 GB per pass at C3), so this kernel spends
 // as few instructions per chain and step as the recurrence allows and reads nothing but the capture:
-//   * 16 lanes per chain, 4 chains per wave64 (one wave per workgroup, no workgroup barrier anywhere);
-//   * the nmodes*ntaps taps of a chain are spread over its 16 lanes, TPL consecutive taps of one input mode per lane, and live
+//   * LPC = 16 or 8 lanes per chain, 4 or 8 chains per wave64 (one wave per workgroup, no workgroup barrier anywhere);
+//   * the nmodes*ntaps taps of a chain are spread over its lanes, TPL consecutive taps of one input mode per lane, and live
 //     in registers for the whole segment; per step a lane reads its TPL samples from an LDS window (staged chunk-wise with
 //     coalesced loads, double buffered; chains of the same segment - its output modes - share the window);
-//   * the dot product is reduced over the 16 lanes with 4 DPP steps (quad_perm, row_half_mirror, row_mirror: every lane ends
-//     up with the total), the error function is evaluated redundantly in all lanes, every lane updates its own taps;
-//   * ~45 instructions per step for 4 chains (~11 per chain and step, against ~25 of the look-ahead form over its 4 waves and
-//     ~125 of the block-iterative one).
+//   * the dot product is reduced over the chain's lanes with 3 or 4 DPP steps (quad_perm, row_half_mirror, row_mirror: every
+//     lane ends up with the total), the error function is evaluated redundantly in all lanes, every lane updates its own taps;
+//   * the complex multiply-adds are packed FMAs with operand selectors (pk_re / pk_im / pk_im_rot below);
+//   * per wave and step at 41 taps x 2 modes: 68 instructions for 4 chains (16 lanes, 6 taps per lane), 94 for 8 chains (8 lanes,
+//     11 taps per lane) - 17 / 11.8 per chain and step, against ~25 of the look-ahead form over its 4 waves and ~125 of the
+//     block-iterative one.  8 lanes per chain is used from 3000 chains on (single precision, layouts with 6 or 11 taps per lane).
 // Same recurrence, same error functions (la_errfn); results equal the other forms up to the order of the additions in the dot
-// product (16-lane tree instead of 64-lane tree / look-ahead identity).
+// product (lane tree instead of 64-lane tree / look-ahead identity).
 #pragma once
 #include "train_bi.h"
 
@@ -89,29 +91,56 @@ __device__ __forceinline__ sg_d2 pk_im(sg_d2 x, sg_d2 b, sg_d2 acc) { return __b
 __device__ __forceinline__ sg_d2 pk_im_rot(sg_d2 x, sg_d2 b, sg_d2 acc) { return __builtin_elementwise_fma(sg_d2{x.y, x.y}, sg_d2{b.y, -b.x}, acc); }
 template <int N> struct SgInt { static constexpr int value = N; };
 
+// sum over the 8 lanes of a half row
+__device__ __forceinline__ void row8_csum(float &re, float &im)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        : "+v"(re), "+v"(im));
+}
+__device__ __forceinline__ void row8_csum(double &re, double &im)
+{
+    re += dpp_mov<DPP_QUAD_1032>(re);       im += dpp_mov<DPP_QUAD_1032>(im);
+    re += dpp_mov<DPP_QUAD_2301>(re);       im += dpp_mov<DPP_QUAD_2301>(im);
+    re += dpp_mov<DPP_ROW_HALF_MIRROR>(re); im += dpp_mov<DPP_ROW_HALF_MIRROR>(im);
+}
+template <int LPC, typename R> __device__ __forceinline__ void chain_csum(R &re, R &im)
+{
+    if (LPC == 8) row8_csum(re, im); else row16_csum(re, im);
+}
+
 constexpr int SG_PITCH = 192;      // samples per LDS row (one segment window of one input mode): 3 pieces of 64
 constexpr int SG_PIECES = SG_PITCH / 64;
-constexpr int SG_ROWS = 4;         // rows per buffer: segment windows of the wave x input modes
-constexpr int SG_NSTG = SG_ROWS * SG_PIECES;      // staging registers per lane
+// rows per buffer (segment windows of the wave x input modes) = chains per wave; staging registers per lane = rows x pieces
 constexpr int SG_MAXRAG = 3;       // padding taps a lane may hold (handled by selects on its last three tap slots)
 
-template <typename R, int METHOD, int NPART, int TPL>
+template <typename R, int METHOD, int NPART, int TPL, int LPC>
 __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
 {
+    constexpr int CPW = 64 / LPC;                               // chains per wave
+    constexpr int SG_ROWS = CPW, SG_NSTG = SG_ROWS * SG_PIECES;
     if (a.skip && *a.skip) return;
     extern __shared__ __attribute__((aligned(16))) char sg_smem[];
     Cx<R> *lds = reinterpret_cast<Cx<R> *>(sg_smem);          // [2 buffers][SG_ROWS][SG_PITCH] + zero row [SG_PITCH]
     using v2 = typename V2<R>::type;
     const int lane = threadIdx.x;
-    const int l16 = lane & 15;
+    const int l16 = lane & (LPC - 1);                          // lane within the chain
     const int nq = a.S * a.nsel;                               // chains of the launch
-    const int q0 = blockIdx.x * 4;
-    const int q = q0 + (lane >> 4);
+    const int q0 = blockIdx.x * CPW;
+    const int q = q0 + lane / LPC;
     const bool alive = q < nq;
     const int qc = alive ? q : nq - 1;
     const int seg = qc / a.nsel, jsel = qc - seg * a.nsel;
     const int seg0 = q0 / a.nsel;                              // first segment of this wave
-    const int segl = ((q0 + 3 < nq ? q0 + 3 : nq - 1)) / a.nsel;
+    const int segl = ((q0 + CPW - 1 < nq ? q0 + CPW - 1 : nq - 1)) / a.nsel;
     const int nslot = segl - seg0 + 1;
     const int slot = seg - seg0;
     const int mode = (int)a.modes[jsel];
@@ -123,7 +152,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     const int my_steps = alive ? seg_steps(seg) : 0;
     int max_steps = 0, min_steps = 0x7fffffff;                  // over the chains of the wave (a wave with a dead chain checks every step)
     for (int s = seg0; s <= segl; s++) { const int n = seg_steps(s); max_steps = n > max_steps ? n : max_steps; min_steps = n < min_steps ? n : min_steps; }
-    if (q0 + 3 >= nq) min_steps = 0;
+    if (q0 + CPW - 1 >= nq) min_steps = 0;
 
     // ---- taps: lane <-> TPL consecutive taps of input mode kin
     const int kin = l16 / a.lpm, t0 = (l16 - kin * a.lpm) * TPL;
@@ -200,12 +229,12 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
             r = pk_im(x[j], w[j], r);                          // x.im * (w.re, w.im)
         }
         R yr = p.x - r.y, yi = p.y + r.x;
-        row16_csum(yr, yi);
+        chain_csum<LPC>(yr, yi);
         const Cx<R> y{yr, yi};
         const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K);
         Cx<R> cc = la_errfn<R, METHOD, NPART, true>(y, K);     // mu * e with mu folded in
         if (decltype(CHK)::value && gstep >= my_steps) cc = Cx<R>{0, 0};   // past the end of this chain's segment: nothing moves
-        const bool mine = l16 == (i & 15);
+        const bool mine = l16 == (i & (LPC - 1));
         ebr = mine ? e.re : ebr;
         ebi = mine ? e.im : ebi;
         // w += c conj(x):  (re, im) += x.re (c.re, c.im) + x.im (c.im, -c.re)
@@ -227,15 +256,15 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
             step(xa, i, ibase + i, CHK, RG);
             load_x(xa, xs + (i + 2) * xstep);                   // may look one step past the chunk: inside the row's slack
             step(xb, i + 1, ibase + i + 1, CHK, RG);
-            if (((i + 1) & 15) == 15) {                         // 16 errors per chain staged: one store per chain
-                const int gi = ibase + i + 1 - 15 + l16;
+            if (((i + 1) & (LPC - 1)) == LPC - 1) {             // LPC errors per chain staged: one store per chain
+                const int gi = ibase + i + 1 - (LPC - 1) + l16;
                 if (gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
             }
         }
         if (i < nst) { step(xa, i, ibase + i, CHK, RG); i++; }
-        if ((nst & 15) != 0) {                                   // ragged end of the last chunk
-            const int gi = ibase + (nst & ~15) + l16;
-            if (l16 < (nst & 15) && gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
+        if ((nst & (LPC - 1)) != 0) {                            // ragged end of the last chunk
+            const int gi = ibase + (nst & ~(LPC - 1)) + l16;
+            if (l16 < (nst & (LPC - 1)) && gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
         }
     };
 
@@ -270,18 +299,22 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-inline int seg_tpl(int nmodes, int ntaps)
+// taps per lane for `lpc` lanes per chain (0: no layout).  16 lanes per chain is the general form; 8 lanes per chain (8 chains
+// per wave, instantiated for single precision and 6 / 11 taps per lane) issues 0.64 x the instructions per chain and step and
+// is what launches with many chains use (see launch_seg).
+inline int seg_tpl(int nmodes, int ntaps, int lpc = 16)
 {
-    for (int tpl : {2, 4, 6, 8}) {
+    for (int tpl : {2, 4, 6, 8, 11}) {
+        if (lpc == 16 ? tpl == 11 : (tpl != 6 && tpl != 11)) continue;
         const int lpm = (ntaps + tpl - 1) / tpl;
-        if (nmodes * lpm <= 16 && lpm * tpl - ntaps <= SG_MAXRAG && lpm * tpl - ntaps < tpl) return tpl;
+        if (nmodes * lpm <= lpc && lpm * tpl - ntaps <= SG_MAXRAG && lpm * tpl - ntaps < tpl) return tpl;
     }
     return 0;
 }
-inline int seg_slots(int nsel)                                      // distinct segments among the 4 chains of a wave
+inline int seg_slots(int nsel, int cpw = 4)                         // distinct segments among the chains of a wave
 {
     int n = 1;
-    for (int q0 = 0; q0 <= 4 * nsel; q0 += 4) { const int m = (q0 + 3) / nsel - q0 / nsel + 1; n = m > n ? m : n; }
+    for (int q0 = 0; q0 <= cpw * nsel; q0 += cpw) { const int m = (q0 + cpw - 1) / nsel - q0 / nsel + 1; n = m > n ? m : n; }
     return n;
 }
 inline bool seg_supported(int method, int nmodes, int ntaps, int os, int64_t nsy, size_t elem, int nsel = 1)
@@ -289,7 +322,7 @@ inline bool seg_supported(int method, int nmodes, int ntaps, int os, int64_t nsy
     (void)elem;
     if (seg_tpl(nmodes, ntaps) == 0) return false;
     if ((SG_CH + 1) * os + ntaps + 8 > SG_PITCH) return false;      // chunk + one step of look-ahead + padding taps fit a row
-    if (seg_slots(nsel) * nmodes > SG_ROWS) return false;
+    if (seg_slots(nsel) * nmodes > 4) return false;
     switch (method) {
     case QH_M_CMA: case QH_M_SGNCMA: case QH_M_CMA2: case QH_M_MCMA: return true;
     case QH_M_RDE: case QH_M_MRDE: return nsy - (nsy + 1) / 2 >= 1 && nsy - (nsy + 1) / 2 <= LA_MAXPART;
@@ -297,34 +330,53 @@ inline bool seg_supported(int method, int nmodes, int ntaps, int os, int64_t nsy
     default: return false;
     }
 }
-
-template <typename R, int METHOD, int NPART> static int launch_seg_tpl(const SegArgs<R> &a, int tpl, dim3 grid, size_t lds)
+constexpr int SG_LPC8_MIN = 3000;        // chains from which 8 lanes per chain pay (measured at C3: 3840 chains 486 -> 472 us, 7936 chains 386 -> 275 us per pass)
+template <typename R> inline int seg_lanes(int nmodes, int ntaps, int nsel, int nq)
 {
+    const char *e = getenv("QAMPY_HIP_SEG_LANES");                  // 8 | 16: force (measurements, tests)
+    const bool can8 = sizeof(R) == 4 && seg_tpl(nmodes, ntaps, 8) != 0 && seg_slots(nsel, 8) * nmodes <= 8;
+    if (e && atoi(e) == 16) return 16;
+    if (e && atoi(e) == 8) return can8 ? 8 : 16;
+    return can8 && nq >= SG_LPC8_MIN ? 8 : 16;
+}
+
+template <typename R, int METHOD, int NPART> static int launch_seg_tpl(const SegArgs<R> &a, int tpl, int lpc, dim3 grid, size_t lds)
+{
+    if (lpc == 8) {
+        if constexpr (sizeof(R) == 4) {
+            switch (tpl) {
+            case 6: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 6, 8>), grid, dim3(64), lds, g_stream, a); return QH_OK;
+            case 11: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 11, 8>), grid, dim3(64), lds, g_stream, a); return QH_OK;
+            default: break;
+            }
+        }
+        set_error("segment trainer: unsupported tap layout"); return QH_ERR_ARG;
+    }
     switch (tpl) {
-    case 2: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 2>), grid, dim3(64), lds, g_stream, a); break;
-    case 4: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 4>), grid, dim3(64), lds, g_stream, a); break;
-    case 6: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 6>), grid, dim3(64), lds, g_stream, a); break;
-    case 8: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 8>), grid, dim3(64), lds, g_stream, a); break;
+    case 2: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 2, 16>), grid, dim3(64), lds, g_stream, a); break;
+    case 4: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 4, 16>), grid, dim3(64), lds, g_stream, a); break;
+    case 6: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 6, 16>), grid, dim3(64), lds, g_stream, a); break;
+    case 8: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 8, 16>), grid, dim3(64), lds, g_stream, a); break;
     default: set_error("segment trainer: unsupported tap layout"); return QH_ERR_ARG;
     }
     return QH_OK;
 }
-template <typename R, int METHOD> static int launch_seg_parts(const SegArgs<R> &a, int npart, int tpl, dim3 grid, size_t lds)
+template <typename R, int METHOD> static int launch_seg_parts(const SegArgs<R> &a, int npart, int tpl, int lpc, dim3 grid, size_t lds)
 {
-#define QH_SG_NP(N) case N: return launch_seg_tpl<R, METHOD, N>(a, tpl, grid, lds);
+#define QH_SG_NP(N) case N: return launch_seg_tpl<R, METHOD, N>(a, tpl, lpc, grid, lds);
     switch (npart) {
         QH_SG_NP(1) QH_SG_NP(2) QH_SG_NP(3) QH_SG_NP(4) QH_SG_NP(5) QH_SG_NP(6) QH_SG_NP(7) QH_SG_NP(8)
     default: set_error("segment trainer: unsupported partition count"); return QH_ERR_ARG;
     }
 #undef QH_SG_NP
 }
-template <typename R, int METHOD> static int launch_seg_dd(const SegArgs<R> &a, int npart, int tpl, dim3 grid, size_t lds)
+template <typename R, int METHOD> static int launch_seg_dd(const SegArgs<R> &a, int npart, int tpl, int lpc, dim3 grid, size_t lds)
 {
     switch (npart) {            // 4-, 16-, 64-, 256-QAM
-    case 1: return launch_seg_tpl<R, METHOD, 1>(a, tpl, grid, lds);
-    case 3: return launch_seg_tpl<R, METHOD, 3>(a, tpl, grid, lds);
-    case 7: return launch_seg_tpl<R, METHOD, 7>(a, tpl, grid, lds);
-    case 15: return launch_seg_tpl<R, METHOD, 15>(a, tpl, grid, lds);
+    case 1: return launch_seg_tpl<R, METHOD, 1>(a, tpl, lpc, grid, lds);
+    case 3: return launch_seg_tpl<R, METHOD, 3>(a, tpl, lpc, grid, lds);
+    case 7: return launch_seg_tpl<R, METHOD, 7>(a, tpl, lpc, grid, lds);
+    case 15: return launch_seg_tpl<R, METHOD, 15>(a, tpl, lpc, grid, lds);
     default: set_error("segment trainer: unsupported slicer size"); return QH_ERR_ARG;
     }
 }
@@ -332,25 +384,26 @@ template <typename R, int METHOD> static int launch_seg_dd(const SegArgs<R> &a, 
 // `a` complete except lpm / pitch / rag; method-specific table layout as for launch_bi (slicer tables for sbd / mddma / dd)
 template <typename R> int launch_seg(SegArgs<R> a, int method)
 {
-    const int tpl = seg_tpl(a.nmodes, a.ntaps);
+    const int nq = a.S * a.nsel;
+    const int lpc = seg_lanes<R>(a.nmodes, a.ntaps, a.nsel, nq), cpw = 64 / lpc;
+    const int tpl = seg_tpl(a.nmodes, a.ntaps, lpc);
     a.lpm = (a.ntaps + tpl - 1) / tpl;
     a.rag = a.lpm * tpl - a.ntaps;
     a.pitch = SG_PITCH;
-    a.nslots = seg_slots(a.nsel);
-    const size_t lds = (size_t)(2 * SG_ROWS + 1) * SG_PITCH * sizeof(Cx<R>);
-    const int nq = a.S * a.nsel;
-    dim3 grid((nq + 3) / 4);
+    a.nslots = seg_slots(a.nsel, cpw);
+    const size_t lds = (size_t)(2 * cpw + 1) * SG_PITCH * sizeof(Cx<R>);
+    dim3 grid((nq + cpw - 1) / cpw);
     const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
     int rc = QH_OK;
     switch (method) {
-    case QH_M_CMA: case QH_M_SGNCMA: rc = launch_seg_tpl<R, QH_M_CMA, 0>(a, tpl, grid, lds); break;
-    case QH_M_CMA2: rc = launch_seg_tpl<R, QH_M_CMA2, 0>(a, tpl, grid, lds); break;
-    case QH_M_MCMA: rc = launch_seg_tpl<R, QH_M_MCMA, 0>(a, tpl, grid, lds); break;
-    case QH_M_RDE: rc = launch_seg_parts<R, QH_M_RDE>(a, npart, tpl, grid, lds); break;
-    case QH_M_MRDE: rc = launch_seg_parts<R, QH_M_MRDE>(a, npart, tpl, grid, lds); break;
-    case QH_M_SBD: rc = launch_seg_dd<R, QH_M_SBD>(a, npart, tpl, grid, lds); break;
-    case QH_M_MDDMA: rc = launch_seg_dd<R, QH_M_MDDMA>(a, npart, tpl, grid, lds); break;
-    case QH_M_DD: rc = launch_seg_dd<R, QH_M_DD>(a, npart, tpl, grid, lds); break;
+    case QH_M_CMA: case QH_M_SGNCMA: rc = launch_seg_tpl<R, QH_M_CMA, 0>(a, tpl, lpc, grid, lds); break;
+    case QH_M_CMA2: rc = launch_seg_tpl<R, QH_M_CMA2, 0>(a, tpl, lpc, grid, lds); break;
+    case QH_M_MCMA: rc = launch_seg_tpl<R, QH_M_MCMA, 0>(a, tpl, lpc, grid, lds); break;
+    case QH_M_RDE: rc = launch_seg_parts<R, QH_M_RDE>(a, npart, tpl, lpc, grid, lds); break;
+    case QH_M_MRDE: rc = launch_seg_parts<R, QH_M_MRDE>(a, npart, tpl, lpc, grid, lds); break;
+    case QH_M_SBD: rc = launch_seg_dd<R, QH_M_SBD>(a, npart, tpl, lpc, grid, lds); break;
+    case QH_M_MDDMA: rc = launch_seg_dd<R, QH_M_MDDMA>(a, npart, tpl, lpc, grid, lds); break;
+    case QH_M_DD: rc = launch_seg_dd<R, QH_M_DD>(a, npart, tpl, lpc, grid, lds); break;
     default: return QH_ERR_METHOD;
     }
     if (rc) return rc;

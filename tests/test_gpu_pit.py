@@ -44,10 +44,13 @@ def _run_pit(E, tr, niter, mu, w0, sy, method, pit, rt):
     return dw.to_host(), derr.to_host(), rep.read()
 
 
-@pytest.mark.parametrize("form", ["auto", "direct"])
+@pytest.mark.parametrize("form", ["auto", "direct", "segment16", "segment8"])
 @pytest.mark.parametrize("method,M", [("mcma", 16), ("cma", 16), ("mrde", 64), ("sbd", 16)])
 def test_relaxation_fixed_point_is_the_sequential_recurrence(method, M, form, monkeypatch):
-    if form != "auto":
+    if form.startswith("segment"):              # the throughput form (train_seg.h) with 16 / 8 lanes per chain, forced at this small size
+        monkeypatch.setenv("QAMPY_HIP_PIT_FORM", "segment")
+        monkeypatch.setenv("QAMPY_HIP_SEG_LANES", form[7:])
+    elif form != "auto":
         monkeypatch.setenv("QAMPY_HIP_TRAINER", form)
     sig, E, tr, w0, sy, rt = _setup(method, M)
     eo, wo, _ = hk.train_equaliser(E, tr, 2, 2, rt(5e-4), w0.copy(), None, False, sy, method)
@@ -61,8 +64,11 @@ def test_relaxation_fixed_point_is_the_sequential_recurrence(method, M, form, mo
     assert rep["defect"][-1] < 1e-4 and rep["defect"][-1] <= rep["defect"][0]
 
 
+@pytest.mark.parametrize("lanes", ["16", "8"])
 @pytest.mark.parametrize("method,M", [("mcma", 16), ("cma", 64), ("mrde", 64)])
-def test_coarse_correction_converges_to_the_exact_trajectory(method, M):
+def test_coarse_correction_converges_to_the_exact_trajectory(method, M, lanes, monkeypatch):
+    monkeypatch.setenv("QAMPY_HIP_PIT_FORM", "segment")
+    monkeypatch.setenv("QAMPY_HIP_SEG_LANES", lanes)
     """16 segments, tight tolerance: the defect falls fast with the correction and the result agrees with the exact
     trainer far below the gradient noise; plain relaxation needs (many) more passes for the same defect."""
     sig, E, tr, w0, sy, rt = _setup(method, M, nsym=2 ** 16, ntaps=21)
