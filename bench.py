@@ -469,7 +469,7 @@ def main():
     ap.add_argument("--tier", default="b", choices=["a", "b"],
                     help="trainer of the timed pipeline: b = parallel-in-time solver of the recurrence, used for the headline only if it certifies "
                          "itself in this run (converged + SER within +-3 errors of the exact path); a = the exact sequential recurrence")
-    ap.add_argument("--tol", type=float, default=0., help="boundary-defect tolerance of tier b (0 = library default 0.01; stages that only seed the next one 0.05)")
+    ap.add_argument("--tol", type=float, default=0., help="boundary-defect tolerance of tier b (0 = library default 0.01; stages that only seed the next one 0.06)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=None, help="symbol periods the all-thread CPU baseline processes (default: the whole capture)")
     ap.add_argument("--cpu-sample-1t", type=int, default=1 << 19, help="symbol periods of the one-thread CPU run")

@@ -246,7 +246,7 @@ typedef struct qh_pit_opts {
     double tol;             /* 0 = 0.01: largest boundary defect accepted (output deviation from the sequential result ~ 0.6 tol) */
     double gear;            /* 0 = 8 */
     double acq_bound;       /* 0 = 0.08 */
-    double acq_plateau;     /* 0 = 0.9: a chunk whose mean |err|^2 exceeds this fraction of the previous one's ends the acquisition */
+    double acq_plateau;     /* 0 = 0.8: a chunk whose mean |err|^2 exceeds this fraction of the previous one's ends the acquisition */
     int64_t acq_chunk;      /* 0 = automatic (>= 4096 steps) */
     int64_t acq_max;        /* 0 = min(TrSyms / 2, 2^17) steps */
     int32_t correction;     /* -1 / 1: linearised coarse correction between the passes (see below), 0: plain relaxation */

@@ -863,7 +863,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     const double tol = o.tol > 0 ? o.tol : 0.01;
     const double gear = o.gear > 0 ? o.gear : 8.0;
     const double bound = o.acq_bound > 0 ? o.acq_bound : 0.08;
-    const double plateau = o.acq_plateau > 0 ? o.acq_plateau : 0.9;
+    const double plateau = o.acq_plateau > 0 ? o.acq_plateau : 0.8;
     const int sym = pit_symmetry(method);
     const bool seed_phase = o.phase_seed < 0 ? sym == 4 : o.phase_seed != 0;
     const bool want_corr = o.correction != 0 && pit_basis_ok(ntot, sizeof(Cx<R>));

@@ -23,7 +23,7 @@ from .core.equalisation import hip_equalisation as _k
 from .core import hip_dsp as _dsp
 
 
-PIT_TOL_INTERMEDIATE = 0.05       # boundary-defect tolerance of tier-b stages that are followed by another training stage
+PIT_TOL_INTERMEDIATE = 0.06       # boundary-defect tolerance of tier-b stages that are followed by another training stage
 
 
 class ResidentReceiver:
@@ -116,7 +116,12 @@ class ResidentReceiver:
         """Gram terms of the look-ahead trainer: once per capture, shared by all modes, stages and sweeps."""
         self._gram = None
         if self.tier == "a":
-            if len(set(self.TrSyms)) == 1:
+            # shared table only when a block form will read it (>= 128 steps) and it fits the library's scratch budget - otherwise
+            # the trainers chunk the sweep themselves (csrc/train_impl.h: gram_budget), which a caller's table would switch off
+            import os as _os
+            budget = float(_os.environ.get("QAMPY_HIP_GRAM_BUDGET_GB", 160.)) * 2 ** 30
+            fits = self.TrSyms[0] * 1024 * (np.dtype(self.ct).itemsize // 8) <= budget
+            if len(set(self.TrSyms)) == 1 and self.TrSyms[0] >= 128 and fits and _os.environ.get("QAMPY_HIP_TRAINER", "") != "direct":
                 self._gram = _k.gram_build_dev(self.E, self.os, self.Ntaps, self.TrSyms[0])
         elif len(set(self.TrSyms)) == 1 and self.nmodes * self.Ntaps <= 96:
             # tier b builds what its passes need itself (no Gram table in the throughput form, csrc/train_seg.h); what the stages

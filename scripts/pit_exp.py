@@ -43,6 +43,9 @@ VARIANTS = {
     "gear12c2048": (dict(gear=12., acq_bound=0.12, acq_chunk=2048), {}),
     "gear16c1024": (dict(gear=16., acq_bound=0.16, acq_chunk=1024), {}),
     "c1024": (dict(acq_chunk=1024), {}),
+    "p.8c2048": (dict(acq_plateau=0.8, acq_chunk=2048), {}),
+    "p.7c2048": (dict(acq_plateau=0.7, acq_chunk=2048), {}),
+    "p.8": (dict(acq_plateau=0.8), {}),
     "tolF=.01": ({}, dict(tol=0.01)),
     "tolF=.005": ({}, dict(tol=0.005)),
     "tolF=.0025": ({}, dict(tol=0.0025)),
