@@ -590,15 +590,26 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
     }
     for (int k = tid; k < n; k += 1024) lam[k] = (double)A[k * ld + k].x;
     for (int i = wave; i < n; i += 16)
-        for (int k = lane; k < n; k += 64) Vout[(size_t)i * n + k] = V[i * ld + k];
+        for (int k = lane; k < n; k += 64) { Vout[(size_t)i * n + k] = V[i * ld + k]; Vout[(size_t)n * n + (size_t)i * n + k] = V[k * ld + i]; }   // V, then V^T (both products read rows)
 }
 
 // C[m][c] = sum_k op(A)[m][k] B[k][c],  op(A) = A (CONJT = false) or A^H; A is n x n (n <= PIT_EIGMAX), B and C are n x ncol
 // (row-major).  A block takes 16 columns (a few thousand columns in all: twice as many blocks as CUs rather than half as many):
 // op(A) and the B tile are staged in LDS, a thread accumulates 3 rows x 2 columns in registers (8 x 32 threads).
 constexpr int PIT_GT = 16, PIT_GC = PIT_GT / 8;
-template <bool CONJT>
-__global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B, Zf *C, int n, int ncol, const PitCtrl *c)
+// what the products read / write besides the matrices: the defect vectors are formed while the B tile is staged (CONJT: B[f][col] =
+// theta_{s-1} Y[s-1][mode_j][f] - theta_s X[s][mode_j][f], 0 for s = 0) and the corrected start taps are written by the
+// epilogue of the back-transform (X[s] = Y[s] = theta_s X[s] + C[.][col]) - no defect / correction arrays in HBM in between
+template <typename R> struct PitFuse {
+    Cx<R> *X, *Y;
+    const double *theta;
+    const int64_t *modes_dev;
+    int nmodes, nsel;
+};
+// A2 = the matrix whose ROWS are read: V for the forward product (op(A) = V^H: op(A)[m][k] = conj(V[k][m])), V^T for the back
+// transform (op(A) = V: op(A)[m][k] = V^T[k][m]) - consecutive threads read consecutive m either way.
+template <typename R, bool CONJT>
+__global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A2, const Zf *B, Zf *C, int n, int ncol, const PitCtrl *c, PitFuse<R> fz)
 {
     if (c->done) return;
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
@@ -606,15 +617,34 @@ __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B
     Zf *Bs = As + (size_t)PIT_EIGMAX * PIT_EIGMAX;            // [k][PIT_GT]
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;    // columns PIT_GC tx .., rows ty + 32 u
     const int col0 = blockIdx.x * PIT_GT;
+    const size_t wset = (size_t)fz.nmodes * n;
     for (int e = threadIdx.x; e < PIT_EIGMAX * n; e += 256) {
         const int k = e / PIT_EIGMAX, m = e - k * PIT_EIGMAX;
         Zf v{0.f, 0.f};
-        if (m < n) { v = CONJT ? A[(size_t)k * n + m] : A[(size_t)m * n + k]; if (CONJT) v.y = -v.y; }
+        if (m < n) { v = A2[(size_t)k * n + m]; if (CONJT) v.y = -v.y; }
         As[e] = v;
     }
-    for (int e = threadIdx.x; e < n * PIT_GT; e += 256) {
-        const int k = e / PIT_GT, cc = e - k * PIT_GT;
-        Bs[e] = col0 + cc < ncol ? B[(size_t)k * ncol + col0 + cc] : Zf{0.f, 0.f};
+    if (CONJT) {                                              // defect vectors, formed here (consecutive threads: consecutive f of one column)
+        for (int e = threadIdx.x; e < n * PIT_GT; e += 256) {
+            const int cc = e / n, k = e - cc * n, col = col0 + cc;
+            Zf v{0.f, 0.f};
+            if (col < ncol) {
+                const int s = col / fz.nsel, j = col - s * fz.nsel;
+                if (s > 0) {
+                    const size_t ro = (size_t)fz.modes_dev[j] * n;
+                    const Cx<R> b = fz.Y[(size_t)(s - 1) * wset + ro + k], a = fz.X[(size_t)s * wset + ro + k];
+                    const double pr = fz.theta[2 * (size_t)(col - fz.nsel)], pi = fz.theta[2 * (size_t)(col - fz.nsel) + 1];
+                    const double qr = fz.theta[2 * (size_t)col], qi = fz.theta[2 * (size_t)col + 1];
+                    v = Zf{(float)((pr * b.re - pi * b.im) - (qr * a.re - qi * a.im)), (float)((pr * b.im + pi * b.re) - (qr * a.im + qi * a.re))};
+                }
+            }
+            Bs[k * PIT_GT + cc] = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < n * PIT_GT; e += 256) {
+            const int k = e / PIT_GT, cc = e - k * PIT_GT;
+            Bs[e] = col0 + cc < ncol ? B[(size_t)k * ncol + col0 + cc] : Zf{0.f, 0.f};
+        }
     }
     __syncthreads();
     constexpr int RU = PIT_EIGMAX / 32;                       // 3 rows per thread
@@ -637,13 +667,34 @@ __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A, const Zf *B
                 acc[u][v].y += a[u].x * b[v].y + a[u].y * b[v].x;
             }
     }
+    if (CONJT) {
 #pragma unroll
-    for (int u = 0; u < RU; u++) {
-        const int m = ty + 32 * u;
-        if (m < n)
+        for (int u = 0; u < RU; u++) {
+            const int m = ty + 32 * u;
+            if (m < n)
 #pragma unroll
-            for (int v = 0; v < PIT_GC; v++)
-                if (col0 + PIT_GC * tx + v < ncol) C[(size_t)m * ncol + col0 + PIT_GC * tx + v] = acc[u][v];
+                for (int v = 0; v < PIT_GC; v++)
+                    if (col0 + PIT_GC * tx + v < ncol) C[(size_t)m * ncol + col0 + PIT_GC * tx + v] = acc[u][v];
+        }
+    } else {                                                  // X[s] = Y[s] = theta_s X[s] + D[.][col]  (Y: the copy the next pass trains in place)
+#pragma unroll
+        for (int v = 0; v < PIT_GC; v++) {
+            const int col = col0 + PIT_GC * tx + v;
+            if (col >= ncol) continue;
+            const int s = col / fz.nsel, j = col - s * fz.nsel;
+            const size_t base = (size_t)s * wset + (size_t)fz.modes_dev[j] * n;
+            const double qr = fz.theta[2 * (size_t)col], qi = fz.theta[2 * (size_t)col + 1];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const int m = ty + 32 * u;
+                if (m < n) {
+                    const Cx<R> x = fz.X[base + m];
+                    const Cx<R> w{(R)(qr * x.re - qi * x.im + acc[u][v].x), (R)(qr * x.im + qi * x.re + acc[u][v].y)};
+                    fz.X[base + m] = w;
+                    fz.Y[base + m] = w;
+                }
+            }
+        }
     }
 }
 
@@ -715,44 +766,6 @@ static __global__ void __launch_bounds__(256) pit_gauge_kernel(const double *gph
         }
     }
 }
-// D[f][s nsel + j] = theta_{s-1} Y[s-1][mode_j][f] - theta_s X[s][mode_j][f]  (s >= 1), 0 for s = 0
-template <typename R>
-__global__ void __launch_bounds__(128) pit_dvec_kernel(const Cx<R> *X, const Cx<R> *Y, int nmodes, int ntot, const int64_t *modes_dev, int nsel, int S, const PitCtrl *c,
-                                                       const double *theta, Zf *D)
-{
-    if (c->done) return;
-    const int col = blockIdx.x, s = col / nsel, j = col - s * nsel;
-    const size_t wset = (size_t)nmodes * ntot, ro = (size_t)modes_dev[j] * ntot;
-    const int ncol = S * nsel;
-    for (int f = threadIdx.x; f < ntot; f += 128) {
-        Zf v{0.f, 0.f};
-        if (s > 0) {
-            const Cx<R> b = Y[(size_t)(s - 1) * wset + ro + f], a = X[(size_t)s * wset + ro + f];
-            const double pr = theta[2 * (size_t)(col - nsel)], pi = theta[2 * (size_t)(col - nsel) + 1], qr = theta[2 * (size_t)col], qi = theta[2 * (size_t)col + 1];
-            v = Zf{(float)((pr * b.re - pi * b.im) - (qr * a.re - qi * a.im)), (float)((pr * b.im + pi * b.re) - (qr * a.im + qi * a.re))};
-        }
-        D[(size_t)f * ncol + col] = v;
-    }
-}
-// X[s][mode_j][f] = Y[s][mode_j][f] = theta_s X[s][mode_j][f] + D[f][s nsel + j]   (Y: the copy the next pass trains in place)
-template <typename R>
-__global__ void __launch_bounds__(128) pit_dapply_kernel(Cx<R> *X, Cx<R> *Y, int nmodes, int ntot, const int64_t *modes_dev, int nsel, int S, const PitCtrl *c,
-                                                         const double *theta, const Zf *D)
-{
-    if (c->done) return;
-    const int col = blockIdx.x, s = col / nsel, j = col - s * nsel;
-    const size_t wset = (size_t)nmodes * ntot, ro = (size_t)modes_dev[j] * ntot;
-    const int ncol = S * nsel;
-    for (int f = threadIdx.x; f < ntot; f += 128) {
-        const Zf d = D[(size_t)f * ncol + col];
-        const double qr = theta[2 * (size_t)col], qi = theta[2 * (size_t)col + 1];
-        const Cx<R> x = X[(size_t)s * wset + ro + f];
-        const Cx<R> v{(R)(qr * x.re - qi * x.im + d.x), (R)(qr * x.im + qi * x.re + d.y)};
-        X[(size_t)s * wset + ro + f] = v;
-        Y[(size_t)s * wset + ro + f] = v;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ host side
 // kernel time of the most recent call (HIP events around the trainer launches; the host synchronises after each anyway)
 struct PitTiming { int npass; float pass_ms[QH_PIT_MAXPASS]; float acq_ms; };
@@ -794,7 +807,7 @@ inline int pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold)
 
 // Eigenbasis of the input covariance of a capture (depends on E, os, ntaps, TrSyms only - one build serves every stage):
 // basis = [ntot eigenvalues (double)][ntot x ntot eigenvectors (float complex, V[i][k])] in device memory.
-inline size_t pit_basis_bytes(int ntot) { return (size_t)ntot * sizeof(double) + (size_t)ntot * ntot * sizeof(Zf); }
+inline size_t pit_basis_bytes(int ntot) { return (size_t)ntot * sizeof(double) + 2 * (size_t)ntot * ntot * sizeof(Zf); }        // eigenvalues, V, V^T
 inline bool pit_basis_ok(int ntot, size_t elem) { return ntot <= PIT_EIGMAX && (size_t)PIT_COVW * ntot * elem <= 64 * 1024; }
 // overlap != 0: the build runs on the library's other stream (one workgroup grinding through the Jacobi sweeps next to
 // whatever the current stream does next - the acquisition and the first pass do not need the basis); the trainer waits for
@@ -980,8 +993,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     const size_t glds = ((size_t)PIT_EIGMAX * PIT_EIGMAX + (size_t)PIT_EIGMAX * PIT_GT) * sizeof(Zf);
     static bool gemm_attr = false;
     if (want_corr && !gemm_attr) {
-        QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         QH_HIP(hipFuncSetAttribute((const void *)pit_gauge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         gemm_attr = true;
     }
@@ -1073,13 +1086,11 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                     pit_basis_sync().pending = false;
                 }
                 hipLaunchKernelGGL(pit_gauge_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)gph, sg.S, nsel, (const PitCtrl *)ctrl, theta);
-                hipLaunchKernelGGL((pit_dvec_kernel<R>), dim3(ncol), dim3(128), 0, g_stream, (const Cx<R> *)X, (const Cx<R> *)Y, nmodes, ntot, (const int64_t *)modes_dev, nsel, sg.S,
-                                   (const PitCtrl *)ctrl, (const double *)theta, Dz[0]);
-                hipLaunchKernelGGL((pit_cgemm_kernel<true>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb, (const Zf *)Dz[0], Dz[1], ntot, ncol, (const PitCtrl *)ctrl);
+                PitFuse<R> fz;
+                fz.X = X; fz.Y = Y; fz.theta = theta; fz.modes_dev = (const int64_t *)modes_dev; fz.nmodes = nmodes; fz.nsel = nsel;
+                hipLaunchKernelGGL((pit_cgemm_kernel<R, true>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb, (const Zf *)nullptr, Dz[1], ntot, ncol, (const PitCtrl *)ctrl, fz);
                 hipLaunchKernelGGL((pit_recur_kernel<R>), dim3(ntot, nsel), dim3(256), 0, g_stream, Dz[1], lam, nsel, sg.S, sg.len, (const R *)mu_dev, beta, (const PitCtrl *)ctrl);
-                hipLaunchKernelGGL((pit_cgemm_kernel<false>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb, (const Zf *)Dz[1], Dz[0], ntot, ncol, (const PitCtrl *)ctrl);
-                hipLaunchKernelGGL((pit_dapply_kernel<R>), dim3(ncol), dim3(128), 0, g_stream, X, Y, nmodes, ntot, (const int64_t *)modes_dev, nsel, sg.S, (const PitCtrl *)ctrl,
-                                   (const double *)theta, (const Zf *)Dz[0]);
+                hipLaunchKernelGGL((pit_cgemm_kernel<R, false>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb + (size_t)ntot * ntot, (const Zf *)Dz[1], (Zf *)nullptr, ntot, ncol, (const PitCtrl *)ctrl, fz);
                 QH_HIP(hipGetLastError());
             } else if (p > 0) {
                 QH_HIP(hipMemcpyAsync(X + wset, Y, (size_t)(sg.S - 1) * wbytes, hipMemcpyDeviceToDevice, g_stream));   // X[s] = end taps of s-1
