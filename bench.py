@@ -478,6 +478,9 @@ def main():
     ap.add_argument("--bank-trainer", default="iterative", choices=["auto", "iterative"])
     ap.add_argument("--bank", type=int, default=128, help="channels of the informational channel-bank run at N=1 (0 = skip)")
     ap.add_argument("--cpu-bank-workers", type=int, default=-1, help="concurrent single-threaded CPU pipelines of the bank's CPU leg (-1: min(cores, 128), 0: skip)")
+    ap.add_argument("--split-capture", action="store_true",
+                    help="N > 1: ONE capture, the segments of the tier-b trainer spread over the ranks with an all-reduce of their end taps per pass "
+                         "(qampy_amd.distributed; strong scaling, informational - the default is one independent capture per GPU)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: kernels replaced by a sleep, gloo backend - exercises launcher + reductions")
     args = ap.parse_args()
 
@@ -551,8 +554,16 @@ def main():
         return
 
     # ---- independent channel per rank (seed 1000 + channel), synthesised on the GPU (or the host), then made resident
-    sig = make_input(cfg, nsym, sharding.channel_seed(rank), host=args.host_synth)
-    rx = make_receiver(cfg, sig, tier=args.tier, pit=pit)
+    split = args.split_capture and world > 1 and args.tier == "b"
+    sig = make_input(cfg, nsym, sharding.channel_seed(0 if split else rank), host=args.host_synth)
+    if split:                                        # every rank holds the same capture; torch's device = the library's
+        from qampy_amd.distributed import SplitCaptureReceiver
+        torch.cuda.set_device(dev)
+        rx = SplitCaptureReceiver(sig.shape[0], sig.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"],
+                                  adaptive_stepsize=cfg["adaptive"], TrSyms=(None,) * len(cfg["methods"]), Mtestangles=cfg["A"], Nbps=cfg["Nbps"],
+                                  dtype=np.complex64, alphabet=sig.coded_symbols, pit=pit)
+    else:
+        rx = make_receiver(cfg, sig, tier=args.tier, pit=pit)
     rx.load(sig)
     stage_names, _ = stage_list(rx)
 
@@ -575,7 +586,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    value_timed = sharding.aggregate_throughput(nsym, world, args.steps, elapsed)
+    value_timed = sharding.aggregate_throughput(nsym, 1 if split else world, args.steps, elapsed)
     ms_timed = elapsed / args.steps * 1e3
     nsel = rx.modes.size
     # ---- algorithmic bytes per launch of every stage / kernel (SURVEY.md 8d general formula)
@@ -585,11 +596,14 @@ def main():
     stage_bytes += [rx.N * bps_b["apply"]] + ([rx.N * bps_b["bps"]] if cfg["A"] else [])
 
     out = dict(metric="equalised MSym/s (2-pol, 2 SPS)", value=round(value_timed, 4), unit="MSym/s", n_gpus=world, ranks_seen=ranks_seen,
-               steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_timed, 3), higher_is_better=True, scaling="weak", vs_baseline=None,
+               steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_timed, 3), higher_is_better=True, scaling="strong" if split else "weak", vs_baseline=None,
                dtype="f32", data="synthetic",
-               config=dict(workload=cfg["label"], key=args.workload, nsym_per_channel=nsym, channels=world, ntaps=cfg["ntaps"],
+               config=dict(workload=cfg["label"], key=args.workload, nsym_per_channel=nsym, channels=1 if split else world, ntaps=cfg["ntaps"],
                            methods=list(cfg["methods"]), niter=list(cfg["niter"]), test_angles=cfg["A"], bps_N=cfg["Nbps"],
-                           complex_dtype="complex64", parallelism="1 independent channel per GPU", train_mode=None),
+                           complex_dtype="complex64", train_mode=None,
+                           parallelism=("ONE capture: tier-b segments over %d ranks, all-reduce of the segments' end taps per pass (%d exchanges, %.1f MiB per step)"
+                                        % (world, rx.exchanges // max(args.steps + args.warmup, 1), rx.exchanged_bytes / max(args.steps + args.warmup, 1) / 2 ** 20))
+                           if split else "1 independent channel per GPU"),
                stages_ms={n: round(t, 3) for n, t in zip(stage_names, stage_ms)},
                ser=dict(per_mode_rank0=[e / max(n, 1) for e, n in errs], errors_rank0=[e for e, _ in errs], errors_all=int(counts_all[:, 0].sum()),
                         symbols_all=int(counts_all[:, 1].sum())),

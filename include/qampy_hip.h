@@ -253,6 +253,15 @@ typedef struct qh_pit_opts {
     int32_t pad;
     void *basis;            /* NULL, or the eigenbasis of this capture's input covariance from qh_pit_basis_*_dev (device memory) */
     double corr_beta;       /* extra damping of the well-excited directions in the coarse map, exp(-a (1 + beta a)); < 0: by method */
+    /* One capture over several processes / GPUs (optional; every process holds the whole capture and makes the same call):
+     * this process trains segments [seg_first, seg_first + seg_count) only (seg_count = 0: all of them); after the training
+     * launch of every pass the library synchronises its stream, zeroes the end taps of the segments it does not own and calls
+     * exchange(exchange_user, taps, bytes) - the caller sums the buffers of all processes in place (an all-reduce: RCCL over
+     * xGMI) and returns 0 - after which every process evaluates the (cheap) boundary defects and the coarse correction on
+     * identical data and takes identical decisions.  Error traces are written for the owned segments only. */
+    int32_t seg_first, seg_count;
+    int (*exchange)(void *user, void *taps_dev, size_t bytes);
+    void *exchange_user;
 } qh_pit_opts;
 typedef struct qh_pit_report {
     int32_t segments, passes, converged, acq_chunks;

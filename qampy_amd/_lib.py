@@ -102,7 +102,12 @@ class PitOpts(C.Structure):
     """``qh_pit_opts`` of include/qampy_hip.h (zeros = the library's defaults)."""
     _fields_ = [("segments", C.c_int32), ("max_passes", C.c_int32), ("acquire", C.c_int32), ("phase_seed", C.c_int32),
                 ("tol", C.c_double), ("gear", C.c_double), ("acq_bound", C.c_double), ("acq_plateau", C.c_double),
-                ("acq_chunk", C.c_int64), ("acq_max", C.c_int64), ("correction", C.c_int32), ("pad", C.c_int32), ("basis", C.c_void_p), ("corr_beta", C.c_double)]
+                ("acq_chunk", C.c_int64), ("acq_max", C.c_int64), ("correction", C.c_int32), ("pad", C.c_int32), ("basis", C.c_void_p), ("corr_beta", C.c_double),
+                ("seg_first", C.c_int32), ("seg_count", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p)]
+
+
+#: signature of ``qh_pit_opts.exchange``: (user, device pointer of the segments' end taps, bytes) -> 0
+PIT_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 
 
 class PitReport(C.Structure):

@@ -939,6 +939,13 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         else if (!(pf && pf[0] == 's') && (int64_t)sg.S * nsel < 512) seg_ok = false;
     }
     const bool seg_form = seg_ok;
+    const bool split = o.exchange != nullptr && o.seg_count > 0;
+    const int own_first = split ? o.seg_first : 0, own_count = split ? o.seg_count : sg.S;
+    if (split) {
+        QH_REQUIRE(seg_form, "train_equaliser: a capture split over processes needs the throughput form of the passes (>= 512 chains, supported tap layout)");
+        QH_REQUIRE(own_first >= 0 && own_first + own_count <= sg.S, "train_equaliser: owned segments outside the segment grid");
+        QH_REQUIRE(Niter == 1, "train_equaliser: a capture split over processes is trained in one sweep");
+    }
     const bool la_ok = force[0] != 'd' && la_supported(method, 0, nmodes, ntaps, os, sg.len, nsy);
     const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
     (void)partitioned;
@@ -1107,6 +1114,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 sa.seg_len = sg.len; sa.seg_extra = sg.extra; sa.seg_tail = sg.tail; sa.seg_begin = 0;
                 for (int j = 0; j < 16; j++) sa.modes[j] = j < nsel ? modes[j] : 0;
                 sa.skip = &ctrl->done;
+                sa.q_first = own_first * nsel; sa.q_count = split ? own_count * nsel : 0;
                 { int r = launch_seg<R>(sa, method); if (r) return r; }
             } else if (block_form) {
                 LaArgs<R> ls = la;
@@ -1119,6 +1127,15 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 { int r = launch_any<R>(ts); if (r) return r; }
             }
             QH_HIP(hipEventRecord(ev.t1[p], g_stream));
+            if (split) {
+                // one capture over several processes: the end taps of the segments trained elsewhere arrive through the caller's
+                // all-reduce (zeros here, the trained taps there); from then on every process works on identical data
+                if (own_first > 0) QH_HIP(hipMemsetAsync(Y, 0, (size_t)own_first * wbytes, g_stream));
+                if (own_first + own_count < sg.S)
+                    QH_HIP(hipMemsetAsync(Y + (size_t)(own_first + own_count) * wset, 0, (size_t)(sg.S - own_first - own_count) * wbytes, g_stream));
+                QH_HIP(hipStreamSynchronize(g_stream));
+                if (o.exchange(o.exchange_user, Y, (size_t)sg.S * wbytes) != 0) { set_error("train_equaliser: the exchange callback failed"); return QH_ERR_ARG; }
+            }
             const size_t dlds = (2 * (size_t)ntot + (size_t)nmodes * os * pit_phase_pitch(ntaps, os, PIT_PROBE)) * sizeof(Cx<R>);
             QH_REQUIRE(dlds <= 60 * 1024, "train_equaliser: boundary probe does not fit the LDS for this filter shape");
             hipLaunchKernelGGL((pit_defect_kernel<R>), dim3(sg.S - 1, nsel), dim3(PIT_PROBE), dlds, g_stream, (const Cx<R> *)E, nmodes, L, os,
@@ -1139,7 +1156,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         for (int p = 0; p < npass; p++) {
             const bool expect_last = p > 0 && PIT_CONTRACT * (double)ev.hview[2 * (p - 1) + 1] < tol;
             ahead = false;
-            if (p + 1 < npass && !expect_last) { if ((rc = enqueue_pass(p + 1))) return rc; ahead = true; }
+            if (p + 1 < npass && !expect_last && !split) { if ((rc = enqueue_pass(p + 1))) return rc; ahead = true; }   // (split: a pass contains a host-side exchange)
             QH_HIP(hipEventSynchronize(ev.flag[p]));
             if (tm.npass < QH_PIT_MAXPASS) { float ms = 0; QH_HIP(hipEventElapsedTime(&ms, ev.t0[p], ev.t1[p])); tm.pass_ms[tm.npass++] = ms; }
             if (ev.hview[2 * p] != 0.f) break;

@@ -34,6 +34,7 @@ template <typename R> struct SegArgs {
     int64_t seg_len, seg_extra, seg_tail, seg_begin;
     int64_t modes[16];
     const int *skip;
+    int q_first, q_count;          // chains [q_first, q_first + q_count) of the S * nsel are trained by this launch (q_count = 0: all)
     int lpm, pitch, rag, nslots;   // lanes per input mode, LDS row pitch (samples), padding taps in the last lane of a mode, segment windows per wave
 };
 
@@ -133,8 +134,8 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     using v2 = typename V2<R>::type;
     const int lane = threadIdx.x;
     const int l16 = lane & (LPC - 1);                          // lane within the chain
-    const int nq = a.S * a.nsel;                               // chains of the launch
-    const int q0 = blockIdx.x * CPW;
+    const int nq = a.q_count > 0 ? a.q_first + a.q_count : a.S * a.nsel;      // one past the last chain of the launch
+    const int q0 = a.q_first + blockIdx.x * CPW;
     const int q = q0 + lane / LPC;
     const bool alive = q < nq;
     const int qc = alive ? q : nq - 1;
@@ -384,7 +385,8 @@ template <typename R, int METHOD> static int launch_seg_dd(const SegArgs<R> &a, 
 // `a` complete except lpm / pitch / rag; method-specific table layout as for launch_bi (slicer tables for sbd / mddma / dd)
 template <typename R> int launch_seg(SegArgs<R> a, int method)
 {
-    const int nq = a.S * a.nsel;
+    const int nq = a.q_count > 0 ? a.q_count : a.S * a.nsel;
+    if (a.q_count <= 0) a.q_first = 0;
     const int lpc = seg_lanes<R>(a.nmodes, a.ntaps, a.nsel, nq), cpw = 64 / lpc;
     const int tpl = seg_tpl(a.nmodes, a.ntaps, lpc);
     a.lpm = (a.ntaps + tpl - 1) / tpl;

@@ -80,3 +80,34 @@ def test_bench_launches_its_own_ranks():
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True, timeout=120, env=env2)
     assert bad.returncode == 2 and "WORLD_SIZE=1" in bad.stdout
+
+
+def test_owned_segments_partition_the_grid():
+    """qampy_amd.distributed: contiguous, disjoint, complete and nearly equal shares for any segment count / world size."""
+    from qampy_amd.distributed import owned_segments
+    for S in (1, 7, 512, 1920, 3968, 4096):
+        for world in (1, 2, 3, 8):
+            parts = [owned_segments(S, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == S
+            assert all(parts[r][0] + parts[r][1] == parts[r + 1][0] for r in range(world - 1))
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def test_pit_opts_struct_matches_the_header():
+    """The ctypes mirror of qh_pit_opts carries the split-capture fields of include/qampy_hip.h in the header's order."""
+    import re
+    from qampy_amd import _lib
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "qampy_hip.h")).read()
+    body = src[src.index("typedef struct qh_pit_opts {") + len("typedef struct qh_pit_opts {"):src.index("} qh_pit_opts;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for stmt in body.split(";"):
+        stmt = stmt.strip()
+        if not stmt or stmt.startswith("typedef"):
+            continue
+        m = re.search(r"\(\*(\w+)\)", stmt)
+        if m:
+            names.append(m.group(1))
+        else:
+            names += [n.strip(" *") for n in stmt.split(None, 1)[1].split(",")]
+    assert names == [f[0] for f in _lib.PitOpts._fields_]
