@@ -23,13 +23,14 @@ def find_sequence_offset_complex(x, y):
     if not np.iscomplexobj(x) and not np.iscomplexobj(y):
         idx, cc = find_sequence_offset(x, y, show_cc=True)
         return idx, y, 0, cc
-    best, best_i, best_idx = 0., 0, 0
-    for i in range(4):
-        idx, cc = find_sequence_offset(x, y * 1.j ** i, show_cc=True)
-        peak = cc.real.max()
-        if peak > best:
-            best, best_i, best_idx = peak, i, idx
-    return best_idx, y * 1.j ** best_i, best_i, best
+    # turning y by 1j**i turns the whole cross-correlation by (-1j)**i: one correlation serves the four hypotheses, and its
+    # magnitude peak - the offset - is the same for all of them
+    idx, cc = find_sequence_offset(x, y, show_cc=True)
+    peaks = np.array([cc.real.max(), cc.imag.max(), (-cc.real).max(), (-cc.imag).max()])      # max Re((-1j)**i cc), i = 0..3
+    if not peaks.max() > 0:
+        return 0, y, 0, 0.
+    turns = int(np.argmax(peaks))
+    return idx, y * 1.j ** turns, turns, float(peaks[turns])
 
 
 def tx_indices_dev(symbols_tx, alphabet):

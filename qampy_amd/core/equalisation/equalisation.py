@@ -113,22 +113,20 @@ def apply_filter(E, os, wxy, method="pyt", modes=None):
     ``method`` is accepted for signature compatibility ("pyt" and "hip" both run the HIP kernel; "py" is the reference's
     broken NumPy branch and is not provided).
     """
-    E = np.array(E, copy=True, order="C", subok=False)
-    wxy = np.array(wxy, copy=True, order="C", subok=False)
-    modes = np.arange(wxy.shape[0]) if modes is None else np.copy(np.atleast_1d(modes))
-    nmodes = modes.shape[0]
     if method not in ("pyt", "hip"):
         raise NotImplementedError("Only the compiled (pyt/hip) method is implemented")
-    if np.iscomplexobj(E) and np.iscomplexobj(wxy):
-        return _kernels.apply_filter_to_signal(E, os, wxy, modes)
-    if np.iscomplexobj(E):
-        E = _convert_sig_to_real(E)
-    out = _kernels.apply_filter_to_signal(E, os, wxy, modes)
-    if E.itemsize == 8:
-        return _convert_sig_to_cmplx(out, nmodes, np.complex128(1j))
-    if E.itemsize == 4:
-        return _convert_sig_to_cmplx(out, nmodes, np.complex64(1j))
-    raise ValueError("The field has an unknown data type")
+    field = np.array(E, copy=True, order="C", subok=False)
+    taps = np.array(wxy, copy=True, order="C", subok=False)
+    rows = np.arange(taps.shape[0]) if modes is None else np.array(np.atleast_1d(modes))
+    if np.iscomplexobj(field) and np.iscomplexobj(taps):
+        return _kernels.apply_filter_to_signal(field, os, taps, rows)
+    # real-valued taps act on the field stacked as [real rows; imaginary rows]; the result comes back in the same stacking
+    stacked = _convert_sig_to_real(field) if np.iscomplexobj(field) else field
+    unit = {8: np.complex128, 4: np.complex64}.get(stacked.itemsize)
+    out = _kernels.apply_filter_to_signal(stacked, os, taps, rows)
+    if unit is None:
+        raise ValueError("The field has an unknown data type")
+    return _convert_sig_to_cmplx(out, rows.shape[0], unit(1j))
 
 
 class _Field:

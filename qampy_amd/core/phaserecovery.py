@@ -40,24 +40,21 @@ def bps_twostage(E, Mtestangles, symbols, N, B=4, method="pyt", **kwargs):
     if method.lower() not in ("pyt", "hip"):
         raise ValueError("Method needs to be 'pyt' or 'hip' (the py/pyx/af back-ends of the reference are not provided)")
     rdt = E.real.dtype
-    angles = np.linspace(-np.pi / 4, np.pi / 4, Mtestangles, endpoint=False, dtype=rdt).reshape(1, -1)
-    Ew = np.atleast_2d(E)
-    symbols = np.asarray(symbols).astype(E.dtype, copy=False)
-    ph_out = []
-    for i in range(Ew.shape[0]):
-        Ei = np.ascontiguousarray(np.asarray(Ew[i]))
-        idx = _bps_idx_hip(Ei, angles, symbols, N)
-        ph = select_angles(np.copy(angles), idx)
-        b = np.linspace(-B / 2, B / 2, B)
-        phn = (ph[:, np.newaxis] + b[np.newaxis, :] / (B * Mtestangles) * np.pi / 2).astype(rdt)
-        idx2 = _bps_idx_hip(Ei, phn, symbols, N)
-        phf = select_angles(np.copy(phn), idx2)
-        ph_out.append(np.unwrap(phf * 4, discont=np.pi * 4 / 4) / 4)
-    ph_out = np.asarray(ph_out, dtype=rdt)
-    En = Ew * np.exp(1.j * ph_out)
-    if E.ndim == 1:
-        return En.flatten(), ph_out.flatten()
-    return En, ph_out
+    rows = np.atleast_2d(E)
+    alphabet = np.asarray(symbols).astype(E.dtype, copy=False)
+    coarse = np.linspace(-np.pi / 4, np.pi / 4, Mtestangles, endpoint=False, dtype=rdt).reshape(1, -1)
+    steps = np.linspace(-B / 2, B / 2, B)                  # offsets of the fine grid, in units of one coarse step / B
+
+    def track(row):
+        row = np.ascontiguousarray(np.asarray(row))
+        first = select_angles(np.copy(coarse), _bps_idx_hip(row, coarse, alphabet, N))
+        fine = (first[:, np.newaxis] + steps[np.newaxis, :] / (B * Mtestangles) * np.pi / 2).astype(rdt)       # (L, B): a grid per symbol
+        second = select_angles(np.copy(fine), _bps_idx_hip(row, fine, alphabet, N))
+        return np.unwrap(second * 4, discont=np.pi) / 4
+
+    ph = np.asarray([track(r) for r in rows], dtype=rdt)
+    out = rows * np.exp(1.j * ph)
+    return (out.flatten(), ph.flatten()) if E.ndim == 1 else (out, ph)
 
 
 def find_freq_offset(sig, os=1, average_over_modes=True, fft_size=2 ** 16):

@@ -93,6 +93,30 @@ def dual_mode_equalisation(sig, mu, Ntaps, TrSyms=(None, None), Niter=(1, 1), me
     return res
 
 
+class _FrameLayout:
+    """Where the frames of a frame-synchronised pilot capture start for a filter of ``ntaps`` taps (the shifts found by
+    ``sync2frame`` hold for its ``synctaps``-tap search filter; a longer filter reaches further back by half the difference)."""
+
+    def __init__(self, signal, ntaps):
+        if signal.shiftfctrs is None:
+            raise ValueError("the signal has to be synced to the frame first (sync2frame)")
+        self.ntaps, self.synctaps = int(ntaps), int(signal.synctaps)
+        if abs(self.ntaps - self.synctaps) % 2:
+            raise ValueError("Tap difference need to be an integer of the oversampling")
+        self.shifts = np.array(signal.shiftfctrs, dtype=int)
+        self.frame_samples = signal.os * signal.frame_len
+        self.length = signal.shape[-1]
+
+    def starts(self, frame):
+        # like the reference (qampy/equalisation.py:318-321) the frame offset only enters together with the tap correction
+        if self.ntaps == self.synctaps:
+            return self.shifts
+        return self.shifts - (self.ntaps - self.synctaps) // 2 + self.frame_samples * frame
+
+    def holds_whole_frame(self, first_sample):
+        return self.length - first_sample > self.frame_samples
+
+
 def pilot_equaliser(signal, mu, Ntaps, apply=True, foe_comp=True, wxinit=None, frame=0, verbose=False, **eqkwargs):
     """
     Pilot-based equalisation of one frame of a synced pilot signal (qampy/equalisation.py:268-338): data-aided training on
@@ -100,48 +124,41 @@ def pilot_equaliser(signal, mu, Ntaps, apply=True, foe_comp=True, wxinit=None, f
     compensation, then the filter over the frame.  Returns ``taps`` (``apply=False``), ``(taps, sig_out)`` or, with
     ``verbose``, additionally the frequency offsets and ``(Ntaps, synctaps)``.
     """
-    if signal.shiftfctrs is None:
-        raise ValueError("the signal has to be synced to the frame first (sync2frame)")
-    shifts = np.array(signal.shiftfctrs, dtype=int)
-    mu = np.atleast_1d(mu)
-    if len(mu) == 1:
-        mu = np.repeat(mu, 2)
-    if wxinit is not None:
-        Ntaps = wxinit.shape[-1]
-    if abs(Ntaps - signal.synctaps) % 2 != 0:
-        raise ValueError("Tap difference need to be an integer of the oversampling")
-    elif Ntaps != signal.synctaps:
-        shifts = shifts - (Ntaps - signal.synctaps) // 2 + signal.os * signal.frame_len * frame
-    if not signal.shape[-1] - shifts.max() > signal.frame_len * signal.os:
+    layout = _FrameLayout(signal, Ntaps if wxinit is None else wxinit.shape[-1])
+    starts = layout.starts(frame)
+    if not layout.holds_whole_frame(starts.max()):
         raise ValueError("You are trying to equalise an incomplete frame which does not work")
-    taps, foe = pilotbased_receiver.equalize_pilot_sequence(np.asarray(signal), np.asarray(signal.pilot_seq), shifts, os=signal.os, mu=mu,
-                                                            foe_comp=foe_comp, Ntaps=Ntaps, wxinit=wxinit, **eqkwargs)
-    out_sig = phaserec.comp_freq_offset(signal, foe) if foe_comp else signal
-    if not apply:
-        return (taps, foe, (Ntaps, signal.synctaps)) if verbose else taps
-    eq = apply_filter(out_sig, taps, frames=[frame])
-    return (taps, eq, foe, (Ntaps, signal.synctaps)) if verbose else (taps, eq)
+    steps = np.atleast_1d(mu)
+    steps = np.repeat(steps, 2) if len(steps) == 1 else steps
+    taps, foe = pilotbased_receiver.equalize_pilot_sequence(np.asarray(signal), np.asarray(signal.pilot_seq), starts, os=signal.os, mu=steps,
+                                                            foe_comp=foe_comp, Ntaps=layout.ntaps, wxinit=wxinit, **eqkwargs)
+    result = [taps]
+    if apply:
+        source = phaserec.comp_freq_offset(signal, foe) if foe_comp else signal
+        result.append(apply_filter(source, taps, frames=[frame]))
+    if verbose:
+        result += [foe, (layout.ntaps, layout.synctaps)]
+    return result[0] if len(result) == 1 else tuple(result)
 
 
 def pilot_equaliser_nframes(signal, mu, Ntaps, apply=True, foe_comp=True, frames=[0], wxinit=None, verbose=True, **eqkwargs):
     """Pilot-based equalisation frame by frame; the taps of frame 0 initialise the later frames (qampy/equalisation.py:340-397)."""
-    if signal.shiftfctrs is None:
-        raise ValueError("the signal has to be synced to the frame first (sync2frame)")
+    layout = _FrameLayout(signal, Ntaps if wxinit is None else wxinit.shape[-1])
+    last_shift = int(np.max(layout.shifts))
     if frames is None:
-        frames = np.arange((signal.shape[-1] - np.max(signal.shiftfctrs)) // (signal.os * signal.frame_len))
+        frames = np.arange((layout.length - last_shift) // layout.frame_samples)
     frames = np.atleast_1d(frames)
-    if not signal.shape[-1] - (np.max(signal.shiftfctrs) + np.max(frames) * signal.frame_len * signal.os) > signal.frame_len * signal.os:
+    if not layout.holds_whole_frame(last_shift + int(np.max(frames)) * layout.frame_samples):
         raise ValueError("The last frame must be complete for equalisation")
-    if wxinit is not None:
-        Ntaps = wxinit.shape[-1]
-    rets = []
-    for i in frames:
-        ret = pilot_equaliser(signal, mu, Ntaps, apply=apply, foe_comp=foe_comp, wxinit=wxinit, verbose=verbose, frame=i, **eqkwargs)
-        if i == 0:
-            wxinit = ret[0] if isinstance(ret, tuple) else ret
-        rets.append(ret if isinstance(ret, tuple) else (ret,))
-    out = tuple(zip(*rets))
-    if apply:
-        sout = signal.recreate_from_np_array(np.array(np.hstack([np.asarray(o) for o in out[1]])), fs=signal.fb)
-        return out[0], sout, out[2:]
-    return out
+    seed, per_frame = wxinit, []
+    for f in frames:
+        got = pilot_equaliser(signal, mu, layout.ntaps, apply=apply, foe_comp=foe_comp, wxinit=seed, verbose=verbose, frame=f, **eqkwargs)
+        got = got if isinstance(got, tuple) else (got,)
+        if f == 0:
+            seed = got[0]
+        per_frame.append(got)
+    columns = tuple(zip(*per_frame))                   # (taps of every frame, [equalised frames], [offsets, tap counts])
+    if not apply:
+        return columns
+    joined = np.concatenate([np.asarray(x) for x in columns[1]], axis=-1)
+    return columns[0], signal.recreate_from_np_array(joined, fs=signal.fb), columns[2:]

@@ -31,14 +31,14 @@ def comp_freq_offset(sig, freq_offset):
 def pilot_cpe(signal, N=3, pilot_rat=1, max_blocks=None, nframes=1, use_seq=False):
     """Pilot-based carrier-phase estimation on a frame-aligned 1 sample/symbol pilot signal: ``(signal_out, phase_trace)``
     (qampy/phaserec.py:156-192 -> core.pilotbased_receiver.pilot_based_cpe_new)."""
-    if use_seq:
-        seq_len, idx, pilots = signal._pilot_seq_len, np.nonzero(signal._idx_pil)[0], signal.pilots
+    positions = np.flatnonzero(signal._idx_pil)
+    if use_seq:                                          # sequence + phase pilots, or the phase pilots behind the sequence only
+        reference, where, seq = signal.pilots, positions, signal._pilot_seq_len
     else:
-        seq_len, idx, pilots = None, np.nonzero(signal._idx_pil)[0][signal._pilot_seq_len:], signal.ph_pilots
-    out, phase = core.pilotbased_receiver.pilot_based_cpe_new(np.asarray(signal), np.asarray(pilots), idx, signal.frame_len, seq_len=seq_len,
-                                                              max_num_blocks=max_blocks, use_pilot_ratio=pilot_rat, num_average=N,
-                                                              nframes=nframes)
-    return signal.recreate_from_np_array(out), phase
+        reference, where, seq = signal.ph_pilots, positions[signal._pilot_seq_len:], None
+    corrected, trace = core.pilotbased_receiver.pilot_based_cpe_new(np.asarray(signal), np.asarray(reference), where, signal.frame_len, seq_len=seq,
+                                                                    num_average=N, use_pilot_ratio=pilot_rat, max_num_blocks=max_blocks, nframes=nframes)
+    return signal.recreate_from_np_array(corrected), trace
 
 
 def find_pilot_const_phase(rec_pilots, ref_pilots):
