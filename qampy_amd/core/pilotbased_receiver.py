@@ -145,26 +145,27 @@ def pilot_based_cpe_new(signal, pilot_symbs, pilot_idx, frame_len, seq_len=None,
     if num_average % 2 == 0:
         num_average += 1
         warnings.warn("Number of averages should be odd, adding one average, num_average={}".format(num_average))
-    sig, ref = np.atleast_2d(signal), np.atleast_2d(pilot_symbs)
-    per_frame = pilot_idx[:max_num_blocks:use_pilot_ratio]
-    total = min(frame_len * nframes, sig.shape[-1])
-    where = np.add.outer(np.arange(nframes) * frame_len, per_frame).ravel()
-    where = where[where < total]
-    got = sig[:, where]
-    sent = np.tile(ref[:, ::use_pilot_ratio], nframes)[:, :got.shape[-1]]
-    if got.shape != sent.shape:
+    rows, refs = np.atleast_2d(signal), np.atleast_2d(pilot_symbs)
+    span = min(frame_len * nframes, rows.shape[-1])          # symbols that get a phase
+    # pilots in use: every use_pilot_ratio-th of the first max_num_blocks of a frame, in every frame, as far as the signal goes
+    in_frame = pilot_idx[:max_num_blocks:use_pilot_ratio]
+    where = (np.arange(nframes)[:, None] * frame_len + in_frame[None, :]).ravel()
+    where = where[where < span]
+    sent = np.tile(refs[:, ::use_pilot_ratio], nframes)[:, :where.size]
+    if sent.shape[-1] != where.size:
         raise AssertionError("Inproper pilot configuration, the number of received pilots differs from reference ones")
-    if sent.shape[-1] < num_average:
+    if where.size < num_average:
         raise AssertionError("Inpropper pilot symbol configuration. Larger averaging block size than total number of pilot symbols")
-    smooth = moving_average(np.unwrap(np.angle(sent.conjugate() * got), axis=-1), num_average)
-    edge = (num_average - 1) // 2
-    knots = where[edge:-edge]
-    if knots.shape[-1] != smooth.shape[-1]:
+    # phase of every pilot against its reference, unwrapped and averaged over num_average neighbours: the knots of the phase trace
+    knot_phase = moving_average(np.unwrap(np.angle(rows[:, where] * sent.conjugate()), axis=-1), num_average)
+    half = num_average // 2
+    knots = where[half:where.size - half]
+    if knots.size != knot_phase.shape[-1]:
         raise AssertionError("averaged phase and new indices are not the same shape")
-    trace = np.zeros((sent.shape[0], total), dtype=sent.dtype)
-    trace[:] = [np.interp(np.arange(total), knots, row) for row in smooth]
-    out = sig[:, :total] * np.exp(-1j * trace)
-    return out[:, :nframes * frame_len], trace[:, :nframes * frame_len]
+    grid = np.arange(span)
+    trace = np.array([np.interp(grid, knots, p) for p in knot_phase]).astype(sent.dtype)
+    keep = nframes * frame_len
+    return (rows[:, :span] * np.exp(-1j * trace))[:, :keep], trace[:, :keep]
 
 
 def _equalize_pilot_jobs(rx, refs, starts, span, os, foe_comp, mu, M_pilot, Ntaps, Niter, adaptive, methods, wxinit):

@@ -134,15 +134,14 @@ class PilotSignal(np.ndarray):
     @staticmethod
     def _cal_pilot_idx(frame_len, pilot_seq_len, pilot_ins_rat):
         """Positions of pilots / payload inside a frame (behaviour of qampy/signals.py:1532-1545)."""
-        idx = np.arange(frame_len)
-        in_seq = idx < pilot_seq_len
-        if pilot_ins_rat == 0 or pilot_ins_rat is None:
-            idx_pil = in_seq
-        else:
-            if (frame_len - pilot_seq_len) % pilot_ins_rat != 0:
+        where = np.arange(frame_len)
+        behind = where - pilot_seq_len                   # position counted from the end of the pilot sequence
+        idx_pil = behind < 0
+        if pilot_ins_rat:
+            if (frame_len - pilot_seq_len) % pilot_ins_rat:
                 raise ValueError("Frame without pilot sequence divided by pilot rate needs to be an integer")
-            payload = ((idx - pilot_seq_len) % pilot_ins_rat != 0) & (idx - pilot_seq_len > 0)
-            idx_pil = ~payload
+            idx_pil = idx_pil | (behind % pilot_ins_rat == 0)
+        idx = where
         return idx, ~idx_pil, idx_pil
 
     M = property(lambda self: self._M)
@@ -190,18 +189,16 @@ class PilotSignal(np.ndarray):
         """Find the start of the pilot sequence per mode, reorder the modes accordingly and store ``shiftfctrs`` /
         ``synctaps`` (behaviour of qampy/signals.py:1709-1745; all search windows train in ONE launch)."""
         from .core import pilotbased_receiver
-        eqargs = {"adaptive_stepsize": True, "Niter": 10, "method": "cma", "Ntaps": 17, "mu": 5e-3}
-        eqargs.update(kwargs)
-        mu, Ntaps = eqargs.pop("mu"), eqargs.pop("Ntaps")
-        shift, foe, order, wx1, ok = pilotbased_receiver.frame_sync(np.asarray(self), np.asarray(self.pilot_seq), self.os, mu=mu, Ntaps=Ntaps,
-                                                                    frame_len=self.frame_len, M_pilot=self.Mpilots, **eqargs)
+        search = dict(adaptive_stepsize=True, Niter=10, method="cma", Ntaps=17, mu=5e-3)
+        search.update(kwargs)
+        ntaps = search.pop("Ntaps")
+        shift, foe, order, taps, found = pilotbased_receiver.frame_sync(np.asarray(self), np.asarray(self.pilot_seq), self.os, frame_len=self.frame_len,
+                                                                        M_pilot=self.Mpilots, Ntaps=ntaps, **search)
+        period = self.frame_len * self.os                 # shifts are positions inside one frame period
         self[:, :] = np.asarray(self)[order, :]
-        shift = np.array(shift)
-        shift[shift < 0] += self.frame_len * self.os
-        self.shiftfctrs = shift[order]
-        self.synctaps = Ntaps
-        self._foe = foe
-        return (wx1, ok) if returntaps else ok
+        self.shiftfctrs = np.where(np.asarray(shift) < 0, np.asarray(shift) + period, shift)[order]
+        self.synctaps, self._foe = ntaps, foe
+        return (taps, found) if returntaps else found
 
     def corr_foe(self, additional_foe=0):
         """Remove the coarse frequency offset found by :meth:`sync2frame` (qampy/signals.py:1747-1750)."""
