@@ -168,17 +168,24 @@ class _Field:
             raise AssertionError("The first 2 dimensions of wxy need to be the same shape as E")
         return wxy
 
-    def train(self, os, mu, M, wxy, TrSyms, Niter, method, adaptive, symbols, rows):
-        """One training stage on the prepared field; returns ``(taps, err)``."""
+    def train(self, os, mu, M, wxy, TrSyms, Niter, method, adaptive, symbols, rows, pit=None):
+        """One training stage on the prepared field; returns ``(taps, err)``.  ``pit``: options of the parallel-in-time solver
+        (tier b) or ``None`` for the exact recurrence."""
         n = wxy.shape[-1]
         if TrSyms is None:
             TrSyms = _cal_training_symbol_len(os, n, self.L)
         sy = _reshape_symbols(symbols, method, M, self.dtype, self.rows).copy()
         mu = self.dtype.type(0).real.dtype.type(mu)
+        if pit is not None and self.real:
+            raise ValueError("parallel-in-time training (tier='b') is available for the complex-valued methods only")
         if self.real:
             err, wxy, _ = _kernels.train_equaliser_realvalued(self.host, TrSyms, Niter, os, mu, wxy, rows, adaptive, sy, method[:-len("_real")])
         else:
-            err, wxy, _ = self.dev.train(TrSyms, Niter, os, mu, wxy, rows, adaptive, sy, method)
+            if pit is None:
+                err, wxy, _ = self.dev.train(TrSyms, Niter, os, mu, wxy, rows, adaptive, sy, method)
+            else:
+                err, wxy, _ = self.dev.train(TrSyms, Niter, os, mu, wxy, rows, adaptive, sy, method, pit=pit)
+                _PIT_REPORTS.append(self.dev.last_report)
         return wxy, err
 
     def filtered(self, os, wxy, rows):
@@ -187,6 +194,39 @@ class _Field:
             return self.dev.apply(os, wxy, rows)
         out = _kernels.apply_filter_to_signal(self.host, os, np.array(wxy, copy=True, order="C"), rows)
         return _convert_sig_to_cmplx(out, rows.shape[0], (np.complex64 if self.dtype.itemsize == 4 else np.complex128)(1j))
+
+
+#: device reports (qh_pit_report as dicts) of the tier-b stages of the most recent equalise_signal / dual_mode_equalisation call
+_PIT_REPORTS = []
+
+#: boundary-defect tolerance of a tier-b stage whose taps only seed the next stage (the result stage: the library's 0.01)
+PIT_TOL_SEEDING = 0.06
+
+
+def last_pit_reports():
+    """Tier b: what the device decided in the most recent call - one dict per stage (segments, passes, defect per pass,
+    converged, acquisition).  ``converged`` False means the result is NOT certified as equivalent to the sequential recurrence."""
+    return list(_PIT_REPORTS)
+
+
+def _tier_options(kwargs, nstages, cold):
+    """``tier="a"`` (default): the exact sequential recurrence.  ``tier="b"``: the same recurrence solved in parallel in time
+     - fixed step sizes, complex-valued blind / decision-directed methods; ``pit`` = one dict of solver options for
+    all stages or one per stage.  Returns one options dict (or None) per stage."""
+    tier, pit = kwargs.pop("tier", "a"), kwargs.pop("pit", None)
+    del _PIT_REPORTS[:]
+    if tier == "a":
+        return [None] * nstages
+    if tier != "b":
+        raise ValueError("tier must be 'a' (exact sequential recurrence) or 'b' (parallel in time)")
+    per_stage = [dict(p) for p in pit] if isinstance(pit, (list, tuple)) else [dict(pit or {}) for _ in range(nstages)]
+    if len(per_stage) != nstages:
+        raise ValueError("pit needs one options dict per stage")
+    for k, o in enumerate(per_stage):
+        o.setdefault("acquire", 1 if (k == 0 and cold) else 0)     # centre-spike start taps: sequential acquisition first
+        if k < nstages - 1:
+            o.setdefault("tol", PIT_TOL_SEEDING)
+    return per_stage
 
 
 def _method_name(method):
@@ -202,12 +242,13 @@ def equalise_signal(E, os, mu, M, wxy=None, Ntaps=None, TrSyms=None, Niter=1, me
     Blind / decision-directed / data-aided equaliser training (behaviour of equalisation.py:468-566).
 
     Returns ``(wxy, err)`` or, with ``apply=True``, ``(E_equalised, wxy, err)``.  Unknown keyword arguments are
-    swallowed like in the reference.
+    swallowed like in the reference; ``tier="b"`` / ``pit=...`` select the parallel-in-time solver (:func:`_tier_options`).
     """
     method = _method_name(method)
+    pit = _tier_options(kwargs, 1, wxy is None)[0]
     field = _Field(E, method in REAL_VALUED)
     rows = field.mode_rows(modes)
-    taps, err = field.train(os, mu, M, field.taps(wxy, Ntaps), TrSyms, Niter, method, adaptive_stepsize, symbols, rows)
+    taps, err = field.train(os, mu, M, field.taps(wxy, Ntaps), TrSyms, Niter, method, adaptive_stepsize, symbols, rows, pit=pit)
     if apply:
         return field.filtered(os, taps, rows), taps, err
     return taps, err
@@ -225,6 +266,7 @@ def dual_mode_equalisation(E, os, mu, M, wxy=None, Ntaps=None, TrSyms=(None, Non
     ``None`` generates the alphabet like ``equalise_signal`` does.
     """
     stages = [_method_name(m) for m in methods]
+    pits = _tier_options(kwargs, 2, wxy is None)
     real = [m in REAL_VALUED for m in stages]
     if real[0] != real[1]:
         raise ValueError("the two stages must both be complex-valued or both real-valued methods")
@@ -238,7 +280,7 @@ def dual_mode_equalisation(E, os, mu, M, wxy=None, Ntaps=None, TrSyms=(None, Non
     taps = field.taps(wxy, Ntaps)
     errs = []
     for k in range(2):
-        taps, err = field.train(os, mu[k], M, taps, TrSyms[k], Niter[k], stages[k], adaptive_stepsize[k], sy[k], rows)
+        taps, err = field.train(os, mu[k], M, taps, TrSyms[k], Niter[k], stages[k], adaptive_stepsize[k], sy[k], rows, pit=pits[k])
         errs.append(err)
     if apply:
         return field.filtered(os, taps, rows), taps, tuple(errs)

@@ -212,7 +212,9 @@ class ResidentField:
         self.shape, self.ct, self.rt = E.shape, ct, rt
         self.dev = DeviceArray.from_host(E)
 
-    def train(self, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method):
+    def train(self, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method, pit=None):
+        """``pit``: ``None`` for the exact sequential recurrence, or a dict of ``qh_pit_opts`` fields for the parallel-in-time
+        solver (tier b); its device report is kept in ``self.last_report``."""
         if method not in _lib.METHOD_ID:
             raise ValueError("Unknown method %s" % method)
         nmodes, L = self.shape
@@ -228,7 +230,13 @@ class ResidentField:
         dw, dsy = DeviceArray.from_host(wx), DeviceArray.from_host(symbols)
         dmu = DeviceArray.from_host(np.array([mu], dtype=self.rt))
         derr = DeviceArray((nmodes, int(TrSyms) * int(Niter)), self.ct)
-        train_equaliser_dev(self.dev, TrSyms, Niter, os, dmu, dw, modes, adaptive, dsy, method, derr, zero_err=True)
+        self.last_report = None
+        if pit is None:
+            train_equaliser_dev(self.dev, TrSyms, Niter, os, dmu, dw, modes, adaptive, dsy, method, derr, zero_err=True)
+        else:
+            rep = PitReportBuffer()
+            train_equaliser_dev(self.dev, TrSyms, Niter, os, dmu, dw, modes, adaptive, dsy, method, derr, zero_err=True, pit=dict(pit), report=rep)
+            self.last_report = rep.read()
         wx[...] = dw.to_host()
         return derr.to_host(), wx, self.rt(dmu.to_host()[0])
 

@@ -179,3 +179,33 @@ def test_ser_equivalence_with_symbol_errors():
     assert min(errs["a"]) > 500, errs                                   # the capture does have symbol errors
     for a, b in zip(errs["a"], errs["b"]):
         assert abs(a - b) <= 4 * np.sqrt(a), (errs, reps["b"])
+
+
+def test_tier_b_through_the_mirrored_api():
+    """`tier="b"` on QAMpy's own call surface (equalise_signal / dual_mode_equalisation): same return values, device reports through
+    last_pit_reports(); against the default exact path on the same signal object."""
+    import qampy_amd
+    sig = synth.make_capture(64, 2 ** 18, nmodes=2, snr_db=30, theta=np.pi / 5.6, dgd=30e-12, linewidth=100., seed=5, dtype=np.complex64)
+    ea, wa, (e1a, e2a) = qampy_amd.equalisation.dual_mode_equalisation(sig, (2e-4, 2e-4), 41, methods=("cma", "mrde"))
+    assert core_eq.last_pit_reports() == []
+    eb, wb, (e1b, e2b) = qampy_amd.equalisation.dual_mode_equalisation(sig, (2e-4, 2e-4), 41, methods=("cma", "mrde"), tier="b")
+    reps = core_eq.last_pit_reports()
+    assert len(reps) == 2 and all(r["converged"] for r in reps) and reps[0]["acquisition"]["steps"] > 0 and reps[1]["acquisition"]["steps"] == 0
+    assert type(eb) is type(ea) and eb.shape == ea.shape and e1b.shape == e1a.shape and wb.shape == wa.shape
+    for m in range(2):
+        g = 1j ** int(np.rint(np.angle(np.vdot(wb[m].ravel(), wa[m].ravel())) / (np.pi / 2)))
+        assert np.sqrt(np.mean(np.abs(np.asarray(ea)[m] - g * np.asarray(eb)[m]) ** 2)) < 1e-2
+    ra, _ = qampy_amd.phaserec.bps(ea, 64, 20)
+    rb, _ = qampy_amd.phaserec.bps(eb, 64, 20)
+    for m in range(2):
+        na = synth.count_symbol_errors(np.asarray(ra)[m], sig.symbols, sig.coded_symbols, trim=2000)[0]
+        nb = synth.count_symbol_errors(np.asarray(rb)[m], sig.symbols, sig.coded_symbols, trim=2000)[0]
+        assert abs(na - nb) <= 3, (na, nb)
+    # one stage, warm start from given taps: no acquisition; bad option -> ValueError; adaptive step -> ValueError
+    w2, err = qampy_amd.equalisation.equalise_signal(sig, 2e-4, wxy=wa.copy(), method="mrde", tier="b")
+    r = core_eq.last_pit_reports()
+    assert len(r) == 1 and r[0]["acquisition"]["steps"] == 0 and r[0]["converged"]
+    with pytest.raises(ValueError):
+        qampy_amd.equalisation.equalise_signal(sig, 2e-4, Ntaps=41, method="cma", tier="c")
+    with pytest.raises(ValueError):
+        qampy_amd.equalisation.equalise_signal(sig, 2e-4, Ntaps=41, method="cma", tier="b", adaptive_stepsize=True)
