@@ -404,6 +404,10 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
             if (!(amp > 1.0)) amp = 1.0;
         }
         if (red[0] * amp < c->tol) { c->converged = 1; c->done = 1; }
+        // nothing gained over two passes: the trajectory has no fixed point the passes can agree on (a stage that cannot track the
+        // carrier) - stop, NOT converged; further passes would only cost time.  (Slow but steady gains - rde's ring decisions - go on
+        // to max_passes: the uncertified result keeps improving with them.)
+        else if (p >= 2 && p < QH_PIT_MAXPASS && !(red[0] < c->defect[p - 2])) c->done = 1;
         host_view[0] = c->done ? 1.f : 0.f;                   // what the host reads after the pass: flag + defect (to decide
         host_view[1] = (float)red[0];                         // whether the pass after the next one is worth enqueueing early)
     }
