@@ -621,7 +621,8 @@ def main():
                              "coarse correction until every boundary defect < tol" % " -> ".join(cfg["methods"]),
                       value=round(value_timed, 4), unit="MSym/s", ms_per_step=round(ms_timed, 3),
                       stages=[dict(stage=stage_names[1 + s], S=r["segments"], seg_len=r["seg_len"], P=r["passes"], converged=r["converged"], tol=r["tol"],
-                                   defect=[float("%.3g" % d) for d in r["defect"]], prefix=r["acquisition"]["steps"],
+                                   defect=[float("%.3g" % d) for d in r["defect"]], result_change=[float("%.3g" % d) for d in r.get("result_change", [])],
+                                   prefix=r["acquisition"]["steps"],
                                    acquisition=dict(steps=r["acquisition"]["steps"], mu=r["acquisition"]["mu"], diverged=r["acquisition"]["diverged"]),
                                    coarse_correction=r["correction"], gain=round(r["gain"], 4),
                                    pass_ms=round(kern[s]["mean_ms"], 3), acquisition_ms=round(kern[s]["acquisition_ms"], 3))

@@ -271,6 +271,9 @@ typedef struct qh_pit_report {
     double acq_err[QH_PIT_MAXCHUNK];    /* mean |err|^2 of the acquisition chunks */
     double gain, out_power;             /* linearised error-function gain g and mean output power used by the correction */
     int32_t acq_done, done, diverged, corr_on;   /* device-side flags */
+    double result_change[QH_PIT_MAXPASS]; /* how far the sweep's RESULT (end taps of the last segment) moved from pass p-1 to pass p, as the relative
+                                            rms difference of the two outputs on the last 128 steps (modulo the error function's symmetry);
+                                            pass 0: against the start taps; -1 = not run */
 } qh_pit_report;
 int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold, int *segments);   /* cold: the sweep starts from unconverged taps (acquire) */
 /* Eigenbasis of the input covariance <conj(x) x^T> of the training windows of a capture, for the coarse correction: depends

@@ -117,7 +117,8 @@ class PitReport(C.Structure):
                 ("mu", C.c_double), ("mu_acq", C.c_double), ("power", C.c_double), ("tol", C.c_double),
                 ("defect", C.c_double * PIT_MAXPASS), ("acq_err", C.c_double * PIT_MAXCHUNK),
                 ("gain", C.c_double), ("out_power", C.c_double),
-                ("acq_done", C.c_int32), ("done", C.c_int32), ("diverged", C.c_int32), ("corr_on", C.c_int32)]
+                ("acq_done", C.c_int32), ("done", C.c_int32), ("diverged", C.c_int32), ("corr_on", C.c_int32),
+                ("result_change", C.c_double * PIT_MAXPASS)]
 
     def as_dict(self):
         return dict(segments=int(self.segments), seg_len=int(self.seg_len), passes=int(self.passes), converged=bool(self.converged),
@@ -125,7 +126,7 @@ class PitReport(C.Structure):
                     acquisition=dict(steps=int(self.acq_steps), chunks=int(self.acq_chunks), mu=float(self.mu_acq),
                                      diverged=bool(self.diverged), mean_sq_err=[float(v) for v in self.acq_err if v >= 0]),
                     mu=float(self.mu), power=float(self.power), gain=float(self.gain), out_power=float(self.out_power),
-                    correction=bool(self.corr_on))
+                    correction=bool(self.corr_on), result_change=[float(d) for d in self.result_change if d >= 0])
 
 
 _lib = None

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(256) pit_setup_kernel(const Cx<R> *E, int nmod
         if (ma > cap) ma = cap;
         if (!(ma > m)) ma = m;
         c->segments = sg.S; c->seg_len = sg.len; c->mu = m; c->mu_acq = ma; c->power = p; c->tol = tol;
-        c->passes = 0; c->converged = 0; c->acq_chunks = 0; c->acq_steps = 0; c->acq_done = 0; c->done = 0; c->diverged = 0; c->corr_on = 0; c->gain = 0; c->out_power = 0;
+        for (int q = 0; q < QH_PIT_MAXPASS; q++) c->result_change[q] = -1; c->passes = 0; c->converged = 0; c->acq_chunks = 0; c->acq_steps = 0; c->acq_done = 0; c->done = 0; c->diverged = 0; c->corr_on = 0; c->gain = 0; c->out_power = 0;
         for (int i = 0; i < QH_PIT_MAXPASS; i++) c->defect[i] = -1;
         for (int i = 0; i < QH_PIT_MAXCHUNK; i++) c->acq_err[i] = -1;
         *mu_acq = (R)ma;
@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(256) pit_setup_kernel(const Cx<R> *E, int nmod
 static __global__ void pit_sweep_kernel(PitCtrl *c)
 {
     c->done = 0; c->converged = 0; c->passes = 0;
+    for (int q = 0; q < QH_PIT_MAXPASS; q++) c->result_change[q] = -1;
     for (int i = 0; i < QH_PIT_MAXPASS; i++) c->defect[i] = -1;
 }
 
@@ -266,7 +267,8 @@ __global__ void __launch_bounds__(256) pit_seed_kernel(const Cx<R> *wx, int nmod
 // on PIT_PROBE symbol periods from the boundary on, modulo the symmetry of the error function
 template <typename R>
 __global__ void __launch_bounds__(PIT_PROBE) pit_defect_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, int ntaps, PitSeg sg, int64_t TrSyms,
-                                                                const int64_t *modes_dev, const Cx<R> *X, const Cx<R> *Y, int sym, const PitCtrl *c, double *dfc, double *pw, double *gph)
+                                                                const int64_t *modes_dev, const Cx<R> *X, const Cx<R> *Y, int sym, const PitCtrl *c, double *dfc, double *pw, double *gph,
+                                                                const Cx<R> *wx_prev)
 {
     if (c->done) return;
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
@@ -279,11 +281,14 @@ __global__ void __launch_bounds__(PIT_PROBE) pit_defect_kernel(const Cx<R> *E, i
     const int b = blockIdx.x + 1, j = blockIdx.y;
     const int mode = (int)modes_dev[j];
     const size_t wset = (size_t)nmodes * ntot;
+    // b == S (one block row more than there are boundaries): the sweep's RESULT - end taps of the last segment - against the
+    // result of the previous pass (wx_prev), probed on the last PIT_PROBE steps of the sweep: how far the output still moved
+    const bool result_probe = b == sg.S;
     for (int f = threadIdx.x; f < ntot; f += PIT_PROBE) {
-        wa[f] = X[(size_t)b * wset + (size_t)mode * ntot + f];
+        wa[f] = result_probe ? wx_prev[(size_t)mode * ntot + f] : X[(size_t)b * wset + (size_t)mode * ntot + f];
         wb[f] = Y[(size_t)(b - 1) * wset + (size_t)mode * ntot + f];
     }
-    const int64_t st0 = sg.start(b);
+    const int64_t st0 = result_probe ? (TrSyms > PIT_PROBE ? TrSyms - PIT_PROBE : 0) : sg.start(b);
     int64_t nout = TrSyms - st0;
     if (nout > PIT_PROBE) nout = PIT_PROBE;
     const int ns = nout > 0 ? (int)(nout - 1) * os + ntaps : 0;
@@ -333,11 +338,11 @@ __global__ void __launch_bounds__(PIT_PROBE) pit_defect_kernel(const Cx<R> *E, i
             gr = cos(k); gi = sin(k);
             proj = Cr * gr + Ci * gi;
         }
-        gph[2 * ((size_t)blockIdx.x * gridDim.y + j)] = gr; gph[2 * ((size_t)blockIdx.x * gridDim.y + j) + 1] = gi;
+        if (!result_probe) { gph[2 * ((size_t)blockIdx.x * gridDim.y + j)] = gr; gph[2 * ((size_t)blockIdx.x * gridDim.y + j) + 1] = gi; }
         double d2 = (A + B - 2 * proj) / (B > 1e-300 ? B : 1e-300);
         if (d2 < 0) d2 = 0;
         dfc[(size_t)blockIdx.x * gridDim.y + j] = (A == A && B == B) ? sqrt(d2) : 1e30;
-        pw[(size_t)blockIdx.x * gridDim.y + j] = B / PIT_PROBE;
+        if (!result_probe) pw[(size_t)blockIdx.x * gridDim.y + j] = B / PIT_PROBE;
     }
 }
 
@@ -359,7 +364,7 @@ template <typename R> __device__ inline double pit_gain(int method, double Py, C
 // end of a pass: largest boundary defect -> report; the pass's end taps become the sweep's result; converged -> later passes skip
 template <typename R>
 __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, const double *pw, int nb, const Cx<R> *Ylast, int n, Cx<R> *wx, int method,
-                                                         const Cx<R> *sy0, int want_corr, PitCtrl *c, float *host_view)
+                                                         const Cx<R> *sy0, int want_corr, PitCtrl *c, float *host_view, int sym, int nrow)
 {
     if (c->done) return;
     __shared__ double red[256], redp[256];
@@ -378,10 +383,13 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
         }
         __syncthreads();
     }
+    // how far the sweep's result still moved in this pass, in output terms (pit_defect_kernel's extra block row; nrow entries after the nb boundaries)
+    double chg = 0;
+    for (int r = 0; r < nrow; r++) { const double v = dfc[nb + r]; chg = (v > chg || !(v == v)) ? v : chg; }
     for (int e = threadIdx.x; e < n; e += 256) wx[e] = Ylast[e];
     if (threadIdx.x == 0) {
         const int p = c->passes;
-        if (p < QH_PIT_MAXPASS) c->defect[p] = red[0];
+        if (p < QH_PIT_MAXPASS) { c->defect[p] = red[0]; c->result_change[p] = chg; }
         c->passes = p + 1;
         if (p == 0) {
             const double Py = redp[0] / nb;
@@ -1154,11 +1162,11 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             }
             const size_t dlds = (2 * (size_t)ntot + (size_t)nmodes * os * pit_phase_pitch(ntaps, os, PIT_PROBE)) * sizeof(Cx<R>);
             QH_REQUIRE(dlds <= 60 * 1024, "train_equaliser: boundary probe does not fit the LDS for this filter shape");
-            hipLaunchKernelGGL((pit_defect_kernel<R>), dim3(sg.S - 1, nsel), dim3(PIT_PROBE), dlds, g_stream, (const Cx<R> *)E, nmodes, L, os,
-                               ntaps, sg, TrSyms, (const int64_t *)modes_dev, (const Cx<R> *)X, (const Cx<R> *)Y, sym, (const PitCtrl *)ctrl, dfc, pw, gph);
+            hipLaunchKernelGGL((pit_defect_kernel<R>), dim3(sg.S, nsel), dim3(PIT_PROBE), dlds, g_stream, (const Cx<R> *)E, nmodes, L, os,
+                               ntaps, sg, TrSyms, (const int64_t *)modes_dev, (const Cx<R> *)X, (const Cx<R> *)Y, sym, (const PitCtrl *)ctrl, dfc, pw, gph, (const Cx<R> *)wx);
             hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, (int)((sg.S - 1) * nsel),
                                (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, method,
-                               (const Cx<R> *)symbols + (size_t)modes[0] * nsy, want_corr ? 1 : 0, ctrl, host_view);
+                               (const Cx<R> *)symbols + (size_t)modes[0] * nsy, want_corr ? 1 : 0, ctrl, host_view, sym, nsel);
             QH_HIP(hipGetLastError());
             QH_HIP(hipMemcpyAsync(&ev.hview[2 * p], host_view, 2 * sizeof(float), hipMemcpyDeviceToHost, g_stream));
             QH_HIP(hipEventRecord(ev.flag[p], g_stream));

@@ -122,7 +122,7 @@ for seed in [int(s) for s in args.seeds.split(",")]:
                        err_pow_exact=[[[round(float(np.mean(np.abs(e[m, i * n8:(i + 1) * n8]) ** 2)), 5) for i in range(8)] for m in range(2)] for e in e_ref])
         out.append(rec)
         print(json.dumps(rec), flush=True)
-        print("##", v, seed, rec["ms"], st, rec["errors"], [(r["segments"], r["passes"], [round(x, 4) for x in r["defect"]], r["acquisition"]["steps"]) for r in rec["report"]],
+        print("##", v, seed, rec["ms"], st, rec["errors"], [(r["segments"], r["passes"], [round(x, 4) for x in r["defect"]], [round(x, 4) for x in r["result_change"]], r["acquisition"]["steps"]) for r in rec["report"]],
               [round(x, 5) for x in rec.get("eq_rms_dev", [])], flush=True)
         del rx
     del ref

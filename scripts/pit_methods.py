@@ -43,4 +43,4 @@ for c in CASES:
             res[tier] = dict(error=repr(e)[:200])
     b = res["b"]
     print("##", c["name"], "| a:", res["a"].get("ms"), res["a"].get("errors"), "| b:", b.get("ms"), b.get("errors"), b.get("error"),
-          [(r["segments"], r["passes"], r["converged"], [round(x, 4) for x in r["defect"]]) for r in (b.get("rep") or [])], flush=True)
+          [(r["segments"], r["passes"], r["converged"], [round(x, 4) for x in r["defect"]], [round(x, 4) for x in r["result_change"]]) for r in (b.get("rep") or [])], flush=True)
