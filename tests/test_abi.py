@@ -85,3 +85,29 @@ def test_c_program_drives_the_hot_path(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("symbol errors") == 2
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of qh_pit_opts and qh_pit_report as the C compiler sees them against the ctypes mirrors in qampy_amd/_lib.py."""
+    import shutil
+    import subprocess
+    import ctypes as C
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    from qampy_amd import _lib
+    src = tmp_path / "layout.c"
+    fields_o = ["segments", "tol", "acq_chunk", "correction", "basis", "corr_beta", "seg_first", "exchange", "exchange_user"]
+    fields_r = ["segments", "seg_len", "mu", "defect", "acq_err", "gain", "acq_done", "result_change"]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "qampy_hip.h"', 'int main(void) {',
+             'printf("%zu %zu\\n", sizeof(qh_pit_opts), sizeof(qh_pit_report));']
+    lines += ['printf("%%zu\\n", offsetof(qh_pit_opts, %s));' % f for f in fields_o]
+    lines += ['printf("%%zu\\n", offsetof(qh_pit_report, %s));' % f for f in fields_r]
+    lines += ["return 0; }"]
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert [int(out[0]), int(out[1])] == [C.sizeof(_lib.PitOpts), C.sizeof(_lib.PitReport)]
+    got = [int(v) for v in out[2:]]
+    want = [getattr(_lib.PitOpts, f).offset for f in fields_o] + [getattr(_lib.PitReport, f).offset for f in fields_r]
+    assert got == want
