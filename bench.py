@@ -9,7 +9,9 @@ unwrap and de-rotation of every mode) over one synthetic dual-polarisation 2 SPS
 With N GPUs every rank processes its own independent channel (seed 1000 + rank, BASELINE.json config 4): weak scaling, no
 collective on the data path; torch.distributed (RCCL) carries only the barriers, the max-over-ranks of the elapsed time,
 the sum of the symbol-error counters and the count of ranks.  `--gpus N` with N > 1 launches the N ranks itself (re-exec
-under torch.distributed.run, 127.0.0.1 rendezvous) unless it already runs inside such a launch.
+under torch.distributed.run, 127.0.0.1 rendezvous) unless it already runs inside such a launch.  `--split-capture` (N > 1,
+informational) is the other sharding: ONE capture, the tier-b segments spread over the ranks with an all-reduce of their end
+taps per pass (qampy_amd/distributed.py; "scaling": "strong").
 
 Trainer tiers.  The timed pipeline uses tier "b", the parallel-in-time solver of the equaliser recurrence
 (concurrently trained segments + waveform relaxation + linearised coarse correction, stopped by a device-side boundary

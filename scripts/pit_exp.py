@@ -37,6 +37,8 @@ VARIANTS = {
     "tol1=.035": (dict(tol=0.035), {}),
     "tol1=.1": (dict(tol=0.1), {}),
     "S1=2816": (dict(segments=2816), {}),
+    "S1=2304": (dict(segments=2304), {}),
+    "S1=3328": (dict(segments=3328), {}),
     "S1=3840": (dict(segments=3840), {}),
     "chunk2048": (dict(acq_chunk=2048), {}),
     "gear16c2048": (dict(gear=16., acq_bound=0.16, acq_chunk=2048), {}),
