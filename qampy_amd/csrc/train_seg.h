@@ -123,6 +123,7 @@ constexpr int SG_PIECES = SG_PITCH / 64;
 // rows per buffer (segment windows of the wave x input modes) = chains per wave; staging registers per lane = rows x pieces
 constexpr int SG_MAXRAG = 3;       // padding taps a lane may hold (handled by selects on its last three tap slots)
 
+#ifdef QH_SEG_KERNELS        // the kernels and their per-method launchers live in train_seg_{a,b}_{f32,f64}.hip (build time: ~190 instantiations)
 template <typename R, int METHOD, int NPART, int TPL, int LPC>
 __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
 {
@@ -299,6 +300,8 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     }
 }
 
+#endif  // QH_SEG_KERNELS
+
 // ------------------------------------------------------------------------------------------------ host side
 // taps per lane for `lpc` lanes per chain (0: no layout).  16 lanes per chain is the general form; 8 lanes per chain (8 chains
 // per wave, instantiated for single precision and 6 / 11 taps per lane) issues 0.64 x the instructions per chain and step and
@@ -341,6 +344,7 @@ template <typename R> inline int seg_lanes(int nmodes, int ntaps, int nsel, int 
     return can8 && nq >= SG_LPC8_MIN ? 8 : 16;
 }
 
+#ifdef QH_SEG_KERNELS
 template <typename R, int METHOD, int NPART> static int launch_seg_tpl(const SegArgs<R> &a, int tpl, int lpc, dim3 grid, size_t lds)
 {
     if (lpc == 8) {
@@ -382,6 +386,36 @@ template <typename R, int METHOD> static int launch_seg_dd(const SegArgs<R> &a, 
     }
 }
 
+// group A: the partitioned (radius-directed) functions; group B: cma-type and decision-directed ones.  One translation unit each.
+template <typename R> int launch_seg_group_a(const SegArgs<R> &a, int method, int npart, int tpl, int lpc, dim3 grid, size_t lds)
+{
+    switch (method) {
+    case QH_M_RDE: return launch_seg_parts<R, QH_M_RDE>(a, npart, tpl, lpc, grid, lds);
+    case QH_M_MRDE: return launch_seg_parts<R, QH_M_MRDE>(a, npart, tpl, lpc, grid, lds);
+    default: return QH_ERR_METHOD;
+    }
+}
+template <typename R> int launch_seg_group_b(const SegArgs<R> &a, int method, int npart, int tpl, int lpc, dim3 grid, size_t lds)
+{
+    switch (method) {
+    case QH_M_CMA: case QH_M_SGNCMA: return launch_seg_tpl<R, QH_M_CMA, 0>(a, tpl, lpc, grid, lds);
+    case QH_M_CMA2: return launch_seg_tpl<R, QH_M_CMA2, 0>(a, tpl, lpc, grid, lds);
+    case QH_M_MCMA: return launch_seg_tpl<R, QH_M_MCMA, 0>(a, tpl, lpc, grid, lds);
+    case QH_M_SBD: return launch_seg_dd<R, QH_M_SBD>(a, npart, tpl, lpc, grid, lds);
+    case QH_M_MDDMA: return launch_seg_dd<R, QH_M_MDDMA>(a, npart, tpl, lpc, grid, lds);
+    case QH_M_DD: return launch_seg_dd<R, QH_M_DD>(a, npart, tpl, lpc, grid, lds);
+    default: return QH_ERR_METHOD;
+    }
+}
+#else
+template <typename R> int launch_seg_group_a(const SegArgs<R> &a, int method, int npart, int tpl, int lpc, dim3 grid, size_t lds);
+template <typename R> int launch_seg_group_b(const SegArgs<R> &a, int method, int npart, int tpl, int lpc, dim3 grid, size_t lds);
+extern template int launch_seg_group_a<float>(const SegArgs<float> &, int, int, int, int, dim3, size_t);
+extern template int launch_seg_group_a<double>(const SegArgs<double> &, int, int, int, int, dim3, size_t);
+extern template int launch_seg_group_b<float>(const SegArgs<float> &, int, int, int, int, dim3, size_t);
+extern template int launch_seg_group_b<double>(const SegArgs<double> &, int, int, int, int, dim3, size_t);
+#endif  // QH_SEG_KERNELS
+
 // `a` complete except lpm / pitch / rag; method-specific table layout as for launch_bi (slicer tables for sbd / mddma / dd)
 template <typename R> int launch_seg(SegArgs<R> a, int method)
 {
@@ -396,18 +430,8 @@ template <typename R> int launch_seg(SegArgs<R> a, int method)
     const size_t lds = (size_t)(2 * cpw + 1) * SG_PITCH * sizeof(Cx<R>);
     dim3 grid((nq + cpw - 1) / cpw);
     const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
-    int rc = QH_OK;
-    switch (method) {
-    case QH_M_CMA: case QH_M_SGNCMA: rc = launch_seg_tpl<R, QH_M_CMA, 0>(a, tpl, lpc, grid, lds); break;
-    case QH_M_CMA2: rc = launch_seg_tpl<R, QH_M_CMA2, 0>(a, tpl, lpc, grid, lds); break;
-    case QH_M_MCMA: rc = launch_seg_tpl<R, QH_M_MCMA, 0>(a, tpl, lpc, grid, lds); break;
-    case QH_M_RDE: rc = launch_seg_parts<R, QH_M_RDE>(a, npart, tpl, lpc, grid, lds); break;
-    case QH_M_MRDE: rc = launch_seg_parts<R, QH_M_MRDE>(a, npart, tpl, lpc, grid, lds); break;
-    case QH_M_SBD: rc = launch_seg_dd<R, QH_M_SBD>(a, npart, tpl, lpc, grid, lds); break;
-    case QH_M_MDDMA: rc = launch_seg_dd<R, QH_M_MDDMA>(a, npart, tpl, lpc, grid, lds); break;
-    case QH_M_DD: rc = launch_seg_dd<R, QH_M_DD>(a, npart, tpl, lpc, grid, lds); break;
-    default: return QH_ERR_METHOD;
-    }
+    const int rc = (method == QH_M_RDE || method == QH_M_MRDE) ? launch_seg_group_a<R>(a, method, npart, tpl, lpc, grid, lds)
+                                                                : launch_seg_group_b<R>(a, method, npart, tpl, lpc, grid, lds);
     if (rc) return rc;
     QH_HIP(hipGetLastError());
     return QH_OK;
