@@ -464,8 +464,8 @@ def run_c5(args, cfg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--nsym", type=int, default=None, help="override the number of symbol periods per capture")
     ap.add_argument("--tier", default="b", choices=["a", "b"],
