@@ -84,7 +84,10 @@ def test_coarse_correction_converges_to_the_exact_trajectory(method, M, lanes, m
     assert abs(np.mean(np.abs(e[:, nlast:]) ** 2) / np.mean(np.abs(eo[:, nlast:]) ** 2) - 1) < 2e-2
 
 
-def test_complex128_and_oracle():
+@pytest.mark.parametrize("form", ["auto", "segment"])
+def test_complex128_and_oracle(form, monkeypatch):
+    if form == "segment":                       # the throughput form in double precision (16 lanes per chain; 8 lanes are single precision only)
+        monkeypatch.setenv("QAMPY_HIP_PIT_FORM", "segment")
     sig, E, tr, w0, sy, rt = _setup("mcma", 16, dtype=np.complex128)
     eo, wo, _ = oracle.train_equaliser(E, tr, 1, 2, 5e-4, w0.copy(), None, False, sy, "mcma")
     w, e, rep = _run_pit(E, tr, 1, 5e-4, w0, sy, "mcma", dict(segments=4, max_passes=4, tol=1e-14, correction=0, phase_seed=0, acquire=0), rt)
