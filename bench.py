@@ -679,12 +679,15 @@ def main():
         out["stages_ms"] = {n: round(t, 3) for n, t in zip(res_a["names"], res_a["stage_ms"])}
         out["steps"] = args.exact_steps
         out["note"] = "tier b did not certify itself in this run: headline = exact path"
-    out["config"]["train_mode"] = ("parallel-in-time (tier b), certified in-run: converged + SER within +-%d errors of the exact path" % SER_TOL_ERRORS) if use_b \
-        else "exact sequential recurrence (tier a)"
-    head_ms = stage_ms if (use_b or args.tier == "a") else res_a["stage_ms"]
+    uncertified_b = args.tier == "b" and not use_b and res_a is None       # N > 1 (no exact run beside it) and a stage that did not converge
+    if uncertified_b:
+        out["note"] = "tier b did NOT certify itself on every rank and no exact path ran beside it (N > 1): value is tier b's, uncertified"
+    out["config"]["train_mode"] = (("parallel-in-time (tier b), certified in-run: converged" + (" + SER within +-%d errors of the exact path" % SER_TOL_ERRORS if world == 1 else " on every rank"))
+                                   if use_b else ("parallel-in-time (tier b), NOT certified" if uncertified_b else "exact sequential recurrence (tier a)"))
+    head_ms = stage_ms if (use_b or args.tier == "a" or uncertified_b) else res_a["stage_ms"]
 
     # ---- roofline of the dominant kernel (largest total kernel time per step)
-    if use_b:
+    if use_b or uncertified_b:
         cands = [(tier_b["stages"][s]["pass_ms"] * tier_b["stages"][s]["P"], "train%d:%s relaxation pass" % (s + 1, cfg["methods"][s]),
                   train_bytes[s], tier_b["stages"][s]["pass_ms"]) for s in range(rx.nstage)]
         cands.append((stage_ms[0], "gram", stage_bytes[0], stage_ms[0]))

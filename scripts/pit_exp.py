@@ -38,6 +38,9 @@ VARIANTS = {
     "tol1=.1": (dict(tol=0.1), {}),
     "S1=2816": (dict(segments=2816), {}),
     "S1=2304": (dict(segments=2304), {}),
+    "acq6144": (dict(acq_chunk=3072, acq_max=6144), {}),
+    "acq4096": (dict(acq_chunk=2048, acq_max=4096), {}),
+    "acq5120": (dict(acq_chunk=2560, acq_max=5120), {}),
     "S1=3328": (dict(segments=3328), {}),
     "S1=3840": (dict(segments=3840), {}),
     "chunk2048": (dict(acq_chunk=2048), {}),

@@ -32,6 +32,7 @@ for c in CASES:
         try:
             pit = [dict() for _ in c["methods"]]
             pit[-1].update(PIT2)
+            pit[0].update(json.loads(os.environ.get("PIT1", "{}")))
             rx = ResidentReceiver(2, 2 * c["nsym"], 2, c["M"], c["ntaps"], c["mu"], tier=tier, pit=pit if tier == "b" else None, **kw)
             rx.E.copy_from(d["E"])
             rx.run(); _lib.sync()
