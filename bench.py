@@ -701,9 +701,10 @@ def main():
                         pipeline=tier_b["roofline"])
         if kname == "bps_recover" and rx.ct == np.complex64 and cfg["A"] <= 64:
             # streaming phase search: VALU instructions per symbol and wave counted in the ISA of bps_stream_kernel
-            # for a mirror-symmetric square alphabet with NL = sqrt(M)/2 positive levels per axis: 16.4 + 2 NL (24.4 at 64-QAM)
+            # for a mirror-symmetric square alphabet with NL = sqrt(M)/2 positive levels per axis: 20 + 2 NL (28 at 64-QAM; SQ_INSTS_VALU
+            # measures 27.95 per row, profiles/r02_pmc_instr_c3.txt)
             NL = max(1, int(round(np.sqrt(cfg["M"]))) // 2)
-            per_sym = 16.4 + 2 * NL
+            per_sym = 20.0 + 2 * NL
             C, W = 1024, 2 * cfg["Nbps"]
             rows = -(-nsym // C) * (-(-(C + W - 1) // 16) * 16) * rx.modes.size          # distance rows incl. the 2N-1 halo of every chunk
             winstr = rows * per_sym
