@@ -38,6 +38,11 @@ VARIANTS = {
     "tol1=.1": (dict(tol=0.1), {}),
     "S1=2816": (dict(segments=2816), {}),
     "S1=2304": (dict(segments=2304), {}),
+    "b2=.3": ({}, dict(corr_beta=0.3)),
+    "b2=.7": ({}, dict(corr_beta=0.7)),
+    "b2=1.5": ({}, dict(corr_beta=1.5)),
+    "S2=2944": ({}, dict(segments=2944)),
+    "S2=1984": ({}, dict(segments=1984)),
     "acq6144": (dict(acq_chunk=3072, acq_max=6144), {}),
     "acq4096": (dict(acq_chunk=2048, acq_max=4096), {}),
     "acq5120": (dict(acq_chunk=2560, acq_max=5120), {}),
