@@ -2,30 +2,36 @@
 """
 bench.py - equalised MSym/s of the adaptive-equaliser + carrier-recovery hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|ns] [--tier b|a] [--nsym S] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|ns|c2|c1|c5] [--tier b|a] [--tol T] [--no-cpu-baseline] ...
 
-One "step" = one pass of the hot path (Gram terms -> dual-mode tap training -> filter application -> blind phase search,
-unwrap and de-rotation of every mode) over one synthetic dual-polarisation 2 SPS capture that is already resident in HBM.
+One "step" = one pass of the hot path (dual-mode tap training -> filter application -> blind phase search, unwrap and
+de-rotation of every mode) over one synthetic dual-polarisation 2 SPS capture that is already resident in HBM.
 With N GPUs every rank processes its own independent channel (seed 1000 + rank, BASELINE.json config 4): weak scaling, no
-collective on the data path; torch.distributed (RCCL) carries only the barriers, the max-over-ranks of the elapsed time,
-the sum of the symbol-error counters and the count of ranks.  `--gpus N` with N > 1 launches the N ranks itself (re-exec
-under torch.distributed.run, 127.0.0.1 rendezvous) unless it already runs inside such a launch.  `--split-capture` (N > 1,
-informational) is the other sharding: ONE capture, the tier-b segments spread over the ranks with an all-reduce of their end
-taps per pass (qampy_amd/distributed.py; "scaling": "strong").
+collective on the data path; the process group (qampy_amd/comm.py: RCCL through ctypes on the library's HIP stream, no PyTorch)
+carries only the barriers, the max-over-ranks of the elapsed time, the sum of the symbol-error counters and the count of ranks.
+`--gpus N` with N > 1 starts the N ranks itself unless it already runs inside a launcher's environment (RANK / WORLD_SIZE, e.g.
+under torch.distributed.run as the driver starts it).  `--split-capture` (N > 1, informational) is the other sharding: ONE capture,
+the tier-b segments spread over the ranks with an all-reduce of their end taps per pass ("scaling": "strong").
 
-Trainer tiers.  The timed pipeline uses tier "b", the parallel-in-time solver of the equaliser recurrence
-(concurrently trained segments + waveform relaxation + linearised coarse correction, stopped by a device-side boundary
-defect below `tol`) - provided its own certificate holds in this very run: every stage reports `converged` and the symbol
-errors per mode are within +-3 of the exact sequential path (tier "a") run beside it on the same capture.  If either check
-fails, or with `--tier a`, the headline `value` is the exact path's.  Both numbers are always in the line (`tier_a`, `tier_b`).
+Trainer tiers.  Tier "a" is the exact sequential recurrence (the reference's order of evaluation).  Tier "b"
+solves the SAME recurrence from the SAME start taps in parallel in time (concurrently trained segments + waveform relaxation +
+linearised coarse correction) and stops when its device-side estimate of the rms deviation of the equaliser output from the
+sequential recurrence is below `tol` (default 1e-3, relative).  The timed pipeline uses tier b, and its number is the headline
+`value` only if it certifies itself in this very run: every stage converged by that estimate AND, measured against the exact
+path run beside it on the same capture, the recovered output is within tol (relative rms), the taps within 2 tol (relative) and
+the symbol errors within +-3 per mode.  Otherwise, or with `--tier a`, the headline is the exact path's.  Both are always in
+the line (`tier_a`, `tier_b`, `headline_tier`), and `speedup_vs_cpu` is keyed to the tier that produced `value`.
 
-The JSON line carries, besides the driver's contract fields:
-  roofline      dominant kernel of the step (largest total kernel time): algorithmic bytes per launch / mean launch duration
-                from HIP events on the library stream inside the timed region; plus `pipeline`: 88 B per symbol period (fully
-                fused lower bound) x symbol periods / step time
-  cpu_baseline  the oracle's reference-flag OpenMP build ("port" of the pythran loops) on this box's host cores: the whole
-                capture with all threads (3 runs), a bounded sample with one thread, CPU model, H2D / D2H times
-  tier_a, tier_b, parity_vs_cpu, channel_bank (+ its own CPU leg), stages_ms, ser
+The default line (N = 1, workload c3) additionally carries
+  tier_b_loose  the same solver held to tol = 1e-2 (the SER-equivalent tier), informational
+  cert_24dB     the same shape at 24 dB SNR, where both paths make thousands of symbol errors: counts within 3 sigma per mode
+  ns, c2        the north star's 10^7-symbol shape and BASELINE configs[1]: tier b + exact path + certificate
+  roofline      dominant kernel of the step (largest total kernel time): for the relaxation passes and the phase search the bound is
+                VALU issue (achieved / peak in wave instructions per second, instruction count from the PMC profile of the same
+                kernel sources when there is one), with the HBM view (algorithmic bytes / 8 TB/s) and the flop view beside it
+  cpu_baseline  the oracle's reference-flag OpenMP build ("port" of the pythran loops, exact recurrence) on this box's host cores:
+                the whole capture with all threads (3 runs) and with one thread, CPU model, H2D / D2H times
+  parity_vs_cpu, channel_bank (+ its own CPU leg), stages_ms, ser
 """
 import argparse
 import json
@@ -67,21 +73,15 @@ VALU_PEAK_GINSTR = 614.4        # wave64 fp32 instructions per second, nominal: 
 SEG_INSTR_PER_WAVE_STEP = {16: 68, 8: 94}    # train_seg_kernel main loop per wave and step by lanes per chain (ISA count at 41 taps x 2 modes)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FUSED_BYTES_PER_SYM = 88   # read E once, write err1, err2, out, ph (complex64, 2 modes, 2 samples/symbol)
-SER_TOL_ERRORS = 3         # tier b counts as SER-equivalent when every mode is within this many symbol errors of tier a
+SER_TOL_ERRORS = 3         # decisions: tier b's symbol errors per mode within this many of the exact path's (ONE of the checks; see run_pair)
 
 
 # ------------------------------------------------------------------------------------------------------------ launcher
 def self_launch(argv, gpus):
-    """`python bench.py --gpus N` outside a torchrun environment: start the N ranks (one per GPU) and relay their output."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + argv
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.call(cmd, env=env)
+    """`python bench.py --gpus N` outside a launcher's environment: start the N ranks (one per GPU) and relay their exit code
+    (qampy_amd.comm.launch: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT, as torch.distributed.run sets them)."""
+    from qampy_amd import comm
+    return comm.launch(os.path.abspath(__file__), argv, gpus)
 
 
 # ------------------------------------------------------------------------------------------------------------ workload
@@ -460,6 +460,147 @@ def run_c5(args, cfg):
     print(json.dumps(out))
 
 
+# ------------------------------------------------------------------------------------------------------------ tiers
+def deviation_vs_exact(rx, rxa, cfg):
+    """How far tier b's results are from the exact path's on the same capture (host copies): recovered output, taps and the error
+    trace of every stage, per output mode, modulo a common quarter turn per mode (symmetry of the error functions)."""
+    wa, wb = rxa.wxy.to_host(), rx.wxy.to_host()
+    ea = (rxa.out if cfg["A"] else rxa.eq).to_host()
+    eb = (rx.out if cfg["A"] else rx.eq).to_host()
+    out_rms, out_max, tap_rel, tap_max, g_m = [], [], [], [], []
+    for m in range(wa.shape[0]):
+        g = 1j ** int(np.rint(np.angle(np.vdot(wb[m].ravel(), wa[m].ravel())) / (np.pi / 2)))
+        g_m.append(g)
+        tap_rel.append(float(np.linalg.norm(wa[m] - g * wb[m]) / np.linalg.norm(wa[m])))
+        tap_max.append(float(np.max(np.abs(wa[m] - g * wb[m]))))
+        dd = np.abs(ea[m] - g * eb[m])
+        out_rms.append(float(np.sqrt(np.mean(dd ** 2)) / np.sqrt(np.mean(np.abs(ea[m]) ** 2))))
+        out_max.append(float(dd.max()))
+    del ea, eb
+    err_rms = []
+    for s_ in range(rx.nstage):                                   # error traces: rms of the difference, in units of the signal rms (unit power)
+        xa, xb = rxa.err[s_].to_host(), rx.err[s_].to_host()
+        row = []
+        for m in range(xa.shape[0]):
+            c = np.vdot(xb[m], xa[m])
+            g = 1j ** int(np.rint(np.angle(c) / (np.pi / 2))) if abs(c) > 0 else 1.0
+            row.append(float(np.sqrt(np.mean(np.abs(xa[m] - g * xb[m]) ** 2))))
+        err_rms.append(row)
+        del xa, xb
+    return dict(out_rms_dev_vs_exact=out_rms, out_max_dev_vs_exact=out_max, tap_rel_dev_vs_exact=tap_rel, max_abs_tap_dev_vs_exact=tap_max,
+                err_trace_rms_dev_vs_exact=err_rms)
+
+
+def tier_b_block(cfg, rx, stage_names, pass_ms, acq_ms, reports, value, ms, errs, nsym):
+    kern = []
+    for s in range(rx.nstage):
+        flat = [p for step in pass_ms[s] for p in step]
+        kern.append(dict(mean_ms=float(np.mean(flat)) if flat else 0., acquisition_ms=float(np.mean(acq_ms[s])) if acq_ms[s] else 0.))
+    return dict(method="parallel in time: %s; segments trained concurrently by the exact kernels, waveform relaxation + linearised coarse "
+                       "correction; segment 0 starts from the caller's taps (fixed point = the sequential recurrence); stopped by the device-side "
+                       "estimate of the output deviation from the sequential recurrence < tol" % " -> ".join(cfg["methods"]),
+                value=round(value, 4), unit="MSym/s", ms_per_step=round(ms, 3),
+                stages=[dict(stage=stage_names[1 + s], S=r["segments"], seg_len=r["seg_len"], P=r["passes"], converged=r["converged"], tol=r["tol"],
+                             defect=[float("%.3g" % d) for d in r["defect"]],
+                             est_deviation_rms=[float("%.3g" % d) for d in r.get("deviation_rms", [])],
+                             est_deviation_worst=[float("%.3g" % d) for d in r.get("deviation", [])],
+                             est_deviation_taps=[float("%.3g" % d) for d in r.get("deviation_taps", [])],
+                             result_change=[float("%.3g" % d) for d in r.get("result_change", [])],
+                             acquisition=dict(steps=r["acquisition"]["steps"], mu=r["acquisition"]["mu"], diverged=r["acquisition"]["diverged"]),
+                             coarse_correction=r["correction"], gain=round(r["gain"], 4),
+                             pass_ms=round(kern[s]["mean_ms"], 3), acquisition_ms=round(kern[s]["acquisition_ms"], 3))
+                        for s, r in enumerate(reports)],
+                errors=[e for e, _ in errs], converged=bool(all(r["converged"] for r in reports)),
+                limits=dict(max_segments=65536, coarse_correction_max_taps_per_mode=96, segment_kernel_max_taps="(64+1)*os + ntaps + 8 <= 192",
+                            max_passes_default=12, max_passes_cap=24),
+                pipeline_hbm=dict(achieved=round(FUSED_BYTES_PER_SYM * nsym / (ms * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                                  frac=round(FUSED_BYTES_PER_SYM * nsym / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                  note="whole step against the fully fused lower bound of 88 B per symbol period"))
+
+
+def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_check):
+    """Tier b (timed, `steps` passes) and the exact path beside it on the same resident capture: both blocks, the measured
+    deviation and the certificate.  Returns (tier_b, tier_a, extras for the roofline)."""
+    rx = make_receiver(cfg, sig, tier="b", pit=pit)
+    rx.load(sig)
+    names, _ = stage_list(rx)
+    elapsed, stage_ms, pass_ms, acq_ms = timed_steps(rx, steps, warmup, barrier_sync)
+    reports = rx.pit_reports()
+    ser_rows = rx.ser(sig.symbols, maxlag=256, window=8192, trim=2000) if cfg["A"] else []
+    errs = [(d["errors"], d["compared"]) for d in ser_rows]
+    tb = tier_b_block(cfg, rx, names, pass_ms, acq_ms, reports, nsym * steps / elapsed / 1e6, elapsed / steps * 1e3, errs, nsym)
+    tb["stages_ms"] = {n: round(t, 3) for n, t in zip(names, stage_ms)}
+    ta = None
+    if exact_steps > 0:
+        rxa = make_receiver(cfg, sig, tier="a")
+        rxa.load(sig)
+        el_a, ms_a, _, _ = timed_steps(rxa, exact_steps, 1, barrier_sync)
+        errs_a = [d["errors"] for d in rxa.ser(sig.symbols, maxlag=256, window=8192, trim=2000)] if cfg["A"] else []
+        ta = dict(method="exact sequential recurrence (reference order of evaluation)", value=round(nsym * exact_steps / el_a / 1e6, 4), unit="MSym/s",
+                  steps=exact_steps, ms_per_step=round(el_a / exact_steps * 1e3, 3), stages_ms={n: round(t, 3) for n, t in zip(names, ms_a)},
+                  errors=errs_a,
+                  train_cycles_per_step={names[1 + s2]: round(ms_a[1 + s2] * 1e-3 * 2.4e9 / (rxa.TrSyms[s2] * rxa.Niter[s2]), 1) for s2 in range(rxa.nstage)})
+        dev = deviation_vs_exact(rx, rxa, cfg)
+        tb.update(dev)
+        tb["errors_exact"] = errs_a
+        tb["speedup_vs_exact"] = round(tb["value"] / ta["value"], 2)
+        # the certificate of this run: the device's own (every stage's estimated deviation below tol) AND the measurement against
+        # the exact path: recovered output within tol (relative rms), taps within 2e-3 (relative), decisions: identical error counts +-3
+        ok_out = all(d <= tol_check for d in dev["out_rms_dev_vs_exact"])
+        ok_tap = all(d <= 2 * tol_check for d in dev["tap_rel_dev_vs_exact"])
+        ok_ser = all(abs(a - b) <= SER_TOL_ERRORS for a, b in zip(errs_a, [e for e, _ in errs]))
+        tb["checks"] = dict(converged=tb["converged"], out_rms_dev_le_tol=bool(ok_out), tap_rel_dev_le_2tol=bool(ok_tap), errors_within_3=bool(ok_ser), tol=tol_check)
+        tb["certified"] = bool(tb["converged"] and ok_out and ok_tap and ok_ser)
+        del rxa
+    else:
+        tb["certified"] = tb["converged"]
+    return tb, ta, dict(rx=rx, names=names, stage_ms=stage_ms, elapsed=elapsed, errs=errs, reports=reports)
+
+
+def cert_snr_block(cfg, snr_db, nsym, seed, barrier_sync, pit):
+    """Certification capture WITH symbol errors (the default capture makes none on either path, so its error count cannot fail):
+    same shape at a lower SNR; tier b's error counts against the exact path's, per mode, within 3 standard deviations of the count."""
+    c2 = dict(cfg, snr_db=snr_db)
+    sig = make_input(c2, nsym, seed)
+    tb, ta, ex = run_pair(c2, sig, nsym, 2, 1, barrier_sync, pit, 1, pit.get("tol", TOL_DEFAULT) if pit else TOL_DEFAULT)
+    ea, eb = ta["errors"], tb["errors"]
+    sig3 = [3.0 * float(np.sqrt(max(a, 1))) for a in ea]
+    ok = all(abs(a - b) <= s3 for a, b, s3 in zip(ea, eb, sig3)) and min(ea) > 100
+    del ex
+    return dict(snr_db=snr_db, nsym=nsym, seed=seed, errors_exact=ea, errors_tier_b=eb, allowed_difference_3sigma=[round(x, 1) for x in sig3],
+                exact_path_has_errors=bool(min(ea) > 100), within_3sigma=bool(ok), converged=tb["converged"], passes=[st["P"] for st in tb["stages"]],
+                out_rms_dev_vs_exact=tb["out_rms_dev_vs_exact"], tap_rel_dev_vs_exact=tb["tap_rel_dev_vs_exact"],
+                tier_b_MSym_s=tb["value"], tier_a_MSym_s=ta["value"])
+
+
+def shape_block(key, barrier_sync, pit, steps):
+    """Another BASELINE shape in the same line (ns: the north star's 10^7 symbols; c2: configs[1]): tier b, the exact path, SER, certificate."""
+    cfg = dict(WORKLOADS[key])
+    nsym = cfg["nsym"]
+    sig = make_input(cfg, nsym, 1000)
+    tb, ta, ex = run_pair(cfg, sig, nsym, steps, 1, barrier_sync, pit, 1, pit.get("tol", TOL_DEFAULT) if pit else TOL_DEFAULT)
+    del ex
+    return dict(workload=cfg["label"], nsym=nsym, tier_b=dict(value=tb["value"], ms_per_step=tb["ms_per_step"], certified=tb["certified"], checks=tb.get("checks"),
+                                                               stages=[dict(stage=st["stage"], S=st["S"], seg_len=st["seg_len"], P=st["P"], converged=st["converged"],
+                                                                            est_deviation_rms=st["est_deviation_rms"][-1:] , pass_ms=st["pass_ms"]) for st in tb["stages"]],
+                                                               out_rms_dev_vs_exact=tb["out_rms_dev_vs_exact"], tap_rel_dev_vs_exact=tb["tap_rel_dev_vs_exact"],
+                                                               err_trace_rms_dev_vs_exact=tb["err_trace_rms_dev_vs_exact"], errors=tb["errors"], stages_ms=tb["stages_ms"]),
+                tier_a=dict(value=ta["value"], ms_per_step=ta["ms_per_step"], errors=ta["errors"]), speedup_vs_exact=tb["speedup_vs_exact"])
+
+
+def pmc_json(name, workload):
+    """profiles/<name>_<workload>.json from the PMC passes of the same workload (scripts/gpu_pmc*.sh), only while the kernel sources
+    are the ones that were profiled."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "%s_%s.json" % (name, workload))))
+        return pmc if pmc.get("kernel_sources_sha") == kernel_sources_sha() else None
+    except (OSError, ValueError):
+        return None
+
+
+TOL_DEFAULT = 1e-3         # library default of tier b: estimated relative rms deviation of the equaliser output from the sequential recurrence
+
+
 # ------------------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -469,27 +610,29 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--nsym", type=int, default=None, help="override the number of symbol periods per capture")
     ap.add_argument("--tier", default="b", choices=["a", "b"],
-                    help="trainer of the timed pipeline: b = parallel-in-time solver of the recurrence, used for the headline only if it certifies "
-                         "itself in this run (converged + SER within +-3 errors of the exact path); a = the exact sequential recurrence")
-    ap.add_argument("--tol", type=float, default=0., help="boundary-defect tolerance of tier b (0 = library default 0.01; stages that only seed the next one 0.06)")
+                    help="trainer of the timed pipeline: b = parallel-in-time solver of the recurrence held to --tol (headline only if it certifies "
+                         "itself in this run, device estimate AND measurement against the exact path); a = the exact sequential recurrence")
+    ap.add_argument("--tol", type=float, default=0., help="tier b: accepted relative rms deviation of the equaliser output from the sequential recurrence (0 = library default 1e-3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=None, help="symbol periods the all-thread CPU baseline processes (default: the whole capture)")
-    ap.add_argument("--cpu-sample-1t", type=int, default=1 << 19, help="symbol periods of the one-thread CPU run")
+    ap.add_argument("--cpu-sample-1t", type=int, default=None, help="symbol periods of the one-thread CPU run (default: the whole capture)")
     ap.add_argument("--exact-steps", type=int, default=2, help="timed passes of the exact path beside tier b (N = 1)")
     ap.add_argument("--host-synth", action="store_true", help="generate the capture with the host (numpy) generator instead of on the GPU")
     ap.add_argument("--bank-trainer", default="iterative", choices=["auto", "iterative"])
     ap.add_argument("--bank", type=int, default=128, help="channels of the informational channel-bank run at N=1 (0 = skip)")
     ap.add_argument("--cpu-bank-workers", type=int, default=-1, help="concurrent single-threaded CPU pipelines of the bank's CPU leg (-1: min(cores, 128), 0: skip)")
+    ap.add_argument("--no-extra-shapes", action="store_true", help="skip the ns / c2 / 24 dB / loose-tolerance blocks of the default line")
     ap.add_argument("--split-capture", action="store_true",
                     help="N > 1: ONE capture, the segments of the tier-b trainer spread over the ranks with an all-reduce of their end taps per pass "
                          "(qampy_amd.distributed; strong scaling, informational - the default is one independent capture per GPU)")
-    ap.add_argument("--dry-run", action="store_true", help="no GPU: kernels replaced by a sleep, gloo backend - exercises launcher + reductions")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: kernels replaced by a sleep, socket collectives - exercises launcher + reductions")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(sys.argv[1:], args.gpus))
 
     from qampy_amd import sharding
+    from qampy_amd.comm import Comm
     rank, local_rank, world = sharding.rank_info()
     if world != args.gpus:
         if rank == 0:
@@ -503,36 +646,25 @@ def main():
             sys.exit(2)
         return run_c5(args, cfg)
 
-    import torch                                     # plumbing only: barriers / reductions / device sync
-    dist = None
-    backend = "gloo" if args.dry_run else os.environ.get("QAMPY_BENCH_BACKEND", "nccl")
+    # ---- process group: RCCL through ctypes (one rank per GPU); sockets where there is no GPU or RCCL cannot start
     if args.dry_run:
-        dev = 0
-        _lib = None
+        dev, _lib = None, None
     else:
         from qampy_amd import _lib
         ndev = max(_lib.device_count(), 1)
         dev = local_rank % ndev                      # a launcher may expose a single device per rank
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            torch.cuda.set_device(dev)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(backend=backend)
-    red_dev = "cuda" if (backend == "nccl" and not args.dry_run) else "cpu"
-    if not args.dry_run:
         _lib.init(dev)
-    ranks_seen = int(round(sharding.reduce_sum_counts([[1.0]], dist, device=red_dev)[0, 0]))
+    backend = "tcp" if args.dry_run else os.environ.get("QAMPY_BENCH_BACKEND", "auto")
+    cm = Comm(device=dev, backend=backend)
+    ranks_seen = int(round(sharding.reduce_sum_counts([[1.0]], cm)[0, 0]))
 
     def barrier_sync():
         if not args.dry_run:
             _lib.sync()
-            torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        cm.barrier()
 
     pit = dict(tol=args.tol) if args.tol > 0 else {}
+    tol_check = args.tol if args.tol > 0 else TOL_DEFAULT
     if args.dry_run:
         rx = DryReceiver(cfg, nsym, args.tier)
         for _ in range(args.warmup):
@@ -542,50 +674,56 @@ def main():
         for _ in range(args.steps):
             rx.run()
         barrier_sync()
-        elapsed = sharding.reduce_max_time(time.perf_counter() - t0, dist, device=red_dev)
-        counts_all = sharding.reduce_sum_counts([[d["errors"], d["compared"]] for d in rx.ser()], dist, device=red_dev)
+        elapsed = sharding.reduce_max_time(time.perf_counter() - t0, cm)
+        counts_all = sharding.reduce_sum_counts([[d["errors"], d["compared"]] for d in rx.ser()], cm)
         if rank == 0:
             print(json.dumps(dict(metric="equalised MSym/s (2-pol, 2 SPS)", value=round(sharding.aggregate_throughput(nsym, world, args.steps, elapsed), 4),
                                   unit="MSym/s", n_gpus=world, ranks_seen=ranks_seen, steps=args.steps, warmup=args.warmup,
                                   ms_per_step=round(elapsed / args.steps * 1e3, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
-                                  data="synthetic", dry_run=True, config=dict(workload=cfg["label"], key=args.workload, channels=world),
+                                  data="synthetic", dry_run=True, comm_backend=cm.backend, config=dict(workload=cfg["label"], key=args.workload, channels=world),
                                   ser=dict(errors_all=int(counts_all[:, 0].sum()), symbols_all=int(counts_all[:, 1].sum())))))
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        cm.close()
         return
 
     # ---- independent channel per rank (seed 1000 + channel), synthesised on the GPU (or the host), then made resident
     split = args.split_capture and world > 1 and args.tier == "b"
     sig = make_input(cfg, nsym, sharding.channel_seed(0 if split else rank), host=args.host_synth)
-    if split:                                        # every rank holds the same capture; torch's device = the library's
+    tier_a = tier_b = None
+    if split:                                        # every rank holds the same capture
         from qampy_amd.distributed import SplitCaptureReceiver
-        torch.cuda.set_device(dev)
         rx = SplitCaptureReceiver(sig.shape[0], sig.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"],
                                   adaptive_stepsize=cfg["adaptive"], TrSyms=(None,) * len(cfg["methods"]), Mtestangles=cfg["A"], Nbps=cfg["Nbps"],
-                                  dtype=np.complex64, alphabet=sig.coded_symbols, pit=pit)
+                                  dtype=np.complex64, alphabet=sig.coded_symbols, pit=pit, comm=cm)
+        rx.load(sig)
+        stage_names, _ = stage_list(rx)
+        elapsed, stage_ms, pass_ms, acq_ms = timed_steps(rx, args.steps, args.warmup, barrier_sync)
+        reports = rx.pit_reports()
+        errs = [(d["errors"], d["compared"]) for d in rx.ser(sig.symbols, maxlag=256, window=8192, trim=2000)]
+        tier_b = tier_b_block(cfg, rx, stage_names, pass_ms, acq_ms, reports, nsym * args.steps / elapsed / 1e6, elapsed / args.steps * 1e3, errs, nsym)
+        tier_b["certified"] = tier_b["converged"]
+    elif args.tier == "b":
+        tier_b, tier_a, ex = run_pair(cfg, sig, nsym, args.steps, args.warmup, barrier_sync, pit, args.exact_steps if world == 1 else 0, tol_check)
+        rx, stage_names, stage_ms, elapsed, errs, reports = ex["rx"], ex["names"], ex["stage_ms"], ex["elapsed"], ex["errs"], ex["reports"]
     else:
-        rx = make_receiver(cfg, sig, tier=args.tier, pit=pit)
-    rx.load(sig)
-    stage_names, _ = stage_list(rx)
-
-    # ---- timed region: exactly K steps, HIP events between the stages (same stream as the kernels)
-    elapsed, stage_ms, pass_ms, acq_ms = timed_steps(rx, args.steps, args.warmup, barrier_sync)
-    elapsed = sharding.reduce_max_time(elapsed, dist, device=red_dev)
-    reports = rx.pit_reports()
-    certified_local = 1.0 if (args.tier == "a" or all(r["converged"] for r in reports)) else 0.0
-    certified_all = int(round(sharding.reduce_sum_counts([[certified_local]], dist, device=red_dev)[0, 0])) == world
-
-    # ---- results of the last step: SER against the transmitted symbols
-    # (on-device harness: alignment search + decisions + count in HBM, qh_ser_*_dev; nothing but 7 integers per row moves)
-    ser_rows = rx.ser(sig.symbols, maxlag=256, window=8192, trim=2000)
-    errs = [(d["errors"], d["compared"]) for d in ser_rows]
-    counts_all = sharding.reduce_sum_counts([[e, n] for e, n in errs], dist, device=red_dev)
-
+        rx = make_receiver(cfg, sig, tier="a")
+        rx.load(sig)
+        stage_names, _ = stage_list(rx)
+        elapsed, stage_ms, _, _ = timed_steps(rx, args.steps, args.warmup, barrier_sync)
+        reports = None
+        errs = [(d["errors"], d["compared"]) for d in rx.ser(sig.symbols, maxlag=256, window=8192, trim=2000)] if cfg["A"] else []
+        tier_a = dict(method="exact sequential recurrence (reference order of evaluation)", value=round(nsym * args.steps / elapsed / 1e6, 4), unit="MSym/s",
+                      steps=args.steps, ms_per_step=round(elapsed / args.steps * 1e3, 3), stages_ms={n: round(t, 3) for n, t in zip(stage_names, stage_ms)},
+                      errors=[e for e, _ in errs])
+    elapsed = sharding.reduce_max_time(elapsed, cm)
+    certified_local = 1.0 if (args.tier == "a" or tier_b["certified"]) else 0.0
+    certified_all = int(round(sharding.reduce_sum_counts([[certified_local]], cm)[0, 0])) == world
+    counts_all = sharding.reduce_sum_counts([[e, n] for e, n in errs], cm) if errs else np.zeros((1, 2))
+    comm_backend, comm_note = cm.backend, cm.note
+    if not split:
+        cm.close()                                   # the other ranks are done; rank 0 goes on alone (CPU legs, extra shapes)
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        if split:
+            cm.close()
         return
 
     value_timed = sharding.aggregate_throughput(nsym, 1 if split else world, args.steps, elapsed)
@@ -601,90 +739,45 @@ def main():
                steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_timed, 3), higher_is_better=True, scaling="strong" if split else "weak", vs_baseline=None,
                dtype="f32", data="synthetic",
                config=dict(workload=cfg["label"], key=args.workload, nsym_per_channel=nsym, channels=1 if split else world, ntaps=cfg["ntaps"],
-                           methods=list(cfg["methods"]), niter=list(cfg["niter"]), test_angles=cfg["A"], bps_N=cfg["Nbps"],
-                           complex_dtype="complex64", train_mode=None,
+                           methods=list(cfg["methods"]), niter=list(cfg["niter"]), mu=list(cfg["mu"]), test_angles=cfg["A"], bps_N=cfg["Nbps"],
+                           complex_dtype="complex64", train_mode=None, comm_backend=comm_backend,
                            parallelism=("ONE capture: tier-b segments over %d ranks, all-reduce of the segments' end taps per pass (%d exchanges, %.1f MiB per step)"
                                         % (world, rx.exchanges // max(args.steps + args.warmup, 1), rx.exchanged_bytes / max(args.steps + args.warmup, 1) / 2 ** 20))
-                           if split else "1 independent channel per GPU"),
+                           if split else "1 independent channel per GPU, no collective on the data path"),
                stages_ms={n: round(t, 3) for n, t in zip(stage_names, stage_ms)},
                ser=dict(per_mode_rank0=[e / max(n, 1) for e, n in errs], errors_rank0=[e for e, _ in errs], errors_all=int(counts_all[:, 0].sum()),
                         symbols_all=int(counts_all[:, 1].sum())),
                device=_lib.device_name())
-
-    # ---- tier blocks
-    tier_b = None
-    if args.tier == "b":
-        kern = []
-        for s in range(rx.nstage):
-            flat = [p for step in pass_ms[s] for p in step]
-            kern.append(dict(stage=stage_names[1 + s], kernel="relaxation pass (all segments, one launch)", launches_per_step=len(flat) / max(len(pass_ms[s]), 1),
-                             mean_ms=float(np.mean(flat)) if flat else 0., acquisition_ms=float(np.mean(acq_ms[s])) if acq_ms[s] else 0.))
-        tier_b = dict(method="parallel in time: %s; segments trained concurrently by the exact kernels, waveform relaxation + linearised "
-                             "coarse correction until every boundary defect < tol" % " -> ".join(cfg["methods"]),
-                      value=round(value_timed, 4), unit="MSym/s", ms_per_step=round(ms_timed, 3),
-                      stages=[dict(stage=stage_names[1 + s], S=r["segments"], seg_len=r["seg_len"], P=r["passes"], converged=r["converged"], tol=r["tol"],
-                                   defect=[float("%.3g" % d) for d in r["defect"]], result_change=[float("%.3g" % d) for d in r.get("result_change", [])],
-                                   prefix=r["acquisition"]["steps"],
-                                   acquisition=dict(steps=r["acquisition"]["steps"], mu=r["acquisition"]["mu"], diverged=r["acquisition"]["diverged"]),
-                                   coarse_correction=r["correction"], gain=round(r["gain"], 4),
-                                   pass_ms=round(kern[s]["mean_ms"], 3), acquisition_ms=round(kern[s]["acquisition_ms"], 3))
-                              for s, r in enumerate(reports)],
-                      errors=[e for e, _ in errs], certified=bool(certified_all),
-                      roofline=dict(bound="hbm", achieved=round(FUSED_BYTES_PER_SYM * nsym / (ms_timed * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                                    frac=round(FUSED_BYTES_PER_SYM * nsym / (ms_timed * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                                    note="whole step against the fully fused lower bound of 88 B per symbol period"))
+    if comm_note:
+        out["config"]["comm_note"] = comm_note
+    if split:
+        cm.close()
+    if tier_b is not None:
+        if world > 1:
+            tier_b["certified"] = bool(certified_all)
         out["tier_b"] = tier_b
-
-    tier_a = None
-    res_a = None
-    if world == 1 and (args.tier == "a" or args.exact_steps > 0):
-        if args.tier == "a":
-            rxa, el_a, ms_a = rx, elapsed, stage_ms
-            steps_a = args.steps
-        else:
-            rxa = make_receiver(cfg, sig, tier="a")
-            rxa.load(sig)
-            steps_a = args.exact_steps
-            el_a, ms_a, _, _ = timed_steps(rxa, steps_a, 1, barrier_sync)
-        ser_a = rxa.ser(sig.symbols, maxlag=256, window=8192, trim=2000)
-        errs_a = [d["errors"] for d in ser_a]
-        names_a, _ = stage_list(rxa)
-        tier_a = dict(method="exact sequential recurrence (reference order of evaluation)", value=round(nsym * steps_a / el_a / 1e6, 4), unit="MSym/s",
-                      steps=steps_a, ms_per_step=round(el_a / steps_a * 1e3, 3), stages_ms={n: round(t, 3) for n, t in zip(names_a, ms_a)},
-                      errors=errs_a,
-                      train_cycles_per_step={names_a[1 + s2]: round(ms_a[1 + s2] * 1e-3 * 2.4e9 / (rxa.TrSyms[s2] * rxa.Niter[s2]), 1) for s2 in range(rxa.nstage)})
+    if tier_a is not None:
         out["tier_a"] = tier_a
-        if args.tier == "b":
-            wa, wb = rxa.wxy.to_host(), rx.wxy.to_host()
-            ea = (rxa.out if cfg["A"] else rxa.eq).to_host()
-            eb = (rx.out if cfg["A"] else rx.eq).to_host()
-            dev_t, dev_o, dev_omax = [], [], []
-            for m in range(wa.shape[0]):                       # modulo a common quarter turn per output mode (symmetry of the error functions)
-                g = 1j ** int(np.rint(np.angle(np.vdot(wb[m].ravel(), wa[m].ravel())) / (np.pi / 2)))
-                dev_t.append(float(np.max(np.abs(wa[m] - g * wb[m]))))
-                dd = np.abs(ea[m] - g * eb[m])
-                dev_o.append(float(np.sqrt(np.mean(dd ** 2))))
-                dev_omax.append(float(dd.max()))
-            ser_ok = all(abs(a - b) <= SER_TOL_ERRORS for a, b in zip(errs_a, [e for e, _ in errs]))
-            tier_b.update(errors_exact=errs_a, ser_equivalent=bool(ser_ok), max_abs_tap_dev_vs_exact=dev_t, out_rms_dev_vs_exact=dev_o,
-                          out_max_dev_vs_exact=dev_omax, speedup_vs_exact=round(tier_b["value"] / tier_a["value"], 2))
-            tier_b["certified"] = bool(certified_all and ser_ok)
-            res_a = dict(value=tier_a["value"], ms=el_a / steps_a * 1e3, stage_ms=ms_a, names=names_a)
 
     # ---- headline: tier b only with its certificate; else the exact path
     use_b = args.tier == "b" and tier_b is not None and tier_b["certified"]
-    if args.tier == "b" and not use_b and res_a is not None:
-        out["value"] = round(res_a["value"], 4)
-        out["ms_per_step"] = round(res_a["ms"], 3)
-        out["stages_ms"] = {n: round(t, 3) for n, t in zip(res_a["names"], res_a["stage_ms"])}
-        out["steps"] = args.exact_steps
+    uncertified_b = args.tier == "b" and not use_b and tier_a is None       # N > 1 (no exact run beside it) and a stage that did not converge
+    head_ms = stage_ms
+    if args.tier == "b" and not use_b and tier_a is not None:
+        out["value"] = tier_a["value"]
+        out["ms_per_step"] = tier_a["ms_per_step"]
+        out["stages_ms"] = tier_a["stages_ms"]
+        out["steps"] = tier_a["steps"]
         out["note"] = "tier b did not certify itself in this run: headline = exact path"
-    uncertified_b = args.tier == "b" and not use_b and res_a is None       # N > 1 (no exact run beside it) and a stage that did not converge
+        head_ms = [tier_a["stages_ms"][n] for n in stage_names]
     if uncertified_b:
         out["note"] = "tier b did NOT certify itself on every rank and no exact path ran beside it (N > 1): value is tier b's, uncertified"
-    out["config"]["train_mode"] = (("parallel-in-time (tier b), certified in-run: converged" + (" + SER within +-%d errors of the exact path" % SER_TOL_ERRORS if world == 1 else " on every rank"))
-                                   if use_b else ("parallel-in-time (tier b), NOT certified" if uncertified_b else "exact sequential recurrence (tier a)"))
-    head_ms = stage_ms if (use_b or args.tier == "a" or uncertified_b) else res_a["stage_ms"]
+    out["headline_tier"] = "b" if (use_b or uncertified_b) else "a"
+    out["config"]["train_mode"] = (
+        ("parallel-in-time solver of the reference's recurrence (tier b, tol %g): certified in-run - device estimate of the output deviation < tol on every stage" % tol_check
+         + (" AND measured against the exact path on the same capture: recovered output within tol (relative rms), taps within 2 tol, error counts within +-%d" % SER_TOL_ERRORS
+            if world == 1 else " on every rank")) if use_b else
+        ("parallel-in-time (tier b), NOT certified" if uncertified_b else "exact sequential recurrence (tier a)"))
 
     # ---- roofline of the dominant kernel (largest total kernel time per step)
     if use_b or uncertified_b:
@@ -694,83 +787,108 @@ def main():
         if cfg["A"]:
             cands.append((stage_ms[-1], "bps_recover", stage_bytes[-1], stage_ms[-1]))
         tot, kname, kbytes, kms = max(cands)
-        roofline = dict(bound="hbm", kernel=kname, achieved=round(kbytes / (kms * 1e-3) / 1e9, 3), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), traffic=None, algorithmic_bytes=int(kbytes), launch_ms=round(kms, 3),
-                        note="one launch trains all segments of the sweep; algorithmic bytes = one sweep (read E, write err); the look-ahead form "
-                             "additionally streams the Gram table (1 KiB per step) - see profiles/ for the PMC traffic",
-                        pipeline=tier_b["roofline"])
+        hbm = dict(achieved=round(kbytes / (kms * 1e-3) / 1e9, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(kbytes / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                   algorithmic_bytes=int(kbytes))
+        roofline = dict(bound="hbm", kernel=kname, achieved=hbm["achieved"], peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm["frac"], traffic=None,
+                        algorithmic_bytes=int(kbytes), launch_ms=round(kms, 3), launches_per_step=None, pipeline=tier_b["pipeline_hbm"])
+        instr = pmc_json("pmc_instr", args.workload)
         if kname == "bps_recover" and rx.ct == np.complex64 and cfg["A"] <= 64:
-            # streaming phase search: VALU instructions per symbol and wave counted in the ISA of bps_stream_kernel
-            # for a mirror-symmetric square alphabet with NL = sqrt(M)/2 positive levels per axis: 20 + 2 NL (28 at 64-QAM; SQ_INSTS_VALU
-            # measures 27.95 per row, profiles/r02_pmc_instr_c3.txt)
+            # streaming phase search: lane <-> test angle, VALU instructions per distance row and wave
             NL = max(1, int(round(np.sqrt(cfg["M"]))) // 2)
-            per_sym = 20.0 + 2 * NL
-            C, W = 1024, 2 * cfg["Nbps"]
-            rows = -(-nsym // C) * (-(-(C + W - 1) // 16) * 16) * rx.modes.size          # distance rows incl. the 2N-1 halo of every chunk
+            per_sym, src = 20.0 + 2 * NL, "ISA count of bps_stream_kernel (20 + 2 levels per axis)"
+            hit = [v for k, v in (instr or {}).get("kernels", {}).items() if k.startswith("qh::bps_stream_kernel")]
+            if hit and hit[0].get("valu_per_row"):
+                per_sym, src = float(hit[0]["valu_per_row"]), "SQ_INSTS_VALU / distance rows (profiles/pmc_instr_%s.json)" % args.workload
+            C_, W = 1024, 2 * cfg["Nbps"]
+            rows = -(-nsym // C_) * (-(-(C_ + W - 1) // 16) * 16) * rx.modes.size          # distance rows incl. the 2N-1 halo of every chunk
             winstr = rows * per_sym
-            roofline["valu"] = dict(bound="valu-issue", symbol_angle_pairs=int(nsym * rx.modes.size * cfg["A"]), valu_instr_per_symbol=round(per_sym, 1),
-                                    achieved_ginstr_s=round(winstr / (kms * 1e-3) / 1e9, 1), peak_ginstr_s=VALU_PEAK_GINSTR,
-                                    issue_frac=round(winstr / (kms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4),
-                                    note="lane <-> test angle, one wave per 1024 symbols; the stage time also holds alphabet analysis, unwrap scan and "
-                                         "de-rotation (3 small launches, ~0.2 ms at C3), so the kernel's own fraction is higher")
-        # what actually bounds the pass kernel: instruction issue of the fp32 vector units, not HBM
+            roofline.update(bound="valu-issue", achieved=round(winstr / (kms * 1e-3) / 1e9, 1), peak=VALU_PEAK_GINSTR, unit="G wave-instr/s",
+                            frac=round(winstr / (kms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4), hbm=hbm, valu_instr_per_symbol=round(per_sym, 2), valu_instr_source=src,
+                            note="lane <-> test angle, one wave per 1024 symbols; the stage time also holds alphabet analysis, unwrap scan and de-rotation")
         if "relaxation pass" in kname:
+            # what bounds the pass kernel: instruction issue of the fp32 vector units, not HBM
             st = tier_b["stages"][int(kname[5]) - 1]
             chains = st["S"] * rx.modes.size
             ntot = rx.nmodes * rx.Ntaps
             flops = chains * st["seg_len"] * (2 * ntot) * 8.0           # filter + update: 2 x ntot complex multiply-adds per chain and step
             tpl8 = 11 if rx.nmodes * -(-rx.Ntaps // 11) <= 8 and 11 * -(-rx.Ntaps // 11) - rx.Ntaps <= 3 else (6 if rx.nmodes * -(-rx.Ntaps // 6) <= 8 and 6 * -(-rx.Ntaps // 6) - rx.Ntaps <= 3 else 0)
             lpc = 8 if chains >= 3000 and tpl8 else 16                  # launch_seg's rule (train_seg.h)
-            ipw = SEG_INSTR_PER_WAVE_STEP[lpc]
             waves = -(-chains // (64 // lpc))
+            ipw, src = float(SEG_INSTR_PER_WAVE_STEP[lpc]), "ISA count of the main loop incl. s_nop / s_waitcnt (DESIGN.md 3.2.2)"
+            mid = _lib.METHOD_ID[cfg["methods"][int(kname[5]) - 1]]
+            hit = [v for k, v in (instr or {}).get("kernels", {}).items() if k.startswith("qh::train_seg_kernel<float, %d," % mid)]
+            if hit and hit[0].get("valu_per_wave_step"):
+                ipw = float(hit[0]["valu_per_wave_step"])
+                src = "SQ_INSTS_VALU / (SQ_WAVES x steps per chain) of the same kernel sources (profiles/pmc_instr_%s.json)" % args.workload
             winstr = waves * st["seg_len"] * ipw
-            roofline["valu"] = dict(bound="valu-issue", flops_per_launch=int(flops), achieved_tflops=round(flops / (kms * 1e-3) / 1e12, 2), peak_tflops=VALU_PEAK_TFLOPS,
-                                    frac=round(flops / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4), chains=int(chains), lanes_per_chain=lpc, waves=int(waves),
-                                    steps_per_chain=int(st["seg_len"]), instr_per_wave_step=ipw, achieved_ginstr_s=round(winstr / (kms * 1e-3) / 1e9, 1),
-                                    peak_ginstr_s=VALU_PEAK_GINSTR, issue_frac=round(winstr / (kms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4),
-                                    note="8 (16) lanes per chain, 8 (4) chains per wave; 94 (68) instructions per wave and step, 44 (24) of them the packed FMAs of "
-                                         "the recurrence - counted in the ISA of train_seg_kernel<float, cma, 0, 11, 8> (<.., 6, 16>) at 41 taps x 2 modes; peak = 1024 SIMDs "
-                                         "x 2.4 GHz / 4 cycles per wave64 instruction; a lone wave on a SIMD issues one instruction per ~8 cycles (profiles/r02_ubench_*.txt)")
+            roofline.update(bound="valu-issue", achieved=round(winstr / (kms * 1e-3) / 1e9, 1), peak=VALU_PEAK_GINSTR, unit="G wave-instr/s",
+                            frac=round(winstr / (kms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4), hbm=hbm, launches_per_step=st["P"],
+                            valu=dict(flops_per_launch=int(flops), achieved_tflops=round(flops / (kms * 1e-3) / 1e12, 2), peak_tflops=VALU_PEAK_TFLOPS,
+                                      frac=round(flops / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)),
+                            chains=int(chains), lanes_per_chain=lpc, waves=int(waves), waves_per_simd=round(waves / 1024.0, 2), steps_per_chain=int(st["seg_len"]),
+                            valu_instr_per_wave_step=round(ipw, 1), valu_instr_source=src,
+                            note="one launch trains all segments of the sweep (8 lanes per chain, 8 chains per wave64): bound by VALU issue - achieved / peak are "
+                                 "vector instructions per second against 1024 SIMDs x 2.4 GHz / 4 cycles; `hbm`: algorithmic bytes of one sweep (read E, write "
+                                 "err) against 8 TB/s, `valu`: recurrence flops against the packed-fp32 peak")
     else:
         dom = int(np.argmax(head_ms))
         achieved = stage_bytes[dom] / (head_ms[dom] * 1e-3) / 1e9
-        roofline = dict(bound="valu-issue" if 1 <= dom <= rx.nstage else "hbm", kernel=stage_names[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS,
+        roofline = dict(bound="latency (dependent instruction issue)" if 1 <= dom <= rx.nstage else "hbm", kernel=stage_names[dom], achieved=round(achieved, 3), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None, algorithmic_bytes=int(stage_bytes[dom]),
                         note="exact sequential LMS recurrence: dependent-issue bound, one workgroup per output mode (DESIGN.md 3.1); HBM figure for reference")
     # measured HBM traffic of the dominant kernel: from the PMC passes of the same workload (scripts/gpu_pmc.sh ->
     # profiles/pmc_traffic_<workload>.json), quoted only while the kernel sources are the ones that were profiled
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % args.workload)))
-        if pmc.get("kernel_sources_sha") == kernel_sources_sha():
-            kern = roofline["kernel"]
-            pat = None
-            if "relaxation pass" in kern:
-                stage = int(kern[5]) - 1
-                pat = "qh::train_seg_kernel<float, %d," % _lib.METHOD_ID[cfg["methods"][stage]]
-            elif kern.startswith("train"):
-                mid = _lib.METHOD_ID[cfg["methods"][int(kern[5]) - 1]]
-                pat = ("qh::train_la_kernel<float, %d," % mid, "qh::train_bi_kernel<float, %d," % mid)
-            elif kern == "bps_recover":
-                pat = ("qh::bps_stream_kernel", "qh::bps_kernel<float>")
-            elif kern == "gram":
-                pat = "qh::gram_slide_kernel<float"
-            hit = [v for k, v in pmc["kernels"].items() if pat and k.startswith(pat)]
-            if hit:
-                roofline["traffic"] = hit[0]["hbm_bytes"]
-        else:
-            roofline["traffic_note"] = "profiles/pmc_traffic_%s.json belongs to other kernel sources: not quoted" % args.workload
-    except (OSError, KeyError, ValueError, IndexError):
-        pass
+    pmc = pmc_json("pmc_traffic", args.workload)
+    if pmc:
+        kern = roofline["kernel"]
+        pat = None
+        if "relaxation pass" in kern:
+            pat = "qh::train_seg_kernel<float, %d," % _lib.METHOD_ID[cfg["methods"][int(kern[5]) - 1]]
+        elif kern.startswith("train"):
+            mid = _lib.METHOD_ID[cfg["methods"][int(kern[5]) - 1]]
+            pat = ("qh::train_la_kernel<float, %d," % mid, "qh::train_bi_kernel<float, %d," % mid)
+        elif kern == "bps_recover":
+            pat = ("qh::bps_stream_kernel", "qh::bps_kernel<float>")
+        elif kern == "gram":
+            pat = "qh::gram_slide_kernel<float"
+        hit = [v for k, v in pmc["kernels"].items() if pat and k.startswith(pat)]
+        if hit:
+            roofline["traffic"] = hit[0]["hbm_bytes"]
+    else:
+        roofline["traffic_note"] = "no PMC traffic profile of these kernel sources under profiles/: not quoted"
     out["roofline"] = roofline
+
+    # ---- the other shapes and tolerances of the default line (N = 1): loose tolerance, a capture with symbol errors, ns, c2
+    if world == 1 and args.tier == "b" and not args.no_extra_shapes and not split:
+        try:
+            ksteps = max(2, min(args.steps, 10))
+            tb2, _, ex2 = run_pair(cfg, sig, nsym, ksteps, 1, barrier_sync, dict(pit, tol=1e-2), 0, 1e-2)
+            rx2 = ex2["rx"]
+            rxa = make_receiver(cfg, sig, tier="a"); rxa.load(sig); rxa.run(); _lib.sync()
+            dv = deviation_vs_exact(rx2, rxa, cfg)
+            out["tier_b_loose"] = dict(tol=1e-2, value=tb2["value"], ms_per_step=tb2["ms_per_step"], converged=tb2["converged"], errors=tb2["errors"],
+                                       passes=[st["P"] for st in tb2["stages"]], est_deviation_rms=[st["est_deviation_rms"][-1:] for st in tb2["stages"]],
+                                       out_rms_dev_vs_exact=dv["out_rms_dev_vs_exact"], tap_rel_dev_vs_exact=dv["tap_rel_dev_vs_exact"],
+                                       err_trace_rms_dev_vs_exact=dv["err_trace_rms_dev_vs_exact"],
+                                       note="informational: the same solver held to a 10 x looser deviation (SER-equivalent tier of SURVEY 7.3-1(b)); never the headline")
+            del rx2, rxa, ex2
+            if args.workload == "c3":
+                out["cert_24dB"] = cert_snr_block(cfg, 24.0, min(nsym, 1 << 21), 1001, barrier_sync, pit)
+                for key in ("ns", "c2"):
+                    out[key] = shape_block(key, barrier_sync, pit, 3)
+            _lib.call("qh_release_scratch")
+        except Exception as e:                    # informational blocks never take the headline down
+            out["extra_shapes_error"] = "%s: %s" % (type(e).__name__, e)
 
     if world == 1 and not args.no_cpu_baseline:
         sample = min(nsym, args.cpu_sample or nsym)
-        cb = cpu_baseline(cfg, sig, sample, min(sample, args.cpu_sample_1t))
+        cb = cpu_baseline(cfg, sig, sample, min(sample, args.cpu_sample_1t or sample))
         r_cpu = cb["result"]
         sig_s = sig.recreate_from_np_array(np.asarray(sig)[:, :2 * sample])
         sig_s._symbols = sig.symbols[:, :sample]
         e_cpu = symbol_errors(r_cpu["out"], sig_s)
         out["cpu_baseline"] = dict(value=round(cb["all"]["value"], 4), unit="MSym/s", cores=cb["all"]["cores"], kind="port",
+                                   algorithm="exact sequential recurrence (the reference's loops and OpenMP placement)",
                                    sample="%s symbol periods of the same capture, all stages, %d OpenMP threads (placement as in the reference: "
                                           "modes-parallel train, collapse(2) apply, L-parallel BPS distances)" % ("all %d" % sample if sample == nsym else "first %d" % sample, cb["all"]["cores"]),
                                    runs_s=cb["all"]["runs_s"], stages_s=cb["all"]["stages_s"], cpu_model=cpu_model(),
@@ -780,7 +898,6 @@ def main():
         if sample == nsym:
             e_gpu = errs
             w_gpu = rx.wxy.to_host()
-            e_gpu_a = [(e, None) for e in tier_a["errors"]] if tier_a else None
         else:
             rx2 = make_receiver(cfg, sig_s, tier=args.tier, pit=pit)
             rx2.load(np.asarray(sig)[:, :2 * sample])
@@ -788,16 +905,18 @@ def main():
             r2 = rx2.fetch()
             e_gpu = symbol_errors(r2["out"] if cfg["A"] else r2["eq"], sig_s)
             w_gpu = r2["wxy"]
-            e_gpu_a = None
         tapd = []
         for m in range(w_gpu.shape[0]):
             g = 1j ** int(np.rint(np.angle(np.vdot(w_gpu[m].ravel(), r_cpu["wxy"][m].ravel())) / (np.pi / 2)))
             tapd.append(float(np.max(np.abs(r_cpu["wxy"][m] - g * w_gpu[m]))))
         out["parity_vs_cpu"] = dict(sample=sample, errors_gpu=[e for e, _ in e_gpu], errors_cpu=[e for e, _ in e_cpu],
-                                    errors_gpu_exact=[e for e, _ in e_gpu_a] if e_gpu_a else None,
+                                    errors_gpu_exact=tier_a["errors"] if (tier_a and sample == nsym) else None,
                                     ser_gpu=[e / max(n, 1) for e, n in e_gpu] if sample != nsym else out["ser"]["per_mode_rank0"],
                                     ser_cpu=[e / n for e, n in e_cpu], max_abs_tap_diff=tapd)
+        # The ratio is keyed to the tier that produced `value`.  The CPU leg runs the exact recurrence; tier b solves the SAME recurrence
+        # from the same start taps in another order of evaluation, to the stated tolerance (measured above) - tier a's own ratio beside it.
         out["speedup_vs_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
+        out["speedup_vs_cpu_tier"] = out["headline_tier"]
         if tier_a:
             tier_a["speedup_vs_cpu"] = round(tier_a["value"] / out["cpu_baseline"]["value"], 2)
         if tier_b:
@@ -819,9 +938,6 @@ def main():
             out["channel_bank"] = dict(channels=args.bank, error="%s: %s" % (type(e).__name__, e))
 
     print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 def kernel_sources_sha():

@@ -34,6 +34,14 @@
 extern "C" {
 #endif
 
+/* ---- ABI version: bumped whenever an entry point changes its argument list or a public struct its layout, so that a caller
+ * built against another header fails loudly (compare with qh_abi_version() at load time) instead of passing shifted
+ * arguments.  History: 1 = round 1; 2 = round 2 (qh_bps_recover_*_dev gained `angles`, qh_train_equaliser_*_pit_dev takes
+ * (gram, opts, report), the *_seg_dev entry points were removed - unversioned at the time); 3 = round 3 (qh_pit_opts:
+ * start, dev_safety; qh_pit_report: deviation[]). */
+#define QH_ABI_VERSION 3
+int qh_abi_version(void);
+
 /* ---- status codes (python shim: 1,2 -> ValueError, 3,4 -> RuntimeError) */
 #define QH_OK 0
 #define QH_ERR_METHOD 1   /* unknown method id   (reference: ValueError, pythran_equalisation.py:151-152) */
@@ -70,6 +78,7 @@ int qh_release_scratch(void);
  * one stream; filter, phase search and SER harness on the other - what ChannelBank.run_pipelined does). */
 int qh_use_stream(int idx);
 int qh_stream_wait_event(void *ev);
+int qh_stream_handle(void **stream);           /* the current library stream as a hipStream_t, for collectives enqueued next to the kernels (RCCL: qampy_amd/comm.py) */
 /* HIP events recorded on the current library stream (bench.py measures kernel time with these) */
 int qh_event_create(void **ev);
 int qh_event_destroy(void *ev);
@@ -222,8 +231,21 @@ int qh_set_trainer(int form);
  * decided on the device (skip flags): the call only enqueues, nothing synchronises.
  *   acquire != 0 (cold start, e.g. centre-spike taps): a sequential "acquisition" first trains a prefix of the capture with
  *     a gear-shifted step size mu_acq = clamp(gear * mu, mu, acq_bound / (nmodes ntaps <|x|^2>)) in chunks until the mean
- *     squared error stops improving (or acq_max steps); the sweep proper then runs from the acquired taps.  The result
- *     is therefore the recurrence WARM-STARTED from the acquired taps, not the trajectory from the initial taps.
+ *     squared error stops improving (or acq_max steps).  The acquired taps SEED the start taps of segments 1 .. S-1; segment 0
+ *     starts from the caller's taps (start = 0, the default), so the fixed point of the passes is the reference's recurrence from
+ *     the caller's taps - the cold-start trajectory itself.  start = 1 is the round-2 behaviour: segment 0 starts from the
+ *     acquired taps too, i.e. the result is the recurrence WARM-STARTED from them (one or two passes fewer, taps of the weakly
+ *     excited directions ~1e-2 away from the cold-start result).
+ *   Stop rule (`tol`): with the coarse correction on, the passes stop when the ESTIMATED DEVIATION of the pass's trajectory from
+ *     the sequential recurrence - relative rms deviation of the equaliser OUTPUT, worst segment - is below tol.  The estimate is
+ *     the first-order solution of the error equation E[s+1] = F'_s E[s] + d[s+1] (d the boundary defects of the pass, F'_s the
+ *     segment Jacobian replaced by its linearised model J), measured in output power: sum_k lambda_k |E~_k[s]|^2 / <|y|^2> in the
+ *     eigenbasis of the input covariance - the same scan that forms the next correction; the rule takes its rms over all segments
+ *     and modes (times dev_safety, default 1: measured against the exact path the estimate is within a factor 1.5 of the rms
+ *     deviation of the error trace) and additionally holds the worst segment below 3 tol and the estimated relative deviation of
+ *     the taps themselves (unweighted norm of the same vectors: the weakly excited directions count fully) below 2 tol.
+ *     Without the correction (more than 96 taps per output mode, or switched off) the round-2 rule applies: largest boundary
+ *     defect x a segment-length factor below tol.
  *   phase_seed: for the phase-sensitive functions (mcma, mrde, sbd, mddma, dd) the pass-0 start taps of segment s are the
  *     start taps rotated by an unwrapped 4th-power phase estimate of their output at the head of the segment, so that
  *     every segment starts phase-locked however far the carrier has drifted (-1: by method, 0 off, 1 on).
@@ -236,14 +258,15 @@ int qh_set_trainer(int form);
  *     iteration - at the fixed point all defects vanish and the result is the sequential recurrence either way.
  * Fixed step only (adaptive = 0), no data-aided methods.  gram: table from qh_gram_build_*_dev for this (E, os, ntaps,
  * TrSyms), or NULL.  report_dev: device memory for one qh_pit_report (read it after qh_sync), or NULL. */
-#define QH_PIT_MAXPASS 16
+#define QH_PIT_MAXPASS 24
 #define QH_PIT_MAXCHUNK 32
 typedef struct qh_pit_opts {
     int32_t segments;       /* 0 = automatic: segments of about 0.2 / mu (warm) or 0.4 / mu (cold start) steps, qh_pit_auto_segments */
-    int32_t max_passes;     /* 0 = 8 (at most QH_PIT_MAXPASS) */
+    int32_t max_passes;     /* 0 = 12 (at most QH_PIT_MAXPASS) */
     int32_t acquire;        /* 0 warm start, 1 cold start: gear-shifted sequential acquisition first */
     int32_t phase_seed;     /* -1 by method, 0 off, 1 on */
-    double tol;             /* 0 = 0.01: largest boundary defect accepted (output deviation from the sequential result ~ 0.6 tol) */
+    double tol;             /* 0 = 1e-3: accepted estimated rms deviation of the equaliser output from the sequential recurrence, relative to the
+                             * output rms (see "Stop rule"); without the coarse correction: largest boundary defect accepted */
     double gear;            /* 0 = 8 */
     double acq_bound;       /* 0 = 0.08 */
     double acq_plateau;     /* 0 = 0.8: a chunk whose mean |err|^2 exceeds this fraction of the previous one's ends the acquisition */
@@ -254,14 +277,20 @@ typedef struct qh_pit_opts {
     void *basis;            /* NULL, or the eigenbasis of this capture's input covariance from qh_pit_basis_*_dev (device memory) */
     double corr_beta;       /* extra damping of the well-excited directions in the coarse map, exp(-a (1 + beta a)); < 0: by method */
     /* One capture over several processes / GPUs (optional; every process holds the whole capture and makes the same call):
-     * this process trains segments [seg_first, seg_first + seg_count) only (seg_count = 0: all of them); after the training
-     * launch of every pass the library synchronises its stream, zeroes the end taps of the segments it does not own and calls
+     * this process trains segments [seg_first, seg_first + seg_count) only (exchange == NULL: all of them; with an exchange
+     * callback seg_count = 0 means "none": the process still takes part in every exchange); after the training
+     * launch of every pass the library zeroes the end taps of the segments it does not own, synchronises its stream (unless
+     * exchange_on_stream) and calls
      * exchange(exchange_user, taps, bytes) - the caller sums the buffers of all processes in place (an all-reduce: RCCL over
      * xGMI) and returns 0 - after which every process evaluates the (cheap) boundary defects and the coarse correction on
      * identical data and takes identical decisions.  Error traces are written for the owned segments only. */
     int32_t seg_first, seg_count;
     int (*exchange)(void *user, void *taps_dev, size_t bytes);
     void *exchange_user;
+    int32_t start;          /* 0: segment 0 starts from the caller's taps (fixed point = the reference's recurrence); 1: from the acquired taps */
+    int32_t exchange_on_stream; /* != 0: `exchange` only ENQUEUES the all-reduce on the library stream (RCCL with qh_stream_handle): the library
+                             * does not synchronise around it and enqueues the next pass ahead as in the single-process case */
+    double dev_safety;      /* 0 = 1: factor on the deviation estimate in the stop rule */
 } qh_pit_opts;
 typedef struct qh_pit_report {
     int32_t segments, passes, converged, acq_chunks;
@@ -274,6 +303,10 @@ typedef struct qh_pit_report {
     double result_change[QH_PIT_MAXPASS]; /* how far the sweep's RESULT (end taps of the last segment) moved from pass p-1 to pass p, as the relative
                                             rms difference of the two outputs on the last 128 steps (modulo the error function's symmetry);
                                             pass 0: against the start taps; -1 = not run */
+    double deviation[QH_PIT_MAXPASS];   /* estimated relative rms output deviation of pass p's trajectory from the sequential recurrence (worst
+                                            segment, without the safety factor); -1 = not available (no coarse correction) */
+    double deviation_rms[QH_PIT_MAXPASS]; /* the same estimate as an rms over all segments and modes */
+    double deviation_taps[QH_PIT_MAXPASS]; /* estimated deviation of the TAPS from the sequential recurrence's: |D[s]| / |w|, rms over segments and modes */
 } qh_pit_report;
 int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold, int *segments);   /* cold: the sweep starts from unconverged taps (acquire) */
 /* Eigenbasis of the input covariance <conj(x) x^T> of the training windows of a capture, for the coarse correction: depends

@@ -91,11 +91,13 @@ SIGNATURES = {
     "qh_use_stream": [_i],
     "qh_release_scratch": [],
     "qh_stream_wait_event": [_vp],
+    "qh_stream_handle": [C.POINTER(_vp)],
     "qh_ser_c64_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
     "qh_ser_c128_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
 }
 
-PIT_MAXPASS, PIT_MAXCHUNK = 16, 32
+PIT_MAXPASS, PIT_MAXCHUNK = 24, 32
+ABI_VERSION = 3              # QH_ABI_VERSION of include/qampy_hip.h
 
 
 class PitOpts(C.Structure):
@@ -103,7 +105,8 @@ class PitOpts(C.Structure):
     _fields_ = [("segments", C.c_int32), ("max_passes", C.c_int32), ("acquire", C.c_int32), ("phase_seed", C.c_int32),
                 ("tol", C.c_double), ("gear", C.c_double), ("acq_bound", C.c_double), ("acq_plateau", C.c_double),
                 ("acq_chunk", C.c_int64), ("acq_max", C.c_int64), ("correction", C.c_int32), ("pad", C.c_int32), ("basis", C.c_void_p), ("corr_beta", C.c_double),
-                ("seg_first", C.c_int32), ("seg_count", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p)]
+                ("seg_first", C.c_int32), ("seg_count", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p),
+                ("start", C.c_int32), ("exchange_on_stream", C.c_int32), ("dev_safety", C.c_double)]
 
 
 #: signature of ``qh_pit_opts.exchange``: (user, device pointer of the segments' end taps, bytes) -> 0
@@ -118,7 +121,8 @@ class PitReport(C.Structure):
                 ("defect", C.c_double * PIT_MAXPASS), ("acq_err", C.c_double * PIT_MAXCHUNK),
                 ("gain", C.c_double), ("out_power", C.c_double),
                 ("acq_done", C.c_int32), ("done", C.c_int32), ("diverged", C.c_int32), ("corr_on", C.c_int32),
-                ("result_change", C.c_double * PIT_MAXPASS)]
+                ("result_change", C.c_double * PIT_MAXPASS), ("deviation", C.c_double * PIT_MAXPASS),
+                ("deviation_rms", C.c_double * PIT_MAXPASS), ("deviation_taps", C.c_double * PIT_MAXPASS)]
 
     def as_dict(self):
         return dict(segments=int(self.segments), seg_len=int(self.seg_len), passes=int(self.passes), converged=bool(self.converged),
@@ -126,7 +130,10 @@ class PitReport(C.Structure):
                     acquisition=dict(steps=int(self.acq_steps), chunks=int(self.acq_chunks), mu=float(self.mu_acq),
                                      diverged=bool(self.diverged), mean_sq_err=[float(v) for v in self.acq_err if v >= 0]),
                     mu=float(self.mu), power=float(self.power), gain=float(self.gain), out_power=float(self.out_power),
-                    correction=bool(self.corr_on), result_change=[float(d) for d in self.result_change if d >= 0])
+                    correction=bool(self.corr_on), result_change=[float(d) for d in self.result_change if d >= 0],
+                    deviation=[float(d) for d, q in zip(self.deviation, self.defect) if q >= 0],
+                    deviation_rms=[float(d) for d, q in zip(self.deviation_rms, self.defect) if q >= 0],
+                    deviation_taps=[float(d) for d, q in zip(self.deviation_taps, self.defect) if q >= 0])
 
 
 _lib = None
@@ -146,6 +153,10 @@ def load():
             fn.restype = _i
         lib.qh_last_error.argtypes = []
         lib.qh_last_error.restype = C.c_char_p
+        # the structs and signatures above belong to ONE version of include/qampy_hip.h: refuse any other build of the library
+        ver = lib.qh_abi_version() if hasattr(lib, "qh_abi_version") else 0
+        if ver != ABI_VERSION:
+            raise RuntimeError("%s has C-ABI version %d, this package binds version %d: rebuild it (qampy_amd/csrc/build.sh)" % (LIB_PATH, ver, ABI_VERSION))
         _lib = lib
     return _lib
 

@@ -1,0 +1,320 @@
+"""
+Process group of the multi-GPU path without PyTorch: one process per GPU, RCCL over xGMI through ctypes.
+
+The hot path shards by independent channel: no collective touches the data.  What ranks exchange is
+  * control values - barriers, the MAX of the elapsed time, the SUM of the symbol-error counters, the rank count -
+  * and, in the optional split-capture mode (qampy_amd/distributed.py), the end taps of the tier-b segments per pass.
+Both go through ``librccl.so`` (``ncclCommInitRank`` / ``ncclAllReduce`` / ``ncclBroadcast``), the collectives enqueued on the
+library's own HIP stream (``qh_stream_handle``), so a tap exchange sits between the kernels of a pass like any other launch.
+
+Rendezvous.  The launcher (``bench.py --gpus N`` itself, or ``torch.distributed.run`` as the driver uses it) provides
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT.  Rank 0 listens on an ephemeral TCP port of MASTER_ADDR and
+publishes it in a file keyed by (MASTER_PORT, parent pid) - MASTER_PORT itself belongs to the launcher's own store - the other
+ranks connect; this star of sockets carries the ``ncclUniqueId`` and is also a complete (slow, host-side) implementation of
+the collectives: the ``tcp`` backend, used where there is no GPU (CPU tests, ``--dry-run``), where several ranks share one
+GPU (RCCL refuses duplicate devices), and as the fallback when RCCL cannot initialise - the JSON line says which ran.
+"""
+import ctypes as C
+import os
+import pickle
+import socket
+import struct
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+NCCL_UNIQUE_ID_BYTES = 128
+_NCCL_DTYPE = {np.dtype(np.int8): 0, np.dtype(np.uint8): 1, np.dtype(np.int32): 2, np.dtype(np.uint32): 3, np.dtype(np.int64): 4,
+               np.dtype(np.uint64): 5, np.dtype(np.float32): 7, np.dtype(np.float64): 8}
+_NCCL_OP = {"sum": 0, "prod": 1, "max": 2, "min": 3}
+_NP_OP = {"sum": np.add, "prod": np.multiply, "max": np.maximum, "min": np.minimum}
+
+
+class _UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * NCCL_UNIQUE_ID_BYTES)]
+
+
+def rank_info(env=None):
+    """(rank, local_rank, world_size) from the launcher's environment; (0, 0, 1) when launched plainly."""
+    env = os.environ if env is None else env
+    return int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")), int(env.get("WORLD_SIZE", "1"))
+
+
+def launch(script, argv, nproc, env=None):
+    """Start ``nproc`` ranks of ``script`` on this node (one per GPU) with the usual environment and relay their exit codes:
+    what ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` does, without the dependency."""
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.setdefault("OMP_NUM_THREADS", "1")
+    base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc))
+    procs = [subprocess.Popen([sys.executable, script] + list(argv), env=dict(base, RANK=str(r), LOCAL_RANK=str(r))) for r in range(nproc)]
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------ sockets
+def _send(sock, obj):
+    b = pickle.dumps(obj, protocol=4)
+    sock.sendall(struct.pack("<Q", len(b)) + b)
+
+
+def _recv(sock):
+    def rd(n):
+        buf = bytearray()
+        while len(buf) < n:
+            chunk = sock.recv(n - len(buf))
+            if not chunk:
+                raise ConnectionError("peer closed the rendezvous socket")
+            buf += chunk
+        return bytes(buf)
+    (n,) = struct.unpack("<Q", rd(8))
+    return pickle.loads(rd(n))
+
+
+class Comm:
+    """World group of the launch.  ``backend``: "auto" (RCCL when a device is given and every rank can initialise it, else
+    tcp), "rccl", "tcp"."""
+
+    def __init__(self, device=None, backend="auto", env=None, timeout=120.0):
+        env = os.environ if env is None else env
+        self.rank, self.local_rank, self.world = rank_info(env)
+        self.device = device
+        self.backend = "single" if self.world == 1 else "tcp"
+        self.note = None
+        self.op_timeout = 3600.0                           # a collective may wait for a rank that is still computing
+        self._peers, self._root, self._srv, self._file = [], None, None, None
+        self._nccl, self._ncomm, self._scratch = None, None, None
+        if self.world > 1:
+            self._rendezvous(env, timeout)
+        want_rccl = backend == "rccl" or (backend == "auto" and device is not None and self.world > 1)
+        if want_rccl:
+            ok, why = self._init_rccl()
+            # every rank must take the same path
+            flags = self._tcp_allreduce(np.array([1.0 if ok else 0.0]), "min") if self.world > 1 else np.array([1.0 if ok else 0.0])
+            if flags[0] > 0:
+                self.backend = "rccl"
+            else:
+                self._drop_rccl()
+                self.note = "rccl unavailable (%s): host-side tcp collectives" % (why or "another rank failed")
+                if backend == "rccl":
+                    raise RuntimeError(self.note)
+
+    # ---------------------------------------------------------------------------------------------- rendezvous (tcp star)
+    def _rendezvous(self, env, timeout):
+        addr = env.get("MASTER_ADDR", "127.0.0.1")
+        key = "qampy_comm_%s_%s_%d" % (addr.replace(":", "_"), env.get("MASTER_PORT", "0"), os.getppid())
+        path = os.path.join(tempfile.gettempdir(), key)
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, int(env.get("QAMPY_COMM_PORT", "0"))))
+            srv.listen(self.world)
+            tmp = path + ".%d" % os.getpid()
+            with open(tmp, "w") as f:
+                f.write("%s %d %d" % (addr, srv.getsockname()[1], os.getpid()))
+            os.replace(tmp, path)
+            self._srv, self._file = srv, path
+            srv.settimeout(timeout)
+            peers = {}
+            while len(peers) < self.world - 1:
+                c, _ = srv.accept()
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                c.settimeout(timeout)
+                peers[_recv(c)] = c
+            self._peers = [peers[r] for r in range(1, self.world)]
+            for c in self._peers:
+                c.settimeout(self.op_timeout)
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    host, port, pid = open(path).read().split()
+                    os.kill(int(pid), 0)                 # a file left behind by a dead launch of the same key is ignored
+                    s = socket.create_connection((host, int(port)), timeout=timeout)
+                    break
+                except (OSError, ValueError):
+                    if time.time() - t0 > timeout:
+                        raise TimeoutError("rank %d: no rendezvous at %s" % (self.rank, path))
+                    time.sleep(0.05)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.settimeout(timeout)
+            _send(s, self.rank)
+            s.settimeout(self.op_timeout)
+            self._root = s
+
+    def _tcp_allreduce(self, a, op):
+        a = np.ascontiguousarray(a)
+        if self.world == 1:
+            return a.copy()
+        f = _NP_OP[op]
+        if self.rank == 0:
+            acc = a.copy()
+            for p in self._peers:
+                acc = f(acc, _recv(p))
+            for p in self._peers:
+                _send(p, acc)
+            return acc
+        _send(self._root, a)
+        return _recv(self._root)
+
+    def _tcp_bcast_obj(self, obj, root=0):
+        if self.world == 1:
+            return obj
+        if root != 0:                                  # via rank 0
+            if self.rank == root:
+                _send(self._root, obj)
+            if self.rank == 0:
+                obj = _recv(self._peers[root - 1])
+        if self.rank == 0:
+            for p in self._peers:
+                _send(p, obj)
+            return obj
+        return _recv(self._root)
+
+    # ---------------------------------------------------------------------------------------------- RCCL
+    def _init_rccl(self):
+        try:
+            from . import _lib
+            lib = None
+            for name in ("librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
+                try:
+                    lib = C.CDLL(name)
+                    break
+                except OSError:
+                    continue
+            if lib is None:
+                return False, "librccl.so not found"
+            lib.ncclGetErrorString.restype = C.c_char_p
+            lib.ncclGetErrorString.argtypes = [C.c_int]
+            lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+            lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+            lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            lib.ncclBroadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            _lib.init(self.device)                       # hipSetDevice for this process before the communicator exists
+            uid = _UniqueId()
+            raw = None
+            if self.rank == 0:
+                rc = lib.ncclGetUniqueId(C.byref(uid))
+                raw = None if rc else C.string_at(C.addressof(uid), NCCL_UNIQUE_ID_BYTES)      # (the whole structure: it may hold NULs)
+            raw = self._tcp_bcast_obj(raw)                 # rank 0's failure reaches everybody: no rank waits in vain
+            if raw is None:
+                return False, "ncclGetUniqueId failed on rank 0"
+            C.memmove(C.addressof(uid), raw, NCCL_UNIQUE_ID_BYTES)
+            comm = C.c_void_p()
+            # (RCCL prints a version banner on stdout when the first communicator is created: stdout carries bench.py's JSON line)
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                rc = lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank)
+            finally:
+                os.dup2(keep, 1)
+                os.close(keep)
+            if rc:
+                return False, "ncclCommInitRank: %s" % lib.ncclGetErrorString(rc).decode()
+            self._nccl, self._ncomm = lib, comm
+            self._scratch = _lib.DeviceArray((64,), np.float64)
+            return True, None
+        except Exception as e:                             # noqa: BLE001 - any failure means "use the fallback"
+            return False, "%s: %s" % (type(e).__name__, e)
+
+    def _drop_rccl(self):
+        if self._nccl is not None and self._ncomm is not None:
+            try:
+                self._nccl.ncclCommDestroy(self._ncomm)
+            except Exception:                              # noqa: BLE001
+                pass
+        self._nccl, self._ncomm, self._scratch = None, None, None
+
+    def _stream(self):
+        from . import _lib
+        s = C.c_void_p()
+        _lib.call("qh_stream_handle", C.byref(s))
+        return s
+
+    def _ck(self, rc, what):
+        if rc:
+            raise RuntimeError("%s: %s" % (what, self._nccl.ncclGetErrorString(rc).decode()))
+
+    # ---------------------------------------------------------------------------------------------- collectives: host values
+    def allreduce(self, values, op="sum"):
+        """Element-wise reduction over the ranks of a small table of host values (float64); returns an ndarray."""
+        a = np.ascontiguousarray(np.asarray(values, dtype=np.float64))
+        if self.world == 1:
+            return a.copy()
+        if self.backend == "rccl":
+            from . import _lib
+            flat = a.ravel()
+            if flat.size > self._scratch.shape[0]:
+                self._scratch = _lib.DeviceArray((flat.size,), np.float64)
+            _lib.call("qh_memcpy_h2d", self._scratch.ptr, _lib.ptr(flat), flat.nbytes)
+            self._ck(self._nccl.ncclAllReduce(self._scratch.ptr, self._scratch.ptr, flat.size, 8, _NCCL_OP[op], self._ncomm, self._stream()), "ncclAllReduce")
+            out = np.empty_like(flat)
+            _lib.call("qh_memcpy_d2h", _lib.ptr(out), self._scratch.ptr, flat.nbytes)      # synchronises the library stream
+            return out.reshape(a.shape)
+        return self._tcp_allreduce(a, op)
+
+    def barrier(self):
+        self.allreduce([0.0])
+
+    # ---------------------------------------------------------------------------------------------- collectives: device buffers
+    def allreduce_dev(self, ptr, count, dtype, op="sum"):
+        """In-place all-reduce of a DEVICE buffer of ``count`` elements.  RCCL: enqueued on the library stream, returns at once;
+        tcp: staged through the host (synchronises)."""
+        dt = np.dtype(dtype)
+        if self.world == 1:
+            return
+        if self.backend == "rccl":
+            self._ck(self._nccl.ncclAllReduce(C.c_void_p(ptr), C.c_void_p(ptr), int(count), _NCCL_DTYPE[dt], _NCCL_OP[op], self._ncomm, self._stream()), "ncclAllReduce")
+            return
+        from . import _lib
+        host = np.empty(int(count), dt)
+        _lib.call("qh_memcpy_d2h", _lib.ptr(host), C.c_void_p(ptr), host.nbytes)
+        host = self._tcp_allreduce(host, op)
+        _lib.call("qh_memcpy_h2d", C.c_void_p(ptr), _lib.ptr(host), host.nbytes)
+
+    def broadcast_dev(self, ptr, nbytes, root=0):
+        """Broadcast of a device buffer from ``root`` (the north star's "broadcast of converged taps": 1312 B at 2 x 2 x 41)."""
+        if self.world == 1:
+            return
+        if self.backend == "rccl":
+            self._ck(self._nccl.ncclBroadcast(C.c_void_p(ptr), C.c_void_p(ptr), int(nbytes), 1, int(root), self._ncomm, self._stream()), "ncclBroadcast")
+            return
+        from . import _lib
+        host = np.empty(int(nbytes), np.uint8)
+        _lib.call("qh_memcpy_d2h", _lib.ptr(host), C.c_void_p(ptr), host.nbytes)
+        host = self._tcp_bcast_obj(host if self.rank == root else None, root)
+        _lib.call("qh_memcpy_h2d", C.c_void_p(ptr), _lib.ptr(host), host.nbytes)
+
+    @property
+    def on_stream(self):
+        """Device collectives are enqueued on the library stream (no host synchronisation around them)."""
+        return self.backend == "rccl"
+
+    def close(self):
+        try:
+            if self.world > 1:
+                self._tcp_allreduce(np.array([0.0]), "sum")      # nobody tears the star down while another rank still needs it
+        except Exception:                                  # noqa: BLE001
+            pass
+        self._drop_rccl()
+        for s in self._peers + ([self._root] if self._root else []) + ([self._srv] if self._srv else []):
+            try:
+                s.close()
+            except OSError:
+                pass
+        if self._file:
+            try:
+                os.remove(self._file)
+            except OSError:
+                pass
+        self._peers, self._root, self._srv, self._file = [], None, None, None

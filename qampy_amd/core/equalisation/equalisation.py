@@ -10,6 +10,8 @@ with the same signatures, return values and error behaviour, so that reference c
 can switch to ``qampy_amd.core.equalisation`` unchanged.  Everything numerically heavy is delegated to
 :mod:`.hip_equalisation` (the drop-in for the pythran extension).  Methods are selected by the same strings.
 """
+import warnings
+
 import numpy as np
 
 from ... import theory
@@ -185,7 +187,15 @@ class _Field:
                 err, wxy, _ = self.dev.train(TrSyms, Niter, os, mu, wxy, rows, adaptive, sy, method)
             else:
                 err, wxy, _ = self.dev.train(TrSyms, Niter, os, mu, wxy, rows, adaptive, sy, method, pit=pit)
-                _PIT_REPORTS.append(self.dev.last_report)
+                rep = self.dev.last_report
+                _PIT_REPORTS.append(rep)
+                # the report is on the host already: never hand back an uncertified result silently
+                if rep["acquisition"]["diverged"]:
+                    warnings.warn("tier b (%s): the gear-shifted acquisition diverged and was undone; the passes started from the given taps" % method, RuntimeWarning)
+                if not rep["converged"]:
+                    warnings.warn("tier b (%s): the parallel-in-time solver stopped after %d passes WITHOUT reaching its tolerance (%g; last estimate %s): the "
+                                  "result is not certified as the sequential recurrence's - use tier='a' or raise max_passes"
+                                  % (method, rep["passes"], rep["tol"], ("%.3g" % rep["deviation_rms"][-1]) if rep.get("deviation_rms") else "n/a"), RuntimeWarning)
         return wxy, err
 
     def filtered(self, os, wxy, rows):
@@ -199,8 +209,6 @@ class _Field:
 #: device reports (qh_pit_report as dicts) of the tier-b stages of the most recent equalise_signal / dual_mode_equalisation call
 _PIT_REPORTS = []
 
-#: boundary-defect tolerance of a tier-b stage whose taps only seed the next stage (the result stage: the library's 0.01)
-PIT_TOL_SEEDING = 0.06
 
 
 def last_pit_reports():
@@ -224,8 +232,7 @@ def _tier_options(kwargs, nstages, cold):
         raise ValueError("pit needs one options dict per stage")
     for k, o in enumerate(per_stage):
         o.setdefault("acquire", 1 if (k == 0 and cold) else 0)     # centre-spike start taps: sequential acquisition first
-        if k < nstages - 1:
-            o.setdefault("tol", PIT_TOL_SEEDING)
+        # (every stage is held to the same tolerance: what a seeding stage leaves in the weakly excited tap directions reaches the result undamped)
     return per_stage
 
 

@@ -42,11 +42,15 @@ def _blind_search(rx, grid, os, mu, M_pilot, Ntaps, eqargs):
     that window ended with."""
     steps = np.arange(grid.first, grid.nsteps)
     var, best, taps = _eq.search_windows(rx, os, mu, M_pilot, steps * grid.hop, grid.window, Ntaps=Ntaps, **eqargs)
-    table = np.full((rx.shape[0], grid.nsteps), 1e2)          # steps that are never visited can never win
-    table[:, steps] = var
-    winner = np.argmin(table, axis=-1)
+    # The winner is the DEVICE's choice - the window whose taps came back (first minimum with a strict `<`: a NaN variance, i.e. a
+    # diverged adaptive-step window, never wins there, whereas np.argmin would pick it and the centre would belong to one window,
+    # the taps to another).  Steps that are never visited can never win: the placeholder of the reference's table is 1e2.
+    best = np.asarray(best, dtype=np.int64)
+    winner = steps[best]
     for m in range(rx.shape[0]):                              # degenerate capture: nothing beat the placeholder
-        if winner[m] < grid.first:
+        v = var[m, best[m]]
+        if not (v < 1e2):
+            winner[m] = 0
             taps[m] = 0
     return winner, taps
 

@@ -132,6 +132,8 @@ int qh_set_trainer(int form)
     return QH_OK;
 }
 
+int qh_abi_version(void) { return QH_ABI_VERSION; }
+
 int qh_device_count(int *count)
 {
     int n = 0;
@@ -177,6 +179,13 @@ int qh_use_stream(int idx)
     if (rc) return rc;
     if (idx < 0 || idx > 1) { qh::set_error("qh_use_stream: the library has streams 0 and 1"); return QH_ERR_ARG; }
     qh::g_stream = qh::g_streams[idx];
+    return QH_OK;
+}
+int qh_stream_handle(void **stream)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    *stream = (void *)qh::g_stream;
     return QH_OK;
 }
 int qh_stream_wait_event(void *ev)

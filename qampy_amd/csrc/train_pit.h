@@ -19,7 +19,8 @@ typedef qh_pit_report PitCtrl;
 
 constexpr double PIT_CONTRACT = 0.2; // expected defect ratio of consecutive passes with the coarse correction (measured 0.1 .. 0.4)
 constexpr int PIT_PROBE = 128;      // symbol periods of the capture a boundary defect is measured on
-constexpr int PIT_SEEDWIN = 512;    // symbol periods of a segment's head the phase seed is estimated on
+constexpr int PIT_SEEDWIN = 512;
+constexpr int PIT_MAXSEG = 65536;  // segments of a sweep (was 4096: the 10^7-symbol capture already sat on it)    // symbol periods of a segment's head the phase seed is estimated on
 
 // symmetry group of an error function: errfn(g y) = g errfn(y).  0: every phase (cma, rde); n: the n-th roots of unity
 __host__ __device__ inline int pit_symmetry(int method)
@@ -100,7 +101,7 @@ __global__ void __launch_bounds__(256) pit_setup_kernel(const Cx<R> *E, int nmod
         if (ma > cap) ma = cap;
         if (!(ma > m)) ma = m;
         c->segments = sg.S; c->seg_len = sg.len; c->mu = m; c->mu_acq = ma; c->power = p; c->tol = tol;
-        for (int q = 0; q < QH_PIT_MAXPASS; q++) c->result_change[q] = -1; c->passes = 0; c->converged = 0; c->acq_chunks = 0; c->acq_steps = 0; c->acq_done = 0; c->done = 0; c->diverged = 0; c->corr_on = 0; c->gain = 0; c->out_power = 0;
+        for (int q = 0; q < QH_PIT_MAXPASS; q++) { c->result_change[q] = -1; c->deviation[q] = -1; c->deviation_rms[q] = -1; c->deviation_taps[q] = -1; } c->passes = 0; c->converged = 0; c->acq_chunks = 0; c->acq_steps = 0; c->acq_done = 0; c->done = 0; c->diverged = 0; c->corr_on = 0; c->gain = 0; c->out_power = 0;
         for (int i = 0; i < QH_PIT_MAXPASS; i++) c->defect[i] = -1;
         for (int i = 0; i < QH_PIT_MAXCHUNK; i++) c->acq_err[i] = -1;
         *mu_acq = (R)ma;
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(256) pit_setup_kernel(const Cx<R> *E, int nmod
 static __global__ void pit_sweep_kernel(PitCtrl *c)
 {
     c->done = 0; c->converged = 0; c->passes = 0;
-    for (int q = 0; q < QH_PIT_MAXPASS; q++) c->result_change[q] = -1;
+    for (int q = 0; q < QH_PIT_MAXPASS; q++) { c->result_change[q] = -1; c->deviation[q] = -1; c->deviation_rms[q] = -1; c->deviation_taps[q] = -1; }
     for (int i = 0; i < QH_PIT_MAXPASS; i++) c->defect[i] = -1;
 }
 
@@ -214,11 +215,9 @@ __global__ void __launch_bounds__(256) pit_phase_kernel(const Cx<R> *E, int nmod
 }
 
 // rot[s, j] = exp(-i phi_s): phi = arg(-z)/4 (E[s^4] is negative real for the QAM alphabets), unwrapped along the segments
-static __global__ void __launch_bounds__(256) pit_unwrap_kernel(const double *z, int S, int nsel, double *rot)
+static __global__ void __launch_bounds__(256) pit_unwrap_kernel(const double *z, int S, int nsel, double *rot, double *phi, int *jump)
 {
-    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
-    double *phi = reinterpret_cast<double *>(pit_smem);       // [S]
-    int *jump = reinterpret_cast<int *>(phi + S);            // [S]
+    // phi[S], jump[S]: work arrays in device memory (one block; S may be tens of thousands)
     __shared__ int ptot[512];
     const double q = 1.5707963267948966;
     for (int j = 0; j < nsel; j++) {
@@ -241,16 +240,19 @@ static __global__ void __launch_bounds__(256) pit_unwrap_kernel(const double *z,
     }
 }
 
-// X[s] = wx with the rows of the selected modes rotated by rot[s, j] (rot == nullptr: plain copies)
+// X[s] = wx with the rows of the selected modes rotated by rot[s, j] (rot == nullptr: plain copies).  w0 != nullptr: segment 0
+// starts from w0 as it is - the taps the sweep starts from in the reference - whatever seeds the other segments get.
 template <typename R>
-__global__ void __launch_bounds__(256) pit_seed_kernel(const Cx<R> *wx, int nmodes, int ntot, const int64_t *modes_dev, int nsel, const double *rot, Cx<R> *X)
+__global__ void __launch_bounds__(256) pit_seed_kernel(const Cx<R> *wx, int nmodes, int ntot, const int64_t *modes_dev, int nsel, const double *rot, Cx<R> *X,
+                                                       const Cx<R> *w0)
 {
     const int s = blockIdx.x;
     const int n = nmodes * ntot;
+    const bool exact0 = s == 0 && w0 != nullptr;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int row = e / ntot;
-        Cx<R> v = wx[e];
-        if (rot) {
+        Cx<R> v = exact0 ? w0[e] : wx[e];
+        if (rot && !exact0) {
             for (int j = 0; j < nsel; j++)
                 if ((int)modes_dev[j] == row) {
                     const double c = rot[2 * ((size_t)s * nsel + j)], d = rot[2 * ((size_t)s * nsel + j) + 1];
@@ -361,25 +363,38 @@ template <typename R> __device__ inline double pit_gain(int method, double Py, C
     }
 }
 
-// end of a pass: largest boundary defect -> report; the pass's end taps become the sweep's result; converged -> later passes skip
+// end of a pass: largest boundary defect and the deviation estimate -> report; the pass's end taps become the sweep's result;
+// converged -> later passes skip.  devmax: per-block maxima of sum_k lambda_k |D~_k[col]|^2 from pit_devest_kernel (ndev of them;
+// nullptr / corr_on = 0: no estimate, the defect rule decides).
+constexpr double PIT_DEV_SAFETY = 1.0, PIT_DEV_WORST = 3.0, PIT_DEV_TAPS = 2.0;    // rule: safety x rms estimate < tol, worst segment < 3 tol, taps (relative norm, rms over segments) < 2 tol
 template <typename R>
-__global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, const double *pw, int nb, const Cx<R> *Ylast, int n, Cx<R> *wx, int method,
-                                                         const Cx<R> *sy0, int want_corr, PitCtrl *c, float *host_view, int sym, int nrow)
+__global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, const double *pw, int nb, const Cx<R> *Ylast, int n, Cx<R> *wx, PitCtrl *c, float *host_view,
+                                                         int nrow, const float *devmax, int ndev, double safety)
 {
     if (c->done) return;
-    __shared__ double red[256], redp[256];
-    double m = 0, ps = 0;
+    __shared__ double red[256], redd[256], reds[256], redt[256], redw[256];
+    double m = 0, dv = 0, ds = 0, dt = 0, wn = 0;
     for (int i = threadIdx.x; i < nb; i += 256) {
         const double v = dfc[i];
         m = (v > m || !(v == v)) ? (v == v ? v : 1e30) : m;
-        ps += pw[i];
     }
-    red[threadIdx.x] = m; redp[threadIdx.x] = ps;
+    if (devmax)
+        for (int i = threadIdx.x; i < ndev; i += 256) {
+            const double v = (double)devmax[3 * i];
+            dv = (v > dv || !(v == v)) ? (v == v ? v : 1e30) : dv;
+            ds += (double)devmax[3 * i + 1];
+            dt += (double)devmax[3 * i + 2];
+        }
+    for (int e = threadIdx.x; e < n; e += 256) { const Cx<R> v = Ylast[e]; wn += (double)v.re * v.re + (double)v.im * v.im; }      // |taps|^2 of all output modes
+    red[threadIdx.x] = m; redd[threadIdx.x] = dv; reds[threadIdx.x] = ds; redt[threadIdx.x] = dt; redw[threadIdx.x] = wn;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
             red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
-            redp[threadIdx.x] += redp[threadIdx.x + s];
+            redd[threadIdx.x] = redd[threadIdx.x] > redd[threadIdx.x + s] ? redd[threadIdx.x] : redd[threadIdx.x + s];
+            reds[threadIdx.x] += reds[threadIdx.x + s];
+            redt[threadIdx.x] += redt[threadIdx.x + s];
+            redw[threadIdx.x] += redw[threadIdx.x + s];
         }
         __syncthreads();
     }
@@ -389,35 +404,44 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
     for (int e = threadIdx.x; e < n; e += 256) wx[e] = Ylast[e];
     if (threadIdx.x == 0) {
         const int p = c->passes;
-        if (p < QH_PIT_MAXPASS) { c->defect[p] = red[0]; c->result_change[p] = chg; }
+        const bool have_dev = devmax != nullptr && c->corr_on && c->out_power > 0;
+        const double dev = have_dev ? sqrt(redd[0] / c->out_power) : -1.0;                            // worst segment
+        const double dev_rms = have_dev ? sqrt(reds[0] / ((double)(nb + nrow) * c->out_power)) : -1.0;  // rms over segments and modes
+        // taps: rms over segments of |D[s]| / |w|, |w|^2 = the squared tap norm of one output mode (mean over the modes that have taps)
+        const double wnorm2 = redw[0] / (double)(nrow > 0 ? nrow : 1);
+        const double dev_tap = (have_dev && wnorm2 > 0) ? sqrt(redt[0] / ((double)(nb + nrow) * wnorm2)) : -1.0;
+        if (p < QH_PIT_MAXPASS) { c->defect[p] = red[0]; c->result_change[p] = chg; c->deviation[p] = dev; c->deviation_rms[p] = dev_rms; c->deviation_taps[p] = dev_tap; }
         c->passes = p + 1;
-        if (p == 0) {
-            const double Py = redp[0] / nb;
-            const double g = pit_gain<R>(method, Py, sy0[0]);
-            c->out_power = Py; c->gain = g;
-            c->corr_on = (want_corr && g > 0 && g == g) ? 1 : 0;
-        } else if (!(red[0] < c->defect[p - 1 < QH_PIT_MAXPASS ? p - 1 : QH_PIT_MAXPASS - 1])) {
-            c->corr_on = 0;            // the correction did not help: plain relaxation from here on
+        // The criterion.  With the coarse correction: `dev`, the first-order estimate of how far this pass's trajectory is from the
+        // sequential recurrence (rms of the output, worst segment, relative to the output rms; include/qampy_hip.h "Stop rule"),
+        // times a safety factor for what the linearised model misses.  Without it: the largest boundary defect, which says how
+        // far the trajectory is only through how much a segment forgets - errors of the start taps decay by rho = exp(-mu g T
+        // lambda) per segment, so defects of size d everywhere leave ~ d / (1 - rho); `tol` is then calibrated on the automatic
+        // grid (mu T = 0.2) and the defect of shorter segments is held to a proportionally smaller value.
+        double crit;
+        if (have_dev) {
+            crit = safety * dev_rms;
+            if (safety * dev / PIT_DEV_WORST > crit) crit = safety * dev / PIT_DEV_WORST;
+            if (dev_tap >= 0 && safety * dev_tap / PIT_DEV_TAPS > crit) crit = safety * dev_tap / PIT_DEV_TAPS;
         }
-        // What a boundary defect d says about the distance from the sequential trajectory depends on how much a segment forgets:
-        // errors of the start taps decay by rho = exp(-mu g T lambda) per segment (lambda ~ 2 <|x|^2> in band), so defects of size d
-        // everywhere leave ~ d / (1 - rho).  `tol` is calibrated on the automatic grid (mu T = 0.2, where the output deviates by
-        // ~0.6 d); for shorter segments - a caller's choice - the defect is held to a proportionally smaller value, so that short
-        // segments cannot buy a certificate by barely moving their taps (measured: 256-QAM, 4 x shorter segments, defect 0.009 and
-        // 8000 symbol errors).  Never loosened for longer ones.
-        double amp = 1.0;
-        if (c->gain > 0 && c->power > 0 && c->mu > 0) {
-            const double gl = c->gain * 2.0 * c->power, a = c->mu * (double)c->seg_len * gl;
-            if (a > 0) amp = (1.0 - exp(-0.2 * gl)) / (1.0 - exp(-a));
-            if (!(amp > 1.0)) amp = 1.0;
+        else {
+            double amp = 1.0;
+            if (c->gain > 0 && c->power > 0 && c->mu > 0) {
+                const double gl = c->gain * 2.0 * c->power, a = c->mu * (double)c->seg_len * gl;
+                if (a > 0) amp = (1.0 - exp(-0.2 * gl)) / (1.0 - exp(-a));
+                if (!(amp > 1.0)) amp = 1.0;
+            }
+            crit = red[0] * amp;
         }
-        if (red[0] * amp < c->tol) { c->converged = 1; c->done = 1; }
+        const int pl = p - 1 < QH_PIT_MAXPASS ? p - 1 : QH_PIT_MAXPASS - 1, pl2 = p - 2 < QH_PIT_MAXPASS ? p - 2 : QH_PIT_MAXPASS - 1;
+        if (p >= 1 && c->corr_on && !(red[0] < c->defect[pl])) c->corr_on = 0;      // the correction did not help: plain relaxation from here on
+        if (crit < c->tol) { c->converged = 1; c->done = 1; }
         // nothing gained over two passes: the trajectory has no fixed point the passes can agree on (a stage that cannot track the
         // carrier) - stop, NOT converged; further passes would only cost time.  (Slow but steady gains - rde's ring decisions - go on
         // to max_passes: the uncertified result keeps improving with them.)
-        else if (p >= 2 && p < QH_PIT_MAXPASS && !(red[0] < c->defect[p - 2])) c->done = 1;
-        host_view[0] = c->done ? 1.f : 0.f;                   // what the host reads after the pass: flag + defect (to decide
-        host_view[1] = (float)red[0];                         // whether the pass after the next one is worth enqueueing early)
+        else if (p >= 2 && p < QH_PIT_MAXPASS && !(red[0] < c->defect[pl2])) c->done = 1;
+        host_view[0] = c->done ? 1.f : 0.f;                   // what the host reads after the pass: flag + criterion (to decide
+        host_view[1] = (float)crit;                           // whether the pass after the next one is worth enqueueing early)
     }
 }
 
@@ -769,9 +793,29 @@ __global__ void __launch_bounds__(256) pit_recur_kernel(Zf *D, const double *lam
 // end taps of segment s-1 (yB ~ g_s yA, from the defect kernel) is not an error: theta_s = g_1 ... g_s brings every segment
 // into the frame of segment 0, where the boundary defects are formed and corrected (a rotation treated as an additive
 // defect would be wrong in second order and keep the iteration from converging below ~theta^2).
-static __global__ void __launch_bounds__(256) pit_gauge_kernel(const double *gph, int S, int nsel, const PitCtrl *c, double *theta)
+template <typename R>
+__global__ void __launch_bounds__(256) pit_gauge_kernel(const double *gph, int S, int nsel, PitCtrl *c, double *theta, const double *pw, int nb, int method, const Cx<R> *sy0,
+                                                        int want_corr)
 {
     if (c->done) return;
+    if (c->passes == 0) {                                     // first pass of a sweep: mean output power -> gain of the linearised map (the scan below needs it)
+        __shared__ double redp[256];
+        double ps = 0;
+        for (int i = threadIdx.x; i < nb; i += 256) ps += pw[i];
+        redp[threadIdx.x] = ps;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) redp[threadIdx.x] += redp[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const double Py = redp[0] / (nb > 0 ? nb : 1);
+            const double g = pit_gain<R>(method, Py, sy0[0]);
+            c->out_power = Py; c->gain = g;
+            c->corr_on = (want_corr && g > 0 && g == g) ? 1 : 0;
+        }
+        __syncthreads();
+    }
     // theta_s = g_1 ... g_s as a running PRODUCT of unit complex numbers (chunk per thread, scan of the chunk products):
     // no angles, no trigonometry; renormalised on output
     __shared__ double2 gbuf[512];
@@ -789,6 +833,36 @@ static __global__ void __launch_bounds__(256) pit_gauge_kernel(const double *gph
             theta[2 * ((size_t)s * nsel + j)] = run.x * r; theta[2 * ((size_t)s * nsel + j) + 1] = run.y * r;
         }
     }
+}
+// Output power of the accumulated corrections: dev2[col] = sum_k lambda_k |D~_k[col]|^2 (D~ in the eigenbasis, after the scan), the
+// block's maximum -> devmax[blockIdx.x].  D~[s] is the first-order estimate of how far the start taps of segment s are from the
+// sequential trajectory; lambda-weighted it is the power of the output deviation they cause.
+static __global__ void __launch_bounds__(256) pit_devest_kernel(const Zf *D, const double *lam, int n, int ncol, const PitCtrl *c, float *devmax)
+{
+    if (c->done) return;
+    __shared__ float red[256], reds[256], redt[256];
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.f, tap = 0.f;
+    if (col < ncol)
+        for (int k = 0; k < n; k++) {
+            const Zf v = D[(size_t)k * ncol + col];
+            const float l = (float)lam[k], m2 = v.x * v.x + v.y * v.y;
+            acc += (l > 0.f ? l : 0.f) * m2;
+            tap += m2;                                            // V is unitary: the squared norm of the tap deviation itself
+        }
+    red[threadIdx.x] = (acc == acc) ? acc : 3.0e38f;
+    reds[threadIdx.x] = (acc == acc) ? acc : 3.0e38f;
+    redt[threadIdx.x] = (tap == tap) ? tap : 3.0e38f;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
+            reds[threadIdx.x] += reds[threadIdx.x + s];
+            redt[threadIdx.x] += redt[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { devmax[3 * blockIdx.x] = red[0]; devmax[3 * blockIdx.x + 1] = reds[0]; devmax[3 * blockIdx.x + 2] = redt[0]; }   // worst column, sums over the columns
 }
 // ------------------------------------------------------------------------------------------------ host side
 // kernel time of the most recent call (HIP events around the trainer launches; the host synchronises after each anyway)
@@ -822,7 +896,7 @@ inline int pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold)
     if (target > 1048576) target = 1048576;
     const int64_t seg = ((int64_t)target + 63) / 64 * 64;
     int64_t S = TrSyms / seg;
-    if (S > 4096) S = 4096;
+    if (S > PIT_MAXSEG) S = PIT_MAXSEG;
     const int64_t ncu = 256;                                   // MI355X: whole rounds of workgroups
     if (S * nsel > ncu && nsel <= ncu) S = S * nsel / ncu * ncu / nsel;
     if (S < 4) S = 1;
@@ -893,11 +967,12 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     memset(&o, 0, sizeof(o));
     o.phase_seed = -1; o.corr_beta = -1;
     if (opts) o = *opts;
-    QH_REQUIRE(o.segments >= 0 && o.segments <= 4096 && o.max_passes >= 0 && o.max_passes <= QH_PIT_MAXPASS, "train_equaliser: bad segment / pass count");
+    QH_REQUIRE(o.segments >= 0 && o.segments <= PIT_MAXSEG && o.max_passes >= 0 && o.max_passes <= QH_PIT_MAXPASS, "train_equaliser: bad segment / pass count");
     const int ntot = nmodes * ntaps;
     QH_REQUIRE(ntot <= 64 * 16, "train_equaliser: more than 1024 taps per output mode are not supported");
-    const int npass = o.max_passes > 0 ? o.max_passes : 8;
-    const double tol = o.tol > 0 ? o.tol : 0.01;
+    const int npass = o.max_passes > 0 ? o.max_passes : 12;
+    const double tol = o.tol > 0 ? o.tol : 1e-3;
+    const double safety = o.dev_safety > 0 ? o.dev_safety : PIT_DEV_SAFETY;
     const double gear = o.gear > 0 ? o.gear : 8.0;
     const double bound = o.acq_bound > 0 ? o.acq_bound : 0.08;
     const double plateau = o.acq_plateau > 0 ? o.acq_plateau : 0.8;
@@ -963,11 +1038,12 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         else if (!(pf && pf[0] == 's') && (int64_t)sg.S * nsel < 512) seg_ok = false;
     }
     const bool seg_form = seg_ok;
-    const bool split = o.exchange != nullptr && o.seg_count > 0;
+    const bool split = o.exchange != nullptr;
     const int own_first = split ? o.seg_first : 0, own_count = split ? o.seg_count : sg.S;
+    const bool xchg_async = split && o.exchange_on_stream != 0;
     if (split) {
         QH_REQUIRE(seg_form, "train_equaliser: a capture split over processes needs the throughput form of the passes (>= 512 chains, supported tap layout)");
-        QH_REQUIRE(own_first >= 0 && own_first + own_count <= sg.S, "train_equaliser: owned segments outside the segment grid");
+        QH_REQUIRE(own_first >= 0 && own_count >= 0 && own_first + own_count <= sg.S, "train_equaliser: owned segments outside the segment grid");
         QH_REQUIRE(Niter == 1, "train_equaliser: a capture split over processes is trained in one sweep");
     }
     const bool la_ok = force[0] != 'd' && la_supported(method, 0, nmodes, ntaps, os, sg.len, nsy);
@@ -986,10 +1062,14 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     void *wbuf = nullptr;
     const size_t nsj = (size_t)sg.S * nsel;
     const size_t bytes_w = ((2 * (size_t)sg.S + 1) * wbytes + 63) / 64 * 64;
-    if ((rc = scratch(2, bytes_w + 10 * nsj * sizeof(double) + (size_t)nsel * sizeof(int64_t) + 64, &wbuf))) return rc;
+    if ((rc = scratch(2, bytes_w + 10 * nsj * sizeof(double) + (size_t)nsel * sizeof(int64_t) + 320 + (size_t)sg.S * 16 + 3 * ((nsj + 255) / 256) * sizeof(float), &wbuf))) return rc;
     Cx<R> *X = (Cx<R> *)wbuf, *Y = X + (size_t)sg.S * wset, *w_start = Y + (size_t)sg.S * wset;
     double *z = (double *)((char *)wbuf + bytes_w), *rot = z + 2 * nsj, *dfc = rot + 2 * nsj, *pw = dfc + nsj, *gph = pw + nsj, *theta = gph + 2 * nsj;
     int64_t *modes_dev = (int64_t *)(theta + 2 * nsj);
+    double *uw_phi = (double *)(modes_dev + ((nsel + 7) / 8 * 8));
+    int *uw_jump = (int *)(uw_phi + sg.S);
+    float *devmax = (float *)(uw_jump + sg.S);                    // per-block maxima of the deviation estimate (ndev of them)
+    const int ndev = (int)((nsj + 255) / 256);                     // (three floats per block: worst column, sum, sum of the tap norms)
     QH_HIP(hipMemcpyAsync(modes_dev, modes, (size_t)nsel * sizeof(int64_t), hipMemcpyHostToDevice, g_stream));
     QH_HIP(hipStreamSynchronize(g_stream));                       // `modes` is the caller's memory
 
@@ -1026,8 +1106,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     if (want_corr && !gemm_attr) {
         QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        QH_HIP(hipFuncSetAttribute((const void *)pit_gauge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        gemm_attr = true;
+                gemm_attr = true;
     }
 
     LaArgs<R> la;
@@ -1102,25 +1181,20 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             QH_REQUIRE(phase_lds(nwin) <= 60 * 1024, "train_equaliser: phase seeding does not fit the LDS for this filter shape (pass phase_seed = 0)");
             hipLaunchKernelGGL((pit_phase_kernel<R>), dim3(sg.S, nsel), dim3(256), phase_lds(nwin), g_stream, (const Cx<R> *)E, nmodes, L, os,
                                (const Cx<R> *)wx, ntaps, sg, (const int64_t *)modes_dev, nwin, z);
-            hipLaunchKernelGGL(pit_unwrap_kernel, dim3(1), dim3(256), (size_t)sg.S * (sizeof(double) + sizeof(int)), g_stream, (const double *)z, sg.S, nsel, rot);
+            hipLaunchKernelGGL(pit_unwrap_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)z, sg.S, nsel, rot, uw_phi, uw_jump);
             rot_use = rot;
         }
-        hipLaunchKernelGGL((pit_seed_kernel<R>), dim3(sg.S), dim3(256), 0, g_stream, (const Cx<R> *)wx, nmodes, ntot, (const int64_t *)modes_dev, nsel, rot_use, X);
+        // segment 0 starts from the taps the sweep starts from in the reference (before the acquisition moved them), unrotated
+        const Cx<R> *w_exact = o.start == 1 ? nullptr : ((it == 0 && o.acquire) ? (const Cx<R> *)w_start : (const Cx<R> *)wx);
+        hipLaunchKernelGGL((pit_seed_kernel<R>), dim3(sg.S), dim3(256), 0, g_stream, (const Cx<R> *)wx, nmodes, ntot, (const int64_t *)modes_dev, nsel, rot_use, X, w_exact);
         QH_HIP(hipGetLastError());
         // ================================================================ relaxation passes
         auto enqueue_pass = [&](int p) -> int {
+            PitFuse<R> fz;
+            fz.X = X; fz.Y = Y; fz.theta = theta; fz.modes_dev = (const int64_t *)modes_dev; fz.nmodes = nmodes; fz.nsel = nsel;
             if (p > 0 && want_corr) {
-                // start taps += D,  D[s+1] = d[s+1] + J D[s]  (d = boundary defects): a parallel scan over the segments.  With the
-                // correction switched off on the device (corr_on = 0) the products are skipped and D = d: plain relaxation.
-                if (o.basis && pit_basis_sync().pending) {           // a basis still being built on the other stream
-                    QH_HIP(hipStreamWaitEvent(g_stream, pit_basis_sync().out, 0));
-                    pit_basis_sync().pending = false;
-                }
-                hipLaunchKernelGGL(pit_gauge_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)gph, sg.S, nsel, (const PitCtrl *)ctrl, theta);
-                PitFuse<R> fz;
-                fz.X = X; fz.Y = Y; fz.theta = theta; fz.modes_dev = (const int64_t *)modes_dev; fz.nmodes = nmodes; fz.nsel = nsel;
-                hipLaunchKernelGGL((pit_cgemm_kernel<R, true>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb, (const Zf *)nullptr, Dz[1], ntot, ncol, (const PitCtrl *)ctrl, fz);
-                hipLaunchKernelGGL((pit_recur_kernel<R>), dim3(ntot, nsel), dim3(256), 0, g_stream, Dz[1], lam, nsel, sg.S, sg.len, (const R *)mu_dev, beta, (const PitCtrl *)ctrl);
+                // start taps = theta X + V D~ with D[s+1] = d[s+1] + J D[s] from the analysis that closed pass p - 1 (below); with the
+                // correction switched off on the device (corr_on = 0) the scan ran with coefficient 0, D = d: plain relaxation
                 hipLaunchKernelGGL((pit_cgemm_kernel<R, false>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb + (size_t)ntot * ntot, (const Zf *)Dz[1], (Zf *)nullptr, ntot, ncol, (const PitCtrl *)ctrl, fz);
                 QH_HIP(hipGetLastError());
             } else if (p > 0) {
@@ -1139,7 +1213,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 for (int j = 0; j < 16; j++) sa.modes[j] = j < nsel ? modes[j] : 0;
                 sa.skip = &ctrl->done;
                 sa.q_first = own_first * nsel; sa.q_count = split ? own_count * nsel : 0;
-                { int r = launch_seg<R>(sa, method); if (r) return r; }
+                if (!split || own_count > 0) { int r = launch_seg<R>(sa, method); if (r) return r; }
             } else if (block_form) {
                 LaArgs<R> ls = la;
                 ls.TrSyms = sg.len; ls.nch = sg.S; ls.wx = Y; ls.err_off = (int64_t)it * TrSyms; ls.seg = 1; ls.seg_extra = sg.extra; ls.seg_tail = sg.tail;
@@ -1157,16 +1231,29 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 if (own_first > 0) QH_HIP(hipMemsetAsync(Y, 0, (size_t)own_first * wbytes, g_stream));
                 if (own_first + own_count < sg.S)
                     QH_HIP(hipMemsetAsync(Y + (size_t)(own_first + own_count) * wset, 0, (size_t)(sg.S - own_first - own_count) * wbytes, g_stream));
-                QH_HIP(hipStreamSynchronize(g_stream));
+                if (!xchg_async) QH_HIP(hipStreamSynchronize(g_stream));
                 if (o.exchange(o.exchange_user, Y, (size_t)sg.S * wbytes) != 0) { set_error("train_equaliser: the exchange callback failed"); return QH_ERR_ARG; }
             }
+            // ---- analysis of the pass: boundary defects -> gauge -> defect vectors in the eigenbasis -> scan (the next correction,
+            // and - weighted with the eigenvalues - the estimate of how far this pass is from the sequential recurrence) -> decision
             const size_t dlds = (2 * (size_t)ntot + (size_t)nmodes * os * pit_phase_pitch(ntaps, os, PIT_PROBE)) * sizeof(Cx<R>);
             QH_REQUIRE(dlds <= 60 * 1024, "train_equaliser: boundary probe does not fit the LDS for this filter shape");
             hipLaunchKernelGGL((pit_defect_kernel<R>), dim3(sg.S, nsel), dim3(PIT_PROBE), dlds, g_stream, (const Cx<R> *)E, nmodes, L, os,
                                ntaps, sg, TrSyms, (const int64_t *)modes_dev, (const Cx<R> *)X, (const Cx<R> *)Y, sym, (const PitCtrl *)ctrl, dfc, pw, gph, (const Cx<R> *)wx);
+            hipLaunchKernelGGL((pit_gauge_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)gph, sg.S, nsel, ctrl, theta, (const double *)pw,
+                               (int)((sg.S - 1) * nsel), method, (const Cx<R> *)symbols + (size_t)modes[0] * nsy, want_corr ? 1 : 0);
+            if (want_corr) {
+                if (o.basis && pit_basis_sync().pending) {           // a basis still being built on the other stream
+                    QH_HIP(hipStreamWaitEvent(g_stream, pit_basis_sync().out, 0));
+                    pit_basis_sync().pending = false;
+                }
+                hipLaunchKernelGGL((pit_cgemm_kernel<R, true>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb, (const Zf *)nullptr, Dz[1], ntot, ncol, (const PitCtrl *)ctrl, fz);
+                hipLaunchKernelGGL((pit_recur_kernel<R>), dim3(ntot, nsel), dim3(256), 0, g_stream, Dz[1], lam, nsel, sg.S, sg.len, (const R *)mu_dev, beta, (const PitCtrl *)ctrl);
+                hipLaunchKernelGGL(pit_devest_kernel, dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax);
+            }
             hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, (int)((sg.S - 1) * nsel),
-                               (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, method,
-                               (const Cx<R> *)symbols + (size_t)modes[0] * nsy, want_corr ? 1 : 0, ctrl, host_view, sym, nsel);
+                               (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, ctrl, host_view, nsel,
+                               want_corr ? (const float *)devmax : (const float *)nullptr, ndev, safety);
             QH_HIP(hipGetLastError());
             QH_HIP(hipMemcpyAsync(&ev.hview[2 * p], host_view, 2 * sizeof(float), hipMemcpyDeviceToHost, g_stream));
             QH_HIP(hipEventRecord(ev.flag[p], g_stream));
@@ -1180,7 +1267,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         for (int p = 0; p < npass; p++) {
             const bool expect_last = p > 0 && PIT_CONTRACT * (double)ev.hview[2 * (p - 1) + 1] < tol;
             ahead = false;
-            if (p + 1 < npass && !expect_last && !split) { if ((rc = enqueue_pass(p + 1))) return rc; ahead = true; }   // (split: a pass contains a host-side exchange)
+            if (p + 1 < npass && !expect_last && (!split || xchg_async)) { if ((rc = enqueue_pass(p + 1))) return rc; ahead = true; }   // (a host-side exchange cannot be enqueued ahead)
             QH_HIP(hipEventSynchronize(ev.flag[p]));
             if (tm.npass < QH_PIT_MAXPASS) { float ms = 0; QH_HIP(hipEventElapsedTime(&ms, ev.t0[p], ev.t1[p])); tm.pass_ms[tm.npass++] = ms; }
             if (ev.hview[2 * p] != 0.f) break;

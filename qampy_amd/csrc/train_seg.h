@@ -131,7 +131,8 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     constexpr int SG_ROWS = CPW, SG_NSTG = SG_ROWS * SG_PIECES;
     if (a.skip && *a.skip) return;
     extern __shared__ __attribute__((aligned(16))) char sg_smem[];
-    Cx<R> *lds = reinterpret_cast<Cx<R> *>(sg_smem);          // [2 buffers][SG_ROWS][SG_PITCH] + zero row [SG_PITCH]
+    Cx<R> *lds = reinterpret_cast<Cx<R> *>(sg_smem);          // [SG_ROWS][SG_PITCH] + zero row [SG_PITCH]  (ONE buffer: the next chunk waits in registers
+                                                              // while this one computes and is stored after it - one wave per workgroup, LDS operations in program order)
     using v2 = typename V2<R>::type;
     const int lane = threadIdx.x;
     const int l16 = lane & (LPC - 1);                          // lane within the chain
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     constexpr int rowsz = SG_PITCH;
     constexpr int bufsz = SG_ROWS * SG_PITCH;
     const int nrow = nslot * a.nmodes;                          // <= SG_ROWS (checked on the host)
-    Cx<R> *zero_row = lds + 2 * bufsz;
+    Cx<R> *zero_row = lds + bufsz;
     for (int e = lane; e < rowsz; e += 64) zero_row[e] = Cx<R>{0, 0};
     int64_t rowbase[SG_ROWS], rowlim[SG_ROWS];                  // sample offset of row r at chunk 0, last sample of its capture row (wave-uniform)
 #pragma unroll
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     };
     // ... and from there into the buffer of that chunk once the previous user of the buffer is done
     auto stage_store = [&](int chunk) {
-        Cx<R> *dst = lds + (chunk & 1) * bufsz;
+        Cx<R> *dst = lds;
 #pragma unroll
         for (int u = 0; u < SG_NSTG; u++)
             if (u / SG_PIECES < nrow) dst[u * 64 + lane] = stg_r[u];
@@ -276,7 +277,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     __syncthreads();
     for (int c = 0; c < nchunk; c++) {
         if (c + 1 < nchunk) stage_load(c + 1);                  // in flight while this chunk computes
-        const Cx<R> *xs = has ? lds + (c & 1) * bufsz + (slot * a.nmodes + kin) * rowsz + t0 : zero_row;
+        const Cx<R> *xs = has ? lds + (slot * a.nmodes + kin) * rowsz + t0 : zero_row;
         const int xstep = has ? os_ : 0;
         const int ibase = c * SG_CH;
         const int nst = (max_steps - ibase) < SG_CH ? (max_steps - ibase) : SG_CH;
@@ -290,7 +291,8 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         case 2: run(SgInt<(TPL > 2 ? 2 : 0)>{}); break;
         default: run(SgInt<(TPL > 3 ? 3 : 0)>{}); break;
         }
-        if (c + 1 < nchunk) stage_store(c + 1);                  // the other buffer: its last readers finished a chunk ago
+        __syncthreads();                                         // (compiler fence: no store of the next chunk above a read of this one)
+        if (c + 1 < nchunk) stage_store(c + 1);                  // same buffer: its readers (this wave) are done with chunk c
         __syncthreads();
     }
     if (alive) {
@@ -427,7 +429,7 @@ template <typename R> int launch_seg(SegArgs<R> a, int method)
     a.rag = a.lpm * tpl - a.ntaps;
     a.pitch = SG_PITCH;
     a.nslots = seg_slots(a.nsel, cpw);
-    const size_t lds = (size_t)(2 * cpw + 1) * SG_PITCH * sizeof(Cx<R>);
+    const size_t lds = (size_t)(cpw + 1) * SG_PITCH * sizeof(Cx<R>);
     dim3 grid((nq + cpw - 1) / cpw);
     const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
     const int rc = (method == QH_M_RDE || method == QH_M_MRDE) ? launch_seg_group_a<R>(a, method, npart, tpl, lpc, grid, lds)

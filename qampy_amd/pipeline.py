@@ -23,7 +23,9 @@ from .core.equalisation import hip_equalisation as _k
 from .core import hip_dsp as _dsp
 
 
-PIT_TOL_INTERMEDIATE = 0.06       # boundary-defect tolerance of tier-b stages that are followed by another training stage
+# Tier b holds EVERY stage to the same tolerance (library default 1e-3, estimated rms deviation of the equaliser output from
+# the sequential recurrence): what a seeding stage leaves in the weakly excited tap directions is handed to the next stage
+# undamped, so a looser first stage would show up one-to-one in the result (round 2 used 0.06 there).
 
 
 class ResidentReceiver:
@@ -91,10 +93,6 @@ class ResidentReceiver:
             self.pit_report = [_k.PitReportBuffer() for _ in methods]
             for s_, o in enumerate(self.pit):          # segment grid from the host copy of mu: the call then never synchronises
                 o.setdefault("acquire", 1 if s_ == 0 else 0)
-                # a stage whose taps only seed the next stage is held to a looser boundary defect than the last one, whose
-                # output IS the result (measured at C3: one pass less in stage 1, final defect / output deviation unchanged)
-                if s_ < len(self.pit) - 1:
-                    o.setdefault("tol", PIT_TOL_INTERMEDIATE)
                 o.setdefault("segments", _k.pit_auto_segments(self.TrSyms[s_], float(self.mu0[s_]), self.modes.size, cold=bool(o["acquire"])))
         _lib.sync()
 

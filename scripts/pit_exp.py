@@ -113,8 +113,18 @@ for seed in [int(s) for s in args.seeds.split(",")]:
                         errors=[r["errors"] for r in ser_ref], rot=[r["rotation"] for r in ser_ref]))
         print(json.dumps(out[-1]), flush=True)
     for v in args.variants.split(","):
+        if v.startswith("g:"):          # g:S1:S2:tol1:tol2[:maxpass]  generic two-stage variant
+            f = v.split(":")
+            mp = int(f[5]) if len(f) > 5 else 0
+            VARIANTS[v] = (dict(segments=int(f[1]), tol=float(f[3]), max_passes=mp), dict(segments=int(f[2]), tol=float(f[4]), max_passes=mp))
+        if v.startswith("t:"):          # t:tol1:tol2[:start[:maxpass]]  automatic grid
+            f = v.split(":")
+            st = int(f[3]) if len(f) > 3 else 0
+            mp = int(f[4]) if len(f) > 4 else 0
+            VARIANTS[v] = (dict(tol=float(f[1]), start=st, max_passes=mp), dict(tol=float(f[2]), start=st, max_passes=mp))
         rx, t, st, ser = run("b", VARIANTS[v])
-        rec = dict(seed=seed, tier="b", variant=v, ms=round(t * 1e3, 2), MSym_s=round(nsym / t / 1e6, 2), stages_ms=st,
+        ptm = [rx.pit_timing[s_] for s_ in range(rx.nstage)]
+        rec = dict(seed=seed, tier="b", variant=v, pass_ms=[[round(x, 3) for x in p_[0]] for p_ in ptm], acq_ms=[round(p_[1], 3) for p_ in ptm], ms=round(t * 1e3, 2), MSym_s=round(nsym / t / 1e6, 2), stages_ms=st,
                    errors=[r["errors"] for r in ser], rot=[r["rotation"] for r in ser], report=rx.pit_reports())
         if ref is not None:
             w, eq = rx.wxy.to_host(), rx.eq.to_host()
@@ -125,6 +135,19 @@ for seed in [int(s) for s in args.seeds.split(",")]:
                 g = 1j ** int(np.rint(np.angle(c) / (np.pi / 2)))
                 dev_t.append(float(np.linalg.norm(w_ref[m] - g * w[m]) / np.linalg.norm(w_ref[m])))
                 dev_o.append(float(np.sqrt(np.mean(np.abs(eq_ref[m] - g * eq[m]) ** 2))))
+            # error traces against the exact path's (same start taps -> same trajectory up to the tolerance): rms over the sweep and
+            # the worst of 256 blocks, per stage and mode
+            err_dev = []
+            for e_b, e_a in zip((x.to_host() for x in rx.err), e_ref):
+                row = []
+                for m in range(e_b.shape[0]):
+                    c = np.vdot(e_b[m], e_a[m]); g = 1j ** int(np.rint(np.angle(c) / (np.pi / 2)))
+                    d2 = np.abs(e_a[m] - g * e_b[m]) ** 2
+                    nb_ = d2.size // 256
+                    blk = np.sqrt(d2[:nb_ * 256].reshape(256, nb_).mean(axis=1))
+                    row.append((float(np.sqrt(d2.mean())), float(blk.max()), float(blk[-1])))
+                err_dev.append(row)
+            rec["err_dev_rms_worstblock_lastblock"] = err_dev
             n8 = rx.err[0].shape[1] // 8
             rec.update(tap_dev_rel=dev_t, eq_rms_dev=dev_o,
                        err_pow_by_eighth=[[[round(float(np.mean(np.abs(e[m, i * n8:(i + 1) * n8]) ** 2)), 5) for i in range(8)] for m in range(2)]
@@ -132,8 +155,8 @@ for seed in [int(s) for s in args.seeds.split(",")]:
                        err_pow_exact=[[[round(float(np.mean(np.abs(e[m, i * n8:(i + 1) * n8]) ** 2)), 5) for i in range(8)] for m in range(2)] for e in e_ref])
         out.append(rec)
         print(json.dumps(rec), flush=True)
-        print("##", v, seed, rec["ms"], st, rec["errors"], [(r["segments"], r["passes"], [round(x, 4) for x in r["defect"]], [round(x, 4) for x in r["result_change"]], r["acquisition"]["steps"]) for r in rec["report"]],
-              [round(x, 5) for x in rec.get("eq_rms_dev", [])], flush=True)
+        print("##", v, seed, rec["ms"], st, rec["errors"], [(r["segments"], r["passes"], [round(x, 4) for x in r["defect"]], [round(x, 5) for x in r["deviation_rms"]], [round(x, 5) for x in r["deviation_taps"]]) for r in rec["report"]], [[tuple(round(v, 5) for v in t) for t in row] for row in rec.get("err_dev_rms_worstblock_lastblock", [])],
+              [round(x, 5) for x in rec.get("eq_rms_dev", [])], [round(x, 5) for x in rec.get("tap_dev_rel", [])], rec["pass_ms"], rec["acq_ms"], flush=True)
         del rx
     del ref
 print(json.dumps(dict(what="exact (tier a) vs parallel-in-time (tier b)", workload=args.workload, nsym=nsym, results=out)))

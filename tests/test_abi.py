@@ -22,8 +22,12 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 39
     for n in names:
         assert hasattr(lib, n), "%s declared in include/qampy_hip.h but not exported" % n
-    # and the ctypes signature table covers the whole header (minus qh_last_error which returns a string)
-    assert set(names) - {"qh_last_error"} == set(_lib.SIGNATURES)
+    # and the ctypes signature table covers the whole header (minus qh_last_error, which returns a string, and qh_abi_version,
+    # which returns the version itself and is checked by the loader)
+    assert set(names) - {"qh_last_error", "qh_abi_version"} == set(_lib.SIGNATURES)
+    # the loader refuses a library built from another version of the header
+    text = open(os.path.join(ROOT, "include", "qampy_hip.h")).read()
+    assert int(re.search(r"#define QH_ABI_VERSION (\d+)", text).group(1)) == _lib.ABI_VERSION == lib.qh_abi_version()
 
 
 def test_method_ids_match_header():

@@ -1,5 +1,6 @@
-"""The N > 1 path of bench.py on CPU: world size 2, gloo, 127.0.0.1 rendezvous.  Covers the per-rank channel assignment,
-the barrier / MAX-time / SUM-counter reductions and the whole-job throughput formula (no data-path collective exists)."""
+"""The N > 1 path of bench.py on CPU: world size 2, 127.0.0.1 rendezvous, qampy_amd.comm's socket backend (the collectives RCCL
+carries on the GPUs).  Covers the per-rank channel assignment, the barrier / MAX-time / SUM-counter reductions, the launcher
+(ours and torch.distributed.run, as the driver starts bench.py) and the whole-job throughput formula (no data-path collective exists)."""
 import os
 import socket
 import subprocess
@@ -28,23 +29,47 @@ def test_channel_assignment_is_independent_per_rank():
 WORKER = textwrap.dedent("""
     import os, sys, json
     sys.path.insert(0, %r)
-    import numpy as np, torch, torch.distributed as dist
+    import numpy as np
     from qampy_amd import sharding
+    from qampy_amd.comm import Comm
     rank, local, world = sharding.rank_info()
-    dist.init_process_group(backend="gloo")
-    dist.barrier()
+    cm = Comm(device=None)                    # no GPU here: socket collectives
+    cm.barrier()
     elapsed = 1.0 + rank                      # rank 1 is the slow one
-    tmax = sharding.reduce_max_time(elapsed, dist)
-    counts = sharding.reduce_sum_counts([[rank + 1, 100], [0, 100]], dist)
-    dist.barrier()
+    tmax = sharding.reduce_max_time(elapsed, cm)
+    counts = sharding.reduce_sum_counts([[rank + 1, 100], [0, 100]], cm)
+    lo = cm.allreduce([float(rank)], "min")
+    cm.barrier()
     if rank == 0:
-        print(json.dumps(dict(tmax=tmax, counts=counts.tolist(), seed=sharding.channel_seed(rank),
+        print(json.dumps(dict(tmax=tmax, counts=counts.tolist(), seed=sharding.channel_seed(rank), backend=cm.backend, lo=lo.tolist(),
                               value=sharding.aggregate_throughput(1000, world, 2, tmax))))
-    dist.destroy_process_group()
+    cm.close()
 """)
 
 
-def test_world_size_two_gloo(tmp_path):
+def _check_worker_output(out):
+    import json
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["tmax"] == 2.0                                  # MAX over ranks
+    assert res["counts"] == [[3.0, 200.0], [0.0, 200.0]]       # SUM over ranks
+    assert res["lo"] == [0.0] and res["backend"] == "tcp"
+    assert res["value"] == 1000 * 2 * 2 / 2.0 / 1e6
+
+
+def test_world_size_two_own_launcher(tmp_path):
+    """Two ranks started by qampy_amd.comm.launch (what `bench.py --gpus 2` does when it is not inside a launcher)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    code = "import sys; sys.path.insert(0, %r); from qampy_amd import comm; sys.exit(comm.launch(%r, [], 2))" % (ROOT, str(script))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    _check_worker_output(out)
+
+
+def test_world_size_two_under_torchrun(tmp_path):
+    """The same two ranks under `python -m torch.distributed.run` - how the driver starts bench.py for N > 1: the ranks only read its
+    environment (its own store keeps MASTER_PORT; ours publishes an ephemeral port in a file keyed by that port and the parent pid)."""
+    pytest.importorskip("torch")
     script = tmp_path / "worker.py"
     script.write_text(WORKER % ROOT)
     with socket.socket() as s:
@@ -52,20 +77,27 @@ def test_world_size_two_gloo(tmp_path):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(script)]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
-    import json
-    res = json.loads(line)
-    assert res["tmax"] == 2.0                                  # MAX over ranks
-    assert res["counts"] == [[3.0, 200.0], [0.0, 200.0]]       # SUM over ranks
-    assert res["value"] == 1000 * 2 * 2 / 2.0 / 1e6
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    _check_worker_output(out)
+
+
+def test_product_tree_does_not_import_torch():
+    """North star: Python host code over a ctypes C-ABI, no PyTorch - neither the package nor bench.py imports it."""
+    import re
+    bad = []
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for d, _, fs in os.walk(os.path.join(ROOT, "qampy_amd")):
+        files += [os.path.join(d, f) for f in fs if f.endswith(".py")]
+    for f in files:
+        for i, line in enumerate(open(f), 1):
+            if re.match(r"\s*(import torch|from torch)", line):
+                bad.append("%s:%d" % (f, i))
+    assert not bad, bad
 
 
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` (no torchrun around it) starts two ranks itself, checks WORLD_SIZE == --gpus and reports
-    ranks_seen from an all-reduce of ones; --dry-run replaces the kernels by a sleep (gloo), so this runs without a GPU."""
+    ranks_seen from an all-reduce of ones; --dry-run replaces the kernels by a sleep (socket collectives), so this runs without a GPU."""
     import json
     env = dict(os.environ, OMP_NUM_THREADS="1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
@@ -73,7 +105,7 @@ def test_bench_launches_its_own_ranks():
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["steps"] == 3 and res["dry_run"] is True
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["steps"] == 3 and res["dry_run"] is True and res["comm_backend"] == "tcp"
     assert res["ser"]["symbols_all"] == 2 * 2 * 2 ** 22            # both ranks' counters were summed
     assert res["value"] == pytest.approx(2 * 2 ** 22 * 3 / (res["ms_per_step"] * 3e-3) / 1e6, rel=1e-3)
     # a launch whose world size contradicts --gpus is refused

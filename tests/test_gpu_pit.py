@@ -4,11 +4,12 @@ Parallel-in-time training (tier b; qh_train_equaliser_*_pit_dev) 
 What is asserted:
   * the relaxation's fixed point IS the sequential recurrence: S passes over S segments reproduce the exact trainer (and
     the oracle) to rounding, for every kernel form that can take the segments;
-  * with the linearised coarse correction the boundary defect falls by an order of magnitude per pass and a tight
+  * with the linearised coarse correction the boundary defect falls several times per pass and a tight
     tolerance reproduces the exact taps / error trace to ~1e-3 in a handful of passes;
-  * at scale (64-QAM, 41 taps, 2^20 symbol periods, CMA -> MRDE + 64-angle BPS) the default settings certify themselves
-    (every stage converged) and are SER-equivalent: symbol errors per mode within +-3 of the exact path AND of the CPU
-    oracle on the same capture;
+  * at scale (64-QAM, 41 taps, 2^20 symbol periods, CMA -> MRDE + 64-angle BPS) the default settings (tol = 1e-3: estimated rms
+    deviation of the output from the sequential recurrence; segment 0 starts from the caller's taps) certify themselves and the
+    MEASURED deviation from the exact cold-start path is inside that tolerance: output, taps and both error traces; symbol errors
+    per mode within +-3 of the exact path AND of the CPU oracle on the same capture;
   * the entry point refuses what it cannot do, and tiny sweeps fall through to the exact path bit for bit.
 """
 import numpy as np
@@ -119,7 +120,7 @@ def test_ser_equivalence_at_scale():
     d = synth.make_capture_dev(M, nsym, nmodes=2, snr_db=30, theta=np.pi / 5.6, dgd=30e-12, linewidth=100., seed=1000)
     kw = dict(methods=("cma", "mrde"), Niter=(1, 1), Mtestangles=64, Nbps=20, alphabet=d["alphabet_host"])
     res = {}
-    for name, tier, pit in (("a", "a", None), ("b", "b", None), ("b_tight", "b", dict(tol=1e-3, max_passes=10))):
+    for name, tier, pit in (("a", "a", None), ("b", "b", None), ("b_loose", "b", dict(tol=1e-2))):
         rx = ResidentReceiver(2, 2 * nsym, 2, M, ntaps, mu, tier=tier, pit=pit, **kw)
         rx.E.copy_from(d["E"])
         rx.run()
@@ -130,22 +131,28 @@ def test_ser_equivalence_at_scale():
         res[name] = r
         del rx
     errs = {k: [s["errors"] for s in v["ser"]] for k, v in res.items()}
-    for k in ("b", "b_tight"):
+    for k in ("b", "b_loose"):
         assert all(st["converged"] for st in res[k]["rep"]), res[k]["rep"]
         assert all(st["segments"] >= 64 for st in res[k]["rep"])
         assert all(abs(a - b) <= 3 for a, b in zip(errs["a"], errs[k])), errs
-    assert all(st["passes"] <= 4 for st in res["b"]["rep"]), res["b"]["rep"]
-    # deviation from the exact path (modulo a common quarter turn per mode): ~0.6 x the last boundary defect, i.e. 2e-3 rms at
-    # the default tolerance (0.01) and an order of magnitude below at 1e-3
+        # the device's certificate: the last pass's estimated rms deviation is below the tolerance it was held to
+        assert all(st["deviation_rms"][-1] < st["tol"] and st["deviation"][-1] < 3 * st["tol"] for st in res[k]["rep"]), res[k]["rep"]
+    assert all(st["passes"] <= 10 for st in res["b"]["rep"]) and all(st["passes"] <= 6 for st in res["b_loose"]["rep"]), (res["b"]["rep"], res["b_loose"]["rep"])
+    assert all(st["tol"] == 1e-3 for st in res["b"]["rep"])
+    # measured deviation from the exact path, which starts from the same taps (modulo a common quarter turn per mode): relative tap
+    # deviation, rms deviation of the equalised signal, rms deviation of the error traces (in units of the signal rms; an error
+    # function multiplies an output deviation by its slope, up to ~2 for cma)
     def dev(r):
         out = []
         for m in range(2):
             g = 1j ** int(np.rint(np.angle(np.vdot(r["wxy"][m].ravel(), res["a"]["wxy"][m].ravel())) / (np.pi / 2)))
+            et = [np.sqrt(np.mean(np.abs(ea[m] - g * eb[m]) ** 2)) for ea, eb in zip(res["a"]["err"], r["err"])]      # absolute: the signal has unit power
             out.append((np.linalg.norm(res["a"]["wxy"][m] - g * r["wxy"][m]) / np.linalg.norm(res["a"]["wxy"][m]),
-                        np.sqrt(np.mean(np.abs(res["a"]["eq"][m] - g * r["eq"][m]) ** 2))))
+                        np.sqrt(np.mean(np.abs(res["a"]["eq"][m] - g * r["eq"][m]) ** 2)), max(et)))
         return np.array(out)
-    d_b, d_t = dev(res["b"]), dev(res["b_tight"])
-    assert d_b[:, 1].max() < 8e-3 and d_t[:, 1].max() < 1e-3 and d_t[:, 0].max() < 2e-2, (d_b.tolist(), d_t.tolist(), [r["rep"] for r in res.values()])
+    d_b, d_l = dev(res["b"]), dev(res["b_loose"])
+    assert d_b[:, 1].max() < 1e-3 and d_b[:, 0].max() < 2e-3 and d_b[:, 2].max() < 3e-3, (d_b.tolist(), [r["rep"] for r in res.values()])
+    assert d_l[:, 1].max() < 1e-2 and d_l[:, 0].max() < 3e-2 and d_l[:, 2].max() < 3e-2, (d_l.tolist(), [r["rep"] for r in res.values()])
     # the CPU oracle (reference-flag build) on the same capture
     E = d["E"].to_host()
     w = core_eq._init_taps(ntaps, 2, 2, np.complex64)
@@ -164,8 +171,8 @@ def test_ser_equivalence_at_scale():
 
 def test_ser_equivalence_with_symbol_errors():
     """24 dB SNR: ~1.2e-3 symbol error rate, where an output deviation of 1 % rms from the sequential result would already cost
-    15 % more errors (the error rate moves with (d/sigma)^2 ~ 10 times the relative change of sigma).  Default tolerances:
-    error counts within 4 standard deviations of the exact path's (the residual difference flips borderline decisions both ways)."""
+    15 % more errors (the error rate moves with (d/sigma)^2 ~ 10 times the relative change of sigma).  Default tolerance (1e-3):
+    error counts within 3 standard deviations of the exact path's (the residual difference flips borderline decisions both ways)."""
     nsym, M, ntaps, mu = 2 ** 21, 64, 41, (2e-4, 2e-4)
     d = synth.make_capture_dev(M, nsym, nmodes=2, snr_db=24, theta=np.pi / 5.6, dgd=30e-12, linewidth=100., seed=1001)
     kw = dict(methods=("cma", "mrde"), Niter=(1, 1), Mtestangles=64, Nbps=20, alphabet=d["alphabet_host"])
@@ -181,7 +188,7 @@ def test_ser_equivalence_with_symbol_errors():
     assert all(st["converged"] for st in reps["b"]), reps["b"]
     assert min(errs["a"]) > 500, errs                                   # the capture does have symbol errors
     for a, b in zip(errs["a"], errs["b"]):
-        assert abs(a - b) <= 4 * np.sqrt(a), (errs, reps["b"])
+        assert abs(a - b) <= 3 * np.sqrt(a), (errs, reps["b"])
 
 
 def test_tier_b_through_the_mirrored_api():

@@ -1,5 +1,6 @@
-"""One capture over two ranks (qampy_amd.distributed.SplitCaptureReceiver) on ONE MI355X: two processes share the GPU, gloo
-carries the all-reduce of the segments' end taps.  scripts/split_check.py compares with the single-process tier-b run of the
+"""One capture over two ranks (qampy_amd.distributed.SplitCaptureReceiver) on ONE MI355X: two processes share the GPU, the socket
+backend of qampy_amd.comm carries the all-reduce of the segments' end taps (RCCL refuses two ranks on one device; its single-rank
+path and its refusal -> fallback are exercised below).  scripts/split_check.py compares with the single-process tier-b run of the
 same capture: identical pass counts and symbol errors, taps and outputs equal (the same kernels train every segment, only on
 different ranks), all ranks end with identical taps."""
 import json
@@ -22,9 +23,9 @@ def _free_port():
 
 def test_split_capture_equals_single_process():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "scripts", "split_check.py"), "--same-gpu", "--backend", "gloo"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    code = "import sys; sys.path.insert(0, %r); from qampy_amd import comm; sys.exit(comm.launch(%r, ['--same-gpu', '--backend', 'tcp'], 2))" % (
+        ROOT, os.path.join(ROOT, "scripts", "split_check.py"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "SPLIT_CHECK_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     rep = json.loads(line)
@@ -32,7 +33,7 @@ def test_split_capture_equals_single_process():
 
 
 def test_bench_split_capture_flag():
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", QAMPY_BENCH_BACKEND="gloo")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", QAMPY_BENCH_BACKEND="tcp")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--split-capture", "--nsym", str(2 ** 20), "--steps", "2", "--warmup", "1"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -40,3 +41,48 @@ def test_bench_split_capture_flag():
     assert rep["n_gpus"] == 2 and rep["ranks_seen"] == 2 and rep["scaling"] == "strong" and rep["config"]["channels"] == 1
     assert "all-reduce" in rep["config"]["parallelism"] and rep["tier_b"]["certified"] is not None
     assert rep["ser"]["errors_rank0"] == [0, 0]
+
+
+def test_rccl_single_rank_and_duplicate_device_fallback():
+    """qampy_amd.comm on the GPU: (1) a one-rank RCCL communicator built through ctypes all-reduces a device buffer on the library
+    stream; (2) two ranks on the SAME device - which RCCL refuses - agree on the socket fallback instead of hanging, and say so."""
+    import textwrap
+    import numpy as np
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    one = textwrap.dedent("""
+        import sys, json, ctypes as C; sys.path.insert(0, %r)
+        import numpy as np
+        from qampy_amd import _lib
+        from qampy_amd.comm import Comm
+        _lib.init(0)
+        cm = Comm(device=0, backend="rccl", env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+        ok, why = cm._init_rccl() if cm._nccl is None else (True, None)      # world 1 skips the collectives: build the communicator explicitly
+        a = _lib.DeviceArray.from_host(np.arange(8, dtype=np.float32))
+        s = C.c_void_p(); _lib.call("qh_stream_handle", C.byref(s))
+        rc = cm._nccl.ncclAllReduce(a.ptr, a.ptr, 8, 7, 0, cm._ncomm, s) if ok else -1
+        _lib.sync()
+        print(json.dumps(dict(ok=bool(ok), why=why, rc=int(rc), vals=a.to_host().tolist())))
+        cm.close()
+    """) % ROOT
+    out = subprocess.run([sys.executable, "-c", one], env=env, capture_output=True, text=True, timeout=300)
+    rep = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep["ok"] and rep["rc"] == 0 and rep["vals"] == list(range(8)), (rep, out.stderr[-1500:])
+    two = textwrap.dedent("""
+        import sys, json; sys.path.insert(0, %r)
+        from qampy_amd import _lib
+        from qampy_amd.comm import Comm
+        _lib.init(0)
+        cm = Comm(device=0, backend="auto")
+        tot = cm.allreduce([1.0])
+        if cm.rank == 0:
+            print(json.dumps(dict(backend=cm.backend, note=cm.note, ranks=tot.tolist())))
+        cm.close()
+    """) % ROOT
+    path = os.path.join(ROOT, "gpurun_out", "_comm_two.py")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    open(path, "w").write(two)
+    code = "import sys; sys.path.insert(0, %r); from qampy_amd import comm; sys.exit(comm.launch(%r, [], 2))" % (ROOT, path)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    rep = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep["ranks"] == [2.0] and rep["backend"] in ("rccl", "tcp"), (rep, out.stderr[-1500:])
+    assert rep["backend"] == "rccl" or "rccl unavailable" in rep["note"]
