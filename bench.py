@@ -797,10 +797,10 @@ def main():
             NL = max(1, int(round(np.sqrt(cfg["M"]))) // 2)
             per_sym, src = 20.0 + 2 * NL, "ISA count of bps_stream_kernel (20 + 2 levels per axis)"
             hit = [v for k, v in (instr or {}).get("kernels", {}).items() if k.startswith("qh::bps_stream_kernel")]
-            if hit and hit[0].get("valu_per_row"):
-                per_sym, src = float(hit[0]["valu_per_row"]), "SQ_INSTS_VALU / distance rows (profiles/pmc_instr_%s.json)" % args.workload
             C_, W = 1024, 2 * cfg["Nbps"]
             rows = -(-nsym // C_) * (-(-(C_ + W - 1) // 16) * 16) * rx.modes.size          # distance rows incl. the 2N-1 halo of every chunk
+            if hit and hit[0].get("SQ_INSTS_VALU"):
+                per_sym, src = float(hit[0]["SQ_INSTS_VALU"]) / rows, "SQ_INSTS_VALU / distance rows (profiles/pmc_instr_%s.json)" % args.workload
             winstr = rows * per_sym
             roofline.update(bound="valu-issue", achieved=round(winstr / (kms * 1e-3) / 1e9, 1), peak=VALU_PEAK_GINSTR, unit="G wave-instr/s",
                             frac=round(winstr / (kms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4), hbm=hbm, valu_instr_per_symbol=round(per_sym, 2), valu_instr_source=src,
@@ -817,8 +817,8 @@ def main():
             ipw, src = float(SEG_INSTR_PER_WAVE_STEP[lpc]), "ISA count of the main loop incl. s_nop / s_waitcnt (DESIGN.md 3.2.2)"
             mid = _lib.METHOD_ID[cfg["methods"][int(kname[5]) - 1]]
             hit = [v for k, v in (instr or {}).get("kernels", {}).items() if k.startswith("qh::train_seg_kernel<float, %d," % mid)]
-            if hit and hit[0].get("valu_per_wave_step"):
-                ipw = float(hit[0]["valu_per_wave_step"])
+            if hit and hit[0].get("SQ_INSTS_VALU") and hit[0].get("SQ_WAVES"):
+                ipw = float(hit[0]["SQ_INSTS_VALU"]) / (float(hit[0]["SQ_WAVES"]) * st["seg_len"])
                 src = "SQ_INSTS_VALU / (SQ_WAVES x steps per chain) of the same kernel sources (profiles/pmc_instr_%s.json)" % args.workload
             winstr = waves * st["seg_len"] * ipw
             roofline.update(bound="valu-issue", achieved=round(winstr / (kms * 1e-3) / 1e9, 1), peak=VALU_PEAK_GINSTR, unit="G wave-instr/s",

@@ -1,17 +1,26 @@
 #!/bin/bash
 # Build libqampy_hip.so for gfx950 (cross-compiles without a GPU).  Usage: qampy_amd/csrc/build.sh [extra hipcc flags]
+# One object per translation unit, rebuilt when its source or any header is newer; $(nproc) compilers at a time.
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
 mkdir -p build
-pids=()
-for f in api train_f32 train_f64 train_seg_a_f32 train_seg_b_f32 train_seg_a_f64 train_seg_b_f64 apply bps ser synth; do
-    if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ train_impl.h -nt build/$f.o ] || [ train_la.h -nt build/$f.o ] || [ train_bi.h -nt build/$f.o ] || [ train_pit.h -nt build/$f.o ] || [ train_seg.h -nt build/$f.o ] || [ ../../include/qampy_hip.h -nt build/$f.o ]; then
-        $HIPCC $FLAGS "$@" -c $f.hip -o build/$f.o &
-        pids+=($!)
-    fi
+UNITS="api train_f32 train_f64 apply bps ser synth"
+for m in mrde cma rde mcma sbd mddma dd cma2; do UNITS="$UNITS train_seg_${m}_f32 train_seg_${m}_f64"; done
+todo=""
+for f in $UNITS; do
+    stale=0
+    [ -f build/$f.o ] || stale=1
+    for dep in $f.hip common.h train_impl.h train_la.h train_bi.h train_pit.h train_seg.h ../../include/qampy_hip.h; do
+        [ $stale = 1 ] || { [ $dep -nt build/$f.o ] && stale=1; } || true
+    done
+    [ $stale = 1 ] && todo="$todo $f"
 done
-for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libqampy_hip.so build/api.o build/train_f32.o build/train_f64.o build/train_seg_a_f32.o build/train_seg_b_f32.o build/train_seg_a_f64.o build/train_seg_b_f64.o build/apply.o build/bps.o build/ser.o build/synth.o
+if [ -n "$todo" ]; then
+    echo $todo | tr ' ' '\n' | xargs -P ${QH_BUILD_JOBS:-$(nproc)} -I{} $HIPCC $FLAGS -c {}.hip -o build/{}.o
+fi
+OBJS=""
+for f in $UNITS; do OBJS="$OBJS build/$f.o"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libqampy_hip.so $OBJS
 echo "built $(cd .. && pwd)/libqampy_hip.so"

@@ -44,20 +44,20 @@ struct PitSeg {                      // segment grid of a sweep: see LaArgs::seg
 // Exclusive scan over the 256 threads of a block (thread order) with an associative op(earlier, later); buf: [512] of T in LDS.
 // (Hillis-Steele on ping-pong buffers, 8 barriers - the scans here used to end in ONE thread walking all 256 partial results,
 // 256 dependent LDS round trips = 10-15 us per call.)
-template <typename T, typename Op> __device__ __forceinline__ T block_scan_excl(T v, Op op, T ident, T *buf)
+template <typename T, typename Op, int NT = 256> __device__ __forceinline__ T block_scan_excl(T v, Op op, T ident, T *buf)      // buf: [2 NT]
 {
     const int t = threadIdx.x;
     int cur = 0;
     buf[t] = v;
     __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        T x = buf[cur * 256 + t];
-        if (t >= o) x = op(buf[cur * 256 + t - o], x);
-        buf[(cur ^ 1) * 256 + t] = x;
+    for (int o = 1; o < NT; o <<= 1) {
+        T x = buf[cur * NT + t];
+        if (t >= o) x = op(buf[cur * NT + t - o], x);
+        buf[(cur ^ 1) * NT + t] = x;
         cur ^= 1;
         __syncthreads();
     }
-    const T r = t > 0 ? buf[cur * 256 + t - 1] : ident;
+    const T r = t > 0 ? buf[cur * NT + t - 1] : ident;
     __syncthreads();
     return r;
 }
@@ -369,9 +369,11 @@ template <typename R> __device__ inline double pit_gain(int method, double Py, C
 constexpr double PIT_DEV_SAFETY = 1.0, PIT_DEV_WORST = 3.0, PIT_DEV_TAPS = 2.0;    // rule: safety x rms estimate < tol, worst segment < 3 tol, taps (relative norm, rms over segments) < 2 tol
 template <typename R>
 __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, const double *pw, int nb, const Cx<R> *Ylast, int n, Cx<R> *wx, PitCtrl *c, float *host_view,
-                                                         int nrow, const float *devmax, int ndev, double safety)
+                                                         int nrow, const float *devmax, int ndev, double safety, const float2 *Ye, float2 *Yprev, int ne, int ncol_e)
 {
     if (c->done) return;
+    if (Yprev)                                                // eigen-space copy of this pass's result, for the next pass's "how far did the result move"
+        for (int e = threadIdx.x; e < ne * nrow; e += 256) { const int k = e / nrow, j = e - k * nrow; Yprev[e] = Ye[(size_t)k * ncol_e + (ncol_e - nrow) + j]; }
     __shared__ double red[256], redd[256], reds[256], redt[256], redw[256];
     double m = 0, dv = 0, ds = 0, dt = 0, wn = 0;
     for (int i = threadIdx.x; i < nb; i += 256) {
@@ -746,6 +748,429 @@ __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A2, const Zf *
     }
 }
 
+// ------------------------------------------------------------------------------------------------ eigen-space analysis (single precision)
+// The analysis of a pass needs the boundary states in the eigenbasis anyway (defect vectors -> scan -> correction).  For complex64
+// everything between the two basis products therefore lives THERE: x~[s] = V^H X[s] (start taps, kept up to date through the passes:
+// x~ <- theta x~ + D~, one product per sweep) and y~[s] = V^H Y[s] (end taps, one product per pass).  Boundary defects, gauge
+// elements, output powers and the deviation estimate are lambda-weighted sums over the 82 components of a column
+// (E[(x^T b) conj(x^T a)] = a~^H Lambda b~) - no probe of the capture, no filtering: the 35 us probe kernel of round 2 becomes a 5 us
+// reduction, and the products themselves are blocked for registers (3 rows x 4 columns per thread, 32 columns per block:
+// 5 LDS reads per 12 complex multiply-adds instead of 5 per 6; 42 -> ~15 us at 7936 columns).
+constexpr int PIT_NC = 32;                 // columns per block of the basis products
+constexpr int PIT_BP = PIT_NC + 2;         // pitch (elements) of the staged B tile: rows 16-byte aligned, staging writes spread over the banks
+inline size_t pit_gemm_lds(int n) { return (size_t)n * (PIT_EIGMAX + PIT_BP) * sizeof(Zf); }
+// MODE 0 (forward): Out[m][col] = sum_f conj(V[f][m]) T[col][f], T = the tap sets (column col = (s, j): row modes[j] of set s); A2 = V.
+// MODE 1 (back + apply): X[col][m] = Y[col][m] = theta_col X[col][m] + sum_k V[m][k] D[k][col]; A2 = V^T.
+template <typename R, int MODE>
+__global__ void __launch_bounds__(256) pit_basis_gemm_kernel(const Zf *A2, const Cx<R> *T, const Zf *D, Zf *Out, int n, int ncol, const PitCtrl *c, PitFuse<R> fz)
+{
+    if (c->done) return;
+    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
+    Zf *As = reinterpret_cast<Zf *>(pit_smem);                // [n][PIT_EIGMAX]: contraction index major, output rows contiguous
+    Zf *Bs = As + (size_t)n * PIT_EIGMAX;                     // [n][PIT_BP]
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;    // columns 4 tx .., rows ty + 32 u
+    const int col0 = blockIdx.x * PIT_NC;
+    const size_t wset = (size_t)fz.nmodes * n;
+    for (int e = threadIdx.x; e < PIT_EIGMAX * n; e += 256) {
+        const int k = e / PIT_EIGMAX, m = e - k * PIT_EIGMAX;
+        Zf v{0.f, 0.f};
+        if (m < n) { v = A2[(size_t)k * n + m]; if (MODE == 0) v.y = -v.y; }
+        As[e] = v;
+    }
+    if (MODE == 0) {
+        for (int e = threadIdx.x; e < n * PIT_NC; e += 256) {      // consecutive threads: consecutive f of one column (coalesced)
+            const int cc = e / n, f = e - cc * n, col = col0 + cc;
+            Zf v{0.f, 0.f};
+            if (col < ncol) {
+                const int s = col / fz.nsel, j = col - s * fz.nsel;
+                const Cx<R> t = T[(size_t)s * wset + (size_t)fz.modes_dev[j] * n + f];
+                v = Zf{(float)t.re, (float)t.im};
+            }
+            Bs[f * PIT_BP + cc] = v;
+        }
+    } else {
+        for (int e = threadIdx.x; e < n * PIT_NC; e += 256) {
+            const int k = e / PIT_NC, cc = e - k * PIT_NC;
+            Bs[k * PIT_BP + cc] = col0 + cc < ncol ? D[(size_t)k * ncol + col0 + cc] : Zf{0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    constexpr int RU = PIT_EIGMAX / 32, CU = PIT_NC / 8;     // 3 rows x 4 columns per thread
+    Zf acc[RU][CU];
+#pragma unroll
+    for (int u = 0; u < RU; u++)
+#pragma unroll
+        for (int v = 0; v < CU; v++) acc[u][v] = Zf{0.f, 0.f};
+#pragma unroll 2
+    for (int k = 0; k < n; k++) {
+        Zf a[RU], b[CU];
+        const float4 b01 = *reinterpret_cast<const float4 *>(Bs + k * PIT_BP + CU * tx);
+        const float4 b23 = *reinterpret_cast<const float4 *>(Bs + k * PIT_BP + CU * tx + 2);
+        b[0] = Zf{b01.x, b01.y}; b[1] = Zf{b01.z, b01.w}; b[2] = Zf{b23.x, b23.y}; b[3] = Zf{b23.z, b23.w};
+#pragma unroll
+        for (int u = 0; u < RU; u++) a[u] = As[k * PIT_EIGMAX + ty + 32 * u];
+#pragma unroll
+        for (int u = 0; u < RU; u++)
+#pragma unroll
+            for (int v = 0; v < CU; v++) {
+                acc[u][v].x = fmaf(a[u].x, b[v].x, fmaf(-a[u].y, b[v].y, acc[u][v].x));
+                acc[u][v].y = fmaf(a[u].x, b[v].y, fmaf(a[u].y, b[v].x, acc[u][v].y));
+            }
+    }
+    if (MODE == 0) {
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            const int m = ty + 32 * u;
+            if (m < n)
+#pragma unroll
+                for (int v = 0; v < CU; v++)
+                    if (col0 + CU * tx + v < ncol) Out[(size_t)m * ncol + col0 + CU * tx + v] = acc[u][v];
+        }
+    } else {                                                  // X[s] = Y[s] = theta_s X[s] + D[.][col]  (Y: the copy the next pass trains in place)
+#pragma unroll
+        for (int v = 0; v < CU; v++) {
+            const int col = col0 + CU * tx + v;
+            if (col >= ncol) continue;
+            const int s = col / fz.nsel, j = col - s * fz.nsel;
+            const size_t base = (size_t)s * wset + (size_t)fz.modes_dev[j] * n;
+            const double qr = fz.theta[2 * (size_t)col], qi = fz.theta[2 * (size_t)col + 1];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const int m = ty + 32 * u;
+                if (m < n) {
+                    const Cx<R> x = fz.X[base + m];
+                    const Cx<R> w{(R)(qr * x.re - qi * x.im + acc[u][v].x), (R)(qr * x.im + qi * x.re + acc[u][v].y)};
+                    fz.X[base + m] = w;
+                    fz.Y[base + m] = w;
+                }
+            }
+        }
+    }
+}
+
+// The same two products on the matrix cores: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: exact single precision at the vector
+// rate, MI355X_MICROARCH.md) - the one place on this path where the work IS a dense GEMM: (n x n) x (n x S nsel), n = nmodes ntaps = 82,
+// thousands of columns.  A block of 3 waves takes 32 columns; wave w owns output rows 32 w .. 32 w + 31 (n padded to 96).  Complex
+// product from three real accumulators: rr += Ar Br, ii += Ai Bi, im += Ar Bi + Ai Br (C = rr - ii + i im): 4 MFMAs per pair of k,
+// fed by two 8-byte LDS reads per lane (operand layout: A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]; C/D:
+// column lane & 31, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).  41 steps x 4 x 64 cycles = 4.4 us of MFMA issue per tile; with
+// staging ~8 us at 7936 columns against ~25 us of the register-blocked VALU form above (which stays as QAMPY_HIP_PIT_GEMM=valu).
+typedef float pit_f16 __attribute__((ext_vector_type(16)));
+inline size_t pit_mfma_lds(int n) { return ((size_t)(n + 2) * PIT_BP + (size_t)PIT_NC * (PIT_EIGMAX + 1)) * sizeof(Zf); }
+template <typename R, int MODE>
+__global__ void __launch_bounds__(192) pit_basis_mfma_kernel(const Zf *__restrict__ A2, const Cx<R> *__restrict__ T, const Zf *__restrict__ D, Zf *__restrict__ Out, int n, int ncol,
+                                                             const PitCtrl *c, PitFuse<R> fz)
+{
+    if (c->done) return;
+    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
+    const int np = (n + 1) & ~1;                              // contraction length padded to whole MFMA steps (zero rows)
+    Zf *Bs = reinterpret_cast<Zf *>(pit_smem);                // [np][PIT_BP]
+    Zf *Ct = Bs + (size_t)(n + 2) * PIT_BP;                   // [PIT_NC][PIT_EIGMAX + 1] (MODE 1: transposition of the result)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col0 = blockIdx.x * PIT_NC;
+    const size_t wset = (size_t)fz.nmodes * n;
+    // op(A) - 54 KB, the same for every block and launch, L2 resident - goes from global memory straight into the A operand
+    // (lane: row 32 wave + (lane & 31), k + (lane >> 5); 8 steps prefetched), the B tile through LDS (shared by the three waves)
+    const int am = 32 * wave + (lane & 31), ak = lane >> 5;
+    const Zf *ag = A2 + (size_t)ak * n + am;
+    auto lda = [&](int k) -> Zf { return (am < n && k + ak < n) ? ag[(size_t)k * n] : Zf{0.f, 0.f}; };
+    constexpr int PF = 8;
+    Zf abuf[PF];
+#pragma unroll
+    for (int i = 0; i < PF; i++) abuf[i] = lda(2 * i);
+    // B tile (no integer divisions in the loops: they cost more than the loads)
+    if (MODE == 0) {
+        // wave w: columns w, w + 3, ...; lanes: f = lane, lane + 64 (one column's taps are contiguous: coalesced); all 11 columns of a
+        // wave in flight together - one round trip to L2 / HBM for the whole tile
+        constexpr int NCB = (PIT_NC + 2) / 3;
+        Zf tmp[NCB][2];
+#pragma unroll
+        for (int q = 0; q < NCB; q++) {
+            const int cc = wave + 3 * q, col = col0 + cc;
+            tmp[q][0] = Zf{0.f, 0.f}; tmp[q][1] = Zf{0.f, 0.f};
+            if (cc < PIT_NC && col < ncol) {
+                const int s = col / fz.nsel, j = col - s * fz.nsel;               // wave-uniform
+                const Cx<R> *src = T + (size_t)s * wset + (size_t)fz.modes_dev[j] * n;
+                if (lane < n) { const Cx<R> t = src[lane]; tmp[q][0] = Zf{(float)t.re, (float)t.im}; }
+                if (lane + 64 < n) { const Cx<R> t = src[lane + 64]; tmp[q][1] = Zf{(float)t.re, (float)t.im}; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NCB; q++) {
+            const int cc = wave + 3 * q;
+            if (cc < PIT_NC) {
+                if (lane < np) Bs[lane * PIT_BP + cc] = tmp[q][0];
+                if (lane + 64 < np) Bs[(lane + 64) * PIT_BP + cc] = tmp[q][1];
+            }
+        }
+    } else {
+        // thread: column tid & 31, rows tid >> 5, + 6, ...: a row of the tile is 256 contiguous bytes; all 16 rows of a thread in flight
+        const int cc = tid & 31, k0 = tid >> 5;
+        const bool okc = col0 + cc < ncol;
+        Zf tmp[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int k = k0 + 6 * q;
+            tmp[q] = (okc && k < n) ? D[(size_t)k * ncol + col0 + cc] : Zf{0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int k = k0 + 6 * q;
+            if (k < np) Bs[k * PIT_BP + cc] = tmp[q];
+        }
+    }
+    // MODE 1: the start taps and frames the epilogue combines with the product are fetched now, under the MFMAs
+    constexpr int NCW = (PIT_NC + 2) / 3;
+    Cx<R> xv[MODE == 1 ? NCW : 1][2];
+    double th[MODE == 1 ? NCW : 1][2];
+    if (MODE == 1) {
+#pragma unroll
+        for (int q = 0; q < NCW; q++) {
+            const int cc = wave + 3 * q, col = col0 + cc;
+            xv[q][0] = Cx<R>{0, 0}; xv[q][1] = Cx<R>{0, 0}; th[q][0] = 1; th[q][1] = 0;
+            if (cc < PIT_NC && col < ncol) {
+                const int s = col / fz.nsel, j = col - s * fz.nsel;
+                const size_t base = (size_t)s * wset + (size_t)fz.modes_dev[j] * n;
+                th[q][0] = fz.theta[2 * (size_t)col]; th[q][1] = fz.theta[2 * (size_t)col + 1];
+                if (lane < n) xv[q][0] = fz.X[base + lane];
+                if (lane + 64 < n) xv[q][1] = fz.X[base + lane + 64];
+            }
+        }
+    }
+    __syncthreads();
+    pit_f16 rr, ii, im;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { rr[q] = 0.f; ii[q] = 0.f; im[q] = 0.f; }
+    const Zf *bp = Bs + (lane >> 5) * PIT_BP + (lane & 31);
+    for (int k0 = 0; k0 < np; k0 += 2 * PF) {
+#pragma unroll
+        for (int i = 0; i < PF; i++) {
+            const int k = k0 + 2 * i;
+            if (k < np) {                                       // block-uniform
+                Zf a = abuf[i];
+                abuf[i] = lda(k + 2 * PF);
+                if (MODE == 0) a.y = -a.y;                      // V^H
+                const Zf b = bp[(size_t)k * PIT_BP];
+                rr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, rr, 0, 0, 0);
+                ii = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, ii, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, im, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, im, 0, 0, 0);
+            }
+        }
+    }
+    const int cl = lane & 31;
+    if (MODE == 0) {
+        const int col = col0 + cl;
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int m = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            if (m < n && col < ncol) Out[(size_t)m * ncol + col] = Zf{rr[q] - ii[q], im[q]};      // 32 consecutive columns per half wave
+        }
+    } else {
+        // X[s] = Y[s] = theta_s X[s] + C[.][col]: through LDS, so that the tap sets are written along m (their fast axis)
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int m = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            Ct[cl * (PIT_EIGMAX + 1) + m] = Zf{rr[q] - ii[q], im[q]};
+        }
+        __syncthreads();
+        // wave: columns wave, wave + 3, ...; lanes along m (the tap sets' fast axis); X and theta of its columns were fetched before the product
+#pragma unroll
+        for (int q = 0; q < NCW; q++) {
+            const int cc = wave + 3 * q, col = col0 + cc;
+            if (cc < PIT_NC && col < ncol) {
+                const int s = col / fz.nsel, j = col - s * fz.nsel;
+                const size_t base = (size_t)s * wset + (size_t)fz.modes_dev[j] * n;
+                const double qr = th[q][0], qi = th[q][1];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int m = lane + 64 * h;
+                    if (m < n) {
+                        const Cx<R> x = xv[q][h];
+                        const Zf d = Ct[cc * (PIT_EIGMAX + 1) + m];
+                        const Cx<R> w{(R)(qr * x.re - qi * x.im + d.x), (R)(qr * x.im + qi * x.re + d.y)};
+                        fz.X[base + m] = w;
+                        fz.Y[base + m] = w;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Boundary b = 1 .. S-1 of mode j (one wave each; entries (b-1) nsel + j): a = x~[b] against b = y~[b-1], lambda-weighted:
+// best group element g (y_B ~ g y_A), defect |b - g a|_Lambda / |b|_Lambda, output power |b|^2_Lambda.  nsel extra rows: how far the
+// sweep's RESULT moved - y~[S-1] of this pass against the previous pass's (pass 0: against the start taps of the last segment).
+static __global__ void __launch_bounds__(256) pit_bound_kernel(const Zf *Xe, const Zf *Ye, const Zf *Yprev, const double *lam, int n, int S, int nsel, int sym,
+                                                              const PitCtrl *c, double *dfc, double *pw, double *gph)
+{
+    if (c->done) return;
+    const int lane = threadIdx.x & 63, bi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nb = (S - 1) * nsel, ncol = S * nsel;
+    if (bi >= nb + nsel) return;
+    const bool result_probe = bi >= nb;
+    const int j = result_probe ? bi - nb : bi % nsel;
+    const int sb = result_probe ? S - 1 : bi / nsel;             // segment whose end taps are `b`
+    const Zf *pa = result_probe ? (c->passes == 0 ? Xe + (size_t)(S - 1) * nsel + j : Yprev + j) : Xe + (size_t)(sb + 1) * nsel + j;
+    const size_t sa = (result_probe && c->passes != 0) ? (size_t)nsel : (size_t)ncol;
+    const Zf *pb = Ye + (size_t)sb * nsel + j;
+    Zf av[(PIT_EIGMAX + 63) / 64], bv[(PIT_EIGMAX + 63) / 64];
+    float lv[(PIT_EIGMAX + 63) / 64];
+    double A = 0, B = 0, Cr = 0, Ci = 0;
+#pragma unroll
+    for (int q = 0; q < (PIT_EIGMAX + 63) / 64; q++) {
+        const int k = lane + 64 * q;
+        av[q] = Zf{0.f, 0.f}; bv[q] = Zf{0.f, 0.f}; lv[q] = 0.f;
+        if (k < n) {
+            av[q] = pa[(size_t)k * sa]; bv[q] = pb[(size_t)k * ncol];
+            const float l = (float)lam[k];
+            lv[q] = l > 0.f ? l : 0.f;
+        }
+        A += (double)lv[q] * ((double)av[q].x * av[q].x + (double)av[q].y * av[q].y);
+        B += (double)lv[q] * ((double)bv[q].x * bv[q].x + (double)bv[q].y * bv[q].y);
+        Cr += (double)lv[q] * ((double)bv[q].x * av[q].x + (double)bv[q].y * av[q].y);      // b conj(a)
+        Ci += (double)lv[q] * ((double)bv[q].y * av[q].x - (double)bv[q].x * av[q].y);
+    }
+    for (int o = 32; o > 0; o >>= 1) { A += __shfl_xor(A, o); B += __shfl_xor(B, o); Cr += __shfl_xor(Cr, o); Ci += __shfl_xor(Ci, o); }
+    double gr = 1, gi = 0;
+    if (sym == 0) {
+        const double pr = sqrt(Cr * Cr + Ci * Ci);
+        if (pr > 0) { gr = Cr / pr; gi = Ci / pr; }
+    } else if (sym == 4 || sym == 2 || sym == 1) {              // nearest of +-1 (, +-i)
+        if (sym == 4 && fabs(Ci) > fabs(Cr)) { gr = 0; gi = Ci >= 0 ? 1 : -1; }
+        else if (sym == 1) gr = 1;
+        else gr = Cr >= 0 ? 1 : -1;
+    } else {
+        const double step = 6.283185307179586 / sym;
+        const double kk = rint(atan2(Ci, Cr) / step) * step;
+        gr = cos(kk); gi = sin(kk);
+    }
+    // the defect from the DIFFERENCES (A + B - 2 Re(conj(g) C) cancels to nothing in single precision once the passes agree)
+    double d2 = 0;
+    const float grf = (float)gr, gif = (float)gi;
+#pragma unroll
+    for (int q = 0; q < (PIT_EIGMAX + 63) / 64; q++) {
+        const float dr = bv[q].x - (grf * av[q].x - gif * av[q].y), di = bv[q].y - (grf * av[q].y + gif * av[q].x);
+        d2 += (double)lv[q] * ((double)dr * dr + (double)di * di);
+    }
+    for (int o = 32; o > 0; o >>= 1) d2 += __shfl_xor(d2, o);
+    if (lane == 0) {
+        if (!result_probe) { gph[2 * (size_t)bi] = gr; gph[2 * (size_t)bi + 1] = gi; pw[bi] = B; }
+        dfc[bi] = (A == A && B == B) ? sqrt(d2 / (B > 1e-300 ? B : 1e-300)) : 1e30;
+    }
+}
+
+// The scan of pit_recur_kernel on defect vectors formed on the fly, d~_k[s] = theta_{s-1} y~_k[s-1] - theta_s x~_k[s] (0 for s = 0), and the
+// eigen-space start taps of the next pass: x~_k[s] <- theta_s x~_k[s] + D~_k[s] (what the back product adds to X, V being unitary).
+constexpr int PIT_RT = 1024;            // threads of the eigen-space scan: up to 4 segments per thread stay in registers (S <= 4096: one round of loads)
+template <typename R>
+__global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf *Ye, Zf *D, const double *theta, const double *lam, int nsel, int S, int64_t T, const R *mu,
+                                                               double beta, const PitCtrl *c)
+{
+    if (c->done) return;
+    __shared__ float4 aff[2 * PIT_RT];
+    const int k = blockIdx.x, j = blockIdx.y;
+    const int ncol = S * nsel;
+    Zf *row = D + (size_t)k * ncol + j, *xr = Xe + (size_t)k * ncol + j;
+    const Zf *yr = Ye + (size_t)k * ncol + j;
+    double a = (double)*mu * c->gain * (double)T * lam[k];
+    if (a < 0) a = 0;
+    const float coef = c->corr_on ? (float)exp(-a * (1 + beta * a)) : 0.f;       // (beta: see pit_recur_kernel)
+    const int len = (S + PIT_RT - 1) / PIT_RT;
+    const int s0 = threadIdx.x * len, s1 = s0 + len < S ? s0 + len : S;
+    auto th = [&](int s) { return Zf{(float)theta[2 * ((size_t)s * nsel + j)], (float)theta[2 * ((size_t)s * nsel + j) + 1]}; };
+    auto scan_op = [](float4 e, float4 l) { return float4{l.x * e.x, l.x * e.y + l.y, l.x * e.z + l.z, 0.f}; };
+    if (len <= 4) {
+        // everything a thread touches is loaded once, together, and stays in registers across the scan
+        Zf y[4], x[4], t[5], r[4];
+        t[0] = s0 > 0 && s0 < S ? th(s0 - 1) : Zf{1.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int s = s0 + q;
+            const bool ok = s < s1;
+            y[q] = (ok && s > 0) ? yr[(size_t)(s - 1) * nsel] : Zf{0.f, 0.f};
+            x[q] = ok ? xr[(size_t)s * nsel] : Zf{0.f, 0.f};
+            t[q + 1] = ok ? th(s) : Zf{1.f, 0.f};
+        }
+        Zf run{0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int s = s0 + q;
+            if (s < s1) {
+                x[q] = cmulf(t[q + 1], x[q]);                   // theta_s x~[s]
+                Zf d{0.f, 0.f};
+                if (s > 0) { const Zf aa = cmulf(t[q], y[q]); d = Zf{aa.x - x[q].x, aa.y - x[q].y}; }
+                run = Zf{d.x + coef * run.x, d.y + coef * run.y};
+                r[q] = run;
+            }
+        }
+        const float clen = powf(coef, (float)len);
+        const float4 comp = block_scan_excl<float4, decltype(scan_op), PIT_RT>(float4{clen, run.x, run.y, 0.f}, scan_op, float4{1.f, 0.f, 0.f, 0.f}, aff);
+        float pw = coef;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int s = s0 + q;
+            if (s < s1) {
+                const Zf v{r[q].x + pw * comp.y, r[q].y + pw * comp.z};
+                row[(size_t)s * nsel] = v;
+                xr[(size_t)s * nsel] = Zf{x[q].x + v.x, x[q].y + v.y};
+                pw *= coef;
+            }
+        }
+        return;
+    }
+    // long sweeps: batches of 4 segments (their loads are issued together), running values through memory
+    Zf run{0.f, 0.f};
+    for (int sb = s0; sb < s1; sb += 4) {
+        Zf y[4], x[4], t[5];
+        t[0] = sb > 0 ? th(sb - 1) : Zf{1.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int s = sb + q;
+            const bool ok = s < s1;
+            y[q] = (ok && s > 0) ? yr[(size_t)(s - 1) * nsel] : Zf{0.f, 0.f};
+            x[q] = ok ? xr[(size_t)s * nsel] : Zf{0.f, 0.f};
+            t[q + 1] = ok ? th(s) : Zf{1.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int s = sb + q;
+            if (s < s1) {
+                Zf d{0.f, 0.f};
+                if (s > 0) { const Zf aa = cmulf(t[q], y[q]), bb = cmulf(t[q + 1], x[q]); d = Zf{aa.x - bb.x, aa.y - bb.y}; }
+                run = Zf{d.x + coef * run.x, d.y + coef * run.y};
+                row[(size_t)s * nsel] = run;
+            }
+        }
+    }
+    const float clen = powf(coef, (float)len);
+    const float4 comp = block_scan_excl<float4, decltype(scan_op), PIT_RT>(float4{clen, run.x, run.y, 0.f}, scan_op, float4{1.f, 0.f, 0.f, 0.f}, aff);
+    const Zf cin{comp.y, comp.z};
+    float pw = coef;
+    for (int sb = s0; sb < s1; sb += 4) {
+        Zf v[4], x[4], t[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int s = sb + q;
+            const bool ok = s < s1;
+            v[q] = ok ? row[(size_t)s * nsel] : Zf{0.f, 0.f};
+            x[q] = ok ? xr[(size_t)s * nsel] : Zf{0.f, 0.f};
+            t[q] = ok ? th(s) : Zf{1.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int s = sb + q;
+            if (s < s1) {
+                v[q].x += pw * cin.x; v[q].y += pw * cin.y;
+                row[(size_t)s * nsel] = v[q];
+                const Zf xx = cmulf(t[q], x[q]);
+                xr[(size_t)s * nsel] = Zf{xx.x + v[q].x, xx.y + v[q].y};
+                pw *= coef;
+            }
+        }
+    }
+}
+
 // In the eigenbasis the linearised segment map is diagonal, J = diag(exp(-mu g T lam_k)), and D[s] = d[s] + J D[s-1] is one
 // first-order recurrence with a constant coefficient per (eigen-direction k, mode j): block (k, j) runs it over the S
 // segments (chunks per thread, then the carries).  Correction off -> coefficient 0 (D = d: plain relaxation).
@@ -840,21 +1265,31 @@ __global__ void __launch_bounds__(256) pit_gauge_kernel(const double *gph, int S
 static __global__ void __launch_bounds__(256) pit_devest_kernel(const Zf *D, const double *lam, int n, int ncol, const PitCtrl *c, float *devmax)
 {
     if (c->done) return;
-    __shared__ float red[256], reds[256], redt[256];
-    const int col = blockIdx.x * 256 + threadIdx.x;
+    // 64 columns per block, 4 threads per column (each a quarter of the k, loads of consecutive columns coalesce and overlap)
+    __shared__ float part[2][4][64], red[64], reds[64], redt[64];
+    const int cl = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
     float acc = 0.f, tap = 0.f;
-    if (col < ncol)
-        for (int k = 0; k < n; k++) {
+    if (col < ncol) {
+#pragma unroll 8
+        for (int k = kg; k < n; k += 4) {
             const Zf v = D[(size_t)k * ncol + col];
             const float l = (float)lam[k], m2 = v.x * v.x + v.y * v.y;
             acc += (l > 0.f ? l : 0.f) * m2;
             tap += m2;                                            // V is unitary: the squared norm of the tap deviation itself
         }
-    red[threadIdx.x] = (acc == acc) ? acc : 3.0e38f;
-    reds[threadIdx.x] = (acc == acc) ? acc : 3.0e38f;
-    redt[threadIdx.x] = (tap == tap) ? tap : 3.0e38f;
+    }
+    part[0][kg][cl] = acc; part[1][kg][cl] = tap;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    if (kg == 0) {
+        acc = (part[0][0][cl] + part[0][1][cl]) + (part[0][2][cl] + part[0][3][cl]);
+        tap = (part[1][0][cl] + part[1][1][cl]) + (part[1][2][cl] + part[1][3][cl]);
+        red[cl] = (acc == acc) ? acc : 3.0e38f;
+        reds[cl] = (acc == acc) ? acc : 3.0e38f;
+        redt[cl] = (tap == tap) ? tap : 3.0e38f;
+    }
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
             red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
             reds[threadIdx.x] += reds[threadIdx.x + s];
@@ -1062,14 +1497,14 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     void *wbuf = nullptr;
     const size_t nsj = (size_t)sg.S * nsel;
     const size_t bytes_w = ((2 * (size_t)sg.S + 1) * wbytes + 63) / 64 * 64;
-    if ((rc = scratch(2, bytes_w + 10 * nsj * sizeof(double) + (size_t)nsel * sizeof(int64_t) + 320 + (size_t)sg.S * 16 + 3 * ((nsj + 255) / 256) * sizeof(float), &wbuf))) return rc;
+    if ((rc = scratch(2, bytes_w + 10 * nsj * sizeof(double) + (size_t)nsel * sizeof(int64_t) + 320 + (size_t)sg.S * 16 + 3 * ((nsj + 63) / 64) * sizeof(float), &wbuf))) return rc;
     Cx<R> *X = (Cx<R> *)wbuf, *Y = X + (size_t)sg.S * wset, *w_start = Y + (size_t)sg.S * wset;
     double *z = (double *)((char *)wbuf + bytes_w), *rot = z + 2 * nsj, *dfc = rot + 2 * nsj, *pw = dfc + nsj, *gph = pw + nsj, *theta = gph + 2 * nsj;
     int64_t *modes_dev = (int64_t *)(theta + 2 * nsj);
     double *uw_phi = (double *)(modes_dev + ((nsel + 7) / 8 * 8));
     int *uw_jump = (int *)(uw_phi + sg.S);
     float *devmax = (float *)(uw_jump + sg.S);                    // per-block maxima of the deviation estimate (ndev of them)
-    const int ndev = (int)((nsj + 255) / 256);                     // (three floats per block: worst column, sum, sum of the tap norms)
+    const int ndev = (int)((nsj + 63) / 64);                     // (three floats per block: worst column, sum, sum of the tap norms)
     QH_HIP(hipMemcpyAsync(modes_dev, modes, (size_t)nsel * sizeof(int64_t), hipMemcpyHostToDevice, g_stream));
     QH_HIP(hipStreamSynchronize(g_stream));                       // `modes` is the caller's memory
 
@@ -1093,19 +1528,31 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     const double *lam = nullptr;
     const Zf *Vb = nullptr;
     Zf *Dz[2] = {nullptr, nullptr};
+    Zf *Xe = nullptr, *Ye = nullptr, *Yprev = nullptr;
     if (want_corr) {
         void *cb = nullptr;
-        if ((rc = scratch(10, pit_basis_bytes(ntot) + 2 * (size_t)ntot * ncol * sizeof(Zf) + 64, &cb))) return rc;
+        if ((rc = scratch(10, pit_basis_bytes(ntot) + 4 * (size_t)ntot * ncol * sizeof(Zf) + (size_t)ntot * nsel * sizeof(Zf) + 256, &cb))) return rc;
         void *basis = o.basis ? o.basis : cb;
         if (!o.basis && (rc = pit_basis<R>(E, nmodes, L, os, ntaps, TrSyms, basis))) return rc;
         lam = (const double *)basis; Vb = (const Zf *)((const char *)basis + (size_t)ntot * sizeof(double));
         Dz[0] = (Zf *)((char *)cb + (pit_basis_bytes(ntot) + 63) / 64 * 64); Dz[1] = Dz[0] + (size_t)ntot * ncol;
+        Xe = Dz[1] + (size_t)ntot * ncol; Ye = Xe + (size_t)ntot * ncol; Yprev = Ye + (size_t)ntot * ncol;
     }
+    // complex64: the analysis of a pass runs in the eigenbasis (pit_basis_gemm_kernel / pit_bound_kernel / pit_recur_eig_kernel); complex128
+    // keeps the probe-based analysis, whose defect vectors are formed in double precision before they are projected
+    // (QAMPY_HIP_PIT_PROBE=1 forces it for complex64 too: tests compare the two)
+    static int gemm_valu = -1;
+    if (gemm_valu < 0) { const char *e = getenv("QAMPY_HIP_PIT_GEMM"); gemm_valu = (e && e[0] == 'v') ? 1 : 0; }
+    const bool eig = want_corr && sizeof(R) == 4 && !(getenv("QAMPY_HIP_PIT_PROBE") && atoi(getenv("QAMPY_HIP_PIT_PROBE")) != 0);
     const size_t glds = ((size_t)PIT_EIGMAX * PIT_EIGMAX + (size_t)PIT_EIGMAX * PIT_GT) * sizeof(Zf);
     static bool gemm_attr = false;
     if (want_corr && !gemm_attr) {
         QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        QH_HIP(hipFuncSetAttribute((const void *)pit_basis_gemm_kernel<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        QH_HIP(hipFuncSetAttribute((const void *)pit_basis_gemm_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        QH_HIP(hipFuncSetAttribute((const void *)pit_basis_mfma_kernel<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        QH_HIP(hipFuncSetAttribute((const void *)pit_basis_mfma_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                 gemm_attr = true;
     }
 
@@ -1195,7 +1642,14 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             if (p > 0 && want_corr) {
                 // start taps = theta X + V D~ with D[s+1] = d[s+1] + J D[s] from the analysis that closed pass p - 1 (below); with the
                 // correction switched off on the device (corr_on = 0) the scan ran with coefficient 0, D = d: plain relaxation
-                hipLaunchKernelGGL((pit_cgemm_kernel<R, false>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb + (size_t)ntot * ntot, (const Zf *)Dz[1], (Zf *)nullptr, ntot, ncol, (const PitCtrl *)ctrl, fz);
+                if (eig && !gemm_valu)
+                    hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 1>), dim3((ncol + PIT_NC - 1) / PIT_NC), dim3(192), pit_mfma_lds(ntot), g_stream, Vb + (size_t)ntot * ntot,
+                                       (const Cx<R> *)nullptr, (const Zf *)Dz[1], (Zf *)nullptr, ntot, ncol, (const PitCtrl *)ctrl, fz);
+                else if (eig)
+                    hipLaunchKernelGGL((pit_basis_gemm_kernel<R, 1>), dim3((ncol + PIT_NC - 1) / PIT_NC), dim3(256), pit_gemm_lds(ntot), g_stream, Vb + (size_t)ntot * ntot,
+                                       (const Cx<R> *)nullptr, (const Zf *)Dz[1], (Zf *)nullptr, ntot, ncol, (const PitCtrl *)ctrl, fz);
+                else
+                    hipLaunchKernelGGL((pit_cgemm_kernel<R, false>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb + (size_t)ntot * ntot, (const Zf *)Dz[1], (Zf *)nullptr, ntot, ncol, (const PitCtrl *)ctrl, fz);
                 QH_HIP(hipGetLastError());
             } else if (p > 0) {
                 QH_HIP(hipMemcpyAsync(X + wset, Y, (size_t)(sg.S - 1) * wbytes, hipMemcpyDeviceToDevice, g_stream));   // X[s] = end taps of s-1
@@ -1236,12 +1690,36 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             }
             // ---- analysis of the pass: boundary defects -> gauge -> defect vectors in the eigenbasis -> scan (the next correction,
             // and - weighted with the eigenvalues - the estimate of how far this pass is from the sequential recurrence) -> decision
+            const int nbnd = (int)((sg.S - 1) * nsel);
+            if (eig) {
+                if (o.basis && pit_basis_sync().pending) {           // a basis still being built on the other stream
+                    QH_HIP(hipStreamWaitEvent(g_stream, pit_basis_sync().out, 0));
+                    pit_basis_sync().pending = false;
+                }
+                const dim3 ggrid((ncol + PIT_NC - 1) / PIT_NC);
+                auto forward = [&](const Cx<R> *src, Zf *dst) {      // dst = V^H src
+                    if (gemm_valu) hipLaunchKernelGGL((pit_basis_gemm_kernel<R, 0>), ggrid, dim3(256), pit_gemm_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
+                    else hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 0>), ggrid, dim3(192), pit_mfma_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
+                };
+                if (p == 0) forward((const Cx<R> *)X, Xe);           // start taps of the sweep into the eigenbasis (kept up to date from here on)
+                forward((const Cx<R> *)Y, Ye);
+                hipLaunchKernelGGL(pit_bound_kernel, dim3((nbnd + nsel + 3) / 4), dim3(256), 0, g_stream, (const Zf *)Xe, (const Zf *)Ye, (const Zf *)Yprev, lam, ntot, sg.S, nsel, sym,
+                                   (const PitCtrl *)ctrl, dfc, pw, gph);
+                hipLaunchKernelGGL((pit_gauge_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)gph, sg.S, nsel, ctrl, theta, (const double *)pw,
+                                   nbnd, method, (const Cx<R> *)symbols + (size_t)modes[0] * nsy, 1);
+                hipLaunchKernelGGL((pit_recur_eig_kernel<R>), dim3(ntot, nsel), dim3(PIT_RT), 0, g_stream, Xe, (const Zf *)Ye, Dz[1], (const double *)theta, lam, nsel, sg.S, sg.len,
+                                   (const R *)mu_dev, beta, (const PitCtrl *)ctrl);
+                hipLaunchKernelGGL(pit_devest_kernel, dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax);
+                hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, nbnd,
+                                   (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, ctrl, host_view, nsel, (const float *)devmax, ndev, safety,
+                                   (const float2 *)Ye, (float2 *)Yprev, ntot, ncol);
+            } else {
             const size_t dlds = (2 * (size_t)ntot + (size_t)nmodes * os * pit_phase_pitch(ntaps, os, PIT_PROBE)) * sizeof(Cx<R>);
             QH_REQUIRE(dlds <= 60 * 1024, "train_equaliser: boundary probe does not fit the LDS for this filter shape");
             hipLaunchKernelGGL((pit_defect_kernel<R>), dim3(sg.S, nsel), dim3(PIT_PROBE), dlds, g_stream, (const Cx<R> *)E, nmodes, L, os,
                                ntaps, sg, TrSyms, (const int64_t *)modes_dev, (const Cx<R> *)X, (const Cx<R> *)Y, sym, (const PitCtrl *)ctrl, dfc, pw, gph, (const Cx<R> *)wx);
             hipLaunchKernelGGL((pit_gauge_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)gph, sg.S, nsel, ctrl, theta, (const double *)pw,
-                               (int)((sg.S - 1) * nsel), method, (const Cx<R> *)symbols + (size_t)modes[0] * nsy, want_corr ? 1 : 0);
+                               nbnd, method, (const Cx<R> *)symbols + (size_t)modes[0] * nsy, want_corr ? 1 : 0);
             if (want_corr) {
                 if (o.basis && pit_basis_sync().pending) {           // a basis still being built on the other stream
                     QH_HIP(hipStreamWaitEvent(g_stream, pit_basis_sync().out, 0));
@@ -1251,9 +1729,10 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 hipLaunchKernelGGL((pit_recur_kernel<R>), dim3(ntot, nsel), dim3(256), 0, g_stream, Dz[1], lam, nsel, sg.S, sg.len, (const R *)mu_dev, beta, (const PitCtrl *)ctrl);
                 hipLaunchKernelGGL(pit_devest_kernel, dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax);
             }
-            hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, (int)((sg.S - 1) * nsel),
+            hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, nbnd,
                                (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, ctrl, host_view, nsel,
-                               want_corr ? (const float *)devmax : (const float *)nullptr, ndev, safety);
+                               want_corr ? (const float *)devmax : (const float *)nullptr, ndev, safety, (const float2 *)nullptr, (float2 *)nullptr, 0, 0);
+            }
             QH_HIP(hipGetLastError());
             QH_HIP(hipMemcpyAsync(&ev.hview[2 * p], host_view, 2 * sizeof(float), hipMemcpyDeviceToHost, g_stream));
             QH_HIP(hipEventRecord(ev.flag[p], g_stream));
@@ -1265,7 +1744,13 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         if ((rc = enqueue_pass(0))) return rc;
         bool ahead = false;                                       // pass p + 1 already in the stream
         for (int p = 0; p < npass; p++) {
-            const bool expect_last = p > 0 && PIT_CONTRACT * (double)ev.hview[2 * (p - 1) + 1] < tol;
+            // (expected criterion of pass p: the last one times the contraction the last two passes showed; the first guess is PIT_CONTRACT)
+            double contr = PIT_CONTRACT;
+            if (p >= 2 && ev.hview[2 * (p - 2) + 1] > 0) {
+                contr = (double)ev.hview[2 * (p - 1) + 1] / (double)ev.hview[2 * (p - 2) + 1];
+                contr = contr < 0.1 ? 0.1 : (contr > 0.9 ? 0.9 : contr);
+            }
+            const bool expect_last = p > 0 && contr * (double)ev.hview[2 * (p - 1) + 1] < tol;
             ahead = false;
             if (p + 1 < npass && !expect_last && (!split || xchg_async)) { if ((rc = enqueue_pass(p + 1))) return rc; ahead = true; }   // (a host-side exchange cannot be enqueued ahead)
             QH_HIP(hipEventSynchronize(ev.flag[p]));

@@ -90,6 +90,21 @@ __device__ __forceinline__ sg_f2 pk_im_rot(sg_f2 x, sg_f2 b, sg_f2 acc)
 __device__ __forceinline__ sg_d2 pk_re(sg_d2 x, sg_d2 b, sg_d2 acc) { return __builtin_elementwise_fma(sg_d2{x.x, x.x}, b, acc); }
 __device__ __forceinline__ sg_d2 pk_im(sg_d2 x, sg_d2 b, sg_d2 acc) { return __builtin_elementwise_fma(sg_d2{x.y, x.y}, b, acc); }
 __device__ __forceinline__ sg_d2 pk_im_rot(sg_d2 x, sg_d2 b, sg_d2 acc) { return __builtin_elementwise_fma(sg_d2{x.y, x.y}, sg_d2{b.y, -b.x}, acc); }
+// first terms of the accumulators: x.re * (b.re, b.im) / x.im * (b.re, b.im) without a zero to add to
+__device__ __forceinline__ sg_f2 pk_re0(sg_f2 x, sg_f2 b)
+{
+    sg_f2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(x), "v"(b));
+    return d;
+}
+__device__ __forceinline__ sg_f2 pk_im0(sg_f2 x, sg_f2 b)
+{
+    sg_f2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(x), "v"(b));
+    return d;
+}
+__device__ __forceinline__ sg_d2 pk_re0(sg_d2 x, sg_d2 b) { return sg_d2{x.x, x.x} * b; }
+__device__ __forceinline__ sg_d2 pk_im0(sg_d2 x, sg_d2 b) { return sg_d2{x.y, x.y} * b; }
 template <int N> struct SgInt { static constexpr int value = N; };
 
 // sum over the 8 lanes of a half row
@@ -130,6 +145,14 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     constexpr int CPW = 64 / LPC;                               // chains per wave
     constexpr int SG_ROWS = CPW, SG_NSTG = SG_ROWS * SG_PIECES;
     if (a.skip && *a.skip) return;
+    // One wave per SIMD, by construction.  A launch of this kernel has about as many single-wave workgroups as the chip has SIMDs
+    // (992 at C3's mrde stage); with <= 256 VGPRs two of them fit on a SIMD and the dispatcher does pair them up while other SIMDs
+    // of the same CU stay empty - each of the pair then issues every other turn (measured: 783 instead of 553 cycles per step).
+    // A few registers kept alive from here to the end push the allocation past half the file, so that a second wave never fits.
+    constexpr int SG_PADV = (sizeof(R) == 4 && LPC == 8) ? 12 : 0;
+    float padv[SG_PADV > 0 ? SG_PADV : 1];
+#pragma unroll
+    for (int q = 0; q < SG_PADV; q++) asm volatile("v_mov_b32 %0, 0" : "=v"(padv[q]));
     extern __shared__ __attribute__((aligned(16))) char sg_smem[];
     Cx<R> *lds = reinterpret_cast<Cx<R> *>(sg_smem);          // [SG_ROWS][SG_PITCH] + zero row [SG_PITCH]  (ONE buffer: the next chunk waits in registers
                                                               // while this one computes and is stored after it - one wave per workgroup, LDS operations in program order)
@@ -212,62 +235,91 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
             if (u / SG_PIECES < nrow) dst[u * 64 + lane] = stg_r[u];
     };
     Cx<R> *errow = a.err + (size_t)mode * a.err_pitch + a.err_off + my_start;
-    R ebr = 0, ebi = 0;                                        // error of step i waits in lane (i & 15) of the chain for a 16-step store
+    // The error of a step is the same in all lanes of its chain; lane l keeps the error of step l of a group of LPC steps (two
+    // selects per step - the groups are unrolled, so "is this my step" is a loop-invariant lane mask in a scalar register pair, not a
+    // compare per step) and stores it when the group is complete: one coalesced store per chain and group.
+    R ebr = 0, ebi = 0;
     // padding taps: the last lane of an input mode may hold up to SG_MAXRAG of them, in its last slots.  They start as zeros and
     // stay zeros because that lane's update of those slots is multiplied by 0 (tailmask; 1 in every other lane).
     const bool lastlane = has && (l16 - kin * a.lpm) == a.lpm - 1;
     const v2 tailmask = lastlane ? v2{0, 0} : v2{1, 1};
     const int rag = a.rag;
 
-    auto load_x = [&](v2 (&x)[TPL], const Cx<R> *p) {
+    constexpr int WIN = TPL + 2;                                 // samples of a pair of steps at 2 samples per symbol: they share TPL - 2 of them
+    auto load_x = [&](v2 (&x)[WIN], const Cx<R> *p, auto NLOAD) {
 #pragma unroll
-        for (int j = 0; j < TPL; j++) { const Cx<R> v = p[j]; x[j] = v2{v.re, v.im}; }
+        for (int j = 0; j < decltype(NLOAD)::value; j++) { const Cx<R> v = p[j]; x[j] = v2{v.re, v.im}; }
     };
-    auto step = [&](v2 (&x)[TPL], int i, int gstep, auto CHK, auto RG) {
+    // one step on the samples x[OFF .. OFF + TPL); returns the error (unscaled) of the step
+    auto step = [&](auto XO, v2 (&x)[WIN], int gstep, auto CHK, auto RG) -> Cx<R> {
+        constexpr int OFF = decltype(XO)::value;
         // y = sum w x  (no conjugate, pythran_equalisation.py:24-31): two accumulators, combined before the reduction
-        v2 p = {0, 0}, r = {0, 0};
+        // (NCH accumulator chains per product, taps j, j + NCH, ... each: a packed FMA that reads the result of another one needs four
+        // independent instructions in between, or the assembler pads with s_nop - each a lost issue slot of this lone wave)
+        constexpr int NCH = TPL >= 6 ? 3 : (TPL >= 4 ? 2 : 1);
+        v2 pa[NCH], ra[NCH];
 #pragma unroll
-        for (int j = 0; j < TPL; j++) {
-            p = pk_re(x[j], w[j], p);                          // x.re * (w.re, w.im)
-            r = pk_im(x[j], w[j], r);                          // x.im * (w.re, w.im)
+        for (int q = 0; q < NCH; q++) { pa[q] = pk_re0(x[OFF + q], w[q]); ra[q] = pk_im0(x[OFF + q], w[q]); }   // x.re * (w.re, w.im), x.im * (w.re, w.im)
+#pragma unroll
+        for (int j = NCH; j < TPL; j++) {
+            pa[j % NCH] = pk_re(x[OFF + j], w[j], pa[j % NCH]);
+            ra[j % NCH] = pk_im(x[OFF + j], w[j], ra[j % NCH]);
         }
+        v2 p = pa[0], r = ra[0];
+#pragma unroll
+        for (int q = 1; q < NCH; q++) { p += pa[q]; r += ra[q]; }
         R yr = p.x - r.y, yi = p.y + r.x;
         chain_csum<LPC>(yr, yi);
         const Cx<R> y{yr, yi};
         const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K);
         Cx<R> cc = la_errfn<R, METHOD, NPART, true>(y, K);     // mu * e with mu folded in
         if (decltype(CHK)::value && gstep >= my_steps) cc = Cx<R>{0, 0};   // past the end of this chain's segment: nothing moves
-        const bool mine = l16 == (i & (LPC - 1));
-        ebr = mine ? e.re : ebr;
-        ebi = mine ? e.im : ebi;
         // w += c conj(x):  (re, im) += x.re (c.re, c.im) + x.im (c.im, -c.re)
         const v2 c1 = {cc.re, cc.im};
         constexpr int NR = decltype(RG)::value;
         v2 ct = c1;
         if (NR > 0) ct = c1 * tailmask;
 #pragma unroll
-        for (int j = 0; j < TPL; j++) w[j] = pk_re(x[j], j >= TPL - NR ? ct : c1, w[j]);        // two rounds: no instruction waits
+        for (int j = 0; j < TPL; j++) w[j] = pk_re(x[OFF + j], j >= TPL - NR ? ct : c1, w[j]);        // two rounds: no instruction waits
 #pragma unroll
-        for (int j = 0; j < TPL; j++) w[j] = pk_im_rot(x[j], j >= TPL - NR ? ct : c1, w[j]);    // for the one right before it
+        for (int j = 0; j < TPL; j++) w[j] = pk_im_rot(x[OFF + j], j >= TPL - NR ? ct : c1, w[j]);    // for the one right before it
+        return e;
     };
-    auto run_chunk = [&](const Cx<R> *xs, int xstep, int ibase, int nst, auto CHK, auto RG) {
-        v2 xa[TPL], xb[TPL];
-        load_x(xa, xs);
+    auto keep = [&](Cx<R> e, int u) { const bool mine = l16 == u; ebr = mine ? e.re : ebr; ebi = mine ? e.im : ebi; };
+    auto run_chunk = [&](const Cx<R> *xs, int xstep, int ibase, int nst, auto CHK, auto RG, auto OS2) {
+        constexpr bool os2 = decltype(OS2)::value != 0;
+        v2 xa[WIN], xb[WIN];
         int i = 0;
-        for (; i + 2 <= nst; i += 2) {                          // the samples of step i+1 are read while step i computes
-            load_x(xb, xs + (i + 1) * xstep);
-            step(xa, i, ibase + i, CHK, RG);
-            load_x(xa, xs + (i + 2) * xstep);                   // may look one step past the chunk: inside the row's slack
-            step(xb, i + 1, ibase + i + 1, CHK, RG);
-            if (((i + 1) & (LPC - 1)) == LPC - 1) {             // LPC errors per chain staged: one store per chain
-                const int gi = ibase + i + 1 - (LPC - 1) + l16;
+        // ---- whole groups of LPC steps
+        if (os2) {
+            // 2 samples per symbol: steps i and i + 1 read x[2 i .. 2 i + TPL + 2) - ONE window of TPL + 2 samples serves both (13 LDS
+            // words instead of 22 at 11 taps per lane); the window of the next pair is read while this one computes
+            load_x(xa, xs, SgInt<WIN>{});
+            for (; i + LPC <= nst; i += LPC) {
+#pragma unroll
+                for (int u = 0; u < LPC; u += 4) {
+                    load_x(xb, xs + (i + u + 2) * xstep, SgInt<WIN>{});
+                    keep(step(SgInt<0>{}, xa, ibase + i + u, CHK, RG), u);
+                    keep(step(SgInt<2>{}, xa, ibase + i + u + 1, CHK, RG), u + 1);
+                    load_x(xa, xs + (i + u + 4) * xstep, SgInt<WIN>{});       // may look past the chunk: inside the row's slack
+                    keep(step(SgInt<0>{}, xb, ibase + i + u + 2, CHK, RG), u + 2);
+                    keep(step(SgInt<2>{}, xb, ibase + i + u + 3, CHK, RG), u + 3);
+                }
+                const int gi = ibase + i + l16;
                 if (gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
             }
         }
-        if (i < nst) { step(xa, i, ibase + i, CHK, RG); i++; }
-        if ((nst & (LPC - 1)) != 0) {                            // ragged end of the last chunk
-            const int gi = ibase + (nst & ~(LPC - 1)) + l16;
-            if (l16 < (nst & (LPC - 1)) && gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
+        // (other sampling rates, and the ragged end of the last chunk, take the plain loop below)
+        // ---- step by step: LPC errors per chain staged, then one store per chain
+        for (int i0 = i; i0 < nst; i0 += LPC) {
+            const int ng = nst - i0 < LPC ? nst - i0 : LPC;
+#pragma unroll 1
+            for (int u = 0; u < ng; u++) {
+                load_x(xa, xs + (i0 + u) * xstep, SgInt<TPL>{});
+                keep(step(SgInt<0>{}, xa, ibase + i0 + u, CHK, RG), u);
+            }
+            const int gi = ibase + i0 + l16;
+            if (l16 < ng && gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
         }
     };
 
@@ -281,9 +333,12 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         const int xstep = has ? os_ : 0;
         const int ibase = c * SG_CH;
         const int nst = (max_steps - ibase) < SG_CH ? (max_steps - ibase) : SG_CH;
-        auto run = [&](auto RG) {
-            if (ibase + nst <= min_steps) run_chunk(xs, xstep, ibase, nst, SgInt<0>{}, RG);
-            else run_chunk(xs, xstep, ibase, nst, SgInt<1>{}, RG);
+        auto run2 = [&](auto RG, auto OS2) {
+            if (ibase + nst <= min_steps) run_chunk(xs, xstep, ibase, nst, SgInt<0>{}, RG, OS2);
+            else run_chunk(xs, xstep, ibase, nst, SgInt<1>{}, RG, OS2);
+        };
+        auto run = [&](auto RG) {                               // (wave-uniform)
+            if (os_ == 2) run2(RG, SgInt<1>{}); else run2(RG, SgInt<0>{});
         };
         switch (rag) {                                         // wave-uniform: the loops exist once per padding count
         case 0: run(SgInt<0>{}); break;
@@ -300,6 +355,8 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         for (int j = 0; j < TPL; j++)
             if (has && t0 + j < a.ntaps) stg(wrow + kin * a.ntaps + t0 + j, Cx<R>{w[j].x, w[j].y});
     }
+#pragma unroll
+    for (int q = 0; q < SG_PADV; q++) asm volatile("" ::"v"(padv[q]));
 }
 
 #endif  // QH_SEG_KERNELS
@@ -327,7 +384,8 @@ inline bool seg_supported(int method, int nmodes, int ntaps, int os, int64_t nsy
 {
     (void)elem;
     if (seg_tpl(nmodes, ntaps) == 0) return false;
-    if ((SG_CH + 1) * os + ntaps + 8 > SG_PITCH) return false;      // chunk + one step of look-ahead + padding taps fit a row
+    if ((SG_CH + 4) * os + ntaps + 8 > SG_PITCH && os == 2) return false;      // chunk + the look-ahead of the window pairs + padding taps fit a row
+    if ((SG_CH + 2) * os + ntaps + 8 > SG_PITCH) return false;
     if (seg_slots(nsel) * nmodes > 4) return false;
     switch (method) {
     case QH_M_CMA: case QH_M_SGNCMA: case QH_M_CMA2: case QH_M_MCMA: return true;
@@ -388,34 +446,22 @@ template <typename R, int METHOD> static int launch_seg_dd(const SegArgs<R> &a, 
     }
 }
 
-// group A: the partitioned (radius-directed) functions; group B: cma-type and decision-directed ones.  One translation unit each.
-template <typename R> int launch_seg_group_a(const SegArgs<R> &a, int method, int npart, int tpl, int lpc, dim3 grid, size_t lds)
+// one launcher per error function (translation units train_seg_<method>_{f32,f64}.hip instantiate them: the kernels' main loops are
+// unrolled eight or sixteen steps deep in four padding x two end-of-segment variants - build time is spread over many units)
+template <typename R, int METHOD> int launch_seg_m(const SegArgs<R> &a, int npart, int tpl, int lpc, dim3 grid, size_t lds)
 {
-    switch (method) {
-    case QH_M_RDE: return launch_seg_parts<R, QH_M_RDE>(a, npart, tpl, lpc, grid, lds);
-    case QH_M_MRDE: return launch_seg_parts<R, QH_M_MRDE>(a, npart, tpl, lpc, grid, lds);
-    default: return QH_ERR_METHOD;
-    }
-}
-template <typename R> int launch_seg_group_b(const SegArgs<R> &a, int method, int npart, int tpl, int lpc, dim3 grid, size_t lds)
-{
-    switch (method) {
-    case QH_M_CMA: case QH_M_SGNCMA: return launch_seg_tpl<R, QH_M_CMA, 0>(a, tpl, lpc, grid, lds);
-    case QH_M_CMA2: return launch_seg_tpl<R, QH_M_CMA2, 0>(a, tpl, lpc, grid, lds);
-    case QH_M_MCMA: return launch_seg_tpl<R, QH_M_MCMA, 0>(a, tpl, lpc, grid, lds);
-    case QH_M_SBD: return launch_seg_dd<R, QH_M_SBD>(a, npart, tpl, lpc, grid, lds);
-    case QH_M_MDDMA: return launch_seg_dd<R, QH_M_MDDMA>(a, npart, tpl, lpc, grid, lds);
-    case QH_M_DD: return launch_seg_dd<R, QH_M_DD>(a, npart, tpl, lpc, grid, lds);
-    default: return QH_ERR_METHOD;
-    }
+    if constexpr (METHOD == QH_M_RDE || METHOD == QH_M_MRDE) return launch_seg_parts<R, METHOD>(a, npart, tpl, lpc, grid, lds);
+    else if constexpr (METHOD == QH_M_SBD || METHOD == QH_M_MDDMA || METHOD == QH_M_DD) return launch_seg_dd<R, METHOD>(a, npart, tpl, lpc, grid, lds);
+    else return launch_seg_tpl<R, METHOD, 0>(a, tpl, lpc, grid, lds);
 }
 #else
-template <typename R> int launch_seg_group_a(const SegArgs<R> &a, int method, int npart, int tpl, int lpc, dim3 grid, size_t lds);
-template <typename R> int launch_seg_group_b(const SegArgs<R> &a, int method, int npart, int tpl, int lpc, dim3 grid, size_t lds);
-extern template int launch_seg_group_a<float>(const SegArgs<float> &, int, int, int, int, dim3, size_t);
-extern template int launch_seg_group_a<double>(const SegArgs<double> &, int, int, int, int, dim3, size_t);
-extern template int launch_seg_group_b<float>(const SegArgs<float> &, int, int, int, int, dim3, size_t);
-extern template int launch_seg_group_b<double>(const SegArgs<double> &, int, int, int, int, dim3, size_t);
+template <typename R, int METHOD> int launch_seg_m(const SegArgs<R> &a, int npart, int tpl, int lpc, dim3 grid, size_t lds);
+#define QH_SEG_EXTERN(M) \
+    extern template int launch_seg_m<float, M>(const SegArgs<float> &, int, int, int, dim3, size_t); \
+    extern template int launch_seg_m<double, M>(const SegArgs<double> &, int, int, int, dim3, size_t);
+QH_SEG_EXTERN(QH_M_CMA) QH_SEG_EXTERN(QH_M_CMA2) QH_SEG_EXTERN(QH_M_MCMA) QH_SEG_EXTERN(QH_M_RDE) QH_SEG_EXTERN(QH_M_MRDE)
+QH_SEG_EXTERN(QH_M_SBD) QH_SEG_EXTERN(QH_M_MDDMA) QH_SEG_EXTERN(QH_M_DD)
+#undef QH_SEG_EXTERN
 #endif  // QH_SEG_KERNELS
 
 // `a` complete except lpm / pitch / rag; method-specific table layout as for launch_bi (slicer tables for sbd / mddma / dd)
@@ -432,8 +478,18 @@ template <typename R> int launch_seg(SegArgs<R> a, int method)
     const size_t lds = (size_t)(cpw + 1) * SG_PITCH * sizeof(Cx<R>);
     dim3 grid((nq + cpw - 1) / cpw);
     const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
-    const int rc = (method == QH_M_RDE || method == QH_M_MRDE) ? launch_seg_group_a<R>(a, method, npart, tpl, lpc, grid, lds)
-                                                                : launch_seg_group_b<R>(a, method, npart, tpl, lpc, grid, lds);
+    int rc;
+    switch (method) {
+    case QH_M_CMA: case QH_M_SGNCMA: rc = launch_seg_m<R, QH_M_CMA>(a, npart, tpl, lpc, grid, lds); break;
+    case QH_M_CMA2: rc = launch_seg_m<R, QH_M_CMA2>(a, npart, tpl, lpc, grid, lds); break;
+    case QH_M_MCMA: rc = launch_seg_m<R, QH_M_MCMA>(a, npart, tpl, lpc, grid, lds); break;
+    case QH_M_RDE: rc = launch_seg_m<R, QH_M_RDE>(a, npart, tpl, lpc, grid, lds); break;
+    case QH_M_MRDE: rc = launch_seg_m<R, QH_M_MRDE>(a, npart, tpl, lpc, grid, lds); break;
+    case QH_M_SBD: rc = launch_seg_m<R, QH_M_SBD>(a, npart, tpl, lpc, grid, lds); break;
+    case QH_M_MDDMA: rc = launch_seg_m<R, QH_M_MDDMA>(a, npart, tpl, lpc, grid, lds); break;
+    case QH_M_DD: rc = launch_seg_m<R, QH_M_DD>(a, npart, tpl, lpc, grid, lds); break;
+    default: rc = QH_ERR_METHOD;
+    }
     if (rc) return rc;
     QH_HIP(hipGetLastError());
     return QH_OK;

@@ -1,17 +1,13 @@
 #!/bin/bash
-# copy the round's profile set from gpurun_out/prof_r (scripts/gpu_profiles.sh + a final `bench.py` run) into profiles/
+# copy the round's evidence set from gpurun_out/r03 (scripts/gpu_round3.sh) into profiles/
 set -e
-R=gpurun_out/prof_r
+R=gpurun_out/r03
 cp $R/pmc_traffic_c3.json profiles/pmc_traffic_c3.json
-cp $R/c3_kernel_stats.txt profiles/r02_c3_kernel_stats.txt
-cp $R/c3_timeline.txt profiles/r02_c3_timeline.txt
-cp $R/pmc_summary.txt profiles/r02_pmc_counters_c3.txt
-tail -1 $R/bench_c3_final.json > profiles/r02_bench_c3.json
-for w in ns c2 c5; do tail -1 $R/bench_$w.json > profiles/r02_bench_$w.json; done
-python - <<'PY'
-import json, sys
-sys.path.insert(0, '.')
-import bench
-d = json.load(open('profiles/r02_bench_c3.json'))
-print("c3", d["value"], d["ms_per_step"], "traffic", d["roofline"]["traffic"], "sha", json.load(open('profiles/pmc_traffic_c3.json'))["kernel_sources_sha"], bench.kernel_sources_sha())
-PY
+cp $R/pmc_instr_c3.json profiles/pmc_instr_c3.json
+cp $R/c3_kernel_stats.txt profiles/r03_c3_kernel_stats.txt
+cp $R/c3_timeline.txt profiles/r03_c3_timeline.txt
+cp $R/pmc_summary.txt profiles/r03_pmc_counters_c3.txt
+cp $R/pmc_valu_summary.txt profiles/r03_pmc_instr_c3.txt
+grep "^{" $R/bench_c3.json | tail -1 > profiles/r03_bench_c3.json
+grep "^{" $R/bench_c5.json | tail -1 > profiles/r03_bench_c5.json
+python scripts/show_bench.py profiles/r03_bench_c3.json

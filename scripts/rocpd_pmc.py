@@ -5,14 +5,24 @@ import sqlite3
 import sys
 
 args = sys.argv[1:]
-json_out = workload = None
+json_out = workload = instr_out = None
+if "--instr-json" in args:                 # --instr-json OUT.json WORKLOAD: per-launch instruction counters for bench.py's roofline
+    i = args.index("--instr-json")
+    instr_out, workload = args[i + 1], args[i + 2]
+    del args[i:i + 3]
 if "--json" in args:                       # --json OUT.json WORKLOAD: per-launch HBM bytes for bench.py's roofline.traffic
     i = args.index("--json")
     json_out, workload = args[i + 1], args[i + 2]
     del args[i:i + 3]
 rows = {}
+launches = {}
 for path in args:
     db = sqlite3.connect(path)
+    try:
+        for name, n in db.execute("select name, count(*) from kernels group by name"):
+            launches[name] = n                 # dispatches of the profiled command (the same command in every pass)
+    except Exception:
+        pass
     try:
         cur = db.execute("select name, counter_name, count(*), avg(counter_value), sum(counter_value) from pmc_events "
                          "group by name, counter_name")
@@ -48,3 +58,22 @@ if json_out:
             h.update(open(os.path.join(d, f), "rb").read())
     # kernel_sources_sha: bench.py only quotes these numbers while the kernel sources are the ones that were profiled
     json.dump(dict(workload=workload, note=note, kernel_sources_sha=h.hexdigest()[:16], kernels=kern), open(json_out, "w"), indent=1)
+
+if instr_out:
+    import os, hashlib
+    kern = {}
+    for (name, ctr), (n, avg, tot) in rows.items():
+        short = name[5:] if name.startswith("void ") else name
+        short = short.split("(")[0]
+        nl = launches.get(name, 0)
+        if nl:
+            kern.setdefault(short, dict(launches=nl))[ctr] = round(tot / nl, 1)      # per launch: summed over the counter instances (XCDs / SEs)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    d = os.path.join(root, "qampy_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    note = ("rocprofv3 --kernel-trace --pmc <counters> in separate passes (scripts/gpu_pmc_valu.sh): per-launch totals over all counter "
+            "instances; SQ_INSTS_VALU / SQ_WAVES / steps per chain = vector instructions per wave and step of train_seg_kernel")
+    json.dump(dict(workload=workload, note=note, kernel_sources_sha=h.hexdigest()[:16], kernels=kern), open(instr_out, "w"), indent=1)

@@ -65,11 +65,14 @@ def test_relaxation_fixed_point_is_the_sequential_recurrence(method, M, form, mo
     assert rep["defect"][-1] < 1e-4 and rep["defect"][-1] <= rep["defect"][0]
 
 
+@pytest.mark.parametrize("analysis", ["eigen", "probe"])
 @pytest.mark.parametrize("lanes", ["16", "8"])
 @pytest.mark.parametrize("method,M", [("mcma", 16), ("cma", 64), ("mrde", 64)])
-def test_coarse_correction_converges_to_the_exact_trajectory(method, M, lanes, monkeypatch):
+def test_coarse_correction_converges_to_the_exact_trajectory(method, M, lanes, analysis, monkeypatch):
     monkeypatch.setenv("QAMPY_HIP_PIT_FORM", "segment")
     monkeypatch.setenv("QAMPY_HIP_SEG_LANES", lanes)
+    # analysis of a pass: in the eigenbasis of the input covariance (complex64 default) or with the round-2 probe of the capture
+    monkeypatch.setenv("QAMPY_HIP_PIT_PROBE", "1" if analysis == "probe" else "0")
     """16 segments, tight tolerance: the defect falls fast with the correction and the result agrees with the exact
     trainer far below the gradient noise; plain relaxation needs (many) more passes for the same defect."""
     sig, E, tr, w0, sy, rt = _setup(method, M, nsym=2 ** 16, ntaps=21)
