@@ -243,7 +243,9 @@ int qh_set_trainer(int form);
  *     eigenbasis of the input covariance - the same scan that forms the next correction; the rule takes its rms over all segments
  *     and modes (times dev_safety, default 1: measured against the exact path the estimate is within a factor 1.5 of the rms
  *     deviation of the error trace) and additionally holds the worst segment below 3 tol and the estimated relative deviation of
- *     the taps themselves (unweighted norm of the same vectors: the weakly excited directions count fully) below 2 tol.
+ *     the taps themselves (unweighted norm of the same vectors, rms over the segments: the weakly excited directions count fully)
+ *     below 2 tol.  Measured against the exact path the FINAL taps sit at the worst-segment value of that estimate (deviation_taps_worst,
+ *     up to 1.6 x the rms: deviations of the weakly excited directions accumulate along the sweep), i.e. within 3 tol.
  *     Without the correction (more than 96 taps per output mode, or switched off) the round-2 rule applies: largest boundary
  *     defect x a segment-length factor below tol.
  *   phase_seed: for the phase-sensitive functions (mcma, mrde, sbd, mddma, dd) the pass-0 start taps of segment s are the
@@ -262,7 +264,7 @@ int qh_set_trainer(int form);
 #define QH_PIT_MAXCHUNK 32
 typedef struct qh_pit_opts {
     int32_t segments;       /* 0 = automatic: segments of about 0.2 / mu (warm) or 0.4 / mu (cold start) steps, qh_pit_auto_segments */
-    int32_t max_passes;     /* 0 = 12 (at most QH_PIT_MAXPASS) */
+    int32_t max_passes;     /* 0 = 16 (at most QH_PIT_MAXPASS) */
     int32_t acquire;        /* 0 warm start, 1 cold start: gear-shifted sequential acquisition first */
     int32_t phase_seed;     /* -1 by method, 0 off, 1 on */
     double tol;             /* 0 = 1e-3: accepted estimated rms deviation of the equaliser output from the sequential recurrence, relative to the
@@ -307,6 +309,7 @@ typedef struct qh_pit_report {
                                             segment, without the safety factor); -1 = not available (no coarse correction) */
     double deviation_rms[QH_PIT_MAXPASS]; /* the same estimate as an rms over all segments and modes */
     double deviation_taps[QH_PIT_MAXPASS]; /* estimated deviation of the TAPS from the sequential recurrence's: |D[s]| / |w|, rms over segments and modes */
+    double deviation_taps_worst[QH_PIT_MAXPASS]; /* ... of the worst segment */
 } qh_pit_report;
 int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold, int *segments);   /* cold: the sweep starts from unconverged taps (acquire) */
 /* Eigenbasis of the input covariance <conj(x) x^T> of the training windows of a capture, for the coarse correction: depends

@@ -122,7 +122,8 @@ class PitReport(C.Structure):
                 ("gain", C.c_double), ("out_power", C.c_double),
                 ("acq_done", C.c_int32), ("done", C.c_int32), ("diverged", C.c_int32), ("corr_on", C.c_int32),
                 ("result_change", C.c_double * PIT_MAXPASS), ("deviation", C.c_double * PIT_MAXPASS),
-                ("deviation_rms", C.c_double * PIT_MAXPASS), ("deviation_taps", C.c_double * PIT_MAXPASS)]
+                ("deviation_rms", C.c_double * PIT_MAXPASS), ("deviation_taps", C.c_double * PIT_MAXPASS),
+                ("deviation_taps_worst", C.c_double * PIT_MAXPASS)]
 
     def as_dict(self):
         return dict(segments=int(self.segments), seg_len=int(self.seg_len), passes=int(self.passes), converged=bool(self.converged),
@@ -133,7 +134,8 @@ class PitReport(C.Structure):
                     correction=bool(self.corr_on), result_change=[float(d) for d in self.result_change if d >= 0],
                     deviation=[float(d) for d, q in zip(self.deviation, self.defect) if q >= 0],
                     deviation_rms=[float(d) for d, q in zip(self.deviation_rms, self.defect) if q >= 0],
-                    deviation_taps=[float(d) for d, q in zip(self.deviation_taps, self.defect) if q >= 0])
+                    deviation_taps=[float(d) for d, q in zip(self.deviation_taps, self.defect) if q >= 0],
+                    deviation_taps_worst=[float(d) for d, q in zip(self.deviation_taps_worst, self.defect) if q >= 0])
 
 
 _lib = None

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) pit_setup_kernel(const Cx<R> *E, int nmod
         if (ma > cap) ma = cap;
         if (!(ma > m)) ma = m;
         c->segments = sg.S; c->seg_len = sg.len; c->mu = m; c->mu_acq = ma; c->power = p; c->tol = tol;
-        for (int q = 0; q < QH_PIT_MAXPASS; q++) { c->result_change[q] = -1; c->deviation[q] = -1; c->deviation_rms[q] = -1; c->deviation_taps[q] = -1; } c->passes = 0; c->converged = 0; c->acq_chunks = 0; c->acq_steps = 0; c->acq_done = 0; c->done = 0; c->diverged = 0; c->corr_on = 0; c->gain = 0; c->out_power = 0;
+        for (int q = 0; q < QH_PIT_MAXPASS; q++) { c->result_change[q] = -1; c->deviation[q] = -1; c->deviation_rms[q] = -1; c->deviation_taps[q] = -1; c->deviation_taps_worst[q] = -1; } c->passes = 0; c->converged = 0; c->acq_chunks = 0; c->acq_steps = 0; c->acq_done = 0; c->done = 0; c->diverged = 0; c->corr_on = 0; c->gain = 0; c->out_power = 0;
         for (int i = 0; i < QH_PIT_MAXPASS; i++) c->defect[i] = -1;
         for (int i = 0; i < QH_PIT_MAXCHUNK; i++) c->acq_err[i] = -1;
         *mu_acq = (R)ma;
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) pit_setup_kernel(const Cx<R> *E, int nmod
 static __global__ void pit_sweep_kernel(PitCtrl *c)
 {
     c->done = 0; c->converged = 0; c->passes = 0;
-    for (int q = 0; q < QH_PIT_MAXPASS; q++) { c->result_change[q] = -1; c->deviation[q] = -1; c->deviation_rms[q] = -1; c->deviation_taps[q] = -1; }
+    for (int q = 0; q < QH_PIT_MAXPASS; q++) { c->result_change[q] = -1; c->deviation[q] = -1; c->deviation_rms[q] = -1; c->deviation_taps[q] = -1; c->deviation_taps_worst[q] = -1; }
     for (int i = 0; i < QH_PIT_MAXPASS; i++) c->defect[i] = -1;
 }
 
@@ -374,21 +374,23 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
     if (c->done) return;
     if (Yprev)                                                // eigen-space copy of this pass's result, for the next pass's "how far did the result move"
         for (int e = threadIdx.x; e < ne * nrow; e += 256) { const int k = e / nrow, j = e - k * nrow; Yprev[e] = Ye[(size_t)k * ncol_e + (ncol_e - nrow) + j]; }
-    __shared__ double red[256], redd[256], reds[256], redt[256], redw[256];
-    double m = 0, dv = 0, ds = 0, dt = 0, wn = 0;
+    __shared__ double red[256], redd[256], reds[256], redt[256], redw[256], redm[256];
+    double m = 0, dv = 0, ds = 0, dt = 0, wn = 0, dm = 0;
     for (int i = threadIdx.x; i < nb; i += 256) {
         const double v = dfc[i];
         m = (v > m || !(v == v)) ? (v == v ? v : 1e30) : m;
     }
     if (devmax)
         for (int i = threadIdx.x; i < ndev; i += 256) {
-            const double v = (double)devmax[3 * i];
+            const double v = (double)devmax[4 * i];
             dv = (v > dv || !(v == v)) ? (v == v ? v : 1e30) : dv;
-            ds += (double)devmax[3 * i + 1];
-            dt += (double)devmax[3 * i + 2];
+            ds += (double)devmax[4 * i + 1];
+            dt += (double)devmax[4 * i + 2];
+            const double vm = (double)devmax[4 * i + 3];
+            dm = (vm > dm || !(vm == vm)) ? (vm == vm ? vm : 1e30) : dm;
         }
     for (int e = threadIdx.x; e < n; e += 256) { const Cx<R> v = Ylast[e]; wn += (double)v.re * v.re + (double)v.im * v.im; }      // |taps|^2 of all output modes
-    red[threadIdx.x] = m; redd[threadIdx.x] = dv; reds[threadIdx.x] = ds; redt[threadIdx.x] = dt; redw[threadIdx.x] = wn;
+    red[threadIdx.x] = m; redd[threadIdx.x] = dv; reds[threadIdx.x] = ds; redt[threadIdx.x] = dt; redw[threadIdx.x] = wn; redm[threadIdx.x] = dm;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) {
@@ -397,6 +399,7 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
             reds[threadIdx.x] += reds[threadIdx.x + s];
             redt[threadIdx.x] += redt[threadIdx.x + s];
             redw[threadIdx.x] += redw[threadIdx.x + s];
+            redm[threadIdx.x] = redm[threadIdx.x] > redm[threadIdx.x + s] ? redm[threadIdx.x] : redm[threadIdx.x + s];
         }
         __syncthreads();
     }
@@ -412,7 +415,8 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
         // taps: rms over segments of |D[s]| / |w|, |w|^2 = the squared tap norm of one output mode (mean over the modes that have taps)
         const double wnorm2 = redw[0] / (double)(nrow > 0 ? nrow : 1);
         const double dev_tap = (have_dev && wnorm2 > 0) ? sqrt(redt[0] / ((double)(nb + nrow) * wnorm2)) : -1.0;
-        if (p < QH_PIT_MAXPASS) { c->defect[p] = red[0]; c->result_change[p] = chg; c->deviation[p] = dev; c->deviation_rms[p] = dev_rms; c->deviation_taps[p] = dev_tap; }
+        const double dev_tap_worst = (have_dev && wnorm2 > 0) ? sqrt(redm[0] / wnorm2) : -1.0;
+        if (p < QH_PIT_MAXPASS) { c->defect[p] = red[0]; c->result_change[p] = chg; c->deviation[p] = dev; c->deviation_rms[p] = dev_rms; c->deviation_taps[p] = dev_tap; c->deviation_taps_worst[p] = dev_tap_worst; }
         c->passes = p + 1;
         // The criterion.  With the coarse correction: `dev`, the first-order estimate of how far this pass's trajectory is from the
         // sequential recurrence (rms of the output, worst segment, relative to the output rms; include/qampy_hip.h "Stop rule"),
@@ -1266,7 +1270,7 @@ static __global__ void __launch_bounds__(256) pit_devest_kernel(const Zf *D, con
 {
     if (c->done) return;
     // 64 columns per block, 4 threads per column (each a quarter of the k, loads of consecutive columns coalesce and overlap)
-    __shared__ float part[2][4][64], red[64], reds[64], redt[64];
+    __shared__ float part[2][4][64], red[64], reds[64], redt[64], redm[64];
     const int cl = threadIdx.x & 63, kg = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + cl;
     float acc = 0.f, tap = 0.f;
@@ -1287,6 +1291,7 @@ static __global__ void __launch_bounds__(256) pit_devest_kernel(const Zf *D, con
         red[cl] = (acc == acc) ? acc : 3.0e38f;
         reds[cl] = (acc == acc) ? acc : 3.0e38f;
         redt[cl] = (tap == tap) ? tap : 3.0e38f;
+        redm[cl] = (tap == tap) ? tap : 3.0e38f;
     }
     __syncthreads();
     for (int s = 32; s > 0; s >>= 1) {
@@ -1294,10 +1299,13 @@ static __global__ void __launch_bounds__(256) pit_devest_kernel(const Zf *D, con
             red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
             reds[threadIdx.x] += reds[threadIdx.x + s];
             redt[threadIdx.x] += redt[threadIdx.x + s];
+            redm[threadIdx.x] = redm[threadIdx.x] > redm[threadIdx.x + s] ? redm[threadIdx.x] : redm[threadIdx.x + s];
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { devmax[3 * blockIdx.x] = red[0]; devmax[3 * blockIdx.x + 1] = reds[0]; devmax[3 * blockIdx.x + 2] = redt[0]; }   // worst column, sums over the columns
+    if (threadIdx.x == 0) {                                       // worst column / sum over the columns of the output power; sum / worst column of the tap norm
+        devmax[4 * blockIdx.x] = red[0]; devmax[4 * blockIdx.x + 1] = reds[0]; devmax[4 * blockIdx.x + 2] = redt[0]; devmax[4 * blockIdx.x + 3] = redm[0];
+    }
 }
 // ------------------------------------------------------------------------------------------------ host side
 // kernel time of the most recent call (HIP events around the trainer launches; the host synchronises after each anyway)
@@ -1405,7 +1413,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     QH_REQUIRE(o.segments >= 0 && o.segments <= PIT_MAXSEG && o.max_passes >= 0 && o.max_passes <= QH_PIT_MAXPASS, "train_equaliser: bad segment / pass count");
     const int ntot = nmodes * ntaps;
     QH_REQUIRE(ntot <= 64 * 16, "train_equaliser: more than 1024 taps per output mode are not supported");
-    const int npass = o.max_passes > 0 ? o.max_passes : 12;
+    const int npass = o.max_passes > 0 ? o.max_passes : 16;
     const double tol = o.tol > 0 ? o.tol : 1e-3;
     const double safety = o.dev_safety > 0 ? o.dev_safety : PIT_DEV_SAFETY;
     const double gear = o.gear > 0 ? o.gear : 8.0;
@@ -1497,7 +1505,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     void *wbuf = nullptr;
     const size_t nsj = (size_t)sg.S * nsel;
     const size_t bytes_w = ((2 * (size_t)sg.S + 1) * wbytes + 63) / 64 * 64;
-    if ((rc = scratch(2, bytes_w + 10 * nsj * sizeof(double) + (size_t)nsel * sizeof(int64_t) + 320 + (size_t)sg.S * 16 + 3 * ((nsj + 63) / 64) * sizeof(float), &wbuf))) return rc;
+    if ((rc = scratch(2, bytes_w + 10 * nsj * sizeof(double) + (size_t)nsel * sizeof(int64_t) + 320 + (size_t)sg.S * 16 + 4 * ((nsj + 63) / 64) * sizeof(float), &wbuf))) return rc;
     Cx<R> *X = (Cx<R> *)wbuf, *Y = X + (size_t)sg.S * wset, *w_start = Y + (size_t)sg.S * wset;
     double *z = (double *)((char *)wbuf + bytes_w), *rot = z + 2 * nsj, *dfc = rot + 2 * nsj, *pw = dfc + nsj, *gph = pw + nsj, *theta = gph + 2 * nsj;
     int64_t *modes_dev = (int64_t *)(theta + 2 * nsj);

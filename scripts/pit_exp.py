@@ -155,7 +155,7 @@ for seed in [int(s) for s in args.seeds.split(",")]:
                        err_pow_exact=[[[round(float(np.mean(np.abs(e[m, i * n8:(i + 1) * n8]) ** 2)), 5) for i in range(8)] for m in range(2)] for e in e_ref])
         out.append(rec)
         print(json.dumps(rec), flush=True)
-        print("##", v, seed, rec["ms"], st, rec["errors"], [(r["segments"], r["passes"], [round(x, 4) for x in r["defect"]], [round(x, 5) for x in r["deviation_rms"]], [round(x, 5) for x in r["deviation_taps"]]) for r in rec["report"]], [[tuple(round(v, 5) for v in t) for t in row] for row in rec.get("err_dev_rms_worstblock_lastblock", [])],
+        print("##", v, seed, rec["ms"], st, rec["errors"], [(r["segments"], r["passes"], [round(x, 4) for x in r["defect"]], [round(x, 5) for x in r["deviation_taps"]], [round(x, 5) for x in r["deviation_taps_worst"]]) for r in rec["report"]], [[tuple(round(v, 5) for v in t) for t in row] for row in rec.get("err_dev_rms_worstblock_lastblock", [])],
               [round(x, 5) for x in rec.get("eq_rms_dev", [])], [round(x, 5) for x in rec.get("tap_dev_rel", [])], rec["pass_ms"], rec["acq_ms"], flush=True)
         del rx
     del ref

@@ -154,7 +154,7 @@ def test_ser_equivalence_at_scale():
                         np.sqrt(np.mean(np.abs(res["a"]["eq"][m] - g * r["eq"][m]) ** 2)), max(et)))
         return np.array(out)
     d_b, d_l = dev(res["b"]), dev(res["b_loose"])
-    assert d_b[:, 1].max() < 1e-3 and d_b[:, 0].max() < 2e-3 and d_b[:, 2].max() < 3e-3, (d_b.tolist(), [r["rep"] for r in res.values()])
+    assert d_b[:, 1].max() < 1e-3 and d_b[:, 0].max() < 3e-3 and d_b[:, 2].max() < 3e-3, (d_b.tolist(), [r["rep"] for r in res.values()])
     assert d_l[:, 1].max() < 1e-2 and d_l[:, 0].max() < 3e-2 and d_l[:, 2].max() < 3e-2, (d_l.tolist(), [r["rep"] for r in res.values()])
     # the CPU oracle (reference-flag build) on the same capture
     E = d["E"].to_host()
