@@ -582,22 +582,27 @@ __global__ void __launch_bounds__(UW_THREADS) unwrap_partial_kernel(const int32_
     }
 }
 
-__global__ void __launch_bounds__(64) unwrap_scan_kernel(int *chunk_sum, int64_t nchunk)
+__global__ void __launch_bounds__(1024) unwrap_scan_kernel(int *chunk_sum, int64_t nchunk)
 {
-    // exclusive scan of the chunk sums of one mode by a single wave (nchunk is a few thousand at most)
+    // exclusive scan of the chunk sums of one mode by one workgroup: a run of consecutive chunks per thread (loaded together), wave
+    // scans of the run totals, the 16 wave totals through LDS.  (A single wave walking the array 64 entries at a time was a chain of
+    // 64 dependent global round trips: 32 us for 4096 chunks.)
+    __shared__ int wtot[16];
     int *cs = chunk_sum + (int64_t)blockIdx.x * nchunk;
-    int carry = 0;
-    for (int64_t b = 0; b < nchunk; b += 64) {
-        const int64_t i = b + threadIdx.x;
-        int v = i < nchunk ? cs[i] : 0;
-        int incl = v;
-        for (int o = 1; o < 64; o <<= 1) {
-            int t = __shfl_up(incl, o);
-            if ((int)threadIdx.x >= o) incl += t;
-        }
-        if (i < nchunk) cs[i] = carry + incl - v;
-        carry += __shfl(incl, 63);
+    const int64_t len = (nchunk + 1023) / 1024;
+    const int64_t i0 = (int64_t)threadIdx.x * len, i1 = i0 + len < nchunk ? i0 + len : nchunk;
+    int tot = 0;
+    for (int64_t i = i0; i < i1; i++) tot += cs[i];
+    int incl = tot;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if ((int)(threadIdx.x & 63) >= o) incl += t;
     }
+    if ((threadIdx.x & 63) == 63) wtot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int run = incl - tot;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) run += wtot[w];
+    for (int64_t i = i0; i < i1; i++) { const int v = cs[i]; cs[i] = run; run += v; }
 }
 
 template <typename R>
@@ -685,7 +690,7 @@ int bps_recover_dev(const void *E, int nm, int64_t L, const void *angles, int A,
     if ((rc = bps_dev<R>(E, L, dang, 1, A, symbols, M, N, idx, nm))) return rc;
     hipLaunchKernelGGL((unwrap_partial_kernel<R>), dim3((unsigned)nchunk, nm), dim3(UW_THREADS), 0, g_stream, idx, L, N, (const R *)dang,
                        (int *)dchunk, nchunk);
-    hipLaunchKernelGGL(unwrap_scan_kernel, dim3(nm), dim3(64), 0, g_stream, (int *)dchunk, nchunk);
+    hipLaunchKernelGGL(unwrap_scan_kernel, dim3(nm), dim3(1024), 0, g_stream, (int *)dchunk, nchunk);
     hipLaunchKernelGGL((unwrap_apply_kernel<R>), dim3((unsigned)nchunk, nm), dim3(UW_THREADS), 0, g_stream, (const Cx<R> *)E, idx,
                        (const int *)dchunk, L, N, (const R *)dang, nchunk, (R *)ph, (Cx<R> *)Eout);
     QH_HIP(hipGetLastError());

@@ -217,10 +217,11 @@ __global__ void __launch_bounds__(256) pit_phase_kernel(const Cx<R> *E, int nmod
 // rot[s, j] = exp(-i phi_s): phi = arg(-z)/4 (E[s^4] is negative real for the QAM alphabets), unwrapped along the segments
 static __global__ void __launch_bounds__(256) pit_unwrap_kernel(const double *z, int S, int nsel, double *rot, double *phi, int *jump)
 {
-    // phi[S], jump[S]: work arrays in device memory (one block; S may be tens of thousands)
+    // phi[nsel][S], jump[nsel][S]: work arrays in device memory (S may be tens of thousands); one block per mode
     __shared__ int ptot[512];
     const double q = 1.5707963267948966;
-    for (int j = 0; j < nsel; j++) {
+    phi += (size_t)blockIdx.x * S; jump += (size_t)blockIdx.x * S;
+    for (int j = blockIdx.x; j <= (int)blockIdx.x; j++) {
         for (int s = threadIdx.x; s < S; s += 256) {
             const double zr = z[2 * ((size_t)s * nsel + j)], zi = z[2 * ((size_t)s * nsel + j) + 1];
             phi[s] = (zr == 0 && zi == 0) ? 0.0 : (double)atan2f((float)-zi, (float)-zr) / 4;     // a seed: single precision is plenty
@@ -369,7 +370,8 @@ template <typename R> __device__ inline double pit_gain(int method, double Py, C
 constexpr double PIT_DEV_SAFETY = 1.0, PIT_DEV_WORST = 3.0, PIT_DEV_TAPS = 2.0;    // rule: safety x rms estimate < tol, worst segment < 3 tol, taps (relative norm, rms over segments) < 2 tol
 template <typename R>
 __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, const double *pw, int nb, const Cx<R> *Ylast, int n, Cx<R> *wx, PitCtrl *c, float *host_view,
-                                                         int nrow, const float *devmax, int ndev, double safety, const float2 *Ye, float2 *Yprev, int ne, int ncol_e)
+                                                         int nrow, const float *devmax, int ndev, double safety, const float2 *Ye, float2 *Yprev, int ne, int ncol_e,
+                                                         const double *theta, const int64_t *modes_dev, int ntot_w, int S, int sym, int corr_wanted)
 {
     if (c->done) return;
     if (Yprev)                                                // eigen-space copy of this pass's result, for the next pass's "how far did the result move"
@@ -406,7 +408,23 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
     // how far the sweep's result still moved in this pass, in output terms (pit_defect_kernel's extra block row; nrow entries after the nb boundaries)
     double chg = 0;
     for (int r = 0; r < nrow; r++) { const double v = dfc[nb + r]; chg = (v > chg || !(v == v)) ? v : chg; }
-    for (int e = threadIdx.x; e < n; e += 256) wx[e] = Ylast[e];
+    // The pass's result.  The functions with a continuous symmetry (cma, rde: every common phase) leave the phase of the taps free, and
+    // the end taps of the last segment sit in that segment's own frame: theta_{S-1}, the product of the boundary rotations of this pass,
+    // takes them into the frame of segment 0 - the caller's start taps, i.e. the frame of the sequential recurrence.  (A few 1e-3 rad
+    // over thousands of boundaries; the quarter-turn functions lock the phase themselves.)
+    for (int e = threadIdx.x; e < n; e += 256) {
+        Cx<R> v = Ylast[e];
+        if (sym == 0 && theta) {
+            const int row = e / ntot_w;
+            for (int j = 0; j < nrow; j++)
+                if ((int)modes_dev[j] == row) {
+                    const double tr = theta[2 * ((size_t)(S - 1) * nrow + j)], ti = theta[2 * ((size_t)(S - 1) * nrow + j) + 1];
+                    v = Cx<R>{(R)(tr * v.re - ti * v.im), (R)(tr * v.im + ti * v.re)};
+                    break;
+                }
+        }
+        wx[e] = v;
+    }
     if (threadIdx.x == 0) {
         const int p = c->passes;
         const bool have_dev = devmax != nullptr && c->corr_on && c->out_power > 0;
@@ -440,14 +458,43 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
             crit = red[0] * amp;
         }
         const int pl = p - 1 < QH_PIT_MAXPASS ? p - 1 : QH_PIT_MAXPASS - 1, pl2 = p - 2 < QH_PIT_MAXPASS ? p - 2 : QH_PIT_MAXPASS - 1;
-        if (p >= 1 && c->corr_on && !(red[0] < c->defect[pl])) c->corr_on = 0;      // the correction did not help: plain relaxation from here on
-        if (crit < c->tol) { c->converged = 1; c->done = 1; }
+        // the correction is given up only when the estimate has GROWN two passes in a row (a model that drives the iteration apart);
+        // a pass without progress is not a reason - plain relaxation leaves the weakly excited directions where they are
+        if (have_dev && p >= 2 && p < QH_PIT_MAXPASS && c->deviation_rms[pl] > 0 && c->deviation_rms[pl2] > 0 && dev_rms > 1.5 * c->deviation_rms[pl] &&
+            c->deviation_rms[pl] > 1.5 * c->deviation_rms[pl2]) c->corr_on = 0;
+        // Certified only by the deviation estimate when a coarse model exists: small boundary defects alone say nothing about the
+        // weakly excited directions (round 2's defect rule certified 64-QAM mrde runs whose taps were 3e-2 off).  Without a model
+        // (more than 96 taps per output mode) the defect rule is all there is.
+        if (crit < c->tol && (have_dev || !corr_wanted)) { c->converged = 1; c->done = 1; }
         // nothing gained over two passes: the trajectory has no fixed point the passes can agree on (a stage that cannot track the
         // carrier) - stop, NOT converged; further passes would only cost time.  (Slow but steady gains - rde's ring decisions - go on
         // to max_passes: the uncertified result keeps improving with them.)
-        else if (p >= 2 && p < QH_PIT_MAXPASS && !(red[0] < c->defect[pl2])) c->done = 1;
+        else if (p >= 2 && p < QH_PIT_MAXPASS) {
+            const bool use_dev = have_dev && c->deviation_rms[pl2] > 0;
+            const double prev2 = use_dev ? c->deviation_rms[pl2] : c->defect[pl2], now = use_dev ? dev_rms : red[0];
+            if (!(now < prev2)) c->done = 1;
+        }
         host_view[0] = c->done ? 1.f : 0.f;                   // what the host reads after the pass: flag + criterion (to decide
         host_view[1] = (float)crit;                           // whether the pass after the next one is worth enqueueing early)
+    }
+}
+
+// Error trace of the final pass into the frame of segment 0 (functions with a continuous symmetry only, see pit_decide_kernel):
+// errfn(g y) = g errfn(y), so the errors of segment s turn with theta_s.  Launched after the decision of every pass; acts in the
+// pass that ended the sweep (done set and the pass counter at p + 1), once.
+template <typename R>
+__global__ void __launch_bounds__(256) pit_rotate_err_kernel(Cx<R> *err, int64_t err_pitch, int64_t err_off, PitSeg sg, const int64_t *modes_dev, int nsel,
+                                                             const double *theta, const PitCtrl *c, int p)
+{
+    if (!c->done || c->passes != p + 1) return;
+    const int s = blockIdx.x, j = blockIdx.y;
+    if (s == 0) return;                                           // theta_0 = 1
+    const double tr = theta[2 * ((size_t)s * nsel + j)], ti = theta[2 * ((size_t)s * nsel + j) + 1];
+    Cx<R> *row = err + (size_t)modes_dev[j] * err_pitch + err_off + sg.start(s);
+    const int64_t n = sg.steps(s);
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const Cx<R> v = row[i];
+        row[i] = Cx<R>{(R)(tr * v.re - ti * v.im), (R)(tr * v.im + ti * v.re)};
     }
 }
 
@@ -1505,13 +1552,13 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     void *wbuf = nullptr;
     const size_t nsj = (size_t)sg.S * nsel;
     const size_t bytes_w = ((2 * (size_t)sg.S + 1) * wbytes + 63) / 64 * 64;
-    if ((rc = scratch(2, bytes_w + 10 * nsj * sizeof(double) + (size_t)nsel * sizeof(int64_t) + 320 + (size_t)sg.S * 16 + 4 * ((nsj + 63) / 64) * sizeof(float), &wbuf))) return rc;
+    if ((rc = scratch(2, bytes_w + 10 * nsj * sizeof(double) + (size_t)nsel * sizeof(int64_t) + 320 + nsj * 16 + 4 * ((nsj + 63) / 64) * sizeof(float), &wbuf))) return rc;
     Cx<R> *X = (Cx<R> *)wbuf, *Y = X + (size_t)sg.S * wset, *w_start = Y + (size_t)sg.S * wset;
     double *z = (double *)((char *)wbuf + bytes_w), *rot = z + 2 * nsj, *dfc = rot + 2 * nsj, *pw = dfc + nsj, *gph = pw + nsj, *theta = gph + 2 * nsj;
     int64_t *modes_dev = (int64_t *)(theta + 2 * nsj);
     double *uw_phi = (double *)(modes_dev + ((nsel + 7) / 8 * 8));
-    int *uw_jump = (int *)(uw_phi + sg.S);
-    float *devmax = (float *)(uw_jump + sg.S);                    // per-block maxima of the deviation estimate (ndev of them)
+    int *uw_jump = (int *)(uw_phi + (size_t)sg.S * nsel);
+    float *devmax = (float *)(uw_jump + (size_t)sg.S * nsel);                    // per-block maxima of the deviation estimate (ndev of them)
     const int ndev = (int)((nsj + 63) / 64);                     // (three floats per block: worst column, sum, sum of the tap norms)
     QH_HIP(hipMemcpyAsync(modes_dev, modes, (size_t)nsel * sizeof(int64_t), hipMemcpyHostToDevice, g_stream));
     QH_HIP(hipStreamSynchronize(g_stream));                       // `modes` is the caller's memory
@@ -1636,7 +1683,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             QH_REQUIRE(phase_lds(nwin) <= 60 * 1024, "train_equaliser: phase seeding does not fit the LDS for this filter shape (pass phase_seed = 0)");
             hipLaunchKernelGGL((pit_phase_kernel<R>), dim3(sg.S, nsel), dim3(256), phase_lds(nwin), g_stream, (const Cx<R> *)E, nmodes, L, os,
                                (const Cx<R> *)wx, ntaps, sg, (const int64_t *)modes_dev, nwin, z);
-            hipLaunchKernelGGL(pit_unwrap_kernel, dim3(1), dim3(256), 0, g_stream, (const double *)z, sg.S, nsel, rot, uw_phi, uw_jump);
+            hipLaunchKernelGGL(pit_unwrap_kernel, dim3(nsel), dim3(256), 0, g_stream, (const double *)z, sg.S, nsel, rot, uw_phi, uw_jump);
             rot_use = rot;
         }
         // segment 0 starts from the taps the sweep starts from in the reference (before the acquisition moved them), unrotated
@@ -1720,7 +1767,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 hipLaunchKernelGGL(pit_devest_kernel, dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax);
                 hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, nbnd,
                                    (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, ctrl, host_view, nsel, (const float *)devmax, ndev, safety,
-                                   (const float2 *)Ye, (float2 *)Yprev, ntot, ncol);
+                                   (const float2 *)Ye, (float2 *)Yprev, ntot, ncol, (const double *)theta, (const int64_t *)modes_dev, ntot, sg.S, sym, 1);
             } else {
             const size_t dlds = (2 * (size_t)ntot + (size_t)nmodes * os * pit_phase_pitch(ntaps, os, PIT_PROBE)) * sizeof(Cx<R>);
             QH_REQUIRE(dlds <= 60 * 1024, "train_equaliser: boundary probe does not fit the LDS for this filter shape");
@@ -1739,8 +1786,12 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             }
             hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, nbnd,
                                (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, ctrl, host_view, nsel,
-                               want_corr ? (const float *)devmax : (const float *)nullptr, ndev, safety, (const float2 *)nullptr, (float2 *)nullptr, 0, 0);
+                               want_corr ? (const float *)devmax : (const float *)nullptr, ndev, safety, (const float2 *)nullptr, (float2 *)nullptr, 0, 0,
+                               (const double *)theta, (const int64_t *)modes_dev, ntot, sg.S, sym, want_corr ? 1 : 0);
             }
+            if (sym == 0)
+                hipLaunchKernelGGL((pit_rotate_err_kernel<R>), dim3(sg.S, nsel), dim3(256), 0, g_stream, (Cx<R> *)err, (int64_t)(TrSyms * Niter), (int64_t)it * TrSyms, sg,
+                                   (const int64_t *)modes_dev, nsel, (const double *)theta, (const PitCtrl *)ctrl, p);
             QH_HIP(hipGetLastError());
             QH_HIP(hipMemcpyAsync(&ev.hview[2 * p], host_view, 2 * sizeof(float), hipMemcpyDeviceToHost, g_stream));
             QH_HIP(hipEventRecord(ev.flag[p], g_stream));

@@ -38,10 +38,15 @@ for c in CASES:
             rx.run(); _lib.sync()
             t0 = time.perf_counter(); rx.run(); _lib.sync(); el = time.perf_counter() - t0
             ser = ber.cal_ser_dev(rx.out, d["idx_tx"], rx.alphabet, 256, 8192, 2000)
-            res[tier] = dict(ms=round(el * 1e3, 2), errors=[s["errors"] for s in ser], rep=rx.pit_reports())
+            res[tier] = dict(ms=round(el * 1e3, 2), errors=[s["errors"] for s in ser], rep=rx.pit_reports(), eq=rx.eq.to_host(), w=rx.wxy.to_host())
             del rx
         except Exception as e:
             res[tier] = dict(error=repr(e)[:200])
     b = res["b"]
+    dev = []
+    if "eq" in res["a"] and "eq" in b:
+        for m in range(2):
+            g = 1j ** int(np.rint(np.angle(np.vdot(b["w"][m].ravel(), res["a"]["w"][m].ravel())) / (np.pi / 2)))
+            dev.append(round(float(np.sqrt(np.mean(np.abs(res["a"]["eq"][m] - g * b["eq"][m]) ** 2))), 5))
     print("##", c["name"], "| a:", res["a"].get("ms"), res["a"].get("errors"), "| b:", b.get("ms"), b.get("errors"), b.get("error"),
-          [(r["segments"], r["passes"], r["converged"], [round(x, 4) for x in r["defect"]], [round(x, 4) for x in r["result_change"]]) for r in (b.get("rep") or [])], flush=True)
+          [(r["segments"], r["passes"], r["converged"], [round(x, 5) for x in r["deviation_rms"][-3:]]) for r in (b.get("rep") or [])], "| measured out rms dev", dev, flush=True)
