@@ -476,6 +476,7 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
         }
         host_view[0] = c->done ? 1.f : 0.f;                   // what the host reads after the pass: flag + criterion (to decide
         host_view[1] = (float)crit;                           // whether the pass after the next one is worth enqueueing early)
+        __threadfence_system();                               // (host_view is pinned host memory: no copy kernel in between)
     }
 }
 
@@ -559,7 +560,10 @@ static __global__ void __launch_bounds__(256) pit_cov_reduce_kernel(const Z *par
 typedef float2 Zf;
 constexpr int PIT_EIGMAX = 96, PIT_EIGSWEEPS = 5;        // 5 sweeps: off-diagonal norm 2e-3, smallest eigenvalues good to 2 % - a preconditioner (3 sweeps: twice the passes on some captures)
 __device__ __forceinline__ Zf cmulf(Zf a, Zf b) { return Zf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, int n, double norm, double *lam, Zf *Vout, int nsweep)
+// glog != nullptr: the rotations are LOGGED ([sweep][round][pair] -> (c, s, e.re, e.im)) instead of being accumulated in V - a third of
+// the LDS traffic that bounds this kernel - and pit_jacobi_v_kernel applies them to the rows of V afterwards, which are independent
+// of each other (1.12 -> ~0.78 ms until the basis is there: it had become what the first correction of a cold start waits for).
+static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, int n, double norm, double *lam, Zf *Vout, int nsweep, float4 *glog)
 {
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     const int ld = n + 1;
@@ -571,7 +575,7 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
         for (int j = lane; j < n; j += 64) {
             const Z v = Rc[(size_t)i * n + j];
             A[i * ld + j] = Zf{(float)(v.x * norm), (float)(v.y * norm)};
-            V[i * ld + j] = Zf{i == j ? 1.f : 0.f, 0.f};
+            if (!glog) V[i * ld + j] = Zf{i == j ? 1.f : 0.f, 0.f};
         }
     __syncthreads();
     const int m = (n + 1) & ~1;                               // players of the round-robin (a dummy when n is odd)
@@ -618,6 +622,10 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl.z), a)),
                                __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl.w), a))};
             }
+            if (glog && lane < NP) {                              // lane a logs the wave's pair a of this round
+                const int pi = wave + 16 * lane;
+                if (pi < npair) glog[((size_t)sweep * (m - 1) + r) * npair + pi] = gl;
+            }
             // (no barrier here: the pivots of a pair sit in its own rows / columns, which only its own wave rotates)
             // columns p, q of A and V:  col_p' = c col_p - s conj(e) col_q ;  col_q' = s col_p + c conj(e) col_q
             // (a thread's items - up to 3 pairs x 2 rows x 2 matrices - are all read before any is rotated: one LDS latency)
@@ -632,7 +640,7 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
                         if (64 * b >= n) continue;                    // wave-uniform; lanes past the last row redo row n-1 (same inputs, same result)
                         const int row = lane + 64 * b < n ? lane + 64 * b : n - 1;
                         xp[a][b][0] = A[row * ld + ix.x]; xq[a][b][0] = A[row * ld + ix.y];
-                        xp[a][b][1] = V[row * ld + ix.x]; xq[a][b][1] = V[row * ld + ix.y];
+                        if (!glog) { xp[a][b][1] = V[row * ld + ix.x]; xq[a][b][1] = V[row * ld + ix.y]; }
                     }
                 }
 #pragma unroll
@@ -646,6 +654,7 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
                         const int row = lane + 64 * b < n ? lane + 64 * b : n - 1;
 #pragma unroll
                         for (int which = 0; which < 2; which++) {
+                            if (which && glog) continue;                  // (uniform) V is built from the log afterwards
                             Zf *Mx = which ? V : A;
                             const Zf up = xp[a][b][which];
                             const Zf xqe = cmulf(Zf{g.z, -g.w}, xq[a][b][which]);        // conj(e) x_q
@@ -690,8 +699,49 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
         }
     }
     for (int k = tid; k < n; k += 1024) lam[k] = (double)A[k * ld + k].x;
+    if (glog) return;
     for (int i = wave; i < n; i += 16)
         for (int k = lane; k < n; k += 64) { Vout[(size_t)i * n + k] = V[i * ld + k]; Vout[(size_t)n * n + (size_t)i * n + k] = V[k * ld + i]; }   // V, then V^T (both products read rows)
+}
+
+// Row i of V = e_i times the logged rotations, in their order: one wave per row (the rows do not interact), lane a = pair a of a
+// round (the pairs of a round are disjoint), the log staged through LDS 27 rounds at a time.  Writes V and V^T like the kernel above.
+constexpr int PIT_JV_CH = 27;
+static __global__ void __launch_bounds__(64) pit_jacobi_v_kernel(const float4 *glog, int n, int nsweep, Zf *Vout)
+{
+    __shared__ Zf row[PIT_EIGMAX + 2];
+    __shared__ float4 gch[PIT_JV_CH * (PIT_EIGMAX / 2 + 1)];
+    const int lane = threadIdx.x, i = blockIdx.x;
+    const int m = (n + 1) & ~1, npair = m / 2;
+    for (int k = lane; k < n + 2; k += 64) row[k] = Zf{k == i ? 1.f : 0.f, 0.f};
+    const int nround = nsweep * (m - 1);
+    for (int r0 = 0; r0 < nround; r0 += PIT_JV_CH) {
+        const int nr = nround - r0 < PIT_JV_CH ? nround - r0 : PIT_JV_CH;
+        __syncthreads();
+        for (int e = lane; e < nr * npair; e += 64) gch[e] = glog[(size_t)r0 * npair + e];
+        __syncthreads();
+        for (int rr = 0; rr < nr; rr++) {
+            const int r = (r0 + rr) % (m - 1);
+            if (lane < npair) {
+                int pa, pb;
+                if (lane == 0) { pa = m - 1; pb = r; }
+                else {
+                    pa = r + lane; if (pa >= m - 1) pa -= m - 1;
+                    pb = r - lane; if (pb < 0) pb += m - 1;
+                }
+                const int p = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
+                if (q < n) {
+                    const float4 g = gch[rr * npair + lane];
+                    const Zf up = row[p];
+                    const Zf xqe = cmulf(Zf{g.z, -g.w}, row[q]);                 // conj(e) x_q
+                    row[p] = Zf{g.x * up.x - g.y * xqe.x, g.x * up.y - g.y * xqe.y};
+                    row[q] = Zf{g.y * up.x + g.x * xqe.x, g.y * up.y + g.x * xqe.y};
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // one wave: its LDS operations are in program order; no barrier per round
+        }
+    }
+    for (int k = lane; k < n; k += 64) { Vout[(size_t)i * n + k] = row[k]; Vout[(size_t)n * n + (size_t)k * n + i] = row[k]; }
 }
 
 // C[m][c] = sum_k op(A)[m][k] B[k][c],  op(A) = A (CONJT = false) or A^H; A is n x n (n <= PIT_EIGMAX), B and C are n x ncol
@@ -1434,8 +1484,19 @@ int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t T
     if (!attr_set) { QH_HIP(hipFuncSetAttribute((const void *)pit_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); attr_set = true; }
     static int nsweep = 0;
     if (!nsweep) { const char *e = getenv("QAMPY_HIP_PIT_EIGSWEEPS"); nsweep = e && atoi(e) > 0 ? atoi(e) : PIT_EIGSWEEPS; }
+    // rotations logged by the solver, applied to V row by row afterwards (QAMPY_HIP_PIT_JACOBI=fused: the round-2 single kernel)
+    static int jfused = -1;
+    if (jfused < 0) { const char *e = getenv("QAMPY_HIP_PIT_JACOBI"); jfused = (e && e[0] == 'f') ? 1 : 0; }
+    float4 *glog = nullptr;
+    if (!jfused) {
+        void *gl = nullptr;
+        const int mm = (ntot + 1) & ~1;
+        if ((rc = scratch(11, (size_t)nsweep * (mm - 1) * (mm / 2) * sizeof(float4) + 64, &gl))) return rc;
+        glog = (float4 *)gl;
+    }
     hipLaunchKernelGGL(pit_jacobi_kernel, dim3(1), dim3(1024), jlds, st, (const Z *)Rc, ntot, 1.0 / (double)ncov, (double *)basis,
-                       (Zf *)((char *)basis + (size_t)ntot * sizeof(double)), nsweep);
+                       (Zf *)((char *)basis + (size_t)ntot * sizeof(double)), nsweep, glog);
+    if (glog) hipLaunchKernelGGL(pit_jacobi_v_kernel, dim3(ntot), dim3(64), 0, st, (const float4 *)glog, ntot, nsweep, (Zf *)((char *)basis + (size_t)ntot * sizeof(double)));
     QH_HIP(hipGetLastError());
     if (overlap) { QH_HIP(hipEventRecord(bs.out, st)); bs.pending = true; }
     return QH_OK;
@@ -1476,7 +1537,6 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     if ((rc = scratch(8, sizeof(PitCtrl) + 64, &cbuf))) return rc;
     PitCtrl *ctrl = report_dev ? (PitCtrl *)report_dev : (PitCtrl *)cbuf;
     R *mu_acq = (R *)((char *)cbuf + sizeof(PitCtrl));            // 8-byte aligned: sizeof(PitCtrl) is a multiple of 8
-    float *host_view = (float *)((char *)cbuf + sizeof(PitCtrl) + 16);
 
     // ---- segment grid
     int S = o.segments;
@@ -1766,7 +1826,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                                    (const R *)mu_dev, beta, (const PitCtrl *)ctrl);
                 hipLaunchKernelGGL(pit_devest_kernel, dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax);
                 hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, nbnd,
-                                   (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, ctrl, host_view, nsel, (const float *)devmax, ndev, safety,
+                                   (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, ctrl, &ev.hview[2 * p], nsel, (const float *)devmax, ndev, safety,
                                    (const float2 *)Ye, (float2 *)Yprev, ntot, ncol, (const double *)theta, (const int64_t *)modes_dev, ntot, sg.S, sym, 1);
             } else {
             const size_t dlds = (2 * (size_t)ntot + (size_t)nmodes * os * pit_phase_pitch(ntaps, os, PIT_PROBE)) * sizeof(Cx<R>);
@@ -1785,7 +1845,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 hipLaunchKernelGGL(pit_devest_kernel, dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax);
             }
             hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, nbnd,
-                               (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, ctrl, host_view, nsel,
+                               (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, ctrl, &ev.hview[2 * p], nsel,
                                want_corr ? (const float *)devmax : (const float *)nullptr, ndev, safety, (const float2 *)nullptr, (float2 *)nullptr, 0, 0,
                                (const double *)theta, (const int64_t *)modes_dev, ntot, sg.S, sym, want_corr ? 1 : 0);
             }
@@ -1793,7 +1853,6 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 hipLaunchKernelGGL((pit_rotate_err_kernel<R>), dim3(sg.S, nsel), dim3(256), 0, g_stream, (Cx<R> *)err, (int64_t)(TrSyms * Niter), (int64_t)it * TrSyms, sg,
                                    (const int64_t *)modes_dev, nsel, (const double *)theta, (const PitCtrl *)ctrl, p);
             QH_HIP(hipGetLastError());
-            QH_HIP(hipMemcpyAsync(&ev.hview[2 * p], host_view, 2 * sizeof(float), hipMemcpyDeviceToHost, g_stream));
             QH_HIP(hipEventRecord(ev.flag[p], g_stream));
             return QH_OK;
         };
