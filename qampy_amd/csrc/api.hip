@@ -64,8 +64,8 @@ int ensure_init()
 }
 
 // grow-only scratch slots so that the resident pipeline never allocates (and never synchronises) inside a timed region
-void *g_scratch[12] = {nullptr};
-size_t g_scratch_n[12] = {0};
+void *g_scratch[16] = {nullptr};
+size_t g_scratch_n[16] = {0};
 // form of the exact trainer: 0 = automatic (or the QAMPY_HIP_TRAINER environment variable), 1 direct, 2 look-ahead, 3 block-iterative
 int g_trainer = 0;
 const char *trainer_force()
@@ -166,7 +166,7 @@ int qh_release_scratch(void)
     if (rc) return rc;
     QH_HIP(hipStreamSynchronize(qh::g_streams[0]));
     QH_HIP(hipStreamSynchronize(qh::g_streams[1]));
-    for (int i = 0; i < 12; i++) {
+    for (int i = 0; i < 16; i++) {
         if (qh::g_scratch[i]) QH_HIP(hipFree(qh::g_scratch[i]));
         qh::g_scratch[i] = nullptr; qh::g_scratch_n[i] = 0;
     }

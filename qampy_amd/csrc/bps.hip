@@ -282,9 +282,14 @@ struct BpsStreamArgs {
     int32_t *idx;                // (nm, L)
     int64_t L;
     int A, M, N, C, alpha_lds;
+    // REC (search + np.unwrap + de-rotation in this one kernel): per-symbol phase and recovered symbols out, and the look-back cells
+    float *ph;                   // (nm, L)
+    Cx<float> *Eout;             // (nm, L)
+    unsigned long long *state;   // (nm, nchunk) zeroed before the launch: flag << 32 | value (1: the chunk's jump total, 2: inclusive prefix)
 };
 
 template <int K> struct BsKind { static constexpr int value = K; };
+template <typename R> __device__ __forceinline__ int unwrap_jump(const R *angles, int kprev, int kcur);
 typedef float bs_f2 __attribute__((ext_vector_type(2)));
 // both axes at once: u = (|t.re|, |t.im|), d_k = u - (l_re[k], l_im[k]) is ONE packed subtraction per level pair; the minima are
 // per axis (no packed min).  The same values as the scalar form: subtraction and |.| are exact per component.
@@ -309,6 +314,11 @@ template <bool SMALL> __device__ __forceinline__ bs_f2 bs_axes_sym(bs_f2 t, cons
     return m;
 }
 
+// REC: the host layer's np.unwrap and de-rotation (phaserecovery.py:155-158) in the same kernel.  The chunk keeps its indices in LDS,
+// sums its unwrap jumps, and gets the jumps of everything before it through a decoupled look-back over one 64-bit cell per chunk
+// (chunks are dispatched in order, so a predecessor is resident or done; a wave reads 64 cells at a time and stops at the first
+// that already carries an inclusive prefix) - then walks the chunk once more, coalesced: phase, rotator, recovered symbol.
+template <bool REC>
 __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char bs_smem[];
@@ -317,13 +327,18 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
     float *ring = reinterpret_cast<float *>(bs_smem);                 // [W][64]
     float *tb = ring + (size_t)W * 64;                                // [BS_G][BS_TP]
     float *plev = tb + BS_G * BS_TP + 1;                              // [2][BPS_MAX_LEVELS] levels of a product alphabet
-    Cx<float> *alpha = reinterpret_cast<Cx<float> *>(plev + 2 * BPS_MAX_LEVELS + 1);   // [M] any other alphabet (if it fits)
+    unsigned char *cidx = reinterpret_cast<unsigned char *>(plev + 2 * BPS_MAX_LEVELS + 1);   // REC: [C + 1] index of output c0 - 1, then of the chunk
+    char *after_idx = reinterpret_cast<char *>(cidx) + (REC ? ((a.C + 1 + 15) & ~15) : 0);
+    // REC: [C] running unwrap correction of the chunk's symbols - in the ring's memory once the search is over (the search is bound by
+    // the waves a CU holds: 5 KiB more LDS per wave cost it a fifth of its speed), behind the indices when the ring is too small
+    int *ccorr = (REC && W * 64 < a.C) ? reinterpret_cast<int *>(after_idx) : reinterpret_cast<int *>(ring);
+    Cx<float> *alpha = reinterpret_cast<Cx<float> *>(after_idx + ((REC && W * 64 < a.C) ? (size_t)a.C * sizeof(int) : 0));   // [M] any other alphabet (if it fits)
     const int64_t L = a.L;
     const Cx<float> *E = a.E + (size_t)blockIdx.y * L;
     int32_t *idx = a.idx + (size_t)blockIdx.y * L;
     const int64_t c0 = (int64_t)blockIdx.x * a.C;
     const int64_t c1 = c0 + a.C < L ? c0 + a.C : L;                   // outputs [c0, c1)
-    const int ngroups = (a.C + W - 1 + BS_G - 1) / BS_G;
+    const int ngroups = (a.C + W - 1 + (REC ? 1 : 0) + BS_G - 1) / BS_G;      // REC: one output more at the front (the jump into the chunk needs index c0 - 1)
     const int64_t lstart = c0 + a.C - 1 + a.N - (int64_t)ngroups * BS_G + 1;   // first distance row; row l completes the window of output l - N
 
     // ---- alphabet
@@ -428,7 +443,9 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
             if (m2 < m || (m2 == m && b2 < best)) { m = m2; best = b2; }
         }
         const int64_t i = lg + sym - a.N;
-        if (quarter == 0 && i >= c0 && i < c1) idx[i] = (i >= a.N && i < L - a.N) ? best : 0;
+        const int bo = (i >= a.N && i < L - a.N) ? best : 0;
+        if (quarter == 0 && i >= c0 && i < c1) idx[i] = bo;
+        if (REC && quarter == 0 && i >= c0 - 1 && i < c1) cidx[i - c0 + 1] = (unsigned char)bo;
         __syncthreads();
     }
     };
@@ -436,6 +453,71 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
     else if (symmetric) run(BsKind<0>{});
     else if (product) run(BsKind<1>{});
     else run(BsKind<2>{});
+    if (!REC) return;
+    __syncthreads();                                                    // the ring is free now
+    // ---- np.unwrap of 4 * ph over the interior [N, L - N): the correction is an integer number of quarter turns, a prefix sum of jumps
+    const int per = (a.C + 63) / 64;                                    // consecutive symbols per lane
+    int local = 0;
+    for (int r = 0; r < per; r++) {
+        const int e = lane * per + r;
+        const int64_t i = c0 + e;
+        int j = 0;
+        if (e < a.C && i < c1 && i > a.N && i < L - a.N) j = unwrap_jump<float>(a.angles, cidx[e], cidx[e + 1]);
+        local += j;
+        if (e < a.C) ccorr[e] = local;                                  // inclusive within the lane
+    }
+    int incl = local;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const int total = __shfl(incl, 63);
+    const int lane_off = incl - local;
+    // ---- jumps of the chunks before this one
+    unsigned long long *cell = a.state + (size_t)blockIdx.y * gridDim.x;
+    const int c = blockIdx.x;
+    int before = 0;
+    if (c > 0) {
+        if (lane == 0) __hip_atomic_store(cell + c, (1ull << 32) | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int base = c - 1;
+        for (;;) {
+            const int k = base - lane;
+            unsigned long long v = 2ull << 32;                          // before chunk 0: an inclusive prefix of 0
+            if (k >= 0) v = __hip_atomic_load(cell + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned flag = (unsigned)(v >> 32);
+            if (__ballot(flag == 0) != 0) { __builtin_amdgcn_s_sleep(2); continue; }      // a predecessor has not published yet
+            const unsigned long long m2 = __ballot(flag == 2);
+            const int val = (int)(unsigned)v;
+            const int first2 = m2 ? __builtin_ctzll(m2) : 64;           // nearest cell with an inclusive prefix
+            int part = lane <= first2 ? val : 0;
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+            before += part;
+            if (m2) break;
+            base -= 64;
+        }
+    }
+    if (lane == 0) __hip_atomic_store(cell + c, (2ull << 32) | (unsigned)(before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int r = 0; r < per; r++) {
+        const int e = lane * per + r;
+        if (e < a.C) ccorr[e] += before + lane_off;
+    }
+    __syncthreads();
+    // ---- phase and de-rotation, consecutive symbols per lane
+    float *ph = a.ph + (size_t)blockIdx.y * L;
+    Cx<float> *out = a.Eout + (size_t)blockIdx.y * L;
+    const float pi = 3.14159265358979323846f;
+    for (int e = lane; e < a.C; e += 64) {
+        const int64_t i = c0 + e;
+        if (i >= c1) break;
+        const bool interior = (i >= a.N && i < L - a.N);
+        float p = a.angles[cidx[e + 1]];                                // edges keep the raw grid value of idx = 0 (phaserecovery.py:155 unwraps the interior only)
+        if (interior) p += (pi / 2) * (float)ccorr[e];
+        ph[i] = p;
+        float sn, cs;
+        sincos_<float>(p, &sn, &cs);
+        const Cx<float> x = ldg(E + i);
+        stg(out + i, Cx<float>{fma_(x.re, cs, -(x.im * sn)), fma_(x.re, sn, x.im * cs)});
+    }
 }
 
 template <typename R> static int bps_tile(int A, int N, size_t *lds)
@@ -459,8 +541,10 @@ template <> inline bool bps_stream_ok<float>(int64_t p, int A, int N, int M)
 
 // nm rows of length L (consecutive in memory) against one angle grid; idx likewise
 template <typename R>
-int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, const void *symbols, int M, int N, int32_t *idx, int nm = 1)
+int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, const void *symbols, int M, int N, int32_t *idx, int nm = 1,
+            void *ph = nullptr, void *Eout = nullptr, bool *recovered = nullptr)
 {
+    if (recovered) *recovered = false;
     int rc = ensure_init();
     if (rc) return rc;
     QH_REQUIRE(L >= 0 && A >= 1 && M >= 1 && N >= 1 && nm >= 1, "bps: bad sizes");
@@ -478,10 +562,31 @@ int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, cons
         int C = 1024;                                            // longer chunks: less halo (2N - 1 rows each); shorter: more waves
         while (C > 128 && ((L + C - 1) / C) * nm < 4096) C /= 2;
         s.C = C;
-        const size_t lds = ((size_t)2 * N * 64 + BS_G * BS_TP + 1 + 2 * BPS_MAX_LEVELS + 1) * sizeof(float) + (s.alpha_lds ? (size_t)M * sizeof(Cx<float>) : 0) + 16;
+        // search + unwrap + de-rotation in ONE kernel (QAMPY_HIP_BPS_FUSED=1).  Opt-in: measured at C3 it is slower than the search
+        // followed by the three small unwrap / de-rotation launches (0.80 against 0.70 ms) - the tail of a chunk (jump scan, look-back,
+        // sincos, second pass over the symbols) is a latency chain inside a kernel whose speed is the number of waves a CU holds.
+        const char *fe = getenv("QAMPY_HIP_BPS_FUSED");
+        const int fused = (fe && fe[0] == '1') ? 1 : 0;
+        const bool rec = fused && ph != nullptr && Eout != nullptr && A <= 255;
+        const unsigned nchunk = (unsigned)((L + C - 1) / C);
+        s.ph = (float *)ph; s.Eout = (Cx<float> *)Eout; s.state = nullptr;
+        if (rec) {
+            void *st = nullptr;
+            if ((rc = scratch(12, (size_t)nm * nchunk * sizeof(unsigned long long), &st))) return rc;
+            QH_HIP(hipMemsetAsync(st, 0, (size_t)nm * nchunk * sizeof(unsigned long long), g_stream));
+            s.state = (unsigned long long *)st;
+        }
+        const size_t lds = ((size_t)2 * N * 64 + BS_G * BS_TP + 1 + 2 * BPS_MAX_LEVELS + 1) * sizeof(float) + (rec ? (2 * N * 64 < C ? (size_t)C * sizeof(int) : 0) + (((size_t)C + 1 + 15) & ~(size_t)15) : 0) +
+                           (s.alpha_lds ? (size_t)M * sizeof(Cx<float>) : 0) + 16;
         static bool sattr = false;
-        if (!sattr) { QH_HIP(hipFuncSetAttribute((const void *)bps_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); sattr = true; }
-        hipLaunchKernelGGL(bps_stream_kernel, dim3((unsigned)((L + C - 1) / C), nm), dim3(64), lds, g_stream, s);
+        if (!sattr) {
+            QH_HIP(hipFuncSetAttribute((const void *)bps_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            QH_HIP(hipFuncSetAttribute((const void *)bps_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            sattr = true;
+        }
+        if (rec) hipLaunchKernelGGL(bps_stream_kernel<true>, dim3(nchunk, nm), dim3(64), lds, g_stream, s);
+        else hipLaunchKernelGGL(bps_stream_kernel<false>, dim3(nchunk, nm), dim3(64), lds, g_stream, s);
+        if (recovered) *recovered = rec;
         QH_HIP(hipGetLastError());
         return QH_OK;
     }
@@ -687,7 +792,9 @@ int bps_recover_dev(const void *E, int nm, int64_t L, const void *angles, int A,
         if ((rc = scratch(0, (size_t)A * sizeof(R), &dang))) return rc;
         hipLaunchKernelGGL((linspace_kernel<R>), dim3((A + 63) / 64), dim3(64), 0, g_stream, (R *)dang, A);
     }
-    if ((rc = bps_dev<R>(E, L, dang, 1, A, symbols, M, N, idx, nm))) return rc;
+    bool recovered = false;
+    if ((rc = bps_dev<R>(E, L, dang, 1, A, symbols, M, N, idx, nm, ph, Eout, &recovered))) return rc;
+    if (recovered) return QH_OK;                                   // the streaming kernel unwrapped and de-rotated as well
     hipLaunchKernelGGL((unwrap_partial_kernel<R>), dim3((unsigned)nchunk, nm), dim3(UW_THREADS), 0, g_stream, idx, L, N, (const R *)dang,
                        (int *)dchunk, nchunk);
     hipLaunchKernelGGL(unwrap_scan_kernel, dim3(nm), dim3(1024), 0, g_stream, (int *)dchunk, nchunk);

@@ -485,3 +485,23 @@ def test_window_batch_equals_one_call_per_window(nwin, hop, method, adaptive, dn
     assert np.array_equal(best, np.argmin(ref_var, axis=-1)) or np.allclose(np.sort(ref_var, axis=-1)[:, 0], np.sort(ref_var, axis=-1)[:, 1], rtol=1e-3)
     for m in range(2):
         np.testing.assert_allclose(wbest[m], wx[best[m]], **t)
+
+
+def test_fused_search_unwrap_derotation_equals_separate_kernels(monkeypatch):
+    """QAMPY_HIP_BPS_FUSED=1: search, np.unwrap (decoupled look-back over the chunks) and de-rotation in ONE kernel - same index, phase
+    and recovered symbols as the search followed by the three unwrap / de-rotation launches, on a capture with real phase wander
+    (the unwrapped phase leaves the grid's range many times) and at a length that is not a multiple of the chunk."""
+    from qampy_amd._lib import DeviceArray
+    sig = synth.make_capture(16, 2 ** 17 + 333, nmodes=2, os=1, snr_db=22, linewidth=2e6, seed=11, dtype=np.complex64)
+    E = DeviceArray.from_host(np.ascontiguousarray(np.asarray(sig)))
+    alpha = DeviceArray.from_host(np.ascontiguousarray(sig.coded_symbols, dtype=np.complex64))
+    res = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("QAMPY_HIP_BPS_FUSED", fused)
+        idx, ph, out = DeviceArray(E.shape, np.int32), DeviceArray(E.shape, np.float32), DeviceArray(E.shape, np.complex64)
+        hip_dsp.bps_recover_dev(E, 32, alpha, 20, idx, ph, out, angles=DeviceArray.from_host(hip_dsp.test_angle_grid(32, np.float32)))
+        res[fused] = (idx.to_host(), ph.to_host(), out.to_host())
+    assert np.array_equal(res["0"][0], res["1"][0])
+    assert np.abs(res["0"][1]).max() > np.pi                     # the phase did wander: the unwrap correction is exercised
+    np.testing.assert_array_equal(res["0"][1], res["1"][1])
+    np.testing.assert_array_equal(res["0"][2], res["1"][2])
