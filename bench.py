@@ -726,6 +726,9 @@ def main():
     if rank != 0:
         if split:
             cm.close()
+        if getattr(cm, "stuck", False):
+            sys.stdout.flush()
+            os._exit(0)
         return
 
     value_timed = sharding.aggregate_throughput(nsym, 1 if split else world, args.steps, elapsed)
@@ -940,6 +943,9 @@ def main():
             out["channel_bank"] = dict(channels=args.bank, error="%s: %s" % (type(e).__name__, e))
 
     print(json.dumps(out))
+    sys.stdout.flush()
+    if getattr(cm, "stuck", False):                  # a helper thread is still inside RCCL's bootstrap: do not wait for it at interpreter exit
+        os._exit(0)
 
 
 def kernel_sources_sha():

@@ -89,14 +89,15 @@ class Comm:
         self.device = device
         self.backend = "single" if self.world == 1 else "tcp"
         self.note = None
-        self.op_timeout = 3600.0                           # a collective may wait for a rank that is still computing
+        self.op_timeout = 900.0                            # a collective may wait for a rank that is still computing; a dead rank must not hang the job
         self._peers, self._root, self._srv, self._file = [], None, None, None
         self._nccl, self._ncomm, self._scratch = None, None, None
+        self.stuck = False
         if self.world > 1:
             self._rendezvous(env, timeout)
         want_rccl = backend == "rccl" or (backend == "auto" and device is not None and self.world > 1)
         if want_rccl:
-            ok, why = self._init_rccl()
+            ok, why = self._init_rccl_guarded(float(env.get("QAMPY_COMM_RCCL_TIMEOUT", "120")))
             # every rank must take the same path
             flags = self._tcp_allreduce(np.array([1.0 if ok else 0.0]), "min") if self.world > 1 else np.array([1.0 if ok else 0.0])
             if flags[0] > 0:
@@ -180,6 +181,26 @@ class Comm:
         return _recv(self._root)
 
     # ---------------------------------------------------------------------------------------------- RCCL
+    def _init_rccl_guarded(self, timeout):
+        """RCCL's bootstrap (sockets between the ranks, then the xGMI / PCIe topology) runs in a helper thread: if it does not come back
+        within `timeout` seconds - an interface it cannot use, a peer that died - this rank reports failure, all ranks agree on the socket
+        backend and the job goes on (the collectives here carry a few scalars).  `stuck` makes close() leave without joining it."""
+        import threading
+        # single node: the bootstrap may use the loopback interface (the container's hostname need not resolve); xGMI / PCIe carry the data
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        box = {}
+
+        def work():
+            box["r"] = self._init_rccl()
+
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        t.join(timeout)
+        if t.is_alive():
+            self.stuck = True
+            return False, "ncclCommInitRank did not return within %g s" % timeout
+        return box.get("r", (False, "rccl initialisation raised"))
+
     def _init_rccl(self):
         try:
             from . import _lib
@@ -199,7 +220,12 @@ class Comm:
             lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
             lib.ncclBroadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
             lib.ncclCommDestroy.argtypes = [C.c_void_p]
-            _lib.init(self.device)                       # hipSetDevice for this process before the communicator exists
+            _lib.init(self.device)                       # the library's device (one per process)
+            # the current device is per THREAD and this runs in a helper thread: the communicator must be created on the rank's GPU
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipSetDevice.argtypes = [C.c_int]
+            if hip.hipSetDevice(int(self.device)) != 0:
+                return False, "hipSetDevice(%d) failed" % int(self.device)
             uid = _UniqueId()
             raw = None
             if self.rank == 0:
