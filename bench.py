@@ -512,7 +512,7 @@ def tier_b_block(cfg, rx, stage_names, pass_ms, acq_ms, reports, value, ms, errs
                              pass_ms=round(kern[s]["mean_ms"], 3), acquisition_ms=round(kern[s]["acquisition_ms"], 3))
                         for s, r in enumerate(reports)],
                 errors=[e for e, _ in errs], converged=bool(all(r["converged"] for r in reports)),
-                limits=dict(max_segments=65536, coarse_correction_max_taps_per_mode=96, segment_kernel_max_taps="(64+1)*os + ntaps + 8 <= 192",
+                limits=dict(max_segments=65536, coarse_correction_max_nmodes_x_ntaps=128, segment_kernel_max_taps="(64+4)*os + ntaps + 8 <= 192",
                             max_passes_default=16, max_passes_cap=24),
                 pipeline_hbm=dict(achieved=round(FUSED_BYTES_PER_SYM * nsym / (ms * 1e-3) / 1e9, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                                   frac=round(FUSED_BYTES_PER_SYM * nsym / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),

@@ -246,7 +246,7 @@ int qh_set_trainer(int form);
  *     the taps themselves (unweighted norm of the same vectors, rms over the segments: the weakly excited directions count fully)
  *     below 2 tol.  Measured against the exact path the FINAL taps sit at the worst-segment value of that estimate (deviation_taps_worst,
  *     up to 1.6 x the rms: deviations of the weakly excited directions accumulate along the sweep), i.e. within 3 tol.
- *     Without the correction (more than 96 taps per output mode, or switched off) the round-2 rule applies: largest boundary
+ *     Without the correction (nmodes * ntaps > 128, or switched off) the round-2 rule applies: largest boundary
  *     defect x a segment-length factor below tol.
  *   phase_seed: for the phase-sensitive functions (mcma, mrde, sbd, mddma, dd) the pass-0 start taps of segment s are the
  *     start taps rotated by an unwrapped 4th-power phase estimate of their output at the head of the segment, so that
@@ -314,7 +314,7 @@ typedef struct qh_pit_report {
 int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold, int *segments);   /* cold: the sweep starts from unconverged taps (acquire) */
 /* Eigenbasis of the input covariance <conj(x) x^T> of the training windows of a capture, for the coarse correction: depends
  * on (E, os, ntaps, TrSyms) only, so one build serves every stage and sweep over the same capture.  basis: device memory of
- * qh_pit_basis_bytes(nmodes*ntaps) bytes.  nmodes*ntaps <= 96.  overlap != 0: built on the library's other stream while the
+ * qh_pit_basis_bytes(nmodes*ntaps) bytes.  nmodes*ntaps <= 128.  overlap != 0: built on the library's other stream while the
  * current stream goes on (the trainer waits for it before its first correction; qh_sync waits for both streams). */
 int qh_pit_basis_bytes(int ntot, size_t *bytes);
 int qh_pit_basis_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis, int overlap);

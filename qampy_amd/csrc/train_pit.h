@@ -558,7 +558,7 @@ static __global__ void __launch_bounds__(256) pit_cov_reduce_kernel(const Z *par
 // Hermitian matrix Rc / nwin, whole problem in the LDS of ONE workgroup, single precision (the basis only preconditions the
 // relaxation).  Out: lam[n] eigenvalues, V[i][k] = component i of eigenvector k.  n <= PIT_EIGMAX.
 typedef float2 Zf;
-constexpr int PIT_EIGMAX = 96, PIT_EIGSWEEPS = 5;        // 5 sweeps: off-diagonal norm 2e-3, smallest eigenvalues good to 2 % - a preconditioner (3 sweeps: twice the passes on some captures)
+constexpr int PIT_EIGMAX = 128, PIT_EIGSWEEPS = 5;       // up to 2 x 64 taps (round 2: 96; above 96 the solver must log its rotations: A alone fills the LDS)        // 5 sweeps: off-diagonal norm 2e-3, smallest eigenvalues good to 2 % - a preconditioner (3 sweeps: twice the passes on some captures)
 __device__ __forceinline__ Zf cmulf(Zf a, Zf b) { return Zf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 // glog != nullptr: the rotations are LOGGED ([sweep][round][pair] -> (c, s, e.re, e.im)) instead of being accumulated in V - a third of
 // the LDS traffic that bounds this kernel - and pit_jacobi_v_kernel applies them to the rows of V afterwards, which are independent
@@ -957,9 +957,10 @@ __global__ void __launch_bounds__(256) pit_basis_gemm_kernel(const Zf *A2, const
 // column lane & 31, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).  41 steps x 4 x 64 cycles = 4.4 us of MFMA issue per tile; with
 // staging ~8 us at 7936 columns against ~25 us of the register-blocked VALU form above (which stays as QAMPY_HIP_PIT_GEMM=valu).
 typedef float pit_f16 __attribute__((ext_vector_type(16)));
+constexpr int PIT_MW = PIT_EIGMAX / 32, PIT_MT = 64 * PIT_MW;      // waves / threads of a block of the MFMA products: one wave per 32 output rows
 inline size_t pit_mfma_lds(int n) { return ((size_t)(n + 2) * PIT_BP + (size_t)PIT_NC * (PIT_EIGMAX + 1)) * sizeof(Zf); }
 template <typename R, int MODE>
-__global__ void __launch_bounds__(192) pit_basis_mfma_kernel(const Zf *__restrict__ A2, const Cx<R> *__restrict__ T, const Zf *__restrict__ D, Zf *__restrict__ Out, int n, int ncol,
+__global__ void __launch_bounds__(PIT_MT) pit_basis_mfma_kernel(const Zf *__restrict__ A2, const Cx<R> *__restrict__ T, const Zf *__restrict__ D, Zf *__restrict__ Out, int n, int ncol,
                                                              const PitCtrl *c, PitFuse<R> fz)
 {
     if (c->done) return;
@@ -983,11 +984,11 @@ __global__ void __launch_bounds__(192) pit_basis_mfma_kernel(const Zf *__restric
     if (MODE == 0) {
         // wave w: columns w, w + 3, ...; lanes: f = lane, lane + 64 (one column's taps are contiguous: coalesced); all 11 columns of a
         // wave in flight together - one round trip to L2 / HBM for the whole tile
-        constexpr int NCB = (PIT_NC + 2) / 3;
+        constexpr int NCB = (PIT_NC + PIT_MW - 1) / PIT_MW;
         Zf tmp[NCB][2];
 #pragma unroll
         for (int q = 0; q < NCB; q++) {
-            const int cc = wave + 3 * q, col = col0 + cc;
+            const int cc = wave + PIT_MW * q, col = col0 + cc;
             tmp[q][0] = Zf{0.f, 0.f}; tmp[q][1] = Zf{0.f, 0.f};
             if (cc < PIT_NC && col < ncol) {
                 const int s = col / fz.nsel, j = col - s * fz.nsel;               // wave-uniform
@@ -998,36 +999,36 @@ __global__ void __launch_bounds__(192) pit_basis_mfma_kernel(const Zf *__restric
         }
 #pragma unroll
         for (int q = 0; q < NCB; q++) {
-            const int cc = wave + 3 * q;
+            const int cc = wave + PIT_MW * q;
             if (cc < PIT_NC) {
                 if (lane < np) Bs[lane * PIT_BP + cc] = tmp[q][0];
                 if (lane + 64 < np) Bs[(lane + 64) * PIT_BP + cc] = tmp[q][1];
             }
         }
     } else {
-        // thread: column tid & 31, rows tid >> 5, + 6, ...: a row of the tile is 256 contiguous bytes; all 16 rows of a thread in flight
+        // thread: column tid & 31, rows tid >> 5, + PIT_MT / 32, ...: a row of the tile is 256 contiguous bytes; all 16 rows of a thread in flight
         const int cc = tid & 31, k0 = tid >> 5;
         const bool okc = col0 + cc < ncol;
         Zf tmp[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const int k = k0 + 6 * q;
+            const int k = k0 + (PIT_MT / 32) * q;
             tmp[q] = (okc && k < n) ? D[(size_t)k * ncol + col0 + cc] : Zf{0.f, 0.f};
         }
 #pragma unroll
         for (int q = 0; q < 16; q++) {
-            const int k = k0 + 6 * q;
+            const int k = k0 + (PIT_MT / 32) * q;
             if (k < np) Bs[k * PIT_BP + cc] = tmp[q];
         }
     }
     // MODE 1: the start taps and frames the epilogue combines with the product are fetched now, under the MFMAs
-    constexpr int NCW = (PIT_NC + 2) / 3;
+    constexpr int NCW = (PIT_NC + PIT_MW - 1) / PIT_MW;
     Cx<R> xv[MODE == 1 ? NCW : 1][2];
     double th[MODE == 1 ? NCW : 1][2];
     if (MODE == 1) {
 #pragma unroll
         for (int q = 0; q < NCW; q++) {
-            const int cc = wave + 3 * q, col = col0 + cc;
+            const int cc = wave + PIT_MW * q, col = col0 + cc;
             xv[q][0] = Cx<R>{0, 0}; xv[q][1] = Cx<R>{0, 0}; th[q][0] = 1; th[q][1] = 0;
             if (cc < PIT_NC && col < ncol) {
                 const int s = col / fz.nsel, j = col - s * fz.nsel;
@@ -1043,7 +1044,7 @@ __global__ void __launch_bounds__(192) pit_basis_mfma_kernel(const Zf *__restric
 #pragma unroll
     for (int q = 0; q < 16; q++) { rr[q] = 0.f; ii[q] = 0.f; im[q] = 0.f; }
     const Zf *bp = Bs + (lane >> 5) * PIT_BP + (lane & 31);
-    for (int k0 = 0; k0 < np; k0 += 2 * PF) {
+    for (int k0 = 0; k0 < np && 32 * wave < n; k0 += 2 * PF) {     // (a wave whose 32 rows are all padding has nothing to multiply)
 #pragma unroll
         for (int i = 0; i < PF; i++) {
             const int k = k0 + 2 * i;
@@ -1078,7 +1079,7 @@ __global__ void __launch_bounds__(192) pit_basis_mfma_kernel(const Zf *__restric
         // wave: columns wave, wave + 3, ...; lanes along m (the tap sets' fast axis); X and theta of its columns were fetched before the product
 #pragma unroll
         for (int q = 0; q < NCW; q++) {
-            const int cc = wave + 3 * q, col = col0 + cc;
+            const int cc = wave + PIT_MW * q, col = col0 + cc;
             if (cc < PIT_NC && col < ncol) {
                 const int s = col / fz.nsel, j = col - s * fz.nsel;
                 const size_t base = (size_t)s * wset + (size_t)fz.modes_dev[j] * n;
@@ -1480,7 +1481,6 @@ int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t T
     else hipLaunchKernelGGL((pit_cov_kernel<R, 64>), dim3(PIT_COVB), dim3(256), lds, st, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
     hipLaunchKernelGGL(pit_cov_reduce_kernel, dim3((unsigned)((msz + 63) / 64)), dim3(256), 0, st, (const Z *)part, (int)msz, PIT_COVB, Rc);
     static bool attr_set = false;
-    const size_t jlds = 2 * (size_t)ntot * (ntot + 1) * sizeof(Zf) + (size_t)((PIT_EIGMAX + 2) / 2) * (sizeof(float4) + sizeof(int2));
     if (!attr_set) { QH_HIP(hipFuncSetAttribute((const void *)pit_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); attr_set = true; }
     static int nsweep = 0;
     if (!nsweep) { const char *e = getenv("QAMPY_HIP_PIT_EIGSWEEPS"); nsweep = e && atoi(e) > 0 ? atoi(e) : PIT_EIGSWEEPS; }
@@ -1488,7 +1488,9 @@ int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t T
     static int jfused = -1;
     if (jfused < 0) { const char *e = getenv("QAMPY_HIP_PIT_JACOBI"); jfused = (e && e[0] == 'f') ? 1 : 0; }
     float4 *glog = nullptr;
-    if (!jfused) {
+    const bool logged = !jfused || ntot > 96;                     // above 96 rows A and V do not fit the LDS together
+    const size_t jlds = (logged ? 1 : 2) * (size_t)ntot * (ntot + 1) * sizeof(Zf) + 256;
+    if (logged) {
         void *gl = nullptr;
         const int mm = (ntot + 1) & ~1;
         if ((rc = scratch(11, (size_t)nsweep * (mm - 1) * (mm / 2) * sizeof(float4) + 64, &gl))) return rc;
@@ -1656,16 +1658,17 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     // complex64: the analysis of a pass runs in the eigenbasis (pit_basis_gemm_kernel / pit_bound_kernel / pit_recur_eig_kernel); complex128
     // keeps the probe-based analysis, whose defect vectors are formed in double precision before they are projected
     // (QAMPY_HIP_PIT_PROBE=1 forces it for complex64 too: tests compare the two)
-    static int gemm_valu = -1;
-    if (gemm_valu < 0) { const char *e = getenv("QAMPY_HIP_PIT_GEMM"); gemm_valu = (e && e[0] == 'v') ? 1 : 0; }
+    static int gemm_env = -1;
+    if (gemm_env < 0) { const char *e = getenv("QAMPY_HIP_PIT_GEMM"); gemm_env = (e && e[0] == 'v') ? 1 : 0; }
+    const int gemm_valu = (gemm_env && pit_gemm_lds(ntot) <= 150 * 1024) ? 1 : 0;     // (the register-blocked VALU form stages the whole basis: up to 96 rows)
     const bool eig = want_corr && sizeof(R) == 4 && !(getenv("QAMPY_HIP_PIT_PROBE") && atoi(getenv("QAMPY_HIP_PIT_PROBE")) != 0);
     const size_t glds = ((size_t)PIT_EIGMAX * PIT_EIGMAX + (size_t)PIT_EIGMAX * PIT_GT) * sizeof(Zf);
     static bool gemm_attr = false;
     if (want_corr && !gemm_attr) {
-        QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        QH_HIP(hipFuncSetAttribute((const void *)pit_basis_gemm_kernel<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        QH_HIP(hipFuncSetAttribute((const void *)pit_basis_gemm_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        QH_HIP(hipFuncSetAttribute((const void *)pit_basis_gemm_kernel<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        QH_HIP(hipFuncSetAttribute((const void *)pit_basis_gemm_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         QH_HIP(hipFuncSetAttribute((const void *)pit_basis_mfma_kernel<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         QH_HIP(hipFuncSetAttribute((const void *)pit_basis_mfma_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                 gemm_attr = true;
@@ -1758,7 +1761,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 // start taps = theta X + V D~ with D[s+1] = d[s+1] + J D[s] from the analysis that closed pass p - 1 (below); with the
                 // correction switched off on the device (corr_on = 0) the scan ran with coefficient 0, D = d: plain relaxation
                 if (eig && !gemm_valu)
-                    hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 1>), dim3((ncol + PIT_NC - 1) / PIT_NC), dim3(192), pit_mfma_lds(ntot), g_stream, Vb + (size_t)ntot * ntot,
+                    hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 1>), dim3((ncol + PIT_NC - 1) / PIT_NC), dim3(PIT_MT), pit_mfma_lds(ntot), g_stream, Vb + (size_t)ntot * ntot,
                                        (const Cx<R> *)nullptr, (const Zf *)Dz[1], (Zf *)nullptr, ntot, ncol, (const PitCtrl *)ctrl, fz);
                 else if (eig)
                     hipLaunchKernelGGL((pit_basis_gemm_kernel<R, 1>), dim3((ncol + PIT_NC - 1) / PIT_NC), dim3(256), pit_gemm_lds(ntot), g_stream, Vb + (size_t)ntot * ntot,
@@ -1814,7 +1817,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 const dim3 ggrid((ncol + PIT_NC - 1) / PIT_NC);
                 auto forward = [&](const Cx<R> *src, Zf *dst) {      // dst = V^H src
                     if (gemm_valu) hipLaunchKernelGGL((pit_basis_gemm_kernel<R, 0>), ggrid, dim3(256), pit_gemm_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
-                    else hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 0>), ggrid, dim3(192), pit_mfma_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
+                    else hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 0>), ggrid, dim3(PIT_MT), pit_mfma_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
                 };
                 if (p == 0) forward((const Cx<R> *)X, Xe);           // start taps of the sweep into the eigenbasis (kept up to date from here on)
                 forward((const Cx<R> *)Y, Ye);

@@ -121,7 +121,7 @@ class ResidentReceiver:
             fits = self.TrSyms[0] * 1024 * (np.dtype(self.ct).itemsize // 8) <= budget
             if len(set(self.TrSyms)) == 1 and self.TrSyms[0] >= 128 and fits and _os.environ.get("QAMPY_HIP_TRAINER", "") != "direct":
                 self._gram = _k.gram_build_dev(self.E, self.os, self.Ntaps, self.TrSyms[0])
-        elif len(set(self.TrSyms)) == 1 and self.nmodes * self.Ntaps <= 96:
+        elif len(set(self.TrSyms)) == 1 and self.nmodes * self.Ntaps <= 128:
             # tier b builds what its passes need itself (no Gram table in the throughput form, csrc/train_seg.h); what the stages
             # share is the eigenbasis of the capture's input covariance for the coarse correction
             self._basis = _k.pit_basis_dev(self.E, self.os, self.Ntaps, self.TrSyms[0], getattr(self, "_basis", None), overlap=True)
