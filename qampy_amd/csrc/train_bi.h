@@ -252,10 +252,27 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
 #pragma unroll
         for (int r = 0; r < BI_JW; r++) g[r] = gok[r] ? g[r] : Cx<R>{0, 0};
     };
-    Cx<R> *errow = aerr + (size_t)mode * a.err_pitch + a.err_off;
+    // own tap slice in registers: group rr of round t <-> tap f0 + BI_RPW * t + rr (BI_MAXTAPS / 64 = 2 rounds at most)
+    Cx<R> wreg[2] = {Cx<R>{0, 0}, Cx<R>{0, 0}};
+    R r_blk = ADAPT ? (R)1 / K.mu : (R)0;                              // adaptive step: r = 1/mu at the start of the block, carried from sweep to sweep
+    unsigned long long pf_sweeps = 0, pf_t_sweep = 0, pf_t_upd = 0, pf_t_prior = 0;
+    // The reference's Niter loop (pythran_equalisation.py:163-165) INSIDE the launch: taps and step size stay in registers / LDS from sweep
+    // to sweep; what a sweep needs from scratch is its first two sample windows, the prior outputs of block 0 and the Gram rows of block 0
+    // (the pilot stages of config 5 are 30 sweeps of 1024 steps: a launch per sweep was a third of their time).
+    const int nsweep = a.niter > 1 ? a.niter : 1;
+    for (int it = 0; it < nsweep; it++) {
+    if (it > 0) __syncthreads();                                        // the last block's readers of the sample windows are done
+    Cx<R> *errow = aerr + (size_t)mode * a.err_pitch + a.err_off + (int64_t)it * TrSyms;
     stage_load(0); stage_store(0);
     if (nblk > 1) { stage_load(1); stage_store(1); }
     __syncthreads();
+    if (it == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int f = f0 + BI_RPW * t + rr;
+            wreg[t] = (BI_RPW * t + rr < nf) ? wbuf[f] : Cx<R>{0, 0};
+        }
+    }
     Cx<R> qpart = prior_part(0);
     Cx<R> g[BI_JW], gn[BI_JW];
     load_gram(g, 0);
@@ -264,21 +281,12 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
     BiEnt<R> *pw = P + (size_t)lane * BI_PAD + w;                       // this wave's column of the exchange buffer
     const BiEnt<R> *pr = P + (size_t)(BI_JW * w + rr) * BI_PAD + vv;   // the rows it reduces
     constexpr int PBUF = LA_B * BI_PAD;
-    // own tap slice in registers: group rr of round t <-> tap f0 + BI_RPW * t + rr (BI_MAXTAPS / 64 = 2 rounds at most)
-    Cx<R> wreg[2];
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const int f = f0 + BI_RPW * t + rr;
-        wreg[t] = (BI_RPW * t + rr < nf) ? wbuf[f] : Cx<R>{0, 0};
-    }
     Cx<R> *eown = errow + BI_JW * w + rr;                               // this group's slot of the error trace
-    // adaptive step: r = 1/mu at the start of the block, last error of the previous block, compact layout helpers
-    R r_blk = ADAPT ? (R)1 / K.mu : (R)0;
+    // adaptive step: last error of the previous block (none at the start of a sweep: the reference adapts from step 1 on), compact layout helpers
     Cx<R> e_carry{0, 0};
     const int cl = lane & 7;                                            // compact layout: lane <-> row (lane & 7) of this wave
     const int csrc = cl * BI_W * 4;                                     // ds_bpermute byte address of that row's group
 
-    unsigned long long pf_sweeps = 0, pf_t_sweep = 0, pf_t_upd = 0, pf_t_prior = 0;
     for (int k = 0; k < nblk; k++) {
         const unsigned long long pt0 = a.prof ? clock64() : 0;
         const int64_t s0 = (int64_t)k * LA_B;
@@ -405,6 +413,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
             pf_t_sweep += pt1 - pt0; pf_t_upd += pt2c - pt1; pf_t_prior += pt3 - pt2c;
         }
     }
+    }   // sweeps
     __syncthreads();
     if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) {
         a.prof[0] = pf_sweeps; a.prof[1] = pf_t_sweep; a.prof[2] = pf_t_upd; a.prof[3] = pf_t_prior; a.prof[4] = (unsigned long long)nblk;

@@ -552,7 +552,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             if (use_bi && decision) {   // the kernel reads the slicer table like an mrde table: row pitch 2*BI_DD_MAXLEV, 2*npart+1 used
                 la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV;
             }
-            la.prof = nullptr; la.seg = 0; la.seg_extra = 0; la.seg_tail = 0; la.skip = nullptr;
+            la.prof = nullptr; la.seg = 0; la.seg_extra = 0; la.seg_tail = 0; la.skip = nullptr; la.niter = 1;
             if (getenv("QAMPY_HIP_LA_PROFILE")) {                // developer aid: cycle split of workgroup 0
                 void *pp = nullptr;
                 if ((rc = scratch(5, 16 * sizeof(unsigned long long), &pp))) return rc;
@@ -575,7 +575,10 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             if (adaptive && !mu_modes) la.nsel = 1;
             for (int jm = 0; jm < nmode_runs; jm++) {
                 if (adaptive && !mu_modes) la.modes[0] = a.modes[jm];
-                for (int it = 0; it < Niter; it++) {             // one launch per sweep (and chunk): taps go through HBM in between
+                // block-iterative form, sweep not chunked: ALL sweeps in one launch (the kernel loops over them with taps and step size on chip)
+                const bool sweeps_inside = use_bi && CH >= TrSyms && Niter > 1;
+                for (int it = 0; it < (sweeps_inside ? 1 : Niter); it++) {             // else one launch per sweep (and chunk): taps go through HBM in between
+                    la.niter = sweeps_inside ? Niter : 1;
                     for (int64_t step0 = 0; step0 < TrSyms;) {
                         int64_t n = TrSyms - step0 < CH ? TrSyms - step0 : CH;
                         if (TrSyms - (step0 + n) < 2 * LA_B) n = TrSyms - step0;          // never leave a tail the block forms cannot take

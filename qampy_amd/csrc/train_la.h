@@ -241,6 +241,8 @@ template <typename R> struct LaArgs {
     int seg;
     int64_t seg_extra, seg_tail;
     const int *skip;            // optional device flag: non-zero -> the launch does nothing (device-side early termination)
+    int niter;                  // block-iterative kernel: sweeps over the same TrSyms steps inside ONE launch (taps and step size stay on chip;
+                                // sweep `it` writes its errors at err_off + it * TrSyms); 0 / 1 = one sweep
 };
 
 // per-channel view of the arrays of a launch (channel bank: fixed strides; segmented sweep: see LaArgs::seg)

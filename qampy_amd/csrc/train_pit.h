@@ -1682,7 +1682,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     la.E_cs = 0; la.err_cs = 0; la.G_cs = 0; la.wx_cs = (int64_t)wset;
     for (int j = 0; j < 16; j++) la.modes[j] = j < nsel ? modes[j] : 0;
     if ((use_bi || seg_form) && decision) { la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV; }
-    la.prof = nullptr; la.seg = 0; la.seg_extra = 0; la.seg_tail = 0; la.skip = nullptr;
+    la.prof = nullptr; la.seg = 0; la.seg_extra = 0; la.seg_tail = 0; la.skip = nullptr; la.niter = 1;
     TrainArgs<R> ta;
     ta.E = (const Cx<R> *)E; ta.symbols = (const Cx<R> *)symbols; ta.err = (Cx<R> *)err; ta.mu = mu_dev;
     ta.L = L; ta.TrSyms = TrSyms; ta.nsy = nsy; ta.nmodes = nmodes; ta.ntaps = ntaps; ta.Niter = Niter; ta.os = os;
