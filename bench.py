@@ -817,7 +817,7 @@ def main():
             ntot = rx.nmodes * rx.Ntaps
             flops = chains * st["seg_len"] * (2 * ntot) * 8.0           # filter + update: 2 x ntot complex multiply-adds per chain and step
             tpl8 = 11 if rx.nmodes * -(-rx.Ntaps // 11) <= 8 and 11 * -(-rx.Ntaps // 11) - rx.Ntaps <= 3 else (6 if rx.nmodes * -(-rx.Ntaps // 6) <= 8 and 6 * -(-rx.Ntaps // 6) - rx.Ntaps <= 3 else 0)
-            lpc = 8 if chains >= 3000 and tpl8 else 16                  # launch_seg's rule (train_seg.h)
+            lpc = 8 if chains > 4096 and tpl8 else 16                   # seg_lanes (train_seg.h)
             waves = -(-chains // (64 // lpc))
             ipw, src = float(SEG_INSTR_PER_WAVE_STEP[lpc]), "ISA count of the main loop incl. s_nop / s_waitcnt (DESIGN.md 3.2.2)"
             mid = _lib.METHOD_ID[cfg["methods"][int(kname[5]) - 1]]
@@ -832,7 +832,7 @@ def main():
                                       frac=round(flops / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)),
                             chains=int(chains), lanes_per_chain=lpc, waves=int(waves), waves_per_simd=round(waves / 1024.0, 2), steps_per_chain=int(st["seg_len"]),
                             valu_instr_per_wave_step=round(ipw, 1), valu_instr_source=src,
-                            note="one launch trains all segments of the sweep (8 lanes per chain, 8 chains per wave64): bound by VALU issue - achieved / peak are "
+                            note="one launch trains all segments of the sweep (%d lanes per chain, %d chains per wave64, one wave per SIMD): bound by VALU issue" % (lpc, 64 // lpc) + " - achieved / peak are "
                                  "vector instructions per second against 1024 SIMDs x 2.4 GHz / 4 cycles; `hbm`: algorithmic bytes of one sweep (read E, write "
                                  "err) against 8 TB/s, `valu`: recurrence flops against the packed-fp32 peak")
     else:

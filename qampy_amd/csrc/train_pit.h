@@ -1426,22 +1426,46 @@ inline PitEvents &pit_events()
     return e;
 }
 
-// Automatic segment grid.  A segment should be a fraction of the time constant 1/(mu g lambda) of the well-excited tap
-// directions - short enough for thousands of chains (the throughput form wants >= 2 waves per SIMD: 8192 chains), long enough
-// for the linearised coarse correction to describe what a segment does to its start taps: ~0.2/mu steps when the sweep
-// starts from converged taps (2 passes at C3), ~0.4/mu when it starts cold, i.e. from the taps of the acquisition (3-4).
+// Automatic segment grid.  Two things decide it:
+//   * convergence: a segment should span a fixed fraction of the time constant 1/(mu g lambda) of the well-excited tap directions,
+//     long enough for the linearised coarse correction (mean covariance) to describe what a segment does to its start taps -
+//     measured at C3 (mu = 2e-4): segments of >= ~2300 steps contract the deviation 3x per pass all the way down (7 passes to
+//     1e-3 from the acquisition taps, at any length from 2340 to 3280), 2176 steps stall at 2x after four passes (8 passes), 2048
+//     need 11; from converged taps 2048 steps need 4 passes, 1024 need 5-7.  Target: 0.45 / mu cold, 0.4 / mu warm.
+//   * the machine: the segment kernel runs one wave per SIMD (train_seg.h), 1024 SIMDs; a pass costs
+//     rounds x steps per segment x cycles per wave and step (~303 with 16 lanes per chain = 4 chains per wave, ~428 with 8 lanes
+//     = 8 chains per wave, chosen by seg_lanes from the chain count), so a grid that needs 1.05 rounds costs two.  Cold sweeps
+//     leave one CU per shader engine (32 of 256) to the basis build that runs beside the first pass: 896 waves per round.
+// The grid is the cheapest of: the target length as it is, exactly one round of 16-lane waves, whole rounds of 8-lane waves -
+// among those whose segments are not shorter than 0.87 x the target.
 inline int pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold)
 {
-    double target = (cold ? 0.4 : 0.2) / (mu > 1e-12 ? mu : 1e-12);
+    double target = (cold ? 0.45 : 0.4) / (mu > 1e-12 ? mu : 1e-12);
     if (target < 256) target = 256;
     if (target > 1048576) target = 1048576;
     const int64_t seg = ((int64_t)target + 63) / 64 * 64;
-    int64_t S = TrSyms / seg;
-    if (S > PIT_MAXSEG) S = PIT_MAXSEG;
-    const int64_t ncu = 256;                                   // MI355X: whole rounds of workgroups
-    if (S * nsel > ncu && nsel <= ncu) S = S * nsel / ncu * ncu / nsel;
-    if (S < 4) S = 1;
-    return (int)S;
+    int64_t St = TrSyms / seg;
+    if (St > PIT_MAXSEG) St = PIT_MAXSEG;
+    if (St < 4) return 1;
+    if (nsel < 1) nsel = 1;
+    const int64_t cap = cold ? 896 : 1024;                     // waves per round
+    auto cost = [&](int64_t S) {                               // cycles of one pass
+        const int64_t chains = S * nsel;
+        const bool l16 = chains <= 4096;                       // seg_lanes
+        const int64_t waves = (chains + (l16 ? 3 : 7)) / (l16 ? 4 : 8);
+        return (double)((waves + cap - 1) / cap) * (double)(TrSyms / S) * (l16 ? 303.0 : 428.0);
+    };
+    int64_t best = St;
+    double cbest = cost(St);
+    auto consider = [&](int64_t S) {
+        if (S < 4 || S > PIT_MAXSEG || (double)S > 1.15 * (double)St) return;
+        const double c = cost(S);
+        if (c < cbest * 0.999 || (c < cbest * 1.001 && S > best)) { best = S; cbest = c; }
+    };
+    const int64_t S16 = cap * 4 / nsel, S8 = cap * 8 / nsel;
+    if (S16 * nsel <= 4096) consider(S16 < St ? S16 : St);
+    for (int64_t r = 1; r * S8 <= St + St / 6 && r <= 64; r++) consider(r * S8);
+    return (int)best;
 }
 
 // Eigenbasis of the input covariance of a capture (depends on E, os, ntaps, TrSyms only - one build serves every stage):

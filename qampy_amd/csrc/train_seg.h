@@ -148,11 +148,9 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     // One wave per SIMD, by construction.  A launch of this kernel has about as many single-wave workgroups as the chip has SIMDs
     // (992 at C3's mrde stage); with <= 256 VGPRs two of them fit on a SIMD and the dispatcher does pair them up while other SIMDs
     // of the same CU stay empty - each of the pair then issues every other turn (measured: 783 instead of 553 cycles per step).
-    // A few registers kept alive from here to the end push the allocation past half the file, so that a second wave never fits.
-    constexpr int SG_PADV = (sizeof(R) == 4 && LPC == 8) ? 12 : 0;
-    float padv[SG_PADV > 0 ? SG_PADV : 1];
-#pragma unroll
-    for (int q = 0; q < SG_PADV; q++) asm volatile("v_mov_b32 %0, 0" : "=v"(padv[q]));
+    // Naming the last VGPR and one AGPR as clobbered pushes the allocation past half the register file, so that a second wave
+    // never fits (any layout, any precision; with more chains than SIMDs the waves queue up and still run alone).
+    asm volatile("" ::: "v255", "a0");                          // allocation = 256 VGPRs + the first AGPR granule > half the file
     extern __shared__ __attribute__((aligned(16))) char sg_smem[];
     Cx<R> *lds = reinterpret_cast<Cx<R> *>(sg_smem);          // [SG_ROWS][SG_PITCH] + zero row [SG_PITCH]  (ONE buffer: the next chunk waits in registers
                                                               // while this one computes and is stored after it - one wave per workgroup, LDS operations in program order)
@@ -355,8 +353,6 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         for (int j = 0; j < TPL; j++)
             if (has && t0 + j < a.ntaps) stg(wrow + kin * a.ntaps + t0 + j, Cx<R>{w[j].x, w[j].y});
     }
-#pragma unroll
-    for (int q = 0; q < SG_PADV; q++) asm volatile("" ::"v"(padv[q]));
 }
 
 #endif  // QH_SEG_KERNELS
@@ -394,7 +390,8 @@ inline bool seg_supported(int method, int nmodes, int ntaps, int os, int64_t nsy
     default: return false;
     }
 }
-constexpr int SG_LPC8_MIN = 3000;        // chains from which 8 lanes per chain pay (measured at C3: 3840 chains 486 -> 472 us, 7936 chains 386 -> 275 us per pass)
+constexpr int SG_LPC8_MIN = 4096 + 1;    // chains from which 8 lanes per chain pay: as long as 4 chains per wave fit one wave per SIMD (1024 SIMDs), the
+                                         // shorter instruction stream of the 16-lane layout wins (C3, 3840 chains: 275 against 390 us per pass)
 template <typename R> inline int seg_lanes(int nmodes, int ntaps, int nsel, int nq)
 {
     const char *e = getenv("QAMPY_HIP_SEG_LANES");                  // 8 | 16: force (measurements, tests)

@@ -19,7 +19,7 @@ sy0 = eq._reshape_symbols(None, "cma", M, np.complex64, 2)
 _, w0, _ = hk.train_equaliser(E, tr, 1, 2, np.float32(2e-4), w0, None, False, sy0, "cma")
 dE = DeviceArray.from_host(E)
 res = {}
-for method in ("cma", "mcma", "cma2", "rde", "mrde", "sbd", "mddma", "dd"):
+for method in os.environ.get("BM_METHODS", "cma,mcma,cma2,rde,mrde,sbd,mddma,dd").split(","):
     sy = eq._reshape_symbols(sig.coded_symbols if method in ("sbd", "mddma", "dd") else None, method, M, np.complex64, 2)
     dsy = DeviceArray.from_host(np.ascontiguousarray(sy))
     derr = DeviceArray((2, tr), np.complex64)
@@ -29,7 +29,7 @@ for method in ("cma", "mcma", "cma2", "rde", "mrde", "sbd", "mddma", "dd"):
         if form != "default":
             os.environ["QAMPY_HIP_TRAINER"] = form
         for adaptive in (False, True, "per-mode"):
-            if adaptive and form != "default":
+            if adaptive and form not in ("default", "iterative"):
                 continue
             dw = DeviceArray.from_host(w0.copy())
             hk.train_equaliser_dev(dE, tr, 1, 2, dmu, dw, None, adaptive, dsy, method, derr)      # warm-up
