@@ -320,7 +320,8 @@ int qh_pit_basis_bytes(int ntot, size_t *bytes);
 int qh_pit_basis_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis, int overlap);
 int qh_pit_basis_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis, int overlap);
 /* kernel time (HIP events on the library stream) of the trainer launches of the most recent qh_train_equaliser_*_pit_dev call:
- * the relaxation passes in order (all sweeps) and the sum of the acquisition chunks */
+ * the timed relaxation passes in order (all sweeps) and the sum of the acquisition chunks.  An event idles the stream for ~5.6 us,
+ * so by default ONE pass per sweep is timed (pass 1); environment QAMPY_HIP_PIT_TIMING = all (every pass) | none. */
 int qh_pit_last_timing(float *pass_ms, int max_passes, int *npass, float *acq_ms);
 int qh_train_equaliser_c64_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
                                    void *wx, int ntaps, const int64_t *modes, int nsel, const void *symbols, int64_t nsy,

@@ -10,6 +10,7 @@
 // Buffers per call (scratch slot 2):  X (S tap sets) start taps of the current pass,  Y (S tap sets) trained in place,
 // rot (S x nsel) pass-0 phase rotations, z (S x nsel) 4th-power sums, dfc (S x nsel) boundary defects.
 #pragma once
+#include <atomic>
 #include "train_impl.h"
 #include "train_seg.h"
 
@@ -474,20 +475,22 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
             const double prev2 = use_dev ? c->deviation_rms[pl2] : c->defect[pl2], now = use_dev ? dev_rms : red[0];
             if (!(now < prev2)) c->done = 1;
         }
-        host_view[0] = c->done ? 1.f : 0.f;                   // what the host reads after the pass: flag + criterion (to decide
-        host_view[1] = (float)crit;                           // whether the pass after the next one is worth enqueueing early)
-        __threadfence_system();                               // (host_view is pinned host memory: no copy kernel in between)
+        // what the host reads after the pass: criterion (to decide whether the pass after the next one is worth enqueueing early), then
+        // the flag it polls for (host_view is pinned, coherent host memory: no copy kernel, no event in between)
+        host_view[1] = (float)crit;
+        __threadfence_system();
+        __hip_atomic_store(&host_view[0], c->done ? 1.f : 0.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 // Error trace of the final pass into the frame of segment 0 (functions with a continuous symmetry only, see pit_decide_kernel):
-// errfn(g y) = g errfn(y), so the errors of segment s turn with theta_s.  Launched after the decision of every pass; acts in the
-// pass that ended the sweep (done set and the pass counter at p + 1), once.
+// errfn(g y) = g errfn(y), so the errors of segment s turn with theta_s.  Launched once, after the pass that ended the sweep (the
+// passes enqueued ahead of the host's knowledge return at `done` and leave theta alone).
 template <typename R>
 __global__ void __launch_bounds__(256) pit_rotate_err_kernel(Cx<R> *err, int64_t err_pitch, int64_t err_off, PitSeg sg, const int64_t *modes_dev, int nsel,
                                                              const double *theta, const PitCtrl *c, int p)
 {
-    if (!c->done || c->passes != p + 1) return;
+    if (p >= 0 && (!c->done || c->passes != p + 1)) return;       // p < 0: launched once, after the last pass
     const int s = blockIdx.x, j = blockIdx.y;
     if (s == 0) return;                                           // theta_0 = 1
     const double tr = theta[2 * ((size_t)s * nsel + j)], ti = theta[2 * ((size_t)s * nsel + j) + 1];
@@ -1420,7 +1423,7 @@ inline PitEvents &pit_events()
     if (!e.ok) {
         for (int i = 0; i < PIT_NEV; i++) { (void)hipEventCreate(&e.t0[i]); (void)hipEventCreate(&e.t1[i]); (void)hipEventCreateWithFlags(&e.flag[i], hipEventDisableTiming); }
         (void)hipHostMalloc((void **)&e.hflag, PIT_NEV * sizeof(int32_t), hipHostMallocDefault);
-        (void)hipHostMalloc((void **)&e.hview, 2 * PIT_NEV * sizeof(float), hipHostMallocDefault);
+        (void)hipHostMalloc((void **)&e.hview, 2 * PIT_NEV * sizeof(float), hipHostMallocCoherent);
         e.ok = e.hflag != nullptr && e.hview != nullptr;
     }
     return e;
@@ -1778,7 +1781,12 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         hipLaunchKernelGGL((pit_seed_kernel<R>), dim3(sg.S), dim3(256), 0, g_stream, (const Cx<R> *)wx, nmodes, ntot, (const int64_t *)modes_dev, nsel, rot_use, X, w_exact);
         QH_HIP(hipGetLastError());
         // ================================================================ relaxation passes
+        // HIP events around the trainer launch of a pass (qh_pit_last_timing): an event is ~5.6 us of idle stream, so by default only
+        // pass 1 of a sweep is timed (pass 0 of a cold sweep shares the chip with the basis build); QAMPY_HIP_PIT_TIMING = all | none
+        static const int timing_mode = [] { const char *e = getenv("QAMPY_HIP_PIT_TIMING"); return !e ? 1 : (e[0] == 'a' ? 2 : (e[0] == 'n' ? 0 : 1)); }();
+        auto timed = [&](int p) { return timing_mode == 2 || (timing_mode == 1 && p == 1); };
         auto enqueue_pass = [&](int p) -> int {
+            ((volatile float *)ev.hview)[2 * p] = -1.f;             // "not decided yet": pit_decide_kernel overwrites it (polled below)
             PitFuse<R> fz;
             fz.X = X; fz.Y = Y; fz.theta = theta; fz.modes_dev = (const int64_t *)modes_dev; fz.nmodes = nmodes; fz.nsel = nsel;
             if (p > 0 && want_corr) {
@@ -1799,7 +1807,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             } else {
                 QH_HIP(hipMemcpyAsync(Y, X, (size_t)sg.S * wbytes, hipMemcpyDeviceToDevice, g_stream));
             }
-            QH_HIP(hipEventRecord(ev.t0[p], g_stream));
+            if (timed(p)) QH_HIP(hipEventRecord(ev.t0[p], g_stream));
             if (seg_form) {
                 SegArgs<R> sa;
                 sa.E = (const Cx<R> *)E; sa.wx = Y; sa.symbols = la.symbols; sa.err = (Cx<R> *)err; sa.mu = mu_dev;
@@ -1820,7 +1828,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 ts.wx = Y; ts.nseg = sg.S; ts.seg_begin = 0; ts.seg_len = sg.len; ts.seg_extra = sg.extra; ts.seg_tail = sg.tail; ts.seg_iter = it; ts.skip = &ctrl->done;
                 { int r = launch_any<R>(ts); if (r) return r; }
             }
-            QH_HIP(hipEventRecord(ev.t1[p], g_stream));
+            if (timed(p)) QH_HIP(hipEventRecord(ev.t1[p], g_stream));
             if (split) {
                 // one capture over several processes: the end taps of the segments trained elsewhere arrive through the caller's
                 // all-reduce (zeros here, the trained taps there); from then on every process works on identical data
@@ -1876,11 +1884,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                                want_corr ? (const float *)devmax : (const float *)nullptr, ndev, safety, (const float2 *)nullptr, (float2 *)nullptr, 0, 0,
                                (const double *)theta, (const int64_t *)modes_dev, ntot, sg.S, sym, want_corr ? 1 : 0);
             }
-            if (sym == 0)
-                hipLaunchKernelGGL((pit_rotate_err_kernel<R>), dim3(sg.S, nsel), dim3(256), 0, g_stream, (Cx<R> *)err, (int64_t)(TrSyms * Niter), (int64_t)it * TrSyms, sg,
-                                   (const int64_t *)modes_dev, nsel, (const double *)theta, (const PitCtrl *)ctrl, p);
             QH_HIP(hipGetLastError());
-            QH_HIP(hipEventRecord(ev.flag[p], g_stream));
             return QH_OK;
         };
         // Pass p + 1 is enqueued BEFORE the host has seen the flag of pass p - unless pass p is expected to be the last one, since
@@ -1898,11 +1902,33 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             const bool expect_last = p > 0 && contr * (double)ev.hview[2 * (p - 1) + 1] < tol;
             ahead = false;
             if (p + 1 < npass && !expect_last && (!split || xchg_async)) { if ((rc = enqueue_pass(p + 1))) return rc; ahead = true; }   // (a host-side exchange cannot be enqueued ahead)
-            QH_HIP(hipEventSynchronize(ev.flag[p]));
-            if (tm.npass < QH_PIT_MAXPASS) { float ms = 0; QH_HIP(hipEventElapsedTime(&ms, ev.t0[p], ev.t1[p])); tm.pass_ms[tm.npass++] = ms; }
+            // the decision of pass p: polled in pinned memory (an event here would idle the stream for ~5.6 us per pass); the stream
+            // going idle without a decision means a launch failed or the sweep was already done
+            {
+                volatile float *hv = (volatile float *)ev.hview;
+                unsigned spins = 0;
+                while (hv[2 * p] < 0.f) {
+                    if ((++spins & 1023u) == 0) {
+                        const hipError_t q = hipStreamQuery(g_stream);
+                        if (q == hipSuccess) { if (hv[2 * p] < 0.f) hv[2 * p] = 1.f; break; }
+                        if (q != hipErrorNotReady) QH_HIP(q);
+                    }
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+            }
+            if (timed(p) && tm.npass < QH_PIT_MAXPASS) {
+                float ms = 0;
+                QH_HIP(hipEventSynchronize(ev.t1[p]));
+                QH_HIP(hipEventElapsedTime(&ms, ev.t0[p], ev.t1[p]));
+                tm.pass_ms[tm.npass++] = ms;
+            }
             if (ev.hview[2 * p] != 0.f) break;
             if (p + 1 < npass && !ahead && (rc = enqueue_pass(p + 1))) return rc;
         }
+        if (sym == 0)
+            hipLaunchKernelGGL((pit_rotate_err_kernel<R>), dim3(sg.S, nsel), dim3(256), 0, g_stream, (Cx<R> *)err, (int64_t)(TrSyms * Niter), (int64_t)it * TrSyms, sg,
+                               (const int64_t *)modes_dev, nsel, (const double *)theta, (const PitCtrl *)ctrl, -1);
+        QH_HIP(hipGetLastError());
     }
     return QH_OK;
 }

@@ -4,6 +4,7 @@
     python scripts/pit_exp.py [--workload c3|ns|c2] [--nsym N] [--seeds 1000,1001] [--linewidth Hz] [--variants default,...]
 """
 import argparse, json, os, sys, time
+os.environ.setdefault("QAMPY_HIP_PIT_TIMING", "all")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import bench
