@@ -11,6 +11,7 @@
 // rot (S x nsel) pass-0 phase rotations, z (S x nsel) 4th-power sums, dfc (S x nsel) boundary defects.
 #pragma once
 #include <atomic>
+#include <chrono>
 #include "train_impl.h"
 #include "train_seg.h"
 
@@ -42,23 +43,36 @@ struct PitSeg {                      // segment grid of a sweep: see LaArgs::seg
 
 // in-place inclusive prefix sum of a[0..n) in LDS by a 256-thread block: chunk sums, one serial pass over the 256 chunk
 // totals, chunk-local prefixes (n is a few thousand: ~1 us instead of a serial loop over n)
-// Exclusive scan over the 256 threads of a block (thread order) with an associative op(earlier, later); buf: [512] of T in LDS.
-// (Hillis-Steele on ping-pong buffers, 8 barriers - the scans here used to end in ONE thread walking all 256 partial results,
-// 256 dependent LDS round trips = 10-15 us per call.)
-template <typename T, typename Op, int NT = 256> __device__ __forceinline__ T block_scan_excl(T v, Op op, T ident, T *buf)      // buf: [2 NT]
+// Exclusive scan over the NT threads of a block (thread order) with an associative op(earlier, later) and its identity; buf: LDS,
+// [NT / 64] of T.  Inclusive scan inside each wave with shuffles, the wave totals through LDS: two barriers (the Hillis-Steele
+// version on ping-pong buffers took log2(NT) of them - 2-3 us per call at 1024 threads; the one before that ended in ONE thread
+// walking all partial results).
+template <typename T> __device__ __forceinline__ T shfl_up_any(T v, int d)
 {
-    const int t = threadIdx.x;
-    int cur = 0;
-    buf[t] = v;
-    __syncthreads();
-    for (int o = 1; o < NT; o <<= 1) {
-        T x = buf[cur * NT + t];
-        if (t >= o) x = op(buf[cur * NT + t - o], x);
-        buf[(cur ^ 1) * NT + t] = x;
-        cur ^= 1;
-        __syncthreads();
+    static_assert(sizeof(T) % 4 == 0, "shfl_up_any: 32-bit words");
+    int w[sizeof(T) / 4];
+    __builtin_memcpy(w, &v, sizeof(T));
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) w[i] = __shfl_up(w[i], d);
+    __builtin_memcpy(&v, w, sizeof(T));
+    return v;
+}
+template <typename T, typename Op, int NT = 256> __device__ __forceinline__ T block_scan_excl(T v, Op op, T ident, T *buf)      // buf: [NT / 64]
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    T x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T y = shfl_up_any(x, o);
+        if (lane >= o) x = op(y, x);
     }
-    const T r = t > 0 ? buf[cur * NT + t - 1] : ident;
+    if (lane == 63) buf[wave] = x;
+    __syncthreads();
+    T pre = ident;
+    for (int w = 0; w < wave; w++) pre = op(pre, buf[w]);
+    T ex = shfl_up_any(x, 1);
+    if (lane == 0) ex = ident;
+    const T r = op(pre, ex);
     __syncthreads();
     return r;
 }
@@ -369,12 +383,38 @@ template <typename R> __device__ inline double pit_gain(int method, double Py, C
 // converged -> later passes skip.  devmax: per-block maxima of sum_k lambda_k |D~_k[col]|^2 from pit_devest_kernel (ndev of them;
 // nullptr / corr_on = 0: no estimate, the defect rule decides).
 constexpr double PIT_DEV_SAFETY = 1.0, PIT_DEV_WORST = 3.0, PIT_DEV_TAPS = 2.0;    // rule: safety x rms estimate < tol, worst segment < 3 tol, taps (relative norm, rms over segments) < 2 tol
-template <typename R>
-__global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, const double *pw, int nb, const Cx<R> *Ylast, int n, Cx<R> *wx, PitCtrl *c, float *host_view,
-                                                         int nrow, const float *devmax, int ndev, double safety, const float2 *Ye, float2 *Yprev, int ne, int ncol_e,
-                                                         const double *theta, const int64_t *modes_dev, int ntot_w, int S, int sym, int corr_wanted)
+template <typename R> struct PitDecideArgs {
+    const double *dfc, *pw;
+    int nb;
+    const Cx<R> *Ylast;
+    int n;
+    Cx<R> *wx;
+    PitCtrl *c;
+    float *host_view;
+    int nrow;
+    const float *devmax;
+    int ndev;
+    double safety;
+    const float2 *Ye;
+    float2 *Yprev;
+    int ne, ncol_e;
+    const double *theta;
+    const int64_t *modes_dev;
+    int ntot_w, S, sym, corr_wanted;
+};
+// (256 threads of ONE block: the kernel below, or the last block of pit_devest_kernel to finish)
+template <typename R> __device__ __forceinline__ void pit_decide_body(const PitDecideArgs<R> &a)
 {
-    if (c->done) return;
+    const double *dfc = a.dfc; const int nb = a.nb; const Cx<R> *Ylast = a.Ylast; const int n = a.n; Cx<R> *wx = a.wx; PitCtrl *c = a.c; float *host_view = a.host_view;
+    const int nrow = a.nrow; const float *devmax = a.devmax; const int ndev = a.ndev; const double safety = a.safety; const float2 *Ye = a.Ye; float2 *Yprev = a.Yprev;
+    const int ne = a.ne, ncol_e = a.ncol_e; const double *theta = a.theta; const int64_t *modes_dev = a.modes_dev; const int ntot_w = a.ntot_w, S = a.S, sym = a.sym, corr_wanted = a.corr_wanted;
+    // the fields of the control block the decision reads, fetched now (uniform loads, one round trip under the reductions below;
+    // read one by one between the stores at the end they were most of this function's time)
+    const int p = c->passes, corr_on0 = c->corr_on;
+    const double c_out_power = c->out_power, c_gain = c->gain, c_power = c->power, c_mu = c->mu, c_tol = c->tol;
+    const double c_seg_len = (double)c->seg_len;
+    const int pl = p - 1 < QH_PIT_MAXPASS ? p - 1 : QH_PIT_MAXPASS - 1, pl2 = p - 2 < QH_PIT_MAXPASS ? p - 2 : QH_PIT_MAXPASS - 1;
+    const double drms1 = p >= 1 ? c->deviation_rms[pl] : 0.0, drms2 = p >= 2 ? c->deviation_rms[pl2] : 0.0, dfc2 = p >= 2 ? c->defect[pl2] : 0.0;
     if (Yprev)                                                // eigen-space copy of this pass's result, for the next pass's "how far did the result move"
         for (int e = threadIdx.x; e < ne * nrow; e += 256) { const int k = e / nrow, j = e - k * nrow; Yprev[e] = Ye[(size_t)k * ncol_e + (ncol_e - nrow) + j]; }
     __shared__ double red[256], redd[256], reds[256], redt[256], redw[256], redm[256];
@@ -427,10 +467,9 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
         wx[e] = v;
     }
     if (threadIdx.x == 0) {
-        const int p = c->passes;
-        const bool have_dev = devmax != nullptr && c->corr_on && c->out_power > 0;
-        const double dev = have_dev ? sqrt(redd[0] / c->out_power) : -1.0;                            // worst segment
-        const double dev_rms = have_dev ? sqrt(reds[0] / ((double)(nb + nrow) * c->out_power)) : -1.0;  // rms over segments and modes
+        const bool have_dev = devmax != nullptr && corr_on0 && c_out_power > 0;
+        const double dev = have_dev ? sqrt(redd[0] / c_out_power) : -1.0;                            // worst segment
+        const double dev_rms = have_dev ? sqrt(reds[0] / ((double)(nb + nrow) * c_out_power)) : -1.0;  // rms over segments and modes
         // taps: rms over segments of |D[s]| / |w|, |w|^2 = the squared tap norm of one output mode (mean over the modes that have taps)
         const double wnorm2 = redw[0] / (double)(nrow > 0 ? nrow : 1);
         const double dev_tap = (have_dev && wnorm2 > 0) ? sqrt(redt[0] / ((double)(nb + nrow) * wnorm2)) : -1.0;
@@ -451,36 +490,42 @@ __global__ void __launch_bounds__(256) pit_decide_kernel(const double *dfc, cons
         }
         else {
             double amp = 1.0;
-            if (c->gain > 0 && c->power > 0 && c->mu > 0) {
-                const double gl = c->gain * 2.0 * c->power, a = c->mu * (double)c->seg_len * gl;
+            if (c_gain > 0 && c_power > 0 && c_mu > 0) {
+                const double gl = c_gain * 2.0 * c_power, a = c_mu * c_seg_len * gl;
                 if (a > 0) amp = (1.0 - exp(-0.2 * gl)) / (1.0 - exp(-a));
                 if (!(amp > 1.0)) amp = 1.0;
             }
             crit = red[0] * amp;
         }
-        const int pl = p - 1 < QH_PIT_MAXPASS ? p - 1 : QH_PIT_MAXPASS - 1, pl2 = p - 2 < QH_PIT_MAXPASS ? p - 2 : QH_PIT_MAXPASS - 1;
         // the correction is given up only when the estimate has GROWN two passes in a row (a model that drives the iteration apart);
         // a pass without progress is not a reason - plain relaxation leaves the weakly excited directions where they are
-        if (have_dev && p >= 2 && p < QH_PIT_MAXPASS && c->deviation_rms[pl] > 0 && c->deviation_rms[pl2] > 0 && dev_rms > 1.5 * c->deviation_rms[pl] &&
-            c->deviation_rms[pl] > 1.5 * c->deviation_rms[pl2]) c->corr_on = 0;
+        if (have_dev && p >= 2 && p < QH_PIT_MAXPASS && drms1 > 0 && drms2 > 0 && dev_rms > 1.5 * drms1 && drms1 > 1.5 * drms2) c->corr_on = 0;
         // Certified only by the deviation estimate when a coarse model exists: small boundary defects alone say nothing about the
         // weakly excited directions (round 2's defect rule certified 64-QAM mrde runs whose taps were 3e-2 off).  Without a model
         // (more than 96 taps per output mode) the defect rule is all there is.
-        if (crit < c->tol && (have_dev || !corr_wanted)) { c->converged = 1; c->done = 1; }
+        int done = 0;
+        if (crit < c_tol && (have_dev || !corr_wanted)) { c->converged = 1; done = 1; }
         // nothing gained over two passes: the trajectory has no fixed point the passes can agree on (a stage that cannot track the
         // carrier) - stop, NOT converged; further passes would only cost time.  (Slow but steady gains - rde's ring decisions - go on
         // to max_passes: the uncertified result keeps improving with them.)
         else if (p >= 2 && p < QH_PIT_MAXPASS) {
-            const bool use_dev = have_dev && c->deviation_rms[pl2] > 0;
-            const double prev2 = use_dev ? c->deviation_rms[pl2] : c->defect[pl2], now = use_dev ? dev_rms : red[0];
-            if (!(now < prev2)) c->done = 1;
+            const bool use_dev = have_dev && drms2 > 0;
+            const double prev2 = use_dev ? drms2 : dfc2, now = use_dev ? dev_rms : red[0];
+            if (!(now < prev2)) done = 1;
         }
+        if (done) c->done = 1;
         // what the host reads after the pass: criterion (to decide whether the pass after the next one is worth enqueueing early), then
         // the flag it polls for (host_view is pinned, coherent host memory: no copy kernel, no event in between)
         host_view[1] = (float)crit;
         __threadfence_system();
-        __hip_atomic_store(&host_view[0], c->done ? 1.f : 0.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_view[0], done ? 1.f : 0.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+template <typename R> __global__ void __launch_bounds__(256) pit_decide_kernel(PitDecideArgs<R> a)
+{
+    if (a.c->done) return;
+    pit_decide_body<R>(a);
 }
 
 // Error trace of the final pass into the frame of segment 0 (functions with a continuous symmetry only, see pit_decide_kernel):
@@ -952,88 +997,93 @@ __global__ void __launch_bounds__(256) pit_basis_gemm_kernel(const Zf *A2, const
     }
 }
 
-// The same two products on the matrix cores: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: exact single precision at the vector
+// The same two products on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: exact single precision at the vector
 // rate, MI355X_MICROARCH.md) - the one place on this path where the work IS a dense GEMM: (n x n) x (n x S nsel), n = nmodes ntaps = 82,
-// thousands of columns.  A block of 3 waves takes 32 columns; wave w owns output rows 32 w .. 32 w + 31 (n padded to 96).  Complex
-// product from three real accumulators: rr += Ar Br, ii += Ai Bi, im += Ar Bi + Ai Br (C = rr - ii + i im): 4 MFMAs per pair of k,
-// fed by two 8-byte LDS reads per lane (operand layout: A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31]; C/D:
-// column lane & 31, row (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).  41 steps x 4 x 64 cycles = 4.4 us of MFMA issue per tile; with
-// staging ~8 us at 7936 columns against ~25 us of the register-blocked VALU form above (which stays as QAMPY_HIP_PIT_GEMM=valu).
-typedef float pit_f16 __attribute__((ext_vector_type(16)));
-constexpr int PIT_MW = PIT_EIGMAX / 32, PIT_MT = 64 * PIT_MW;      // waves / threads of a block of the MFMA products: one wave per 32 output rows
-inline size_t pit_mfma_lds(int n) { return ((size_t)(n + 2) * PIT_BP + (size_t)PIT_NC * (PIT_EIGMAX + 1)) * sizeof(Zf); }
+// thousands of columns, and what matters is its LATENCY (it sits between two passes).  A block takes 16 columns, wave w of its
+// ceil(n / 16) waves the output rows 16 w .. 16 w + 15: 224 blocks of 6 waves at C3 - every CU busy, 23 k-steps x 4 MFMAs x 32 cycles
+// = 1.2 us of MFMA issue per wave (the 32x32x2 tiling of the first version: 112 blocks, 4.8 us per wave, 18-22 us per product).
+// Complex product from three real accumulators: rr += Ar Br, ii += Ai Bi, im += Ar Bi + Ai Br (C = rr - ii + i im).  Operand
+// layout: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]; C/D: column lane & 15, row 4 (lane >> 4) + reg.
+// (The register-blocked VALU form above stays as QAMPY_HIP_PIT_GEMM=valu.)
+typedef float pit_f4 __attribute__((ext_vector_type(4)));
+constexpr int PIT_MC = 16, PIT_MBP = PIT_MC + 1;               // columns per block, row pitch of the B tile in LDS
+inline int pit_mfma_threads(int n) { return 64 * ((n + 15) / 16); }
+inline size_t pit_mfma_lds(int n) { return ((size_t)(n + 4) * PIT_MBP + (size_t)PIT_MC * (PIT_EIGMAX + 1)) * sizeof(Zf); }
 template <typename R, int MODE>
-__global__ void __launch_bounds__(PIT_MT) pit_basis_mfma_kernel(const Zf *__restrict__ A2, const Cx<R> *__restrict__ T, const Zf *__restrict__ D, Zf *__restrict__ Out, int n, int ncol,
-                                                             const PitCtrl *c, PitFuse<R> fz)
+__global__ void __launch_bounds__(64 * (PIT_EIGMAX / 16)) pit_basis_mfma_kernel(const Zf *__restrict__ A2, const Cx<R> *__restrict__ T, const Zf *__restrict__ D, Zf *__restrict__ Out,
+                                                                               int n, int ncol, const PitCtrl *c, PitFuse<R> fz)
 {
     if (c->done) return;
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
-    const int np = (n + 1) & ~1;                              // contraction length padded to whole MFMA steps (zero rows)
-    Zf *Bs = reinterpret_cast<Zf *>(pit_smem);                // [np][PIT_BP]
-    Zf *Ct = Bs + (size_t)(n + 2) * PIT_BP;                   // [PIT_NC][PIT_EIGMAX + 1] (MODE 1: transposition of the result)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int col0 = blockIdx.x * PIT_NC;
+    const int np = (n + 3) & ~3;                              // contraction length padded to whole MFMA steps (zero rows)
+    Zf *Bs = reinterpret_cast<Zf *>(pit_smem);                // [np][PIT_MBP]
+    Zf *Ct = Bs + (size_t)(n + 4) * PIT_MBP;                  // [PIT_MC][PIT_EIGMAX + 1] (MODE 1: transposition of the result)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
+    const int col0 = blockIdx.x * PIT_MC;
     const size_t wset = (size_t)fz.nmodes * n;
     // op(A) - 54 KB, the same for every block and launch, L2 resident - goes from global memory straight into the A operand
-    // (lane: row 32 wave + (lane & 31), k + (lane >> 5); 8 steps prefetched), the B tile through LDS (shared by the three waves)
-    const int am = 32 * wave + (lane & 31), ak = lane >> 5;
+    // (lane: row 16 wave + (lane & 15), k + (lane >> 4); 8 steps prefetched), the B tile through LDS (shared by the waves)
+    const int am = 16 * wave + (lane & 15), ak = lane >> 4;
     const Zf *ag = A2 + (size_t)ak * n + am;
     auto lda = [&](int k) -> Zf { return (am < n && k + ak < n) ? ag[(size_t)k * n] : Zf{0.f, 0.f}; };
     constexpr int PF = 8;
     Zf abuf[PF];
 #pragma unroll
-    for (int i = 0; i < PF; i++) abuf[i] = lda(2 * i);
-    // B tile (no integer divisions in the loops: they cost more than the loads)
+    for (int i = 0; i < PF; i++) abuf[i] = lda(4 * i);
+    constexpr int NCW = 3;                                      // columns per wave in the column-wise phases: ceil(16 / nw), nw >= 6 ... (nw < 6: loop)
     if (MODE == 0) {
-        // wave w: columns w, w + 3, ...; lanes: f = lane, lane + 64 (one column's taps are contiguous: coalesced); all 11 columns of a
-        // wave in flight together - one round trip to L2 / HBM for the whole tile
-        constexpr int NCB = (PIT_NC + PIT_MW - 1) / PIT_MW;
-        Zf tmp[NCB][2];
+        // wave w: columns w, w + nw, ...; lanes: f = lane, lane + 64 (one column's taps are contiguous: coalesced); all loads in flight together
+        for (int cb = 0; cb < PIT_MC; cb += NCW * nw) {
+            Zf tmp[NCW][2];
 #pragma unroll
-        for (int q = 0; q < NCB; q++) {
-            const int cc = wave + PIT_MW * q, col = col0 + cc;
-            tmp[q][0] = Zf{0.f, 0.f}; tmp[q][1] = Zf{0.f, 0.f};
-            if (cc < PIT_NC && col < ncol) {
-                const int s = col / fz.nsel, j = col - s * fz.nsel;               // wave-uniform
-                const Cx<R> *src = T + (size_t)s * wset + (size_t)fz.modes_dev[j] * n;
-                if (lane < n) { const Cx<R> t = src[lane]; tmp[q][0] = Zf{(float)t.re, (float)t.im}; }
-                if (lane + 64 < n) { const Cx<R> t = src[lane + 64]; tmp[q][1] = Zf{(float)t.re, (float)t.im}; }
+            for (int q = 0; q < NCW; q++) {
+                const int cc = cb + wave + nw * q, col = col0 + cc;
+                tmp[q][0] = Zf{0.f, 0.f}; tmp[q][1] = Zf{0.f, 0.f};
+                if (cc < PIT_MC && col < ncol) {
+                    const int s = col / fz.nsel, j = col - s * fz.nsel;               // wave-uniform
+                    const Cx<R> *src = T + (size_t)s * wset + (size_t)fz.modes_dev[j] * n;
+                    if (lane < n) { const Cx<R> t = src[lane]; tmp[q][0] = Zf{(float)t.re, (float)t.im}; }
+                    if (lane + 64 < n) { const Cx<R> t = src[lane + 64]; tmp[q][1] = Zf{(float)t.re, (float)t.im}; }
+                }
             }
-        }
 #pragma unroll
-        for (int q = 0; q < NCB; q++) {
-            const int cc = wave + PIT_MW * q;
-            if (cc < PIT_NC) {
-                if (lane < np) Bs[lane * PIT_BP + cc] = tmp[q][0];
-                if (lane + 64 < np) Bs[(lane + 64) * PIT_BP + cc] = tmp[q][1];
+            for (int q = 0; q < NCW; q++) {
+                const int cc = cb + wave + nw * q;
+                if (cc < PIT_MC) {
+                    if (lane < np) Bs[lane * PIT_MBP + cc] = tmp[q][0];
+                    if (lane + 64 < np) Bs[(lane + 64) * PIT_MBP + cc] = tmp[q][1];
+                }
             }
         }
     } else {
-        // thread: column tid & 31, rows tid >> 5, + PIT_MT / 32, ...: a row of the tile is 256 contiguous bytes; all 16 rows of a thread in flight
-        const int cc = tid & 31, k0 = tid >> 5;
+        // thread: column tid & 15, rows tid >> 4, + nt / 16, ...: a row of the tile is 128 contiguous bytes; up to 8 rows of a thread in flight
+        const int cc = tid & 15, k0 = tid >> 4, kstep = nt >> 4;
         const bool okc = col0 + cc < ncol;
-        Zf tmp[16];
+        for (int kb = 0; kb < np; kb += 8 * kstep) {
+            Zf tmp[8];
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int k = k0 + (PIT_MT / 32) * q;
-            tmp[q] = (okc && k < n) ? D[(size_t)k * ncol + col0 + cc] : Zf{0.f, 0.f};
-        }
+            for (int q = 0; q < 8; q++) {
+                const int k = kb + k0 + kstep * q;
+                tmp[q] = (okc && k < n) ? D[(size_t)k * ncol + col0 + cc] : Zf{0.f, 0.f};
+            }
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int k = k0 + (PIT_MT / 32) * q;
-            if (k < np) Bs[k * PIT_BP + cc] = tmp[q];
+            for (int q = 0; q < 8; q++) {
+                const int k = kb + k0 + kstep * q;
+                if (k < np) Bs[k * PIT_MBP + cc] = tmp[q];
+            }
         }
     }
-    // MODE 1: the start taps and frames the epilogue combines with the product are fetched now, under the MFMAs
-    constexpr int NCW = (PIT_NC + PIT_MW - 1) / PIT_MW;
+    // MODE 1: the start taps and frames the epilogue combines with the product are fetched now, under the MFMAs (nw >= 6 waves: up to 3
+    // columns per wave; fewer waves - small n - fetch in the epilogue)
+    const bool pre = MODE == 1 && NCW * nw >= PIT_MC;
     Cx<R> xv[MODE == 1 ? NCW : 1][2];
     double th[MODE == 1 ? NCW : 1][2];
-    if (MODE == 1) {
+    if (pre) {
 #pragma unroll
         for (int q = 0; q < NCW; q++) {
-            const int cc = wave + PIT_MW * q, col = col0 + cc;
+            const int cc = wave + nw * q, col = col0 + cc;
             xv[q][0] = Cx<R>{0, 0}; xv[q][1] = Cx<R>{0, 0}; th[q][0] = 1; th[q][1] = 0;
-            if (cc < PIT_NC && col < ncol) {
+            if (cc < PIT_MC && col < ncol) {
                 const int s = col / fz.nsel, j = col - s * fz.nsel;
                 const size_t base = (size_t)s * wset + (size_t)fz.modes_dev[j] * n;
                 th[q][0] = fz.theta[2 * (size_t)col]; th[q][1] = fz.theta[2 * (size_t)col + 1];
@@ -1043,59 +1093,59 @@ __global__ void __launch_bounds__(PIT_MT) pit_basis_mfma_kernel(const Zf *__rest
         }
     }
     __syncthreads();
-    pit_f16 rr, ii, im;
-#pragma unroll
-    for (int q = 0; q < 16; q++) { rr[q] = 0.f; ii[q] = 0.f; im[q] = 0.f; }
-    const Zf *bp = Bs + (lane >> 5) * PIT_BP + (lane & 31);
-    for (int k0 = 0; k0 < np && 32 * wave < n; k0 += 2 * PF) {     // (a wave whose 32 rows are all padding has nothing to multiply)
+    pit_f4 rr = {0.f, 0.f, 0.f, 0.f}, ii = rr, im = rr;
+    const Zf *bp = Bs + (lane >> 4) * PIT_MBP + (lane & 15);
+    for (int k0 = 0; k0 < np; k0 += 4 * PF) {
 #pragma unroll
         for (int i = 0; i < PF; i++) {
-            const int k = k0 + 2 * i;
+            const int k = k0 + 4 * i;
             if (k < np) {                                       // block-uniform
                 Zf a = abuf[i];
-                abuf[i] = lda(k + 2 * PF);
+                abuf[i] = lda(k + 4 * PF);
                 if (MODE == 0) a.y = -a.y;                      // V^H
-                const Zf b = bp[(size_t)k * PIT_BP];
-                rr = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, rr, 0, 0, 0);
-                ii = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, ii, 0, 0, 0);
-                im = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.y, im, 0, 0, 0);
-                im = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.x, im, 0, 0, 0);
+                const Zf b = bp[(size_t)k * PIT_MBP];
+                rr = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, rr, 0, 0, 0);
+                ii = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, ii, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.y, im, 0, 0, 0);
+                im = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.x, im, 0, 0, 0);
             }
         }
     }
-    const int cl = lane & 31;
+    const int cl = lane & 15;
     if (MODE == 0) {
         const int col = col0 + cl;
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int m = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            if (m < n && col < ncol) Out[(size_t)m * ncol + col] = Zf{rr[q] - ii[q], im[q]};      // 32 consecutive columns per half wave
+        for (int q = 0; q < 4; q++) {
+            const int m = 16 * wave + 4 * (lane >> 4) + q;
+            if (m < n && col < ncol) Out[(size_t)m * ncol + col] = Zf{rr[q] - ii[q], im[q]};      // 16 consecutive columns per quarter wave
         }
     } else {
         // X[s] = Y[s] = theta_s X[s] + C[.][col]: through LDS, so that the tap sets are written along m (their fast axis)
 #pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int m = 32 * wave + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        for (int q = 0; q < 4; q++) {
+            const int m = 16 * wave + 4 * (lane >> 4) + q;
             Ct[cl * (PIT_EIGMAX + 1) + m] = Zf{rr[q] - ii[q], im[q]};
         }
         __syncthreads();
-        // wave: columns wave, wave + 3, ...; lanes along m (the tap sets' fast axis); X and theta of its columns were fetched before the product
+        // wave: columns wave, wave + nw, ...; lanes along m (the tap sets' fast axis)
+        for (int cb = 0; cb < PIT_MC; cb += NCW * nw) {
 #pragma unroll
-        for (int q = 0; q < NCW; q++) {
-            const int cc = wave + PIT_MW * q, col = col0 + cc;
-            if (cc < PIT_NC && col < ncol) {
-                const int s = col / fz.nsel, j = col - s * fz.nsel;
-                const size_t base = (size_t)s * wset + (size_t)fz.modes_dev[j] * n;
-                const double qr = th[q][0], qi = th[q][1];
+            for (int q = 0; q < NCW; q++) {
+                const int cc = cb + wave + nw * q, col = col0 + cc;
+                if (cc < PIT_MC && col < ncol) {
+                    const int s = col / fz.nsel, j = col - s * fz.nsel;
+                    const size_t base = (size_t)s * wset + (size_t)fz.modes_dev[j] * n;
+                    const double qr = pre ? th[q][0] : fz.theta[2 * (size_t)col], qi = pre ? th[q][1] : fz.theta[2 * (size_t)col + 1];
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int m = lane + 64 * h;
-                    if (m < n) {
-                        const Cx<R> x = xv[q][h];
-                        const Zf d = Ct[cc * (PIT_EIGMAX + 1) + m];
-                        const Cx<R> w{(R)(qr * x.re - qi * x.im + d.x), (R)(qr * x.im + qi * x.re + d.y)};
-                        fz.X[base + m] = w;
-                        fz.Y[base + m] = w;
+                    for (int h = 0; h < 2; h++) {
+                        const int m = lane + 64 * h;
+                        if (m < n) {
+                            const Cx<R> x = pre ? xv[q][h] : fz.X[base + m];
+                            const Zf d = Ct[cc * (PIT_EIGMAX + 1) + m];
+                            const Cx<R> w{(R)(qr * x.re - qi * x.im + d.x), (R)(qr * x.im + qi * x.re + d.y)};
+                            fz.X[base + m] = w;
+                            fz.Y[base + m] = w;
+                        }
                     }
                 }
             }
@@ -1323,23 +1373,25 @@ __global__ void __launch_bounds__(256) pit_recur_kernel(Zf *D, const double *lam
 // end taps of segment s-1 (yB ~ g_s yA, from the defect kernel) is not an error: theta_s = g_1 ... g_s brings every segment
 // into the frame of segment 0, where the boundary defects are formed and corrected (a rotation treated as an additive
 // defect would be wrong in second order and keep the iteration from converging below ~theta^2).
+constexpr int PIT_GT_THREADS = 1024;
 template <typename R>
-__global__ void __launch_bounds__(256) pit_gauge_kernel(const double *gph, int S, int nsel, PitCtrl *c, double *theta, const double *pw, int nb, int method, const Cx<R> *sy0,
-                                                        int want_corr)
+__global__ void __launch_bounds__(PIT_GT_THREADS) pit_gauge_kernel(const double *gph, int S, int nsel, PitCtrl *c, double *theta, const double *pw, int nb, int method, const Cx<R> *sy0,
+                                                                   int want_corr)
 {
     if (c->done) return;
+    constexpr int NT = PIT_GT_THREADS;
+    __shared__ double redp[NT / 64];
+    __shared__ double2 gbuf[NT / 64];
     if (c->passes == 0) {                                     // first pass of a sweep: mean output power -> gain of the linearised map (the scan below needs it)
-        __shared__ double redp[256];
         double ps = 0;
-        for (int i = threadIdx.x; i < nb; i += 256) ps += pw[i];
-        redp[threadIdx.x] = ps;
+        for (int i = threadIdx.x; i < nb; i += NT) ps += pw[i];
+        for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o);
+        if ((threadIdx.x & 63) == 0) redp[threadIdx.x >> 6] = ps;
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (threadIdx.x < s) redp[threadIdx.x] += redp[threadIdx.x + s];
-            __syncthreads();
-        }
         if (threadIdx.x == 0) {
-            const double Py = redp[0] / (nb > 0 ? nb : 1);
+            double tot = 0;
+            for (int w = 0; w < NT / 64; w++) tot += redp[w];
+            const double Py = tot / (nb > 0 ? nb : 1);
             const double g = pit_gain<R>(method, Py, sy0[0]);
             c->out_power = Py; c->gain = g;
             c->corr_on = (want_corr && g > 0 && g == g) ? 1 : 0;
@@ -1347,27 +1399,55 @@ __global__ void __launch_bounds__(256) pit_gauge_kernel(const double *gph, int S
         __syncthreads();
     }
     // theta_s = g_1 ... g_s as a running PRODUCT of unit complex numbers (chunk per thread, scan of the chunk products):
-    // no angles, no trigonometry; renormalised on output
-    __shared__ double2 gbuf[512];
-    const int len = (S + 255) / 256;
+    // no angles, no trigonometry; renormalised on output.  Up to 4 segments per thread: every load is issued before the first use.
+    const int len = (S + NT - 1) / NT;
     const int s0 = threadIdx.x * len, s1 = s0 + len < S ? s0 + len : S;
     auto cm = [](double2 x, double2 y) { return double2{x.x * y.x - x.y * y.y, x.x * y.y + x.y * y.x}; };
+    const double2 *g2 = reinterpret_cast<const double2 *>(gph);
+    double2 *th2 = reinterpret_cast<double2 *>(theta);
+    if (len <= 4 && nsel <= 2) {
+        double2 g[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int s = s0 + q;
+                g[j][q] = (j < nsel && s < s1 && s > 0) ? g2[(size_t)(s - 1) * nsel + j] : double2{1.0, 0.0};
+            }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (j >= nsel) break;
+            const double2 prod = cm(cm(g[j][0], g[j][1]), cm(g[j][2], g[j][3]));
+            double2 run = block_scan_excl<double2, decltype(cm), NT>(prod, cm, double2{1.0, 0.0}, gbuf);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int s = s0 + q;
+                run = cm(run, g[j][q]);
+                if (s < s1) {
+                    const double r = rsqrt(run.x * run.x + run.y * run.y);
+                    th2[(size_t)s * nsel + j] = double2{run.x * r, run.y * r};
+                }
+            }
+        }
+        return;
+    }
     for (int j = 0; j < nsel; j++) {
         double2 prod{1.0, 0.0};
         for (int s = s0; s < s1; s++)
-            if (s > 0) prod = cm(prod, double2{gph[2 * ((size_t)(s - 1) * nsel + j)], gph[2 * ((size_t)(s - 1) * nsel + j) + 1]});
-        double2 run = block_scan_excl<double2>(prod, cm, double2{1.0, 0.0}, gbuf);
+            if (s > 0) prod = cm(prod, g2[(size_t)(s - 1) * nsel + j]);
+        double2 run = block_scan_excl<double2, decltype(cm), NT>(prod, cm, double2{1.0, 0.0}, gbuf);
         for (int s = s0; s < s1; s++) {
-            if (s > 0) run = cm(run, double2{gph[2 * ((size_t)(s - 1) * nsel + j)], gph[2 * ((size_t)(s - 1) * nsel + j) + 1]});
+            if (s > 0) run = cm(run, g2[(size_t)(s - 1) * nsel + j]);
             const double r = rsqrt(run.x * run.x + run.y * run.y);
-            theta[2 * ((size_t)s * nsel + j)] = run.x * r; theta[2 * ((size_t)s * nsel + j) + 1] = run.y * r;
+            th2[(size_t)s * nsel + j] = double2{run.x * r, run.y * r};
         }
     }
 }
 // Output power of the accumulated corrections: dev2[col] = sum_k lambda_k |D~_k[col]|^2 (D~ in the eigenbasis, after the scan), the
 // block's maximum -> devmax[blockIdx.x].  D~[s] is the first-order estimate of how far the start taps of segment s are from the
 // sequential trajectory; lambda-weighted it is the power of the output deviation they cause.
-static __global__ void __launch_bounds__(256) pit_devest_kernel(const Zf *D, const double *lam, int n, int ncol, const PitCtrl *c, float *devmax)
+template <typename R>
+__global__ void __launch_bounds__(256) pit_devest_kernel(const Zf *D, const double *lam, int n, int ncol, const PitCtrl *c, float *devmax, unsigned *ticket, PitDecideArgs<R> da)
 {
     if (c->done) return;
     // 64 columns per block, 4 threads per column (each a quarter of the k, loads of consecutive columns coalesce and overlap)
@@ -1407,6 +1487,18 @@ static __global__ void __launch_bounds__(256) pit_devest_kernel(const Zf *D, con
     if (threadIdx.x == 0) {                                       // worst column / sum over the columns of the output power; sum / worst column of the tap norm
         devmax[4 * blockIdx.x] = red[0]; devmax[4 * blockIdx.x + 1] = reds[0]; devmax[4 * blockIdx.x + 2] = redt[0]; devmax[4 * blockIdx.x + 3] = redm[0];
     }
+    // The block that finishes last takes the decision of the pass (one launch less per pass): results released device-wide, a ticket
+    // drawn; whoever draws the last one acquires and goes on.
+    __shared__ int last;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned t = atomicAdd(ticket, 1u);
+        last = t == gridDim.x - 1;
+        if (last) { *ticket = 0; __threadfence(); }
+    }
+    __syncthreads();
+    if (!last) return;
+    pit_decide_body<R>(da);
 }
 // ------------------------------------------------------------------------------------------------ host side
 // kernel time of the most recent call (HIP events around the trainer launches; the host synchronises after each anyway)
@@ -1641,14 +1733,16 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     void *wbuf = nullptr;
     const size_t nsj = (size_t)sg.S * nsel;
     const size_t bytes_w = ((2 * (size_t)sg.S + 1) * wbytes + 63) / 64 * 64;
-    if ((rc = scratch(2, bytes_w + 10 * nsj * sizeof(double) + (size_t)nsel * sizeof(int64_t) + 320 + nsj * 16 + 4 * ((nsj + 63) / 64) * sizeof(float), &wbuf))) return rc;
+    if ((rc = scratch(2, bytes_w + 10 * nsj * sizeof(double) + (size_t)nsel * sizeof(int64_t) + 320 + nsj * 16 + 4 * ((nsj + 63) / 64) * sizeof(float) + 64, &wbuf))) return rc;
     Cx<R> *X = (Cx<R> *)wbuf, *Y = X + (size_t)sg.S * wset, *w_start = Y + (size_t)sg.S * wset;
     double *z = (double *)((char *)wbuf + bytes_w), *rot = z + 2 * nsj, *dfc = rot + 2 * nsj, *pw = dfc + nsj, *gph = pw + nsj, *theta = gph + 2 * nsj;
     int64_t *modes_dev = (int64_t *)(theta + 2 * nsj);
     double *uw_phi = (double *)(modes_dev + ((nsel + 7) / 8 * 8));
     int *uw_jump = (int *)(uw_phi + (size_t)sg.S * nsel);
     float *devmax = (float *)(uw_jump + (size_t)sg.S * nsel);                    // per-block maxima of the deviation estimate (ndev of them)
-    const int ndev = (int)((nsj + 63) / 64);                     // (three floats per block: worst column, sum, sum of the tap norms)
+    const int ndev = (int)((nsj + 63) / 64);                     // (four floats per block: worst column, sum, sum / worst of the tap norms)
+    unsigned *ticket = (unsigned *)(devmax + 4 * (size_t)ndev);  // pit_devest_kernel: which block finishes last
+    QH_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned), g_stream));
     QH_HIP(hipMemcpyAsync(modes_dev, modes, (size_t)nsel * sizeof(int64_t), hipMemcpyHostToDevice, g_stream));
     QH_HIP(hipStreamSynchronize(g_stream));                       // `modes` is the caller's memory
 
@@ -1784,6 +1878,13 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         // HIP events around the trainer launch of a pass (qh_pit_last_timing): an event is ~5.6 us of idle stream, so by default only
         // pass 1 of a sweep is timed (pass 0 of a cold sweep shares the chip with the basis build); QAMPY_HIP_PIT_TIMING = all | none
         static const int timing_mode = [] { const char *e = getenv("QAMPY_HIP_PIT_TIMING"); return !e ? 1 : (e[0] == 'a' ? 2 : (e[0] == 'n' ? 0 : 1)); }();
+        auto decide_args = [&](int p, const float *dm, const float2 *ye, float2 *yprev, int ne, int ncol_e, int corr_wanted) {
+            PitDecideArgs<R> d;
+            d.dfc = dfc; d.pw = pw; d.nb = (int)((sg.S - 1) * nsel); d.Ylast = (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset); d.n = (int)wset; d.wx = (Cx<R> *)wx; d.c = ctrl;
+            d.host_view = &ev.hview[2 * p]; d.nrow = nsel; d.devmax = dm; d.ndev = ndev; d.safety = safety; d.Ye = ye; d.Yprev = yprev; d.ne = ne; d.ncol_e = ncol_e;
+            d.theta = theta; d.modes_dev = (const int64_t *)modes_dev; d.ntot_w = ntot; d.S = (int)sg.S; d.sym = sym; d.corr_wanted = corr_wanted;
+            return d;
+        };
         auto timed = [&](int p) { return timing_mode == 2 || (timing_mode == 1 && p == 1); };
         auto enqueue_pass = [&](int p) -> int {
             ((volatile float *)ev.hview)[2 * p] = -1.f;             // "not decided yet": pit_decide_kernel overwrites it (polled below)
@@ -1793,7 +1894,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 // start taps = theta X + V D~ with D[s+1] = d[s+1] + J D[s] from the analysis that closed pass p - 1 (below); with the
                 // correction switched off on the device (corr_on = 0) the scan ran with coefficient 0, D = d: plain relaxation
                 if (eig && !gemm_valu)
-                    hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 1>), dim3((ncol + PIT_NC - 1) / PIT_NC), dim3(PIT_MT), pit_mfma_lds(ntot), g_stream, Vb + (size_t)ntot * ntot,
+                    hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 1>), dim3((ncol + PIT_MC - 1) / PIT_MC), dim3(pit_mfma_threads(ntot)), pit_mfma_lds(ntot), g_stream, Vb + (size_t)ntot * ntot,
                                        (const Cx<R> *)nullptr, (const Zf *)Dz[1], (Zf *)nullptr, ntot, ncol, (const PitCtrl *)ctrl, fz);
                 else if (eig)
                     hipLaunchKernelGGL((pit_basis_gemm_kernel<R, 1>), dim3((ncol + PIT_NC - 1) / PIT_NC), dim3(256), pit_gemm_lds(ntot), g_stream, Vb + (size_t)ntot * ntot,
@@ -1849,26 +1950,24 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 const dim3 ggrid((ncol + PIT_NC - 1) / PIT_NC);
                 auto forward = [&](const Cx<R> *src, Zf *dst) {      // dst = V^H src
                     if (gemm_valu) hipLaunchKernelGGL((pit_basis_gemm_kernel<R, 0>), ggrid, dim3(256), pit_gemm_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
-                    else hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 0>), ggrid, dim3(PIT_MT), pit_mfma_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
+                    else hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 0>), dim3((ncol + PIT_MC - 1) / PIT_MC), dim3(pit_mfma_threads(ntot)), pit_mfma_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
                 };
                 if (p == 0) forward((const Cx<R> *)X, Xe);           // start taps of the sweep into the eigenbasis (kept up to date from here on)
                 forward((const Cx<R> *)Y, Ye);
                 hipLaunchKernelGGL(pit_bound_kernel, dim3((nbnd + nsel + 3) / 4), dim3(256), 0, g_stream, (const Zf *)Xe, (const Zf *)Ye, (const Zf *)Yprev, lam, ntot, sg.S, nsel, sym,
                                    (const PitCtrl *)ctrl, dfc, pw, gph);
-                hipLaunchKernelGGL((pit_gauge_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)gph, sg.S, nsel, ctrl, theta, (const double *)pw,
+                hipLaunchKernelGGL((pit_gauge_kernel<R>), dim3(1), dim3(PIT_GT_THREADS), 0, g_stream, (const double *)gph, sg.S, nsel, ctrl, theta, (const double *)pw,
                                    nbnd, method, (const Cx<R> *)symbols + (size_t)modes[0] * nsy, 1);
                 hipLaunchKernelGGL((pit_recur_eig_kernel<R>), dim3(ntot, nsel), dim3(PIT_RT), 0, g_stream, Xe, (const Zf *)Ye, Dz[1], (const double *)theta, lam, nsel, sg.S, sg.len,
                                    (const R *)mu_dev, beta, (const PitCtrl *)ctrl);
-                hipLaunchKernelGGL(pit_devest_kernel, dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax);
-                hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, nbnd,
-                                   (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, ctrl, &ev.hview[2 * p], nsel, (const float *)devmax, ndev, safety,
-                                   (const float2 *)Ye, (float2 *)Yprev, ntot, ncol, (const double *)theta, (const int64_t *)modes_dev, ntot, sg.S, sym, 1);
+                hipLaunchKernelGGL((pit_devest_kernel<R>), dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax, ticket,
+                                   decide_args(p, (const float *)devmax, (const float2 *)Ye, (float2 *)Yprev, ntot, ncol, 1));
             } else {
             const size_t dlds = (2 * (size_t)ntot + (size_t)nmodes * os * pit_phase_pitch(ntaps, os, PIT_PROBE)) * sizeof(Cx<R>);
             QH_REQUIRE(dlds <= 60 * 1024, "train_equaliser: boundary probe does not fit the LDS for this filter shape");
             hipLaunchKernelGGL((pit_defect_kernel<R>), dim3(sg.S, nsel), dim3(PIT_PROBE), dlds, g_stream, (const Cx<R> *)E, nmodes, L, os,
                                ntaps, sg, TrSyms, (const int64_t *)modes_dev, (const Cx<R> *)X, (const Cx<R> *)Y, sym, (const PitCtrl *)ctrl, dfc, pw, gph, (const Cx<R> *)wx);
-            hipLaunchKernelGGL((pit_gauge_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)gph, sg.S, nsel, ctrl, theta, (const double *)pw,
+            hipLaunchKernelGGL((pit_gauge_kernel<R>), dim3(1), dim3(PIT_GT_THREADS), 0, g_stream, (const double *)gph, sg.S, nsel, ctrl, theta, (const double *)pw,
                                nbnd, method, (const Cx<R> *)symbols + (size_t)modes[0] * nsy, want_corr ? 1 : 0);
             if (want_corr) {
                 if (o.basis && pit_basis_sync().pending) {           // a basis still being built on the other stream
@@ -1877,12 +1976,10 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 }
                 hipLaunchKernelGGL((pit_cgemm_kernel<R, true>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb, (const Zf *)nullptr, Dz[1], ntot, ncol, (const PitCtrl *)ctrl, fz);
                 hipLaunchKernelGGL((pit_recur_kernel<R>), dim3(ntot, nsel), dim3(256), 0, g_stream, Dz[1], lam, nsel, sg.S, sg.len, (const R *)mu_dev, beta, (const PitCtrl *)ctrl);
-                hipLaunchKernelGGL(pit_devest_kernel, dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax);
-            }
-            hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const double *)dfc, (const double *)pw, nbnd,
-                               (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset), (int)wset, (Cx<R> *)wx, ctrl, &ev.hview[2 * p], nsel,
-                               want_corr ? (const float *)devmax : (const float *)nullptr, ndev, safety, (const float2 *)nullptr, (float2 *)nullptr, 0, 0,
-                               (const double *)theta, (const int64_t *)modes_dev, ntot, sg.S, sym, want_corr ? 1 : 0);
+                hipLaunchKernelGGL((pit_devest_kernel<R>), dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax, ticket,
+                                   decide_args(p, (const float *)devmax, (const float2 *)nullptr, (float2 *)nullptr, 0, 0, 1));
+            } else
+                hipLaunchKernelGGL((pit_decide_kernel<R>), dim3(1), dim3(256), 0, g_stream, decide_args(p, (const float *)nullptr, (const float2 *)nullptr, (float2 *)nullptr, 0, 0, 0));
             }
             QH_HIP(hipGetLastError());
             return QH_OK;
@@ -1907,12 +2004,15 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             {
                 volatile float *hv = (volatile float *)ev.hview;
                 unsigned spins = 0;
+                auto t_last = std::chrono::steady_clock::now();
                 while (hv[2 * p] < 0.f) {
-                    if ((++spins & 1023u) == 0) {
-                        const hipError_t q = hipStreamQuery(g_stream);
-                        if (q == hipSuccess) { if (hv[2 * p] < 0.f) hv[2 * p] = 1.f; break; }
-                        if (q != hipErrorNotReady) QH_HIP(q);
-                    }
+                    if ((++spins & 255u) != 0) continue;
+                    const auto now = std::chrono::steady_clock::now();
+                    if (now - t_last < std::chrono::milliseconds(20)) continue;     // (a stream query puts a marker into the queue: rarely)
+                    t_last = now;
+                    const hipError_t q = hipStreamQuery(g_stream);
+                    if (q == hipSuccess) { if (hv[2 * p] < 0.f) hv[2 * p] = 1.f; break; }
+                    if (q != hipErrorNotReady) QH_HIP(q);
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
             }
