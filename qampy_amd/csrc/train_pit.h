@@ -417,11 +417,14 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
     const double drms1 = p >= 1 ? c->deviation_rms[pl] : 0.0, drms2 = p >= 2 ? c->deviation_rms[pl2] : 0.0, dfc2 = p >= 2 ? c->defect[pl2] : 0.0;
     if (Yprev)                                                // eigen-space copy of this pass's result, for the next pass's "how far did the result move"
         for (int e = threadIdx.x; e < ne * nrow; e += 256) { const int k = e / nrow, j = e - k * nrow; Yprev[e] = Ye[(size_t)k * ncol_e + (ncol_e - nrow) + j]; }
-    __shared__ double red[256], redd[256], reds[256], redt[256], redw[256], redm[256];
+    __shared__ double red[4], redd[4], reds[4], redt[4], redw[4], redm[4];
     double m = 0, dv = 0, ds = 0, dt = 0, wn = 0, dm = 0;
-    for (int i = threadIdx.x; i < nb; i += 256) {
-        const double v = dfc[i];
-        m = (v > m || !(v == v)) ? (v == v ? v : 1e30) : m;
+    for (int i0 = threadIdx.x; i0 < nb; i0 += 8 * 256) {       // eight loads in flight per thread (one by one they were most of this function's time)
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = i0 + 256 * q < nb ? dfc[i0 + 256 * q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) m = (v[q] > m || !(v[q] == v[q])) ? (v[q] == v[q] ? v[q] : 1e30) : m;
     }
     if (devmax)
         for (int i = threadIdx.x; i < ndev; i += 256) {
@@ -432,29 +435,17 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
             const double vm = (double)devmax[4 * i + 3];
             dm = (vm > dm || !(vm == vm)) ? (vm == vm ? vm : 1e30) : dm;
         }
-    for (int e = threadIdx.x; e < n; e += 256) { const Cx<R> v = Ylast[e]; wn += (double)v.re * v.re + (double)v.im * v.im; }      // |taps|^2 of all output modes
-    red[threadIdx.x] = m; redd[threadIdx.x] = dv; reds[threadIdx.x] = ds; redt[threadIdx.x] = dt; redw[threadIdx.x] = wn; redm[threadIdx.x] = dm;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
-            redd[threadIdx.x] = redd[threadIdx.x] > redd[threadIdx.x + s] ? redd[threadIdx.x] : redd[threadIdx.x + s];
-            reds[threadIdx.x] += reds[threadIdx.x + s];
-            redt[threadIdx.x] += redt[threadIdx.x + s];
-            redw[threadIdx.x] += redw[threadIdx.x + s];
-            redm[threadIdx.x] = redm[threadIdx.x] > redm[threadIdx.x + s] ? redm[threadIdx.x] : redm[threadIdx.x + s];
-        }
-        __syncthreads();
-    }
     // how far the sweep's result still moved in this pass, in output terms (pit_defect_kernel's extra block row; nrow entries after the nb boundaries)
     double chg = 0;
     for (int r = 0; r < nrow; r++) { const double v = dfc[nb + r]; chg = (v > chg || !(v == v)) ? v : chg; }
-    // The pass's result.  The functions with a continuous symmetry (cma, rde: every common phase) leave the phase of the taps free, and
-    // the end taps of the last segment sit in that segment's own frame: theta_{S-1}, the product of the boundary rotations of this pass,
-    // takes them into the frame of segment 0 - the caller's start taps, i.e. the frame of the sequential recurrence.  (A few 1e-3 rad
-    // over thousands of boundaries; the quarter-turn functions lock the phase themselves.)
+    // The pass's result (and |taps|^2 of all output modes).  The functions with a continuous symmetry (cma, rde: every common phase)
+    // leave the phase of the taps free, and the end taps of the last segment sit in that segment's own frame: theta_{S-1}, the
+    // product of the boundary rotations of this pass, takes them into the frame of segment 0 - the caller's start taps, i.e. the
+    // frame of the sequential recurrence.  (A few 1e-3 rad over thousands of boundaries; the quarter-turn functions lock the phase
+    // themselves.)  Everything this needs is there before the function starts: issued with the loads above, not after the reduction.
     for (int e = threadIdx.x; e < n; e += 256) {
         Cx<R> v = Ylast[e];
+        wn += (double)v.re * v.re + (double)v.im * v.im;
         if (sym == 0 && theta) {
             const int row = e / ntot_w;
             for (int j = 0; j < nrow; j++)
@@ -466,6 +457,22 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
         }
         wx[e] = v;
     }
+    // six reductions over the block: shuffles inside the waves, the four wave results through LDS
+    for (int o = 32; o > 0; o >>= 1) {
+        const double m2 = __shfl_xor(m, o), dv2 = __shfl_xor(dv, o), dm2 = __shfl_xor(dm, o);
+        m = m > m2 ? m : m2; dv = dv > dv2 ? dv : dv2; dm = dm > dm2 ? dm : dm2;
+        ds += __shfl_xor(ds, o); dt += __shfl_xor(dt, o); wn += __shfl_xor(wn, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        red[w] = m; redd[w] = dv; reds[w] = ds; redt[w] = dt; redw[w] = wn; redm[w] = dm;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int w = 1; w < 4; w++) {
+            red[0] = red[0] > red[w] ? red[0] : red[w]; redd[0] = redd[0] > redd[w] ? redd[0] : redd[w]; redm[0] = redm[0] > redm[w] ? redm[0] : redm[w];
+            reds[0] += reds[w]; redt[0] += redt[w]; redw[0] += redw[w];
+        }
     if (threadIdx.x == 0) {
         const bool have_dev = devmax != nullptr && corr_on0 && c_out_power > 0;
         const double dev = have_dev ? sqrt(redd[0] / c_out_power) : -1.0;                            // worst segment
