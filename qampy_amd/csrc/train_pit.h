@@ -759,6 +759,113 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
         for (int k = lane; k < n; k += 64) { Vout[(size_t)i * n + k] = V[i * ld + k]; Vout[(size_t)n * n + (size_t)i * n + k] = V[k * ld + i]; }   // V, then V^T (both products read rows)
 }
 
+// The same sweeps in 2 x 2 BLOCK form, one barrier per round: the pairs of a round are disjoint, so A' = J^H A J falls apart into
+// the blocks A'[I][J] = G_I^H A[I][J] G_J over pairs I = (p, q), J = (r, s) - four elements read, four written, by ONE thread, which
+// works out G_I and G_J itself from the pivots (three LDS reads and a dozen flops each: cheaper than waiting for them).  Reading
+// from one copy of A and writing the other (ping-pong) removes the hazard between a block holding pivots and its readers, so a
+// round is: the rotations of its pairs (one thread each), barrier, every thread its block of the upper triangle and the mirror image, barrier.  (The row / column form above: two passes over A and two barriers per
+// round, 2.2 us per round at n = 82 - the basis was what the first correction of a cold sweep waited for.)  Rotations logged for
+// pit_jacobi_v_kernel; two copies of A: n <= 96.
+static __global__ void __launch_bounds__(1024) pit_jacobi_blk_kernel(const Z *Rc, int n, double norm, double *lam, int nsweep, float4 *glog)
+{
+    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
+    const int ld = n + 1;
+    Zf *src = reinterpret_cast<Zf *>(pit_smem), *dst = src + (size_t)n * ld;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += 1024) {
+        const int i = e / n, j = e - i * n;
+        const Z v = Rc[e];
+        src[i * ld + j] = Zf{(float)(v.x * norm), (float)(v.y * norm)};
+    }
+    __syncthreads();
+    const int m = (n + 1) & ~1, npair = m / 2, ntri = npair * (npair + 1) / 2;
+    // A stays Hermitian: a thread takes the blocks (I, J), I <= J, of the upper triangle - the same ones in every round - and writes
+    // their mirror images too
+    __shared__ float4 grot[PIT_EIGMAX / 2 + 1];
+    __shared__ int2 gpair[PIT_EIGMAX / 2 + 1];
+    constexpr int NB = (PIT_EIGMAX / 2) * (PIT_EIGMAX / 2 + 1) / 2 / 1024 + 1;
+    int bI[NB], bJ[NB], nbt = 0;
+    {
+        auto off = [&](int I) { return I * npair - I * (I - 1) / 2; };
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const int bq = tid + 1024 * k;
+            bI[k] = 0; bJ[k] = 0;
+            if (bq < ntri) {
+                int I = 0;
+                while (bq >= off(I + 1)) I++;
+                bI[k] = I; bJ[k] = I + (bq - off(I));
+                nbt = k + 1;
+            }
+        }
+    }
+    for (int sweep = 0; sweep < nsweep; sweep++) {
+        for (int r = 0; r < m - 1; r++) {
+            // the round's pairs and rotations, once (circle method: player m - 1 stays, the others rotate; q = n: the partner of the
+            // dummy player - n odd - sits this round out).  (c, s, e.re, e.im); hardware reciprocals (1 ulp): the basis is a preconditioner
+            if (tid < npair) {
+                int pa, pb;
+                if (tid == 0) { pa = m - 1; pb = r; }
+                else {
+                    pa = r + tid; if (pa >= m - 1) pa -= m - 1;
+                    pb = r - tid; if (pb < 0) pb += m - 1;
+                }
+                const int2 ix{pa < pb ? pa : pb, (pa < pb ? pb : pa) < n ? (pa < pb ? pb : pa) : n};
+                float4 g = {1.f, 0.f, 1.f, 0.f};
+                if (ix.y < n) {
+                    const Zf apq = src[ix.x * ld + ix.y];
+                    const float app = src[ix.x * ld + ix.x].x, aqq = src[ix.y * ld + ix.y].x;
+                    const float m2 = apq.x * apq.x + apq.y * apq.y;
+                    if (m2 > 1e-36f) {
+                        const float rmag = __builtin_amdgcn_rsqf(m2);
+                        const float tau = (aqq - app) * 0.5f * rmag;
+                        const float t = (tau >= 0 ? 1.f : -1.f) * __builtin_amdgcn_rcpf(fabsf(tau) + __builtin_amdgcn_sqrtf(1.f + tau * tau));
+                        const float c = __builtin_amdgcn_rsqf(1.f + t * t);
+                        g = float4{c, t * c, apq.x * rmag, apq.y * rmag};
+                    }
+                }
+                grot[tid] = g; gpair[tid] = ix;
+                glog[((size_t)sweep * (m - 1) + r) * npair + tid] = g;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                if (k >= nbt) break;
+                const int I = bI[k], J = bJ[k];
+                const int2 pi = gpair[I], pj = gpair[J];
+                const float4 gi = grot[I], gj = grot[J];
+                const bool qi = pi.y < n, qj = pj.y < n;
+                const Zf z{0.f, 0.f};
+                const Zf a_pr = src[pi.x * ld + pj.x], a_ps = qj ? src[pi.x * ld + pj.y] : z;
+                const Zf a_qr = qi ? src[pi.y * ld + pj.x] : z, a_qs = (qi && qj) ? src[pi.y * ld + pj.y] : z;
+                // T = A[I][J] G_J:  col_r' = c col_r - s conj(e) col_s ;  col_s' = s col_r + c conj(e) col_s
+                const Zf ejc{gj.z, -gj.w};
+                const Zf ps_e = cmulf(ejc, a_ps), qs_e = cmulf(ejc, a_qs);
+                const Zf t_pr{gj.x * a_pr.x - gj.y * ps_e.x, gj.x * a_pr.y - gj.y * ps_e.y}, t_ps{gj.y * a_pr.x + gj.x * ps_e.x, gj.y * a_pr.y + gj.x * ps_e.y};
+                const Zf t_qr{gj.x * a_qr.x - gj.y * qs_e.x, gj.x * a_qr.y - gj.y * qs_e.y}, t_qs{gj.y * a_qr.x + gj.x * qs_e.x, gj.y * a_qr.y + gj.x * qs_e.y};
+                // A' = G_I^H T:  row_p' = c row_p - s e row_q ;  row_q' = s row_p + c e row_q
+                const Zf ei{gi.z, gi.w};
+                const Zf qr_e = cmulf(ei, t_qr), qs_e2 = cmulf(ei, t_qs);
+                const Zf n_pr{gi.x * t_pr.x - gi.y * qr_e.x, gi.x * t_pr.y - gi.y * qr_e.y}, n_ps{gi.x * t_ps.x - gi.y * qs_e2.x, gi.x * t_ps.y - gi.y * qs_e2.y};
+                const Zf n_qr{gi.y * t_pr.x + gi.x * qr_e.x, gi.y * t_pr.y + gi.x * qr_e.y}, n_qs{gi.y * t_ps.x + gi.x * qs_e2.x, gi.y * t_ps.y + gi.x * qs_e2.y};
+                dst[pi.x * ld + pj.x] = n_pr;
+                if (qj) dst[pi.x * ld + pj.y] = n_ps;
+                if (qi) dst[pi.y * ld + pj.x] = n_qr;
+                if (qi && qj) dst[pi.y * ld + pj.y] = n_qs;
+                if (I != J) {                                         // the mirror block A'[J][I] = A'[I][J]^H
+                    dst[pj.x * ld + pi.x] = Zf{n_pr.x, -n_pr.y};
+                    if (qj) dst[pj.y * ld + pi.x] = Zf{n_ps.x, -n_ps.y};
+                    if (qi) dst[pj.x * ld + pi.y] = Zf{n_qr.x, -n_qr.y};
+                    if (qi && qj) dst[pj.y * ld + pi.y] = Zf{n_qs.x, -n_qs.y};
+                }
+            }
+            __syncthreads();
+            Zf *t = src; src = dst; dst = t;
+        }
+    }
+    for (int k = tid; k < n; k += 1024) lam[k] = (double)src[k * ld + k].x;
+}
+
 // Row i of V = e_i times the logged rotations, in their order: one wave per row (the rows do not interact), lane a = pair a of a
 // round (the pairs of a round are disjoint), the log staged through LDS 27 rounds at a time.  Writes V and V^T like the kernel above.
 constexpr int PIT_JV_CH = 27;
@@ -1622,6 +1729,15 @@ int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t T
         if ((rc = scratch(11, (size_t)nsweep * (mm - 1) * (mm / 2) * sizeof(float4) + 64, &gl))) return rc;
         glog = (float4 *)gl;
     }
+    // QAMPY_HIP_PIT_JACOBI = rows: the row / column form for every size (block form: n <= 96, two copies of A in the LDS)
+    static int jrows = -1;
+    if (jrows < 0) { const char *e = getenv("QAMPY_HIP_PIT_JACOBI"); jrows = (e && e[0] == 'r') ? 1 : 0; }
+    const size_t blds = 2 * (size_t)ntot * (ntot + 1) * sizeof(Zf) + 256;
+    if (logged && !jrows && blds <= 160 * 1024 - 2048) {          // (the kernel's static LDS: the round's pairs and rotations)
+        static bool battr = false;
+        if (!battr) { QH_HIP(hipFuncSetAttribute((const void *)pit_jacobi_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); battr = true; }
+        hipLaunchKernelGGL(pit_jacobi_blk_kernel, dim3(1), dim3(1024), blds, st, (const Z *)Rc, ntot, 1.0 / (double)ncov, (double *)basis, nsweep, glog);
+    } else
     hipLaunchKernelGGL(pit_jacobi_kernel, dim3(1), dim3(1024), jlds, st, (const Z *)Rc, ntot, 1.0 / (double)ncov, (double *)basis,
                        (Zf *)((char *)basis + (size_t)ntot * sizeof(double)), nsweep, glog);
     if (glog) hipLaunchKernelGGL(pit_jacobi_v_kernel, dim3(ntot), dim3(64), 0, st, (const float4 *)glog, ntot, nsweep, (Zf *)((char *)basis + (size_t)ntot * sizeof(double)));
