@@ -272,8 +272,8 @@ typedef struct qh_pit_opts {
     double gear;            /* 0 = 8 */
     double acq_bound;       /* 0 = 0.08 */
     double acq_plateau;     /* 0 = 0.8: a chunk whose mean |err|^2 exceeds this fraction of the previous one's ends the acquisition */
-    int64_t acq_chunk;      /* 0 = automatic (>= 4096 steps) */
-    int64_t acq_max;        /* 0 = min(TrSyms / 2, 2^17) steps */
+    int64_t acq_chunk;      /* 0 = automatic: 2 / mu_acq steps (mu_acq = the gear-shifted step size), 256 .. 4096 */
+    int64_t acq_max;        /* 0 = two chunks (at most TrSyms / 2 steps) */
     int32_t correction;     /* -1 / 1: linearised coarse correction between the passes (see below), 0: plain relaxation */
     int32_t pad;
     void *basis;            /* NULL, or the eigenbasis of this capture's input covariance from qh_pit_basis_*_dev (device memory) */

@@ -1867,13 +1867,26 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     unsigned *ticket = (unsigned *)(devmax + 4 * (size_t)ndev);  // pit_devest_kernel: which block finishes last
     QH_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned), g_stream));
     QH_HIP(hipMemcpyAsync(modes_dev, modes, (size_t)nsel * sizeof(int64_t), hipMemcpyHostToDevice, g_stream));
+    R mu_acq_h = 0;                                               // the gear-shifted step size pit_setup_kernel chose (sizes the acquisition run)
+    if (o.acquire) QH_HIP(hipMemcpyAsync(&mu_acq_h, mu_acq, sizeof(R), hipMemcpyDeviceToHost, g_stream));
     QH_HIP(hipStreamSynchronize(g_stream));                       // `modes` is the caller's memory
 
     // ---- Gram table: of the whole sweep when the passes run in a block form (acquisition chunks and segments index into
     // it), of the acquisition range only when they run in the throughput form
-    int64_t amax = 0;
+    int64_t amax = 0, acq_ch = 0;
     if (o.acquire) {
-        amax = o.acq_max > 0 ? o.acq_max : (TrSyms / 2 < 131072 ? TrSyms / 2 : 131072);
+        // Length of the acquisition run: two chunks of 2 / mu_acq steps.  Measured (profiles/r03_acquisition.txt): the passes that follow
+        // do not care whether the run was 2/mu_acq or 8/mu_acq steps long (C3, mu_acq = 9.6e-4: 6-7 passes after 2048 .. 8192 steps, 8-10
+        // after 1024; C2, 1.9e-3: 6-7 after 2048, 6-9 after 896 or 4096, 12-16 after 512) - and every one of its steps is sequential.
+        if (o.acq_chunk > 0) acq_ch = o.acq_chunk;
+        else {
+            const double m = (double)mu_acq_h > 1e-12 ? (double)mu_acq_h : 1e-12;
+            acq_ch = (int64_t)(2.0 / m + 0.5);
+            acq_ch = acq_ch < 256 ? 256 : (acq_ch > 4096 ? 4096 : acq_ch);
+        }
+        acq_ch = (acq_ch + LA_B - 1) / LA_B * LA_B;
+        amax = o.acq_max > 0 ? o.acq_max : 2 * acq_ch;
+        if (amax > TrSyms / 2 && o.acq_max <= 0) amax = TrSyms / 2;
         if (amax > TrSyms) amax = TrSyms;
     }
     void *G = const_cast<void *>(gram);
@@ -1942,7 +1955,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     for (int it = 0; it < Niter; it++) {
         // ================================================================ acquisition (first sweep of a cold start)
         if (it == 0 && o.acquire) {
-            int64_t CH = o.acq_chunk > 0 ? o.acq_chunk : 4096;
+            int64_t CH = acq_ch;
             if (CH * QH_PIT_MAXCHUNK < amax) CH = (amax + QH_PIT_MAXCHUNK - 1) / QH_PIT_MAXCHUNK;
             CH = (CH + LA_B - 1) / LA_B * LA_B;
             if (CH < 4 * LA_B) CH = 4 * LA_B;

@@ -118,6 +118,9 @@ for seed in [int(s) for s in args.seeds.split(",")]:
             f = v.split(":")
             mp = int(f[5]) if len(f) > 5 else 0
             VARIANTS[v] = (dict(segments=int(f[1]), tol=float(f[3]), max_passes=mp), dict(segments=int(f[2]), tol=float(f[4]), max_passes=mp))
+        if v.startswith("a:"):          # a:chunk:max  acquisition of the first stage
+            f = v.split(":")
+            VARIANTS[v] = dict(acq_chunk=int(f[1]), acq_max=int(f[2])) if len(cfg["methods"]) == 1 else (dict(acq_chunk=int(f[1]), acq_max=int(f[2])), {})
         if v.startswith("t:"):          # t:tol1:tol2[:start[:maxpass]]  automatic grid
             f = v.split(":")
             st = int(f[3]) if len(f) > 3 else 0

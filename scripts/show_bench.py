@@ -11,7 +11,7 @@ if tb:
     print("tier_b", tb["value"], "certified", tb["certified"], tb.get("checks"))
     for st in tb["stages"]:
         print("  ", st["stage"], "S", st["S"], "P", st["P"], "pass_ms", st["pass_ms"], "acq", st["acquisition_ms"], "rms", st["est_deviation_rms"][-2:], "taps", st.get("est_deviation_taps", [])[-2:])
-    print("  ", {k: tb.get(k) for k in ("out_rms_dev_vs_exact", "tap_rel_dev_vs_exact", "err_trace_rms_dev_vs_exact", "errors", "errors_exact")})
+    print("  ", {k: tb.get(k) for k in ("out_rms_dev_vs_exact", "eq_rms_dev_vs_exact", "out_rms_dev_same_angle", "bps_angle_mismatch_fraction", "tap_rel_dev_vs_exact", "err_trace_rms_dev_vs_exact", "errors", "errors_exact")})
 if d.get("tier_a"):
     print("tier_a", d["tier_a"]["value"], d["tier_a"].get("speedup_vs_cpu"))
 if d.get("tier_b_loose"):
@@ -22,7 +22,7 @@ for k in ("ns", "c2"):
     b = d.get(k)
     if b:
         print(k, b["tier_b"]["value"], "cert", b["tier_b"]["certified"], b["tier_b"]["checks"], [(s["S"], s["P"]) for s in b["tier_b"]["stages"]],
-              b["tier_b"]["out_rms_dev_vs_exact"], b["tier_b"]["tap_rel_dev_vs_exact"], "a:", b["tier_a"]["value"], b["tier_b"]["errors"], b["tier_a"]["errors"])
+              b["tier_b"]["out_rms_dev_vs_exact"], b["tier_b"].get("eq_rms_dev_vs_exact"), b["tier_b"].get("out_rms_dev_same_angle"), b["tier_b"].get("bps_angle_mismatch_fraction"), b["tier_b"]["tap_rel_dev_vs_exact"], "a:", b["tier_a"]["value"], b["tier_b"]["errors"], b["tier_a"]["errors"])
 r = d.get("roofline", {})
 print("roofline", {k: v for k, v in r.items() if k not in ("note", "pipeline", "valu_instr_source")})
 if d.get("cpu_baseline"):
