@@ -1646,7 +1646,7 @@ inline PitEvents &pit_events()
 //     = 8 chains per wave, chosen by seg_lanes from the chain count), so a grid that needs 1.05 rounds costs two.  Cold sweeps
 //     leave one CU per shader engine (32 of 256) to the basis build that runs beside the first pass: 896 waves per round.
 // The grid is the cheapest of: the target length as it is, exactly one round of 16-lane waves, whole rounds of 8-lane waves -
-// among those whose segments are not shorter than 0.87 x the target.
+// never with segments shorter than the target.
 inline int pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold)
 {
     double target = (cold ? 0.45 : 0.4) / (mu > 1e-12 ? mu : 1e-12);
@@ -1667,13 +1667,13 @@ inline int pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold)
     int64_t best = St;
     double cbest = cost(St);
     auto consider = [&](int64_t S) {
-        if (S < 4 || S > PIT_MAXSEG || (double)S > 1.15 * (double)St) return;
+        if (S < 4 || S > PIT_MAXSEG || S > St) return;
         const double c = cost(S);
         if (c < cbest * 0.999 || (c < cbest * 1.001 && S > best)) { best = S; cbest = c; }
     };
     const int64_t S16 = cap * 4 / nsel, S8 = cap * 8 / nsel;
     if (S16 * nsel <= 4096) consider(S16 < St ? S16 : St);
-    for (int64_t r = 1; r * S8 <= St + St / 6 && r <= 64; r++) consider(r * S8);
+    for (int64_t r = 1; r * S8 <= St && r <= 64; r++) consider(r * S8);
     return (int)best;
 }
 
