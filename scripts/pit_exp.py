@@ -73,12 +73,15 @@ ap.add_argument("--snr", type=float, default=None)
 ap.add_argument("--variants", default="default")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--no-exact", action="store_true")
+ap.add_argument("--mu", default=None, help="step sizes of the stages, comma separated")
 args = ap.parse_args()
 cfg = dict(bench.WORKLOADS[args.workload])
 if args.linewidth is not None:
     cfg["linewidth"] = args.linewidth
 if args.snr is not None:
     cfg["snr_db"] = args.snr
+if args.mu:
+    cfg["mu"] = tuple(float(x) for x in args.mu.split(","))
 nsym = args.nsym or cfg["nsym"]
 _lib.init(0)
 out = []

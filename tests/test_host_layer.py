@@ -268,3 +268,28 @@ def test_pilot_signal_geometry():
     assert type(one) is PilotSignal and one.os == 1 and one.nframes == 1 and one.get_data().shape == (2, 196) and one.extract_pilots().shape == (2, 60)
     with pytest.raises(ValueError):
         PilotSignal(np.zeros((2, 10), np.complex128), 16, 1e9, 2e9, 256, 32, 8, pilots[:, :5])
+
+
+def test_automatic_segment_grid_follows_the_machine_model():
+    """`qh_pit_auto_segments` (no GPU needed): segments of >= 0.45/mu (cold) / 0.4/mu (warm) steps, one wave per SIMD - whole rounds
+    of 896 (cold: one CU per shader engine left to the basis build) or 1024 waves of 4-chain (<= 4096 chains) or 8-chain waves -
+    and never shorter than the target (profiles/r03_segment_grid.txt)."""
+    from qampy_amd.core.equalisation import hip_equalisation as hk
+    n = 2 ** 22 - 40
+    assert hk.pit_auto_segments(n, 2e-4, 2, True) == 1792          # C3 cma: 896 waves x 4 chains / 2 modes
+    assert hk.pit_auto_segments(n, 2e-4, 2, False) == 2047         # C3 mrde: 2048-step segments, 1024 waves
+    assert hk.pit_auto_segments(10 ** 7, 2e-4, 2, True) == 3584    # 10^7 symbols: 8-chain waves, 896 of them
+    assert hk.pit_auto_segments(10 ** 7, 2e-4, 2, False) == 4096
+    assert hk.pit_auto_segments(2 ** 20, 1e-3, 2, True) == 1792    # C2
+    for n, mu, nsel, cold in [(2 ** 17, 2e-4, 2, True), (2 ** 16, 1e-3, 1, True), (4 * 10 ** 7, 2e-4, 2, False), (2 ** 21, 5e-4, 2, False),
+                              (3 * 10 ** 6, 1e-4, 3, True), (2 ** 22, 1e-3, 4, False)]:
+        S = hk.pit_auto_segments(n, mu, nsel, cold)
+        target = (0.45 if cold else 0.4) / mu
+        assert 1 <= S <= 65536
+        if S > 1:
+            assert n // S >= int(target), (n, mu, nsel, cold, S)                  # never shorter than the target
+            chains = S * nsel
+            waves = -(-chains // (4 if chains <= 4096 else 8))
+            cap = 896 if cold else 1024
+            assert waves <= cap or waves % cap == 0, (S, waves)                     # one round, or whole rounds
+    assert hk.pit_auto_segments(1000, 1e-3, 2, True) == 1                          # too short to cut
