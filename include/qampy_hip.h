@@ -38,8 +38,8 @@ extern "C" {
  * built against another header fails loudly (compare with qh_abi_version() at load time) instead of passing shifted
  * arguments.  History: 1 = round 1; 2 = round 2 (qh_bps_recover_*_dev gained `angles`, qh_train_equaliser_*_pit_dev takes
  * (gram, opts, report), the *_seg_dev entry points were removed - unversioned at the time); 3 = round 3 (qh_pit_opts:
- * start, dev_safety; qh_pit_report: deviation[]). */
-#define QH_ABI_VERSION 3
+ * start, dev_safety; qh_pit_report: deviation[]); 4 = qh_pit_opts: adaptive. */
+#define QH_ABI_VERSION 4
 int qh_abi_version(void);
 
 /* ---- status codes (python shim: 1,2 -> ValueError, 3,4 -> RuntimeError) */
@@ -293,6 +293,10 @@ typedef struct qh_pit_opts {
     int32_t exchange_on_stream; /* != 0: `exchange` only ENQUEUES the all-reduce on the library stream (RCCL with qh_stream_handle): the library
                              * does not synchronise around it and enqueues the next pass ahead as in the single-process case */
     double dev_safety;      /* 0 = 1: factor on the deviation estimate in the stop rule */
+    int32_t adaptive;       /* != 0: the step size adapts (adapt_step); ONE output mode per call (nsel = 1), one sweep, complex64, cma / mcma / sbd /
+                             * mddma; mu is in/out like in the exact entry points.  The first 16384 steps run in the exact form; a sweep the passes cannot
+                             * agree on is redone in the exact form (report: converged = 2) (ABI 4) */
+    int32_t reserved0;
 } qh_pit_opts;
 typedef struct qh_pit_report {
     int32_t segments, passes, converged, acq_chunks;

@@ -342,8 +342,6 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
             _adaptive_flag(adaptive), symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)))
     name = "qh_train_equaliser_c" + ("64" if suf == "32" else "128")
     if pit is not None:
-        if _adaptive_flag(adaptive):
-            raise ValueError("parallel-in-time training needs a fixed step size")
         o = _lib.PitOpts()
         o.phase_seed = -1
         o.correction = -1
@@ -352,6 +350,19 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
             if not hasattr(o, k):
                 raise ValueError("unknown parallel-in-time option %s" % k)
             setattr(o, k, v)
+        if _adaptive_flag(adaptive):
+            # the reference carries ONE step size from mode to mode (pythran_equalisation.py:163-172): the modes are solved in turn, each
+            # from the step size the one before it ended with; the report describes the last one
+            if _adaptive_flag(adaptive) != 1:
+                raise ValueError("parallel-in-time training with the adaptive step: the reference's shared step size only (adaptive_stepsize=True)")
+            o.adaptive = 1
+            for m in modes:
+                one = np.array([m], dtype=np.int64)
+                _lib.call(name + "_pit_dev", E.ptr, nmodes, L, int(TrSyms), int(Niter), int(os), mu.ptr, wx.ptr, ntaps, _lib.ptr(one), 1,
+                          symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)), None, C.byref(o),
+                          report.ptr if report is not None else None)
+                zero_err = False
+            return
         _lib.call(name + "_pit_dev", E.ptr, nmodes, L, int(TrSyms), int(Niter), int(os), mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size,
                   symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)), gram, C.byref(o),
                   report.ptr if report is not None else None)

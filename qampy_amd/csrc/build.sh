@@ -8,6 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $*"
 mkdir -p build
 UNITS="api train_f32 train_f64 apply bps ser synth"
 for m in mrde cma rde mcma sbd mddma dd cma2; do UNITS="$UNITS train_seg_${m}_f32 train_seg_${m}_f64"; done
+for m in cma mcma mddma sbd; do UNITS="$UNITS train_seg_${m}_f32_ad"; done
 todo=""
 for f in $UNITS; do
     stale=0

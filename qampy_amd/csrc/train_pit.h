@@ -37,7 +37,8 @@ __host__ __device__ inline int pit_symmetry(int method)
 struct PitSeg {                      // segment grid of a sweep: see LaArgs::seg
     int S;
     int64_t len, extra, tail;
-    __host__ __device__ int64_t start(int64_t s) const { return s * len + (s < extra ? s : extra) * 64; }
+    int64_t begin = 0;               // first step of segment 0 (adaptive step: the head of the sweep runs in the exact form)
+    __host__ __device__ int64_t start(int64_t s) const { return begin + s * len + (s < extra ? s : extra) * 64; }
     __host__ __device__ int64_t steps(int64_t s) const { return len + (s < extra ? 64 : 0) + (s == S - 1 ? tail : 0); }
 };
 
@@ -401,6 +402,7 @@ template <typename R> struct PitDecideArgs {
     const double *theta;
     const int64_t *modes_dev;
     int ntot_w, S, sym, corr_wanted;
+    const float *extra;              // one more figure the criterion must cover (adaptive step: largest relative change of a segment's start step size), or nullptr
 };
 // (256 threads of ONE block: the kernel below, or the last block of pit_devest_kernel to finish)
 template <typename R> __device__ __forceinline__ void pit_decide_body(const PitDecideArgs<R> &a)
@@ -510,6 +512,7 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
         // Certified only by the deviation estimate when a coarse model exists: small boundary defects alone say nothing about the
         // weakly excited directions (round 2's defect rule certified 64-QAM mrde runs whose taps were 3e-2 off).  Without a model
         // (more than 96 taps per output mode) the defect rule is all there is.
+        if (a.extra) { const double ex = (double)a.extra[0]; if (p < QH_PIT_MAXPASS) c->result_change[p] = ex; if (ex > crit || !(ex == ex)) crit = ex == ex ? ex : 1e30; }   // (adaptive step: result_change[] reports the change of the start step sizes)
         int done = 0;
         if (crit < c_tol && (have_dev || !corr_wanted)) { c->converged = 1; done = 1; }
         // nothing gained over two passes: the trajectory has no fixed point the passes can agree on (a stage that cannot track the
@@ -1334,7 +1337,7 @@ static __global__ void __launch_bounds__(256) pit_bound_kernel(const Zf *Xe, con
 constexpr int PIT_RT = 1024;            // threads of the eigen-space scan: up to 4 segments per thread stay in registers (S <= 4096: one round of loads)
 template <typename R>
 __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf *Ye, Zf *D, const double *theta, const double *lam, int nsel, int S, int64_t T, const R *mu,
-                                                               double beta, const PitCtrl *c)
+                                                               double beta, const PitCtrl *c, const float *Msum = nullptr)
 {
     if (c->done) return;
     __shared__ float4 aff[2 * PIT_RT];
@@ -1345,6 +1348,14 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
     double a = (double)*mu * c->gain * (double)T * lam[k];
     if (a < 0) a = 0;
     const float coef = c->corr_on ? (float)exp(-a * (1 + beta * a)) : 0.f;       // (beta: see pit_recur_kernel)
+    // adaptive step: the step sizes a segment used add up to Msum[s] instead of mu T - one coefficient per segment, c_s takes D[s] to D[s + 1]
+    const float gl = (float)(c->gain * lam[k] > 0 ? c->gain * lam[k] : 0.0), betaf = (float)beta;
+    const bool corr = c->corr_on != 0;
+    auto cf = [&](int s) -> float {                              // coefficient of segment s (s >= 0)
+        if (!Msum) return coef;
+        const float as = gl * Msum[(size_t)s * nsel + j];
+        return corr ? __expf(-as * (1.f + betaf * as)) : 0.f;
+    };
     const int len = (S + PIT_RT - 1) / PIT_RT;
     const int s0 = threadIdx.x * len, s1 = s0 + len < S ? s0 + len : S;
     auto th = [&](int s) { return Zf{(float)theta[2 * ((size_t)s * nsel + j)], (float)theta[2 * ((size_t)s * nsel + j) + 1]}; };
@@ -1362,6 +1373,9 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
             t[q + 1] = ok ? th(s) : Zf{1.f, 0.f};
         }
         Zf run{0.f, 0.f};
+        float cq[4], clen = 1.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int s = s0 + q; cq[q] = (s < s1 && s > 0) ? cf(s - 1) : (s < s1 ? 0.f : 1.f); }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int s = s0 + q;
@@ -1369,27 +1383,28 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
                 x[q] = cmulf(t[q + 1], x[q]);                   // theta_s x~[s]
                 Zf d{0.f, 0.f};
                 if (s > 0) { const Zf aa = cmulf(t[q], y[q]); d = Zf{aa.x - x[q].x, aa.y - x[q].y}; }
-                run = Zf{d.x + coef * run.x, d.y + coef * run.y};
+                run = Zf{d.x + cq[q] * run.x, d.y + cq[q] * run.y};
                 r[q] = run;
+                clen *= cq[q];
             }
         }
-        const float clen = powf(coef, (float)len);
         const float4 comp = block_scan_excl<float4, decltype(scan_op), PIT_RT>(float4{clen, run.x, run.y, 0.f}, scan_op, float4{1.f, 0.f, 0.f, 0.f}, aff);
-        float pw = coef;
+        float pw = 1.f;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int s = s0 + q;
             if (s < s1) {
+                pw *= cq[q];
                 const Zf v{r[q].x + pw * comp.y, r[q].y + pw * comp.z};
                 row[(size_t)s * nsel] = v;
                 xr[(size_t)s * nsel] = Zf{x[q].x + v.x, x[q].y + v.y};
-                pw *= coef;
             }
         }
         return;
     }
     // long sweeps: batches of 4 segments (their loads are issued together), running values through memory
     Zf run{0.f, 0.f};
+    float clen = 1.f;
     for (int sb = s0; sb < s1; sb += 4) {
         Zf y[4], x[4], t[5];
         t[0] = sb > 0 ? th(sb - 1) : Zf{1.f, 0.f};
@@ -1407,15 +1422,16 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
             if (s < s1) {
                 Zf d{0.f, 0.f};
                 if (s > 0) { const Zf aa = cmulf(t[q], y[q]), bb = cmulf(t[q + 1], x[q]); d = Zf{aa.x - bb.x, aa.y - bb.y}; }
-                run = Zf{d.x + coef * run.x, d.y + coef * run.y};
+                const float cs = s > 0 ? cf(s - 1) : 0.f;
+                run = Zf{d.x + cs * run.x, d.y + cs * run.y};
+                clen *= cs;
                 row[(size_t)s * nsel] = run;
             }
         }
     }
-    const float clen = powf(coef, (float)len);
     const float4 comp = block_scan_excl<float4, decltype(scan_op), PIT_RT>(float4{clen, run.x, run.y, 0.f}, scan_op, float4{1.f, 0.f, 0.f, 0.f}, aff);
     const Zf cin{comp.y, comp.z};
-    float pw = coef;
+    float pw = 1.f;
     for (int sb = s0; sb < s1; sb += 4) {
         Zf v[4], x[4], t[4];
 #pragma unroll
@@ -1430,11 +1446,11 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
         for (int q = 0; q < 4; q++) {
             const int s = sb + q;
             if (s < s1) {
+                pw *= s > 0 ? cf(s - 1) : 0.f;
                 v[q].x += pw * cin.x; v[q].y += pw * cin.y;
                 row[(size_t)s * nsel] = v[q];
                 const Zf xx = cmulf(t[q], x[q]);
                 xr[(size_t)s * nsel] = Zf{xx.x + v[q].x, xx.y + v[q].y};
-                pw *= coef;
             }
         }
     }
@@ -1487,6 +1503,47 @@ __global__ void __launch_bounds__(256) pit_recur_kernel(Zf *D, const double *lam
 // end taps of segment s-1 (yB ~ g_s yA, from the defect kernel) is not an error: theta_s = g_1 ... g_s brings every segment
 // into the frame of segment 0, where the boundary defects are formed and corrected (a rotation treated as an additive
 // defect would be wrong in second order and keep the iteration from converging below ~theta^2).
+// ---- adaptive step (pythran_equalisation.py:12-16, :171-172) across segments: r = 1 / mu and the previous error are boundary states like the taps.
+// After the head of the sweep (exact form): every segment starts from the head's r (pass 0 only), segment 0 also from its last error.
+template <typename R>
+__global__ void __launch_bounds__(256) pit_adapt_init_kernel(const R *mu, const Cx<R> *e_last, int n, R *rS, Cx<R> *eS)
+{
+    const R r0 = (R)1 / *mu;
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < n; s += gridDim.x * 256) { rS[s] = r0; eS[s] = s == 0 ? *e_last : Cx<R>{0, 0}; }
+}
+// After a pass: what a segment adds to r does not depend on the r it started from (to first order), so the next start values are
+// r[0] + the prefix sums of this pass's increments - one pass carries a change of r through ALL later segments; the previous error of
+// segment s + 1 is the last error of segment s.  chg[0] = the largest relative change of a start value (part of the stop rule).
+template <typename R>
+__global__ void __launch_bounds__(1024) pit_adapt_scan_kernel(R *rS, const R *rE, Cx<R> *eS, const Cx<R> *eE, int n, float *chg, const PitCtrl *c, float relax)
+{
+    if (c->done) return;
+    __shared__ double buf[16];
+    __shared__ float red[16];
+    const int len = (n + 1023) / 1024;
+    const int s0 = threadIdx.x * len, s1 = s0 + len < n ? s0 + len : n;
+    double sum = 0;
+    for (int s = s0; s < s1; s++) sum += (double)rE[s] - (double)rS[s];
+    double run = block_scan_excl<double, double (*)(double, double), 1024>(sum, [](double x, double y) { return x + y; }, 0.0, buf) + (double)rS[0];
+    float worst = 0.f;
+    for (int s = s0; s < s1; s++) {
+        const double inc = (double)rE[s] - (double)rS[s];
+        if (s > 0) {
+            const float old = (float)rS[s], nw = c->passes == 0 ? (float)run : old + relax * ((float)run - old);
+            const float rel = fabsf(nw - old) / (fabsf(old) > 1e-30f ? fabsf(old) : 1e-30f);
+            worst = (rel > worst || !(rel == rel)) ? (rel == rel ? rel : 3.0e38f) : worst;
+            rS[s] = (R)nw;
+            eS[s] = eE[s - 1];
+        }
+        run += inc;
+    }
+    for (int o = 32; o > 0; o >>= 1) { const float w2 = __shfl_xor(worst, o); worst = worst > w2 ? worst : w2; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = worst;
+    __syncthreads();
+    if (threadIdx.x == 0) { float m = 0.f; for (int w = 0; w < 16; w++) m = m > red[w] ? m : red[w]; chg[0] = m; }
+}
+template <typename R> __global__ void pit_adapt_finish_kernel(R *mu, const R *rE, int n) { *mu = (R)1 / rE[n - 1]; }
+
 constexpr int PIT_GT_THREADS = 1024;
 template <typename R>
 __global__ void __launch_bounds__(PIT_GT_THREADS) pit_gauge_kernel(const double *gph, int S, int nsel, PitCtrl *c, double *theta, const double *pw, int nb, int method, const Cx<R> *sy0,
@@ -1763,6 +1820,15 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     o.phase_seed = -1; o.corr_beta = -1;
     if (opts) o = *opts;
     QH_REQUIRE(o.segments >= 0 && o.segments <= PIT_MAXSEG && o.max_passes >= 0 && o.max_passes <= QH_PIT_MAXPASS, "train_equaliser: bad segment / pass count");
+    // Adaptive step (opts.adaptive): ONE output mode per call (the reference carries one step size from mode to mode: the caller runs
+    // the modes in turn), one sweep, single precision, the error functions of train_seg_*_f32_ad.hip.  The head of the sweep runs in
+    // the exact form; the segments cover the rest, with r = 1 / mu and the previous error as boundary states.
+    const bool adaptive = o.adaptive != 0;
+    if (adaptive) {
+        QH_REQUIRE(sizeof(R) == 4 && nsel == 1 && Niter == 1 && !o.exchange, "train_equaliser: parallel-in-time training with the adaptive step takes one output mode, one sweep, complex64");
+        QH_REQUIRE(seg_adaptive_supported(method), "train_equaliser: parallel-in-time training with the adaptive step: cma, mcma, sbd, mddma");
+        o.acquire = 0;
+    }
     const int ntot = nmodes * ntaps;
     QH_REQUIRE(ntot <= 64 * 16, "train_equaliser: more than 1024 taps per output mode are not supported");
     const int npass = o.max_passes > 0 ? o.max_passes : 16;
@@ -1784,26 +1850,36 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
 
     // ---- segment grid
     int S = o.segments;
+    // adaptive step: the first 16384 steps (while the step is large) in the exact form, then segments of 2048 steps
+    static int64_t head_env = -1, seg_env = -1;                   // (measurements: QAMPY_HIP_PIT_ADAPT_HEAD / _SEG = steps)
+    if (head_env < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_HEAD"); head_env = e && atoll(e) > 0 ? atoll(e) : 0; const char *g = getenv("QAMPY_HIP_PIT_ADAPT_SEG"); seg_env = g && atoll(g) > 0 ? atoll(g) : 0; }
+    static float ad_relax = -1.f;
+    if (ad_relax < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_RELAX"); ad_relax = e && atof(e) > 0 ? (float)atof(e) : 1.0f; }
+    const int64_t head_want = head_env > 0 ? head_env : 16384, seg_want = seg_env > 0 ? seg_env : 2048;
+    const int64_t head = adaptive ? ((TrSyms / 4 < head_want ? TrSyms / 4 : head_want) / LA_B * LA_B) : 0;
+    if (S == 0 && adaptive) S = (int)((TrSyms - head) / seg_want < PIT_MAXSEG ? (TrSyms - head) / seg_want : PIT_MAXSEG);
     if (S == 0) {
         R mu_h = 0;
         QH_HIP(hipMemcpyAsync(&mu_h, mu_dev, sizeof(R), hipMemcpyDeviceToHost, g_stream));
         QH_HIP(hipStreamSynchronize(g_stream));
         S = pit_auto_segments(TrSyms, (double)mu_h, nsel, o.acquire);
     }
-    const int64_t nblk_all = TrSyms / LA_B;
+    const int64_t nblk_all = (TrSyms - head) / LA_B;
     if ((int64_t)S * 4 > nblk_all) S = (int)(nblk_all / 4);       // at least 4 blocks per segment
+    if (adaptive && S < 16) S = 1;                                // (too short to be worth it: the exact form)
     PitSeg sg;
     sg.S = S > 1 ? S : 1;
     sg.len = sg.S > 0 ? nblk_all / sg.S * LA_B : 0;
     sg.extra = nblk_all - (sg.len / LA_B) * sg.S;
-    sg.tail = TrSyms - nblk_all * LA_B;
+    sg.tail = (TrSyms - head) - nblk_all * LA_B;
+    sg.begin = head;
     if (zero_err) QH_HIP(hipMemsetAsync(err, 0, (size_t)nmodes * TrSyms * Niter * sizeof(Cx<R>), g_stream));
     const int64_t npow = L < 4096 ? L : 4096;
     hipLaunchKernelGGL((pit_setup_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const Cx<R> *)E, nmodes, L, npow, ntot, (const R *)mu_dev, gear, bound, tol, sg, ctrl, mu_acq);
     QH_HIP(hipGetLastError());
     if (TrSyms == 0 || Niter == 0) return QH_OK;
     if (sg.S < 2) {                 // nothing to parallelise: the sequential path (report: one segment, one pass, defect 0)
-        if ((rc = train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, 0, symbols, nsy, method, err, 0, gram))) return rc;
+        if ((rc = train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive ? 1 : 0, symbols, nsy, method, err, 0, gram))) return rc;
         const double zero = 0;
         const int32_t hdr[3] = {1, 1, 1};                          // segments, passes, converged
         QH_HIP(hipMemcpyAsync(&ctrl->segments, hdr, sizeof(hdr), hipMemcpyHostToDevice, g_stream));
@@ -1831,6 +1907,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         if (pf && pf[0] == 'b') seg_ok = false;
         else if (!(pf && pf[0] == 's') && (int64_t)sg.S * nsel < 512) seg_ok = false;
     }
+    if (adaptive) { QH_REQUIRE(seg_supported(method, nmodes, ntaps, os, nsy, sizeof(Cx<R>), nsel, 8) && (!decision || dd_npart == 1 || dd_npart == 3 || dd_npart == 7 || dd_npart == 15),
+                               "train_equaliser: parallel-in-time training with the adaptive step needs the throughput form of the passes (tap layout / alphabet)"); seg_ok = true; }
     const bool seg_form = seg_ok;
     const bool split = o.exchange != nullptr;
     const int own_first = split ? o.seg_first : 0, own_count = split ? o.seg_count : sg.S;
@@ -1866,6 +1944,19 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     const int ndev = (int)((nsj + 63) / 64);                     // (four floats per block: worst column, sum, sum / worst of the tap norms)
     unsigned *ticket = (unsigned *)(devmax + 4 * (size_t)ndev);  // pit_devest_kernel: which block finishes last
     QH_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned), g_stream));
+    // adaptive step: r and previous error at the start / end of every segment, the sum of its step sizes, the change of the start values;
+    // error rows of the head (the exact form writes rows of its own length)
+    R *ad_rS = nullptr, *ad_rE = nullptr;
+    Cx<R> *ad_eS = nullptr, *ad_eE = nullptr, *ad_errh = nullptr;
+    float *ad_M = nullptr, *ad_chg = nullptr;
+    if (adaptive) {
+        void *ab = nullptr;
+        const size_t nS = ((size_t)sg.S + 15) / 16 * 16;
+        if ((rc = scratch(13, nS * (2 * sizeof(R) + 2 * sizeof(Cx<R>) + sizeof(float)) + 64 + (size_t)nmodes * head * sizeof(Cx<R>), &ab))) return rc;
+        ad_eS = (Cx<R> *)ab; ad_eE = ad_eS + nS; ad_errh = ad_eE + nS;
+        ad_rS = (R *)(ad_errh + (size_t)nmodes * head); ad_rE = ad_rS + nS;
+        ad_M = (float *)(ad_rE + nS); ad_chg = ad_M + nS;
+    }
     QH_HIP(hipMemcpyAsync(modes_dev, modes, (size_t)nsel * sizeof(int64_t), hipMemcpyHostToDevice, g_stream));
     R mu_acq_h = 0;                                               // the gear-shifted step size pit_setup_kernel chose (sizes the acquisition run)
     if (o.acquire) QH_HIP(hipMemcpyAsync(&mu_acq_h, mu_acq, sizeof(R), hipMemcpyDeviceToHost, g_stream));
@@ -1993,6 +2084,16 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             hipLaunchKernelGGL((pit_acq_finish_kernel<R>), dim3((unsigned)((wset + 255) / 256)), dim3(256), 0, g_stream, (Cx<R> *)wx, (const Cx<R> *)w_start, (int)wset, ctrl);
             QH_HIP(hipGetLastError());
         }
+        // ================================================================ adaptive step: the head of the sweep in the exact form
+        if (adaptive) {
+            QH_HIP(hipMemcpyAsync(w_start, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));           // (kept for the way out below)
+            QH_HIP(hipMemcpyAsync(ad_chg + 1, mu_dev, sizeof(R), hipMemcpyDeviceToDevice, g_stream));
+            if ((rc = train_dev<R>(E, nmodes, L, head, 1, os, mu_dev, wx, ntaps, modes, 1, 1, symbols, nsy, method, ad_errh, 0, nullptr))) return rc;
+            QH_HIP(hipMemcpyAsync((Cx<R> *)err + (size_t)modes[0] * TrSyms, ad_errh + (size_t)modes[0] * head, (size_t)head * sizeof(Cx<R>), hipMemcpyDeviceToDevice, g_stream));
+            hipLaunchKernelGGL((pit_adapt_init_kernel<R>), dim3((sg.S + 255) / 256), dim3(256), 0, g_stream, (const R *)mu_dev, (const Cx<R> *)(ad_errh + (size_t)modes[0] * head + head - 1),
+                               sg.S, ad_rS, ad_eS);
+            QH_HIP(hipGetLastError());
+        }
         // ================================================================ pass-0 start taps
         hipLaunchKernelGGL(pit_sweep_kernel, dim3(1), dim3(1), 0, g_stream, ctrl);
         const double *rot_use = nullptr;
@@ -2019,6 +2120,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             d.dfc = dfc; d.pw = pw; d.nb = (int)((sg.S - 1) * nsel); d.Ylast = (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset); d.n = (int)wset; d.wx = (Cx<R> *)wx; d.c = ctrl;
             d.host_view = &ev.hview[2 * p]; d.nrow = nsel; d.devmax = dm; d.ndev = ndev; d.safety = safety; d.Ye = ye; d.Yprev = yprev; d.ne = ne; d.ncol_e = ncol_e;
             d.theta = theta; d.modes_dev = (const int64_t *)modes_dev; d.ntot_w = ntot; d.S = (int)sg.S; d.sym = sym; d.corr_wanted = corr_wanted;
+            d.extra = adaptive ? (const float *)ad_chg : nullptr;
             return d;
         };
         auto timed = [&](int p) { return timing_mode == 2 || (timing_mode == 1 && p == 1); };
@@ -2050,11 +2152,13 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 sa.E = (const Cx<R> *)E; sa.wx = Y; sa.symbols = la.symbols; sa.err = (Cx<R> *)err; sa.mu = mu_dev;
                 sa.L = L; sa.TrSyms = TrSyms; sa.nsy = la.nsy; sa.sy_pitch = la.sy_pitch; sa.err_pitch = TrSyms * Niter; sa.err_off = (int64_t)it * TrSyms;
                 sa.nmodes = nmodes; sa.ntaps = ntaps; sa.os = os; sa.nsel = nsel; sa.S = sg.S;
-                sa.seg_len = sg.len; sa.seg_extra = sg.extra; sa.seg_tail = sg.tail; sa.seg_begin = 0;
+                sa.seg_len = sg.len; sa.seg_extra = sg.extra; sa.seg_tail = sg.tail; sa.seg_begin = sg.begin;
+                sa.r_in = ad_rS; sa.r_out = ad_rE; sa.e_in = ad_eS; sa.e_out = ad_eE; sa.mu_sum = (R *)ad_M; sa.adapt_first = sg.begin > 0 ? 1 : 0;
                 for (int j = 0; j < 16; j++) sa.modes[j] = j < nsel ? modes[j] : 0;
                 sa.skip = &ctrl->done;
                 sa.q_first = own_first * nsel; sa.q_count = split ? own_count * nsel : 0;
-                if (!split || own_count > 0) { int r = launch_seg<R>(sa, method); if (r) return r; }
+                if (!split || own_count > 0) { int r = launch_seg<R>(sa, method, adaptive); if (r) return r; }
+                if (adaptive) hipLaunchKernelGGL((pit_adapt_scan_kernel<R>), dim3(1), dim3(1024), 0, g_stream, ad_rS, (const R *)ad_rE, ad_eS, (const Cx<R> *)ad_eE, sg.S, ad_chg, (const PitCtrl *)ctrl, ad_relax);
             } else if (block_form) {
                 LaArgs<R> ls = la;
                 ls.TrSyms = sg.len; ls.nch = sg.S; ls.wx = Y; ls.err_off = (int64_t)it * TrSyms; ls.seg = 1; ls.seg_extra = sg.extra; ls.seg_tail = sg.tail;
@@ -2095,7 +2199,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 hipLaunchKernelGGL((pit_gauge_kernel<R>), dim3(1), dim3(PIT_GT_THREADS), 0, g_stream, (const double *)gph, sg.S, nsel, ctrl, theta, (const double *)pw,
                                    nbnd, method, (const Cx<R> *)symbols + (size_t)modes[0] * nsy, 1);
                 hipLaunchKernelGGL((pit_recur_eig_kernel<R>), dim3(ntot, nsel), dim3(PIT_RT), 0, g_stream, Xe, (const Zf *)Ye, Dz[1], (const double *)theta, lam, nsel, sg.S, sg.len,
-                                   (const R *)mu_dev, beta, (const PitCtrl *)ctrl);
+                                   (const R *)mu_dev, beta, (const PitCtrl *)ctrl, (const float *)ad_M);
                 hipLaunchKernelGGL((pit_devest_kernel<R>), dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax, ticket,
                                    decide_args(p, (const float *)devmax, (const float2 *)Ye, (float2 *)Yprev, ntot, ncol, 1));
             } else {
@@ -2160,6 +2264,23 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             }
             if (ev.hview[2 * p] != 0.f) break;
             if (p + 1 < npass && !ahead && (rc = enqueue_pass(p + 1))) return rc;
+        }
+        if (adaptive) {
+            hipLaunchKernelGGL((pit_adapt_finish_kernel<R>), dim3(1), dim3(1), 0, g_stream, mu_dev, (const R *)ad_rE, sg.S);
+            // A sweep the passes cannot agree on - the later modes of a BLIND stage, which start from centre-spike taps with the tiny step
+            // the first mode left behind: no linear model describes that - ends not converged after a few passes; the call then does what
+            // the reference does: the exact form from the saved taps and step size (report: converged = 2).
+            int32_t conv = 0;
+            QH_HIP(hipMemcpyAsync(&conv, &ctrl->converged, sizeof(conv), hipMemcpyDeviceToHost, g_stream));
+            QH_HIP(hipStreamSynchronize(g_stream));
+            if (!conv) {
+                QH_HIP(hipMemcpyAsync(wx, w_start, wbytes, hipMemcpyDeviceToDevice, g_stream));
+                QH_HIP(hipMemcpyAsync(mu_dev, ad_chg + 1, sizeof(R), hipMemcpyDeviceToDevice, g_stream));
+                if ((rc = train_dev<R>(E, nmodes, L, TrSyms, 1, os, mu_dev, wx, ntaps, modes, 1, 1, symbols, nsy, method, err, 0, nullptr))) return rc;
+                const int32_t two = 2;
+                QH_HIP(hipMemcpyAsync(&ctrl->converged, &two, sizeof(two), hipMemcpyHostToDevice, g_stream));
+                QH_HIP(hipStreamSynchronize(g_stream));
+            }
         }
         if (sym == 0)
             hipLaunchKernelGGL((pit_rotate_err_kernel<R>), dim3(sg.S, nsel), dim3(256), 0, g_stream, (Cx<R> *)err, (int64_t)(TrSyms * Niter), (int64_t)it * TrSyms, sg,

@@ -36,6 +36,10 @@ template <typename R> struct SegArgs {
     const int *skip;
     int q_first, q_count;          // chains [q_first, q_first + q_count) of the S * nsel are trained by this launch (q_count = 0: all)
     int lpm, pitch, rag, nslots;   // lanes per input mode, LDS row pitch (samples), padding taps in the last lane of a mode, segment windows per wave
+    // adaptive step (ADAPT kernels, pythran_equalisation.py:12-16, :171-172): per chain r = 1 / mu and the previous error at the start of
+    // its segment in, at the end out, and the sum of the step sizes its steps used (the coarse model's mu T); adapt_first = 0: the
+    // sweep's step 0 belongs to this grid (no adaptation after it)
+    const R *r_in; R *r_out; const Cx<R> *e_in; Cx<R> *e_out; R *mu_sum; int adapt_first;
 };
 
 // sum over the 16 lanes of a row; every lane gets the total
@@ -139,11 +143,11 @@ constexpr int SG_PIECES = SG_PITCH / 64;
 constexpr int SG_MAXRAG = 3;       // padding taps a lane may hold (handled by selects on its last three tap slots)
 
 #ifdef QH_SEG_KERNELS        // the kernels and their per-method launchers live in train_seg_{a,b}_{f32,f64}.hip (build time: ~190 instantiations)
-template <typename R, int METHOD, int NPART, int TPL, int LPC>
+template <typename R, int METHOD, int NPART, int TPL, int LPC, bool ADAPT = false>
 __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
 {
     constexpr int CPW = 64 / LPC;                               // chains per wave
-    constexpr int SG_ROWS = CPW, SG_NSTG = SG_ROWS * SG_PIECES;
+    constexpr int SG_ROWS = ADAPT ? 2 * CPW : CPW, SG_NSTG = SG_ROWS * SG_PIECES;   // (ADAPT: one output mode per launch - every chain of the wave its own segment window)
     if (a.skip && *a.skip) return;
     // One wave per SIMD, by construction.  A launch of this kernel has about as many single-wave workgroups as the chip has SIMDs
     // (992 at C3's mrde stage); with <= 256 VGPRs two of them fit on a SIMD and the dispatcher does pair them up while other SIMDs
@@ -196,6 +200,12 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     { const Cx<R> c0 = sy[0]; K.R_re = c0.re; K.R_im = c0.im; }
     K.code0_re = K.R_re; K.code0_im = K.R_im;
     tab_fill<R, NPART>(K.tab, sy, 0, NPART + 1);
+    // ADAPT: the chain's step size as r = 1 / mu (adapt_step adds |e_prev|^2 to it unless both component products of successive
+    // errors are positive), the previous error, the sum of the step sizes used
+    R ad_r = 1, ad_sum = 0;
+    Cx<R> ad_ep{0, 0};
+    bool ad_skip0 = false;                                      // this chain's step 0 is step 0 of the sweep: no adaptation after it
+    if constexpr (ADAPT) { ad_r = a.r_in[qc]; ad_ep = a.e_in[qc]; ad_skip0 = a.adapt_first == 0 && my_start == 0; }
 
     // ---- LDS windows: SG_ROWS rows of SG_PITCH samples per buffer, one per (segment window, input mode)
     constexpr int rowsz = SG_PITCH;
@@ -213,7 +223,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     }
     Cx<R> stg_r[SG_NSTG];
     // global loads of chunk `chunk` into registers (no wait) ...
-    auto stage_load = [&](int chunk) {
+    auto stage_load = [&](int chunk) __attribute__((always_inline)) {
         const int64_t adv = (int64_t)chunk * SG_CH * os_;
 #pragma unroll
         for (int u = 0; u < SG_NSTG; u++) {
@@ -226,7 +236,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         }
     };
     // ... and from there into the buffer of that chunk once the previous user of the buffer is done
-    auto stage_store = [&](int chunk) {
+    auto stage_store = [&](int chunk) __attribute__((always_inline)) {
         Cx<R> *dst = lds;
 #pragma unroll
         for (int u = 0; u < SG_NSTG; u++)
@@ -244,12 +254,14 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     const int rag = a.rag;
 
     constexpr int WIN = TPL + 2;                                 // samples of a pair of steps at 2 samples per symbol: they share TPL - 2 of them
-    auto load_x = [&](v2 (&x)[WIN], const Cx<R> *p, auto NLOAD) {
+    auto load_x = [&](v2 (&x)[WIN], const Cx<R> *p, auto NLOAD) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < decltype(NLOAD)::value; j++) { const Cx<R> v = p[j]; x[j] = v2{v.re, v.im}; }
     };
     // one step on the samples x[OFF .. OFF + TPL); returns the error (unscaled) of the step
-    auto step = [&](auto XO, v2 (&x)[WIN], int gstep, auto CHK, auto RG) -> Cx<R> {
+    // (always_inline: a lambda left as a call takes the taps - captured by reference - through scratch memory, as the 2-taps-per-lane
+    // layout did: 5000 instead of 300 cycles per step)
+    auto step = [&](auto XO, v2 (&x)[WIN], int gstep, auto CHK, auto RG) __attribute__((always_inline)) -> Cx<R> {
         constexpr int OFF = decltype(XO)::value;
         // y = sum w x  (no conjugate, pythran_equalisation.py:24-31): two accumulators, combined before the reduction
         // (NCH accumulator chains per product, taps j, j + NCH, ... each: a packed FMA that reads the result of another one needs four
@@ -270,7 +282,22 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         chain_csum<LPC>(yr, yi);
         const Cx<R> y{yr, yi};
         const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K);
-        Cx<R> cc = la_errfn<R, METHOD, NPART, true>(y, K);     // mu * e with mu folded in
+        Cx<R> cc;
+        if constexpr (ADAPT) {
+            const bool live = !decltype(CHK)::value || gstep < my_steps;
+            R m;
+            if constexpr (sizeof(R) == 4) m = __builtin_amdgcn_rcpf(ad_r); else m = (R)1 / ad_r;
+            cc = Cx<R>{m * e.re, m * e.im};
+            const bool keep = (e.re * ad_ep.re > 0) && (e.im * ad_ep.im > 0);
+            const bool first = ad_skip0 && gstep == 0;
+            if (live) {
+                if (!keep && !first) ad_r += ad_ep.re * ad_ep.re + ad_ep.im * ad_ep.im;
+                ad_ep = e;
+                ad_sum += m;
+            }
+        } else {
+            cc = la_errfn<R, METHOD, NPART, true>(y, K);       // mu * e with mu folded in
+        }
         if (decltype(CHK)::value && gstep >= my_steps) cc = Cx<R>{0, 0};   // past the end of this chain's segment: nothing moves
         // w += c conj(x):  (re, im) += x.re (c.re, c.im) + x.im (c.im, -c.re)
         const v2 c1 = {cc.re, cc.im};
@@ -283,8 +310,8 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         for (int j = 0; j < TPL; j++) w[j] = pk_im_rot(x[OFF + j], j >= TPL - NR ? ct : c1, w[j]);    // for the one right before it
         return e;
     };
-    auto keep = [&](Cx<R> e, int u) { const bool mine = l16 == u; ebr = mine ? e.re : ebr; ebi = mine ? e.im : ebi; };
-    auto run_chunk = [&](const Cx<R> *xs, int xstep, int ibase, int nst, auto CHK, auto RG, auto OS2) {
+    auto keep = [&](Cx<R> e, int u) __attribute__((always_inline)) { const bool mine = l16 == u; ebr = mine ? e.re : ebr; ebi = mine ? e.im : ebi; };
+    auto run_chunk = [&](const Cx<R> *xs, int xstep, int ibase, int nst, auto CHK, auto RG, auto OS2) __attribute__((always_inline)) {
         constexpr bool os2 = decltype(OS2)::value != 0;
         v2 xa[WIN], xb[WIN];
         int i = 0;
@@ -331,11 +358,11 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         const int xstep = has ? os_ : 0;
         const int ibase = c * SG_CH;
         const int nst = (max_steps - ibase) < SG_CH ? (max_steps - ibase) : SG_CH;
-        auto run2 = [&](auto RG, auto OS2) {
+        auto run2 = [&](auto RG, auto OS2) __attribute__((always_inline)) {
             if (ibase + nst <= min_steps) run_chunk(xs, xstep, ibase, nst, SgInt<0>{}, RG, OS2);
             else run_chunk(xs, xstep, ibase, nst, SgInt<1>{}, RG, OS2);
         };
-        auto run = [&](auto RG) {                               // (wave-uniform)
+        auto run = [&](auto RG) __attribute__((always_inline)) {   // (wave-uniform)
             if (os_ == 2) run2(RG, SgInt<1>{}); else run2(RG, SgInt<0>{});
         };
         switch (rag) {                                         // wave-uniform: the loops exist once per padding count
@@ -352,6 +379,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
 #pragma unroll
         for (int j = 0; j < TPL; j++)
             if (has && t0 + j < a.ntaps) stg(wrow + kin * a.ntaps + t0 + j, Cx<R>{w[j].x, w[j].y});
+        if constexpr (ADAPT) if (l16 == 0) { a.r_out[q] = ad_r; a.e_out[q] = ad_ep; a.mu_sum[q] = ad_sum; }
     }
 }
 
@@ -376,13 +404,13 @@ inline int seg_slots(int nsel, int cpw = 4)                         // distinct 
     for (int q0 = 0; q0 <= cpw * nsel; q0 += cpw) { const int m = (q0 + cpw - 1) / nsel - q0 / nsel + 1; n = m > n ? m : n; }
     return n;
 }
-inline bool seg_supported(int method, int nmodes, int ntaps, int os, int64_t nsy, size_t elem, int nsel = 1)
+inline bool seg_supported(int method, int nmodes, int ntaps, int os, int64_t nsy, size_t elem, int nsel = 1, int rows = 4)
 {
     (void)elem;
     if (seg_tpl(nmodes, ntaps) == 0) return false;
     if ((SG_CH + 4) * os + ntaps + 8 > SG_PITCH && os == 2) return false;      // chunk + the look-ahead of the window pairs + padding taps fit a row
     if ((SG_CH + 2) * os + ntaps + 8 > SG_PITCH) return false;
-    if (seg_slots(nsel) * nmodes > 4) return false;
+    if (seg_slots(nsel) * nmodes > rows) return false;
     switch (method) {
     case QH_M_CMA: case QH_M_SGNCMA: case QH_M_CMA2: case QH_M_MCMA: return true;
     case QH_M_RDE: case QH_M_MRDE: return nsy - (nsy + 1) / 2 >= 1 && nsy - (nsy + 1) / 2 <= LA_MAXPART;
@@ -443,6 +471,31 @@ template <typename R, int METHOD> static int launch_seg_dd(const SegArgs<R> &a, 
     }
 }
 
+// the adaptive-step kernels (single precision, 16 lanes per chain): translation units train_seg_<method>_f32_ad.hip
+template <typename R, int METHOD, int NPART> static int launch_seg_tpl_ad(const SegArgs<R> &a, int tpl, dim3 grid, size_t lds)
+{
+    switch (tpl) {
+    case 2: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 2, 16, true>), grid, dim3(64), lds, g_stream, a); break;
+    case 4: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 4, 16, true>), grid, dim3(64), lds, g_stream, a); break;
+    case 6: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 6, 16, true>), grid, dim3(64), lds, g_stream, a); break;
+    case 8: hipLaunchKernelGGL((train_seg_kernel<R, METHOD, NPART, 8, 16, true>), grid, dim3(64), lds, g_stream, a); break;
+    default: set_error("segment trainer: unsupported tap layout"); return QH_ERR_ARG;
+    }
+    return QH_OK;
+}
+template <typename R, int METHOD> int launch_seg_ad(const SegArgs<R> &a, int npart, int tpl, dim3 grid, size_t lds)
+{
+    if constexpr (METHOD == QH_M_SBD || METHOD == QH_M_MDDMA || METHOD == QH_M_DD) {
+        switch (npart) {            // 4-, 16-, 64-, 256-QAM
+        case 1: return launch_seg_tpl_ad<R, METHOD, 1>(a, tpl, grid, lds);
+        case 3: return launch_seg_tpl_ad<R, METHOD, 3>(a, tpl, grid, lds);
+        case 7: return launch_seg_tpl_ad<R, METHOD, 7>(a, tpl, grid, lds);
+        case 15: return launch_seg_tpl_ad<R, METHOD, 15>(a, tpl, grid, lds);
+        default: set_error("segment trainer: unsupported slicer size"); return QH_ERR_ARG;
+        }
+    } else return launch_seg_tpl_ad<R, METHOD, 0>(a, tpl, grid, lds);
+}
+
 // one launcher per error function (translation units train_seg_<method>_{f32,f64}.hip instantiate them: the kernels' main loops are
 // unrolled eight or sixteen steps deep in four padding x two end-of-segment variants - build time is spread over many units)
 template <typename R, int METHOD> int launch_seg_m(const SegArgs<R> &a, int npart, int tpl, int lpc, dim3 grid, size_t lds)
@@ -452,6 +505,11 @@ template <typename R, int METHOD> int launch_seg_m(const SegArgs<R> &a, int npar
     else return launch_seg_tpl<R, METHOD, 0>(a, tpl, lpc, grid, lds);
 }
 #else
+template <typename R, int METHOD> int launch_seg_ad(const SegArgs<R> &a, int npart, int tpl, dim3 grid, size_t lds);
+extern template int launch_seg_ad<float, QH_M_CMA>(const SegArgs<float> &, int, int, dim3, size_t);
+extern template int launch_seg_ad<float, QH_M_MCMA>(const SegArgs<float> &, int, int, dim3, size_t);
+extern template int launch_seg_ad<float, QH_M_MDDMA>(const SegArgs<float> &, int, int, dim3, size_t);
+extern template int launch_seg_ad<float, QH_M_SBD>(const SegArgs<float> &, int, int, dim3, size_t);
 template <typename R, int METHOD> int launch_seg_m(const SegArgs<R> &a, int npart, int tpl, int lpc, dim3 grid, size_t lds);
 #define QH_SEG_EXTERN(M) \
     extern template int launch_seg_m<float, M>(const SegArgs<float> &, int, int, int, dim3, size_t); \
@@ -462,20 +520,35 @@ QH_SEG_EXTERN(QH_M_SBD) QH_SEG_EXTERN(QH_M_MDDMA) QH_SEG_EXTERN(QH_M_DD)
 #endif  // QH_SEG_KERNELS
 
 // `a` complete except lpm / pitch / rag; method-specific table layout as for launch_bi (slicer tables for sbd / mddma / dd)
-template <typename R> int launch_seg(SegArgs<R> a, int method)
+inline bool seg_adaptive_supported(int method) { return method == QH_M_CMA || method == QH_M_SGNCMA || method == QH_M_MCMA || method == QH_M_MDDMA || method == QH_M_SBD; }
+template <typename R> int launch_seg(SegArgs<R> a, int method, bool adaptive = false)
 {
     const int nq = a.q_count > 0 ? a.q_count : a.S * a.nsel;
     if (a.q_count <= 0) a.q_first = 0;
-    const int lpc = seg_lanes<R>(a.nmodes, a.ntaps, a.nsel, nq), cpw = 64 / lpc;
+    const int lpc = adaptive ? 16 : seg_lanes<R>(a.nmodes, a.ntaps, a.nsel, nq), cpw = 64 / lpc;
     const int tpl = seg_tpl(a.nmodes, a.ntaps, lpc);
     a.lpm = (a.ntaps + tpl - 1) / tpl;
     a.rag = a.lpm * tpl - a.ntaps;
     a.pitch = SG_PITCH;
     a.nslots = seg_slots(a.nsel, cpw);
-    const size_t lds = (size_t)(cpw + 1) * SG_PITCH * sizeof(Cx<R>);
+    const size_t lds = (size_t)((adaptive ? 2 * cpw : cpw) + 1) * SG_PITCH * sizeof(Cx<R>);
     dim3 grid((nq + cpw - 1) / cpw);
     const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
     int rc;
+    if (adaptive) {
+        if constexpr (sizeof(R) == 4) {
+            switch (method) {
+            case QH_M_CMA: case QH_M_SGNCMA: rc = launch_seg_ad<R, QH_M_CMA>(a, npart, tpl, grid, lds); break;
+            case QH_M_MCMA: rc = launch_seg_ad<R, QH_M_MCMA>(a, npart, tpl, grid, lds); break;
+            case QH_M_MDDMA: rc = launch_seg_ad<R, QH_M_MDDMA>(a, npart, tpl, grid, lds); break;
+            case QH_M_SBD: rc = launch_seg_ad<R, QH_M_SBD>(a, npart, tpl, grid, lds); break;
+            default: rc = QH_ERR_METHOD;
+            }
+        } else rc = QH_ERR_ARG;
+        if (rc) return rc;
+        QH_HIP(hipGetLastError());
+        return QH_OK;
+    }
     switch (method) {
     case QH_M_CMA: case QH_M_SGNCMA: rc = launch_seg_m<R, QH_M_CMA>(a, npart, tpl, lpc, grid, lds); break;
     case QH_M_CMA2: rc = launch_seg_m<R, QH_M_CMA2>(a, npart, tpl, lpc, grid, lds); break;
