@@ -126,7 +126,7 @@ class PitReport(C.Structure):
                 ("deviation_taps_worst", C.c_double * PIT_MAXPASS)]
 
     def as_dict(self):
-        return dict(segments=int(self.segments), seg_len=int(self.seg_len), passes=int(self.passes), converged=bool(self.converged),
+        return dict(segments=int(self.segments), seg_len=int(self.seg_len), passes=int(self.passes), converged=bool(self.converged), exact_form=bool(self.converged == 2),
                     tol=float(self.tol), defect=[float(d) for d in self.defect if d >= 0],
                     acquisition=dict(steps=int(self.acq_steps), chunks=int(self.acq_chunks), mu=float(self.mu_acq),
                                      diverged=bool(self.diverged), mean_sq_err=[float(v) for v in self.acq_err if v >= 0]),

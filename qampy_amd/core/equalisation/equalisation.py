@@ -219,7 +219,8 @@ def last_pit_reports():
 
 def _tier_options(kwargs, nstages, cold):
     """``tier="a"`` (default): the exact sequential recurrence.  ``tier="b"``: the same recurrence solved in parallel in time
-     - fixed step sizes, complex-valued blind / decision-directed methods; ``pit`` = one dict of solver options for
+     - complex-valued blind / decision-directed methods, fixed step sizes or the reference's adaptive step
+    (cma / mcma / sbd / mddma; a sweep the solver cannot certify is redone in the exact form); ``pit`` = one dict of solver options for
     all stages or one per stage.  Returns one options dict (or None) per stage."""
     tier, pit = kwargs.pop("tier", "a"), kwargs.pop("pit", None)
     del _PIT_REPORTS[:]

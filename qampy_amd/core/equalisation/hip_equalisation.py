@@ -331,6 +331,8 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
     relaxation until the boundary defect is below ``tol``.  Keys (all optional): ``segments`` (0 = automatic),
     ``max_passes``, ``tol``, ``acquire`` (cold start: gear-shifted acquisition first), ``phase_seed``, ``gear``,
     ``acq_bound``, ``acq_plateau``, ``acq_chunk``, ``acq_max``.  ``report``: a :class:`PitReportBuffer` the device fills.
+    With ``adaptive=True`` (the reference's shared step size) the output modes are solved in turn, each from the step size the one
+    before it ended with; a mode the passes cannot agree on is redone in the exact form (report: ``exact_form``).
     """
     if method not in _lib.METHOD_ID:
         raise ValueError("Unknown method %s" % method)

@@ -344,7 +344,7 @@ def test_adaptive_step_recipe_through_tier_b(log2n):
         wb, (e1b, e2b) = core_eq.dual_mode_equalisation(E, 2, (1.9e-3, 1.9e-3), 64, tier="b", **kw)
     reps = core_eq.last_pit_reports()
     assert len(reps) == 2 and all(r["converged"] for r in reps)
-    assert reps[1]["converged"] == 1 and reps[1]["segments"] > 16, reps[1]        # the decision-directed stage (last mode) ran in parallel in time
+    assert not reps[1]["exact_form"] and reps[1]["segments"] > 16, reps[1]          # the decision-directed stage (last mode) ran in parallel in time
     for m in range(2):
         assert np.linalg.norm(wa[m] - wb[m]) / np.linalg.norm(wa[m]) < 3e-3
         assert np.sqrt(np.mean(np.abs(e1a[m] - e1b[m]) ** 2)) < 3e-3
