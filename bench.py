@@ -603,6 +603,48 @@ def cert_snr_block(cfg, snr_db, nsym, seed, barrier_sync, pit):
                 tier_b_MSym_s=tb["value"], tier_a_MSym_s=ta["value"])
 
 
+def adaptive_block(log2n=20, seed=1000):
+    """Informational: the reference script's adaptive-step recipe (Scripts/64_qam_equalisation.py:26-32: 64-QAM, 25 dB, 13 taps, mu = 1.9e-3,
+    mcma -> mddma, adaptive_stepsize=(True, True), the shared step size carried from mode to mode) through tier b against the exact path,
+    stage by stage on one capture (each stage from the exact taps of the one before; kernels only, arrays resident; second call timed)."""
+    from qampy_amd import synth, _lib
+    from qampy_amd.core.equalisation import equalisation as eq, hip_equalisation as hk
+    from qampy_amd._lib import DeviceArray
+    nsym, ntaps, mu0 = 1 << log2n, 13, 1.9e-3
+    sig = synth.make_capture(64, nsym, nmodes=2, snr_db=25, theta=np.pi / 3, dgd=30e-12, linewidth=0., seed=seed, dtype=np.complex64)
+    E = np.ascontiguousarray(np.asarray(sig))
+    tr = eq._cal_training_symbol_len(2, ntaps, E.shape[1])
+    dE = DeviceArray.from_host(E)
+    w0 = eq._init_taps(ntaps, 2, 2, np.complex64)
+    stages = []
+    for method in ("mcma", "mddma"):
+        sy = eq._reshape_symbols(sig.coded_symbols if method == "mddma" else None, method, 64, np.complex64, 2)
+        dsy = DeviceArray.from_host(np.ascontiguousarray(sy))
+        res = {}
+        for tier in ("a", "b"):
+            dw, derr, dmu = DeviceArray.from_host(w0.copy()), DeviceArray((2, tr), np.complex64), DeviceArray.from_host(np.array([mu0], np.float32))
+            rep = hk.PitReportBuffer() if tier == "b" else None
+            kw = dict(pit={}, report=rep) if tier == "b" else {}
+            for _ in range(2):
+                dw.set(w0.copy()); dmu.set(np.array([mu0], np.float32)); _lib.sync()
+                t0 = time.perf_counter()
+                hk.train_equaliser_dev(dE, tr, 1, 2, dmu, dw, None, True, dsy, method, derr, zero_err=True, **kw)
+                _lib.sync(); dt = time.perf_counter() - t0
+            res[tier] = dict(w=dw.to_host(), err=derr.to_host(), mu=float(dmu.to_host()[0]), ms=dt * 1e3, rep=rep.read() if rep is not None else None)
+        a, b = res["a"], res["b"]
+        r = b["rep"]
+        stages.append(dict(stage=method, ms_exact=round(a["ms"], 2), ms_tier_b=round(b["ms"], 2), speedup=round(a["ms"] / b["ms"], 2),
+                           tap_rel_dev_vs_exact=[float(np.linalg.norm(a["w"][m] - b["w"][m]) / np.linalg.norm(a["w"][m])) for m in range(2)],
+                           err_trace_rms_dev_vs_exact=[float(np.sqrt(np.mean(np.abs(a["err"][m] - b["err"][m]) ** 2))) for m in range(2)],
+                           final_mu_rel_dev=abs(a["mu"] - b["mu"]) / a["mu"], final_mu_exact=a["mu"],
+                           last_mode=dict(segments=r["segments"], seg_len=r["seg_len"], passes=r["passes"], converged=r["converged"], exact_form=r.get("exact_form", False),
+                                          est_deviation_rms=[float("%.3g" % d) for d in r["deviation_rms"]])))
+        w0 = a["w"]
+    return dict(workload="64-QAM 2-pol 2 SPS 2^%d sym, 13-tap MCMA -> MDDMA, adaptive step (the reference script's recipe)" % log2n, nsym=nsym, stages=stages,
+                note="tier b with adapt_step: modes solved in turn (shared step size), exact head of 16384 steps, r = 1/mu and the previous error as boundary "
+                     "states; a sweep the passes cannot agree on (the blind stage) is redone in the exact form - exact_form = true, deviations 0")
+
+
 def shape_block(key, barrier_sync, pit, steps):
     """Another BASELINE shape in the same line (ns: the north star's 10^7 symbols; c2: configs[1]): tier b, the exact path, SER, certificate."""
     cfg = dict(WORKLOADS[key])
@@ -911,6 +953,7 @@ def main():
                 out["cert_24dB"] = cert_snr_block(cfg, 24.0, min(nsym, 1 << 21), 1001, barrier_sync, pit)
                 for key in ("ns", "c2"):
                     out[key] = shape_block(key, barrier_sync, pit, 3)
+                out["adaptive_step"] = adaptive_block()
             _lib.call("qh_release_scratch")
         except Exception as e:                    # informational blocks never take the headline down
             out["extra_shapes_error"] = "%s: %s" % (type(e).__name__, e)

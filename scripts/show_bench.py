@@ -29,3 +29,6 @@ if d.get("cpu_baseline"):
     print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["one_thread"]["value"])
 if d.get("channel_bank"):
     print("bank", d["channel_bank"].get("value"), d["channel_bank"].get("speedup_vs_cpu_bank"))
+if d.get("adaptive_step"):
+    for st in d["adaptive_step"]["stages"]:
+        print("adaptive", st["stage"], st["ms_exact"], st["ms_tier_b"], st["speedup"], st["tap_rel_dev_vs_exact"], st["err_trace_rms_dev_vs_exact"], st["final_mu_rel_dev"], st["last_mode"])
