@@ -402,6 +402,7 @@ template <typename R> struct PitDecideArgs {
     const double *theta;
     const int64_t *modes_dev;
     int ntot_w, S, sym, corr_wanted;
+    int stall_from;                  // first pass at which "nothing gained over two passes" ends the sweep (2; damped adaptive sweeps: 5)
     const float *extra;              // one more figure the criterion must cover (adaptive step: largest relative change of a segment's start step size), or nullptr
 };
 // (256 threads of ONE block: the kernel below, or the last block of pit_devest_kernel to finish)
@@ -518,7 +519,7 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
         // nothing gained over two passes: the trajectory has no fixed point the passes can agree on (a stage that cannot track the
         // carrier) - stop, NOT converged; further passes would only cost time.  (Slow but steady gains - rde's ring decisions - go on
         // to max_passes: the uncertified result keeps improving with them.)
-        else if (p >= 2 && p < QH_PIT_MAXPASS) {
+        else if (p >= a.stall_from && p < QH_PIT_MAXPASS) {
             const bool use_dev = have_dev && drms2 > 0;
             const double prev2 = use_dev ? drms2 : dfc2, now = use_dev ? dev_rms : red[0];
             if (!(now < prev2)) done = 1;
@@ -921,6 +922,7 @@ template <typename R> struct PitFuse {
     const double *theta;
     const int64_t *modes_dev;
     int nmodes, nsel;
+    float damp = 1.f;                // X = theta X + damp V D~ (1: the full correction)
 };
 // A2 = the matrix whose ROWS are read: V for the forward product (op(A) = V^H: op(A)[m][k] = conj(V[k][m])), V^T for the back
 // transform (op(A) = V: op(A)[m][k] = V^T[k][m]) - consecutive threads read consecutive m either way.
@@ -1259,7 +1261,7 @@ __global__ void __launch_bounds__(64 * (PIT_EIGMAX / 16)) pit_basis_mfma_kernel(
                         if (m < n) {
                             const Cx<R> x = pre ? xv[q][h] : fz.X[base + m];
                             const Zf d = Ct[cc * (PIT_EIGMAX + 1) + m];
-                            const Cx<R> w{(R)(qr * x.re - qi * x.im + d.x), (R)(qr * x.im + qi * x.re + d.y)};
+                            const Cx<R> w{(R)(qr * x.re - qi * x.im + fz.damp * d.x), (R)(qr * x.im + qi * x.re + fz.damp * d.y)};
                             fz.X[base + m] = w;
                             fz.Y[base + m] = w;
                         }
@@ -1337,7 +1339,7 @@ static __global__ void __launch_bounds__(256) pit_bound_kernel(const Zf *Xe, con
 constexpr int PIT_RT = 1024;            // threads of the eigen-space scan: up to 4 segments per thread stay in registers (S <= 4096: one round of loads)
 template <typename R>
 __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf *Ye, Zf *D, const double *theta, const double *lam, int nsel, int S, int64_t T, const R *mu,
-                                                               double beta, const PitCtrl *c, const float *Msum = nullptr)
+                                                               double beta, const PitCtrl *c, const float *Msum = nullptr, float damp = 1.f)
 {
     if (c->done) return;
     __shared__ float4 aff[2 * PIT_RT];
@@ -1397,7 +1399,7 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
                 pw *= cq[q];
                 const Zf v{r[q].x + pw * comp.y, r[q].y + pw * comp.z};
                 row[(size_t)s * nsel] = v;
-                xr[(size_t)s * nsel] = Zf{x[q].x + v.x, x[q].y + v.y};
+                xr[(size_t)s * nsel] = Zf{x[q].x + damp * v.x, x[q].y + damp * v.y};
             }
         }
         return;
@@ -1450,7 +1452,7 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
                 v[q].x += pw * cin.x; v[q].y += pw * cin.y;
                 row[(size_t)s * nsel] = v[q];
                 const Zf xx = cmulf(t[q], x[q]);
-                xr[(size_t)s * nsel] = Zf{xx.x + v[q].x, xx.y + v[q].y};
+                xr[(size_t)s * nsel] = Zf{xx.x + damp * v[q].x, xx.y + damp * v[q].y};
             }
         }
     }
@@ -1831,8 +1833,11 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     }
     const int ntot = nmodes * ntaps;
     QH_REQUIRE(ntot <= 64 * 16, "train_equaliser: more than 1024 taps per output mode are not supported");
-    const int npass = o.max_passes > 0 ? o.max_passes : 16;
-    const double tol = o.tol > 0 ? o.tol : 1e-3;
+    // Adaptive sweeps apply 0.7 of every correction after the first (the full one overshoots: the estimate then GROWS 1.7 x per pass on the
+    // blind stage of the reference script's recipe; damped it falls 0.3-0.5 x per pass, profiles/r03_adaptive_tier_b.txt) and what is left
+    // of the early corrections sits in the result, so they are held to a third of the tolerance and may take 24 passes.
+    const int npass = o.max_passes > 0 ? o.max_passes : (adaptive ? QH_PIT_MAXPASS : 16);
+    const double tol = (o.tol > 0 ? o.tol : 1e-3) * (adaptive ? 1.0 / 3.0 : 1.0);
     const double safety = o.dev_safety > 0 ? o.dev_safety : PIT_DEV_SAFETY;
     const double gear = o.gear > 0 ? o.gear : 8.0;
     const double bound = o.acq_bound > 0 ? o.acq_bound : 0.08;
@@ -1853,7 +1858,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     // adaptive step: the first 16384 steps (while the step is large) in the exact form, then segments of 2048 steps
     static int64_t head_env = -1, seg_env = -1;                   // (measurements: QAMPY_HIP_PIT_ADAPT_HEAD / _SEG = steps)
     if (head_env < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_HEAD"); head_env = e && atoll(e) > 0 ? atoll(e) : 0; const char *g = getenv("QAMPY_HIP_PIT_ADAPT_SEG"); seg_env = g && atoll(g) > 0 ? atoll(g) : 0; }
-    static float ad_relax = -1.f;
+    static float ad_relax = -1.f, ad_damp = -1.f;
+    if (ad_damp < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_DAMP"); ad_damp = e && atof(e) > 0 ? (float)atof(e) : 0.7f; }
     if (ad_relax < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_RELAX"); ad_relax = e && atof(e) > 0 ? (float)atof(e) : 1.0f; }
     const int64_t head_want = head_env > 0 ? head_env : 16384, seg_want = seg_env > 0 ? seg_env : 2048;
     const int64_t head = adaptive ? ((TrSyms / 4 < head_want ? TrSyms / 4 : head_want) / LA_B * LA_B) : 0;
@@ -2121,6 +2127,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             d.host_view = &ev.hview[2 * p]; d.nrow = nsel; d.devmax = dm; d.ndev = ndev; d.safety = safety; d.Ye = ye; d.Yprev = yprev; d.ne = ne; d.ncol_e = ncol_e;
             d.theta = theta; d.modes_dev = (const int64_t *)modes_dev; d.ntot_w = ntot; d.S = (int)sg.S; d.sym = sym; d.corr_wanted = corr_wanted;
             d.extra = adaptive ? (const float *)ad_chg : nullptr;
+            d.stall_from = adaptive ? 5 : 2;
             return d;
         };
         auto timed = [&](int p) { return timing_mode == 2 || (timing_mode == 1 && p == 1); };
@@ -2128,6 +2135,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             ((volatile float *)ev.hview)[2 * p] = -1.f;             // "not decided yet": pit_decide_kernel overwrites it (polled below)
             PitFuse<R> fz;
             fz.X = X; fz.Y = Y; fz.theta = theta; fz.modes_dev = (const int64_t *)modes_dev; fz.nmodes = nmodes; fz.nsel = nsel;
+            fz.damp = (adaptive && p > 1) ? ad_damp : 1.f;      // (the first correction - from the seeds to the trajectory - in full)
             if (p > 0 && want_corr) {
                 // start taps = theta X + V D~ with D[s+1] = d[s+1] + J D[s] from the analysis that closed pass p - 1 (below); with the
                 // correction switched off on the device (corr_on = 0) the scan ran with coefficient 0, D = d: plain relaxation
@@ -2199,7 +2207,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 hipLaunchKernelGGL((pit_gauge_kernel<R>), dim3(1), dim3(PIT_GT_THREADS), 0, g_stream, (const double *)gph, sg.S, nsel, ctrl, theta, (const double *)pw,
                                    nbnd, method, (const Cx<R> *)symbols + (size_t)modes[0] * nsy, 1);
                 hipLaunchKernelGGL((pit_recur_eig_kernel<R>), dim3(ntot, nsel), dim3(PIT_RT), 0, g_stream, Xe, (const Zf *)Ye, Dz[1], (const double *)theta, lam, nsel, sg.S, sg.len,
-                                   (const R *)mu_dev, beta, (const PitCtrl *)ctrl, (const float *)ad_M);
+                                   (const R *)mu_dev, beta, (const PitCtrl *)ctrl, (const float *)ad_M, (adaptive && p >= 1) ? ad_damp : 1.f);
                 hipLaunchKernelGGL((pit_devest_kernel<R>), dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax, ticket,
                                    decide_args(p, (const float *)devmax, (const float2 *)Ye, (float2 *)Yprev, ntot, ncol, 1));
             } else {
