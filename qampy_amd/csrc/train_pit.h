@@ -1516,28 +1516,51 @@ __global__ void __launch_bounds__(256) pit_adapt_init_kernel(const R *mu, const 
 // After a pass: what a segment adds to r does not depend on the r it started from (to first order), so the next start values are
 // r[0] + the prefix sums of this pass's increments - one pass carries a change of r through ALL later segments; the previous error of
 // segment s + 1 is the last error of segment s.  chg[0] = the largest relative change of a start value (part of the stop rule).
+// newton != 0 (from the third pass on): a segment's increment d_s is not quite independent of the r it started from - in a blind
+// stage the tap-noise part of |e|^2 shrinks with the step, d ln d / d ln r = -kappa with kappa ~ 1-3 - and the plain prefix sum hands
+// that on to every later segment with the opposite sign, pass after pass (profiles/r03_adaptive_tier_b.txt).  With kappa_s from the
+// last two passes (secant, clamped to [0, 4]) the new start values solve r'[s+1] = r'[s] + d_s (1 - kappa_s (r'[s] - r[s]) / r[s]):
+// a first-order recurrence with one coefficient per segment - a scan of affine maps like the one of the taps.
 template <typename R>
-__global__ void __launch_bounds__(1024) pit_adapt_scan_kernel(R *rS, const R *rE, Cx<R> *eS, const Cx<R> *eE, int n, float *chg, const PitCtrl *c, float relax)
+__global__ void __launch_bounds__(1024) pit_adapt_scan_kernel(R *rS, const R *rE, Cx<R> *eS, const Cx<R> *eE, int n, float *chg, const PitCtrl *c, float relax,
+                                                              float *rPrev, float *dPrev, int newton)
 {
     if (c->done) return;
-    __shared__ double buf[16];
+    __shared__ double2 buf[16];
     __shared__ float red[16];
+    const int pass = c->passes;
     const int len = (n + 1023) / 1024;
     const int s0 = threadIdx.x * len, s1 = s0 + len < n ? s0 + len : n;
-    double sum = 0;
-    for (int s = s0; s < s1; s++) sum += (double)rE[s] - (double)rS[s];
-    double run = block_scan_excl<double, double (*)(double, double), 1024>(sum, [](double x, double y) { return x + y; }, 0.0, buf) + (double)rS[0];
+    auto seg_map = [&](int s, double &A, double &B) {             // r'[s+1] = A r'[s] + B
+        const double rho = (double)rS[s], d = (double)rE[s] - rho;
+        double kappa = 0;
+        if (newton && pass >= 2) {
+            const double rp = (double)rPrev[s], dp = (double)dPrev[s];
+            if (fabs(rho - rp) > 1e-6 * rho && fabs(d) > 1e-30) kappa = -((d - dp) / d) / ((rho - rp) / rho);
+            kappa = kappa == kappa ? (kappa < 0 ? 0 : (kappa > 4 ? 4 : kappa)) : 0;
+        }
+        A = 1.0 - kappa * d / rho;
+        B = d * (1.0 + kappa);
+    };
+    double Ac = 1, Bc = 0;
+    for (int s = s0; s < s1; s++) { double A, B; seg_map(s, A, B); Bc = A * Bc + B; Ac = A * Ac; }
+    auto comp = [](double2 e, double2 l) { return double2{l.x * e.x, l.x * e.y + l.y}; };
+    const double2 pre = block_scan_excl<double2, decltype(comp), 1024>(double2{Ac, Bc}, comp, double2{1.0, 0.0}, buf);
+    double run = pre.x * (double)rS[0] + pre.y;                   // r'[s0]
     float worst = 0.f;
     for (int s = s0; s < s1; s++) {
-        const double inc = (double)rE[s] - (double)rS[s];
+        double A, B;
+        seg_map(s, A, B);
+        const float old = (float)rS[s];
+        rPrev[s] = old; dPrev[s] = (float)((double)rE[s] - (double)old);
         if (s > 0) {
-            const float old = (float)rS[s], nw = c->passes == 0 ? (float)run : old + relax * ((float)run - old);
+            const float nw = pass == 0 ? (float)run : old + relax * ((float)run - old);
             const float rel = fabsf(nw - old) / (fabsf(old) > 1e-30f ? fabsf(old) : 1e-30f);
             worst = (rel > worst || !(rel == rel)) ? (rel == rel ? rel : 3.0e38f) : worst;
             rS[s] = (R)nw;
             eS[s] = eE[s - 1];
         }
-        run += inc;
+        run = A * run + B;
     }
     for (int o = 32; o > 0; o >>= 1) { const float w2 = __shfl_xor(worst, o); worst = worst > w2 ? worst : w2; }
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = worst;
@@ -1859,6 +1882,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     static int64_t head_env = -1, seg_env = -1;                   // (measurements: QAMPY_HIP_PIT_ADAPT_HEAD / _SEG = steps)
     if (head_env < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_HEAD"); head_env = e && atoll(e) > 0 ? atoll(e) : 0; const char *g = getenv("QAMPY_HIP_PIT_ADAPT_SEG"); seg_env = g && atoll(g) > 0 ? atoll(g) : 0; }
     static float ad_relax = -1.f, ad_damp = -1.f;
+    static int ad_newton = -1;
+    if (ad_newton < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_NEWTON"); ad_newton = e ? atoi(e) : 1; }
     if (ad_damp < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_DAMP"); ad_damp = e && atof(e) > 0 ? (float)atof(e) : 0.7f; }
     if (ad_relax < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_RELAX"); ad_relax = e && atof(e) > 0 ? (float)atof(e) : 1.0f; }
     const int64_t head_want = head_env > 0 ? head_env : 16384, seg_want = seg_env > 0 ? seg_env : 2048;
@@ -1954,14 +1979,14 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     // error rows of the head (the exact form writes rows of its own length)
     R *ad_rS = nullptr, *ad_rE = nullptr;
     Cx<R> *ad_eS = nullptr, *ad_eE = nullptr, *ad_errh = nullptr;
-    float *ad_M = nullptr, *ad_chg = nullptr;
+    float *ad_M = nullptr, *ad_chg = nullptr, *ad_rP = nullptr, *ad_dP = nullptr;
     if (adaptive) {
         void *ab = nullptr;
         const size_t nS = ((size_t)sg.S + 15) / 16 * 16;
-        if ((rc = scratch(13, nS * (2 * sizeof(R) + 2 * sizeof(Cx<R>) + sizeof(float)) + 64 + (size_t)nmodes * head * sizeof(Cx<R>), &ab))) return rc;
+        if ((rc = scratch(13, nS * (2 * sizeof(R) + 2 * sizeof(Cx<R>) + 3 * sizeof(float)) + 64 + (size_t)nmodes * head * sizeof(Cx<R>), &ab))) return rc;
         ad_eS = (Cx<R> *)ab; ad_eE = ad_eS + nS; ad_errh = ad_eE + nS;
         ad_rS = (R *)(ad_errh + (size_t)nmodes * head); ad_rE = ad_rS + nS;
-        ad_M = (float *)(ad_rE + nS); ad_chg = ad_M + nS;
+        ad_M = (float *)(ad_rE + nS); ad_rP = ad_M + nS; ad_dP = ad_rP + nS; ad_chg = ad_dP + nS;
     }
     QH_HIP(hipMemcpyAsync(modes_dev, modes, (size_t)nsel * sizeof(int64_t), hipMemcpyHostToDevice, g_stream));
     R mu_acq_h = 0;                                               // the gear-shifted step size pit_setup_kernel chose (sizes the acquisition run)
@@ -2166,7 +2191,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 sa.skip = &ctrl->done;
                 sa.q_first = own_first * nsel; sa.q_count = split ? own_count * nsel : 0;
                 if (!split || own_count > 0) { int r = launch_seg<R>(sa, method, adaptive); if (r) return r; }
-                if (adaptive) hipLaunchKernelGGL((pit_adapt_scan_kernel<R>), dim3(1), dim3(1024), 0, g_stream, ad_rS, (const R *)ad_rE, ad_eS, (const Cx<R> *)ad_eE, sg.S, ad_chg, (const PitCtrl *)ctrl, ad_relax);
+                if (adaptive) hipLaunchKernelGGL((pit_adapt_scan_kernel<R>), dim3(1), dim3(1024), 0, g_stream, ad_rS, (const R *)ad_rE, ad_eS, (const Cx<R> *)ad_eE, sg.S, ad_chg, (const PitCtrl *)ctrl, ad_relax, ad_rP, ad_dP, ad_newton);
             } else if (block_form) {
                 LaArgs<R> ls = la;
                 ls.TrSyms = sg.len; ls.nch = sg.S; ls.wx = Y; ls.err_off = (int64_t)it * TrSyms; ls.seg = 1; ls.seg_extra = sg.extra; ls.seg_tail = sg.tail;
