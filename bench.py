@@ -642,7 +642,8 @@ def adaptive_block(log2n=20, seed=1000):
         w0 = a["w"]
     return dict(workload="64-QAM 2-pol 2 SPS 2^%d sym, 13-tap MCMA -> MDDMA, adaptive step (the reference script's recipe)" % log2n, nsym=nsym, stages=stages,
                 note="tier b with adapt_step: modes solved in turn (shared step size), exact head of 16384 steps, r = 1/mu and the previous error as boundary "
-                     "states; a sweep the passes cannot agree on (the blind stage) is redone in the exact form - exact_form = true, deviations 0")
+                     "states, corrections damped (0.7), tolerance / 3; a sweep that is not certified within 24 passes is redone in the exact form inside the call "
+                     "(exact_form = true for the last mode, deviations exactly 0 for such a mode)")
 
 
 def shape_block(key, barrier_sync, pit, steps):

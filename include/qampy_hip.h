@@ -294,8 +294,9 @@ typedef struct qh_pit_opts {
                              * does not synchronise around it and enqueues the next pass ahead as in the single-process case */
     double dev_safety;      /* 0 = 1: factor on the deviation estimate in the stop rule */
     int32_t adaptive;       /* != 0: the step size adapts (adapt_step); ONE output mode per call (nsel = 1), one sweep, complex64, cma / mcma / sbd /
-                             * mddma; mu is in/out like in the exact entry points.  The first 16384 steps run in the exact form; a sweep the passes cannot
-                             * agree on is redone in the exact form (report: converged = 2) (ABI 4) */
+                             * mddma; mu is in/out like in the exact entry points.  The first 16384 steps run in the exact form, the sweep is held to
+                             * tol / 3 with up to 24 passes (damped corrections); one that is not certified is redone in the exact form
+                             * (report: converged = 2) (ABI 4) */
     int32_t reserved0;
 } qh_pit_opts;
 typedef struct qh_pit_report {
