@@ -88,12 +88,15 @@ class ResidentReceiver:
             self.ph = DeviceArray((self.modes.size, self.N), self.rt)
             self.out = DeviceArray((self.modes.size, self.N), self.ct)
         if tier == "b":
-            if any(self.adaptive):
-                raise ValueError("parallel-in-time training needs fixed step sizes")
+            if any(isinstance(a, str) for a in self.adaptive):
+                raise ValueError("parallel-in-time training with the adaptive step: the reference's shared step size only (adaptive_stepsize=True)")
             self.pit_report = [_k.PitReportBuffer() for _ in methods]
             for s_, o in enumerate(self.pit):          # segment grid from the host copy of mu: the call then never synchronises
                 o.setdefault("acquire", 1 if s_ == 0 else 0)
-                o.setdefault("segments", _k.pit_auto_segments(self.TrSyms[s_], float(self.mu0[s_]), self.modes.size, cold=bool(o["acquire"])))
+                if self.adaptive[s_]:                  # adaptive step: the library's own grid (exact head + 2048-step segments), modes in turn
+                    o.setdefault("segments", 0)
+                else:
+                    o.setdefault("segments", _k.pit_auto_segments(self.TrSyms[s_], float(self.mu0[s_]), self.modes.size, cold=bool(o["acquire"])))
         _lib.sync()
 
     # ------------------------------------------------------------------------------------------ data movement
