@@ -1886,8 +1886,17 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     if (ad_newton < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_NEWTON"); ad_newton = e ? atoi(e) : 1; }
     if (ad_damp < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_DAMP"); ad_damp = e && atof(e) > 0 ? (float)atof(e) : 0.7f; }
     if (ad_relax < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_RELAX"); ad_relax = e && atof(e) > 0 ? (float)atof(e) : 1.0f; }
-    const int64_t head_want = head_env > 0 ? head_env : 16384, seg_want = seg_env > 0 ? seg_env : 2048;
+    const int64_t head_want = head_env > 0 ? head_env : 16384;
     const int64_t head = adaptive ? ((TrSyms / 4 < head_want ? TrSyms / 4 : head_want) / LA_B * LA_B) : 0;
+    // Segment length of an adaptive sweep: 2048 steps; a BLIND stage gets at most ~512 segments - the transient of its iteration grows
+    // with the number of segments (2^22 symbols: 2039 segments of 2048 steps meet tol / 3 only at the 24-pass cap or not at all, 509
+    // segments of 8192 steps in 12-14 passes; the decision-directed stage needs 5-7 passes either way and is faster with short segments)
+    int64_t seg_want = 2048;
+    if (adaptive && !(method == QH_M_SBD || method == QH_M_MDDMA || method == QH_M_DD)) {
+        const int64_t t = ((TrSyms - head) / 512 + LA_B - 1) / LA_B * LA_B;
+        if (t > seg_want) seg_want = t;
+    }
+    if (seg_env > 0) seg_want = seg_env;
     if (S == 0 && adaptive) S = (int)((TrSyms - head) / seg_want < PIT_MAXSEG ? (TrSyms - head) / seg_want : PIT_MAXSEG);
     if (S == 0) {
         R mu_h = 0;
