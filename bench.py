@@ -522,7 +522,7 @@ def tier_b_block(cfg, rx, stage_names, pass_ms, acq_ms, reports, value, ms, errs
                        "correction; segment 0 starts from the caller's taps (fixed point = the sequential recurrence); stopped by the device-side "
                        "estimate of the output deviation from the sequential recurrence < tol" % " -> ".join(cfg["methods"]),
                 value=round(value, 4), unit="MSym/s", ms_per_step=round(ms, 3),
-                stages=[dict(stage=stage_names[1 + s], S=r["segments"], seg_len=r["seg_len"], P=r["passes"], converged=r["converged"], tol=r["tol"],
+                stages=[dict(stage=stage_names[1 + s], S=r["segments"], seg_len=r["seg_len"], P=r["passes"], converged=r["converged"], exact_form=bool(r.get("exact_form", False)), tol=r["tol"],
                              defect=[float("%.3g" % d) for d in r["defect"]],
                              est_deviation_rms=[float("%.3g" % d) for d in r.get("deviation_rms", [])],
                              est_deviation_worst=[float("%.3g" % d) for d in r.get("deviation", [])],
@@ -573,14 +573,18 @@ def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_
         # (with a phase search behind the equaliser the tolerance is held by the equaliser output and by the recovered output on the
         # symbols where both searches chose the same test angle; where a near-tie of the arg-min fell the other way the recovered output
         # differs by one angle step whatever the tolerance - the fraction of such symbols and the all-symbol figure are in the line too)
-        ok_out = all(d <= tol_check for d in dev.get("eq_rms_dev_vs_exact", dev["out_rms_dev_vs_exact"])) and \
-                 all(d <= tol_check for d in dev.get("out_rms_dev_same_angle", dev["out_rms_dev_vs_exact"]))
-        ok_all = all(d <= tol_check for d in dev["out_rms_dev_vs_exact"])
+        ok_eq = all(d <= tol_check for d in dev.get("eq_rms_dev_vs_exact", dev["out_rms_dev_vs_exact"]))
+        ok_same = all(d <= tol_check for d in dev.get("out_rms_dev_same_angle", dev["out_rms_dev_vs_exact"]))
         ok_tap = all(d <= 3 * tol_check for d in dev["tap_rel_dev_vs_exact"])
         ok_ser = all(abs(a - b) <= SER_TOL_ERRORS for a, b in zip(errs_a, [e for e, _ in errs]))
-        tb["checks"] = dict(converged=tb["converged"], out_rms_dev_le_tol=bool(ok_out), recovered_out_all_symbols_le_tol=bool(ok_all), tap_rel_dev_le_3tol=bool(ok_tap),
-                            errors_within_3=bool(ok_ser), tol=tol_check)
-        tb["certified"] = bool(tb["converged"] and ok_out and ok_tap and ok_ser)
+        # every entry of `checks` is part of the certificate (all must hold); figures that are reported but not held to the tolerance
+        # are under `info` - the recovered output over ALL symbols includes the windows in which a near-tie of the phase search's arg-min
+        # fell the other way (one test-angle step, whatever the tolerance; the reference's own float32 / float64 runs differ there too)
+        tb["checks"] = dict(converged=tb["converged"], equaliser_out_rms_dev_le_tol=bool(ok_eq), recovered_out_rms_dev_on_same_angle_symbols_le_tol=bool(ok_same),
+                            tap_rel_dev_le_3tol=bool(ok_tap), errors_within_3=bool(ok_ser), tol=tol_check)
+        tb["info"] = dict(recovered_out_rms_dev_all_symbols=dev["out_rms_dev_vs_exact"], other_angle_symbol_fraction=dev.get("bps_angle_mismatch_fraction"),
+                          exact_form_stages=[st["stage"] for st in tb["stages"] if st.get("exact_form")])
+        tb["certified"] = bool(all(v for k, v in tb["checks"].items() if k != "tol"))
         del rxa
     else:
         tb["certified"] = tb["converged"]
@@ -653,8 +657,8 @@ def shape_block(key, barrier_sync, pit, steps):
     sig = make_input(cfg, nsym, 1000)
     tb, ta, ex = run_pair(cfg, sig, nsym, steps, 1, barrier_sync, pit, 1, pit.get("tol", TOL_DEFAULT) if pit else TOL_DEFAULT)
     del ex
-    return dict(workload=cfg["label"], nsym=nsym, tier_b=dict(value=tb["value"], ms_per_step=tb["ms_per_step"], certified=tb["certified"], checks=tb.get("checks"),
-                                                               stages=[dict(stage=st["stage"], S=st["S"], seg_len=st["seg_len"], P=st["P"], converged=st["converged"],
+    return dict(workload=cfg["label"], nsym=nsym, tier_b=dict(value=tb["value"], ms_per_step=tb["ms_per_step"], certified=tb["certified"], checks=tb.get("checks"), info=tb.get("info"),
+                                                               stages=[dict(stage=st["stage"], S=st["S"], seg_len=st["seg_len"], P=st["P"], converged=st["converged"], exact_form=st.get("exact_form", False),
                                                                             est_deviation_rms=st["est_deviation_rms"][-1:] , pass_ms=st["pass_ms"]) for st in tb["stages"]],
                                                                out_rms_dev_vs_exact=tb["out_rms_dev_vs_exact"], tap_rel_dev_vs_exact=tb["tap_rel_dev_vs_exact"],
                                                                eq_rms_dev_vs_exact=tb.get("eq_rms_dev_vs_exact"), out_rms_dev_same_angle=tb.get("out_rms_dev_same_angle"),
@@ -700,6 +704,9 @@ def main():
     ap.add_argument("--split-capture", action="store_true",
                     help="N > 1: ONE capture, the segments of the tier-b trainer spread over the ranks with an all-reduce of their end taps per pass "
                          "(qampy_amd.distributed; strong scaling, informational - the default is one independent capture per GPU)")
+    ap.add_argument("--allow-tcp", action="store_true",
+                    help="N > 1 on GPUs: go on with the host-side socket collectives when RCCL cannot start (default: exit non-zero - a multi-GPU line must not be "
+                         "produced without RCCL ever being used)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: kernels replaced by a sleep, socket collectives - exercises launcher + reductions")
     args = ap.parse_args()
 
@@ -732,6 +739,16 @@ def main():
     backend = "tcp" if args.dry_run else os.environ.get("QAMPY_BENCH_BACKEND", "auto")
     cm = Comm(device=dev, backend=backend)
     ranks_seen = int(round(sharding.reduce_sum_counts([[1.0]], cm)[0, 0]))
+    if world > 1 and not args.dry_run and cm.backend != "rccl" and not args.allow_tcp and ndev >= world:
+        # every rank has its own GPU and the group is still not RCCL: refuse (all ranks agreed on the backend, so all of them leave here)
+        if rank == 0:
+            print(json.dumps(dict(error="N = %d ranks on %d visible GPUs but the process group is '%s', not RCCL (%s); --allow-tcp to run with host-side collectives"
+                                        % (world, ndev, cm.backend, cm.note or "no reason recorded"), n_gpus=world, ranks_seen=ranks_seen, comm_backend=cm.backend)))
+        cm.close()
+        sys.stdout.flush()
+        if getattr(cm, "stuck", False):
+            os._exit(3)
+        sys.exit(3)
 
     def barrier_sync():
         if not args.dry_run:
@@ -825,7 +842,7 @@ def main():
                stages_ms={n: round(t, 3) for n, t in zip(stage_names, stage_ms)},
                ser=dict(per_mode_rank0=[e / max(n, 1) for e, n in errs], errors_rank0=[e for e, _ in errs], errors_all=int(counts_all[:, 0].sum()),
                         symbols_all=int(counts_all[:, 1].sum())),
-               device=_lib.device_name())
+               device=_lib.device_name(), comm_backend=comm_backend)
     if comm_note:
         out["config"]["comm_note"] = comm_note
     if split:
@@ -852,8 +869,12 @@ def main():
         out["note"] = "tier b did NOT certify itself on every rank and no exact path ran beside it (N > 1): value is tier b's, uncertified"
     out["headline_tier"] = "b" if (use_b or uncertified_b) else "a"
     out["config"]["train_mode"] = (
-        ("parallel-in-time solver of the reference's recurrence (tier b, tol %g): certified in-run - device estimate of the output deviation < tol on every stage" % tol_check
-         + (" AND measured against the exact path on the same capture: recovered output within tol (relative rms), taps within 3 tol, error counts within +-%d" % SER_TOL_ERRORS
+        ("parallel-in-time solver of the reference's recurrence (tier b, tol %g), certified in-run.  Device: estimated rms deviation of the equaliser output from the "
+         "sequential recurrence < tol on every stage (a stage that is not certified is redone in the exact form inside the call)" % tol_check
+         + ("; measured against the exact path on the same capture, two levels: (1) equaliser output <= tol (relative rms) and taps <= 3 tol (relative norm) - every symbol; "
+            "(2) recovered output (after the phase search) <= tol on the symbols where both searches chose the same test angle; the other symbols (fraction f = %s per mode: "
+            "near-ties of the arg-min over the test angles, one angle step apart whatever the tolerance) are reported, not held to tol; symbol-error counts within +-%d"
+            % (["%.2g" % v for v in (tier_b.get("bps_angle_mismatch_fraction") or [])], SER_TOL_ERRORS)
             if world == 1 else " on every rank")) if use_b else
         ("parallel-in-time (tier b), NOT certified" if uncertified_b else "exact sequential recurrence (tier a)"))
 
@@ -880,8 +901,12 @@ def main():
             if hit and hit[0].get("SQ_INSTS_VALU"):
                 per_sym, src = float(hit[0]["SQ_INSTS_VALU"]) / rows, "SQ_INSTS_VALU / distance rows (profiles/pmc_instr_%s.json)" % args.workload
             winstr = rows * per_sym
-            roofline.update(bound="valu-issue", achieved=round(winstr / (kms * 1e-3) / 1e9, 1), peak=VALU_PEAK_GINSTR, unit="G wave-instr/s",
-                            frac=round(winstr / (kms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4), hbm=hbm, valu_instr_per_symbol=round(per_sym, 2), valu_instr_source=src,
+            sflops = nsym * rx.modes.size * cfg["A"] * 25.0                         # slicer search ~ A x 25 flop per symbol and mode
+            roofline.update(bound="valu-fp32", achieved=round(sflops / (kms * 1e-3) / 1e12, 3), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(sflops / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4), algorithmic_flops=int(sflops),
+                            issue_frac=round(winstr / (kms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4),
+                            issue=dict(achieved=round(winstr / (kms * 1e-3) / 1e9, 1), peak=VALU_PEAK_GINSTR, unit="G wave-instr/s"),
+                            hbm=hbm, valu_instr_per_symbol=round(per_sym, 2), valu_instr_source=src,
                             note="lane <-> test angle, one wave per 1024 symbols; the stage time also holds alphabet analysis, unwrap scan and de-rotation")
         if "relaxation pass" in kname:
             # what bounds the pass kernel: instruction issue of the fp32 vector units, not HBM
@@ -899,15 +924,33 @@ def main():
                 ipw = float(hit[0]["SQ_INSTS_VALU"]) / (float(hit[0]["SQ_WAVES"]) * st["seg_len"])
                 src = "SQ_INSTS_VALU / (SQ_WAVES x steps per chain) of the same kernel sources (profiles/pmc_instr_%s.json)" % args.workload
             winstr = waves * st["seg_len"] * ipw
-            roofline.update(bound="valu-issue", achieved=round(winstr / (kms * 1e-3) / 1e9, 1), peak=VALU_PEAK_GINSTR, unit="G wave-instr/s",
-                            frac=round(winstr / (kms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4), hbm=hbm, launches_per_step=st["P"],
-                            valu=dict(flops_per_launch=int(flops), achieved_tflops=round(flops / (kms * 1e-3) / 1e12, 2), peak_tflops=VALU_PEAK_TFLOPS,
-                                      frac=round(flops / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)),
+            # The roofline of this kernel is the packed-fp32 VECTOR peak (intensity 54 flop/B against a machine balance of ~20: the compute
+            # side binds; no GEMM shape at 2 output modes, so not MFMA): `achieved` = ALGORITHMIC flops of one launch (filter +
+            # update = 2 x nmodes x ntaps complex multiply-adds x 8 flop per chain and step) / the event-timed launch duration, `frac` = that over
+            # 157.3 TFLOP/s.  `issue_frac` beside it is the utilisation view (all vector instructions the kernel issues - DPP adds, selects,
+            # error function included - against 1024 SIMDs x 2.4 GHz / 4 cycles): how busy the issue ports are, not how much of it is useful.
+            roofline.update(bound="valu-fp32", achieved=round(flops / (kms * 1e-3) / 1e12, 3), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                            frac=round(flops / (kms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4), algorithmic_flops=int(flops), hbm=hbm, launches_per_step=st["P"],
+                            issue_frac=round(winstr / (kms * 1e-3) / 1e9 / VALU_PEAK_GINSTR, 4),
+                            issue=dict(achieved=round(winstr / (kms * 1e-3) / 1e9, 1), peak=VALU_PEAK_GINSTR, unit="G wave-instr/s", valu_instr_per_wave_step=round(ipw, 1),
+                                       irreducible_pk_fma_per_wave_step=round((64 // lpc) * 2 * ntot * 4 / 2 / 64.0, 1), valu_instr_source=src),
                             chains=int(chains), lanes_per_chain=lpc, waves=int(waves), waves_per_simd=round(waves / 1024.0, 2), steps_per_chain=int(st["seg_len"]),
-                            valu_instr_per_wave_step=round(ipw, 1), valu_instr_source=src,
-                            note="one launch trains all segments of the sweep (%d lanes per chain, %d chains per wave64, one wave per SIMD): bound by VALU issue" % (lpc, 64 // lpc) + " - achieved / peak are "
-                                 "vector instructions per second against 1024 SIMDs x 2.4 GHz / 4 cycles; `hbm`: algorithmic bytes of one sweep (read E, write "
-                                 "err) against 8 TB/s, `valu`: recurrence flops against the packed-fp32 peak")
+                            note="one launch trains all segments of the sweep (%d lanes per chain, %d chains per wave64, one wave per SIMD); frac = algorithmic flops of the "
+                                 "recurrence / packed-fp32 vector peak; issue_frac = vector instructions issued / nominal issue rate; `hbm`: algorithmic bytes of one sweep "
+                                 "(read E, write err) against 8 TB/s" % (lpc, 64 // lpc))
+        # ---- whole step: useful arithmetic and traffic against the fused bound - what the NUMBER of passes costs
+        ntot_ = rx.nmodes * rx.Ntaps
+        useful = sum(rx.Niter[s2] * rx.TrSyms[s2] * nsel * 2 * ntot_ * 8.0 for s2 in range(rx.nstage)) + rx.N * nsel * ntot_ * 8.0 \
+            + (rx.N * nsel * cfg["A"] * 25.0 if cfg["A"] else 0.0)
+        moved = sum(tier_b["stages"][s2]["P"] * train_bytes[s2] for s2 in range(rx.nstage)) + stage_bytes[-2 if cfg["A"] else -1] + (stage_bytes[-1] if cfg["A"] else 0)
+        roofline["step"] = dict(useful_flops=int(useful), useful_flops_frac=round(useful / (ms_timed * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4),
+                                passes=[st_["P"] for st_ in tier_b["stages"]], sweeps_of_the_recurrence=[int(n) for n in rx.Niter],
+                                algorithmic_bytes_moved=int(moved), fused_bound_bytes=int(FUSED_BYTES_PER_SYM * nsym),
+                                traffic_vs_fused=round(moved / float(FUSED_BYTES_PER_SYM * nsym), 2),
+                                note="useful flops = the sweeps of the recurrence themselves (once each) + filter + slicer phase search (SURVEY.md 8d); bytes moved = "
+                                     "every pass re-reads the capture and re-writes the error trace: passes x 48 B + filter 48 B + search 40 B per symbol against the fused 88 B")
+        roofline["useful_flops_frac"] = roofline["step"]["useful_flops_frac"]
+        roofline["traffic_vs_fused"] = roofline["step"]["traffic_vs_fused"]
     else:
         dom = int(np.argmax(head_ms))
         achieved = stage_bytes[dom] / (head_ms[dom] * 1e-3) / 1e9

@@ -39,7 +39,7 @@ extern "C" {
  * arguments.  History: 1 = round 1; 2 = round 2 (qh_bps_recover_*_dev gained `angles`, qh_train_equaliser_*_pit_dev takes
  * (gram, opts, report), the *_seg_dev entry points were removed - unversioned at the time); 3 = round 3 (qh_pit_opts:
  * start, dev_safety; qh_pit_report: deviation[]); 4 = qh_pit_opts: adaptive. */
-#define QH_ABI_VERSION 4
+#define QH_ABI_VERSION 5
 int qh_abi_version(void);
 
 /* ---- status codes (python shim: 1,2 -> ValueError, 3,4 -> RuntimeError) */
@@ -258,7 +258,9 @@ int qh_set_trainer(int form);
  *     input covariance <conj(x) x^T> and g the mean gain of the error function: D[s+1] = d[s+1] + J D[s] (in the
  *     eigenbasis of Rc: one scalar first-order recurrence per direction, run as a parallel scan), start taps += D.  With J = 0 this is plain relaxation; J only preconditions the
  *     iteration - at the fixed point all defects vanish and the result is the sequential recurrence either way.
- * Fixed step only (adaptive = 0), no data-aided methods.  gram: table from qh_gram_build_*_dev for this (E, os, ntaps,
+ * Fixed step, or the adaptive step through qh_pit_opts.adaptive (one output mode per call, see there); no data-aided methods.
+ * EVERY call returns the reference's result: a sweep that is not certified is redone in the exact form inside the call
+ * (qh_pit_opts.exact_redo_off, qh_pit_report.converged = 2).  gram: table from qh_gram_build_*_dev for this (E, os, ntaps,
  * TrSyms), or NULL.  report_dev: device memory for one qh_pit_report (read it after qh_sync), or NULL. */
 #define QH_PIT_MAXPASS 24
 #define QH_PIT_MAXCHUNK 32
@@ -297,7 +299,9 @@ typedef struct qh_pit_opts {
                              * mddma; mu is in/out like in the exact entry points.  The first 16384 steps run in the exact form, the sweep is held to
                              * tol / 3 with up to 24 passes (damped corrections); one that is not certified is redone in the exact form
                              * (report: converged = 2) (ABI 4) */
-    int32_t reserved0;
+    int32_t exact_redo_off; /* 0 (default): a sweep the passes do not certify (estimate above tol when they stop, pass budget used up, no coarse
+                             * model) is redone in the EXACT form from the taps the call started with, inside the call - every call returns the
+                             * reference's result; report: converged = 2.  != 0: the uncertified result stays (converged = 0) (ABI 5) */
 } qh_pit_opts;
 typedef struct qh_pit_report {
     int32_t segments, passes, converged, acq_chunks;

@@ -16,7 +16,6 @@ GPU (RCCL refuses duplicate devices), and as the fallback when RCCL cannot initi
 """
 import ctypes as C
 import os
-import pickle
 import socket
 import struct
 import sys
@@ -61,22 +60,78 @@ def launch(script, argv, nproc, env=None):
 
 
 # ------------------------------------------------------------------------------------------------------------ sockets
+# Wire format of the star: typed frames, no pickle - what travels is None, an integer (a rank), bytes (the ncclUniqueId, the rendezvous
+# token) or a numeric ndarray (dtype name from a fixed list + shape + raw bytes), and nothing read from a socket is ever executed.
+_WIRE_DTYPES = ("int8", "uint8", "int32", "uint32", "int64", "uint64", "float32", "float64", "complex64", "complex128")
+_MAX_FRAME = 1 << 32
+
+
+def _rd(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(min(n - len(buf), 1 << 20))
+        if not chunk:
+            raise ConnectionError("peer closed the rendezvous socket")
+        buf += chunk
+    return bytes(buf)
+
+
 def _send(sock, obj):
-    b = pickle.dumps(obj, protocol=4)
-    sock.sendall(struct.pack("<Q", len(b)) + b)
+    if obj is None:
+        sock.sendall(b"N")
+    elif isinstance(obj, (int, np.integer)) and not isinstance(obj, bool):
+        sock.sendall(b"I" + struct.pack("<q", int(obj)))
+    elif isinstance(obj, (bytes, bytearray)):
+        sock.sendall(b"B" + struct.pack("<Q", len(obj)) + bytes(obj))
+    elif isinstance(obj, np.ndarray) and obj.dtype.name in _WIRE_DTYPES:
+        a = np.ascontiguousarray(obj)
+        name = a.dtype.name.encode()
+        sock.sendall(b"A" + struct.pack("<BB", len(name), a.ndim) + name + struct.pack("<%dq" % a.ndim, *a.shape) + a.tobytes())
+    else:
+        raise TypeError("qampy_amd.comm: cannot send %r over the rendezvous socket" % type(obj))
 
 
 def _recv(sock):
-    def rd(n):
-        buf = bytearray()
-        while len(buf) < n:
-            chunk = sock.recv(n - len(buf))
-            if not chunk:
-                raise ConnectionError("peer closed the rendezvous socket")
-            buf += chunk
-        return bytes(buf)
-    (n,) = struct.unpack("<Q", rd(8))
-    return pickle.loads(rd(n))
+    tag = _rd(sock, 1)
+    if tag == b"N":
+        return None
+    if tag == b"I":
+        return struct.unpack("<q", _rd(sock, 8))[0]
+    if tag == b"B":
+        (n,) = struct.unpack("<Q", _rd(sock, 8))
+        if n > _MAX_FRAME:
+            raise ConnectionError("rendezvous socket: oversized frame")
+        return _rd(sock, n)
+    if tag == b"A":
+        ln, nd = struct.unpack("<BB", _rd(sock, 2))
+        name = _rd(sock, ln).decode("ascii", "replace")
+        if name not in _WIRE_DTYPES or nd > 8:
+            raise ConnectionError("rendezvous socket: unexpected array header")
+        shape = struct.unpack("<%dq" % nd, _rd(sock, 8 * nd)) if nd else ()
+        count = 1
+        for d in shape:
+            if d < 0:
+                raise ConnectionError("rendezvous socket: negative dimension")
+            count *= d
+        dt = np.dtype(name)
+        if count * dt.itemsize > _MAX_FRAME:
+            raise ConnectionError("rendezvous socket: oversized frame")
+        return np.frombuffer(_rd(sock, count * dt.itemsize), dtype=dt).reshape(shape).copy()
+    raise ConnectionError("rendezvous socket: unknown frame type %r" % tag)
+
+
+def _rendezvous_dir():
+    """Per-user directory (mode 0700, owned by this user - checked, not assumed) for the rendezvous files."""
+    d = os.path.join(tempfile.gettempdir(), "qampy_comm_%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError("qampy_amd.comm: %s is not a private directory of this user" % d)
+    return d
 
 
 class Comm:
@@ -111,25 +166,40 @@ class Comm:
     # ---------------------------------------------------------------------------------------------- rendezvous (tcp star)
     def _rendezvous(self, env, timeout):
         addr = env.get("MASTER_ADDR", "127.0.0.1")
-        key = "qampy_comm_%s_%s_%d" % (addr.replace(":", "_"), env.get("MASTER_PORT", "0"), os.getppid())
-        path = os.path.join(tempfile.gettempdir(), key)
+        key = "%s_%s_%d" % (addr.replace(":", "_").replace("/", "_"), env.get("MASTER_PORT", "0"), os.getppid())
+        path = os.path.join(_rendezvous_dir(), key)
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, int(env.get("QAMPY_COMM_PORT", "0"))))
             srv.listen(self.world)
+            token = os.urandom(16)                       # only readers of the (0600, own directory) file can join the star
             tmp = path + ".%d" % os.getpid()
-            with open(tmp, "w") as f:
-                f.write("%s %d %d" % (addr, srv.getsockname()[1], os.getpid()))
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+            with os.fdopen(fd, "w") as f:
+                f.write("%s %d %d %s" % (addr, srv.getsockname()[1], os.getpid(), token.hex()))
             os.replace(tmp, path)
             self._srv, self._file = srv, path
             srv.settimeout(timeout)
             peers = {}
+            t0 = time.time()
             while len(peers) < self.world - 1:
+                if time.time() - t0 > timeout:
+                    raise TimeoutError("rank 0: %d of %d ranks joined the rendezvous" % (len(peers) + 1, self.world))
                 c, _ = srv.accept()
-                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                c.settimeout(timeout)
-                peers[_recv(c)] = c
+                try:
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    c.settimeout(timeout)
+                    tok, r = _recv(c), _recv(c)
+                    if tok != token or not isinstance(r, int) or not 1 <= r < self.world or r in peers:
+                        raise ConnectionError("bad hello")
+                    peers[r] = c
+                except (ConnectionError, OSError, struct.error, ValueError):
+                    c.close()                            # not one of ours: ignored
             self._peers = [peers[r] for r in range(1, self.world)]
             for c in self._peers:
                 c.settimeout(self.op_timeout)
@@ -137,7 +207,10 @@ class Comm:
             t0 = time.time()
             while True:
                 try:
-                    host, port, pid = open(path).read().split()
+                    st = os.stat(path)
+                    if st.st_uid != os.getuid():
+                        raise ValueError("rendezvous file of another user")
+                    host, port, pid, tok = open(path).read().split()
                     os.kill(int(pid), 0)                 # a file left behind by a dead launch of the same key is ignored
                     s = socket.create_connection((host, int(port)), timeout=timeout)
                     break
@@ -147,6 +220,7 @@ class Comm:
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout)
+            _send(s, bytes.fromhex(tok))
             _send(s, self.rank)
             s.settimeout(self.op_timeout)
             self._root = s
@@ -182,26 +256,15 @@ class Comm:
 
     # ---------------------------------------------------------------------------------------------- RCCL
     def _init_rccl_guarded(self, timeout):
-        """RCCL's bootstrap (sockets between the ranks, then the xGMI / PCIe topology) runs in a helper thread: if it does not come back
-        within `timeout` seconds - an interface it cannot use, a peer that died - this rank reports failure, all ranks agree on the socket
-        backend and the job goes on (the collectives here carry a few scalars).  `stuck` makes close() leave without joining it."""
+        """RCCL's bootstrap (sockets between the ranks, then the xGMI / PCIe topology).  Everything that talks over the rendezvous star -
+        the broadcast of the ncclUniqueId - happens HERE, on the calling thread; only ``ncclCommInitRank`` itself runs in a helper
+        thread: if it does not come back within `timeout` seconds (an interface it cannot use, a peer that died) this rank reports
+        failure, all ranks agree on the socket backend and the job goes on (the collectives here carry a few scalars).  The helper never
+        touches the star, and stdout - which RCCL's banner must not reach: it carries bench.py's JSON line - is redirected and restored
+        by this thread, so a helper that hangs leaves both intact.  `stuck` makes close() leave without joining it."""
         import threading
         # single node: the bootstrap may use the loopback interface (the container's hostname need not resolve); xGMI / PCIe carry the data
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        box = {}
-
-        def work():
-            box["r"] = self._init_rccl()
-
-        t = threading.Thread(target=work, daemon=True)
-        t.start()
-        t.join(timeout)
-        if t.is_alive():
-            self.stuck = True
-            return False, "ncclCommInitRank did not return within %g s" % timeout
-        return box.get("r", (False, "rccl initialisation raised"))
-
-    def _init_rccl(self):
         try:
             from . import _lib
             lib = None
@@ -211,40 +274,60 @@ class Comm:
                     break
                 except OSError:
                     continue
-            if lib is None:
+            ok_local = lib is not None
+            if ok_local:
+                lib.ncclGetErrorString.restype = C.c_char_p
+                lib.ncclGetErrorString.argtypes = [C.c_int]
+                lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+                lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+                lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+                lib.ncclBroadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+                lib.ncclCommDestroy.argtypes = [C.c_void_p]
+                _lib.init(self.device)                   # the library's device (one per process)
+            uid = _UniqueId()
+            raw = None
+            if self.rank == 0 and ok_local:
+                rc = lib.ncclGetUniqueId(C.byref(uid))
+                raw = None if rc else C.string_at(C.addressof(uid), NCCL_UNIQUE_ID_BYTES)      # (the whole structure: it may hold NULs)
+            raw = self._tcp_bcast_obj(raw)               # rank 0's failure reaches everybody: no rank waits in vain
+            if not ok_local:
                 return False, "librccl.so not found"
-            lib.ncclGetErrorString.restype = C.c_char_p
-            lib.ncclGetErrorString.argtypes = [C.c_int]
-            lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
-            lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
-            lib.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-            lib.ncclBroadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-            lib.ncclCommDestroy.argtypes = [C.c_void_p]
-            _lib.init(self.device)                       # the library's device (one per process)
+            if raw is None:
+                return False, "ncclGetUniqueId failed on rank 0"
+            C.memmove(C.addressof(uid), raw, NCCL_UNIQUE_ID_BYTES)
+        except Exception as e:                           # noqa: BLE001 - any failure means "use the fallback"
+            return False, "%s: %s" % (type(e).__name__, e)
+        box = {}
+
+        def work():
+            box["r"] = self._init_rccl(lib, uid)
+
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            t = threading.Thread(target=work, daemon=True)
+            t.start()
+            t.join(timeout)
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
+        if t.is_alive():
+            self.stuck = True
+            return False, "ncclCommInitRank did not return within %g s" % timeout
+        return box.get("r", (False, "rccl initialisation raised"))
+
+    def _init_rccl(self, lib, uid):
+        try:
+            from . import _lib
             # the current device is per THREAD and this runs in a helper thread: the communicator must be created on the rank's GPU
             hip = C.CDLL("libamdhip64.so")
             hip.hipSetDevice.argtypes = [C.c_int]
             if hip.hipSetDevice(int(self.device)) != 0:
                 return False, "hipSetDevice(%d) failed" % int(self.device)
-            uid = _UniqueId()
-            raw = None
-            if self.rank == 0:
-                rc = lib.ncclGetUniqueId(C.byref(uid))
-                raw = None if rc else C.string_at(C.addressof(uid), NCCL_UNIQUE_ID_BYTES)      # (the whole structure: it may hold NULs)
-            raw = self._tcp_bcast_obj(raw)                 # rank 0's failure reaches everybody: no rank waits in vain
-            if raw is None:
-                return False, "ncclGetUniqueId failed on rank 0"
-            C.memmove(C.addressof(uid), raw, NCCL_UNIQUE_ID_BYTES)
             comm = C.c_void_p()
-            # (RCCL prints a version banner on stdout when the first communicator is created: stdout carries bench.py's JSON line)
-            sys.stdout.flush()
-            keep = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                rc = lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank)
-            finally:
-                os.dup2(keep, 1)
-                os.close(keep)
+            rc = lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank)
             if rc:
                 return False, "ncclCommInitRank: %s" % lib.ncclGetErrorString(rc).decode()
             self._nccl, self._ncomm = lib, comm

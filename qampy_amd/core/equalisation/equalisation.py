@@ -178,10 +178,12 @@ class _Field:
             TrSyms = _cal_training_symbol_len(os, n, self.L)
         sy = _reshape_symbols(symbols, method, M, self.dtype, self.rows).copy()
         mu = self.dtype.type(0).real.dtype.type(mu)
-        if pit is not None and self.real:
-            raise ValueError("parallel-in-time training (tier='b') is available for the complex-valued methods only")
         if self.real:
+            # (tier b: the real-valued trainer has no parallel-in-time solver - the exact form, reported as such)
             err, wxy, _ = _kernels.train_equaliser_realvalued(self.host, TrSyms, Niter, os, mu, wxy, rows, adaptive, sy, method[:-len("_real")])
+            if pit is not None:
+                _PIT_REPORTS.append(dict(segments=1, passes=0, converged=True, exact_form=True, tol=float(pit.get("tol", 0) or 1e-3), defect=[], deviation_rms=[],
+                                         acquisition=dict(steps=0, chunks=0, mu=0., diverged=False, mean_sq_err=[])))
         else:
             if pit is None:
                 err, wxy, _ = self.dev.train(TrSyms, Niter, os, mu, wxy, rows, adaptive, sy, method)
@@ -192,7 +194,7 @@ class _Field:
                 # the report is on the host already: never hand back an uncertified result silently
                 if rep["acquisition"]["diverged"]:
                     warnings.warn("tier b (%s): the gear-shifted acquisition diverged and was undone; the passes started from the given taps" % method, RuntimeWarning)
-                if not rep["converged"]:
+                if not rep["converged"]:                     # (only with pit=dict(exact_redo_off=1): by default such a sweep is redone in the exact form)
                     warnings.warn("tier b (%s): the parallel-in-time solver stopped after %d passes WITHOUT reaching its tolerance (%g; last estimate %s): the "
                                   "result is not certified as the sequential recurrence's - use tier='a' or raise max_passes"
                                   % (method, rep["passes"], rep["tol"], ("%.3g" % rep["deviation_rms"][-1]) if rep.get("deviation_rms") else "n/a"), RuntimeWarning)

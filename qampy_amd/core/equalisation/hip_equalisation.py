@@ -332,7 +332,9 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
     ``max_passes``, ``tol``, ``acquire`` (cold start: gear-shifted acquisition first), ``phase_seed``, ``gear``,
     ``acq_bound``, ``acq_plateau``, ``acq_chunk``, ``acq_max``.  ``report``: a :class:`PitReportBuffer` the device fills.
     With ``adaptive=True`` (the reference's shared step size) the output modes are solved in turn, each from the step size the one
-    before it ended with; a mode the passes cannot agree on is redone in the exact form (report: ``exact_form``).
+    before it ended with.  Tier b is total: a sweep the passes do not certify is redone in the exact form inside the call, and a
+    call no parallel-in-time solver exists for (data-aided methods, one step size per mode, the adaptive step with cma2 / rde / mrde /
+    dd or complex128) takes the exact form right away - the report says ``exact_form`` in both cases, the result is the reference's.
     """
     if method not in _lib.METHOD_ID:
         raise ValueError("Unknown method %s" % method)
@@ -352,19 +354,26 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
             if not hasattr(o, k):
                 raise ValueError("unknown parallel-in-time option %s" % k)
             setattr(o, k, v)
-        if _adaptive_flag(adaptive):
+        if _adaptive_flag(adaptive) == 2:
+            # one step size per mode (the extension): no parallel-in-time solver - the library takes the exact form and says so in the report
+            o.adaptive = 2
+        elif _adaptive_flag(adaptive):
             # the reference carries ONE step size from mode to mode (pythran_equalisation.py:163-172): the modes are solved in turn, each
-            # from the step size the one before it ended with; the report describes the last one
-            if _adaptive_flag(adaptive) != 1:
-                raise ValueError("parallel-in-time training with the adaptive step: the reference's shared step size only (adaptive_stepsize=True)")
+            # from the step size the one before it ended with (one report per mode, PitReportBuffer.read aggregates)
             o.adaptive = 1
+            if report is not None:
+                report.per_mode = []
             for m in modes:
                 one = np.array([m], dtype=np.int64)
                 _lib.call(name + "_pit_dev", E.ptr, nmodes, L, int(TrSyms), int(Niter), int(os), mu.ptr, wx.ptr, ntaps, _lib.ptr(one), 1,
                           symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)), None, C.byref(o),
                           report.ptr if report is not None else None)
+                if report is not None:      # one report per mode (the device buffer holds the last call's): the adaptive solve synchronises anyway
+                    report.per_mode.append(report.read_one())
                 zero_err = False
             return
+        if report is not None:
+            report.per_mode = None
         _lib.call(name + "_pit_dev", E.ptr, nmodes, L, int(TrSyms), int(Niter), int(os), mu.ptr, wx.ptr, ntaps, _lib.ptr(modes), modes.size,
                   symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], err.ptr, int(bool(zero_err)), gram, C.byref(o),
                   report.ptr if report is not None else None)
@@ -375,15 +384,30 @@ def train_equaliser_dev(E, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, 
 
 
 class PitReportBuffer(DeviceArray):
-    """Device memory for one ``qh_pit_report``; :meth:`read` synchronises and returns it as a dict."""
+    """Device memory for one ``qh_pit_report``; :meth:`read` synchronises and returns it as a dict.  After a solve with the
+    adaptive step (one library call per output mode, in the reference's mode order) the dict is the LAST mode's report with the
+    fields that must not be lost aggregated over the modes - ``converged`` (all), ``exact_form`` (any), ``passes`` (largest) - and
+    every mode's own report under ``per_mode``."""
+
+    per_mode = None
 
     def __init__(self):
         super().__init__((C.sizeof(_lib.PitReport),), np.uint8, zero=True)
 
-    def read(self):
+    def read_one(self):
         _lib.sync()
         raw = self.to_host()
         return _lib.PitReport.from_buffer_copy(raw.tobytes()).as_dict()
+
+    def read(self):
+        if not self.per_mode:
+            return self.read_one()
+        rep = dict(self.per_mode[-1])
+        rep["converged"] = all(r["converged"] for r in self.per_mode)
+        rep["exact_form"] = any(r["exact_form"] for r in self.per_mode)
+        rep["passes"] = max(r["passes"] for r in self.per_mode)
+        rep["per_mode"] = [dict(r) for r in self.per_mode]
+        return rep
 
 
 def pit_basis_dev(E, os, ntaps, TrSyms, basis=None, overlap=False):
@@ -409,6 +433,11 @@ def pit_last_timing():
     n, acq = C.c_int(0), C.c_float(0)
     _lib.call("qh_pit_last_timing", buf, _lib.PIT_MAXPASS, C.byref(n), C.byref(acq))
     return [float(buf[i]) for i in range(n.value)], float(acq.value)
+
+
+def pit_effective_segments(S, TrSyms):
+    """Segments the library actually uses when asked for ``S``: at least four 64-step blocks per segment (csrc/train_pit.h)."""
+    return max(min(int(S), (int(TrSyms) // 64) // 4), 1)
 
 
 def pit_auto_segments(TrSyms, mu, nsel=1, cold=False):

@@ -514,8 +514,8 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
         // weakly excited directions (round 2's defect rule certified 64-QAM mrde runs whose taps were 3e-2 off).  Without a model
         // (more than 96 taps per output mode) the defect rule is all there is.
         if (a.extra) { const double ex = (double)a.extra[0]; if (p < QH_PIT_MAXPASS) c->result_change[p] = ex; if (ex > crit || !(ex == ex)) crit = ex == ex ? ex : 1e30; }   // (adaptive step: result_change[] reports the change of the start step sizes)
-        int done = 0;
-        if (crit < c_tol && (have_dev || !corr_wanted)) { c->converged = 1; done = 1; }
+        int done = 0, conv = 0;
+        if (crit < c_tol && (have_dev || !corr_wanted)) { c->converged = 1; done = 1; conv = 1; }
         // nothing gained over two passes: the trajectory has no fixed point the passes can agree on (a stage that cannot track the
         // carrier) - stop, NOT converged; further passes would only cost time.  (Slow but steady gains - rde's ring decisions - go on
         // to max_passes: the uncertified result keeps improving with them.)
@@ -529,7 +529,7 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
         // the flag it polls for (host_view is pinned, coherent host memory: no copy kernel, no event in between)
         host_view[1] = (float)crit;
         __threadfence_system();
-        __hip_atomic_store(&host_view[0], done ? 1.f : 0.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_view[0], done ? (conv ? 1.f : 2.f) : 0.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (2: stopped, NOT certified)
     }
 }
 
@@ -1838,22 +1838,41 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     if (method < 0 || method > QH_M_SBD_DATA) { set_error("unknown equaliser method id"); return QH_ERR_METHOD; }
     QH_REQUIRE(nmodes >= 1 && ntaps >= 1 && os >= 1 && Niter >= 0 && TrSyms >= 0 && nsel >= 1 && nsel <= 16 && nsy >= 1, "train_equaliser: bad sizes");
     QH_REQUIRE(TrSyms == 0 || (TrSyms - 1) * os + ntaps <= L, "train_equaliser: field shorter than TrSyms*os + ntaps");
-    QH_REQUIRE(method != QH_M_SBD_DATA, "train_equaliser: parallel-in-time training is not available for data-aided methods");
     for (int j = 0; j < nsel; j++) QH_REQUIRE(modes[j] >= 0 && modes[j] < nmodes, "train_equaliser: mode number >= nmodes");
     qh_pit_opts o;
     memset(&o, 0, sizeof(o));
     o.phase_seed = -1; o.corr_beta = -1;
     if (opts) o = *opts;
     QH_REQUIRE(o.segments >= 0 && o.segments <= PIT_MAXSEG && o.max_passes >= 0 && o.max_passes <= QH_PIT_MAXPASS, "train_equaliser: bad segment / pass count");
-    // Adaptive step (opts.adaptive): ONE output mode per call (the reference carries one step size from mode to mode: the caller runs
+    QH_REQUIRE(o.adaptive >= 0 && o.adaptive <= 2, "train_equaliser: adaptive must be 0, 1 or 2");
+    // Adaptive step (opts.adaptive = 1): ONE output mode per call (the reference carries one step size from mode to mode: the caller runs
     // the modes in turn), one sweep, single precision, the error functions of train_seg_*_f32_ad.hip.  The head of the sweep runs in
     // the exact form; the segments cover the rest, with r = 1 / mu and the previous error as boundary states.
-    const bool adaptive = o.adaptive != 0;
-    if (adaptive) {
-        QH_REQUIRE(sizeof(R) == 4 && nsel == 1 && Niter == 1 && !o.exchange, "train_equaliser: parallel-in-time training with the adaptive step takes one output mode, one sweep, complex64");
-        QH_REQUIRE(seg_adaptive_supported(method), "train_equaliser: parallel-in-time training with the adaptive step: cma, mcma, sbd, mddma");
-        o.acquire = 0;
+    // Tier b is TOTAL: a call for which no parallel-in-time solver exists - data-aided training (the symbols are indexed by the step:
+    // nothing to certify against a segment grid yet), the adaptive step with another error function / precision / several sweeps /
+    // several modes at once / one step size per mode (adaptive = 2) - takes the exact form right away and says so (report:
+    // segments = 1, converged = 2); the result is the reference's either way.
+    bool adaptive = o.adaptive != 0;
+    {
+        bool exact_only = method == QH_M_SBD_DATA;
+        if (adaptive && (o.adaptive == 2 || sizeof(R) != 4 || nsel != 1 || Niter != 1 || !seg_adaptive_supported(method))) exact_only = true;
+        QH_REQUIRE(!(adaptive && o.exchange), "train_equaliser: a capture split over processes is trained with a fixed step");
+        if (exact_only) {
+            QH_REQUIRE(!o.exchange, "train_equaliser: a capture split over processes needs the parallel-in-time solver (blind / decision-directed method, fixed step)");
+            void *cb0 = nullptr;
+            if ((rc = scratch(8, sizeof(PitCtrl) + 64, &cb0))) return rc;
+            PitCtrl *c0 = report_dev ? (PitCtrl *)report_dev : (PitCtrl *)cb0;
+            PitSeg s1; s1.S = 1; s1.len = TrSyms; s1.extra = 0; s1.tail = 0;
+            hipLaunchKernelGGL((pit_setup_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const Cx<R> *)E, nmodes, L, (int64_t)(L < 4096 ? L : 4096), nmodes * ntaps, (const R *)mu_dev, 1.0, 1.0,
+                               o.tol > 0 ? o.tol : 1e-3, s1, c0, (R *)((char *)cb0 + sizeof(PitCtrl)));
+            if ((rc = train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, o.adaptive, symbols, nsy, method, err, zero_err, adaptive ? nullptr : gram))) return rc;
+            const int32_t hdr[3] = {1, 0, 2};                          // segments, passes, converged = 2: the exact form
+            QH_HIP(hipMemcpyAsync(&c0->segments, hdr, sizeof(hdr), hipMemcpyHostToDevice, g_stream));
+            QH_HIP(hipStreamSynchronize(g_stream));
+            return QH_OK;
+        }
     }
+    if (adaptive) o.acquire = 0;
     const int ntot = nmodes * ntaps;
     QH_REQUIRE(ntot <= 64 * 16, "train_equaliser: more than 1024 taps per output mode are not supported");
     // Adaptive sweeps apply 0.7 of every correction after the first (the full one overshoots: the estimate then GROWS 1.7 x per pass on the
@@ -1921,7 +1940,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     if (sg.S < 2) {                 // nothing to parallelise: the sequential path (report: one segment, one pass, defect 0)
         if ((rc = train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, adaptive ? 1 : 0, symbols, nsy, method, err, 0, gram))) return rc;
         const double zero = 0;
-        const int32_t hdr[3] = {1, 1, 1};                          // segments, passes, converged
+        const int32_t hdr[3] = {1, 1, 2};                          // segments, passes, converged = 2: the exact form
         QH_HIP(hipMemcpyAsync(&ctrl->segments, hdr, sizeof(hdr), hipMemcpyHostToDevice, g_stream));
         QH_HIP(hipMemcpyAsync(&ctrl->defect[0], &zero, sizeof(double), hipMemcpyHostToDevice, g_stream));
         QH_HIP(hipStreamSynchronize(g_stream));
@@ -1947,8 +1966,17 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         if (pf && pf[0] == 'b') seg_ok = false;
         else if (!(pf && pf[0] == 's') && (int64_t)sg.S * nsel < 512) seg_ok = false;
     }
-    if (adaptive) { QH_REQUIRE(seg_supported(method, nmodes, ntaps, os, nsy, sizeof(Cx<R>), nsel, 8) && (!decision || dd_npart == 1 || dd_npart == 3 || dd_npart == 7 || dd_npart == 15),
-                               "train_equaliser: parallel-in-time training with the adaptive step needs the throughput form of the passes (tap layout / alphabet)"); seg_ok = true; }
+    if (adaptive) {
+        // the adaptive solver needs the throughput form of the passes; a tap layout / alphabet it cannot take: the exact form (converged = 2)
+        if (!(seg_supported(method, nmodes, ntaps, os, nsy, sizeof(Cx<R>), nsel, 8) && (!decision || dd_npart == 1 || dd_npart == 3 || dd_npart == 7 || dd_npart == 15))) {
+            if ((rc = train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, 1, symbols, nsy, method, err, 0, nullptr))) return rc;
+            const int32_t hdr[3] = {1, 0, 2};
+            QH_HIP(hipMemcpyAsync(&ctrl->segments, hdr, sizeof(hdr), hipMemcpyHostToDevice, g_stream));
+            QH_HIP(hipStreamSynchronize(g_stream));
+            return QH_OK;
+        }
+        seg_ok = true;
+    }
     const bool seg_form = seg_ok;
     const bool split = o.exchange != nullptr;
     const int own_first = split ? o.seg_first : 0, own_count = split ? o.seg_count : sg.S;
@@ -1973,9 +2001,9 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     const size_t wbytes = wset * sizeof(Cx<R>);
     void *wbuf = nullptr;
     const size_t nsj = (size_t)sg.S * nsel;
-    const size_t bytes_w = ((2 * (size_t)sg.S + 1) * wbytes + 63) / 64 * 64;
+    const size_t bytes_w = ((2 * (size_t)sg.S + 2) * wbytes + 63) / 64 * 64;
     if ((rc = scratch(2, bytes_w + 10 * nsj * sizeof(double) + (size_t)nsel * sizeof(int64_t) + 320 + nsj * 16 + 4 * ((nsj + 63) / 64) * sizeof(float) + 64, &wbuf))) return rc;
-    Cx<R> *X = (Cx<R> *)wbuf, *Y = X + (size_t)sg.S * wset, *w_start = Y + (size_t)sg.S * wset;
+    Cx<R> *X = (Cx<R> *)wbuf, *Y = X + (size_t)sg.S * wset, *w_start = Y + (size_t)sg.S * wset, *w_call = w_start + wset;
     double *z = (double *)((char *)wbuf + bytes_w), *rot = z + 2 * nsj, *dfc = rot + 2 * nsj, *pw = dfc + nsj, *gph = pw + nsj, *theta = gph + 2 * nsj;
     int64_t *modes_dev = (int64_t *)(theta + 2 * nsj);
     double *uw_phi = (double *)(modes_dev + ((nsel + 7) / 8 * 8));
@@ -2083,6 +2111,13 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     tm.npass = 0; tm.acq_ms = 0;
     PitEvents &ev = pit_events();
     QH_REQUIRE(ev.ok, "train_equaliser: no pinned memory for the pass flags");
+    // Way out (every tier-b call returns the reference's result): a sweep the passes do not certify - estimate stuck above tol, pass
+    // budget used up, no coarse model to certify with - is redone in the EXACT form from the taps the call started with, inside the
+    // call (report: converged = 2, `exact_form`).  opts.exact_redo_off != 0 leaves the uncertified result in place (converged = 0): for
+    // the tests of the iteration itself.
+    const bool redo_ok = o.exact_redo_off == 0;
+    bool fell_back = false;
+    if (redo_ok && !adaptive) QH_HIP(hipMemcpyAsync(w_call, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
     for (int it = 0; it < Niter; it++) {
         // ================================================================ acquisition (first sweep of a cold start)
         if (it == 0 && o.acquire) {
@@ -2271,6 +2306,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         // expected defect of pass p = PIT_CONTRACT x the defect of pass p - 1 (the first pass never converges from seeds).
         if ((rc = enqueue_pass(0))) return rc;
         bool ahead = false;                                       // pass p + 1 already in the stream
+        bool certified = false;                                   // the sweep's last decision: stopped AND below the tolerance
         for (int p = 0; p < npass; p++) {
             // (expected criterion of pass p: the last one times the contraction the last two passes showed; the first guess is PIT_CONTRACT)
             double contr = PIT_CONTRACT;
@@ -2293,7 +2329,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                     if (now - t_last < std::chrono::milliseconds(20)) continue;     // (a stream query puts a marker into the queue: rarely)
                     t_last = now;
                     const hipError_t q = hipStreamQuery(g_stream);
-                    if (q == hipSuccess) { if (hv[2 * p] < 0.f) hv[2 * p] = 1.f; break; }
+                    if (q == hipSuccess) { if (hv[2 * p] < 0.f) hv[2 * p] = 2.f; break; }       // (nothing decided: treated as not certified)
                     if (q != hipErrorNotReady) QH_HIP(q);
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
@@ -2304,8 +2340,19 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 QH_HIP(hipEventElapsedTime(&ms, ev.t0[p], ev.t1[p]));
                 tm.pass_ms[tm.npass++] = ms;
             }
-            if (ev.hview[2 * p] != 0.f) break;
+            if (ev.hview[2 * p] != 0.f) { certified = ev.hview[2 * p] == 1.f; break; }
             if (p + 1 < npass && !ahead && (rc = enqueue_pass(p + 1))) return rc;
+        }
+        if (!adaptive && !certified && redo_ok) {
+            // not certified: the whole call again in the exact form, from the taps it started with (all sweeps: a later sweep starts from
+            // the result of this one).  Identical on every process of a split capture (they all took the same decision).
+            QH_HIP(hipMemcpyAsync(wx, w_call, wbytes, hipMemcpyDeviceToDevice, g_stream));
+            if ((rc = train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, 0, symbols, nsy, method, err, 0, gram))) return rc;
+            const int32_t two = 2;
+            QH_HIP(hipMemcpyAsync(&ctrl->converged, &two, sizeof(two), hipMemcpyHostToDevice, g_stream));
+            QH_HIP(hipStreamSynchronize(g_stream));               // (`two` lives on this stack frame)
+            fell_back = true;
+            break;
         }
         if (adaptive) {
             hipLaunchKernelGGL((pit_adapt_finish_kernel<R>), dim3(1), dim3(1), 0, g_stream, mu_dev, (const R *)ad_rE, sg.S);
@@ -2315,7 +2362,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             int32_t conv = 0;
             QH_HIP(hipMemcpyAsync(&conv, &ctrl->converged, sizeof(conv), hipMemcpyDeviceToHost, g_stream));
             QH_HIP(hipStreamSynchronize(g_stream));
-            if (!conv) {
+            if (!conv && redo_ok) {
+                fell_back = true;
                 QH_HIP(hipMemcpyAsync(wx, w_start, wbytes, hipMemcpyDeviceToDevice, g_stream));
                 QH_HIP(hipMemcpyAsync(mu_dev, ad_chg + 1, sizeof(R), hipMemcpyDeviceToDevice, g_stream));
                 if ((rc = train_dev<R>(E, nmodes, L, TrSyms, 1, os, mu_dev, wx, ntaps, modes, 1, 1, symbols, nsy, method, err, 0, nullptr))) return rc;
@@ -2324,7 +2372,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 QH_HIP(hipStreamSynchronize(g_stream));
             }
         }
-        if (sym == 0)
+        if (sym == 0 && !fell_back)
             hipLaunchKernelGGL((pit_rotate_err_kernel<R>), dim3(sg.S, nsel), dim3(256), 0, g_stream, (Cx<R> *)err, (int64_t)(TrSyms * Niter), (int64_t)it * TrSyms, sg,
                                (const int64_t *)modes_dev, nsel, (const double *)theta, (const PitCtrl *)ctrl, -1);
         QH_HIP(hipGetLastError());

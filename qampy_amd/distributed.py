@@ -36,14 +36,19 @@ class SplitCaptureReceiver(ResidentReceiver):
         if comm is None:
             raise ValueError("SplitCaptureReceiver needs the process group (qampy_amd.comm.Comm)")
         kw["tier"] = "b"
+        if any(kw.get("adaptive_stepsize", (False, False))):
+            raise ValueError("split capture: the adaptive step is solved one output mode at a time inside one process (csrc/train_pit.h); "
+                             "use a fixed step size, or a ResidentReceiver per rank")
         super().__init__(*args, **kw)
         self.comm = comm
         self.rank, self.world = comm.rank, comm.world
         self.exchanged_bytes = 0
         self.exchanges = 0
-        for o in self.pit:
+        from .core.equalisation import hip_equalisation as _k
+        for s_, o in enumerate(self.pit):              # the grid the library will really use (it keeps >= 4 blocks per segment)
+            o["segments"] = _k.pit_effective_segments(o["segments"], self.TrSyms[s_])
             if int(o["segments"]) < self.world:
-                raise ValueError("split capture: %d segments cannot be shared by %d ranks" % (int(o["segments"]), self.world))
+                raise ValueError("split capture: stage %d has %d segments, too few to be shared by %d ranks" % (s_, int(o["segments"]), self.world))
 
         def exchange(user, ptr, nbytes):
             try:

@@ -88,8 +88,6 @@ class ResidentReceiver:
             self.ph = DeviceArray((self.modes.size, self.N), self.rt)
             self.out = DeviceArray((self.modes.size, self.N), self.ct)
         if tier == "b":
-            if any(isinstance(a, str) for a in self.adaptive):
-                raise ValueError("parallel-in-time training with the adaptive step: the reference's shared step size only (adaptive_stepsize=True)")
             self.pit_report = [_k.PitReportBuffer() for _ in methods]
             for s_, o in enumerate(self.pit):          # segment grid from the host copy of mu: the call then never synchronises
                 o.setdefault("acquire", 1 if s_ == 0 else 0)

@@ -31,6 +31,8 @@ for c in CASES:
     for tier in ("a", "b"):
         try:
             pit = [dict() for _ in c["methods"]]
+            for p_ in pit:
+                p_.update(json.loads(os.environ.get("PITALL", "{}")))
             pit[-1].update(PIT2)
             pit[0].update(json.loads(os.environ.get("PIT1", "{}")))
             rx = ResidentReceiver(2, 2 * c["nsym"], 2, c["M"], c["ntaps"], c["mu"], tier=tier, pit=pit if tier == "b" else None, **kw)
@@ -49,4 +51,4 @@ for c in CASES:
             g = 1j ** int(np.rint(np.angle(np.vdot(b["w"][m].ravel(), res["a"]["w"][m].ravel())) / (np.pi / 2)))
             dev.append(round(float(np.sqrt(np.mean(np.abs(res["a"]["eq"][m] - g * b["eq"][m]) ** 2))), 5))
     print("##", c["name"], "| a:", res["a"].get("ms"), res["a"].get("errors"), "| b:", b.get("ms"), b.get("errors"), b.get("error"),
-          [(r["segments"], r["passes"], r["converged"], [round(x, 5) for x in r["deviation_rms"][-3:]]) for r in (b.get("rep") or [])], "| measured out rms dev", dev, flush=True)
+          [(r["segments"], r["passes"], "exact_form" if r.get("exact_form") else r["converged"], [round(x, 5) for x in (r["deviation_rms"] if os.environ.get("FULL") else r["deviation_rms"][-3:])], round(r["gain"], 3)) for r in (b.get("rep") or [])], "| measured out rms dev", dev, flush=True)

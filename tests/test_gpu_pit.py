@@ -60,7 +60,7 @@ def test_relaxation_fixed_point_is_the_sequential_recurrence(method, M, form, mo
     S = 4
     # plain relaxation, no seeds, no acquisition, a tolerance that is never met: after S passes the triangular map has
     # propagated the true start taps through every segment
-    w, e, rep = _run_pit(E, tr, 2, 5e-4, w0, sy, method, dict(segments=S, max_passes=S, tol=1e-12, correction=0, phase_seed=0, acquire=0), rt)
+    w, e, rep = _run_pit(E, tr, 2, 5e-4, w0, sy, method, dict(segments=S, max_passes=S, tol=1e-12, correction=0, phase_seed=0, acquire=0, exact_redo_off=1), rt)
     assert rep["segments"] == S and rep["passes"] == S and len(rep["defect"]) == S
     np.testing.assert_allclose(w, wo, rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(e, eo, rtol=2e-4, atol=1e-4)
@@ -79,7 +79,7 @@ def test_coarse_correction_converges_to_the_exact_trajectory(method, M, lanes, a
     trainer far below the gradient noise; plain relaxation needs (many) more passes for the same defect."""
     sig, E, tr, w0, sy, rt = _setup(method, M, nsym=2 ** 16, ntaps=21)
     eo, wo, _ = hk.train_equaliser(E, tr, 1, 2, rt(1e-3), w0.copy(), None, False, sy, method)
-    kw = dict(segments=16, max_passes=10, tol=2e-4, phase_seed=0, acquire=0)
+    kw = dict(segments=16, max_passes=10, tol=2e-4, phase_seed=0, acquire=0, exact_redo_off=1)       # (the iteration itself: no exact-form way out)
     w, e, rep = _run_pit(E, tr, 1, 1e-3, w0, sy, method, dict(kw, correction=1), rt)
     w2, e2, rep2 = _run_pit(E, tr, 1, 1e-3, w0, sy, method, dict(kw, correction=0), rt)
     assert rep["converged"] and rep["correction"] and rep["passes"] <= 8, rep
@@ -96,7 +96,7 @@ def test_complex128_and_oracle(form, monkeypatch):
         monkeypatch.setenv("QAMPY_HIP_PIT_FORM", "segment")
     sig, E, tr, w0, sy, rt = _setup("mcma", 16, dtype=np.complex128)
     eo, wo, _ = oracle.train_equaliser(E, tr, 1, 2, 5e-4, w0.copy(), None, False, sy, "mcma")
-    w, e, rep = _run_pit(E, tr, 1, 5e-4, w0, sy, "mcma", dict(segments=4, max_passes=4, tol=1e-14, correction=0, phase_seed=0, acquire=0), rt)
+    w, e, rep = _run_pit(E, tr, 1, 5e-4, w0, sy, "mcma", dict(segments=4, max_passes=4, tol=1e-14, correction=0, phase_seed=0, acquire=0, exact_redo_off=1), rt)
     np.testing.assert_allclose(w, wo, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(e, eo, rtol=1e-8, atol=1e-9)
 
@@ -105,20 +105,82 @@ def test_small_sweeps_fall_through_and_bad_calls_raise():
     sig, E, tr, w0, sy, rt = _setup("mcma", 16, nsym=2 ** 10)
     eo, wo, _ = hk.train_equaliser(E, tr, 1, 2, rt(1e-3), w0.copy(), None, False, sy, "mcma")
     w, e, rep = _run_pit(E, tr, 1, 1e-3, w0, sy, "mcma", {}, rt)        # automatic segment count: too short to cut -> exact path
-    assert rep["segments"] == 1 and rep["converged"]
+    assert rep["segments"] == 1 and rep["converged"] and rep["exact_form"]
     assert np.array_equal(w, wo) and np.array_equal(e, eo)
     dE, dsy, dmu = DeviceArray.from_host(E), DeviceArray.from_host(sy), DeviceArray.from_host(np.array([1e-3], rt))
     dw, derr = DeviceArray.from_host(w0.copy()), DeviceArray((2, tr), E.dtype, zero=True)
     with pytest.raises(ValueError):
-        hk.train_equaliser_dev(dE, tr, 1, 2, dmu, dw, None, "per-mode", dsy, "mcma", derr, pit={})     # adaptive step: the reference's shared step only
-    with pytest.raises(ValueError):
-        hk.train_equaliser_dev(dE, tr, 1, 2, dmu, dw, None, True, dsy, "cma2", derr, pit={})           # adaptive step: cma / mcma / sbd / mddma
-    with pytest.raises(ValueError):
         hk.train_equaliser_dev(dE, tr, 1, 2, dmu, dw, None, False, dsy, "mcma", derr, pit=dict(nonsense=1))
-    with pytest.raises(ValueError):
-        hk.train_equaliser_dev(dE, tr, 1, 2, dmu, dw, None, False, dsy, "sbd_data", derr, pit={})       # data-aided
-    with pytest.raises(ValueError):
-        ResidentReceiver(2, E.shape[1], 2, 16, 15, (1e-3,), methods=("mcma",), Niter=(1,), adaptive_stepsize=("per-mode",), tier="b")
+
+
+def _exact_and_tier_b(E, tr, niter, mu, w0, sy, method, adaptive, pit, rt):
+    """One training call through the exact entry point and through the parallel-in-time one: (taps, err, mu) of both + the report."""
+    out = []
+    for p in (None, pit):
+        dE, dsy, dmu = DeviceArray.from_host(E), DeviceArray.from_host(sy), DeviceArray.from_host(np.array([mu], rt))
+        dw, derr = DeviceArray.from_host(w0.copy()), DeviceArray((E.shape[0], tr * niter), E.dtype, zero=True)
+        rep = hk.PitReportBuffer() if p is not None else None
+        hk.train_equaliser_dev(dE, tr, niter, 2, dmu, dw, None, adaptive, dsy, method, derr, pit=p, report=rep)
+        out.append((dw.to_host(), derr.to_host(), dmu.to_host()[0]))
+    return out[0], out[1], rep.read()
+
+
+@pytest.mark.parametrize("method,adaptive,dtype", [("sbd_data", False, np.complex64), ("sbd_data", True, np.complex64), ("mcma", "per-mode", np.complex64),
+                                                   ("cma2", True, np.complex64), ("mrde", True, np.complex64), ("mcma", True, np.complex128)])
+def test_tier_b_is_total_calls_without_a_parallel_solver_take_the_exact_form(method, adaptive, dtype):
+    """Tier b returns the reference's result for EVERY call: where no parallel-in-time solver exists (data-aided training, one step size
+    per mode, the adaptive step with an error function / precision the segment kernels do not carry) the library runs the exact form
+    inside the call - bit-identical to the exact entry point - and reports it (``exact_form``)."""
+    M = 64 if method == "mrde" else 16
+    sig, E, tr, w0, sy, rt = _setup("mcma" if method == "sbd_data" else method, M, nsym=2 ** 13, dtype=dtype)
+    if method == "sbd_data":
+        Er = np.roll(E, 15 // 2, axis=1)                              # symbol i at the centre tap of window i (test/test_equalisation.py:109-110)
+        sy = np.ascontiguousarray(np.asarray(sig.symbols)[:, :tr + 8].astype(dtype))
+        E = np.ascontiguousarray(Er)
+    (wa, ea, ma), (wb, eb, mb), rep = _exact_and_tier_b(E, tr, 1, 1e-3, w0, sy, method, adaptive, {}, rt)
+    assert rep["exact_form"] and rep["converged"], rep
+    assert np.array_equal(wa, wb) and np.array_equal(ea, eb) and ma == mb
+
+
+@pytest.mark.parametrize("method,M,niter", [("cma", 16, 1), ("cma", 16, 2), ("mcma", 16, 2), ("mrde", 64, 1), ("sbd", 16, 1)])
+def test_uncertified_sweep_is_redone_in_the_exact_form(method, M, niter, monkeypatch):
+    """A sweep the passes do not certify - here: one pass against a tolerance it cannot meet - is redone in the exact form from the taps the
+    call started with, inside the call: taps AND error trace are the exact entry point's bit for bit (for cma this includes NOT turning
+    the exact trace by the gauge phases of the failed pass), the report says ``exact_form``; with ``exact_redo_off`` the same call
+    hands back the uncertified result and says ``converged`` False."""
+    monkeypatch.setenv("QAMPY_HIP_PIT_FORM", "segment")
+    sig, E, tr, w0, sy, rt = _setup(method, M, nsym=2 ** 15, ntaps=21)
+    pit = dict(segments=16, max_passes=1, tol=1e-9, acquire=0)
+    (wa, ea, _), (wb, eb, _), rep = _exact_and_tier_b(E, tr, niter, 1e-3, w0, sy, method, False, pit, rt)
+    assert rep["exact_form"] and rep["converged"] and rep["segments"] == 16, rep
+    assert np.array_equal(wa, wb) and np.array_equal(ea, eb)
+    (_, _, _), (wc, ec, _), rep2 = _exact_and_tier_b(E, tr, niter, 1e-3, w0, sy, method, False, dict(pit, exact_redo_off=1), rt)
+    assert not rep2["converged"] and not rep2["exact_form"], rep2
+    assert not np.array_equal(wa, wc)
+
+
+@pytest.mark.parametrize("method", ["cma", "mcma"])
+def test_adaptive_sweep_that_falls_back_returns_the_exact_error_trace(method, monkeypatch):
+    """The adaptive solver's way out (a sweep not certified within the passes) writes the error trace in the exact form; it must come back
+    as it is - for cma (continuous symmetry) NOT turned by the gauge phases of the failed passes - and every mode's report must
+    survive (``per_mode``)."""
+    sig = synth.make_capture(16, 2 ** 17, nmodes=2, snr_db=25, theta=np.pi / 3, dgd=30e-12, linewidth=0., seed=1000, dtype=np.complex64)
+    E = np.ascontiguousarray(np.asarray(sig))
+    kw = dict(Ntaps=13, method=method, adaptive_stepsize=True)
+    wa, ea = core_eq.equalise_signal(E, 2, 1.9e-3, 16, **kw)
+    wb, eb = core_eq.equalise_signal(E, 2, 1.9e-3, 16, tier="b", pit=dict(max_passes=1, tol=1e-9), **kw)
+    rep = core_eq.last_pit_reports()[0]
+    assert rep["exact_form"] and rep["converged"] and len(rep["per_mode"]) == 2 and all(r["exact_form"] for r in rep["per_mode"]), rep
+    assert np.array_equal(wa, wb) and np.array_equal(ea, eb)
+
+
+def test_real_valued_methods_through_tier_b_take_the_exact_form():
+    sig = synth.make_capture(16, 2 ** 13, nmodes=2, snr_db=25, theta=np.pi / 5.6, dgd=30e-12, seed=5, dtype=np.complex64)
+    E = np.ascontiguousarray(np.asarray(sig))
+    wa, ea = core_eq.equalise_signal(E, 2, 1e-3, 16, Ntaps=15, method="cma_real")
+    wb, eb = core_eq.equalise_signal(E, 2, 1e-3, 16, Ntaps=15, method="cma_real", tier="b")
+    assert np.array_equal(wa, wb) and np.array_equal(ea, eb)
+    assert core_eq.last_pit_reports()[0]["exact_form"]
 
 
 def test_ser_equivalence_at_scale():
@@ -244,7 +306,7 @@ def test_segment_form_at_other_sampling_rates(os_, monkeypatch):
     dw, derr = DeviceArray.from_host(w0.copy()), DeviceArray((2, tr), np.complex64, zero=True)
     rep = hk.PitReportBuffer()
     hk.train_equaliser_dev(dE, tr, 1, os_, dmu, dw, None, False, dsy, "mcma", derr,
-                           pit=dict(segments=4, max_passes=4, tol=1e-12, correction=0, phase_seed=0, acquire=0), report=rep)
+                           pit=dict(segments=4, max_passes=4, tol=1e-12, correction=0, phase_seed=0, acquire=0, exact_redo_off=1), report=rep)
     r = rep.read()
     assert r["segments"] == 4 and r["passes"] == 4
     np.testing.assert_allclose(dw.to_host(), wo, rtol=2e-4, atol=2e-5)
