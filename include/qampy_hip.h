@@ -39,7 +39,7 @@ extern "C" {
  * arguments.  History: 1 = round 1; 2 = round 2 (qh_bps_recover_*_dev gained `angles`, qh_train_equaliser_*_pit_dev takes
  * (gram, opts, report), the *_seg_dev entry points were removed - unversioned at the time); 3 = round 3 (qh_pit_opts:
  * start, dev_safety; qh_pit_report: deviation[]); 4 = qh_pit_opts: adaptive. */
-#define QH_ABI_VERSION 5
+#define QH_ABI_VERSION 6
 int qh_abi_version(void);
 
 /* ---- status codes (python shim: 1,2 -> ValueError, 3,4 -> RuntimeError) */
@@ -277,7 +277,8 @@ typedef struct qh_pit_opts {
     int64_t acq_chunk;      /* 0 = automatic: 2 / mu_acq steps (mu_acq = the gear-shifted step size), 256 .. 4096 */
     int64_t acq_max;        /* 0 = two chunks (at most TrSyms / 2 steps) */
     int32_t correction;     /* -1 / 1: linearised coarse correction between the passes (see below), 0: plain relaxation */
-    int32_t pad;
+    int32_t head_steps;     /* fixed step: > 0 - the first head_steps steps of every sweep run in the EXACT form, the segments cover the rest; 0: none, unless
+                             * the passes stall on the start of the sweep (see head_auto_off) (ABI 6) */
     void *basis;            /* NULL, or the eigenbasis of this capture's input covariance from qh_pit_basis_*_dev (device memory) */
     double corr_beta;       /* extra damping of the well-excited directions in the coarse map, exp(-a (1 + beta a)); < 0: by method */
     /* One capture over several processes / GPUs (optional; every process holds the whole capture and makes the same call):
@@ -302,6 +303,11 @@ typedef struct qh_pit_opts {
     int32_t exact_redo_off; /* 0 (default): a sweep the passes do not certify (estimate above tol when they stop, pass budget used up, no coarse
                              * model) is redone in the EXACT form from the taps the call started with, inside the call - every call returns the
                              * reference's result; report: converged = 2.  != 0: the uncertified result stays (converged = 0) (ABI 5) */
+    int32_t head_auto_off;  /* 0 (default): a sweep whose passes stall with the estimated deviation confined to the first quarter of the segments (a
+                             * non-linear transient at the start of the stage: e.g. a decision-directed stage pulling in from taps locked to another
+                             * carrier phase) is repeated with that stretch as an exact head - sequential there, parallel in time after it - before the
+                             * whole call is given to the exact form; != 0: off (ABI 6) */
+    int32_t reserved1;
 } qh_pit_opts;
 typedef struct qh_pit_report {
     int32_t segments, passes, converged, acq_chunks;

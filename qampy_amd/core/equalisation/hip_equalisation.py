@@ -292,6 +292,38 @@ class ResidentJobs:
             wx[m] = out[j, m]
         return wx
 
+    def train_bank(self, TrSyms, Niter, os, mu, bank, adaptive, symbols, method):
+        """Like :meth:`train` with one tap set PER JOB in and out (``bank (njobs, nmodes, nmodes, ntaps)``): jobs that do not share their
+        start taps, e.g. the frames of a capture (job ``j`` still only moves row ``job_modes[j]`` of its set)."""
+        if method not in _lib.METHOD_ID:
+            raise ValueError("Unknown method %s" % method)
+        nj, nmodes, L = self.shape
+        bank = np.ascontiguousarray(bank, dtype=self.ct)
+        symbols = np.ascontiguousarray(symbols)
+        _need(symbols, self.ct, "symbols")
+        dw, dsy = DeviceArray.from_host(bank), DeviceArray.from_host(symbols)
+        dmu = DeviceArray.from_host(np.full(nj, mu, dtype=self.rt))
+        derr = DeviceArray((nj, nmodes, int(TrSyms) * int(Niter)), self.ct)
+        # every job trains ITS mode only: one launch per output mode over the jobs that carry it would need a gather; the bank entry point
+        # trains all selected modes of all jobs - rows of other modes are discarded below (they never feed back into the kept row)
+        train_equaliser_batch_dev(self.dev, TrSyms, Niter, os, dmu, dw, None, "per-mode" if adaptive else False, dsy, method, derr, zero_err=True)
+        out = dw.to_host()
+        res = np.array(bank, copy=True)
+        for j, m in enumerate(self.job_modes):
+            res[j, m] = out[j, m]
+        return res
+
+    def apply_bank(self, os, bank):
+        """Row ``job_modes[j]`` of slice ``j`` through job ``j``'s own taps, stacked."""
+        nj, nmodes, L = self.shape
+        N = max((L - bank.shape[-1] + 1) // os, 0)
+        rows = []
+        for j, m in enumerate(self.job_modes):
+            out = DeviceArray((1, N), self.ct)
+            apply_filter_to_signal_dev(self.dev.row(j), os, DeviceArray.from_host(np.ascontiguousarray(bank[j], dtype=self.ct)), np.array([m]), out)
+            rows.append(out.to_host()[0])
+        return np.array(rows)
+
     def apply(self, os, wx):
         """Row ``job_modes[j]`` of slice ``j`` through the taps, stacked."""
         nj, nmodes, L = self.shape

@@ -207,6 +207,62 @@ def _equalize_pilot_jobs(rx, refs, starts, span, os, foe_comp, mu, M_pilot, Ntap
     return np.array(taps), offsets
 
 
+def equalize_pilot_frames(rx_signal, ref_symbs, starts_per_frame, os, foe_comp=False, mu=(1e-4, 1e-4), M_pilot=4, Ntaps=45,
+                          Niter=30, adaptive_stepsize=True, methods=('cma', 'cma'), wxinit=None):
+    """
+    :func:`equalize_pilot_sequence` for SEVERAL frames of one capture that are all handed the same array of start taps ``wxinit`` -
+    what ``pilot_equaliser_nframes`` does from its second frame on (qampy/equalisation.py:386-390) - when the modes of a frame start
+    at different samples.  What links the frames in the reference is its pre-convergence stage only: it trains the given taps IN
+    PLACE (core/pilotbased_receiver.py:497-510: ``wx = wxinit`` goes through ``equalise_signal``, whose ``np.ascontiguousarray`` keeps
+    the array and whose compiled trainer writes into it), so frame k+1 starts from the taps frame k's pre-convergence left behind;
+    the two pilot-aided stages work on a copy (``out_taps = wx.copy()``) and depend on nothing but their own frame.  Hence:
+      * the pre-convergence stages run frame after frame (the modes of a frame together: independent chains), on ``wxinit`` in place,
+      * the 2 x Niter pilot-aided sweeps of ALL frames - two thirds of the work - run together: every (frame, mode) pair is an
+        independent chain of ONE launch per stage (:class:`hip_equalisation.ResidentJobs`).
+    Per frame the result is exactly :func:`equalize_pilot_sequence`'s, ``wxinit`` ends as the reference leaves it.
+    Returns ``(taps (nframes, nmodes, nmodes, Ntaps), offsets (nframes, nmodes, 1))``; ``None`` when the frames cannot be batched
+    (real-valued methods, modes that share a start sample, no start taps: the caller then goes frame by frame).
+    """
+    rx, refs = np.atleast_2d(rx_signal), np.atleast_2d(ref_symbs)
+    nmodes, seq_len = rx.shape[0], refs.shape[-1]
+    starts_per_frame = [np.asarray(s, dtype=int) for s in starts_per_frame]
+    m0, m1 = _eq._method_name(methods[0]), _eq._method_name(methods[1])
+    dtype = np.asarray(rx).dtype
+    if wxinit is None or m0 in _eq.REAL_VALUED or m1 in _eq.REAL_VALUED or any(np.unique(s).shape[0] != nmodes for s in starts_per_frame) or nmodes < 2:
+        return None
+    if not (isinstance(wxinit, np.ndarray) and wxinit.dtype == dtype and wxinit.flags.c_contiguous):
+        return None                                                   # (the in-place chain needs the caller's own array)
+    span = seq_len * os + Ntaps - 1
+    nfr = len(starts_per_frame)
+    rt = dtype.type(0).real.dtype.type
+    TrSyms = _eq._cal_training_symbol_len(os, Ntaps, span)
+    sy0 = _eq._reshape_symbols(None, m0, M_pilot, dtype, nmodes).copy()
+    pieces, pre = [], []
+    offsets = np.zeros((nfr, nmodes, 1))
+    for f, st in enumerate(starts_per_frame):                         # ---- pre-convergence: the chain through the frames
+        mine = [rx[:, int(st[m]):int(st[m]) + span] for m in range(nmodes)]
+        jobs = _eq._kernels.ResidentJobs(mine, range(nmodes))
+        jobs.train(TrSyms, Niter, os, rt(mu[0]), wxinit, adaptive_stepsize, sy0, m0)          # in place, like the reference
+        pre.append(wxinit.copy())
+        if foe_comp:
+            foe, foe_modes, _ = pilot_based_foe(jobs.apply(os, pre[f]), refs)
+            offsets[f] = np.ones(foe_modes.shape) * foe
+            mine = [phaserecovery.comp_freq_offset(p, offsets[f], os=os) for p in mine]
+        pieces += mine
+    job_modes = [m for _ in range(nfr) for m in range(nmodes)]       # ---- the pilot-aided stages of all frames together
+    jobs = _eq._kernels.ResidentJobs(pieces, job_modes)
+    bank = np.ascontiguousarray(np.repeat(np.array(pre), nmodes, axis=0))
+    for mu_s, M, method in ((mu[0], M_pilot, m0), (mu[1], 4, m1)):   # (QPSK pilots hard-coded for the second method when training mode by mode, :540)
+        sy = _eq._reshape_symbols(refs, method, M, dtype, nmodes).copy()
+        bank = jobs.train_bank(TrSyms, Niter, os, rt(mu_s), bank, adaptive_stepsize, sy, method)
+    taps = np.empty((nfr,) + wxinit.shape, dtype=dtype)
+    for f in range(nfr):
+        taps[f] = pre[f]
+        for m in range(nmodes):
+            taps[f, m] = bank[f * nmodes + m, m]
+    return taps, offsets
+
+
 def equalize_pilot_sequence(rx_signal, ref_symbs, shift_fctrs, os, foe_comp=False, mu=(1e-4, 1e-4), M_pilot=4, Ntaps=45,
                             Niter=30, adaptive_stepsize=True, methods=('cma', 'cma'), wxinit=None):
     """

@@ -13,13 +13,18 @@ todo=""
 for f in $UNITS; do
     stale=0
     [ -f build/$f.o ] || stale=1
-    for dep in $f.hip common.h train_impl.h train_la.h train_bi.h train_pit.h train_seg.h ../../include/qampy_hip.h; do
-        [ $stale = 1 ] || { [ $dep -nt build/$f.o ] && stale=1; } || true
+    # dependencies: the headers the compiler reported for this unit last time (build/<unit>.d, -MMD), else every header
+    deps="$f.hip common.h train_impl.h train_la.h train_bi.h train_pit.h train_seg.h ../../include/qampy_hip.h"
+    if [ -f build/$f.d ]; then
+        deps="$f.hip $(tr -d '\\\n' < build/$f.d | sed 's/^[^:]*://' | tr ' ' '\n' | grep -v '^/opt/' | grep -v '^/usr/' | grep -v '^$' | sort -u | tr '\n' ' ')"
+    fi
+    for dep in $deps; do
+        [ $stale = 1 ] || { [ -e $dep ] && [ $dep -nt build/$f.o ] && stale=1; } || true
     done
     [ $stale = 1 ] && todo="$todo $f"
 done
 if [ -n "$todo" ]; then
-    echo $todo | tr ' ' '\n' | xargs -P ${QH_BUILD_JOBS:-$(nproc)} -I{} $HIPCC $FLAGS -c {}.hip -o build/{}.o
+    echo $todo | tr ' ' '\n' | xargs -P ${QH_BUILD_JOBS:-$(nproc)} -I{} $HIPCC $FLAGS -MMD -MF build/{}.d -c {}.hip -o build/{}.o
 fi
 OBJS=""
 for f in $UNITS; do OBJS="$OBJS build/$f.o"; done

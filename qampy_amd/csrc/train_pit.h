@@ -12,6 +12,8 @@
 #pragma once
 #include <atomic>
 #include <chrono>
+#include <vector>
+#include <cstdio>
 #include "train_impl.h"
 #include "train_seg.h"
 
@@ -383,7 +385,7 @@ template <typename R> __device__ inline double pit_gain(int method, double Py, C
 // end of a pass: largest boundary defect and the deviation estimate -> report; the pass's end taps become the sweep's result;
 // converged -> later passes skip.  devmax: per-block maxima of sum_k lambda_k |D~_k[col]|^2 from pit_devest_kernel (ndev of them;
 // nullptr / corr_on = 0: no estimate, the defect rule decides).
-constexpr double PIT_DEV_SAFETY = 1.0, PIT_DEV_WORST = 3.0, PIT_DEV_TAPS = 2.0;    // rule: safety x rms estimate < tol, worst segment < 3 tol, taps (relative norm, rms over segments) < 2 tol
+constexpr double PIT_DEV_SAFETY = 1.0, PIT_DEV_WORST = 3.0, PIT_DEV_TAPS = 2.0, PIT_DEV_TAPS_WORST = 3.0;    // rule: safety x rms estimate < tol, worst segment < 3 tol, taps (relative norm, rms over segments) < 2 tol
 template <typename R> struct PitDecideArgs {
     const double *dfc, *pw;
     int nb;
@@ -497,6 +499,7 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
             crit = safety * dev_rms;
             if (safety * dev / PIT_DEV_WORST > crit) crit = safety * dev / PIT_DEV_WORST;
             if (dev_tap >= 0 && safety * dev_tap / PIT_DEV_TAPS > crit) crit = safety * dev_tap / PIT_DEV_TAPS;
+            if (dev_tap_worst >= 0 && safety * dev_tap_worst / PIT_DEV_TAPS_WORST > crit) crit = safety * dev_tap_worst / PIT_DEV_TAPS_WORST;    // (the final taps sit at the worst segment's value)
         }
         else {
             double amp = 1.0;
@@ -1016,6 +1019,216 @@ __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A2, const Zf *
     }
 }
 
+// ------------------------------------------------------------------------------------------------ measured coarse model
+// What a segment does to a perturbation of its start taps, to first order and on average:  delta' = delta - mu H delta, H the mean
+// Jacobian of the update around the converged output.  With dy = x^T delta and de = -G dy (G the real 2 x 2 gain matrix of the error
+// function at the output y: its trace / 2 is the holomorphic gain, the rest - different pull along and across y - the anti-holomorphic
+// part) H = E[P^T G P].  The symbols are independent, so everything in H that is NOT g Rc (g = E[tr G] / 2, Rc the input covariance) sits
+// on ONE direction per output mode: u = Rc w / |Rc w| (the window's response to the symbol under the centre tap: E[conj(x) y]), along which
+// a perturbation is an amplitude change (real multiple) or a phase rotation (imaginary multiple) of the output.  For the constant-modulus
+// functions these two have gains 3<|y|^4>/<|y|^2> - R (2.76 at 64-QAM) and ~0 against g = 0.62 for everything else: a model with ONE gain
+// per eigen-direction of Rc (round 3) is off by 0.3-0.5 in the segment map along u, and that mismatch - not the sample covariance of a
+// segment - was the contraction floor of the passes (0.35-0.45 per pass; mcma, whose amplitude direction had no extra damping, stalled).
+// The model is therefore MEASURED per sweep on PIT_MODW windows of the capture at the sweep's seed taps:
+//   g        = E[tr G] / 2                                  (replaces the per-method formulas of pit_gain)
+//   K (2x2)  = E[Z^T G Z],  Z = the 2 x 2 real form of z = x^T u:  the restriction of H to span{u, i u}
+// and the scan of the corrections treats the component of a defect along u with exp(-mu T K) (two scalar recurrences in the eigenbasis of
+// K), the rest with exp(-mu g T lambda_k) as before.  G per error function (pythran_equalisation.py:178-231), decisions held.
+constexpr int PIT_MODW = 8192, PIT_MODB = 128;                 // sample windows, blocks (4 waves x 4 window groups each: 4 windows per group and mode)
+struct PitModel { float g, k1, k2, q11, q12, q21, q22, lam_u; int ok; int pad[3]; };     // per selected mode: gain, eigenvalues of K, Q (columns = eigenvectors), <|z|^2>
+template <typename R> struct PitModelArgs {
+    const Cx<R> *E, *wx, *symbols;
+    int64_t L, TrSyms, nsy, sy_pitch;
+    int nmodes, ntaps, os, nsel, method, tables;               // tables: symbols hold codes / partitions in the rde / mrde layout (also the slicer tables)
+    int64_t modes[16];
+    float *part;                                               // [PIT_MODB blocks][nsel][2 * PIT_EIGMAX + 8] partial sums
+    Cx<R> *u;                                                  // [nsel][ntot]: phase A writes p = sum conj(x) y normalised, phase B reads it
+    PitModel *model;                                           // [nsel]
+    unsigned *ticket;
+    // The windows sit in the HEADS of the segments, and for the phase-sensitive error functions their outputs are turned by the
+    // segment's phase seed rot[s] (pit_phase_kernel / pit_unwrap_kernel: the 4th-power phase of the seed taps' output there) - G depends on
+    // where y sits relative to the axes, and with a drifting carrier the seed taps' output is only aligned after that rotation (measured
+    // without it on 16-QAM / mcma / 50 kHz linewidth: a model so wrong that the passes diverged).  rot == nullptr: no rotation.
+    PitSeg sg;
+    const double *rot;
+};
+// G = [[g11, g12], [g12, g22]] at the output y
+constexpr int PIT_MODTAB = 128;                              // table entries staged in LDS (more: the constants only)
+__device__ __forceinline__ void pit_gain_matrix(int method, float yr, float yi, const Zf *sy, int nsy, int tables, float &g11, float &g12, float &g22)
+{
+    const float y2 = yr * yr + yi * yi;
+    const Zf c0 = sy[0];
+    const int ncode = (nsy + 1) / 2, npart = nsy - ncode;
+    auto look = [&](float v, bool im) -> float {                 // partition_value: the code above the last partition below v
+        float r = im ? c0.y : c0.x;
+        for (int p = 0; p < npart; p++) { const Zf pt = sy[ncode + p], cd = sy[p + 1]; if (v > (im ? pt.y : pt.x)) r = im ? cd.y : cd.x; }
+        return r;
+    };
+    g12 = 0.f;
+    switch (method) {
+    case QH_M_CMA: case QH_M_SGNCMA: { const float r = c0.x; g11 = 3 * yr * yr + yi * yi - r; g22 = yr * yr + 3 * yi * yi - r; g12 = 2 * yr * yi; break; }
+    case QH_M_MCMA: g11 = 3 * yr * yr - c0.x; g22 = 3 * yi * yi - c0.y; break;
+    case QH_M_RDE: { const float r = tables ? look(y2, false) : c0.x; g11 = 3 * yr * yr + yi * yi - r; g22 = yr * yr + 3 * yi * yi - r; g12 = 2 * yr * yi; break; }
+    case QH_M_MRDE: { const float rr = tables ? look(yr * yr, false) : c0.x, ri = tables ? look(yi * yi, true) : c0.y; g11 = 3 * yr * yr - rr; g22 = 3 * yi * yi - ri; break; }
+    case QH_M_SBD: { const float sr = look(yr, false), si = look(yi, true); g11 = fabsf(sr); g22 = fabsf(si); break; }
+    case QH_M_MDDMA: { const float sr = look(yr, false), si = look(yi, true); g11 = 3 * yr * yr - sr * sr; g22 = 3 * yi * yi - si * si; break; }
+    default: g11 = 1.f; g22 = 1.f; break;                      // dd
+    }
+}
+// PHASE 0: p = sum conj(x_i) y_i (-> u), g.  PHASE 1: K, <|z|^2>.  FOUR windows per wave at a time (16 lanes each, up to 8 consecutive taps
+// per lane, 4-step shuffle reductions): a window is one round trip to memory plus a chain of reductions, so what counts is how many are
+// in flight (one window per wave: 70 us per launch; so: ~10).
+template <typename R, int PHASE>
+__global__ void __launch_bounds__(256) pit_model_kernel(PitModelArgs<R> a)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4, l16 = lane & 15;
+    const int gg = (blockIdx.x * 4 + wave) * 4 + grp, ng = gridDim.x * 16;            // window groups of the launch
+    const int ntot = a.nmodes * a.ntaps;
+    constexpr int TP = PIT_EIGMAX / 16;                          // taps per lane (slots)
+    const int pw = 2 * PIT_EIGMAX + 8;                           // floats per (block, mode) partial
+    const int tpl = (ntot + 15) / 16;                            // taps per lane in use
+    for (int j = 0; j < a.nsel; j++) {
+        const int mode = (int)a.modes[j];
+        __shared__ Zf tab[PIT_MODTAB];                                // this mode's constants / tables (read per window: not from global memory)
+        const int nsy_l = a.nsy <= PIT_MODTAB ? (int)a.nsy : 1;
+        const int tables_l = a.nsy <= PIT_MODTAB ? a.tables : 0;
+        __syncthreads();
+        for (int e = threadIdx.x; e < nsy_l; e += 256) { const Cx<R> v = a.symbols[(size_t)mode * a.sy_pitch + e]; tab[e] = Zf{(float)v.re, (float)v.im}; }
+        __syncthreads();
+        Zf wv[TP], uv[TP], pacc[TP];
+        int64_t xoff[TP];                                           // where tap f of a window sits relative to the window's first sample
+        float gacc = 0.f, k11 = 0.f, k12 = 0.f, k22 = 0.f, zz = 0.f, cnt = 0.f;
+#pragma unroll
+        for (int q = 0; q < TP; q++) {
+            const int f = l16 * tpl + q;
+            const bool ok = q < tpl && f < ntot;
+            const int k = ok ? f / a.ntaps : 0;
+            xoff[q] = ok ? (int64_t)k * a.L + (f - k * a.ntaps) : -1;
+            wv[q] = Zf{0.f, 0.f}; uv[q] = Zf{0.f, 0.f}; pacc[q] = Zf{0.f, 0.f};
+            if (ok) { const Cx<R> t = a.wx[(size_t)mode * ntot + f]; wv[q] = Zf{(float)t.re, (float)t.im}; if (PHASE == 1) { const Cx<R> v = a.u[(size_t)j * ntot + f]; uv[q] = Zf{(float)v.re, (float)v.im}; } }
+        }
+        int64_t st = ((int64_t)PIT_SEEDWIN * a.sg.S) / PIT_MODW;
+        st = st < 1 ? 1 : (st > 37 ? 37 : st);
+        for (int wi0 = gg - grp; wi0 < PIT_MODW; wi0 += ng) {     // (wave-uniform trip count; a group without a valid window idles through it)
+            // window wi: segment wi mod S, the (wi / S)-th of the sampled steps of its head (the first PIT_SEEDWIN steps, up to 37 steps apart)
+            const int wi = wi0 + grp;
+            const int sgi = wi % a.sg.S;
+            const int64_t off = (int64_t)(wi / a.sg.S) * st;
+            const int64_t i = a.sg.start(sgi) + off;
+            const bool valid = wi < PIT_MODW && off < PIT_SEEDWIN && off < a.sg.steps(sgi) && i < a.TrSyms;
+            float rc = 1.f, rs = 0.f;
+            if (a.rot && valid) { rc = (float)a.rot[2 * ((size_t)sgi * a.nsel + j)]; rs = (float)a.rot[2 * ((size_t)sgi * a.nsel + j) + 1]; }
+            Zf xv[TP];
+            float yr = 0.f, yi = 0.f, zr = 0.f, zi = 0.f;
+#pragma unroll
+            for (int q = 0; q < TP; q++) {
+                xv[q] = Zf{0.f, 0.f};
+                if (valid && xoff[q] >= 0) { const Cx<R> v = a.E[xoff[q] + i * a.os]; xv[q] = Zf{(float)v.re, (float)v.im}; }
+            }
+#pragma unroll
+            for (int q = 0; q < TP; q++) {
+                yr += xv[q].x * wv[q].x - xv[q].y * wv[q].y; yi += xv[q].x * wv[q].y + xv[q].y * wv[q].x;
+                if (PHASE == 1) { zr += xv[q].x * uv[q].x - xv[q].y * uv[q].y; zi += xv[q].x * uv[q].y + xv[q].y * uv[q].x; }
+            }
+            for (int o = 8; o > 0; o >>= 1) { yr += __shfl_xor(yr, o); yi += __shfl_xor(yi, o); if (PHASE == 1) { zr += __shfl_xor(zr, o); zi += __shfl_xor(zi, o); } }
+            const float yr0 = yr, yi0 = yi;                                                  // (u = E[conj(x) y] belongs to the seed taps as they are)
+            { const float t = yr * rc - yi * rs; yi = yr * rs + yi * rc; yr = t; }            // the segment's frame (seed taps x rot[s])
+            if (PHASE == 1) { const float t = zr * rc - zi * rs; zi = zr * rs + zi * rc; zr = t; }
+            float g11, g12, g22;
+            pit_gain_matrix(a.method, yr, yi, tab, nsy_l, tables_l, g11, g12, g22);
+            if (valid) {
+                if (PHASE == 0) {
+#pragma unroll
+                    for (int q = 0; q < TP; q++) { pacc[q].x += xv[q].x * yr0 + xv[q].y * yi0; pacc[q].y += xv[q].x * yi0 - xv[q].y * yr0; }   // conj(x) y
+                    gacc += 0.5f * (g11 + g22);
+                } else {
+                    k11 += zr * zr * g11 + 2 * zr * zi * g12 + zi * zi * g22;
+                    k22 += zi * zi * g11 - 2 * zr * zi * g12 + zr * zr * g22;
+                    k12 += -zr * zi * g11 + (zr * zr - zi * zi) * g12 + zr * zi * g22;
+                    zz += zr * zr + zi * zi;
+                }
+                cnt += 1.f;
+            }
+        }
+        // the four window groups of the wave add up (shuffles), then the four waves of the block in LDS (fixed order): one partial per block and mode
+        __shared__ float blk[4][2 * PIT_EIGMAX + 8];
+        for (int e = lane; e < 2 * PIT_EIGMAX + 8; e += 64) blk[wave][e] = 0.f;
+        if (PHASE == 0) {
+#pragma unroll
+            for (int q = 0; q < TP; q++) {
+                float pr = pacc[q].x, pi = pacc[q].y;
+                pr += __shfl_xor(pr, 16); pi += __shfl_xor(pi, 16); pr += __shfl_xor(pr, 32); pi += __shfl_xor(pi, 32);
+                const int f = l16 * tpl + q;
+                if (grp == 0 && q < tpl && f < ntot) { blk[wave][2 * f] = pr; blk[wave][2 * f + 1] = pi; }
+            }
+            gacc += __shfl_xor(gacc, 16); gacc += __shfl_xor(gacc, 32); cnt += __shfl_xor(cnt, 16); cnt += __shfl_xor(cnt, 32);
+            if (lane == 0) { blk[wave][2 * PIT_EIGMAX] = gacc; blk[wave][2 * PIT_EIGMAX + 1] = cnt; }
+        } else {
+            for (int o = 16; o <= 32; o <<= 1) { k11 += __shfl_xor(k11, o); k12 += __shfl_xor(k12, o); k22 += __shfl_xor(k22, o); zz += __shfl_xor(zz, o); cnt += __shfl_xor(cnt, o); }
+            if (lane == 0) { blk[wave][0] = k11; blk[wave][1] = k12; blk[wave][2] = k22; blk[wave][3] = zz; blk[wave][4] = cnt; }
+        }
+        __syncthreads();
+        float *dst = a.part + ((size_t)blockIdx.x * a.nsel + j) * pw;
+        const int nval = PHASE == 0 ? 2 * PIT_EIGMAX + 2 : 5;
+        for (int e = threadIdx.x; e < nval; e += 256) dst[e] = (blk[0][e] + blk[1][e]) + (blk[2][e] + blk[3][e]);
+        __syncthreads();
+    }
+    // the block that finishes last adds the partial sums up (fixed order: reproducible) and writes the result
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) { __threadfence(); const unsigned t = atomicAdd(a.ticket, 1u); last = t == gridDim.x - 1; if (last) { *a.ticket = 0; __threadfence(); } }
+    __syncthreads();
+    if (!last) return;
+    __shared__ float red[256];
+    const int nblk = gridDim.x;
+    // sum over the blocks' partials of element e of mode j: loads batched 16 at a time (one by one they were 0.25 ms of latency)
+    auto psum = [&](int j, int e) -> float {
+        float acc = 0.f;
+        for (int b0 = 0; b0 < nblk; b0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) v[q] = b0 + q < nblk ? a.part[((size_t)(b0 + q) * a.nsel + j) * pw + e] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc += v[q];
+        }
+        return acc;
+    };
+    __shared__ float vals[2 * PIT_EIGMAX + 8];
+    const int nval = PHASE == 0 ? 2 * PIT_EIGMAX + 2 : 5;
+    for (int j = 0; j < a.nsel; j++) {
+        // every value of this mode summed over the blocks' partials by its own thread (fixed order: reproducible)
+        for (int e = threadIdx.x; e < nval; e += 256) vals[e] = (PHASE == 1 || e >= 2 * PIT_EIGMAX || e < 2 * ntot) ? psum(j, e) : 0.f;
+        __syncthreads();
+        if (PHASE == 0) {
+            float nrm = 0.f;
+            for (int f = threadIdx.x; f < ntot; f += 256) nrm += vals[2 * f] * vals[2 * f] + vals[2 * f + 1] * vals[2 * f + 1];
+            red[threadIdx.x] = nrm; __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+            const float inv = red[0] > 0.f ? rsqrtf(red[0]) : 0.f;
+            for (int f = threadIdx.x; f < ntot; f += 256) a.u[(size_t)j * ntot + f] = Cx<R>{(R)(vals[2 * f] * inv), (R)(vals[2 * f + 1] * inv)};
+            if (threadIdx.x == 0) {
+                const float gs = vals[2 * PIT_EIGMAX], cs = vals[2 * PIT_EIGMAX + 1];
+                a.model[j].g = cs > 0.f ? gs / cs : 0.f;
+                a.model[j].ok = 0;
+            }
+        } else if (threadIdx.x == 0) {
+            float k11 = vals[0], k12 = vals[1], k22 = vals[2], zz = vals[3];
+            const float cs = vals[4];
+            const float n = cs > 0.f ? 1.f / cs : 0.f;
+            k11 *= n; k12 *= n; k22 *= n; zz *= n;
+            // symmetric 2 x 2 eigen-decomposition: K = Q diag(k1, k2) Q^T
+            const float tr = 0.5f * (k11 + k22), df = 0.5f * (k11 - k22), rad = sqrtf(df * df + k12 * k12);
+            float c = 1.f, sn = 0.f;
+            if (rad > 1e-12f * (fabsf(tr) + 1e-30f)) { const float ang = 0.5f * atan2f(k12, df); c = cosf(ang); sn = sinf(ang); }
+            PitModel m = a.model[j];
+            m.k1 = tr + rad; m.k2 = tr - rad; m.q11 = c; m.q21 = sn; m.q12 = -sn; m.q22 = c; m.lam_u = zz;
+            m.ok = (m.g > 0.f && m.g == m.g && m.k1 == m.k1 && m.k2 == m.k2) ? 1 : 0;
+            a.model[j] = m;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ eigen-space analysis (single precision)
 // The analysis of a pass needs the boundary states in the eigenbasis anyway (defect vectors -> scan -> correction).  For complex64
 // everything between the two basis products therefore lives THERE: x~[s] = V^H X[s] (start taps, kept up to date through the passes:
@@ -1275,8 +1488,11 @@ __global__ void __launch_bounds__(64 * (PIT_EIGMAX / 16)) pit_basis_mfma_kernel(
 // Boundary b = 1 .. S-1 of mode j (one wave each; entries (b-1) nsel + j): a = x~[b] against b = y~[b-1], lambda-weighted:
 // best group element g (y_B ~ g y_A), defect |b - g a|_Lambda / |b|_Lambda, output power |b|^2_Lambda.  nsel extra rows: how far the
 // sweep's RESULT moved - y~[S-1] of this pass against the previous pass's (pass 0: against the start taps of the last segment).
+// ualpha != nullptr (measured model, see pit_model_kernel): per boundary the component of the local defect along the signal direction
+// u = Lambda y~[s-1] / |Lambda y~[s-1]| (Rc w in the eigenbasis) - alpha = u^H (y~[s-1] - g x~[s]), the same number in every frame because
+// u turns with the taps it is made of - and 1 / |Lambda y~[s-1]|: ualpha[bi] = (Re alpha, Im alpha, 1 / norm, 0).
 static __global__ void __launch_bounds__(256) pit_bound_kernel(const Zf *Xe, const Zf *Ye, const Zf *Yprev, const double *lam, int n, int S, int nsel, int sym,
-                                                              const PitCtrl *c, double *dfc, double *pw, double *gph)
+                                                              const PitCtrl *c, double *dfc, double *pw, double *gph, float4 *ualpha = nullptr)
 {
     if (c->done) return;
     const int lane = threadIdx.x & 63, bi = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1328,6 +1544,20 @@ static __global__ void __launch_bounds__(256) pit_bound_kernel(const Zf *Xe, con
         d2 += (double)lv[q] * ((double)dr * dr + (double)di * di);
     }
     for (int o = 32; o > 0; o >>= 1) d2 += __shfl_xor(d2, o);
+    if (ualpha && !result_probe) {
+        float nn = 0.f, ar = 0.f, ai = 0.f;
+#pragma unroll
+        for (int q = 0; q < (PIT_EIGMAX + 63) / 64; q++) {
+            const float dr = bv[q].x - (grf * av[q].x - gif * av[q].y), di = bv[q].y - (grf * av[q].y + gif * av[q].x);
+            const float ur = lv[q] * bv[q].x, ui = lv[q] * bv[q].y;                // Lambda y~ (unnormalised u)
+            nn += ur * ur + ui * ui;
+            ar += ur * dr + ui * di;                                                // conj(u) d
+            ai += ur * di - ui * dr;
+        }
+        for (int o = 32; o > 0; o >>= 1) { nn += __shfl_xor(nn, o); ar += __shfl_xor(ar, o); ai += __shfl_xor(ai, o); }
+        const float inv = nn > 0.f ? rsqrtf(nn) : 0.f;
+        if (lane == 0) ualpha[bi] = float4{ar * inv, ai * inv, inv, 0.f};
+    }
     if (lane == 0) {
         if (!result_probe) { gph[2 * (size_t)bi] = gr; gph[2 * (size_t)bi + 1] = gi; pw[bi] = B; }
         dfc[bi] = (A == A && B == B) ? sqrt(d2 / (B > 1e-300 ? B : 1e-300)) : 1e30;
@@ -1337,9 +1567,12 @@ static __global__ void __launch_bounds__(256) pit_bound_kernel(const Zf *Xe, con
 // The scan of pit_recur_kernel on defect vectors formed on the fly, d~_k[s] = theta_{s-1} y~_k[s-1] - theta_s x~_k[s] (0 for s = 0), and the
 // eigen-space start taps of the next pass: x~_k[s] <- theta_s x~_k[s] + D~_k[s] (what the back product adds to X, V being unitary).
 constexpr int PIT_RT = 1024;            // threads of the eigen-space scan: up to 4 segments per thread stay in registers (S <= 4096: one round of loads)
+// ualpha / uq != nullptr (measured model): the component of every defect along u[s] = theta_{s-1} Lambda y~[s-1] / |Lambda y~[s-1]| is taken out
+// before the scan (d_perp = d - u alpha) and its own scan - pit_gauge_kernel's q - put back afterwards: D~[s] = scan(d_perp) + u[s] q[s].
 template <typename R>
 __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf *Ye, Zf *D, const double *theta, const double *lam, int nsel, int S, int64_t T, const R *mu,
-                                                               double beta, const PitCtrl *c, const float *Msum = nullptr, float damp = 1.f)
+                                                               double beta, const PitCtrl *c, const float *Msum = nullptr, float damp = 1.f,
+                                                               const float4 *ualpha = nullptr, const float2 *uq = nullptr)
 {
     if (c->done) return;
     __shared__ float4 aff[2 * PIT_RT];
@@ -1376,15 +1609,31 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
         }
         Zf run{0.f, 0.f};
         float cq[4], clen = 1.f;
-#pragma unroll
-        for (int q = 0; q < 4; q++) { const int s = s0 + q; cq[q] = (s < s1 && s > 0) ? cf(s - 1) : (s < s1 ? 0.f : 1.f); }
+        float4 ua[4];
+        float2 qq[4];
+        const float lk = (float)(lam[k] > 0 ? lam[k] : 0.0);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int s = s0 + q;
+            cq[q] = (s < s1 && s > 0) ? cf(s - 1) : (s < s1 ? 0.f : 1.f);
+            ua[q] = (ualpha && s < s1 && s > 0) ? ualpha[(size_t)(s - 1) * nsel + j] : float4{0.f, 0.f, 0.f, 0.f};
+            qq[q] = (uq && s < s1 && s > 0) ? uq[(size_t)s * nsel + j] : float2{0.f, 0.f};
+        }
+        Zf uk[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int s = s0 + q;
+            uk[q] = Zf{0.f, 0.f};
             if (s < s1) {
                 x[q] = cmulf(t[q + 1], x[q]);                   // theta_s x~[s]
                 Zf d{0.f, 0.f};
-                if (s > 0) { const Zf aa = cmulf(t[q], y[q]); d = Zf{aa.x - x[q].x, aa.y - x[q].y}; }
+                if (s > 0) {
+                    const Zf aa = cmulf(t[q], y[q]);
+                    d = Zf{aa.x - x[q].x, aa.y - x[q].y};
+                    uk[q] = Zf{aa.x * lk * ua[q].z, aa.y * lk * ua[q].z};          // component k of u[s] (frame 0)
+                    const Zf ual = cmulf(uk[q], Zf{ua[q].x, ua[q].y});
+                    d = Zf{d.x - ual.x, d.y - ual.y};                              // d_perp
+                }
                 run = Zf{d.x + cq[q] * run.x, d.y + cq[q] * run.y};
                 r[q] = run;
                 clen *= cq[q];
@@ -1397,7 +1646,8 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
             const int s = s0 + q;
             if (s < s1) {
                 pw *= cq[q];
-                const Zf v{r[q].x + pw * comp.y, r[q].y + pw * comp.z};
+                const Zf uqv = cmulf(uk[q], Zf{qq[q].x, qq[q].y});
+                const Zf v{r[q].x + pw * comp.y + uqv.x, r[q].y + pw * comp.z + uqv.y};
                 row[(size_t)s * nsel] = v;
                 xr[(size_t)s * nsel] = Zf{x[q].x + damp * v.x, x[q].y + damp * v.y};
             }
@@ -1423,7 +1673,16 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
             const int s = sb + q;
             if (s < s1) {
                 Zf d{0.f, 0.f};
-                if (s > 0) { const Zf aa = cmulf(t[q], y[q]), bb = cmulf(t[q + 1], x[q]); d = Zf{aa.x - bb.x, aa.y - bb.y}; }
+                if (s > 0) {
+                    const Zf aa = cmulf(t[q], y[q]), bb = cmulf(t[q + 1], x[q]);
+                    d = Zf{aa.x - bb.x, aa.y - bb.y};
+                    if (ualpha) {
+                        const float4 al = ualpha[(size_t)(s - 1) * nsel + j];
+                        const float lk2 = (float)(lam[k] > 0 ? lam[k] : 0.0);
+                        const Zf ual = cmulf(Zf{aa.x * lk2 * al.z, aa.y * lk2 * al.z}, Zf{al.x, al.y});
+                        d = Zf{d.x - ual.x, d.y - ual.y};
+                    }
+                }
                 const float cs = s > 0 ? cf(s - 1) : 0.f;
                 run = Zf{d.x + cs * run.x, d.y + cs * run.y};
                 clen *= cs;
@@ -1450,6 +1709,15 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
             if (s < s1) {
                 pw *= s > 0 ? cf(s - 1) : 0.f;
                 v[q].x += pw * cin.x; v[q].y += pw * cin.y;
+                if (uq && s > 0) {                               // the scanned component along u[s] back in
+                    const float4 al = ualpha[(size_t)(s - 1) * nsel + j];
+                    const float2 qv = uq[(size_t)s * nsel + j];
+                    const float lk2 = (float)(lam[k] > 0 ? lam[k] : 0.0);
+                    const Zf ts = s > 0 ? th(s - 1) : Zf{1.f, 0.f};
+                    const Zf aa = cmulf(ts, yr[(size_t)(s - 1) * nsel]);
+                    const Zf uqv = cmulf(Zf{aa.x * lk2 * al.z, aa.y * lk2 * al.z}, Zf{qv.x, qv.y});
+                    v[q].x += uqv.x; v[q].y += uqv.y;
+                }
                 row[(size_t)s * nsel] = v[q];
                 const Zf xx = cmulf(t[q], x[q]);
                 xr[(size_t)s * nsel] = Zf{xx.x + damp * v[q].x, xx.y + damp * v[q].y};
@@ -1570,14 +1838,51 @@ __global__ void __launch_bounds__(1024) pit_adapt_scan_kernel(R *rS, const R *rE
 template <typename R> __global__ void pit_adapt_finish_kernel(R *mu, const R *rE, int n) { *mu = (R)1 / rE[n - 1]; }
 
 constexpr int PIT_GT_THREADS = 1024;
+// model != nullptr (measured coarse model): the gain comes from it, and the components alpha[s] of the defects along the signal direction
+// (pit_bound_kernel) are scanned HERE with exp(-mu T K) - in the eigenbasis of K two real first-order recurrences per mode -
+// q[s] = alpha[s] + C q[s - 1]; uq[col] = (Re q, Im q) is what pit_recur_eig_kernel adds back along u.  Msum: per-segment sums of the step
+// sizes (adaptive step), else mu T.
 template <typename R>
 __global__ void __launch_bounds__(PIT_GT_THREADS) pit_gauge_kernel(const double *gph, int S, int nsel, PitCtrl *c, double *theta, const double *pw, int nb, int method, const Cx<R> *sy0,
-                                                                   int want_corr)
+                                                                   int want_corr, const PitModel *model = nullptr, const float4 *ualpha = nullptr, float2 *uq = nullptr,
+                                                                   const R *mu = nullptr, int64_t T = 0, const float *Msum = nullptr)
 {
     if (c->done) return;
     constexpr int NT = PIT_GT_THREADS;
     __shared__ double redp[NT / 64];
     __shared__ double2 gbuf[NT / 64];
+    __shared__ float4 abuf[NT / 64];
+    if (gridDim.x > 1 && blockIdx.x == 1 && !(model && uq)) return;
+    if (model && uq && (gridDim.x == 1 || blockIdx.x == 1)) {
+        const bool corr = c->passes == 0 ? true : c->corr_on != 0;       // (pass 0: decided below; the model being there, it will be on)
+        const int len = (S + NT - 1) / NT;
+        const int s0 = threadIdx.x * len, s1 = s0 + len < S ? s0 + len : S;
+        const float muT = mu ? (float)((double)*mu * (double)T) : 0.f;
+        auto op = [](float4 e, float4 l) { return float4{l.x * e.x, l.x * e.y + l.y, l.z * e.z, l.z * e.w + l.w}; };     // two affine maps side by side: (A1, B1, A2, B2)
+        for (int j = 0; j < nsel; j++) {
+            const PitModel m = model[j];
+            const bool on = corr && m.ok;
+            auto cf = [&](int s, float &c1, float &c2) {               // coefficients of segment s (takes q[s] to q[s + 1])
+                const float t = Msum ? Msum[(size_t)s * nsel + j] : muT;
+                c1 = on ? __expf(-fmaxf(m.k1, 0.f) * t) : 0.f; c2 = on ? __expf(-fmaxf(m.k2, 0.f) * t) : 0.f;
+            };
+            float4 loc{1.f, 0.f, 1.f, 0.f};
+            for (int s = s0; s < s1; s++) {
+                float b1 = 0.f, b2 = 0.f, c1 = 0.f, c2 = 0.f;
+                if (s > 0) { const float4 al = ualpha[(size_t)(s - 1) * nsel + j]; b1 = m.q11 * al.x + m.q21 * al.y; b2 = m.q12 * al.x + m.q22 * al.y; cf(s - 1, c1, c2); }
+                loc = op(loc, float4{c1, b1, c2, b2});
+            }
+            const float4 pre = block_scan_excl<float4, decltype(op), NT>(loc, op, float4{1.f, 0.f, 1.f, 0.f}, abuf);
+            float r1 = pre.y, r2 = pre.w;
+            for (int s = s0; s < s1; s++) {
+                float b1 = 0.f, b2 = 0.f, c1 = 0.f, c2 = 0.f;
+                if (s > 0) { const float4 al = ualpha[(size_t)(s - 1) * nsel + j]; b1 = m.q11 * al.x + m.q21 * al.y; b2 = m.q12 * al.x + m.q22 * al.y; cf(s - 1, c1, c2); }
+                r1 = c1 * r1 + b1; r2 = c2 * r2 + b2;
+                uq[(size_t)s * nsel + j] = float2{m.q11 * r1 + m.q12 * r2, m.q21 * r1 + m.q22 * r2};
+            }
+        }
+        if (gridDim.x > 1) return;                                   // (block 1 of a two-block launch: the frames are block 0's)
+    }
     if (c->passes == 0) {                                     // first pass of a sweep: mean output power -> gain of the linearised map (the scan below needs it)
         double ps = 0;
         for (int i = threadIdx.x; i < nb; i += NT) ps += pw[i];
@@ -1588,7 +1893,12 @@ __global__ void __launch_bounds__(PIT_GT_THREADS) pit_gauge_kernel(const double 
             double tot = 0;
             for (int w = 0; w < NT / 64; w++) tot += redp[w];
             const double Py = tot / (nb > 0 ? nb : 1);
-            const double g = pit_gain<R>(method, Py, sy0[0]);
+            double g = pit_gain<R>(method, Py, sy0[0]);
+            if (model) {                                          // the measured gain (mean over the modes) instead of the formula
+                double gs = 0; int ng = 0;
+                for (int j = 0; j < nsel; j++) if (model[j].ok) { gs += (double)model[j].g; ng++; }
+                if (ng == nsel && gs > 0) g = gs / ng;
+            }
             c->out_power = Py; c->gain = g;
             c->corr_on = (want_corr && g > 0 && g == g) ? 1 : 0;
         }
@@ -1695,6 +2005,16 @@ __global__ void __launch_bounds__(256) pit_devest_kernel(const Zf *D, const doub
     __syncthreads();
     if (!last) return;
     pit_decide_body<R>(da);
+}
+// last column whose estimated output deviation sum_k lambda_k |D~_k|^2 exceeds thr (way out of a stalled sweep: where does the trouble end?)
+static __global__ void __launch_bounds__(256) pit_front_kernel(const Zf *D, const double *lam, int n, int ncol, double thr, int *front, int *bad)
+{
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncol) return;
+    float acc = 0.f;
+    for (int k = 0; k < n; k++) { const Zf v = D[(size_t)k * ncol + col]; const float l = (float)lam[k]; acc += (l > 0.f ? l : 0.f) * (v.x * v.x + v.y * v.y); }
+    if (!(acc == acc) || acc > 1e30f) { atomicMax(bad, 1); return; }
+    if ((double)acc > thr) atomicMax(front, col);
 }
 // ------------------------------------------------------------------------------------------------ host side
 // kernel time of the most recent call (HIP events around the trainer launches; the host synchronises after each anyway)
@@ -1831,7 +2151,7 @@ int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t T
 template <typename R>
 int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu_dev, void *wx, int ntaps,
                   const int64_t *modes, int nsel, const void *symbols, int64_t nsy, int method, void *err, int zero_err,
-                  const void *gram, const qh_pit_opts *opts, void *report_dev)
+                  const void *gram, const qh_pit_opts *opts, void *report_dev, int depth = 0)
 {
     int rc = ensure_init();
     if (rc) return rc;
@@ -1887,7 +2207,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     const int sym = pit_symmetry(method);
     const bool seed_phase = o.phase_seed < 0 ? sym == 4 : o.phase_seed != 0;
     const bool want_corr = o.correction != 0 && pit_basis_ok(ntot, sizeof(Cx<R>));
-    const double beta = o.corr_beta >= 0 ? o.corr_beta : (sym == 0 ? 1.5 : 0.0);
+    double beta = o.corr_beta >= 0 ? o.corr_beta : (sym == 0 ? 1.5 : 0.0);       // (round-3 model only: the measured model needs no extra damping, see below)
 
     // ---- control block / report
     void *cbuf = nullptr;
@@ -1906,7 +2226,15 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     if (ad_damp < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_DAMP"); ad_damp = e && atof(e) > 0 ? (float)atof(e) : 0.7f; }
     if (ad_relax < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_RELAX"); ad_relax = e && atof(e) > 0 ? (float)atof(e) : 1.0f; }
     const int64_t head_want = head_env > 0 ? head_env : 16384;
-    const int64_t head = adaptive ? ((TrSyms / 4 < head_want ? TrSyms / 4 : head_want) / LA_B * LA_B) : 0;
+    // Fixed step: opts.head_steps > 0 - the first head_steps steps of every sweep in the exact form, the segments cover the rest (what the
+    // automatic way out below uses when the passes stall on a transient at the start of the sweep that no linear model describes)
+    int64_t head = adaptive ? ((TrSyms / 4 < head_want ? TrSyms / 4 : head_want) / LA_B * LA_B) : 0;
+    if (!adaptive && o.head_steps > 0) {
+        QH_REQUIRE(!o.exchange, "train_equaliser: a capture split over processes takes no exact head");
+        head = (int64_t)o.head_steps / LA_B * LA_B;
+        if (head > TrSyms) head = TrSyms / LA_B * LA_B;
+        o.acquire = 0;                                            // the head's end taps seed the segments: nothing to acquire
+    }
     // Segment length of an adaptive sweep: 2048 steps; a BLIND stage gets at most ~512 segments - the transient of its iteration grows
     // with the number of segments (2^22 symbols: 2039 segments of 2048 steps meet tol / 3 only at the 24-pass cap or not at all, 509
     // segments of 8192 steps in 12-14 passes; the decision-directed stage needs 5-7 passes either way and is faster with short segments)
@@ -2017,6 +2345,11 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     R *ad_rS = nullptr, *ad_rE = nullptr;
     Cx<R> *ad_eS = nullptr, *ad_eE = nullptr, *ad_errh = nullptr;
     float *ad_M = nullptr, *ad_chg = nullptr, *ad_rP = nullptr, *ad_dP = nullptr;
+    if (!adaptive && head > 0) {
+        void *ab = nullptr;
+        if ((rc = scratch(13, (size_t)nmodes * head * sizeof(Cx<R>) + 64, &ab))) return rc;
+        ad_errh = (Cx<R> *)ab;
+    }
     if (adaptive) {
         void *ab = nullptr;
         const size_t nS = ((size_t)sg.S + 15) / 16 * 16;
@@ -2078,6 +2411,32 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     if (gemm_env < 0) { const char *e = getenv("QAMPY_HIP_PIT_GEMM"); gemm_env = (e && e[0] == 'v') ? 1 : 0; }
     const int gemm_valu = (gemm_env && pit_gemm_lds(ntot) <= 150 * 1024) ? 1 : 0;     // (the register-blocked VALU form stages the whole basis: up to 96 rows)
     const bool eig = want_corr && sizeof(R) == 4 && !(getenv("QAMPY_HIP_PIT_PROBE") && atoi(getenv("QAMPY_HIP_PIT_PROBE")) != 0);
+    // Measured coarse model (pit_model_kernel): gain and the 2 x 2 block of the signal direction from the capture itself.  opts.correction = 2
+    // keeps round 3's model (one formula gain per error function, diagonal in the eigenbasis, extra damping beta) for comparisons.
+    const bool tables_ok = method == QH_M_CMA || method == QH_M_SGNCMA || method == QH_M_MCMA || method == QH_M_RDE || method == QH_M_MRDE ||
+                           (decision && (use_bi || seg_form));
+    const bool ssb = eig && o.correction != 2 && tables_ok && method != QH_M_CMA2;
+    PitModel *model = nullptr;
+    float4 *ualpha = nullptr;
+    float2 *uqv = nullptr;
+    PitModelArgs<R> ma;
+    if (ssb) {
+        void *mb = nullptr;
+        const size_t pw_ = 2 * PIT_EIGMAX + 8;
+        const size_t b_part = (size_t)PIT_MODB * 4 * nsel * pw_ * sizeof(float), b_u = ((size_t)nsel * ntot * sizeof(Cx<R>) + 63) / 64 * 64;
+        const size_t b_ua = ((size_t)ncol * sizeof(float4) + 63) / 64 * 64, b_uq = ((size_t)ncol * sizeof(float2) + 63) / 64 * 64;
+        if ((rc = scratch(14, b_part + b_u + b_ua + b_uq + 16 * sizeof(PitModel) + 128, &mb))) return rc;
+        ma.part = (float *)mb; ma.u = (Cx<R> *)((char *)mb + b_part);
+        ualpha = (float4 *)((char *)mb + b_part + b_u); uqv = (float2 *)((char *)ualpha + b_ua);
+        model = (PitModel *)((char *)uqv + b_uq); ma.model = model; ma.ticket = (unsigned *)(model + 16);
+        QH_HIP(hipMemsetAsync(ma.ticket, 0, sizeof(unsigned), g_stream));
+        QH_HIP(hipMemsetAsync(ualpha, 0, b_ua + b_uq, g_stream));
+        ma.E = (const Cx<R> *)E; ma.wx = (const Cx<R> *)wx; ma.L = L; ma.TrSyms = TrSyms; ma.nmodes = nmodes; ma.ntaps = ntaps; ma.os = os; ma.nsel = nsel; ma.method = method;
+        if (decision) { ma.symbols = (const Cx<R> *)dd_table; ma.nsy = 2 * dd_npart + 1; ma.sy_pitch = 2 * BI_DD_MAXLEV; ma.tables = 1; }
+        else { ma.symbols = (const Cx<R> *)symbols; ma.nsy = nsy; ma.sy_pitch = nsy; ma.tables = (method == QH_M_RDE || method == QH_M_MRDE) ? 1 : 0; }
+        for (int j = 0; j < 16; j++) ma.modes[j] = j < nsel ? modes[j] : 0;
+        if (o.corr_beta < 0) beta = 0.0;
+    }
     const size_t glds = ((size_t)PIT_EIGMAX * PIT_EIGMAX + (size_t)PIT_EIGMAX * PIT_GT) * sizeof(Zf);
     static bool gemm_attr = false;
     if (want_corr && !gemm_attr) {
@@ -2169,6 +2528,13 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                                sg.S, ad_rS, ad_eS);
             QH_HIP(hipGetLastError());
         }
+        // ================================================================ fixed step: the head of the sweep in the exact form
+        if (!adaptive && head > 0) {
+            if ((rc = train_dev<R>(E, nmodes, L, head, 1, os, mu_dev, wx, ntaps, modes, nsel, 0, symbols, nsy, method, ad_errh, 0, nullptr))) return rc;
+            for (int j = 0; j < nsel; j++)
+                QH_HIP(hipMemcpyAsync((Cx<R> *)err + (size_t)modes[j] * TrSyms * Niter + (size_t)it * TrSyms, ad_errh + (size_t)modes[j] * head, (size_t)head * sizeof(Cx<R>),
+                                      hipMemcpyDeviceToDevice, g_stream));
+        }
         // ================================================================ pass-0 start taps
         hipLaunchKernelGGL(pit_sweep_kernel, dim3(1), dim3(1), 0, g_stream, ctrl);
         const double *rot_use = nullptr;
@@ -2185,6 +2551,11 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         // segment 0 starts from the taps the sweep starts from in the reference (before the acquisition moved them), unrotated
         const Cx<R> *w_exact = o.start == 1 ? nullptr : ((it == 0 && o.acquire) ? (const Cx<R> *)w_start : (const Cx<R> *)wx);
         hipLaunchKernelGGL((pit_seed_kernel<R>), dim3(sg.S), dim3(256), 0, g_stream, (const Cx<R> *)wx, nmodes, ntot, (const int64_t *)modes_dev, nsel, rot_use, X, w_exact);
+        if (ssb) {               // the coarse model of this sweep, measured at its seed taps (two small launches; the passes need it after pass 0)
+            ma.sg = sg; ma.rot = rot_use;
+            hipLaunchKernelGGL((pit_model_kernel<R, 0>), dim3(PIT_MODB), dim3(256), 0, g_stream, ma);
+            hipLaunchKernelGGL((pit_model_kernel<R, 1>), dim3(PIT_MODB), dim3(256), 0, g_stream, ma);
+        }
         QH_HIP(hipGetLastError());
         // ================================================================ relaxation passes
         // HIP events around the trainer launch of a pass (qh_pit_last_timing): an event is ~5.6 us of idle stream, so by default only
@@ -2272,13 +2643,35 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 if (p == 0) forward((const Cx<R> *)X, Xe);           // start taps of the sweep into the eigenbasis (kept up to date from here on)
                 forward((const Cx<R> *)Y, Ye);
                 hipLaunchKernelGGL(pit_bound_kernel, dim3((nbnd + nsel + 3) / 4), dim3(256), 0, g_stream, (const Zf *)Xe, (const Zf *)Ye, (const Zf *)Yprev, lam, ntot, sg.S, nsel, sym,
-                                   (const PitCtrl *)ctrl, dfc, pw, gph);
-                hipLaunchKernelGGL((pit_gauge_kernel<R>), dim3(1), dim3(PIT_GT_THREADS), 0, g_stream, (const double *)gph, sg.S, nsel, ctrl, theta, (const double *)pw,
-                                   nbnd, method, (const Cx<R> *)symbols + (size_t)modes[0] * nsy, 1);
+                                   (const PitCtrl *)ctrl, dfc, pw, gph, ualpha);
+                hipLaunchKernelGGL((pit_gauge_kernel<R>), dim3(ssb ? 2 : 1), dim3(PIT_GT_THREADS), 0, g_stream, (const double *)gph, sg.S, nsel, ctrl, theta, (const double *)pw,
+                                   nbnd, method, (const Cx<R> *)symbols + (size_t)modes[0] * nsy, 1, (const PitModel *)model, (const float4 *)ualpha, uqv,
+                                   (const R *)mu_dev, sg.len, (const float *)ad_M);
                 hipLaunchKernelGGL((pit_recur_eig_kernel<R>), dim3(ntot, nsel), dim3(PIT_RT), 0, g_stream, Xe, (const Zf *)Ye, Dz[1], (const double *)theta, lam, nsel, sg.S, sg.len,
-                                   (const R *)mu_dev, beta, (const PitCtrl *)ctrl, (const float *)ad_M, (adaptive && p >= 1) ? ad_damp : 1.f);
+                                   (const R *)mu_dev, beta, (const PitCtrl *)ctrl, (const float *)ad_M, (adaptive && p >= 1) ? ad_damp : 1.f,
+                                   (const float4 *)ualpha, (const float2 *)uqv);
                 hipLaunchKernelGGL((pit_devest_kernel<R>), dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax, ticket,
                                    decide_args(p, (const float *)devmax, (const float2 *)Ye, (float2 *)Yprev, ntot, ncol, 1));
+                if (const char *dp = getenv("QAMPY_HIP_PIT_DUMP")) {       // DEBUG (temporary): D~ of the pass, the eigenvalues, the model
+                    static int dump_call = 0;
+                    if (p == 0) dump_call++;
+                    QH_HIP(hipStreamSynchronize(g_stream));
+                    std::vector<Zf> hD((size_t)ntot * ncol);
+                    std::vector<double> hl(ntot);
+                    QH_HIP(hipMemcpy(hD.data(), Dz[1], hD.size() * sizeof(Zf), hipMemcpyDeviceToHost));
+                    QH_HIP(hipMemcpy(hl.data(), lam, ntot * sizeof(double), hipMemcpyDeviceToHost));
+                    char fn[512];
+                    snprintf(fn, sizeof(fn), "%s_c%d_p%d.bin", dp, dump_call, p);
+                    if (FILE *f = fopen(fn, "wb")) {
+                        const int32_t hdr[4] = {ntot, ncol, nsel, (int32_t)sg.S};
+                        fwrite(hdr, sizeof(hdr), 1, f); fwrite(hl.data(), sizeof(double), ntot, f); fwrite(hD.data(), sizeof(Zf), hD.size(), f);
+                        QH_HIP(hipMemcpy(hD.data(), Xe, hD.size() * sizeof(Zf), hipMemcpyDeviceToHost)); fwrite(hD.data(), sizeof(Zf), hD.size(), f);     // x~ AFTER the update (next pass's start taps)
+                        QH_HIP(hipMemcpy(hD.data(), Ye, hD.size() * sizeof(Zf), hipMemcpyDeviceToHost)); fwrite(hD.data(), sizeof(Zf), hD.size(), f);
+                        { std::vector<double> ht(2 * (size_t)ncol); QH_HIP(hipMemcpy(ht.data(), theta, ht.size() * sizeof(double), hipMemcpyDeviceToHost)); fwrite(ht.data(), sizeof(double), ht.size(), f); }
+                        if (model) { PitModel hm[16]; QH_HIP(hipMemcpy(hm, model, nsel * sizeof(PitModel), hipMemcpyDeviceToHost)); fwrite(hm, sizeof(PitModel), nsel, f); }
+                        fclose(f);
+                    }
+                }
             } else {
             const size_t dlds = (2 * (size_t)ntot + (size_t)nmodes * os * pit_phase_pitch(ntaps, os, PIT_PROBE)) * sizeof(Cx<R>);
             QH_REQUIRE(dlds <= 60 * 1024, "train_equaliser: boundary probe does not fit the LDS for this filter shape");
@@ -2342,6 +2735,40 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             }
             if (ev.hview[2 * p] != 0.f) { certified = ev.hview[2 * p] == 1.f; break; }
             if (p + 1 < npass && !ahead && (rc = enqueue_pass(p + 1))) return rc;
+        }
+        if (!adaptive && !certified && redo_ok && !split && depth < 3 && o.head_auto_off == 0) {
+            // Stalled on the START of the sweep?  A stage that begins far from its own fixed point - a decision-directed stage whose start
+            // taps were locked to the carrier phase at the END of the capture - goes through a non-linear pull-in that the passes can only
+            // follow at the speed of plain relaxation (measured, 64-QAM mcma -> sbd: the bulk of the sweep converged after two passes, a
+            // front of ~0.1 deviation moved 1.5 segments per pass).  If the estimate of the last pass sits in the first quarter of the
+            // segments only, the call is repeated with that stretch (+ a margin) as an EXACT head: sequential there, parallel after it.
+            double hp = 0;
+            int hfront[2] = {-1, 0};
+            bool finite = false;
+            if (eig) {
+                int *fr = (int *)(ticket + 4);                               // (two ints behind the ticket: scratch slot 2 has the room)
+                QH_HIP(hipMemcpyAsync(&hp, &ctrl->out_power, sizeof(double), hipMemcpyDeviceToHost, g_stream));
+                QH_HIP(hipStreamSynchronize(g_stream));
+                QH_HIP(hipMemcpyAsync(fr, hfront, sizeof(hfront), hipMemcpyHostToDevice, g_stream));
+                hipLaunchKernelGGL(pit_front_kernel, dim3((ncol + 255) / 256), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, tol * tol * (hp > 0 ? hp : 1.0), fr, fr + 1);
+                QH_HIP(hipMemcpyAsync(hfront, fr, sizeof(hfront), hipMemcpyDeviceToHost, g_stream));
+                QH_HIP(hipStreamSynchronize(g_stream));
+                finite = hp > 0 && hfront[1] == 0;
+            }
+            const int front = hfront[0];
+            const int64_t front_seg = front < 0 ? -1 : front / nsel + 1;      // one past the last segment above the tolerance
+            if (eig && finite && front >= 0 && front_seg <= sg.S / 4) {
+                int64_t hs = front_seg + 8 + (front_seg + 1) / 2;                 // margin: the front keeps moving while the head is redone
+                if (hs > sg.S - 4) hs = sg.S - 4;
+                const int64_t new_head = sg.start(hs);
+                if (new_head > head && new_head < TrSyms && new_head <= 0x7fffffff) {
+                    QH_HIP(hipMemcpyAsync(wx, w_call, wbytes, hipMemcpyDeviceToDevice, g_stream));
+                    qh_pit_opts o2 = opts ? *opts : o;
+                    if (!opts) { memset(&o2, 0, sizeof(o2)); o2.phase_seed = -1; o2.corr_beta = -1; }
+                    o2.head_steps = (int32_t)new_head; o2.acquire = 0; o2.segments = 0;
+                    return train_pit_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, symbols, nsy, method, err, 0, gram, &o2, report_dev, depth + 1);
+                }
+            }
         }
         if (!adaptive && !certified && redo_ok) {
             // not certified: the whole call again in the exact form, from the taps it started with (all sweeps: a later sweep starts from

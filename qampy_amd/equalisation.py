@@ -141,6 +141,33 @@ def pilot_equaliser(signal, mu, Ntaps, apply=True, foe_comp=True, wxinit=None, f
     return result[0] if len(result) == 1 else tuple(result)
 
 
+def _pilot_equaliser_frames(signal, mu, layout, frames, seed, apply, foe_comp, verbose, eqkwargs):
+    """The frames ``frames`` of a synced pilot signal, all from the taps ``seed``, trained together; {frame: what pilot_equaliser returns}
+    or None when they cannot be batched (then the caller goes frame by frame)."""
+    lay = _FrameLayout(signal, seed.shape[-1])
+    starts = [lay.starts(f) for f in frames]
+    if any(not lay.holds_whole_frame(st.max()) for st in starts):
+        return None
+    steps = np.atleast_1d(mu)
+    steps = np.repeat(steps, 2) if len(steps) == 1 else steps
+    kw = dict(eqkwargs)
+    res = pilotbased_receiver.equalize_pilot_frames(np.asarray(signal), np.asarray(signal.pilot_seq), starts, os=signal.os, mu=steps, foe_comp=foe_comp,
+                                                    Ntaps=lay.ntaps, wxinit=seed, **kw)
+    if res is None:
+        return None
+    taps, foes = res
+    out = {}
+    for k, f in enumerate(frames):
+        result = [taps[k]]
+        if apply:
+            source = phaserec.comp_freq_offset(signal, foes[k]) if foe_comp else signal
+            result.append(apply_filter(source, taps[k], frames=[f]))
+        if verbose:
+            result += [foes[k], (lay.ntaps, lay.synctaps)]
+        out[f] = tuple(result)
+    return out
+
+
 def pilot_equaliser_nframes(signal, mu, Ntaps, apply=True, foe_comp=True, frames=[0], wxinit=None, verbose=True, **eqkwargs):
     """Pilot-based equalisation frame by frame; the taps of frame 0 initialise the later frames (qampy/equalisation.py:340-397)."""
     layout = _FrameLayout(signal, Ntaps if wxinit is None else wxinit.shape[-1])
@@ -151,12 +178,21 @@ def pilot_equaliser_nframes(signal, mu, Ntaps, apply=True, foe_comp=True, frames
     if not layout.holds_whole_frame(last_shift + int(np.max(frames)) * layout.frame_samples):
         raise ValueError("The last frame must be complete for equalisation")
     seed, per_frame = wxinit, []
-    for f in frames:
-        got = pilot_equaliser(signal, mu, layout.ntaps, apply=apply, foe_comp=foe_comp, wxinit=seed, verbose=verbose, frame=f, **eqkwargs)
-        got = got if isinstance(got, tuple) else (got,)
+    batched = {}
+    for k, f in enumerate(frames):
+        if f in batched:
+            got = batched[f]
+        else:
+            got = pilot_equaliser(signal, mu, layout.ntaps, apply=apply, foe_comp=foe_comp, wxinit=seed, verbose=verbose, frame=f, **eqkwargs)
+            got = got if isinstance(got, tuple) else (got,)
         if f == 0:
             seed = got[0]
         per_frame.append(got)
+        # every frame after this one starts from the same taps (`seed` only changes at frame 0) and the frames do not depend on each
+        # other: train them together - one launch per stage over all (frame, mode) chains (core.pilotbased_receiver.equalize_pilot_frames)
+        rest = [int(g) for g in frames[k + 1:]]
+        if not batched and seed is not None and len(rest) > 1 and 0 not in rest:
+            batched = _pilot_equaliser_frames(signal, mu, layout, rest, seed, apply, foe_comp, verbose, eqkwargs) or {}
     columns = tuple(zip(*per_frame))                   # (taps of every frame, [equalised frames], [offsets, tap counts])
     if not apply:
         return columns

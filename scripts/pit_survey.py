@@ -35,5 +35,5 @@ for lw in (0., 5e3):
             dev.append((float(np.sqrt(np.mean(np.abs(a["eq"][m] - g * b["eq"][m]) ** 2))), float(np.linalg.norm(a["wxy"][m] - g * b["wxy"][m]) / np.linalg.norm(a["wxy"][m]))))
         print("2^%d %5.0f Hz | a: %8.2f ms %s | b: %7.3f ms %s %s | %s" % (
             lg, lw, a["ms"], a["errors"], b["ms"], b["errors"],
-            [(st["segments"], st["passes"], st["converged"], round(st["deviation_rms"][-1], 5) if st["deviation_rms"] else None) for st in b["rep"]],
+            [(st["segments"], st["passes"], "exact_form" if st.get("exact_form") else st["converged"], round(st["deviation_rms"][-1], 5) if st["deviation_rms"] else None) for st in b["rep"]],
             [(round(x, 5), round(y, 5)) for x, y in dev]), flush=True)

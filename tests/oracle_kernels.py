@@ -26,5 +26,12 @@ class OracleJobs:                           # stands in for hip_equalisation.Res
             _, wx, _ = oracle.train_equaliser(E, TrSyms, Niter, os, mu, wx, np.array([m]), adaptive, symbols, method)
         return wx
 
+    def train_bank(self, TrSyms, Niter, os, mu, bank, adaptive, symbols, method):
+        res = np.array(bank, copy=True)
+        for j, (E, m) in enumerate(zip(self.slices, self.job_modes)):
+            _, w, _ = oracle.train_equaliser(E, TrSyms, Niter, os, mu, np.ascontiguousarray(res[j]), np.array([m]), adaptive, symbols, method)
+            res[j] = w
+        return res
+
     def apply(self, os, wx):
         return np.array([oracle.apply_filter_to_signal(E, os, np.ascontiguousarray(wx), np.array([m]))[0] for E, m in zip(self.slices, self.job_modes)])

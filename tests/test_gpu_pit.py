@@ -280,14 +280,16 @@ def test_tier_b_through_the_mirrored_api():
         na = synth.count_symbol_errors(np.asarray(ra)[m], sig.symbols, sig.coded_symbols, trim=2000)[0]
         nb = synth.count_symbol_errors(np.asarray(rb)[m], sig.symbols, sig.coded_symbols, trim=2000)[0]
         assert abs(na - nb) <= 3, (na, nb)
-    # one stage, warm start from given taps: no acquisition; bad option -> ValueError; per-mode adaptive step -> ValueError
+    # one stage, warm start from given taps: no acquisition; bad option -> ValueError
     w2, err = qampy_amd.equalisation.equalise_signal(sig, 2e-4, wxy=wa.copy(), method="mrde", tier="b")
     r = core_eq.last_pit_reports()
     assert len(r) == 1 and r[0]["acquisition"]["steps"] == 0 and r[0]["converged"]
     with pytest.raises(ValueError):
         qampy_amd.equalisation.equalise_signal(sig, 2e-4, Ntaps=41, method="cma", tier="c")
-    with pytest.raises(ValueError):
-        qampy_amd.equalisation.equalise_signal(sig, 2e-4, Ntaps=41, method="cma", tier="b", adaptive_stepsize="per-mode")
+    # one step size per mode: no parallel-in-time solver - tier b takes the exact form and says so, results identical to tier a
+    wpa, epa = qampy_amd.equalisation.equalise_signal(sig, 2e-4, Ntaps=41, method="cma", adaptive_stepsize="per-mode")
+    wpb, epb = qampy_amd.equalisation.equalise_signal(sig, 2e-4, Ntaps=41, method="cma", tier="b", adaptive_stepsize="per-mode")
+    assert core_eq.last_pit_reports()[0]["exact_form"] and np.array_equal(wpa, wpb) and np.array_equal(epa, epb)
 
 
 @pytest.mark.parametrize("os_", [1])

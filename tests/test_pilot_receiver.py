@@ -206,6 +206,49 @@ def test_pilot_frames_on_gpu(golden):
     _run_frames(golden["pilot"], golden["pilot_frames"], 1e-8)
 
 
+def _frames_batched_vs_sequential(dtype, rtol, **capkw):
+    """From its second frame on ``pilot_equaliser_nframes`` trains the pilot-aided sweeps of all remaining frames together (one launch per
+    stage over all (frame, mode) chains; the pre-convergence stages stay a chain through the frames because the reference trains the
+    handed-on taps in place).  Same results as going frame by frame - the taps, the equalised frames, and the state the caller's array
+    of start taps is left in."""
+    from qampy_amd import equalisation, synth
+    from qampy_amd.signals import PilotSignal
+    cap = synth.make_pilot_capture(**capkw)
+
+    def run(batched):
+        sig = PilotSignal(cap["E"].astype(dtype), cap["M"], cap["fb"], cap["fs"], cap["frame_len"], cap["seq_len"], cap["ins_rat"], cap["pilots"],
+                          symbols=cap["payload"], coded_symbols=cap["alphabet"])
+        assert sig.sync2frame()
+        sig.corr_foe()
+        saved = equalisation._pilot_equaliser_frames
+        if not batched:
+            equalisation._pilot_equaliser_frames = lambda *a, **k: None
+        try:
+            nfr = (sig.shape[-1] - int(np.max(sig.shiftfctrs))) // (sig.os * sig.frame_len) - 1
+            assert nfr >= 3
+            taps, out, rest = equalisation.pilot_equaliser_nframes(sig, (1e-3, 1e-3), 25, foe_comp=True, frames=list(range(nfr)), methods=("cma", "sbd_data"), Niter=6)
+        finally:
+            equalisation._pilot_equaliser_frames = saved
+        return np.array(taps), np.asarray(out), np.array(rest[0])
+
+    ta, oa, fa = run(False)
+    tb, ob, fb = run(True)
+    assert ta.shape[0] >= 3
+    np.testing.assert_allclose(tb, ta, rtol=rtol, atol=rtol)
+    np.testing.assert_allclose(ob, oa, rtol=rtol, atol=10 * rtol)
+    np.testing.assert_allclose(fb, fa, rtol=1e-6, atol=1e-12)
+
+
+def test_batched_frames_equal_frame_by_frame_on_oracle_kernels(oracle_kernels):
+    _frames_batched_vs_sequential(np.complex128, 1e-10, M=16, frame_len=2 ** 12, seq_len=2 ** 8, nframes=5, modal_delay=100, frame_offset=999, snr_db=25)
+
+
+@pytest.mark.gpu
+def test_batched_frames_equal_frame_by_frame_on_gpu():
+    _frames_batched_vs_sequential(np.complex128, 1e-9, M=64, frame_len=2 ** 14, seq_len=2 ** 9, nframes=6, modal_delay=300, frame_offset=2345)
+    _frames_batched_vs_sequential(np.complex64, 2e-4, M=64, frame_len=2 ** 14, seq_len=2 ** 9, nframes=6, modal_delay=300, frame_offset=2345)
+
+
 # ------------------------------------------------------------------------------------------------ config 5 shape
 def _config5_chain(cap, dtype):
     from qampy_amd import equalisation, phaserec
