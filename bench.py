@@ -429,12 +429,19 @@ class _OracleKernels:
         self.dsp, self.cfo = phaserecovery._dsp, phaserecovery._dsp.comp_freq_offset
         t_exp = lambda E, fo, os_=1: (E * np.exp(-2j * np.pi * np.arange(1, E.shape[1] + 1, dtype=float) * np.asarray(fo, dtype=float).reshape(-1, 1) / os_)).astype(E.dtype)
         self.dsp.comp_freq_offset = t_exp
+        self.trace = self.dsp.pilot_phase_trace
+
+        def t_trace(E, knots, kph):
+            tr = np.array([np.interp(np.arange(E.shape[1]), knots, p) for p in kph]).astype(E.dtype)
+            return E * np.exp(-1j * tr), tr
+        self.dsp.pilot_phase_trace = t_trace
         return self
 
     def __exit__(self, *exc):
         for n, v in self.saved.items():
             setattr(self.k, n, v)
         self.dsp.comp_freq_offset = self.cfo
+        self.dsp.pilot_phase_trace = self.trace
 
 
 def run_c5(args, cfg):

@@ -198,6 +198,11 @@ int qh_bps_recover_c128_dev(const void *E, int nm, int64_t L, const void *angles
  * fo (nmodes,) in units of the symbol rate, E / out (nmodes, L) host arrays */
 int qh_comp_freq_offset_c64(const void *E, int nmodes, int64_t L, const double *fo, int os, void *out);
 int qh_comp_freq_offset_c128(const void *E, int nmodes, int64_t L, const double *fo, int os, void *out);
+/* Tail of pilot_based_cpe_new (qampy/core/pilotbased_receiver.py:318-327): the averaged pilot phases kph (nmodes, nk) at the symbol
+ * positions knots (nk, increasing) interpolated linearly to every symbol (np.interp) and taken out: out = E exp(-1j trace); trace in the
+ * signal's complex dtype like the reference returns it.  Host arrays. */
+int qh_pilot_phase_trace_c64(const void *E, int nmodes, int64_t L, const int64_t *knots, const double *kph, int nk, void *out, void *trace);
+int qh_pilot_phase_trace_c128(const void *E, int nmodes, int64_t L, const int64_t *knots, const double *kph, int nk, void *out, void *trace);
 
 /* ---- select_angles: out[i] = angles[(p > 1 ? i : 0), idx[i]] ;  idx int64 (L,) ------------------------------- */
 int qh_select_angles_f32(const void *angles, int64_t p, int A, const int64_t *idx, int64_t L, void *out);
@@ -218,6 +223,16 @@ int qh_count_errors_dev(const int32_t *idx_rx, const int32_t *idx_tx, int64_t n,
  * to direct / lookahead / iterative, then decides), 1 direct, 2 look-ahead, 3 block-iterative.  All forms give the
  * reference's results up to the order of floating-point additions; a form that cannot take a call falls through. */
 int qh_set_trainer(int form);
+/* Environment switches the library reads (measurement / test aids: each forces a path the automatic choice would not take at that size,
+ * none selects a different algorithm; every one is exercised through this C ABI by the -m gpu tests named):
+ *   QAMPY_HIP_TRAINER = direct | lookahead | iterative   form of the exact trainer, like qh_set_trainer (tests/test_gpu_parity.py)
+ *   QAMPY_HIP_GRAM_BUDGET_GB = N                          scratch the Gram tables of one call may take, else time chunks (test_gpu_parity.py)
+ *   QAMPY_HIP_PIT_FORM = segment | block                  parallel in time: throughput / latency form of the passes (tests/test_gpu_pit.py)
+ *   QAMPY_HIP_SEG_LANES = 8 | 16                          throughput form: lanes per chain (tests/test_gpu_pit.py)
+ *   QAMPY_HIP_PIT_PROBE = 1                               complex64: the complex128 analysis of a pass (probe of the capture) (tests/test_gpu_pit.py)
+ *   QAMPY_HIP_PIT_TIMING = all | none                     which relaxation passes get HIP events (qh_pit_last_timing; scripts/pit_exp.py)
+ *   QAMPY_HIP_BPS = tile, QAMPY_HIP_BPS_FUSED = 1         phase search: tile kernel for complex64 / search + unwrap + de-rotation in one kernel (test_gpu_parity.py)
+ *   QAMPY_HIP_LA_PROFILE = 1                              developer aid: cycle split of workgroup 0 of the block trainers on stderr */
 
 /* ---- parallel-in-time training ("tier B": opt-in, NOT the reference's order of evaluation) -----------
  * The sweep of TrSyms steps is cut into S contiguous segments that are trained CONCURRENTLY with the exact kernels

@@ -70,6 +70,7 @@ SIGNATURES = {
     "qh_bps_c64": _BPS, "qh_bps_c128": _BPS, "qh_bps_c64_dev": _BPS, "qh_bps_c128_dev": _BPS,
     "qh_bps_recover_c64_dev": _RECOVER, "qh_bps_recover_c128_dev": _RECOVER,
     "qh_comp_freq_offset_c64": [_vp, _i, _i64, _vp, _i, _vp], "qh_comp_freq_offset_c128": [_vp, _i, _i64, _vp, _i, _vp],
+    "qh_pilot_phase_trace_c64": [_vp, _i, _i64, _vp, _vp, _i, _vp, _vp], "qh_pilot_phase_trace_c128": [_vp, _i, _i64, _vp, _vp, _i, _vp, _vp],
     "qh_select_angles_f32": _SELECT, "qh_select_angles_f64": _SELECT,
     "qh_make_decision_c64": _DECIDE, "qh_make_decision_c128": _DECIDE,
     "qh_make_decision_c64_dev": _DECIDE, "qh_make_decision_c128_dev": _DECIDE,

@@ -105,3 +105,21 @@ def comp_freq_offset(E, freq_offset, os=1):
     out = np.empty_like(E)
     _lib.call("qh_comp_freq_offset_c" + ("64" if suf == "32" else "128"), _lib.ptr(E), E.shape[0], E.shape[1], _lib.ptr(fo), int(os), _lib.ptr(out))
     return out
+
+
+def pilot_phase_trace(E, knots, knot_phase):
+    """Linear interpolation of the pilot phases ``knot_phase (nmodes, nk)`` at the symbol positions ``knots`` to every symbol of ``E
+    (nmodes, L)`` (np.interp) and its removal, on the device: ``(E * exp(-1j trace), trace)``, the trace in E's complex dtype as the
+    reference returns it (qampy/core/pilotbased_receiver.py:318-327)."""
+    suf, rt, ct = _lib.suffix(E.dtype)
+    E = np.ascontiguousarray(E)
+    if E.ndim != 2 or not np.iscomplexobj(E):
+        raise TypeError("pilot_phase_trace works on a 2-d complex array")
+    knots = np.ascontiguousarray(knots, dtype=np.int64)
+    kph = np.ascontiguousarray(knot_phase, dtype=np.float64)
+    if kph.shape != (E.shape[0], knots.size) or knots.size < 1:
+        raise ValueError("one phase per mode and knot")
+    out, trace = np.empty_like(E), np.empty_like(E)
+    _lib.call("qh_pilot_phase_trace_c" + ("64" if suf == "32" else "128"), _lib.ptr(E), E.shape[0], E.shape[1], _lib.ptr(knots), _lib.ptr(kph), knots.size,
+              _lib.ptr(out), _lib.ptr(trace))
+    return out, trace

@@ -166,10 +166,11 @@ def pilot_based_cpe_new(signal, pilot_symbs, pilot_idx, frame_len, seq_len=None,
     knots = where[half:where.size - half]
     if knots.size != knot_phase.shape[-1]:
         raise AssertionError("averaged phase and new indices are not the same shape")
-    grid = np.arange(span)
-    trace = np.array([np.interp(grid, knots, p) for p in knot_phase]).astype(sent.dtype)
+    # the phase at every symbol (linear between the knots, constant outside: np.interp) and its removal: one pass over the frame(s) on the device
     keep = nframes * frame_len
-    return (rows[:, :span] * np.exp(-1j * trace))[:, :keep], trace[:, :keep]
+    field = np.ascontiguousarray(rows[:, :span], dtype=sent.dtype)
+    corrected, trace = phaserecovery._dsp.pilot_phase_trace(field, knots, knot_phase)
+    return corrected[:, :keep], trace[:, :keep]
 
 
 def _equalize_pilot_jobs(rx, refs, starts, span, os, foe_comp, mu, M_pilot, Ntaps, Niter, adaptive, methods, wxinit):

@@ -923,6 +923,54 @@ template <typename R> int comp_freq_offset_host(const void *E, int nmodes, int64
     return QH_OK;
 }
 
+// Pilot-aided phase trace (qampy/core/pilotbased_receiver.py:258-327, the tail of pilot_based_cpe_new): the averaged pilot phases
+// knot_phase[k, j] at the symbol positions knots[j] (increasing) are interpolated linearly to every symbol - np.interp: constant before the
+// first and after the last knot - and taken out: out[k, i] = E[k, i] exp(-1j trace[k, i]); trace is returned in the signal's complex dtype
+// (real part; the reference casts it so).  The interpolation is formed in double like numpy's.
+template <typename R>
+__global__ void __launch_bounds__(256) pilot_phase_trace_kernel(const Cx<R> *E, int64_t L, const int64_t *knots, const double *kph, int nk, Cx<R> *out, Cx<R> *trace)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (i >= L) return;
+    const double *p = kph + (size_t)k * nk;
+    double ph;
+    if (i <= knots[0]) ph = p[0];
+    else if (i >= knots[nk - 1]) ph = p[nk - 1];
+    else {
+        int lo = 0, hi = nk - 1;                                   // knots[lo] <= i < knots[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (knots[mid] <= i) lo = mid; else hi = mid; }
+        const double slope = (p[hi] - p[lo]) / (double)(knots[hi] - knots[lo]);
+        ph = slope * (double)(i - knots[lo]) + p[lo];
+    }
+    const R t = (R)ph;                                             // the trace in the signal's precision, as the reference's cast leaves it
+    R sn, cs;
+    if constexpr (sizeof(R) == 4) sincosf(-t, &sn, &cs); else sincos(-t, &sn, &cs);
+    const Cx<R> x = ldg(E + (size_t)k * L + i);
+    stg(out + (size_t)k * L + i, Cx<R>{x.re * cs - x.im * sn, x.re * sn + x.im * cs});
+    stg(trace + (size_t)k * L + i, Cx<R>{t, (R)0});
+}
+template <typename R> int pilot_phase_trace_host(const void *E, int nmodes, int64_t L, const int64_t *knots, const double *kph, int nk, void *out, void *trace)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    QH_REQUIRE(nmodes >= 1 && L >= 0 && nk >= 1, "pilot_phase_trace: bad sizes");
+    if (L == 0) return QH_OK;
+    DevBuf dE, dk, dp, dout, dtr;
+    if ((rc = dE.from_host(E, (size_t)nmodes * L * sizeof(Cx<R>)))) return rc;
+    if ((rc = dk.from_host(knots, (size_t)nk * sizeof(int64_t)))) return rc;
+    if ((rc = dp.from_host(kph, (size_t)nmodes * nk * sizeof(double)))) return rc;
+    if ((rc = dout.alloc((size_t)nmodes * L * sizeof(Cx<R>)))) return rc;
+    if ((rc = dtr.alloc((size_t)nmodes * L * sizeof(Cx<R>)))) return rc;
+    hipLaunchKernelGGL((pilot_phase_trace_kernel<R>), dim3((unsigned)((L + 255) / 256), nmodes), dim3(256), 0, g_stream, (const Cx<R> *)dE.p, L, (const int64_t *)dk.p,
+                       (const double *)dp.p, nk, (Cx<R> *)dout.p, (Cx<R> *)dtr.p);
+    QH_HIP(hipGetLastError());
+    if ((rc = dout.to_host(out, dout.n))) return rc;
+    if ((rc = dtr.to_host(trace, dtr.n))) return rc;
+    QH_HIP(hipStreamSynchronize(g_stream));
+    return QH_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ error counter
 __global__ void __launch_bounds__(256) count_errors_kernel(const int32_t *rx, const int32_t *tx, int64_t n, int64_t lag, int64_t ntx,
                                                            unsigned long long *count)
@@ -967,6 +1015,10 @@ int qh_comp_freq_offset_c64(const void *E, int nmodes, int64_t L, const double *
 { return qh::comp_freq_offset_host<float>(E, nmodes, L, fo, os, out); }
 int qh_comp_freq_offset_c128(const void *E, int nmodes, int64_t L, const double *fo, int os, void *out)
 { return qh::comp_freq_offset_host<double>(E, nmodes, L, fo, os, out); }
+int qh_pilot_phase_trace_c64(const void *E, int nmodes, int64_t L, const int64_t *knots, const double *kph, int nk, void *out, void *trace)
+{ return qh::pilot_phase_trace_host<float>(E, nmodes, L, knots, kph, nk, out, trace); }
+int qh_pilot_phase_trace_c128(const void *E, int nmodes, int64_t L, const int64_t *knots, const double *kph, int nk, void *out, void *trace)
+{ return qh::pilot_phase_trace_host<double>(E, nmodes, L, knots, kph, nk, out, trace); }
 int qh_count_errors_dev(const int32_t *rx, const int32_t *tx, int64_t n, int64_t lag, int64_t ntx, unsigned long long *count_dev)
 {
     int rc = qh::ensure_init();

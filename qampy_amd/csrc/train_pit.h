@@ -13,7 +13,6 @@
 #include <atomic>
 #include <chrono>
 #include <vector>
-#include <cstdio>
 #include "train_impl.h"
 #include "train_seg.h"
 
@@ -1237,106 +1236,13 @@ __global__ void __launch_bounds__(256) pit_model_kernel(PitModelArgs<R> a)
 // (E[(x^T b) conj(x^T a)] = a~^H Lambda b~) - no probe of the capture, no filtering: the 35 us probe kernel of round 2 becomes a 5 us
 // reduction, and the products themselves are blocked for registers (3 rows x 4 columns per thread, 32 columns per block:
 // 5 LDS reads per 12 complex multiply-adds instead of 5 per 6; 42 -> ~15 us at 7936 columns).
-constexpr int PIT_NC = 32;                 // columns per block of the basis products
-constexpr int PIT_BP = PIT_NC + 2;         // pitch (elements) of the staged B tile: rows 16-byte aligned, staging writes spread over the banks
-inline size_t pit_gemm_lds(int n) { return (size_t)n * (PIT_EIGMAX + PIT_BP) * sizeof(Zf); }
-// MODE 0 (forward): Out[m][col] = sum_f conj(V[f][m]) T[col][f], T = the tap sets (column col = (s, j): row modes[j] of set s); A2 = V.
-// MODE 1 (back + apply): X[col][m] = Y[col][m] = theta_col X[col][m] + sum_k V[m][k] D[k][col]; A2 = V^T.
-template <typename R, int MODE>
-__global__ void __launch_bounds__(256) pit_basis_gemm_kernel(const Zf *A2, const Cx<R> *T, const Zf *D, Zf *Out, int n, int ncol, const PitCtrl *c, PitFuse<R> fz)
-{
-    if (c->done) return;
-    extern __shared__ __attribute__((aligned(16))) char pit_smem[];
-    Zf *As = reinterpret_cast<Zf *>(pit_smem);                // [n][PIT_EIGMAX]: contraction index major, output rows contiguous
-    Zf *Bs = As + (size_t)n * PIT_EIGMAX;                     // [n][PIT_BP]
-    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;    // columns 4 tx .., rows ty + 32 u
-    const int col0 = blockIdx.x * PIT_NC;
-    const size_t wset = (size_t)fz.nmodes * n;
-    for (int e = threadIdx.x; e < PIT_EIGMAX * n; e += 256) {
-        const int k = e / PIT_EIGMAX, m = e - k * PIT_EIGMAX;
-        Zf v{0.f, 0.f};
-        if (m < n) { v = A2[(size_t)k * n + m]; if (MODE == 0) v.y = -v.y; }
-        As[e] = v;
-    }
-    if (MODE == 0) {
-        for (int e = threadIdx.x; e < n * PIT_NC; e += 256) {      // consecutive threads: consecutive f of one column (coalesced)
-            const int cc = e / n, f = e - cc * n, col = col0 + cc;
-            Zf v{0.f, 0.f};
-            if (col < ncol) {
-                const int s = col / fz.nsel, j = col - s * fz.nsel;
-                const Cx<R> t = T[(size_t)s * wset + (size_t)fz.modes_dev[j] * n + f];
-                v = Zf{(float)t.re, (float)t.im};
-            }
-            Bs[f * PIT_BP + cc] = v;
-        }
-    } else {
-        for (int e = threadIdx.x; e < n * PIT_NC; e += 256) {
-            const int k = e / PIT_NC, cc = e - k * PIT_NC;
-            Bs[k * PIT_BP + cc] = col0 + cc < ncol ? D[(size_t)k * ncol + col0 + cc] : Zf{0.f, 0.f};
-        }
-    }
-    __syncthreads();
-    constexpr int RU = PIT_EIGMAX / 32, CU = PIT_NC / 8;     // 3 rows x 4 columns per thread
-    Zf acc[RU][CU];
-#pragma unroll
-    for (int u = 0; u < RU; u++)
-#pragma unroll
-        for (int v = 0; v < CU; v++) acc[u][v] = Zf{0.f, 0.f};
-#pragma unroll 2
-    for (int k = 0; k < n; k++) {
-        Zf a[RU], b[CU];
-        const float4 b01 = *reinterpret_cast<const float4 *>(Bs + k * PIT_BP + CU * tx);
-        const float4 b23 = *reinterpret_cast<const float4 *>(Bs + k * PIT_BP + CU * tx + 2);
-        b[0] = Zf{b01.x, b01.y}; b[1] = Zf{b01.z, b01.w}; b[2] = Zf{b23.x, b23.y}; b[3] = Zf{b23.z, b23.w};
-#pragma unroll
-        for (int u = 0; u < RU; u++) a[u] = As[k * PIT_EIGMAX + ty + 32 * u];
-#pragma unroll
-        for (int u = 0; u < RU; u++)
-#pragma unroll
-            for (int v = 0; v < CU; v++) {
-                acc[u][v].x = fmaf(a[u].x, b[v].x, fmaf(-a[u].y, b[v].y, acc[u][v].x));
-                acc[u][v].y = fmaf(a[u].x, b[v].y, fmaf(a[u].y, b[v].x, acc[u][v].y));
-            }
-    }
-    if (MODE == 0) {
-#pragma unroll
-        for (int u = 0; u < RU; u++) {
-            const int m = ty + 32 * u;
-            if (m < n)
-#pragma unroll
-                for (int v = 0; v < CU; v++)
-                    if (col0 + CU * tx + v < ncol) Out[(size_t)m * ncol + col0 + CU * tx + v] = acc[u][v];
-        }
-    } else {                                                  // X[s] = Y[s] = theta_s X[s] + D[.][col]  (Y: the copy the next pass trains in place)
-#pragma unroll
-        for (int v = 0; v < CU; v++) {
-            const int col = col0 + CU * tx + v;
-            if (col >= ncol) continue;
-            const int s = col / fz.nsel, j = col - s * fz.nsel;
-            const size_t base = (size_t)s * wset + (size_t)fz.modes_dev[j] * n;
-            const double qr = fz.theta[2 * (size_t)col], qi = fz.theta[2 * (size_t)col + 1];
-#pragma unroll
-            for (int u = 0; u < RU; u++) {
-                const int m = ty + 32 * u;
-                if (m < n) {
-                    const Cx<R> x = fz.X[base + m];
-                    const Cx<R> w{(R)(qr * x.re - qi * x.im + acc[u][v].x), (R)(qr * x.im + qi * x.re + acc[u][v].y)};
-                    fz.X[base + m] = w;
-                    fz.Y[base + m] = w;
-                }
-            }
-        }
-    }
-}
-
-// The same two products on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: exact single precision at the vector
+// The two basis products on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: exact single precision at the vector
 // rate, MI355X_MICROARCH.md) - the one place on this path where the work IS a dense GEMM: (n x n) x (n x S nsel), n = nmodes ntaps = 82,
 // thousands of columns, and what matters is its LATENCY (it sits between two passes).  A block takes 16 columns, wave w of its
 // ceil(n / 16) waves the output rows 16 w .. 16 w + 15: 224 blocks of 6 waves at C3 - every CU busy, 23 k-steps x 4 MFMAs x 32 cycles
 // = 1.2 us of MFMA issue per wave (the 32x32x2 tiling of the first version: 112 blocks, 4.8 us per wave, 18-22 us per product).
 // Complex product from three real accumulators: rr += Ar Br, ii += Ai Bi, im += Ar Bi + Ai Br (C = rr - ii + i im).  Operand
 // layout: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15]; C/D: column lane & 15, row 4 (lane >> 4) + reg.
-// (The register-blocked VALU form above stays as QAMPY_HIP_PIT_GEMM=valu.)
 typedef float pit_f4 __attribute__((ext_vector_type(4)));
 constexpr int PIT_MC = 16, PIT_MBP = PIT_MC + 1;               // columns per block, row pitch of the B tile in LDS
 inline int pit_mfma_threads(int n) { return 64 * ((n + 15) / 16); }
@@ -2117,25 +2023,20 @@ int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t T
     hipLaunchKernelGGL(pit_cov_reduce_kernel, dim3((unsigned)((msz + 63) / 64)), dim3(256), 0, st, (const Z *)part, (int)msz, PIT_COVB, Rc);
     static bool attr_set = false;
     if (!attr_set) { QH_HIP(hipFuncSetAttribute((const void *)pit_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); attr_set = true; }
-    static int nsweep = 0;
-    if (!nsweep) { const char *e = getenv("QAMPY_HIP_PIT_EIGSWEEPS"); nsweep = e && atoi(e) > 0 ? atoi(e) : PIT_EIGSWEEPS; }
-    // rotations logged by the solver, applied to V row by row afterwards (QAMPY_HIP_PIT_JACOBI=fused: the round-2 single kernel)
-    static int jfused = -1;
-    if (jfused < 0) { const char *e = getenv("QAMPY_HIP_PIT_JACOBI"); jfused = (e && e[0] == 'f') ? 1 : 0; }
+    const int nsweep = PIT_EIGSWEEPS;
+    // rotations logged by the solver, applied to V row by row afterwards; block form while two copies of A fit the LDS (n <= 96), else
+    // the row / column form
     float4 *glog = nullptr;
-    const bool logged = !jfused || ntot > 96;                     // above 96 rows A and V do not fit the LDS together
-    const size_t jlds = (logged ? 1 : 2) * (size_t)ntot * (ntot + 1) * sizeof(Zf) + 256;
-    if (logged) {
+    const bool logged = true;
+    const size_t jlds = (size_t)ntot * (ntot + 1) * sizeof(Zf) + 256;
+    {
         void *gl = nullptr;
         const int mm = (ntot + 1) & ~1;
         if ((rc = scratch(11, (size_t)nsweep * (mm - 1) * (mm / 2) * sizeof(float4) + 64, &gl))) return rc;
         glog = (float4 *)gl;
     }
-    // QAMPY_HIP_PIT_JACOBI = rows: the row / column form for every size (block form: n <= 96, two copies of A in the LDS)
-    static int jrows = -1;
-    if (jrows < 0) { const char *e = getenv("QAMPY_HIP_PIT_JACOBI"); jrows = (e && e[0] == 'r') ? 1 : 0; }
     const size_t blds = 2 * (size_t)ntot * (ntot + 1) * sizeof(Zf) + 256;
-    if (logged && !jrows && blds <= 160 * 1024 - 2048) {          // (the kernel's static LDS: the round's pairs and rotations)
+    if (logged && blds <= 160 * 1024 - 2048) {          // (the kernel's static LDS: the round's pairs and rotations)
         static bool battr = false;
         if (!battr) { QH_HIP(hipFuncSetAttribute((const void *)pit_jacobi_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); battr = true; }
         hipLaunchKernelGGL(pit_jacobi_blk_kernel, dim3(1), dim3(1024), blds, st, (const Z *)Rc, ntot, 1.0 / (double)ncov, (double *)basis, nsweep, glog);
@@ -2218,14 +2119,9 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     // ---- segment grid
     int S = o.segments;
     // adaptive step: the first 16384 steps (while the step is large) in the exact form, then segments of 2048 steps
-    static int64_t head_env = -1, seg_env = -1;                   // (measurements: QAMPY_HIP_PIT_ADAPT_HEAD / _SEG = steps)
-    if (head_env < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_HEAD"); head_env = e && atoll(e) > 0 ? atoll(e) : 0; const char *g = getenv("QAMPY_HIP_PIT_ADAPT_SEG"); seg_env = g && atoll(g) > 0 ? atoll(g) : 0; }
-    static float ad_relax = -1.f, ad_damp = -1.f;
-    static int ad_newton = -1;
-    if (ad_newton < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_NEWTON"); ad_newton = e ? atoi(e) : 1; }
-    if (ad_damp < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_DAMP"); ad_damp = e && atof(e) > 0 ? (float)atof(e) : 0.7f; }
-    if (ad_relax < 0) { const char *e = getenv("QAMPY_HIP_PIT_ADAPT_RELAX"); ad_relax = e && atof(e) > 0 ? (float)atof(e) : 1.0f; }
-    const int64_t head_want = head_env > 0 ? head_env : 16384;
+    const float ad_relax = 1.0f, ad_damp = 0.7f;                  // (measured: profiles/r03_adaptive_tier_b.txt)
+    const int ad_newton = 1;
+    const int64_t head_want = 16384;
     // Fixed step: opts.head_steps > 0 - the first head_steps steps of every sweep in the exact form, the segments cover the rest (what the
     // automatic way out below uses when the passes stall on a transient at the start of the sweep that no linear model describes)
     int64_t head = adaptive ? ((TrSyms / 4 < head_want ? TrSyms / 4 : head_want) / LA_B * LA_B) : 0;
@@ -2243,7 +2139,6 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         const int64_t t = ((TrSyms - head) / 512 + LA_B - 1) / LA_B * LA_B;
         if (t > seg_want) seg_want = t;
     }
-    if (seg_env > 0) seg_want = seg_env;
     if (S == 0 && adaptive) S = (int)((TrSyms - head) / seg_want < PIT_MAXSEG ? (TrSyms - head) / seg_want : PIT_MAXSEG);
     if (S == 0) {
         R mu_h = 0;
@@ -2361,7 +2256,16 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     QH_HIP(hipMemcpyAsync(modes_dev, modes, (size_t)nsel * sizeof(int64_t), hipMemcpyHostToDevice, g_stream));
     R mu_acq_h = 0;                                               // the gear-shifted step size pit_setup_kernel chose (sizes the acquisition run)
     if (o.acquire) QH_HIP(hipMemcpyAsync(&mu_acq_h, mu_acq, sizeof(R), hipMemcpyDeviceToHost, g_stream));
+    R mu_host = 1;
+    QH_HIP(hipMemcpyAsync(&mu_host, mu_dev, sizeof(R), hipMemcpyDeviceToHost, g_stream));
     QH_HIP(hipStreamSynchronize(g_stream));                       // `modes` is the caller's memory
+    if (!adaptive && !(mu_host != 0)) {                           // a sweep that moves nothing (or a NaN step): the exact form, as it is
+        if ((rc = train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, 0, symbols, nsy, method, err, 0, gram))) return rc;
+        const int32_t hdr[3] = {1, 0, 2};
+        QH_HIP(hipMemcpyAsync(&ctrl->segments, hdr, sizeof(hdr), hipMemcpyHostToDevice, g_stream));
+        QH_HIP(hipStreamSynchronize(g_stream));
+        return QH_OK;
+    }
 
     // ---- Gram table: of the whole sweep when the passes run in a block form (acquisition chunks and segments index into
     // it), of the acquisition range only when they run in the throughput form
@@ -2377,7 +2281,9 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             acq_ch = acq_ch < 256 ? 256 : (acq_ch > 4096 ? 4096 : acq_ch);
         }
         acq_ch = (acq_ch + LA_B - 1) / LA_B * LA_B;
-        amax = o.acq_max > 0 ? o.acq_max : 2 * acq_ch;
+        amax = o.acq_max > 0 ? o.acq_max : 2 * acq_ch;            // two chunks.  (One is enough at C3 / C2 - the same 5 passes, 0.11 ms less - but not in general: the
+                                                                  // coarse model is measured at the acquired taps, and after one chunk the gain comes out 10-25 % low on
+                                                                  // 17-tap / 256-QAM / QPSK recipes, which cost them 2-4 passes: profiles/r04_acquisition.txt)
         if (amax > TrSyms / 2 && o.acq_max <= 0) amax = TrSyms / 2;
         if (amax > TrSyms) amax = TrSyms;
     }
@@ -2407,9 +2313,6 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     // complex64: the analysis of a pass runs in the eigenbasis (pit_basis_gemm_kernel / pit_bound_kernel / pit_recur_eig_kernel); complex128
     // keeps the probe-based analysis, whose defect vectors are formed in double precision before they are projected
     // (QAMPY_HIP_PIT_PROBE=1 forces it for complex64 too: tests compare the two)
-    static int gemm_env = -1;
-    if (gemm_env < 0) { const char *e = getenv("QAMPY_HIP_PIT_GEMM"); gemm_env = (e && e[0] == 'v') ? 1 : 0; }
-    const int gemm_valu = (gemm_env && pit_gemm_lds(ntot) <= 150 * 1024) ? 1 : 0;     // (the register-blocked VALU form stages the whole basis: up to 96 rows)
     const bool eig = want_corr && sizeof(R) == 4 && !(getenv("QAMPY_HIP_PIT_PROBE") && atoi(getenv("QAMPY_HIP_PIT_PROBE")) != 0);
     // Measured coarse model (pit_model_kernel): gain and the 2 x 2 block of the signal direction from the capture itself.  opts.correction = 2
     // keeps round 3's model (one formula gain per error function, diagonal in the eigenbasis, extra damping beta) for comparisons.
@@ -2442,8 +2345,6 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     if (want_corr && !gemm_attr) {
         QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        QH_HIP(hipFuncSetAttribute((const void *)pit_basis_gemm_kernel<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        QH_HIP(hipFuncSetAttribute((const void *)pit_basis_gemm_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         QH_HIP(hipFuncSetAttribute((const void *)pit_basis_mfma_kernel<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         QH_HIP(hipFuncSetAttribute((const void *)pit_basis_mfma_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
                 gemm_attr = true;
@@ -2579,11 +2480,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             if (p > 0 && want_corr) {
                 // start taps = theta X + V D~ with D[s+1] = d[s+1] + J D[s] from the analysis that closed pass p - 1 (below); with the
                 // correction switched off on the device (corr_on = 0) the scan ran with coefficient 0, D = d: plain relaxation
-                if (eig && !gemm_valu)
+                if (eig)
                     hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 1>), dim3((ncol + PIT_MC - 1) / PIT_MC), dim3(pit_mfma_threads(ntot)), pit_mfma_lds(ntot), g_stream, Vb + (size_t)ntot * ntot,
-                                       (const Cx<R> *)nullptr, (const Zf *)Dz[1], (Zf *)nullptr, ntot, ncol, (const PitCtrl *)ctrl, fz);
-                else if (eig)
-                    hipLaunchKernelGGL((pit_basis_gemm_kernel<R, 1>), dim3((ncol + PIT_NC - 1) / PIT_NC), dim3(256), pit_gemm_lds(ntot), g_stream, Vb + (size_t)ntot * ntot,
                                        (const Cx<R> *)nullptr, (const Zf *)Dz[1], (Zf *)nullptr, ntot, ncol, (const PitCtrl *)ctrl, fz);
                 else
                     hipLaunchKernelGGL((pit_cgemm_kernel<R, false>), dim3((ncol + PIT_GT - 1) / PIT_GT), dim3(256), glds, g_stream, Vb + (size_t)ntot * ntot, (const Zf *)Dz[1], (Zf *)nullptr, ntot, ncol, (const PitCtrl *)ctrl, fz);
@@ -2635,10 +2533,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                     QH_HIP(hipStreamWaitEvent(g_stream, pit_basis_sync().out, 0));
                     pit_basis_sync().pending = false;
                 }
-                const dim3 ggrid((ncol + PIT_NC - 1) / PIT_NC);
                 auto forward = [&](const Cx<R> *src, Zf *dst) {      // dst = V^H src
-                    if (gemm_valu) hipLaunchKernelGGL((pit_basis_gemm_kernel<R, 0>), ggrid, dim3(256), pit_gemm_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
-                    else hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 0>), dim3((ncol + PIT_MC - 1) / PIT_MC), dim3(pit_mfma_threads(ntot)), pit_mfma_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
+                    hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 0>), dim3((ncol + PIT_MC - 1) / PIT_MC), dim3(pit_mfma_threads(ntot)), pit_mfma_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
                 };
                 if (p == 0) forward((const Cx<R> *)X, Xe);           // start taps of the sweep into the eigenbasis (kept up to date from here on)
                 forward((const Cx<R> *)Y, Ye);
@@ -2652,26 +2548,6 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                                    (const float4 *)ualpha, (const float2 *)uqv);
                 hipLaunchKernelGGL((pit_devest_kernel<R>), dim3(ndev), dim3(256), 0, g_stream, (const Zf *)Dz[1], lam, ntot, ncol, (const PitCtrl *)ctrl, devmax, ticket,
                                    decide_args(p, (const float *)devmax, (const float2 *)Ye, (float2 *)Yprev, ntot, ncol, 1));
-                if (const char *dp = getenv("QAMPY_HIP_PIT_DUMP")) {       // DEBUG (temporary): D~ of the pass, the eigenvalues, the model
-                    static int dump_call = 0;
-                    if (p == 0) dump_call++;
-                    QH_HIP(hipStreamSynchronize(g_stream));
-                    std::vector<Zf> hD((size_t)ntot * ncol);
-                    std::vector<double> hl(ntot);
-                    QH_HIP(hipMemcpy(hD.data(), Dz[1], hD.size() * sizeof(Zf), hipMemcpyDeviceToHost));
-                    QH_HIP(hipMemcpy(hl.data(), lam, ntot * sizeof(double), hipMemcpyDeviceToHost));
-                    char fn[512];
-                    snprintf(fn, sizeof(fn), "%s_c%d_p%d.bin", dp, dump_call, p);
-                    if (FILE *f = fopen(fn, "wb")) {
-                        const int32_t hdr[4] = {ntot, ncol, nsel, (int32_t)sg.S};
-                        fwrite(hdr, sizeof(hdr), 1, f); fwrite(hl.data(), sizeof(double), ntot, f); fwrite(hD.data(), sizeof(Zf), hD.size(), f);
-                        QH_HIP(hipMemcpy(hD.data(), Xe, hD.size() * sizeof(Zf), hipMemcpyDeviceToHost)); fwrite(hD.data(), sizeof(Zf), hD.size(), f);     // x~ AFTER the update (next pass's start taps)
-                        QH_HIP(hipMemcpy(hD.data(), Ye, hD.size() * sizeof(Zf), hipMemcpyDeviceToHost)); fwrite(hD.data(), sizeof(Zf), hD.size(), f);
-                        { std::vector<double> ht(2 * (size_t)ncol); QH_HIP(hipMemcpy(ht.data(), theta, ht.size() * sizeof(double), hipMemcpyDeviceToHost)); fwrite(ht.data(), sizeof(double), ht.size(), f); }
-                        if (model) { PitModel hm[16]; QH_HIP(hipMemcpy(hm, model, nsel * sizeof(PitModel), hipMemcpyDeviceToHost)); fwrite(hm, sizeof(PitModel), nsel, f); }
-                        fclose(f);
-                    }
-                }
             } else {
             const size_t dlds = (2 * (size_t)ntot + (size_t)nmodes * os * pit_phase_pitch(ntaps, os, PIT_PROBE)) * sizeof(Cx<R>);
             QH_REQUIRE(dlds <= 60 * 1024, "train_equaliser: boundary probe does not fit the LDS for this filter shape");

@@ -247,6 +247,10 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     // selects per step - the groups are unrolled, so "is this my step" is a loop-invariant lane mask in a scalar register pair, not a
     // compare per step) and stores it when the group is complete: one coalesced store per chain and group.
     R ebr = 0, ebi = 0;
+    // fixed step: the step-size-scaled error mu e is what the update needs; the trace is taken from it (x 1 / mu when a group of LPC errors is
+    // stored) instead of evaluating the error function a second time without the factor (2-3 instructions per step; the host sends
+    // sweeps with mu = 0 to the exact path)
+    const R inv_mu = ADAPT ? (R)1 : (R)1 / K.mu;
     // padding taps: the last lane of an input mode may hold up to SG_MAXRAG of them, in its last slots.  They start as zeros and
     // stay zeros because that lane's update of those slots is multiplied by 0 (tailmask; 1 in every other lane).
     const bool lastlane = has && (l16 - kin * a.lpm) == a.lpm - 1;
@@ -281,9 +285,10 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         R yr = p.x - r.y, yi = p.y + r.x;
         chain_csum<LPC>(yr, yi);
         const Cx<R> y{yr, yi};
-        const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K);
+        Cx<R> e{0, 0};
         Cx<R> cc;
         if constexpr (ADAPT) {
+            e = la_errfn<R, METHOD, NPART, false>(y, K);
             const bool live = !decltype(CHK)::value || gstep < my_steps;
             R m;
             if constexpr (sizeof(R) == 4) m = __builtin_amdgcn_rcpf(ad_r); else m = (R)1 / ad_r;
@@ -297,6 +302,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
             }
         } else {
             cc = la_errfn<R, METHOD, NPART, true>(y, K);       // mu * e with mu folded in
+            e = cc;                                            // (the trace: x inv_mu at the store)
         }
         if (decltype(CHK)::value && gstep >= my_steps) cc = Cx<R>{0, 0};   // past the end of this chain's segment: nothing moves
         // w += c conj(x):  (re, im) += x.re (c.re, c.im) + x.im (c.im, -c.re)
@@ -331,7 +337,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
                     keep(step(SgInt<2>{}, xb, ibase + i + u + 3, CHK, RG), u + 3);
                 }
                 const int gi = ibase + i + l16;
-                if (gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
+                if (gi < my_steps) stg(errow + gi, Cx<R>{ebr * inv_mu, ebi * inv_mu});
             }
         }
         // (other sampling rates, and the ragged end of the last chunk, take the plain loop below)
@@ -344,7 +350,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
                 keep(step(SgInt<0>{}, xa, ibase + i0 + u, CHK, RG), u);
             }
             const int gi = ibase + i0 + l16;
-            if (l16 < ng && gi < my_steps) stg(errow + gi, Cx<R>{ebr, ebi});
+            if (l16 < ng && gi < my_steps) stg(errow + gi, Cx<R>{ebr * inv_mu, ebi * inv_mu});
         }
     };
 

@@ -1,13 +1,16 @@
 #!/bin/bash
-# copy the round's evidence set from gpurun_out/r03 (scripts/gpu_round3.sh) into profiles/
+# copy the round's evidence set from gpurun_out/r04 (scripts/gpu_round4.sh) into profiles/
 set -e
-R=gpurun_out/r03
+R=gpurun_out/r04
 cp $R/pmc_traffic_c3.json profiles/pmc_traffic_c3.json
 cp $R/pmc_instr_c3.json profiles/pmc_instr_c3.json
-cp $R/c3_kernel_stats.txt profiles/r03_c3_kernel_stats.txt
-cp $R/c3_timeline.txt profiles/r03_c3_timeline.txt
-cp $R/pmc_summary.txt profiles/r03_pmc_counters_c3.txt
-cp $R/pmc_valu_summary.txt profiles/r03_pmc_instr_c3.txt
-grep "^{" $R/bench_c3.json | tail -1 > profiles/r03_bench_c3.json
-grep "^{" $R/bench_c5.json | tail -1 > profiles/r03_bench_c5.json
-python scripts/show_bench.py profiles/r03_bench_c3.json
+cp $R/c3_kernel_stats.txt profiles/r04_c3_kernel_stats.txt
+cp $R/c3_rocprofv3_kernel_stats.csv profiles/r04_c3_rocprofv3_kernel_stats.csv 2>/dev/null || true
+cp $R/c3_timeline.txt profiles/r04_c3_timeline.txt
+cp $R/pmc_summary.txt profiles/r04_pmc_counters_c3.txt
+cp $R/pmc_valu_summary.txt profiles/r04_pmc_instr_c3.txt
+cp $R/pit_methods.txt profiles/r04_pit_methods.txt
+cp $R/pit_survey_steps.txt profiles/r04_pit_survey_steps.txt
+grep "^{" $R/bench_c3.json | tail -1 > profiles/r04_bench_c3.json
+grep "^{" $R/bench_c5.json | tail -1 > profiles/r04_bench_c5.json
+python scripts/show_bench.py profiles/r04_bench_c3.json

@@ -438,3 +438,49 @@ def test_adaptive_step_recipe_through_tier_b(log2n):
         wo = np.asarray(wo)
         assert np.linalg.norm(wo - w1) / np.linalg.norm(wo) < 5e-2
         assert abs(np.mean(np.abs(eo[:, -4096:]) ** 2) / np.mean(np.abs(err1[:, -4096:]) ** 2) - 1) < 5e-2
+
+
+@pytest.mark.parametrize("M,ntaps,mu,snr", [(64, 41, (3e-4, 1e-4), 28), (16, 21, (1e-3, 2e-4), 22)])
+def test_default_recipe_mcma_sbd_certifies(M, ntaps, mu, snr):
+    """The API's own default pair (qampy/equalisation.py:194-195: methods=("mcma", "sbd")) through tier b at 2^20 symbols, 16- and 64-QAM: both
+    stages certified by the device WITHOUT the exact-form way out, and the result holds against the exact path (equaliser output <= tol,
+    taps <= 3 tol, symbol errors +-3) and - decisions - against the CPU oracle.  The sbd stage starts from taps that are locked to the
+    carrier phase at the END of the capture and pulls in over its first segments: a non-linear transient that the passes can only follow
+    one segment at a time; the solver notices that its estimate sits in the head of the sweep only and repeats the stage with that
+    stretch as an exact head (qh_pit_opts.head_steps / head_auto_off) - sequential there, parallel in time after it."""
+    nsym = 2 ** 20
+    d = synth.make_capture_dev(M, nsym, nmodes=2, snr_db=snr, theta=np.pi / 5.6, dgd=30e-12, linewidth=100., seed=1000)
+    kw = dict(methods=("mcma", "sbd"), Niter=(1, 1), Mtestangles=64 if M == 64 else 32, Nbps=20, alphabet=d["alphabet_host"])
+    res = {}
+    from qampy_amd.core import ber_functions as ber
+    for tier in ("a", "b"):
+        rx = ResidentReceiver(2, 2 * nsym, 2, M, ntaps, mu, tier=tier, **kw)
+        rx.E.copy_from(d["E"])
+        rx.run()
+        res[tier] = rx.fetch()
+        res[tier]["rep"] = rx.pit_reports()
+        res[tier]["ser"] = [r["errors"] for r in ber.cal_ser_dev(rx.out, d["idx_tx"], rx.alphabet, 256, 8192, 2000)]
+        del rx
+    reps = res["b"]["rep"]
+    assert all(r["converged"] and not r["exact_form"] for r in reps), reps
+    assert all(r["deviation_rms"][-1] < r["tol"] for r in reps), reps
+    for m in range(2):
+        g = 1j ** int(np.rint(np.angle(np.vdot(res["b"]["wxy"][m].ravel(), res["a"]["wxy"][m].ravel())) / (np.pi / 2)))
+        assert g == 1
+        assert np.sqrt(np.mean(np.abs(res["a"]["eq"][m] - res["b"]["eq"][m]) ** 2) / np.mean(np.abs(res["a"]["eq"][m]) ** 2)) < 1e-3
+        assert np.linalg.norm(res["a"]["wxy"][m] - res["b"]["wxy"][m]) / np.linalg.norm(res["a"]["wxy"][m]) < 3e-3
+        for s_ in range(2):
+            assert np.sqrt(np.mean(np.abs(res["a"]["err"][s_][m] - res["b"]["err"][s_][m]) ** 2)) < 3e-3
+        assert abs(res["a"]["ser"][m] - res["b"]["ser"][m]) <= 3, (res["a"]["ser"], res["b"]["ser"])
+
+
+def test_exact_head_option():
+    """qh_pit_opts.head_steps: the first head_steps steps of the sweep in the exact form (bit for bit the exact trainer's error trace there),
+    the segments after it; the result is the sequential recurrence's within the tolerance like any tier-b call."""
+    sig, E, tr, w0, sy, rt = _setup("mrde", 64, nsym=2 ** 17, ntaps=21)
+    (wa, ea, _), (wb, eb, _), rep = _exact_and_tier_b(E, tr, 1, 5e-4, w0, sy, "mrde", False, dict(acquire=0, head_steps=8192, head_auto_off=1), rt)
+    assert rep["converged"] and not rep["exact_form"] and rep["segments"] >= 8, rep
+    assert np.array_equal(ea[:, :8192], eb[:, :8192])
+    for m in range(2):
+        assert np.linalg.norm(wa[m] - wb[m]) / np.linalg.norm(wa[m]) < 3e-3
+        assert np.sqrt(np.mean(np.abs(ea[m] - eb[m]) ** 2)) < 3e-3

@@ -29,6 +29,12 @@ def _numpy_cfo(E, fo, os=1):
     return (E * np.exp(-2j * np.pi * t * np.asarray(fo, dtype=float).reshape(-1, 1) / os)).astype(E.dtype)
 
 
+def _numpy_trace(E, knots, kph):
+    """What hip_dsp.pilot_phase_trace computes on the device: the reference's own lines (qampy/core/pilotbased_receiver.py:318-327)."""
+    trace = np.array([np.interp(np.arange(E.shape[1]), knots, p) for p in kph]).astype(E.dtype)
+    return E * np.exp(-1j * trace), trace
+
+
 def _oracle_search(E, starts, win_len, *a):
     err, wx, _ = _oracle_windows(E, starts, win_len, *a)
     var = np.var(err, axis=-1).T                       # (nmodes, nwin)
@@ -58,6 +64,7 @@ def oracle_kernels(monkeypatch):
     monkeypatch.setattr(k, "train_equaliser_windows", _oracle_windows)
     monkeypatch.setattr(k, "train_equaliser_windows_search", _oracle_search)
     monkeypatch.setattr(phaserecovery._dsp, "comp_freq_offset", _numpy_cfo)
+    monkeypatch.setattr(phaserecovery._dsp, "pilot_phase_trace", _numpy_trace)
 
 
 def test_helpers_match_reference(golden, oracle_kernels):
@@ -289,6 +296,7 @@ def test_config5_256qam_against_oracle_kernel_chain(monkeypatch):
     monkeypatch.setattr(k, "apply_filter_to_signal", oracle.apply_filter_to_signal)
     monkeypatch.setattr(k, "train_equaliser_windows_search", _oracle_search)
     monkeypatch.setattr(phaserecovery._dsp, "comp_freq_offset", _numpy_cfo)
+    monkeypatch.setattr(phaserecovery._dsp, "pilot_phase_trace", _numpy_trace)
     cpu = _config5_chain(cap, np.complex128)
     assert hip["ok"] and cpu["ok"] and np.array_equal(hip["shifts"], cpu["shifts"])
     np.testing.assert_allclose(hip["taps"], cpu["taps"], rtol=1e-8, atol=1e-8)
