@@ -2509,10 +2509,14 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 LaArgs<R> ls = la;
                 ls.TrSyms = sg.len; ls.nch = sg.S; ls.wx = Y; ls.err_off = (int64_t)it * TrSyms; ls.seg = 1; ls.seg_extra = sg.extra; ls.seg_tail = sg.tail;
                 ls.skip = &ctrl->done;
+                if (sg.begin > 0) {                                  // an exact head: the segments cover the steps from sg.begin on
+                    ls.E = (const Cx<R> *)E + sg.begin * os; ls.L = L - sg.begin * os; ls.err_off += sg.begin;
+                    ls.G = (const GramPair<R> *)G + sg.begin * g_per_step;
+                }
                 { int r = use_bi ? launch_bi<R>(ls) : launch_la<R>(ls); if (r) return r; }
             } else {
                 TrainArgs<R> ts = ta;
-                ts.wx = Y; ts.nseg = sg.S; ts.seg_begin = 0; ts.seg_len = sg.len; ts.seg_extra = sg.extra; ts.seg_tail = sg.tail; ts.seg_iter = it; ts.skip = &ctrl->done;
+                ts.wx = Y; ts.nseg = sg.S; ts.seg_begin = sg.begin; ts.seg_len = sg.len; ts.seg_extra = sg.extra; ts.seg_tail = sg.tail; ts.seg_iter = it; ts.skip = &ctrl->done;
                 { int r = launch_any<R>(ts); if (r) return r; }
             }
             if (timed(p)) QH_HIP(hipEventRecord(ev.t1[p], g_stream));
