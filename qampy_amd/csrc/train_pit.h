@@ -403,6 +403,13 @@ template <typename R> struct PitDecideArgs {
     const double *theta;
     const int64_t *modes_dev;
     int ntot_w, S, sym, corr_wanted;
+    // Final extrapolation (eigen-space analysis, from the second pass on): the result is the last segment's end taps PLUS the linearised
+    // effect of the correction its start taps would get next, J D[S-1] - what the next pass would give to first order.  It matters for the
+    // weakly excited directions (J ~ 1, model exact): their deviation - the bulk of the TAP deviation, invisible in the output - goes
+    // away without another pass; the tap part of the stop rule is discounted by the contraction the last pass showed.
+    const float2 *Dfin;              // D~ (ntot x ncol, after the scan) or nullptr
+    const float2 *Vfin;              // V[i][k]
+    const double *lam_fin;
     int stall_from;                  // first pass at which "nothing gained over two passes" ends the sweep (2; damped adaptive sweeps: 5)
     const float *extra;              // one more figure the criterion must cover (adaptive step: largest relative change of a segment's start step size), or nullptr
 };
@@ -422,6 +429,8 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
     if (Yprev)                                                // eigen-space copy of this pass's result, for the next pass's "how far did the result move"
         for (int e = threadIdx.x; e < ne * nrow; e += 256) { const int k = e / nrow, j = e - k * nrow; Yprev[e] = Ye[(size_t)k * ncol_e + (ncol_e - nrow) + j]; }
     __shared__ double red[4], redd[4], reds[4], redt[4], redw[4], redm[4];
+    __shared__ int s_flag[2];
+    __shared__ float s_crit;
     double m = 0, dv = 0, ds = 0, dt = 0, wn = 0, dm = 0;
     for (int i0 = threadIdx.x; i0 < nb; i0 += 8 * 256) {       // eight loads in flight per thread (one by one they were most of this function's time)
         double v[8];
@@ -447,17 +456,16 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
     // product of the boundary rotations of this pass, takes them into the frame of segment 0 - the caller's start taps, i.e. the
     // frame of the sequential recurrence.  (A few 1e-3 rad over thousands of boundaries; the quarter-turn functions lock the phase
     // themselves.)  Everything this needs is there before the function starts: issued with the loads above, not after the reduction.
+    const bool extrap = a.Dfin != nullptr && p >= 1 && corr_on0 && c_gain > 0;
     for (int e = threadIdx.x; e < n; e += 256) {
         Cx<R> v = Ylast[e];
         wn += (double)v.re * v.re + (double)v.im * v.im;
-        if (sym == 0 && theta) {
-            const int row = e / ntot_w;
-            for (int j = 0; j < nrow; j++)
-                if ((int)modes_dev[j] == row) {
-                    const double tr = theta[2 * ((size_t)(S - 1) * nrow + j)], ti = theta[2 * ((size_t)(S - 1) * nrow + j) + 1];
-                    v = Cx<R>{(R)(tr * v.re - ti * v.im), (R)(tr * v.im + ti * v.re)};
-                    break;
-                }
+        const int row = e / ntot_w;
+        int jj = -1;
+        for (int j = 0; j < nrow; j++) if ((int)modes_dev[j] == row) { jj = j; break; }
+        if (jj >= 0 && theta) {
+            const double tr = theta[2 * ((size_t)(S - 1) * nrow + jj)], ti = theta[2 * ((size_t)(S - 1) * nrow + jj) + 1];
+            if (sym == 0) v = Cx<R>{(R)(tr * v.re - ti * v.im), (R)(tr * v.im + ti * v.re)};       // into the frame of segment 0
         }
         wx[e] = v;
     }
@@ -497,8 +505,12 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
         if (have_dev) {
             crit = safety * dev_rms;
             if (safety * dev / PIT_DEV_WORST > crit) crit = safety * dev / PIT_DEV_WORST;
-            if (dev_tap >= 0 && safety * dev_tap / PIT_DEV_TAPS > crit) crit = safety * dev_tap / PIT_DEV_TAPS;
-            if (dev_tap_worst >= 0 && safety * dev_tap_worst / PIT_DEV_TAPS_WORST > crit) crit = safety * dev_tap_worst / PIT_DEV_TAPS_WORST;    // (the final taps sit at the worst segment's value)
+            // with the final extrapolation the taps are ahead of this pass by what one more would gain: the contraction the estimate just
+            // showed (never taken better than 0.25)
+            double rho = 1.0;
+            if (extrap && drms1 > 0) { rho = dev_rms / drms1; rho = rho < 0.25 ? 0.25 : (rho > 1.0 ? 1.0 : rho); }
+            if (dev_tap >= 0 && safety * rho * dev_tap / PIT_DEV_TAPS > crit) crit = safety * rho * dev_tap / PIT_DEV_TAPS;
+            if (dev_tap_worst >= 0 && safety * rho * dev_tap_worst / PIT_DEV_TAPS_WORST > crit) crit = safety * rho * dev_tap_worst / PIT_DEV_TAPS_WORST;    // (the final taps sit at the worst segment's value)
         }
         else {
             double amp = 1.0;
@@ -527,11 +539,38 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
             if (!(now < prev2)) done = 1;
         }
         if (done) c->done = 1;
+        s_flag[0] = done; s_flag[1] = conv; s_crit = (float)crit;
+    }
+    __syncthreads();
+    if (s_flag[1] && extrap) {                                    // the certified last pass: its result + J D[S-1] (see PitDecideArgs::Dfin)
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const int row = e / ntot_w;
+            int jj = -1;
+            for (int j = 0; j < nrow; j++) if ((int)modes_dev[j] == row) { jj = j; break; }
+            if (jj < 0) continue;
+            const double tr = theta[2 * ((size_t)(S - 1) * nrow + jj)], ti = theta[2 * ((size_t)(S - 1) * nrow + jj) + 1];
+            const int f = e - row * ntot_w;
+            const size_t col = (size_t)(S - 1) * nrow + jj;
+            float dr = 0.f, di = 0.f;                             // delta = V (c o D~[S-1]) in the frame of segment 0
+            for (int k = 0; k < ntot_w; k++) {
+                const double ak = c_mu * c_gain * c_seg_len * a.lam_fin[k];
+                const float ck = ak > 0 ? __expf(-(float)ak) : 1.f;
+                const float2 dk = a.Dfin[(size_t)k * ncol_e + col], vk = a.Vfin[(size_t)f * ntot_w + k];
+                dr += ck * (vk.x * dk.x - vk.y * dk.y); di += ck * (vk.x * dk.y + vk.y * dk.x);
+            }
+            const Cx<R> v = wx[e];
+            if (sym == 0) wx[e] = Cx<R>{(R)(v.re + dr), (R)(v.im + di)};                                                   // (already in the frame of segment 0)
+            else wx[e] = Cx<R>{(R)(v.re + tr * dr + ti * di), (R)(v.im + tr * di - ti * dr)};                                 // own frame: conj(theta) delta
+        }
+        __threadfence();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         // what the host reads after the pass: criterion (to decide whether the pass after the next one is worth enqueueing early), then
         // the flag it polls for (host_view is pinned, coherent host memory: no copy kernel, no event in between)
-        host_view[1] = (float)crit;
+        host_view[1] = s_crit;
         __threadfence_system();
-        __hip_atomic_store(&host_view[0], done ? (conv ? 1.f : 2.f) : 0.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (2: stopped, NOT certified)
+        __hip_atomic_store(&host_view[0], s_flag[0] ? (s_flag[1] ? 1.f : 2.f) : 0.f, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // (2: stopped, NOT certified)
     }
 }
 
@@ -2468,6 +2507,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             d.host_view = &ev.hview[2 * p]; d.nrow = nsel; d.devmax = dm; d.ndev = ndev; d.safety = safety; d.Ye = ye; d.Yprev = yprev; d.ne = ne; d.ncol_e = ncol_e;
             d.theta = theta; d.modes_dev = (const int64_t *)modes_dev; d.ntot_w = ntot; d.S = (int)sg.S; d.sym = sym; d.corr_wanted = corr_wanted;
             d.extra = adaptive ? (const float *)ad_chg : nullptr;
+            d.Dfin = (ye && !adaptive && !split) ? (const float2 *)Dz[1] : nullptr; d.Vfin = (const float2 *)Vb; d.lam_fin = lam;
             d.stall_from = adaptive ? 5 : 2;
             return d;
         };
