@@ -2317,7 +2317,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         else {
             const double m = (double)mu_acq_h > 1e-12 ? (double)mu_acq_h : 1e-12;
             acq_ch = (int64_t)(2.0 / m + 0.5);
-            acq_ch = acq_ch < 256 ? 256 : (acq_ch > 4096 ? 4096 : acq_ch);
+            acq_ch = acq_ch < 256 ? 256 : (acq_ch > 1024 ? 1024 : acq_ch);    // (round 4: chunks of at most 1024 steps - with the measured model 2 x 1024 do what 2 x 2112 did
+                                                                              // on every recipe of profiles/r04_pit_methods.txt, r04_acquisition.txt)
         }
         acq_ch = (acq_ch + LA_B - 1) / LA_B * LA_B;
         amax = o.acq_max > 0 ? o.acq_max : 2 * acq_ch;            // two chunks.  (One is enough at C3 / C2 - the same 5 passes, 0.11 ms less - but not in general: the
@@ -2362,6 +2363,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     float4 *ualpha = nullptr;
     float2 *uqv = nullptr;
     PitModelArgs<R> ma;
+    hipEvent_t model_event = nullptr;                             // recorded behind the model kernels of the current sweep
     if (ssb) {
         void *mb = nullptr;
         const size_t pw_ = 2 * PIT_EIGMAX + 8;
@@ -2491,10 +2493,19 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         // segment 0 starts from the taps the sweep starts from in the reference (before the acquisition moved them), unrotated
         const Cx<R> *w_exact = o.start == 1 ? nullptr : ((it == 0 && o.acquire) ? (const Cx<R> *)w_start : (const Cx<R> *)wx);
         hipLaunchKernelGGL((pit_seed_kernel<R>), dim3(sg.S), dim3(256), 0, g_stream, (const Cx<R> *)wx, nmodes, ntot, (const int64_t *)modes_dev, nsel, rot_use, X, w_exact);
-        if (ssb) {               // the coarse model of this sweep, measured at its seed taps (two small launches; the passes need it after pass 0)
+        if (ssb) {
+            // the coarse model of this sweep, measured at its seed taps: two small launches on the library's OTHER stream, beside pass 0 (which
+            // does not need it; its analysis waits for it).  On a cold sweep they queue behind the basis build there and are still done first.
             ma.sg = sg; ma.rot = rot_use;
-            hipLaunchKernelGGL((pit_model_kernel<R, 0>), dim3(PIT_MODB), dim3(256), 0, g_stream, ma);
-            hipLaunchKernelGGL((pit_model_kernel<R, 1>), dim3(PIT_MODB), dim3(256), 0, g_stream, ma);
+            static hipEvent_t ev_seed = nullptr, ev_model = nullptr;
+            if (!ev_seed) { QH_HIP(hipEventCreateWithFlags(&ev_seed, hipEventDisableTiming)); QH_HIP(hipEventCreateWithFlags(&ev_model, hipEventDisableTiming)); }
+            hipStream_t ss = side_stream();
+            QH_HIP(hipEventRecord(ev_seed, g_stream));
+            QH_HIP(hipStreamWaitEvent(ss, ev_seed, 0));
+            hipLaunchKernelGGL((pit_model_kernel<R, 0>), dim3(PIT_MODB), dim3(256), 0, ss, ma);
+            hipLaunchKernelGGL((pit_model_kernel<R, 1>), dim3(PIT_MODB), dim3(256), 0, ss, ma);
+            QH_HIP(hipEventRecord(ev_model, ss));
+            model_event = ev_model;
         }
         QH_HIP(hipGetLastError());
         // ================================================================ relaxation passes
@@ -2580,6 +2591,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 auto forward = [&](const Cx<R> *src, Zf *dst) {      // dst = V^H src
                     hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 0>), dim3((ncol + PIT_MC - 1) / PIT_MC), dim3(pit_mfma_threads(ntot)), pit_mfma_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
                 };
+                if (p == 0 && model_event) QH_HIP(hipStreamWaitEvent(g_stream, model_event, 0));       // the sweep's coarse model (other stream)
                 if (p == 0) forward((const Cx<R> *)X, Xe);           // start taps of the sweep into the eigenbasis (kept up to date from here on)
                 forward((const Cx<R> *)Y, Ye);
                 hipLaunchKernelGGL(pit_bound_kernel, dim3((nbnd + nsel + 3) / 4), dim3(256), 0, g_stream, (const Zf *)Xe, (const Zf *)Ye, (const Zf *)Yprev, lam, ntot, sg.S, nsel, sym,
