@@ -8,7 +8,7 @@
 namespace qh {
 
 hipStream_t g_stream = nullptr;          // the stream every entry point enqueues on: one of g_streams (qh_use_stream)
-static hipStream_t g_streams[2] = {nullptr, nullptr};
+static hipStream_t g_streams[3] = {nullptr, nullptr, nullptr};    // two the caller can switch between (qh_use_stream) + one for small helper launches
 int g_device = -1;
 static thread_local std::string g_err;
 static std::mutex g_mu;
@@ -46,7 +46,7 @@ static int init_device(int device)
         return QH_ERR_NODEVICE;
     }
     QH_HIP(hipSetDevice(device));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         if (g_streams[i]) { (void)hipStreamDestroy(g_streams[i]); g_streams[i] = nullptr; }
         QH_HIP(hipStreamCreateWithFlags(&g_streams[i], hipStreamNonBlocking));
     }
@@ -56,6 +56,7 @@ static int init_device(int device)
 }
 
 hipStream_t side_stream() { return g_stream == g_streams[0] ? g_streams[1] : g_streams[0]; }
+hipStream_t helper_stream() { return g_streams[2]; }
 
 int ensure_init()
 {
@@ -158,6 +159,7 @@ int qh_sync(void)
     if (rc) return rc;
     QH_HIP(hipStreamSynchronize(qh::g_streams[0]));
     QH_HIP(hipStreamSynchronize(qh::g_streams[1]));
+    QH_HIP(hipStreamSynchronize(qh::g_streams[2]));
     return QH_OK;
 }
 int qh_release_scratch(void)
@@ -166,6 +168,7 @@ int qh_release_scratch(void)
     if (rc) return rc;
     QH_HIP(hipStreamSynchronize(qh::g_streams[0]));
     QH_HIP(hipStreamSynchronize(qh::g_streams[1]));
+    QH_HIP(hipStreamSynchronize(qh::g_streams[2]));
     for (int i = 0; i < 16; i++) {
         if (qh::g_scratch[i]) QH_HIP(hipFree(qh::g_scratch[i]));
         qh::g_scratch[i] = nullptr; qh::g_scratch_n[i] = 0;

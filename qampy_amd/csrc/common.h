@@ -26,6 +26,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 int ensure_init();
 hipStream_t side_stream();       // the library stream that is NOT the current one (work overlapped with the current stream)
+hipStream_t helper_stream();     // a third stream for small launches beside both (the coarse model of a tier-b sweep)
 const char *trainer_force();   // "" (automatic) or "direct" / "lookahead" / "iterative": qh_set_trainer(), else QAMPY_HIP_TRAINER
 int scratch(int slot, size_t bytes, void **p);   // grow-only device scratch, slots 0..11
 

@@ -2494,12 +2494,12 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         const Cx<R> *w_exact = o.start == 1 ? nullptr : ((it == 0 && o.acquire) ? (const Cx<R> *)w_start : (const Cx<R> *)wx);
         hipLaunchKernelGGL((pit_seed_kernel<R>), dim3(sg.S), dim3(256), 0, g_stream, (const Cx<R> *)wx, nmodes, ntot, (const int64_t *)modes_dev, nsel, rot_use, X, w_exact);
         if (ssb) {
-            // the coarse model of this sweep, measured at its seed taps: two small launches on the library's OTHER stream, beside pass 0 (which
-            // does not need it; its analysis waits for it).  On a cold sweep they queue behind the basis build there and are still done first.
+            // the coarse model of this sweep, measured at its seed taps: two small launches on the library's helper stream, beside pass 0 (which
+            // does not need it; its analysis waits for it) and beside the basis build of a cold sweep on the other stream.
             ma.sg = sg; ma.rot = rot_use;
             static hipEvent_t ev_seed = nullptr, ev_model = nullptr;
             if (!ev_seed) { QH_HIP(hipEventCreateWithFlags(&ev_seed, hipEventDisableTiming)); QH_HIP(hipEventCreateWithFlags(&ev_model, hipEventDisableTiming)); }
-            hipStream_t ss = side_stream();
+            hipStream_t ss = helper_stream();
             QH_HIP(hipEventRecord(ev_seed, g_stream));
             QH_HIP(hipStreamWaitEvent(ss, ev_seed, 0));
             hipLaunchKernelGGL((pit_model_kernel<R, 0>), dim3(PIT_MODB), dim3(256), 0, ss, ma);
