@@ -2518,7 +2518,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             d.host_view = &ev.hview[2 * p]; d.nrow = nsel; d.devmax = dm; d.ndev = ndev; d.safety = safety; d.Ye = ye; d.Yprev = yprev; d.ne = ne; d.ncol_e = ncol_e;
             d.theta = theta; d.modes_dev = (const int64_t *)modes_dev; d.ntot_w = ntot; d.S = (int)sg.S; d.sym = sym; d.corr_wanted = corr_wanted;
             d.extra = adaptive ? (const float *)ad_chg : nullptr;
-            d.Dfin = (ye && !adaptive && !split) ? (const float2 *)Dz[1] : nullptr; d.Vfin = (const float2 *)Vb; d.lam_fin = lam;
+            d.Dfin = (ye && !adaptive) ? (const float2 *)Dz[1] : nullptr; d.Vfin = (const float2 *)Vb; d.lam_fin = lam;
             d.stall_from = adaptive ? 5 : 2;
             return d;
         };
