@@ -289,7 +289,7 @@ typedef struct qh_pit_opts {
     double gear;            /* 0 = 8 */
     double acq_bound;       /* 0 = 0.08 */
     double acq_plateau;     /* 0 = 0.8: a chunk whose mean |err|^2 exceeds this fraction of the previous one's ends the acquisition */
-    int64_t acq_chunk;      /* 0 = automatic: 2 / mu_acq steps (mu_acq = the gear-shifted step size), 256 .. 1024 */
+    int64_t acq_chunk;      /* 0 = automatic: 2 / mu_acq steps (mu_acq = the gear-shifted step size), 256 .. 4096 */
     int64_t acq_max;        /* 0 = two chunks (at most TrSyms / 2 steps) */
     int32_t correction;     /* -1 / 1: linearised coarse correction between the passes (see below), 0: plain relaxation */
     int32_t head_steps;     /* fixed step: > 0 - the first head_steps steps of every sweep run in the EXACT form, the segments cover the rest; 0: none, unless
@@ -322,7 +322,8 @@ typedef struct qh_pit_opts {
                              * non-linear transient at the start of the stage: e.g. a decision-directed stage pulling in from taps locked to another
                              * carrier phase) is repeated with that stretch as an exact head - sequential there, parallel in time after it - before the
                              * whole call is given to the exact form; != 0: off (ABI 6) */
-    int32_t reserved1;
+    int32_t acq_anneal;     /* acquisition: 0 (default) the second and later chunks run at half the step of the one before, never below 2 mu; > 0: never
+                             * below acq_anneal x mu; < 0: every chunk at the gear-shifted step (rounds 2-3) (ABI 6) */
 } qh_pit_opts;
 typedef struct qh_pit_report {
     int32_t segments, passes, converged, acq_chunks;

@@ -170,6 +170,12 @@ __global__ void __launch_bounds__(256) pit_acq_monitor_kernel(const Cx<R> *err, 
 }
 
 // a diverged acquisition (step size too bold for this capture) is undone: the sweep then starts from the original taps
+// gear-down between the acquisition chunks: the next chunk runs at half the step (never below `floor`)
+template <typename R> __global__ void pit_acq_anneal_kernel(R *mu_acq, const R *mu, double floor_gear)
+{
+    const R lo = (R)((double)*mu * floor_gear), h = *mu_acq * (R)0.5;
+    *mu_acq = h > lo ? h : (*mu_acq > lo ? lo : *mu_acq);
+}
 template <typename R> __global__ void pit_acq_finish_kernel(Cx<R> *wx, const Cx<R> *w_start, int n, PitCtrl *c)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2317,13 +2323,13 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         else {
             const double m = (double)mu_acq_h > 1e-12 ? (double)mu_acq_h : 1e-12;
             acq_ch = (int64_t)(2.0 / m + 0.5);
-            acq_ch = acq_ch < 256 ? 256 : (acq_ch > 1024 ? 1024 : acq_ch);    // (round 4: chunks of at most 1024 steps - with the measured model 2 x 1024 do what 2 x 2112 did
-                                                                              // on every recipe of profiles/r04_pit_methods.txt, r04_acquisition.txt)
+            acq_ch = acq_ch < 256 ? 256 : (acq_ch > 4096 ? 4096 : acq_ch);
         }
         acq_ch = (acq_ch + LA_B - 1) / LA_B * LA_B;
-        amax = o.acq_max > 0 ? o.acq_max : 2 * acq_ch;            // two chunks.  (One is enough at C3 / C2 - the same 5 passes, 0.11 ms less - but not in general: the
-                                                                  // coarse model is measured at the acquired taps, and after one chunk the gain comes out 10-25 % low on
-                                                                  // 17-tap / 256-QAM / QPSK recipes, which cost them 2-4 passes: profiles/r04_acquisition.txt)
+        amax = o.acq_max > 0 ? o.acq_max : 2 * acq_ch;            // two chunks, the second at HALF the gear-shifted step (pit_acq_anneal_kernel, never below 2 mu): seeds with
+                                                                  // less misadjustment noise - with the measured model, whose passes contract 5-6 x, that is worth the fifth pass of a
+                                                                  // cold cma sweep at C3 (estimates 0.14, 0.025, 0.0044, 0.00074 against 0.20, 0.036, 0.0067, 0.0012, 0.0002 without;
+                                                                  // one chunk, or chunks of 1024 steps, cost passes on other recipes: profiles/r04_acquisition.txt)
         if (amax > TrSyms / 2 && o.acq_max <= 0) amax = TrSyms / 2;
         if (amax > TrSyms) amax = TrSyms;
     }
@@ -2446,6 +2452,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 QH_HIP(hipEventRecord(ev.t1[c], g_stream));
                 hipLaunchKernelGGL((pit_acq_monitor_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const Cx<R> *)err, (int64_t)(TrSyms * Niter), step0, CH,
                                    nsel, (const int64_t *)modes_dev, plateau, ctrl);
+                if (o.acq_anneal >= 0) hipLaunchKernelGGL((pit_acq_anneal_kernel<R>), dim3(1), dim3(1), 0, g_stream, mu_acq, (const R *)mu_dev, o.acq_anneal > 0 ? (double)o.acq_anneal : 2.0);
                 QH_HIP(hipMemcpyAsync(&ev.hflag[c], &ctrl->acq_done, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
                 QH_HIP(hipEventRecord(ev.flag[c], g_stream));
                 return QH_OK;
