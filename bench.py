@@ -128,16 +128,50 @@ def stage_list(rx):
     return names, fns
 
 
-def timed_steps(rx, steps, warmup, barrier_sync):
+def timed_steps(rx, steps, warmup, barrier_sync, overlap=False):
     """W warm-up passes, then exactly K passes bracketed by barrier + device sync; HIP events between the stages.  Returns
-    (elapsed s, mean stage ms, per-step pass kernel ms of tier b)."""
+    (elapsed s, mean stage ms, per-step pass kernel ms of tier b).
+
+    overlap: consecutive passes as ResidentReceiver.run(overlap=True) enqueues them - the phase search of pass k on stream 2 beside the
+    training of pass k + 1 (the last one flushed inside the timed region).  The stage times are then event pairs on the stream the stage
+    ran on; their sum exceeds the step time by what ran side by side."""
     from qampy_amd import _lib
     names, fns = stage_list(rx)
+    pass_ms = [[] for _ in range(rx.nstage)]
+    acq_ms = [[] for _ in range(rx.nstage)]
+    if overlap:
+        order = ["start", "gram"] + ["train%d" % s for s in range(rx.nstage)] + ["apply"]
+        for _ in range(warmup):
+            rx.run(overlap=True)
+        rx.wait_post()
+        pool = [_lib.Event() for _ in range(steps * (len(order) + 2) + 2)]
+        marks = [dict() for _ in range(steps + 1)]
+
+        def marker(k):
+            def mark(name):
+                e = pool.pop()
+                e.record()
+                marks[k][name] = e
+                if name.startswith("train"):
+                    s = int(name[5:])
+                    p, a = rx.pit_timing[s]
+                    pass_ms[s].append(list(p))
+                    acq_ms[s].append(a)
+            return mark
+        barrier_sync()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            rx.run(overlap=True, mark=marker(k))
+        rx.wait_post(marker(steps))
+        barrier_sync()
+        elapsed = time.perf_counter() - t0
+        stage_ms = [float(np.mean([marks[k][order[j + 1]].elapsed_ms(marks[k][order[j]]) for k in range(steps)])) for j in range(len(order) - 1)]
+        if rx.Mtestangles:
+            stage_ms.append(float(np.mean([mk["post_end"].elapsed_ms(mk["post_begin"]) for mk in marks if "post_end" in mk])))
+        return elapsed, stage_ms, pass_ms, acq_ms
     for _ in range(warmup):
         rx.run()
     ev = [[_lib.Event() for _ in range(len(fns) + 1)] for _ in range(steps)]
-    pass_ms = [[] for _ in range(rx.nstage)]
-    acq_ms = [[] for _ in range(rx.nstage)]
     barrier_sync()
     t0 = time.perf_counter()
     for k in range(steps):
@@ -573,18 +607,30 @@ def tier_b_block(cfg, rx, stage_names, pass_ms, acq_ms, reports, value, ms, errs
                                   note="whole step against the fully fused lower bound of 88 B per symbol period"))
 
 
-def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_check):
+def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_check, overlap=False):
     """Tier b (timed, `steps` passes) and the exact path beside it on the same resident capture: both blocks, the measured
-    deviation and the certificate.  Returns (tier_b, tier_a, extras for the roofline)."""
+    deviation and the certificate.  Returns (tier_b, tier_a, extras for the roofline).
+
+    overlap: the timed passes are consecutive captures of a running receiver (ResidentReceiver.run(overlap=True): phase search of pass k
+    beside the training of pass k + 1); the same receiver is then timed one capture at a time as well (`one_capture_at_a_time`)."""
     rx = make_receiver(cfg, sig, tier="b", pit=pit)
     rx.load(sig)
     names, _ = stage_list(rx)
-    elapsed, stage_ms, pass_ms, acq_ms = timed_steps(rx, steps, warmup, barrier_sync)
+    overlap = bool(overlap and cfg["A"])
+    elapsed, stage_ms, pass_ms, acq_ms = timed_steps(rx, steps, warmup, barrier_sync, overlap=overlap)
     reports = rx.pit_reports()
     ser_rows = rx.ser(sig.symbols, maxlag=256, window=8192, trim=2000) if cfg["A"] else []
     errs = [(d["errors"], d["compared"]) for d in ser_rows]
     tb = tier_b_block(cfg, rx, names, pass_ms, acq_ms, reports, nsym * steps / elapsed / 1e6, elapsed / steps * 1e3, errs, nsym)
     tb["stages_ms"] = {n: round(t, 3) for n, t in zip(names, stage_ms)}
+    if overlap:
+        k1 = max(2, min(steps, 5))
+        el1, ms1, _, _ = timed_steps(rx, k1, 1, barrier_sync)
+        tb["pipelining"] = dict(
+            what="consecutive captures: the phase search of pass k runs on stream 2 beside the training of pass k + 1 (same kernels, same results bit for bit); "
+                 "stages_ms are event pairs on the stream each stage ran on, so their sum exceeds ms_per_step by what ran side by side",
+            one_capture_at_a_time=dict(value=round(nsym * k1 / el1 / 1e6, 4), ms_per_step=round(el1 / k1 * 1e3, 3), steps=k1,
+                                       stages_ms={n: round(t, 3) for n, t in zip(names, ms1)}))
     ta = None
     if exact_steps > 0:
         rxa = make_receiver(cfg, sig, tier="a")
@@ -623,12 +669,12 @@ def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_
     return tb, ta, dict(rx=rx, names=names, stage_ms=stage_ms, elapsed=elapsed, errs=errs, reports=reports)
 
 
-def cert_snr_block(cfg, snr_db, nsym, seed, barrier_sync, pit):
+def cert_snr_block(cfg, snr_db, nsym, seed, barrier_sync, pit, overlap=False):
     """Certification capture WITH symbol errors (the default capture makes none on either path, so its error count cannot fail):
     same shape at a lower SNR; tier b's error counts against the exact path's, per mode, within 3 standard deviations of the count."""
     c2 = dict(cfg, snr_db=snr_db)
     sig = make_input(c2, nsym, seed)
-    tb, ta, ex = run_pair(c2, sig, nsym, 2, 1, barrier_sync, pit, 1, pit.get("tol", TOL_DEFAULT) if pit else TOL_DEFAULT)
+    tb, ta, ex = run_pair(c2, sig, nsym, 2, 1, barrier_sync, pit, 1, pit.get("tol", TOL_DEFAULT) if pit else TOL_DEFAULT, overlap=overlap)
     ea, eb = ta["errors"], tb["errors"]
     sig3 = [3.0 * float(np.sqrt(max(a, 1))) for a in ea]
     ok = all(abs(a - b) <= s3 for a, b, s3 in zip(ea, eb, sig3)) and min(ea) > 100
@@ -682,14 +728,15 @@ def adaptive_block(log2n=20, seed=1000):
                      "(exact_form = true for the last mode, deviations exactly 0 for such a mode)")
 
 
-def shape_block(key, barrier_sync, pit, steps):
+def shape_block(key, barrier_sync, pit, steps, overlap=False):
     """Another BASELINE shape in the same line (ns: the north star's 10^7 symbols; c2: configs[1]): tier b, the exact path, SER, certificate."""
     cfg = dict(WORKLOADS[key])
     nsym = cfg["nsym"]
     sig = make_input(cfg, nsym, 1000)
-    tb, ta, ex = run_pair(cfg, sig, nsym, steps, 1, barrier_sync, pit, 1, pit.get("tol", TOL_DEFAULT) if pit else TOL_DEFAULT)
+    tb, ta, ex = run_pair(cfg, sig, nsym, steps, 1, barrier_sync, pit, 1, pit.get("tol", TOL_DEFAULT) if pit else TOL_DEFAULT, overlap=overlap)
     del ex
-    return dict(workload=cfg["label"], nsym=nsym, tier_b=dict(value=tb["value"], ms_per_step=tb["ms_per_step"], certified=tb["certified"], checks=tb.get("checks"), info=tb.get("info"),
+    return dict(workload=cfg["label"], nsym=nsym, tier_b=dict(value=tb["value"], ms_per_step=tb["ms_per_step"], one_capture_at_a_time=(tb.get("pipelining") or {}).get("one_capture_at_a_time"),
+                                                               certified=tb["certified"], checks=tb.get("checks"), info=tb.get("info"),
                                                                stages=[dict(stage=st["stage"], S=st["S"], seg_len=st["seg_len"], P=st["P"], converged=st["converged"], exact_form=st.get("exact_form", False),
                                                                             est_deviation_rms=st["est_deviation_rms"][-1:] , pass_ms=st["pass_ms"]) for st in tb["stages"]],
                                                                out_rms_dev_vs_exact=tb["out_rms_dev_vs_exact"], tap_rel_dev_vs_exact=tb["tap_rel_dev_vs_exact"],
@@ -732,6 +779,8 @@ def main():
     ap.add_argument("--bank-trainer", default="iterative", choices=["auto", "iterative"])
     ap.add_argument("--bank", type=int, default=128, help="channels of the informational channel-bank run at N=1 (0 = skip)")
     ap.add_argument("--cpu-bank-workers", type=int, default=-1, help="concurrent single-threaded CPU pipelines of the bank's CPU leg (-1: min(cores, 128), 0: skip)")
+    ap.add_argument("--no-overlap", action="store_true", help="tier b: time one capture at a time only (default: consecutive captures, the phase search of "
+                                                              "pass k on stream 2 beside the training of pass k + 1)")
     ap.add_argument("--no-extra-shapes", action="store_true", help="skip the ns / c2 / 24 dB / loose-tolerance blocks of the default line")
     ap.add_argument("--split-capture", action="store_true",
                     help="N > 1: ONE capture, the segments of the tier-b trainer spread over the ranks with an all-reduce of their end taps per pass "
@@ -789,6 +838,7 @@ def main():
         cm.barrier()
 
     pit = dict(tol=args.tol) if args.tol > 0 else {}
+    overlap = args.tier == "b" and not args.no_overlap and not args.dry_run
     tol_check = args.tol if args.tol > 0 else TOL_DEFAULT
     if args.dry_run:
         rx = DryReceiver(cfg, nsym, args.tier)
@@ -827,7 +877,7 @@ def main():
         tier_b = tier_b_block(cfg, rx, stage_names, pass_ms, acq_ms, reports, nsym * args.steps / elapsed / 1e6, elapsed / args.steps * 1e3, errs, nsym)
         tier_b["certified"] = tier_b["converged"]
     elif args.tier == "b":
-        tier_b, tier_a, ex = run_pair(cfg, sig, nsym, args.steps, args.warmup, barrier_sync, pit, args.exact_steps if world == 1 else 0, tol_check)
+        tier_b, tier_a, ex = run_pair(cfg, sig, nsym, args.steps, args.warmup, barrier_sync, pit, args.exact_steps if world == 1 else 0, tol_check, overlap=overlap)
         rx, stage_names, stage_ms, elapsed, errs, reports = ex["rx"], ex["names"], ex["stage_ms"], ex["elapsed"], ex["errs"], ex["reports"]
     else:
         rx = make_receiver(cfg, sig, tier="a")
@@ -884,6 +934,11 @@ def main():
         if world > 1:
             tier_b["certified"] = bool(certified_all)
         out["tier_b"] = tier_b
+        if tier_b.get("pipelining"):
+            # value / ms_per_step: K consecutive captures through one running receiver (step time = K passes / elapsed); the figure for a single
+            # capture handed over and waited for is beside it
+            out["config"]["pipelining"] = "consecutive captures; phase search of pass k (stream 2) beside the training of pass k + 1 (stream 0); --no-overlap for one at a time"
+            out["one_capture_at_a_time"] = tier_b["pipelining"]["one_capture_at_a_time"]
     if tier_a is not None:
         out["tier_a"] = tier_a
 
@@ -1016,7 +1071,7 @@ def main():
     if world == 1 and args.tier == "b" and not args.no_extra_shapes and not split:
         try:
             ksteps = max(2, min(args.steps, 10))
-            tb2, _, ex2 = run_pair(cfg, sig, nsym, ksteps, 1, barrier_sync, dict(pit, tol=1e-2), 0, 1e-2)
+            tb2, _, ex2 = run_pair(cfg, sig, nsym, ksteps, 1, barrier_sync, dict(pit, tol=1e-2), 0, 1e-2, overlap=overlap)
             rx2 = ex2["rx"]
             rxa = make_receiver(cfg, sig, tier="a"); rxa.load(sig); rxa.run(); _lib.sync()
             dv = deviation_vs_exact(rx2, rxa, cfg)
@@ -1027,9 +1082,9 @@ def main():
                                        note="informational: the same solver held to a 10 x looser deviation (SER-equivalent tier of SURVEY 7.3-1(b)); never the headline")
             del rx2, rxa, ex2
             if args.workload == "c3":
-                out["cert_24dB"] = cert_snr_block(cfg, 24.0, min(nsym, 1 << 21), 1001, barrier_sync, pit)
+                out["cert_24dB"] = cert_snr_block(cfg, 24.0, min(nsym, 1 << 21), 1001, barrier_sync, pit, overlap=overlap)
                 for key in ("ns", "c2"):
-                    out[key] = shape_block(key, barrier_sync, pit, 3)
+                    out[key] = shape_block(key, barrier_sync, pit, 3, overlap=overlap)
                 out["adaptive_step"] = adaptive_block()
             _lib.call("qh_release_scratch")
         except Exception as e:                    # informational blocks never take the headline down

@@ -72,8 +72,11 @@ int qh_memcpy_d2d(void *dst, const void *src, size_t bytes);
  * qh_release_scratch frees the grow-only scratch buffers (Gram tables above all - up to QAMPY_HIP_GRAM_BUDGET_GB) after
  * draining both streams; they are re-allocated on demand. */
 int qh_release_scratch(void);
-/* Two library streams.  Every entry point enqueues on the CURRENT one (0 after qh_init); qh_use_stream switches it,
- * qh_stream_wait_event makes the current stream wait for an event recorded on the other one, qh_sync drains both.
+/* Three library streams.  Every entry point enqueues on the CURRENT one (0 after qh_init); qh_use_stream(0..2) switches it,
+ * qh_stream_wait_event makes the current stream wait for an event recorded on another one, qh_sync drains all of them.
+ * Streams 0 and 1 are equals (a tier-b trainer puts its eigen-solver on whichever of the two is not current); stream 2 has the
+ * lowest queue priority and is meant for chip-wide streaming work (phase search of capture k) overlapped with the latency-bound
+ * trainers of capture k+1 on stream 0 (ResidentReceiver.run(overlap=True)).
  * Scratch buffers are per library, not per stream: overlap only stages that use different ones (trainers + Gram tables on
  * one stream; filter, phase search and SER harness on the other - what ChannelBank.run_pipelined does). */
 int qh_use_stream(int idx);

@@ -8,7 +8,7 @@
 namespace qh {
 
 hipStream_t g_stream = nullptr;          // the stream every entry point enqueues on: one of g_streams (qh_use_stream)
-static hipStream_t g_streams[3] = {nullptr, nullptr, nullptr};    // two the caller can switch between (qh_use_stream) + one for small helper launches
+static hipStream_t g_streams[4] = {nullptr, nullptr, nullptr, nullptr};    // three the caller can switch between (qh_use_stream 0..2) + one for small helper launches
 int g_device = -1;
 static thread_local std::string g_err;
 static std::mutex g_mu;
@@ -46,9 +46,28 @@ static int init_device(int device)
         return QH_ERR_NODEVICE;
     }
     QH_HIP(hipSetDevice(device));
-    for (int i = 0; i < 3; i++) {
+    int prio_least = 0, prio_greatest = 0;
+    QH_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    for (int i = 0; i < 4; i++) {
         if (g_streams[i]) { (void)hipStreamDestroy(g_streams[i]); g_streams[i] = nullptr; }
-        QH_HIP(hipStreamCreateWithFlags(&g_streams[i], hipStreamNonBlocking));
+        // stream 2 is where a caller overlaps chip-wide streaming work (filter output -> phase search) with the latency-bound trainers
+        // of the next capture on stream 0: lowest queue priority, so that the trainers' workgroups are dispatched first
+        if (i == 2) {
+            // ... and kept off the first 32 compute units (QAMPY_HIP_RESERVED_CUS): its single-wave workgroups fill every CU they may
+            // use to the LDS limit, and a trainer's one-workgroup kernels that need most of a CU's LDS (eigen-solver: 107 KiB; acquisition)
+            // would otherwise wait for the whole phase search to drain (measured at C3: eigen-solver 1.1 ms instead of 0.5 ms, step
+            // 3.95 ms with 0..16 CUs kept free, 3.50 ms with 24..48)
+            const char *e = getenv("QAMPY_HIP_RESERVED_CUS");
+            const int reserved = e ? atoi(e) : 32;
+            const int ncu = prop.multiProcessorCount;
+            if (reserved > 0 && reserved < ncu) {
+                std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+                for (int c = reserved; c < ncu; c++) mask[c / 32] |= 1u << (c % 32);
+                QH_HIP(hipExtStreamCreateWithCUMask(&g_streams[i], (uint32_t)mask.size(), mask.data()));
+                continue;
+            }
+        }
+        QH_HIP(hipStreamCreateWithPriority(&g_streams[i], hipStreamNonBlocking, i == 2 ? prio_least : prio_greatest));
     }
     g_stream = g_streams[0];
     g_device = device;
@@ -56,7 +75,7 @@ static int init_device(int device)
 }
 
 hipStream_t side_stream() { return g_stream == g_streams[0] ? g_streams[1] : g_streams[0]; }
-hipStream_t helper_stream() { return g_streams[2]; }
+hipStream_t helper_stream() { return g_streams[3]; }
 
 int ensure_init()
 {
@@ -157,18 +176,14 @@ int qh_sync(void)
 {
     int rc = qh::ensure_init();
     if (rc) return rc;
-    QH_HIP(hipStreamSynchronize(qh::g_streams[0]));
-    QH_HIP(hipStreamSynchronize(qh::g_streams[1]));
-    QH_HIP(hipStreamSynchronize(qh::g_streams[2]));
+    for (int i = 0; i < 4; i++) QH_HIP(hipStreamSynchronize(qh::g_streams[i]));
     return QH_OK;
 }
 int qh_release_scratch(void)
 {
     int rc = qh::ensure_init();
     if (rc) return rc;
-    QH_HIP(hipStreamSynchronize(qh::g_streams[0]));
-    QH_HIP(hipStreamSynchronize(qh::g_streams[1]));
-    QH_HIP(hipStreamSynchronize(qh::g_streams[2]));
+    for (int i = 0; i < 4; i++) QH_HIP(hipStreamSynchronize(qh::g_streams[i]));
     for (int i = 0; i < 16; i++) {
         if (qh::g_scratch[i]) QH_HIP(hipFree(qh::g_scratch[i]));
         qh::g_scratch[i] = nullptr; qh::g_scratch_n[i] = 0;
@@ -180,7 +195,7 @@ int qh_use_stream(int idx)
 {
     int rc = qh::ensure_init();
     if (rc) return rc;
-    if (idx < 0 || idx > 1) { qh::set_error("qh_use_stream: the library has streams 0 and 1"); return QH_ERR_ARG; }
+    if (idx < 0 || idx > 2) { qh::set_error("qh_use_stream: the library has streams 0, 1 and 2"); return QH_ERR_ARG; }
     qh::g_stream = qh::g_streams[idx];
     return QH_OK;
 }

@@ -24,6 +24,11 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         if (!(cond)) { qh::set_error(msg); return QH_ERR_ARG; } \
     } while (0)
 
+// First statement of the kernels on a tier-b trainer's critical path (chains, eigen-solver, control kernels): issue priority over the
+// waves of a streaming kernel of another stream that shares the SIMD (the phase search of the previous capture, pipeline.py
+// run(overlap=True)).  Costs one scalar instruction; without a co-runner it changes nothing.
+#define QH_WAVE_FIRST() __builtin_amdgcn_s_setprio(3)
+
 int ensure_init();
 hipStream_t side_stream();       // the library stream that is NOT the current one (work overlapped with the current stream)
 hipStream_t helper_stream();     // a third stream for small launches beside both (the coarse model of a tier-b sweep)

@@ -43,6 +43,7 @@ __host__ __device__ constexpr int gram_tri_row(int j) { return j * (LA_B - 1) - 
 template <typename R, bool PAIR>
 __global__ void __launch_bounds__(256) gram_slide_kernel(const Cx<R> *E, int nmodes, int64_t L, int64_t Lp, int os, int ntaps, int64_t TrSyms, Cx<R> *G)
 {
+    QH_WAVE_FIRST();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Cx<R> *tile = reinterpret_cast<Cx<R> *>(smem);
     constexpr int NT = PAIR ? 2 * LA_B : LA_B;                    // targets reachable from a block: this block (+ the next one)
@@ -284,6 +285,7 @@ template <typename R, int METHOD, int NPART>
 __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
 {
     if (a.skip && *a.skip) return;
+    __builtin_amdgcn_s_setprio(3);       // a sequential recurrence: ahead of any streaming kernel of another stream that shares the CU
     // independent captures of a channel bank / segments of a sweep (blockIdx.y): same shapes, own arrays
     const int64_t ch = blockIdx.y;
     const LaView<R> vw = la_view(a, ch);

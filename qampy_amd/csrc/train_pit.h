@@ -97,6 +97,7 @@ template <typename R>
 __global__ void __launch_bounds__(256) pit_setup_kernel(const Cx<R> *E, int nmodes, int64_t L, int64_t npow, int ntot, const R *mu, double gear,
                                                         double bound, double tol, PitSeg sg, PitCtrl *c, R *mu_acq)
 {
+    QH_WAVE_FIRST();
     __shared__ double red[256];
     double acc = 0;
     for (int k = 0; k < nmodes; k++)
@@ -128,6 +129,7 @@ __global__ void __launch_bounds__(256) pit_setup_kernel(const Cx<R> *E, int nmod
 // start of a sweep's relaxation: passes of this sweep count from zero
 static __global__ void pit_sweep_kernel(PitCtrl *c)
 {
+    QH_WAVE_FIRST();
     c->done = 0; c->converged = 0; c->passes = 0;
     for (int q = 0; q < QH_PIT_MAXPASS; q++) { c->result_change[q] = -1; c->deviation[q] = -1; c->deviation_rms[q] = -1; c->deviation_taps[q] = -1; c->deviation_taps_worst[q] = -1; }
     for (int i = 0; i < QH_PIT_MAXPASS; i++) c->defect[i] = -1;
@@ -138,6 +140,7 @@ template <typename R>
 __global__ void __launch_bounds__(256) pit_acq_monitor_kernel(const Cx<R> *err, int64_t err_pitch, int64_t step0, int64_t n, int nsel,
                                                               const int64_t *modes_dev, double plateau, PitCtrl *c)
 {
+    QH_WAVE_FIRST();
     if (c->acq_done) return;
     __shared__ double red[256];
     double acc = 0;
@@ -173,11 +176,13 @@ __global__ void __launch_bounds__(256) pit_acq_monitor_kernel(const Cx<R> *err, 
 // gear-down between the acquisition chunks: the next chunk runs at half the step (never below `floor`)
 template <typename R> __global__ void pit_acq_anneal_kernel(R *mu_acq, const R *mu, double floor_gear)
 {
+    QH_WAVE_FIRST();
     const R lo = (R)((double)*mu * floor_gear), h = *mu_acq * (R)0.5;
     *mu_acq = h > lo ? h : (*mu_acq > lo ? lo : *mu_acq);
 }
 template <typename R> __global__ void pit_acq_finish_kernel(Cx<R> *wx, const Cx<R> *w_start, int n, PitCtrl *c)
 {
+    QH_WAVE_FIRST();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (c->diverged && i < n) wx[i] = w_start[i];
 }
@@ -191,6 +196,7 @@ template <typename R>
 __global__ void __launch_bounds__(256) pit_phase_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, const Cx<R> *wx, int ntaps, PitSeg sg,
                                                         const int64_t *modes_dev, int nwin, double *z)
 {
+    QH_WAVE_FIRST();
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     Cx<R> *w = reinterpret_cast<Cx<R> *>(pit_smem);
     const int ntot = nmodes * ntaps;
@@ -240,6 +246,7 @@ __global__ void __launch_bounds__(256) pit_phase_kernel(const Cx<R> *E, int nmod
 // rot[s, j] = exp(-i phi_s): phi = arg(-z)/4 (E[s^4] is negative real for the QAM alphabets), unwrapped along the segments
 static __global__ void __launch_bounds__(256) pit_unwrap_kernel(const double *z, int S, int nsel, double *rot, double *phi, int *jump)
 {
+    QH_WAVE_FIRST();
     // phi[nsel][S], jump[nsel][S]: work arrays in device memory (S may be tens of thousands); one block per mode
     __shared__ int ptot[512];
     const double q = 1.5707963267948966;
@@ -270,6 +277,7 @@ template <typename R>
 __global__ void __launch_bounds__(256) pit_seed_kernel(const Cx<R> *wx, int nmodes, int ntot, const int64_t *modes_dev, int nsel, const double *rot, Cx<R> *X,
                                                        const Cx<R> *w0)
 {
+    QH_WAVE_FIRST();
     const int s = blockIdx.x;
     const int n = nmodes * ntot;
     const bool exact0 = s == 0 && w0 != nullptr;
@@ -296,6 +304,7 @@ __global__ void __launch_bounds__(PIT_PROBE) pit_defect_kernel(const Cx<R> *E, i
                                                                 const int64_t *modes_dev, const Cx<R> *X, const Cx<R> *Y, int sym, const PitCtrl *c, double *dfc, double *pw, double *gph,
                                                                 const Cx<R> *wx_prev)
 {
+    QH_WAVE_FIRST();
     if (c->done) return;
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     Cx<R> *wa = reinterpret_cast<Cx<R> *>(pit_smem);
@@ -582,6 +591,7 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
 
 template <typename R> __global__ void __launch_bounds__(256) pit_decide_kernel(PitDecideArgs<R> a)
 {
+    QH_WAVE_FIRST();
     if (a.c->done) return;
     pit_decide_body<R>(a);
 }
@@ -593,6 +603,7 @@ template <typename R>
 __global__ void __launch_bounds__(256) pit_rotate_err_kernel(Cx<R> *err, int64_t err_pitch, int64_t err_off, PitSeg sg, const int64_t *modes_dev, int nsel,
                                                              const double *theta, const PitCtrl *c, int p)
 {
+    QH_WAVE_FIRST();
     if (p >= 0 && (!c->done || c->passes != p + 1)) return;       // p < 0: launched once, after the last pass
     const int s = blockIdx.x, j = blockIdx.y;
     if (s == 0) return;                                           // theta_0 = 1
@@ -615,6 +626,7 @@ constexpr int PIT_COVW = 32, PIT_COVB = 256;                       // windows pe
 template <typename R, int EPT>
 __global__ void __launch_bounds__(256) pit_cov_kernel(const Cx<R> *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, int nwin, Z *part)
 {
+    QH_WAVE_FIRST();
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     Cx<R> *x = reinterpret_cast<Cx<R> *>(pit_smem);               // [PIT_COVW][ntot]
     const int ntot = nmodes * ntaps;
@@ -645,6 +657,7 @@ __global__ void __launch_bounds__(256) pit_cov_kernel(const Cx<R> *E, int nmodes
 // 64 entries per block, 4 threads per entry (each a quarter of the partial sums, loads unrolled so that they overlap)
 static __global__ void __launch_bounds__(256) pit_cov_reduce_kernel(const Z *part, int nent, int nblk, Z *Rc)
 {
+    QH_WAVE_FIRST();
     __shared__ double sr[256], si[256];
     const int e = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
     double ar = 0, ai = 0;
@@ -671,6 +684,7 @@ __device__ __forceinline__ Zf cmulf(Zf a, Zf b) { return Zf{a.x * b.x - a.y * b.
 // of each other (1.12 -> ~0.78 ms until the basis is there: it had become what the first correction of a cold start waits for).
 static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, int n, double norm, double *lam, Zf *Vout, int nsweep, float4 *glog)
 {
+    QH_WAVE_FIRST();
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     const int ld = n + 1;
     Zf *A = reinterpret_cast<Zf *>(pit_smem);                 // [n][ld]
@@ -819,6 +833,7 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_kernel(const Z *Rc, in
 // pit_jacobi_v_kernel; two copies of A: n <= 96.
 static __global__ void __launch_bounds__(1024) pit_jacobi_blk_kernel(const Z *Rc, int n, double norm, double *lam, int nsweep, float4 *glog)
 {
+    QH_WAVE_FIRST();
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     const int ld = n + 1;
     Zf *src = reinterpret_cast<Zf *>(pit_smem), *dst = src + (size_t)n * ld;
@@ -922,6 +937,7 @@ static __global__ void __launch_bounds__(1024) pit_jacobi_blk_kernel(const Z *Rc
 constexpr int PIT_JV_CH = 27;
 static __global__ void __launch_bounds__(64) pit_jacobi_v_kernel(const float4 *glog, int n, int nsweep, Zf *Vout)
 {
+    QH_WAVE_FIRST();
     __shared__ Zf row[PIT_EIGMAX + 2];
     __shared__ float4 gch[PIT_JV_CH * (PIT_EIGMAX / 2 + 1)];
     const int lane = threadIdx.x, i = blockIdx.x;
@@ -976,6 +992,7 @@ template <typename R> struct PitFuse {
 template <typename R, bool CONJT>
 __global__ void __launch_bounds__(256) pit_cgemm_kernel(const Zf *A2, const Zf *B, Zf *C, int n, int ncol, const PitCtrl *c, PitFuse<R> fz)
 {
+    QH_WAVE_FIRST();
     if (c->done) return;
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     Zf *As = reinterpret_cast<Zf *>(pit_smem);                // [k][PIT_EIGMAX]  op(A)[m][k] stored k-major: rows m contiguous
@@ -1125,6 +1142,7 @@ __device__ __forceinline__ void pit_gain_matrix(int method, float yr, float yi, 
 template <typename R, int PHASE>
 __global__ void __launch_bounds__(256) pit_model_kernel(PitModelArgs<R> a)
 {
+    QH_WAVE_FIRST();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, grp = lane >> 4, l16 = lane & 15;
     const int gg = (blockIdx.x * 4 + wave) * 4 + grp, ng = gridDim.x * 16;            // window groups of the launch
     const int ntot = a.nmodes * a.ntaps;
@@ -1296,6 +1314,7 @@ template <typename R, int MODE>
 __global__ void __launch_bounds__(64 * (PIT_EIGMAX / 16)) pit_basis_mfma_kernel(const Zf *__restrict__ A2, const Cx<R> *__restrict__ T, const Zf *__restrict__ D, Zf *__restrict__ Out,
                                                                                int n, int ncol, const PitCtrl *c, PitFuse<R> fz)
 {
+    QH_WAVE_FIRST();
     if (c->done) return;
     extern __shared__ __attribute__((aligned(16))) char pit_smem[];
     const int np = (n + 3) & ~3;                              // contraction length padded to whole MFMA steps (zero rows)
@@ -1445,6 +1464,7 @@ __global__ void __launch_bounds__(64 * (PIT_EIGMAX / 16)) pit_basis_mfma_kernel(
 static __global__ void __launch_bounds__(256) pit_bound_kernel(const Zf *Xe, const Zf *Ye, const Zf *Yprev, const double *lam, int n, int S, int nsel, int sym,
                                                               const PitCtrl *c, double *dfc, double *pw, double *gph, float4 *ualpha = nullptr)
 {
+    QH_WAVE_FIRST();
     if (c->done) return;
     const int lane = threadIdx.x & 63, bi = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nb = (S - 1) * nsel, ncol = S * nsel;
@@ -1525,6 +1545,7 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
                                                                double beta, const PitCtrl *c, const float *Msum = nullptr, float damp = 1.f,
                                                                const float4 *ualpha = nullptr, const float2 *uq = nullptr)
 {
+    QH_WAVE_FIRST();
     if (c->done) return;
     __shared__ float4 aff[2 * PIT_RT];
     const int k = blockIdx.x, j = blockIdx.y;
@@ -1683,6 +1704,7 @@ __global__ void __launch_bounds__(PIT_RT) pit_recur_eig_kernel(Zf *Xe, const Zf 
 template <typename R>
 __global__ void __launch_bounds__(256) pit_recur_kernel(Zf *D, const double *lam, int nsel, int S, int64_t T, const R *mu, double beta, const PitCtrl *c)
 {
+    QH_WAVE_FIRST();
     if (c->done) return;
     __shared__ float4 aff[512];
     const int k = blockIdx.x, j = blockIdx.y;
@@ -1729,6 +1751,7 @@ __global__ void __launch_bounds__(256) pit_recur_kernel(Zf *D, const double *lam
 template <typename R>
 __global__ void __launch_bounds__(256) pit_adapt_init_kernel(const R *mu, const Cx<R> *e_last, int n, R *rS, Cx<R> *eS)
 {
+    QH_WAVE_FIRST();
     const R r0 = (R)1 / *mu;
     for (int s = blockIdx.x * 256 + threadIdx.x; s < n; s += gridDim.x * 256) { rS[s] = r0; eS[s] = s == 0 ? *e_last : Cx<R>{0, 0}; }
 }
@@ -1744,6 +1767,7 @@ template <typename R>
 __global__ void __launch_bounds__(1024) pit_adapt_scan_kernel(R *rS, const R *rE, Cx<R> *eS, const Cx<R> *eE, int n, float *chg, const PitCtrl *c, float relax,
                                                               float *rPrev, float *dPrev, int newton)
 {
+    QH_WAVE_FIRST();
     if (c->done) return;
     __shared__ double2 buf[16];
     __shared__ float red[16];
@@ -1798,6 +1822,7 @@ __global__ void __launch_bounds__(PIT_GT_THREADS) pit_gauge_kernel(const double 
                                                                    int want_corr, const PitModel *model = nullptr, const float4 *ualpha = nullptr, float2 *uq = nullptr,
                                                                    const R *mu = nullptr, int64_t T = 0, const float *Msum = nullptr)
 {
+    QH_WAVE_FIRST();
     if (c->done) return;
     constexpr int NT = PIT_GT_THREADS;
     __shared__ double redp[NT / 64];
@@ -1906,6 +1931,7 @@ __global__ void __launch_bounds__(PIT_GT_THREADS) pit_gauge_kernel(const double 
 template <typename R>
 __global__ void __launch_bounds__(256) pit_devest_kernel(const Zf *D, const double *lam, int n, int ncol, const PitCtrl *c, float *devmax, unsigned *ticket, PitDecideArgs<R> da)
 {
+    QH_WAVE_FIRST();
     if (c->done) return;
     // 64 columns per block, 4 threads per column (each a quarter of the k, loads of consecutive columns coalesce and overlap)
     __shared__ float part[2][4][64], red[64], reds[64], redt[64], redm[64];
@@ -1960,6 +1986,7 @@ __global__ void __launch_bounds__(256) pit_devest_kernel(const Zf *D, const doub
 // last column whose estimated output deviation sum_k lambda_k |D~_k|^2 exceeds thr (way out of a stalled sweep: where does the trouble end?)
 static __global__ void __launch_bounds__(256) pit_front_kernel(const Zf *D, const double *lam, int n, int ncol, double thr, int *front, int *bad)
 {
+    QH_WAVE_FIRST();
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= ncol) return;
     float acc = 0.f;

@@ -155,6 +155,9 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     // Naming the last VGPR and one AGPR as clobbered pushes the allocation past half the register file, so that a second wave
     // never fits (any layout, any precision; with more chains than SIMDs the waves queue up and still run alone).
     asm volatile("" ::: "v255", "a0");                          // allocation = 256 VGPRs + the first AGPR granule > half the file
+    // What CAN share the SIMD is a narrow streaming kernel of another stream (the phase search of the previous capture, 64 registers a
+    // wave: pipeline.py run(overlap=True)); this wave is the latency-bound one, so it goes first whenever both have an instruction ready.
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) char sg_smem[];
     Cx<R> *lds = reinterpret_cast<Cx<R> *>(sg_smem);          // [SG_ROWS][SG_PITCH] + zero row [SG_PITCH]  (ONE buffer: the next chunk waits in registers
                                                               // while this one computes and is stored after it - one wave per workgroup, LDS operations in program order)

@@ -149,19 +149,72 @@ class ResidentReceiver:
     def recover(self):
         _dsp.bps_recover_dev(self.eq, self.Mtestangles, self.alphabet, self.Nbps, self.idx, self.ph, self.out, angles=self.angles)
 
-    def run(self):
-        """One pass of the hot path over the resident capture; returns without synchronising."""
+    def run(self, overlap=False, mark=None):
+        """One pass of the hot path over the resident capture; returns without synchronising.
+
+        ``overlap=True`` (a receiver that is handed capture after capture): the phase search of this pass is left PENDING and goes
+        onto the library's stream 2 when the next ``run`` has enqueued its covariance kernel (the one chip-wide streaming kernel of
+        a tier-b pass, which would otherwise queue up behind the phase search and hold back the eigen-solver), so that it runs
+        beside the training of the next pass on stream 0 - the trainers are latency-bound chains of one wave per SIMD that leave
+        half of the register file and most issue slots free, the phase search is a chip-wide streaming kernel of 64 registers a
+        wave that fits into them (csrc/train_seg.h; stream 2 stays off 32 of the 256 compute units, csrc/api.hip).  The results of
+        a pass are complete after ``wait_post()`` (enqueues what is pending; stream 0 waits for it) or ``fetch()`` (the host waits
+        too).  Bit-identical to ``overlap=False``: the same kernels on the same data, in another order.
+
+        ``mark(name)`` (bench.py): called on the stream the stage was enqueued on after "start", "gram", "train<s>", "apply", "bps",
+        and around the overlapped phase search ("post_begin", "post_end")."""
+        m = mark or (lambda name: None)
         self.reset()
+        m("start")
         self.build_gram()
+        m("gram")
+        self._enqueue_post(m)                     # phase search of the previous overlapped pass, beside the stages below
         for s in range(self.nstage):
             self.train(s)
+            m("train%d" % s)
+        if getattr(self, "_post_running", False):
+            _lib.call("qh_stream_wait_event", self._ev_post.ptr)        # the filter output of the previous pass has been consumed
+            self._post_running = False
         self.apply()
-        if self.Mtestangles:
+        m("apply")
+        if not self.Mtestangles:
+            return
+        if not overlap:
             self.recover()
+            m("bps")
+            return
+        if getattr(self, "_ev_post", None) is None:
+            self._ev_ready, self._ev_post = _lib.Event(), _lib.Event()
+        self._post_pending = True
+
+    def _enqueue_post(self, mark=None):
+        if not getattr(self, "_post_pending", False):
+            return
+        self._ev_ready.record()                   # stream 0 up to here: filter of the pending pass, covariance kernel of the next one
+        _lib.call("qh_use_stream", 2)
+        try:
+            _lib.call("qh_stream_wait_event", self._ev_ready.ptr)
+            if mark:
+                mark("post_begin")
+            self.recover()
+            if mark:
+                mark("post_end")
+            self._ev_post.record()
+        finally:
+            _lib.call("qh_use_stream", 0)
+        self._post_pending, self._post_running = False, True
+
+    def wait_post(self, mark=None):
+        """After ``run(overlap=True)``: enqueue the pending phase search; work enqueued from here on (stream 0) sees its results."""
+        self._enqueue_post(mark)
+        if getattr(self, "_post_running", False):
+            _lib.call("qh_stream_wait_event", self._ev_post.ptr)
+            self._post_running = False
 
     # ------------------------------------------------------------------------------------------ results
     def fetch(self):
         """Synchronise and copy the results to the host as a dict of ndarrays."""
+        self.wait_post()
         _lib.sync()
         res = dict(wxy=self.wxy.to_host(), err=tuple(e.to_host() for e in self.err), eq=self.eq.to_host(),
                    mu=tuple(m.to_host()[0] for m in self.mu))
@@ -177,6 +230,7 @@ class ResidentReceiver:
             raise ValueError("ser() needs the alphabet")
         if getattr(self, "alphabet", None) is None:
             self.alphabet = DeviceArray.from_host(self.alphabet_host)
+        self.wait_post()
         if getattr(self, "_idx_tx", None) is None or self._idx_tx_src is not symbols_tx:
             self._idx_tx = _ber.tx_indices_dev(np.ascontiguousarray(symbols_tx, dtype=self.ct), self.alphabet)
             self._idx_tx_src = symbols_tx

@@ -493,3 +493,38 @@ def test_exact_head_option():
     for m in range(2):
         assert np.linalg.norm(wa[m] - wb[m]) / np.linalg.norm(wa[m]) < 3e-3
         assert np.sqrt(np.mean(np.abs(ea[m] - eb[m]) ** 2)) < 3e-3
+
+
+@pytest.mark.parametrize("tier", ["a", "b"])
+def test_overlapped_passes_give_the_results_of_one_capture_at_a_time(tier):
+    """ResidentReceiver.run(overlap=True): the phase search of pass k is enqueued on stream 2 behind the covariance kernel of pass k + 1 and
+    runs beside its training.  Two DIFFERENT captures handed over one after the other: what fetch() returns after each is bit for bit what the
+    same receiver returns one capture at a time - also for the capture whose phase search was still pending when the next one was loaded
+    into the input buffer (the search reads the filter output, not the capture)."""
+    nsym, M, ntaps, mu = 2 ** 17, 64, 41, (1e-3, 5e-4)
+    caps = [synth.make_capture_dev(M, nsym, nmodes=2, snr_db=30, theta=np.pi / 5.6, dgd=30e-12, linewidth=100., seed=sd) for sd in (1000, 1003)]
+    kw = dict(methods=("cma", "mrde"), Niter=(1, 1), Mtestangles=64, Nbps=20, alphabet=caps[0]["alphabet_host"])
+    rx = ResidentReceiver(2, 2 * nsym, 2, M, ntaps, mu, tier=tier, **kw)
+    serial = []
+    for c in caps:
+        rx.E.copy_from(c["E"])
+        rx.run()
+        serial.append(rx.fetch())
+    # overlapped: capture 0, then capture 1 while the search of capture 0 is pending; the recovered signal of capture 0 is read in between
+    rx.E.copy_from(caps[0]["E"])
+    rx.run(overlap=True)
+    rx.E.copy_from(caps[1]["E"])
+    rx.run(overlap=True)                        # enqueues the search of capture 0 beside this training
+    _lib.sync()
+    out0 = {k: getattr(rx, k).to_host() for k in ("out", "ph", "idx")}
+    for k in out0:
+        assert np.array_equal(out0[k], serial[0][k]), (tier, k, "capture 0, search overlapped with the training of capture 1")
+    res1 = rx.fetch()                           # flushes the pending search of capture 1
+    for k in ("wxy", "eq", "out", "ph", "idx"):
+        assert np.array_equal(res1[k], serial[1][k]), (tier, k, "capture 1")
+    # and a plain run after overlapped ones is unaffected
+    rx.E.copy_from(caps[0]["E"])
+    rx.run()
+    res0 = rx.fetch()
+    for k in ("wxy", "eq", "out", "ph", "idx"):
+        assert np.array_equal(res0[k], serial[0][k]), (tier, k, "plain run after overlapped ones")
