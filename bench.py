@@ -106,6 +106,13 @@ def make_receiver(cfg, sig, tier="a", pit=None):
                             Nbps=cfg["Nbps"], dtype=np.complex64, alphabet=sig.coded_symbols, tier=tier, pit=pit)
 
 
+def make_group(n, cfg, sig, pit=None):
+    from qampy_amd.pipeline import ReceiverGroup
+    return ReceiverGroup(n, sig.shape[0], sig.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"],
+                         adaptive_stepsize=cfg["adaptive"], TrSyms=(None,) * len(cfg["methods"]), Mtestangles=cfg["A"],
+                         Nbps=cfg["Nbps"], dtype=np.complex64, alphabet=sig.coded_symbols, tier="b", pit=pit)
+
+
 class DryReceiver:
     """--dry-run: stands in for the ResidentReceiver where there is no GPU, so that the launcher, the rank bookkeeping and
     the reductions of the N > 1 path can be exercised on CPU (tests/test_distributed.py).  Kernels are replaced by a sleep."""
@@ -187,6 +194,45 @@ def timed_steps(rx, steps, warmup, barrier_sync, overlap=False):
     barrier_sync()
     elapsed = time.perf_counter() - t0
     stage_ms = [float(np.mean([ev[k][j + 1].elapsed_ms(ev[k][j]) for k in range(steps)])) for j in range(len(fns))]
+    return elapsed, stage_ms, pass_ms, acq_ms
+
+
+def timed_group(group, steps, warmup, barrier_sync, overlap=True):
+    """timed_steps for a pipeline.ReceiverGroup: exactly K passes in total, dealt round robin to the receivers (each on its own host thread and
+    library streams), bracketed by barrier + device sync; HIP events on the stream every stage ran on, from all receivers."""
+    from qampy_amd import _lib
+    n = len(group.rx)
+    rx0 = group.rx[0]
+    pass_ms = [[] for _ in range(rx0.nstage)]
+    acq_ms = [[] for _ in range(rx0.nstage)]
+    order = ["start", "gram"] + ["train%d" % s for s in range(rx0.nstage)] + ["apply"]
+    group.run(warmup * n, overlap=overlap)
+    pools = [[_lib.Event() for _ in range((steps // n + 2) * (len(order) + 3) + 4)] for _ in range(n)]
+    marks = {}
+
+    def mark(i, k):
+        d = marks.setdefault((i, k), {})
+
+        def m(name):
+            e = pools[i].pop()
+            e.record()
+            d[name] = e
+            if name.startswith("train"):
+                st = int(name[5:])
+                p, a = group.rx[i].pit_timing[st]
+                pass_ms[st].append(list(p))
+                acq_ms[st].append(a)
+        return m
+    barrier_sync()
+    t0 = time.perf_counter()
+    group.run(steps, overlap=overlap, mark=mark)
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    full = [d for d in marks.values() if "apply" in d]
+    stage_ms = [float(np.mean([d[order[j + 1]].elapsed_ms(d[order[j]]) for d in full])) for j in range(len(order) - 1)]
+    if rx0.Mtestangles:
+        bps = [d["post_end"].elapsed_ms(d["post_begin"]) for d in marks.values() if "post_end" in d] + [d["bps"].elapsed_ms(d["apply"]) for d in full if "bps" in d]
+        stage_ms.append(float(np.mean(bps)))
     return elapsed, stage_ms, pass_ms, acq_ms
 
 
@@ -607,22 +653,46 @@ def tier_b_block(cfg, rx, stage_names, pass_ms, acq_ms, reports, value, ms, errs
                                   note="whole step against the fully fused lower bound of 88 B per symbol period"))
 
 
-def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_check, overlap=False):
+def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_check, overlap=False, in_flight=1):
     """Tier b (timed, `steps` passes) and the exact path beside it on the same resident capture: both blocks, the measured
     deviation and the certificate.  Returns (tier_b, tier_a, extras for the roofline).
 
     overlap: the timed passes are consecutive captures of a running receiver (ResidentReceiver.run(overlap=True): phase search of pass k
     beside the training of pass k + 1); the same receiver is then timed one capture at a time as well (`one_capture_at_a_time`)."""
-    rx = make_receiver(cfg, sig, tier="b", pit=pit)
-    rx.load(sig)
-    names, _ = stage_list(rx)
     overlap = bool(overlap and cfg["A"])
-    elapsed, stage_ms, pass_ms, acq_ms = timed_steps(rx, steps, warmup, barrier_sync, overlap=overlap)
+    group = None
+    if in_flight > 1 and overlap:
+        # `in_flight` captures on the GPU at a time (pipeline.ReceiverGroup): the timed K passes are dealt round robin to that many receivers
+        group = make_group(in_flight, cfg, sig, pit)
+        group.load(sig)
+        rx = group.rx[0]
+        names, _ = stage_list(rx)
+        elapsed, stage_ms, pass_ms, acq_ms = timed_group(group, steps, warmup, barrier_sync, overlap=True)
+    else:
+        rx = make_receiver(cfg, sig, tier="b", pit=pit)
+        rx.load(sig)
+        names, _ = stage_list(rx)
+        elapsed, stage_ms, pass_ms, acq_ms = timed_steps(rx, steps, warmup, barrier_sync, overlap=overlap)
     reports = rx.pit_reports()
     ser_rows = rx.ser(sig.symbols, maxlag=256, window=8192, trim=2000) if cfg["A"] else []
     errs = [(d["errors"], d["compared"]) for d in ser_rows]
     tb = tier_b_block(cfg, rx, names, pass_ms, acq_ms, reports, nsym * steps / elapsed / 1e6, elapsed / steps * 1e3, errs, nsym)
     tb["stages_ms"] = {n: round(t, 3) for n, t in zip(names, stage_ms)}
+    if group is not None:
+        # every receiver of the group: certified by the device, and bit for bit the result of receiver 0
+        others = [g.fetch() for g in group.rx[1:]]
+        mine = rx.fetch()
+        same = all(np.array_equal(o[k], mine[k]) for o in others for k in ("wxy", "eq", "out"))
+        conv = all(r["converged"] for rp in group.pit_reports() for r in rp)
+        del others, mine
+        k0 = max(2, min(steps, 10))
+        el0, ms0, _, _ = timed_steps(rx, k0, 1, barrier_sync, overlap=True)
+        tb["in_flight"] = dict(receivers=in_flight, all_receivers_identical=bool(same), all_receivers_converged=bool(conv),
+                               what="%d captures on the GPU at a time, one host thread and one set of library streams per receiver (pipeline.ReceiverGroup); "
+                                    "pass_ms / stages_ms are means over all receivers inside the timed region" % in_flight,
+                               one_receiver=dict(value=round(nsym * k0 / el0 / 1e6, 4), ms_per_step=round(el0 / k0 * 1e3, 3), steps=k0,
+                                                 stages_ms={n: round(t, 3) for n, t in zip(names, ms0)}))
+        tb["converged"] = bool(tb["converged"] and same and conv)
     if overlap:
         k1 = max(2, min(steps, 5))
         el1, ms1, _, _ = timed_steps(rx, k1, 1, barrier_sync)
@@ -666,7 +736,33 @@ def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_
         del rxa
     else:
         tb["certified"] = tb["converged"]
+    if group is not None:
+        group.close()
     return tb, ta, dict(rx=rx, names=names, stage_ms=stage_ms, elapsed=elapsed, errs=errs, reports=reports)
+
+
+def in_flight_block(cfg, sig, nsym, n, steps, barrier_sync, pit):
+    """Informational: `n` captures on the GPU at a time (pipeline.ReceiverGroup, one host thread + library stream set per receiver), `steps` passes in
+    total, no events inside the timed region; every receiver certified by the device and bit-identical to receiver 0."""
+    g = make_group(n, cfg, sig, pit)
+    try:
+        g.load(sig)
+        g.run(2 * n)
+        barrier_sync()
+        t0 = time.perf_counter()
+        g.run(steps)
+        barrier_sync()
+        el = time.perf_counter() - t0
+        res = [r.fetch() for r in g.rx]
+        same = all(np.array_equal(o[k], res[0][k]) for o in res[1:] for k in ("wxy", "eq", "out"))
+        reps = g.pit_reports()
+        return dict(receivers=n, value=round(nsym * steps / el / 1e6, 4), unit="MSym/s", ms_per_step=round(el / steps * 1e3, 3), steps=steps,
+                    all_receivers_identical=bool(same), all_receivers_converged=bool(all(r["converged"] for rp in reps for r in rp)),
+                    passes=[[r["passes"] for r in rp] for rp in reps],
+                    note="informational, never the headline: %d receivers side by side, each the overlapped single receiver of the headline; what one capture leaves "
+                         "idle (control path between the relaxation passes, acquisition, eigen-solver) the other uses" % n)
+    finally:
+        g.close()
 
 
 def cert_snr_block(cfg, snr_db, nsym, seed, barrier_sync, pit, overlap=False):
@@ -779,6 +875,7 @@ def main():
     ap.add_argument("--bank-trainer", default="iterative", choices=["auto", "iterative"])
     ap.add_argument("--bank", type=int, default=128, help="channels of the informational channel-bank run at N=1 (0 = skip)")
     ap.add_argument("--cpu-bank-workers", type=int, default=-1, help="concurrent single-threaded CPU pipelines of the bank's CPU leg (-1: min(cores, 128), 0: skip)")
+    ap.add_argument("--in-flight", type=int, default=1, help="tier b: captures on the GPU at a time (pipeline.ReceiverGroup, one host thread per receiver); 1 = one receiver")
     ap.add_argument("--no-overlap", action="store_true", help="tier b: time one capture at a time only (default: consecutive captures, the phase search of "
                                                               "pass k on stream 2 beside the training of pass k + 1)")
     ap.add_argument("--no-extra-shapes", action="store_true", help="skip the ns / c2 / 24 dB / loose-tolerance blocks of the default line")
@@ -877,7 +974,7 @@ def main():
         tier_b = tier_b_block(cfg, rx, stage_names, pass_ms, acq_ms, reports, nsym * args.steps / elapsed / 1e6, elapsed / args.steps * 1e3, errs, nsym)
         tier_b["certified"] = tier_b["converged"]
     elif args.tier == "b":
-        tier_b, tier_a, ex = run_pair(cfg, sig, nsym, args.steps, args.warmup, barrier_sync, pit, args.exact_steps if world == 1 else 0, tol_check, overlap=overlap)
+        tier_b, tier_a, ex = run_pair(cfg, sig, nsym, args.steps, args.warmup, barrier_sync, pit, args.exact_steps if world == 1 else 0, tol_check, overlap=overlap, in_flight=args.in_flight)
         rx, stage_names, stage_ms, elapsed, errs, reports = ex["rx"], ex["names"], ex["stage_ms"], ex["elapsed"], ex["errs"], ex["reports"]
     else:
         rx = make_receiver(cfg, sig, tier="a")
@@ -939,6 +1036,9 @@ def main():
             # capture handed over and waited for is beside it
             out["config"]["pipelining"] = "consecutive captures; phase search of pass k (stream 2) beside the training of pass k + 1 (stream 0); --no-overlap for one at a time"
             out["one_capture_at_a_time"] = tier_b["pipelining"]["one_capture_at_a_time"]
+        if tier_b.get("in_flight"):
+            out["config"]["in_flight"] = "%d captures on the GPU at a time (ReceiverGroup: one host thread + stream set per receiver); --in-flight 1 for one receiver" % tier_b["in_flight"]["receivers"]
+            out["one_receiver"] = tier_b["in_flight"]["one_receiver"]
     if tier_a is not None:
         out["tier_a"] = tier_a
 
@@ -1081,10 +1181,12 @@ def main():
                                        err_trace_rms_dev_vs_exact=dv["err_trace_rms_dev_vs_exact"],
                                        note="informational: the same solver held to a 10 x looser deviation (SER-equivalent tier of SURVEY 7.3-1(b)); never the headline")
             del rx2, rxa, ex2
+            if overlap and args.in_flight == 1:
+                out["two_in_flight"] = in_flight_block(cfg, sig, nsym, 2, 2 * max(4, min(args.steps, 20)), barrier_sync, pit)
             if args.workload == "c3":
                 out["cert_24dB"] = cert_snr_block(cfg, 24.0, min(nsym, 1 << 21), 1001, barrier_sync, pit, overlap=overlap)
                 for key in ("ns", "c2"):
-                    out[key] = shape_block(key, barrier_sync, pit, 3, overlap=overlap)
+                    out[key] = shape_block(key, barrier_sync, pit, 10, overlap=overlap)
                 out["adaptive_step"] = adaptive_block()
             _lib.call("qh_release_scratch")
         except Exception as e:                    # informational blocks never take the headline down

@@ -77,7 +77,10 @@ int qh_release_scratch(void);
  * Streams 0 and 1 are equals (a tier-b trainer puts its eigen-solver on whichever of the two is not current); stream 2 has the
  * lowest queue priority and is meant for chip-wide streaming work (phase search of capture k) overlapped with the latency-bound
  * trainers of capture k+1 on stream 0 (ResidentReceiver.run(overlap=True)).
- * Scratch buffers are per library, not per stream: overlap only stages that use different ones (trainers + Gram tables on
+ * Streams, scratch buffers and the events of the tier-b solver are PER HOST THREAD: a thread that calls into the library gets its own
+ * set on first use (same device), so several captures can be in flight on one GPU, one driving thread each (pipeline.py ReceiverGroup);
+ * qh_sync / qh_release_scratch act on the calling thread's set.  Device memory and the staging pool are per process.
+ * Within a thread scratch buffers are per library, not per stream: overlap only stages that use different ones (trainers + Gram tables on
  * one stream; filter, phase search and SER harness on the other - what ChannelBank.run_pipelined does). */
 int qh_use_stream(int idx);
 int qh_stream_wait_event(void *ev);

@@ -7,8 +7,11 @@
 
 namespace qh {
 
-hipStream_t g_stream = nullptr;          // the stream every entry point enqueues on: one of g_streams (qh_use_stream)
-static hipStream_t g_streams[4] = {nullptr, nullptr, nullptr, nullptr};    // three the caller can switch between (qh_use_stream 0..2) + one for small helper launches
+// Streams, scratch slots and the tier-b solver's events are PER HOST THREAD: a thread that calls into the library gets its own set on first
+// use, so that several captures can be in flight on one GPU, each driven by its own thread (pipeline.py ReceiverGroup); within a thread
+// everything is ordered as before.  Device memory, the staging pool and the trainer selection are per process.
+thread_local hipStream_t g_stream = nullptr;          // the stream every entry point enqueues on: one of g_streams (qh_use_stream)
+static thread_local hipStream_t g_streams[4] = {nullptr, nullptr, nullptr, nullptr};    // three the caller can switch between (qh_use_stream 0..2) + one for small helper launches
 int g_device = -1;
 static thread_local std::string g_err;
 static std::mutex g_mu;
@@ -26,7 +29,7 @@ static int init_device(int device)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_stream && device == g_device) return QH_OK;
-    if (g_stream) {
+    if (g_device >= 0 && device != g_device) {
         // One device per process: scratch buffers, streams, events and the kernels' per-device attributes belong to the device
         // the library was initialised on; run one process per GPU (bench.py --gpus N does).
         set_error("libqampy_hip is already initialised on device " + std::to_string(g_device) + ": one device per process");
@@ -80,12 +83,12 @@ hipStream_t helper_stream() { return g_streams[3]; }
 int ensure_init()
 {
     if (g_stream) return QH_OK;
-    return init_device(0);
+    return init_device(g_device >= 0 ? g_device : 0);       // first call of this thread: the process's device, this thread's streams
 }
 
 // grow-only scratch slots so that the resident pipeline never allocates (and never synchronises) inside a timed region
-void *g_scratch[16] = {nullptr};
-size_t g_scratch_n[16] = {0};
+thread_local void *g_scratch[16] = {nullptr};
+thread_local size_t g_scratch_n[16] = {0};
 // form of the exact trainer: 0 = automatic (or the QAMPY_HIP_TRAINER environment variable), 1 direct, 2 look-ahead, 3 block-iterative
 int g_trainer = 0;
 const char *trainer_force()

@@ -8,7 +8,7 @@
 namespace qh {
 
 // ---------------------------------------------------------------------------------------------- host-side state
-extern hipStream_t g_stream;
+extern thread_local hipStream_t g_stream;     // per host thread (api.hip)
 extern int g_device;
 void set_error(const std::string &s);
 int hip_fail(hipError_t e, const char *what, const char *file, int line);

@@ -1997,7 +1997,7 @@ static __global__ void __launch_bounds__(256) pit_front_kernel(const Zf *D, cons
 // ------------------------------------------------------------------------------------------------ host side
 // kernel time of the most recent call (HIP events around the trainer launches; the host synchronises after each anyway)
 struct PitTiming { int npass; float pass_ms[QH_PIT_MAXPASS]; float acq_ms; };
-inline PitTiming &pit_timing() { static PitTiming t; return t; }
+inline PitTiming &pit_timing() { static thread_local PitTiming t; return t; }
 // Events and a pinned landing area for the flags the host reads: one set per pass / acquisition chunk, because the work of
 // pass p + 1 is enqueued BEFORE the host looks at the flag of pass p (every kernel of a pass starts with `if (done) return`,
 // so a pass enqueued in vain costs a few empty launches instead of an idle GPU during every host round trip).
@@ -2005,7 +2005,7 @@ constexpr int PIT_NEV = (QH_PIT_MAXPASS > QH_PIT_MAXCHUNK ? QH_PIT_MAXPASS : QH_
 struct PitEvents { hipEvent_t t0[PIT_NEV], t1[PIT_NEV], flag[PIT_NEV]; int32_t *hflag; float *hview; bool ok; };
 inline PitEvents &pit_events()
 {
-    static PitEvents e = {{nullptr}, {nullptr}, {nullptr}, nullptr, nullptr, false};
+    static thread_local PitEvents e = {{nullptr}, {nullptr}, {nullptr}, nullptr, nullptr, false};
     if (!e.ok) {
         for (int i = 0; i < PIT_NEV; i++) { (void)hipEventCreate(&e.t0[i]); (void)hipEventCreate(&e.t1[i]); (void)hipEventCreateWithFlags(&e.flag[i], hipEventDisableTiming); }
         (void)hipHostMalloc((void **)&e.hflag, PIT_NEV * sizeof(int32_t), hipHostMallocDefault);
@@ -2065,7 +2065,7 @@ inline bool pit_basis_ok(int ntot, size_t elem) { return ntot <= PIT_EIGMAX && (
 // whatever the current stream does next - the acquisition and the first pass do not need the basis); the trainer waits for
 // it right before its first correction.
 struct PitBasisSync { hipEvent_t in = nullptr, out = nullptr; bool pending = false; };
-inline PitBasisSync &pit_basis_sync() { static PitBasisSync b; return b; }
+inline PitBasisSync &pit_basis_sync() { static thread_local PitBasisSync b; return b; }
 template <typename R>
 int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis, int overlap = 0)
 {
@@ -2531,7 +2531,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             // the coarse model of this sweep, measured at its seed taps: two small launches on the library's helper stream, beside pass 0 (which
             // does not need it; its analysis waits for it) and beside the basis build of a cold sweep on the other stream.
             ma.sg = sg; ma.rot = rot_use;
-            static hipEvent_t ev_seed = nullptr, ev_model = nullptr;
+            static thread_local hipEvent_t ev_seed = nullptr, ev_model = nullptr;
             if (!ev_seed) { QH_HIP(hipEventCreateWithFlags(&ev_seed, hipEventDisableTiming)); QH_HIP(hipEventCreateWithFlags(&ev_model, hipEventDisableTiming)); }
             hipStream_t ss = helper_stream();
             QH_HIP(hipEventRecord(ev_seed, g_stream));

@@ -246,6 +246,101 @@ class ResidentReceiver:
         return dict(train=train, apply=apply_, bps=bps, total=train + apply_ + bps)
 
 
+class ReceiverGroup:
+    """
+    ``n`` captures IN FLIGHT on one GPU: ``n`` :class:`ResidentReceiver` objects of identical shape, each driven by its own host thread.
+    The library keeps streams, scratch buffers and the tier-b solver's events per host thread (csrc/api.hip), so the receivers share
+    nothing but the chip: what one capture leaves idle (between the relaxation passes of its trainer, during acquisition and the
+    eigen-solver) the others use.  Every capture gets exactly the result of a receiver that runs alone (same kernels, same data); what
+    changes is when the work is scheduled.  Measured at C3 (profiles/r04_in_flight.txt): 2 receivers 1.1x the throughput of one; two
+    receiver PROCESSES on the GPU reach 1.2x (their streams do not share hardware queues).
+
+        group = ReceiverGroup(2, nmodes, L, os, M, Ntaps, mu, tier="b", ...)      # the arguments of ResidentReceiver
+        group.load(E)                          # the same capture into every receiver (or group.rx[i].load(E_i))
+        group.run(steps)                       # `steps` passes in total, dealt round robin; returns when all of them are complete
+        group.rx[i].fetch()                    # results of the last pass of receiver i
+    """
+
+    def __init__(self, n, *args, **kw):
+        import queue
+        import threading
+        if n < 1:
+            raise ValueError("at least one receiver")
+        self.rx = [ResidentReceiver(*args, **kw) for _ in range(int(n))]
+        _lib.sync()
+        self._jobs = [queue.SimpleQueue() for _ in self.rx]
+        self._done = queue.SimpleQueue()
+        self._threads = [threading.Thread(target=self._work, args=(i,), daemon=True, name="qampy-receiver-%d" % i) for i in range(len(self.rx))]
+        for t in self._threads:
+            t.start()
+
+    def _work(self, i):
+        while True:
+            job = self._jobs[i].get()
+            if job is None:
+                return
+            try:
+                self._done.put((i, job(self.rx[i]), None))
+            except BaseException as e:             # handed to the caller of run() / map()
+                self._done.put((i, None, e))
+
+    def map(self, fn, which=None):
+        """``fn(receiver)`` on the thread of every receiver (or of those in ``which``) at the same time; the list of results."""
+        which = range(len(self.rx)) if which is None else list(which)
+        for i in which:
+            self._jobs[i].put(fn)
+        res, err = {}, None
+        for _ in which:
+            i, r, e = self._done.get()
+            res[i], err = r, (e if e is not None else err)
+        if err is not None:
+            raise err
+        return [res[i] for i in which]
+
+    def load(self, E):
+        for r in self.rx:
+            r.load(E)
+        _lib.sync()
+
+    def run(self, steps, overlap=True, mark=None):
+        """``steps`` passes of the hot path in total, receiver ``i`` taking passes i, i + n, ...; returns when all are complete on the
+        device.  ``overlap``: as ResidentReceiver.run.  ``mark(i, k)``: a mark callback for pass k of receiver i (bench.py)."""
+        n = len(self.rx)
+        share = [len(range(i, int(steps), n)) for i in range(n)]
+
+        def job(i):
+            def go(rx):
+                for k in range(share[i]):
+                    rx.run(overlap=overlap, mark=mark(i, k) if mark else None)
+                rx.wait_post(mark(i, share[i]) if mark else None)
+                _lib.sync()                    # this thread's streams
+            return go
+        for i in range(n):
+            self._jobs[i].put(job(i))
+        err = None
+        for _ in range(n):
+            _, _, e = self._done.get()
+            err = e if e is not None else err
+        if err is not None:
+            raise err
+
+    def pit_reports(self):
+        return [r.pit_reports() for r in self.rx]
+
+    def close(self):
+        for q_ in self._jobs:
+            q_.put(None)
+        for t in self._threads:
+            t.join(timeout=10.)
+        self._threads = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ChannelBank:
     """
     ``nch`` independent captures of identical shape (WDM channels) resident on ONE GPU and processed

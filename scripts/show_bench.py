@@ -6,7 +6,14 @@ d = json.loads(lines[-1])
 for k in ("value", "ms_per_step", "headline_tier", "stages_ms", "speedup_vs_cpu", "note", "extra_shapes_error"):
     if d.get(k) is not None:
         print(k, d.get(k))
+for k in ("one_receiver", "one_capture_at_a_time"):
+    if d.get(k):
+        print(k, d[k]["value"], d[k]["ms_per_step"], d[k].get("stages_ms"))
+if d.get("two_in_flight"):
+    print("two_in_flight", {k: v for k, v in d["two_in_flight"].items() if k != "note"})
 tb = d.get("tier_b")
+if tb and tb.get("in_flight"):
+    print("in_flight", {k: v for k, v in tb["in_flight"].items() if k not in ("what", "one_receiver")})
 if tb:
     print("tier_b", tb["value"], "certified", tb["certified"], tb.get("checks"))
     for st in tb["stages"]:

@@ -528,3 +528,37 @@ def test_overlapped_passes_give_the_results_of_one_capture_at_a_time(tier):
     res0 = rx.fetch()
     for k in ("wxy", "eq", "out", "ph", "idx"):
         assert np.array_equal(res0[k], serial[0][k]), (tier, k, "plain run after overlapped ones")
+
+
+@pytest.mark.parametrize("tier", ["a", "b"])
+def test_receiver_group_gives_every_capture_the_single_receiver_result(tier):
+    """pipeline.ReceiverGroup: two captures in flight, one host thread and one set of library streams / scratch buffers each (csrc/api.hip keeps
+    them per thread).  Different captures in the two receivers, several passes each: bit for bit the results of a receiver that runs alone."""
+    from qampy_amd.pipeline import ReceiverGroup
+    nsym, M, ntaps, mu = 2 ** 17, 64, 41, (1e-3, 5e-4)
+    caps = [synth.make_capture_dev(M, nsym, nmodes=2, snr_db=30, theta=np.pi / 5.6, dgd=30e-12, linewidth=100., seed=sd) for sd in (1000, 1003)]
+    kw = dict(methods=("cma", "mrde"), Niter=(1, 1), Mtestangles=64, Nbps=20, alphabet=caps[0]["alphabet_host"])
+    rx = ResidentReceiver(2, 2 * nsym, 2, M, ntaps, mu, tier=tier, **kw)
+    alone = []
+    for c in caps:
+        rx.E.copy_from(c["E"])
+        rx.run()
+        alone.append(rx.fetch())
+    g = ReceiverGroup(2, 2, 2 * nsym, 2, M, ntaps, mu, tier=tier, **kw)
+    try:
+        for r, c in zip(g.rx, caps):
+            r.E.copy_from(c["E"])
+        _lib.sync()
+        g.run(6)                                 # three passes per receiver, at the same time
+        for i, r in enumerate(g.rx):
+            res = r.fetch()
+            for k in ("wxy", "eq", "out", "ph", "idx"):
+                assert np.array_equal(res[k], alone[i][k]), (tier, i, k)
+            assert all(np.array_equal(a, b) for a, b in zip(res["err"], alone[i]["err"])), (tier, i, "error traces")
+        if tier == "b":
+            assert all(st["converged"] for rp in g.pit_reports() for st in rp)
+        # an exception on a worker thread reaches the caller
+        with pytest.raises(ZeroDivisionError):
+            g.map(lambda r: 1 // 0)
+    finally:
+        g.close()
