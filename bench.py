@@ -686,7 +686,8 @@ def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_
         conv = all(r["converged"] for rp in group.pit_reports() for r in rp)
         del others, mine
         k0 = max(2, min(steps, 10))
-        el0, ms0, _, _ = timed_steps(rx, k0, 1, barrier_sync, overlap=True)
+        from qampy_amd import _lib as _l
+        el0, ms0, _, _ = group.map(lambda r: timed_steps(r, k0, 1, _l.sync, overlap=True), which=[0])[0]      # on the receiver's own thread (its streams, its scratch)
         tb["in_flight"] = dict(receivers=in_flight, all_receivers_identical=bool(same), all_receivers_converged=bool(conv),
                                what="%d captures on the GPU at a time, one host thread and one set of library streams per receiver (pipeline.ReceiverGroup); "
                                     "pass_ms / stages_ms are means over all receivers inside the timed region" % in_flight,
@@ -695,7 +696,10 @@ def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_
         tb["converged"] = bool(tb["converged"] and same and conv)
     if overlap:
         k1 = max(2, min(steps, 5))
-        el1, ms1, _, _ = timed_steps(rx, k1, 1, barrier_sync)
+        if group is not None:
+            el1, ms1, _, _ = group.map(lambda r: timed_steps(r, k1, 1, _l.sync), which=[0])[0]
+        else:
+            el1, ms1, _, _ = timed_steps(rx, k1, 1, barrier_sync)
         tb["pipelining"] = dict(
             what="consecutive captures: the phase search of pass k runs on stream 2 beside the training of pass k + 1 (same kernels, same results bit for bit); "
                  "stages_ms are event pairs on the stream each stage ran on, so their sum exceeds ms_per_step by what ran side by side",

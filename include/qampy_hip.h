@@ -72,6 +72,8 @@ int qh_memcpy_d2d(void *dst, const void *src, size_t bytes);
  * qh_release_scratch frees the grow-only scratch buffers (Gram tables above all - up to QAMPY_HIP_GRAM_BUDGET_GB) after
  * draining both streams; they are re-allocated on demand. */
 int qh_release_scratch(void);
+int qh_thread_release(void);                   /* destroy the calling thread's streams and scratch buffers (they come back on the next call): a worker
+                                                  thread before it ends, the main thread at exit (qampy_amd._lib registers it with atexit) */
 /* Three library streams.  Every entry point enqueues on the CURRENT one (0 after qh_init); qh_use_stream(0..2) switches it,
  * qh_stream_wait_event makes the current stream wait for an event recorded on another one, qh_sync drains all of them.
  * Streams 0 and 1 are equals (a tier-b trainer puts its eigen-solver on whichever of the two is not current); stream 2 has the

@@ -91,6 +91,7 @@ SIGNATURES = {
     "qh_set_trainer": [_i],
     "qh_use_stream": [_i],
     "qh_release_scratch": [],
+    "qh_thread_release": [],
     "qh_stream_wait_event": [_vp],
     "qh_stream_handle": [C.POINTER(_vp)],
     "qh_ser_c64_dev": [_vp, _i64, _vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp],
@@ -161,6 +162,8 @@ def load():
         if ver != ABI_VERSION:
             raise RuntimeError("%s has C-ABI version %d, this package binds version %d: rebuild it (qampy_amd/csrc/build.sh)" % (LIB_PATH, ver, ABI_VERSION))
         _lib = lib
+        import atexit
+        atexit.register(lib.qh_thread_release)       # the main thread's streams, before the runtime's own teardown
     return _lib
 
 

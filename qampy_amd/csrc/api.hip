@@ -194,6 +194,20 @@ int qh_release_scratch(void)
     qh::pool_release();
     return QH_OK;
 }
+int qh_thread_release(void)
+{
+    // the calling thread's streams and scratch buffers (a worker thread before it ends; the main thread before the process exits - a
+    // stream created with a CU mask must not be left to the runtime's own teardown when a profiler is attached)
+    if (!qh::g_stream) return QH_OK;
+    for (int i = 0; i < 4; i++) if (qh::g_streams[i]) (void)hipStreamSynchronize(qh::g_streams[i]);
+    for (int i = 0; i < 16; i++) {
+        if (qh::g_scratch[i]) (void)hipFree(qh::g_scratch[i]);
+        qh::g_scratch[i] = nullptr; qh::g_scratch_n[i] = 0;
+    }
+    for (int i = 0; i < 4; i++) if (qh::g_streams[i]) { (void)hipStreamDestroy(qh::g_streams[i]); qh::g_streams[i] = nullptr; }
+    qh::g_stream = nullptr;
+    return QH_OK;
+}
 int qh_use_stream(int idx)
 {
     int rc = qh::ensure_init();

@@ -278,6 +278,7 @@ class ReceiverGroup:
         while True:
             job = self._jobs[i].get()
             if job is None:
+                _lib.call("qh_thread_release")     # this thread's streams and scratch buffers
                 return
             try:
                 self._done.put((i, job(self.rx[i]), None))

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $C -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o c3 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --bank 0 --exact-steps 1 --no-extra-shapes > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc $C -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$C -o c3 -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --bank 0 --exact-steps 1 --no-extra-shapes --no-overlap > $GRAFT_REPO_ROOT/gpurun_out/pmc_$C.log 2>&1
   echo "$C rc=$?"
 done
 cd $GRAFT_REPO_ROOT

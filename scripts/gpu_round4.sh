@@ -20,6 +20,7 @@ python scripts/rocpd_timeline.py $DB > $R/c3_timeline.txt
 find $R/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $R/c3_rocprofv3_kernel_stats.csv
 rm -rf $R/kt
 timeout 900 python bench.py --workload c5 --steps 3 > $R/bench_c5.json 2> $R/bench_c5.err
+( python scripts/threads_probe.py c3 100 1 2 3; python scripts/dual_probe.py 1 c3 200 | tail -1; python scripts/dual_probe.py 2 c3 200 | tail -1 ) > $R/in_flight.txt 2>&1
 FULL=1 timeout 900 python scripts/pit_methods.py > $R/pit_methods.txt 2>&1
 timeout 600 python scripts/pit_survey.py > $R/pit_survey_steps.txt 2>&1
 ls -la $R
