@@ -39,7 +39,7 @@ extern "C" {
  * arguments.  History: 1 = round 1; 2 = round 2 (qh_bps_recover_*_dev gained `angles`, qh_train_equaliser_*_pit_dev takes
  * (gram, opts, report), the *_seg_dev entry points were removed - unversioned at the time); 3 = round 3 (qh_pit_opts:
  * start, dev_safety; qh_pit_report: deviation[]); 4 = qh_pit_opts: adaptive. */
-#define QH_ABI_VERSION 6
+#define QH_ABI_VERSION 7
 int qh_abi_version(void);
 
 /* ---- status codes (python shim: 1,2 -> ValueError, 3,4 -> RuntimeError) */
@@ -332,6 +332,8 @@ typedef struct qh_pit_opts {
                              * whole call is given to the exact form; != 0: off (ABI 6) */
     int32_t acq_anneal;     /* acquisition: 0 (default) the second and later chunks run at half the step of the one before, never below 2 mu; > 0: never
                              * below acq_anneal x mu; < 0: every chunk at the gear-shifted step (rounds 2-3) (ABI 6) */
+    double mu_hint;         /* fixed step: the caller's HOST copy of *mu (> 0), so that the call does not have to read it back; with it - and acq_chunk
+                             * given when acquire != 0 - the call enqueues its whole prologue without a host synchronisation (0: read back) (ABI 7) */
 } qh_pit_opts;
 typedef struct qh_pit_report {
     int32_t segments, passes, converged, acq_chunks;

@@ -99,7 +99,7 @@ SIGNATURES = {
 }
 
 PIT_MAXPASS, PIT_MAXCHUNK = 24, 32
-ABI_VERSION = 6              # QH_ABI_VERSION of include/qampy_hip.h
+ABI_VERSION = 7              # QH_ABI_VERSION of include/qampy_hip.h
 
 
 class PitOpts(C.Structure):
@@ -108,7 +108,7 @@ class PitOpts(C.Structure):
                 ("tol", C.c_double), ("gear", C.c_double), ("acq_bound", C.c_double), ("acq_plateau", C.c_double),
                 ("acq_chunk", C.c_int64), ("acq_max", C.c_int64), ("correction", C.c_int32), ("head_steps", C.c_int32), ("basis", C.c_void_p), ("corr_beta", C.c_double),
                 ("seg_first", C.c_int32), ("seg_count", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p),
-                ("start", C.c_int32), ("exchange_on_stream", C.c_int32), ("dev_safety", C.c_double), ("adaptive", C.c_int32), ("exact_redo_off", C.c_int32), ("head_auto_off", C.c_int32), ("acq_anneal", C.c_int32)]
+                ("start", C.c_int32), ("exchange_on_stream", C.c_int32), ("dev_safety", C.c_double), ("adaptive", C.c_int32), ("exact_redo_off", C.c_int32), ("head_auto_off", C.c_int32), ("acq_anneal", C.c_int32), ("mu_hint", C.c_double)]
 
 
 #: signature of ``qh_pit_opts.exchange``: (user, device pointer of the segments' end taps, bytes) -> 0

@@ -1812,6 +1812,12 @@ __global__ void __launch_bounds__(1024) pit_adapt_scan_kernel(R *rS, const R *rE
 }
 template <typename R> __global__ void pit_adapt_finish_kernel(R *mu, const R *rE, int n) { *mu = (R)1 / rE[n - 1]; }
 
+struct PitModes { int64_t m[16]; };
+static __global__ void pit_modes_kernel(int64_t *dst, PitModes pm, int n)
+{
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = pm.m[threadIdx.x];
+}
+
 constexpr int PIT_GT_THREADS = 1024;
 // model != nullptr (measured coarse model): the gain comes from it, and the components alpha[s] of the defects along the signal direction
 // (pit_bound_kernel) are scanned HERE with exp(-mu T K) - in the eigenbasis of K two real first-order recurrences per mode -
@@ -2325,12 +2331,21 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         ad_rS = (R *)(ad_errh + (size_t)nmodes * head); ad_rE = ad_rS + nS;
         ad_M = (float *)(ad_rE + nS); ad_rP = ad_M + nS; ad_dP = ad_rP + nS; ad_chg = ad_dP + nS;
     }
-    QH_HIP(hipMemcpyAsync(modes_dev, modes, (size_t)nsel * sizeof(int64_t), hipMemcpyHostToDevice, g_stream));
+    {
+        PitModes pm;                                              // the selected modes go to the device as a kernel argument: no copy from the caller's memory to wait for
+        for (int j = 0; j < 16; j++) pm.m[j] = j < nsel ? modes[j] : 0;
+        hipLaunchKernelGGL(pit_modes_kernel, dim3(1), dim3(16), 0, g_stream, modes_dev, pm, nsel);
+    }
+    // What the host needs to know before it can enqueue the rest: the step size (a sweep with mu = 0 takes the exact form) and, for a cold
+    // start, the gear-shifted step size pit_setup_kernel chose (it sizes the acquisition chunks).  A caller that hands over its host copy of
+    // the step (mu_hint) and the chunk length (acq_chunk: from the report of an earlier capture) spares the call its one synchronisation -
+    // ~90 us of idle GPU per stage at C3.
+    const bool need_mu = adaptive || !(o.mu_hint > 0), need_acq = o.acquire && !(o.acq_chunk > 0);
     R mu_acq_h = 0;                                               // the gear-shifted step size pit_setup_kernel chose (sizes the acquisition run)
-    if (o.acquire) QH_HIP(hipMemcpyAsync(&mu_acq_h, mu_acq, sizeof(R), hipMemcpyDeviceToHost, g_stream));
-    R mu_host = 1;
-    QH_HIP(hipMemcpyAsync(&mu_host, mu_dev, sizeof(R), hipMemcpyDeviceToHost, g_stream));
-    QH_HIP(hipStreamSynchronize(g_stream));                       // `modes` is the caller's memory
+    if (need_acq) QH_HIP(hipMemcpyAsync(&mu_acq_h, mu_acq, sizeof(R), hipMemcpyDeviceToHost, g_stream));
+    R mu_host = need_mu ? (R)1 : (R)o.mu_hint;
+    if (need_mu) QH_HIP(hipMemcpyAsync(&mu_host, mu_dev, sizeof(R), hipMemcpyDeviceToHost, g_stream));
+    if (need_mu || need_acq) QH_HIP(hipStreamSynchronize(g_stream));
     if (!adaptive && !(mu_host != 0)) {                           // a sweep that moves nothing (or a NaN step): the exact form, as it is
         if ((rc = train_dev<R>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, 0, symbols, nsy, method, err, 0, gram))) return rc;
         const int32_t hdr[3] = {1, 0, 2};
@@ -2443,6 +2458,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
 
     PitTiming &tm = pit_timing();
     tm.npass = 0; tm.acq_ms = 0;
+    bool acq_timed = false;                                       // the acquisition's event pair (read when the passes are through)
     PitEvents &ev = pit_events();
     QH_REQUIRE(ev.ok, "train_equaliser: no pinned memory for the pass flags");
     // Way out (every tier-b call returns the reference's result): a sweep the passes do not certify - estimate stuck above tol, pass
@@ -2463,7 +2479,6 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             const int nchunks = (int)(amax / CH);
             auto enqueue_chunk = [&](int c) -> int {
                 const int64_t step0 = (int64_t)c * CH;
-                QH_HIP(hipEventRecord(ev.t0[c], g_stream));
                 if (block_form) {
                     LaArgs<R> lp = la;
                     lp.E = (const Cx<R> *)E + step0 * os; lp.L = L - step0 * os; lp.TrSyms = CH; lp.nch = 1; lp.wx = (Cx<R> *)wx; lp.wx_cs = 0;
@@ -2476,21 +2491,18 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                     int r = launch_any<R>(tp);
                     if (r) return r;
                 }
-                QH_HIP(hipEventRecord(ev.t1[c], g_stream));
                 hipLaunchKernelGGL((pit_acq_monitor_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const Cx<R> *)err, (int64_t)(TrSyms * Niter), step0, CH,
                                    nsel, (const int64_t *)modes_dev, plateau, ctrl);
                 if (o.acq_anneal >= 0) hipLaunchKernelGGL((pit_acq_anneal_kernel<R>), dim3(1), dim3(1), 0, g_stream, mu_acq, (const R *)mu_dev, o.acq_anneal > 0 ? (double)o.acq_anneal : 2.0);
-                QH_HIP(hipMemcpyAsync(&ev.hflag[c], &ctrl->acq_done, sizeof(int32_t), hipMemcpyDeviceToHost, g_stream));
-                QH_HIP(hipEventRecord(ev.flag[c], g_stream));
                 return QH_OK;
             };
-            if (nchunks > 0 && (rc = enqueue_chunk(0))) return rc;
-            for (int c = 0; c < nchunks; c++) {
-                if (c + 1 < nchunks && (rc = enqueue_chunk(c + 1))) return rc;     // skipped on the device once the plateau is reached
-                QH_HIP(hipEventSynchronize(ev.flag[c]));
-                { float ms = 0; QH_HIP(hipEventElapsedTime(&ms, ev.t0[c], ev.t1[c])); tm.acq_ms += ms; }
-                if (ev.hflag[c]) break;
-            }
+            // All chunks are enqueued at once and the host does not wait for any of them: once the plateau is reached (or the run diverged) the
+            // monitor sets acq_done on the device and the chunks behind it return at once, and everything downstream reads the device's flags.
+            // (Rounds 2-3 waited for every chunk's flag: ~30 us of idle GPU after the last one.)  One event pair around the run times it.
+            if (nchunks > 0) { QH_HIP(hipEventRecord(ev.t0[PIT_NEV - 1], g_stream)); acq_timed = true; }
+            for (int c = 0; c < nchunks; c++)
+                if ((rc = enqueue_chunk(c))) return rc;
+            if (nchunks > 0) QH_HIP(hipEventRecord(ev.t1[PIT_NEV - 1], g_stream));
             hipLaunchKernelGGL((pit_acq_finish_kernel<R>), dim3((unsigned)((wset + 255) / 256)), dim3(256), 0, g_stream, (Cx<R> *)wx, (const Cx<R> *)w_start, (int)wset, ctrl);
             QH_HIP(hipGetLastError());
         }
@@ -2701,6 +2713,12 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             }
             if (ev.hview[2 * p] != 0.f) { certified = ev.hview[2 * p] == 1.f; break; }
             if (p + 1 < npass && !ahead && (rc = enqueue_pass(p + 1))) return rc;
+        }
+        if (acq_timed) {                                          // (complete long before the passes were)
+            float ms = 0;
+            QH_HIP(hipEventSynchronize(ev.t1[PIT_NEV - 1]));
+            QH_HIP(hipEventElapsedTime(&ms, ev.t0[PIT_NEV - 1], ev.t1[PIT_NEV - 1]));
+            tm.acq_ms = ms; acq_timed = false;
         }
         if (!adaptive && !certified && redo_ok && !split && depth < 3 && o.head_auto_off == 0) {
             // Stalled on the START of the sweep?  A stage that begins far from its own fixed point - a decision-directed stage whose start

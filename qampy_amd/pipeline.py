@@ -91,6 +91,8 @@ class ResidentReceiver:
             self.pit_report = [_k.PitReportBuffer() for _ in methods]
             for s_, o in enumerate(self.pit):          # segment grid from the host copy of mu: the call then never synchronises
                 o.setdefault("acquire", 1 if s_ == 0 else 0)
+                if not self.adaptive[s_]:              # fixed step: the host copy spares the call the read-back of *mu (qh_pit_opts.mu_hint)
+                    o.setdefault("mu_hint", float(self.mu0[s_]))
                 if self.adaptive[s_]:                  # adaptive step: the library's own grid (exact head + 2048-step segments), modes in turn
                     o.setdefault("segments", 0)
                 else:
@@ -137,6 +139,13 @@ class ResidentReceiver:
                                report=self.pit_report[stage] if tb else None)
         if tb:
             self.pit_timing[stage] = _k.pit_last_timing()      # host-side copy of the HIP-event times: no synchronisation
+            o = self.pit[stage]
+            if o.get("acquire") and not o.get("acq_chunk") and not self.adaptive[stage]:
+                # the chunk length of the acquisition (2 / the gear-shifted step the device derives from the signal power) as the first
+                # capture used it: handed back from now on, so that later calls do not wait for the device to say it (one read, once)
+                a = self.pit_report[stage].read()["acquisition"]
+                if a["chunks"] > 0 and a["steps"] > 0:
+                    o["acq_chunk"] = int(a["steps"] // a["chunks"])
 
     def pit_reports(self):
         """Tier b: what the device decided in the last run, one dict per stage (segments, passes, boundary defects,
