@@ -153,9 +153,20 @@ class ResidentReceiver:
         return [r.read() for r in self.pit_report] if self.pit_report else None
 
     def apply(self):
-        _k.apply_filter_to_signal_dev(self.E, self.os, self.wxy, self.modes, self.eq)
+        """Filter the capture with the current taps (a phase search still pending from run(overlap=True) is completed first: it reads
+        the filter output this call overwrites)."""
+        self.wait_post()
+        self._apply()
 
     def recover(self):
+        """Phase search, unwrap and de-rotation of the filter output (after a pending one, see apply)."""
+        self.wait_post()
+        self._recover()
+
+    def _apply(self):
+        _k.apply_filter_to_signal_dev(self.E, self.os, self.wxy, self.modes, self.eq)
+
+    def _recover(self):
         _dsp.bps_recover_dev(self.eq, self.Mtestangles, self.alphabet, self.Nbps, self.idx, self.ph, self.out, angles=self.angles)
 
     def run(self, overlap=False, mark=None):
@@ -184,12 +195,12 @@ class ResidentReceiver:
         if getattr(self, "_post_running", False):
             _lib.call("qh_stream_wait_event", self._ev_post.ptr)        # the filter output of the previous pass has been consumed
             self._post_running = False
-        self.apply()
+        self._apply()
         m("apply")
         if not self.Mtestangles:
             return
         if not overlap:
-            self.recover()
+            self._recover()
             m("bps")
             return
         if getattr(self, "_ev_post", None) is None:
@@ -205,7 +216,7 @@ class ResidentReceiver:
             _lib.call("qh_stream_wait_event", self._ev_ready.ptr)
             if mark:
                 mark("post_begin")
-            self.recover()
+            self._recover()
             if mark:
                 mark("post_end")
             self._ev_post.record()
