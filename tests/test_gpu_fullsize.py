@@ -1,6 +1,6 @@
 """
 Tier b pinned to the REFERENCE at BASELINE.json's full sizes: configs[2] (C3: 64-QAM, 2^22 symbol periods, 41 taps,
-cma -> mrde, 64-angle search) and configs[1] (C2: 16-QAM, 2^20, 21-tap mcma, 32 angles) through ``ResidentReceiver(tier="b")`` against the CPU
+cma -> mrde, 64-angle search), the north star's 10^7-symbol variant of it and configs[1] (C2: 16-QAM, 2^20, 21-tap mcma, 32 angles) through ``ResidentReceiver(tier="b")`` against the CPU
 oracle (the restatement of the reference's loops that the golden vectors pin, reference-flag build, exact sequential recurrence) on the
 same capture, with FLOAT tolerances - not only error counts:
 
@@ -27,6 +27,8 @@ TOL = 1e-3
 CASES = {
     "c3": dict(M=64, nsym=2 ** 22, ntaps=41, methods=("cma", "mrde"), mu=(2e-4, 2e-4), A=64, snr=30, lw=100.),
     "c2": dict(M=16, nsym=2 ** 20, ntaps=21, methods=("mcma",), mu=(1e-3,), A=32, snr=25, lw=50e3),
+    # the north star's own size: 10^7 symbol periods of the C3 recipe (8-lane chains: 3584 / 4096 segments)
+    "ns": dict(M=64, nsym=10 ** 7, ntaps=41, methods=("cma", "mrde"), mu=(2e-4, 2e-4), A=64, snr=30, lw=100.),
 }
 
 
@@ -47,7 +49,7 @@ def _oracle_chain(c, E, coded):
     return np.asarray(w), errs, np.asarray(eq), (eq * np.exp(1j * ph)).astype(np.complex64)
 
 
-@pytest.mark.parametrize("key", ["c2", "c3"])
+@pytest.mark.parametrize("key", ["c2", "c3", "ns"])
 def test_tier_b_at_full_size_against_the_oracle(key):
     c = CASES[key]
     d = synth.make_capture_dev(c["M"], c["nsym"], nmodes=2, snr_db=c["snr"], theta=np.pi / 5.6, dgd=30e-12, linewidth=c["lw"], seed=1000)
