@@ -429,6 +429,7 @@ template <typename R> struct PitDecideArgs {
     const float *extra;              // one more figure the criterion must cover (adaptive step: largest relative change of a segment's start step size), or nullptr
 };
 // (256 threads of ONE block: the kernel below, or the last block of pit_devest_kernel to finish)
+constexpr int PIT_FIN_MAX = 128;     // rows of the eigenbasis the final extrapolation stages (= PIT_EIGMAX, asserted where that is defined)
 template <typename R> __device__ __forceinline__ void pit_decide_body(const PitDecideArgs<R> &a)
 {
     const double *dfc = a.dfc; const int nb = a.nb; const Cx<R> *Ylast = a.Ylast; const int n = a.n; Cx<R> *wx = a.wx; PitCtrl *c = a.c; float *host_view = a.host_view;
@@ -558,24 +559,35 @@ template <typename R> __device__ __forceinline__ void pit_decide_body(const PitD
     }
     __syncthreads();
     if (s_flag[1] && extrap) {                                    // the certified last pass: its result + J D[S-1] (see PitDecideArgs::Dfin)
-        for (int e = threadIdx.x; e < n; e += 256) {
-            const int row = e / ntot_w;
-            int jj = -1;
-            for (int j = 0; j < nrow; j++) if ((int)modes_dev[j] == row) { jj = j; break; }
-            if (jj < 0) continue;
-            const double tr = theta[2 * ((size_t)(S - 1) * nrow + jj)], ti = theta[2 * ((size_t)(S - 1) * nrow + jj) + 1];
-            const int f = e - row * ntot_w;
+        // delta = V (c o D~[S-1]) in the frame of segment 0, one output mode at a time: c o D~ staged in LDS (one exponential per component,
+        // not one per component and tap), V read through its transposed copy so that the threads of a wave read consecutive addresses
+        // (round 4's first version - a strided row of V per thread, 82 dependent exponentials - was 24 us of the last pass of every stage)
+        __shared__ float2 s_cd[PIT_FIN_MAX];
+        const float2 *VT = a.Vfin + (size_t)ntot_w * ntot_w;
+        for (int jj = 0; jj < nrow; jj++) {
             const size_t col = (size_t)(S - 1) * nrow + jj;
-            float dr = 0.f, di = 0.f;                             // delta = V (c o D~[S-1]) in the frame of segment 0
-            for (int k = 0; k < ntot_w; k++) {
+            for (int k = threadIdx.x; k < ntot_w; k += 256) {
                 const double ak = c_mu * c_gain * c_seg_len * a.lam_fin[k];
                 const float ck = ak > 0 ? __expf(-(float)ak) : 1.f;
-                const float2 dk = a.Dfin[(size_t)k * ncol_e + col], vk = a.Vfin[(size_t)f * ntot_w + k];
-                dr += ck * (vk.x * dk.x - vk.y * dk.y); di += ck * (vk.x * dk.y + vk.y * dk.x);
+                const float2 dk = a.Dfin[(size_t)k * ncol_e + col];
+                s_cd[k] = float2{ck * dk.x, ck * dk.y};
             }
-            const Cx<R> v = wx[e];
-            if (sym == 0) wx[e] = Cx<R>{(R)(v.re + dr), (R)(v.im + di)};                                                   // (already in the frame of segment 0)
-            else wx[e] = Cx<R>{(R)(v.re + tr * dr + ti * di), (R)(v.im + tr * di - ti * dr)};                                 // own frame: conj(theta) delta
+            __syncthreads();
+            const int row = (int)modes_dev[jj];
+            const double tr = theta[2 * ((size_t)(S - 1) * nrow + jj)], ti = theta[2 * ((size_t)(S - 1) * nrow + jj) + 1];
+            for (int f = threadIdx.x; f < ntot_w; f += 256) {
+                float dr = 0.f, di = 0.f;
+#pragma unroll 8
+                for (int k = 0; k < ntot_w; k++) {
+                    const float2 vk = VT[(size_t)k * ntot_w + f], cd = s_cd[k];
+                    dr += vk.x * cd.x - vk.y * cd.y; di += vk.x * cd.y + vk.y * cd.x;
+                }
+                const int e = row * ntot_w + f;
+                const Cx<R> v = wx[e];
+                if (sym == 0) wx[e] = Cx<R>{(R)(v.re + dr), (R)(v.im + di)};                                                   // (already in the frame of segment 0)
+                else wx[e] = Cx<R>{(R)(v.re + tr * dr + ti * di), (R)(v.im + tr * di - ti * dr)};                                 // own frame: conj(theta) delta
+            }
+            __syncthreads();
         }
         __threadfence();
     }
@@ -677,7 +689,9 @@ static __global__ void __launch_bounds__(256) pit_cov_reduce_kernel(const Z *par
 // Hermitian matrix Rc / nwin, whole problem in the LDS of ONE workgroup, single precision (the basis only preconditions the
 // relaxation).  Out: lam[n] eigenvalues, V[i][k] = component i of eigenvector k.  n <= PIT_EIGMAX.
 typedef float2 Zf;
-constexpr int PIT_EIGMAX = 128, PIT_EIGSWEEPS = 5;       // up to 2 x 64 taps (round 2: 96; above 96 the solver must log its rotations: A alone fills the LDS)        // 5 sweeps: off-diagonal norm 2e-3, smallest eigenvalues good to 2 % - a preconditioner (3 sweeps: twice the passes on some captures)
+constexpr int PIT_EIGMAX = 128, PIT_EIGSWEEPS = 5;
+static_assert(PIT_FIN_MAX >= PIT_EIGMAX, "final extrapolation stages one eigen-space column");
+// PIT_EIGMAX: up to 2 x 64 taps (round 2: 96; above 96 the solver must log its rotations: A alone fills the LDS)        // 5 sweeps: off-diagonal norm 2e-3, smallest eigenvalues good to 2 % - a preconditioner (3 sweeps: twice the passes on some captures)
 __device__ __forceinline__ Zf cmulf(Zf a, Zf b) { return Zf{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 // glog != nullptr: the rotations are LOGGED ([sweep][round][pair] -> (c, s, e.re, e.im)) instead of being accumulated in V - a third of
 // the LDS traffic that bounds this kernel - and pit_jacobi_v_kernel applies them to the rows of V afterwards, which are independent
