@@ -240,6 +240,7 @@ int qh_set_trainer(int form);
  *   QAMPY_HIP_PIT_PROBE = 1                               complex64: the complex128 analysis of a pass (probe of the capture) (tests/test_gpu_pit.py)
  *   QAMPY_HIP_PIT_TIMING = all | none                     which relaxation passes get HIP events (qh_pit_last_timing; scripts/pit_exp.py)
  *   QAMPY_HIP_BPS = tile, QAMPY_HIP_BPS_FUSED = 1         phase search: tile kernel for complex64 / search + unwrap + de-rotation in one kernel (test_gpu_parity.py)
+ *   QAMPY_HIP_RESERVED_CUS = N                            compute units library stream 2 stays off (default 32; 0: none) - read when a thread's streams are created
  *   QAMPY_HIP_LA_PROFILE = 1                              developer aid: cycle split of workgroup 0 of the block trainers on stderr */
 
 /* ---- parallel-in-time training ("tier B": opt-in, NOT the reference's order of evaluation) -----------
