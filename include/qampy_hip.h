@@ -298,7 +298,7 @@ typedef struct qh_pit_opts {
     double gear;            /* 0 = 8 */
     double acq_bound;       /* 0 = 0.08 */
     double acq_plateau;     /* 0 = 0.8: a chunk whose mean |err|^2 exceeds this fraction of the previous one's ends the acquisition */
-    int64_t acq_chunk;      /* 0 = automatic: 2 / mu_acq steps (mu_acq = the gear-shifted step size), 256 .. 4096 */
+    int64_t acq_chunk;      /* 0 = automatic: 2 / mu_acq steps (mu_acq = the gear-shifted step size) rounded to the nearest power of two, 256 .. 4096 */
     int64_t acq_max;        /* 0 = two chunks (at most TrSyms / 2 steps) */
     int32_t correction;     /* -1 / 1: linearised coarse correction between the passes (see below), 0: plain relaxation */
     int32_t head_steps;     /* fixed step: > 0 - the first head_steps steps of every sweep run in the EXACT form, the segments cover the rest; 0: none, unless

@@ -2377,8 +2377,11 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         // after 1024; C2, 1.9e-3: 6-7 after 2048, 6-9 after 896 or 4096, 12-16 after 512) - and every one of its steps is sequential.
         if (o.acq_chunk > 0) acq_ch = o.acq_chunk;
         else {
+            // 2 / mu_acq, rounded to the nearest power of two: mu_acq follows the measured signal power, and a receiver hands the chunk of
+            // its first capture back for the later ones (acq_chunk) - a few per cent of power must not make the result of a capture depend
+            // on which capture the receiver saw first
             const double m = (double)mu_acq_h > 1e-12 ? (double)mu_acq_h : 1e-12;
-            acq_ch = (int64_t)(2.0 / m + 0.5);
+            acq_ch = (int64_t)1 << (int)floor(log2(2.0 / m) + 0.5);
             acq_ch = acq_ch < 256 ? 256 : (acq_ch > 4096 ? 4096 : acq_ch);
         }
         acq_ch = (acq_ch + LA_B - 1) / LA_B * LA_B;

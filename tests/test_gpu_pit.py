@@ -562,3 +562,28 @@ def test_receiver_group_gives_every_capture_the_single_receiver_result(tier):
             g.map(lambda r: 1 // 0)
     finally:
         g.close()
+
+
+def test_result_of_a_capture_does_not_depend_on_what_the_receiver_saw_before():
+    """A resident tier-b receiver hands the acquisition chunk length of its FIRST capture back to the library for the later ones (so that a call
+    need not wait for the device to derive it from the signal power, qh_pit_opts.acq_chunk).  The chunk is 2 / mu_acq rounded to a power of two:
+    a second capture with 6 % more power gets bit for bit the result a fresh receiver gives it."""
+    nsym, M, ntaps, mu = 2 ** 20, 64, 41, (2e-4, 2e-4)
+    a = synth.make_capture_dev(M, nsym, nmodes=2, snr_db=30, theta=np.pi / 5.6, dgd=30e-12, linewidth=100., seed=1000)
+    b = synth.make_capture_dev(M, nsym, nmodes=2, snr_db=30, theta=np.pi / 5.6, dgd=30e-12, linewidth=100., seed=1003)
+    Eb = DeviceArray.from_host(np.ascontiguousarray(b["E"].to_host() * np.complex64(1.03)))
+    kw = dict(methods=("cma", "mrde"), Niter=(1, 1), Mtestangles=64, Nbps=20, alphabet=a["alphabet_host"], tier="b")
+    fresh = ResidentReceiver(2, 2 * nsym, 2, M, ntaps, mu, **kw)
+    fresh.E.copy_from(Eb)
+    fresh.run()
+    want = fresh.fetch()
+    seen = ResidentReceiver(2, 2 * nsym, 2, M, ntaps, mu, **kw)
+    seen.E.copy_from(a["E"])
+    seen.run()                                   # from here on the receiver passes acq_chunk
+    assert seen.pit[0].get("acq_chunk", 0) > 0 and fresh.pit[0]["acq_chunk"] == seen.pit[0]["acq_chunk"]
+    seen.E.copy_from(Eb)
+    seen.run()
+    got = seen.fetch()
+    assert all(r["converged"] and not r["exact_form"] for r in seen.pit_reports())
+    for k in ("wxy", "eq", "out", "ph", "idx"):
+        assert np.array_equal(got[k], want[k]), k
