@@ -1,5 +1,5 @@
 """Soak of the overlapped / multi-receiver schedules: many consecutive passes over DIFFERENT captures, every result compared bit for bit with the
-same receiver run one capture at a time.  Usage: python scripts/soak_overlap.py [passes] [log2 symbols]"""
+same receiver run one capture at a time.  Usage: python scripts/soak_overlap.py [passes] [log2 symbols] [c3 | c2]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -12,6 +12,10 @@ nsym, M, ntaps, mu = 2 ** log2n, 64, 41, (1e-3, 5e-4) if log2n < 20 else (2e-4, 
 seeds = (1000, 1003, 1007, 1011)
 caps = [synth.make_capture_dev(M, nsym, nmodes=2, snr_db=30, theta=np.pi / 5.6, dgd=30e-12, linewidth=100., seed=sd) for sd in seeds]
 kw = dict(methods=("cma", "mrde"), Niter=(1, 1), Mtestangles=64, Nbps=20, alphabet=caps[0]["alphabet_host"])
+if len(sys.argv) > 3 and sys.argv[3] == "c2":           # configs[1]: 16-QAM, 21-tap mcma, 32 test angles, 50 kHz linewidth
+    M, ntaps, mu = 16, 21, (1e-3,)
+    caps = [synth.make_capture_dev(M, nsym, nmodes=2, snr_db=25, theta=np.pi / 5.6, dgd=30e-12, linewidth=50e3, seed=sd) for sd in seeds]
+    kw = dict(methods=("mcma",), Niter=(1,), Mtestangles=32, Nbps=20, alphabet=caps[0]["alphabet_host"])
 KEYS = ("wxy", "eq", "out", "ph", "idx")
 bad = 0
 for tier in ("b", "a"):
