@@ -66,8 +66,11 @@ static int init_device(int device)
             if (reserved > 0 && reserved < ncu) {
                 std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
                 for (int c = reserved; c < ncu; c++) mask[c / 32] |= 1u << (c % 32);
-                QH_HIP(hipExtStreamCreateWithCUMask(&g_streams[i], (uint32_t)mask.size(), mask.data()));
-                continue;
+                // (a runtime that refuses the mask - an environment-wide CU mask is in force, say - gets the plain low-priority stream below:
+                // overlapped receivers then run slower, nothing else changes)
+                if (hipExtStreamCreateWithCUMask(&g_streams[i], (uint32_t)mask.size(), mask.data()) == hipSuccess) continue;
+                (void)hipGetLastError();
+                g_streams[i] = nullptr;
             }
         }
         QH_HIP(hipStreamCreateWithPriority(&g_streams[i], hipStreamNonBlocking, i == 2 ? prio_least : prio_greatest));
