@@ -281,13 +281,17 @@ class ReceiverGroup:
         group.rx[i].fetch()                    # results of the last pass of receiver i
     """
 
-    def __init__(self, n, *args, **kw):
+    def __init__(self, n, *args, factory=None, sync=None, release=None, **kw):
+        """``factory`` / ``sync`` / ``release`` (tests): what builds a receiver, waits for the calling thread's streams and releases them -
+        ResidentReceiver, the library's qh_sync and qh_thread_release by default."""
         import queue
         import threading
         if n < 1:
             raise ValueError("at least one receiver")
-        self.rx = [ResidentReceiver(*args, **kw) for _ in range(int(n))]
-        _lib.sync()
+        self._sync = sync if sync is not None else _lib.sync
+        self._release = release if release is not None else (lambda: _lib.call("qh_thread_release"))
+        self.rx = [(factory or ResidentReceiver)(*args, **kw) for _ in range(int(n))]
+        self._sync()
         self._jobs = [queue.SimpleQueue() for _ in self.rx]
         self._done = queue.SimpleQueue()
         self._threads = [threading.Thread(target=self._work, args=(i,), daemon=True, name="qampy-receiver-%d" % i) for i in range(len(self.rx))]
@@ -298,7 +302,7 @@ class ReceiverGroup:
         while True:
             job = self._jobs[i].get()
             if job is None:
-                _lib.call("qh_thread_release")     # this thread's streams and scratch buffers
+                self._release()                    # this thread's streams and scratch buffers
                 return
             try:
                 self._done.put((i, job(self.rx[i]), None))
@@ -321,7 +325,7 @@ class ReceiverGroup:
     def load(self, E):
         for r in self.rx:
             r.load(E)
-        _lib.sync()
+        self._sync()
 
     def run(self, steps, overlap=True, mark=None):
         """``steps`` passes of the hot path in total, receiver ``i`` taking passes i, i + n, ...; returns when all are complete on the
@@ -334,7 +338,7 @@ class ReceiverGroup:
                 for k in range(share[i]):
                     rx.run(overlap=overlap, mark=mark(i, k) if mark else None)
                 rx.wait_post(mark(i, share[i]) if mark else None)
-                _lib.sync()                    # this thread's streams
+                self._sync()                   # this thread's streams
             return go
         for i in range(n):
             self._jobs[i].put(job(i))

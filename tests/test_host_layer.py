@@ -293,3 +293,49 @@ def test_automatic_segment_grid_follows_the_machine_model():
             cap = 896 if cold else 1024
             assert waves <= cap or waves % cap == 0, (S, waves)                     # one round, or whole rounds
     assert hk.pit_auto_segments(1000, 1e-3, 2, True) == 1                          # too short to cut
+
+
+def test_receiver_group_deals_passes_round_robin_and_hands_exceptions_to_the_caller():
+    """pipeline.ReceiverGroup without a GPU: the dispatch logic on stand-in receivers - `steps` passes dealt round robin, each receiver on its own
+    thread, the pending work completed before run() returns, a worker's exception raised in the caller, threads released on close()."""
+    import threading
+    from qampy_amd.pipeline import ReceiverGroup
+
+    class Fake:
+        def __init__(self, tag):
+            self.tag, self.calls, self.threads, self.flushed = tag, [], set(), 0
+
+        def run(self, overlap=False, mark=None):
+            self.calls.append(overlap)
+            self.threads.add(threading.get_ident())
+            if mark:
+                mark("apply")
+
+        def wait_post(self, mark=None):
+            self.flushed += 1
+
+        def load(self, E):
+            self.E = E
+
+    synced, released = [], []
+    g = ReceiverGroup(3, "x", factory=Fake, sync=lambda: synced.append(threading.get_ident()), release=lambda: released.append(threading.get_ident()))
+    try:
+        g.load("capture")
+        assert all(r.E == "capture" for r in g.rx)
+        g.run(7)
+        assert [len(r.calls) for r in g.rx] == [3, 2, 2] and all(all(r.calls) for r in g.rx)
+        assert all(r.flushed == 1 for r in g.rx)
+        tids = [next(iter(r.threads)) for r in g.rx]
+        assert len(set(tids)) == 3 and threading.get_ident() not in tids          # one thread per receiver, none of them the caller's
+        marks = []
+        g.run(4, overlap=False, mark=lambda i, k: (lambda name: marks.append((i, k, name))))
+        assert sorted(marks) == [(0, 0, "apply"), (0, 1, "apply"), (1, 0, "apply"), (2, 0, "apply")]
+        assert g.map(lambda r: r.tag) == ["x", "x", "x"] and g.map(lambda r: len(r.calls), which=[2]) == [3]
+        with pytest.raises(KeyError):
+            g.map(lambda r: {}["missing"])
+        assert g.map(lambda r: 1) == [1, 1, 1]                                      # the group survives a failed job
+    finally:
+        g.close()
+    assert sorted(released) == sorted(tids) and not any(t.is_alive() for t in g._threads)
+    with pytest.raises(ValueError):
+        ReceiverGroup(0, factory=Fake)
