@@ -126,21 +126,18 @@ __global__ void __launch_bounds__(256) pit_setup_kernel(const Cx<R> *E, int nmod
     }
 }
 
-// start of a sweep's relaxation: passes of this sweep count from zero
-static __global__ void pit_sweep_kernel(PitCtrl *c)
-{
-    QH_WAVE_FIRST();
-    c->done = 0; c->converged = 0; c->passes = 0;
-    for (int q = 0; q < QH_PIT_MAXPASS; q++) { c->result_change[q] = -1; c->deviation[q] = -1; c->deviation_rms[q] = -1; c->deviation_taps[q] = -1; c->deviation_taps_worst[q] = -1; }
-    for (int i = 0; i < QH_PIT_MAXPASS; i++) c->defect[i] = -1;
-}
-
 // after an acquisition chunk: mean |err|^2 over the chunk -> plateau / divergence test
 template <typename R>
 __global__ void __launch_bounds__(256) pit_acq_monitor_kernel(const Cx<R> *err, int64_t err_pitch, int64_t step0, int64_t n, int nsel,
-                                                              const int64_t *modes_dev, double plateau, PitCtrl *c)
+                                                              const int64_t *modes_dev, double plateau, PitCtrl *c, R *mu_acq, const R *mu, double floor_gear)
 {
     QH_WAVE_FIRST();
+    // gear-down between the acquisition chunks: the next chunk runs at half the step, never below floor_gear x mu (floor_gear < 0: every
+    // chunk at the gear-shifted step).  Nothing in this kernel reads mu_acq; the chunk behind it does.  (Was a launch of its own.)
+    if (threadIdx.x == 0 && floor_gear >= 0) {
+        const R lo = (R)((double)*mu * floor_gear), h = *mu_acq * (R)0.5;
+        *mu_acq = h > lo ? h : (*mu_acq > lo ? lo : *mu_acq);
+    }
     if (c->acq_done) return;
     __shared__ double red[256];
     double acc = 0;
@@ -173,13 +170,6 @@ __global__ void __launch_bounds__(256) pit_acq_monitor_kernel(const Cx<R> *err, 
 }
 
 // a diverged acquisition (step size too bold for this capture) is undone: the sweep then starts from the original taps
-// gear-down between the acquisition chunks: the next chunk runs at half the step (never below `floor`)
-template <typename R> __global__ void pit_acq_anneal_kernel(R *mu_acq, const R *mu, double floor_gear)
-{
-    QH_WAVE_FIRST();
-    const R lo = (R)((double)*mu * floor_gear), h = *mu_acq * (R)0.5;
-    *mu_acq = h > lo ? h : (*mu_acq > lo ? lo : *mu_acq);
-}
 template <typename R> __global__ void pit_acq_finish_kernel(Cx<R> *wx, const Cx<R> *w_start, int n, PitCtrl *c)
 {
     QH_WAVE_FIRST();
@@ -275,11 +265,17 @@ static __global__ void __launch_bounds__(256) pit_unwrap_kernel(const double *z,
 // starts from w0 as it is - the taps the sweep starts from in the reference - whatever seeds the other segments get.
 template <typename R>
 __global__ void __launch_bounds__(256) pit_seed_kernel(const Cx<R> *wx, int nmodes, int ntot, const int64_t *modes_dev, int nsel, const double *rot, Cx<R> *X,
-                                                       const Cx<R> *w0)
+                                                       const Cx<R> *w0, Cx<R> *Y, PitCtrl *c)
 {
     QH_WAVE_FIRST();
     const int s = blockIdx.x;
     const int n = nmodes * ntot;
+    if (s == 0 && c) {                                            // a new sweep: the control block's per-sweep fields (was a launch of its own)
+        if (threadIdx.x == 0) { c->done = 0; c->converged = 0; c->passes = 0; }
+        for (int q = threadIdx.x; q < QH_PIT_MAXPASS; q += 256) {
+            c->result_change[q] = -1; c->deviation[q] = -1; c->deviation_rms[q] = -1; c->deviation_taps[q] = -1; c->deviation_taps_worst[q] = -1; c->defect[q] = -1;
+        }
+    }
     const bool exact0 = s == 0 && w0 != nullptr;
     for (int e = threadIdx.x; e < n; e += 256) {
         const int row = e / ntot;
@@ -294,6 +290,7 @@ __global__ void __launch_bounds__(256) pit_seed_kernel(const Cx<R> *wx, int nmod
                 }
         }
         X[(size_t)s * n + e] = v;
+        Y[(size_t)s * n + e] = v;                                 // pass 0 trains Y in place (was a copy of X before the launch)
     }
 }
 
@@ -1826,12 +1823,21 @@ __global__ void __launch_bounds__(1024) pit_adapt_scan_kernel(R *rS, const R *rE
 }
 template <typename R> __global__ void pit_adapt_finish_kernel(R *mu, const R *rE, int n) { *mu = (R)1 / rE[n - 1]; }
 
-struct PitModes { int64_t m[16]; };
-static __global__ void pit_modes_kernel(int64_t *dst, PitModes pm, int n)
+// The small initialisations of a call's prologue in ONE launch (they were a memset / copy / one-thread kernel each, ~5 us of idle stream apiece:
+// 35 us before the first kernel of a cold sweep that does any work): up to three regions to zero, two to copy, the selected modes.
+struct PitInit { void *z[3]; unsigned zn[3]; void *cd[2]; const void *cs[2]; unsigned cn[2]; int64_t *modes_dev; int64_t modes[16]; int nsel; };
+static __global__ void __launch_bounds__(256) pit_init_kernel(PitInit a)
 {
-    if ((int)threadIdx.x < n) dst[threadIdx.x] = pm.m[threadIdx.x];
+    QH_WAVE_FIRST();
+    const unsigned t = blockIdx.x * 256 + threadIdx.x, nt = gridDim.x * 256;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        if (a.z[r]) for (unsigned i = t; i < a.zn[r] / 4; i += nt) reinterpret_cast<uint32_t *>(a.z[r])[i] = 0u;
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+        if (a.cd[r]) for (unsigned i = t; i < a.cn[r] / 8; i += nt) reinterpret_cast<uint64_t *>(a.cd[r])[i] = reinterpret_cast<const uint64_t *>(a.cs[r])[i];
+    if ((int)t < a.nsel) a.modes_dev[t] = a.modes[t];
 }
-
 constexpr int PIT_GT_THREADS = 1024;
 // model != nullptr (measured coarse model): the gain comes from it, and the components alpha[s] of the defects along the signal direction
 // (pit_bound_kernel) are scanned HERE with exp(-mu T K) - in the eigenbasis of K two real first-order recurrences per mode -
@@ -2326,7 +2332,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     float *devmax = (float *)(uw_jump + (size_t)sg.S * nsel);                    // per-block maxima of the deviation estimate (ndev of them)
     const int ndev = (int)((nsj + 63) / 64);                     // (four floats per block: worst column, sum, sum / worst of the tap norms)
     unsigned *ticket = (unsigned *)(devmax + 4 * (size_t)ndev);  // pit_devest_kernel: which block finishes last
-    QH_HIP(hipMemsetAsync(ticket, 0, sizeof(unsigned), g_stream));
+    PitInit init{};                                              // (launched once, right before the sweeps: pit_init_kernel)
+    init.z[0] = ticket; init.zn[0] = sizeof(unsigned);
     // adaptive step: r and previous error at the start / end of every segment, the sum of its step sizes, the change of the start values;
     // error rows of the head (the exact form writes rows of its own length)
     R *ad_rS = nullptr, *ad_rE = nullptr;
@@ -2345,11 +2352,9 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         ad_rS = (R *)(ad_errh + (size_t)nmodes * head); ad_rE = ad_rS + nS;
         ad_M = (float *)(ad_rE + nS); ad_rP = ad_M + nS; ad_dP = ad_rP + nS; ad_chg = ad_dP + nS;
     }
-    {
-        PitModes pm;                                              // the selected modes go to the device as a kernel argument: no copy from the caller's memory to wait for
-        for (int j = 0; j < 16; j++) pm.m[j] = j < nsel ? modes[j] : 0;
-        hipLaunchKernelGGL(pit_modes_kernel, dim3(1), dim3(16), 0, g_stream, modes_dev, pm, nsel);
-    }
+    // (the selected modes go to the device as a kernel argument - pit_init_kernel - : no copy from the caller's memory to wait for)
+    init.modes_dev = modes_dev; init.nsel = nsel;
+    for (int j = 0; j < 16; j++) init.modes[j] = j < nsel ? modes[j] : 0;
     // What the host needs to know before it can enqueue the rest: the step size (a sweep with mu = 0 takes the exact form) and, for a cold
     // start, the gear-shifted step size pit_setup_kernel chose (it sizes the acquisition chunks).  A caller that hands over its host copy of
     // the step (mu_hint) and the chunk length (acq_chunk: from the report of an earlier capture) spares the call its one synchronisation -
@@ -2385,7 +2390,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             acq_ch = acq_ch < 256 ? 256 : (acq_ch > 4096 ? 4096 : acq_ch);
         }
         acq_ch = (acq_ch + LA_B - 1) / LA_B * LA_B;
-        amax = o.acq_max > 0 ? o.acq_max : 2 * acq_ch;            // two chunks, the second at HALF the gear-shifted step (pit_acq_anneal_kernel, never below 2 mu): seeds with
+        amax = o.acq_max > 0 ? o.acq_max : 2 * acq_ch;            // two chunks, the second at HALF the gear-shifted step (pit_acq_monitor_kernel, never below 2 mu): seeds with
                                                                   // less misadjustment noise - with the measured model, whose passes contract 5-6 x, that is worth the fifth pass of a
                                                                   // cold cma sweep at C3 (estimates 0.14, 0.025, 0.0044, 0.00074 against 0.20, 0.036, 0.0067, 0.0012, 0.0002 without;
                                                                   // one chunk, or chunks of 1024 steps, cost passes on other recipes: profiles/r04_acquisition.txt)
@@ -2438,8 +2443,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         ma.part = (float *)mb; ma.u = (Cx<R> *)((char *)mb + b_part);
         ualpha = (float4 *)((char *)mb + b_part + b_u); uqv = (float2 *)((char *)ualpha + b_ua);
         model = (PitModel *)((char *)uqv + b_uq); ma.model = model; ma.ticket = (unsigned *)(model + 16);
-        QH_HIP(hipMemsetAsync(ma.ticket, 0, sizeof(unsigned), g_stream));
-        QH_HIP(hipMemsetAsync(ualpha, 0, b_ua + b_uq, g_stream));
+        init.z[1] = ma.ticket; init.zn[1] = sizeof(unsigned);
+        init.z[2] = ualpha; init.zn[2] = (unsigned)(b_ua + b_uq);
         ma.E = (const Cx<R> *)E; ma.wx = (const Cx<R> *)wx; ma.L = L; ma.TrSyms = TrSyms; ma.nmodes = nmodes; ma.ntaps = ntaps; ma.os = os; ma.nsel = nsel; ma.method = method;
         if (decision) { ma.symbols = (const Cx<R> *)dd_table; ma.nsy = 2 * dd_npart + 1; ma.sy_pitch = 2 * BI_DD_MAXLEV; ma.tables = 1; }
         else { ma.symbols = (const Cx<R> *)symbols; ma.nsy = nsy; ma.sy_pitch = nsy; ma.tables = (method == QH_M_RDE || method == QH_M_MRDE) ? 1 : 0; }
@@ -2484,7 +2489,10 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     // the tests of the iteration itself.
     const bool redo_ok = o.exact_redo_off == 0;
     bool fell_back = false;
-    if (redo_ok && !adaptive) QH_HIP(hipMemcpyAsync(w_call, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
+    if (redo_ok && !adaptive) { init.cd[0] = w_call; init.cs[0] = wx; init.cn[0] = (unsigned)wbytes; }
+    if (o.acquire && Niter > 0) { init.cd[1] = w_start; init.cs[1] = wx; init.cn[1] = (unsigned)wbytes; }     // (the taps the acquisition starts from)
+    hipLaunchKernelGGL(pit_init_kernel, dim3(32), dim3(256), 0, g_stream, init);
+    QH_HIP(hipGetLastError());
     for (int it = 0; it < Niter; it++) {
         // ================================================================ acquisition (first sweep of a cold start)
         if (it == 0 && o.acquire) {
@@ -2492,7 +2500,6 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             if (CH * QH_PIT_MAXCHUNK < amax) CH = (amax + QH_PIT_MAXCHUNK - 1) / QH_PIT_MAXCHUNK;
             CH = (CH + LA_B - 1) / LA_B * LA_B;
             if (CH < 4 * LA_B) CH = 4 * LA_B;
-            QH_HIP(hipMemcpyAsync(w_start, wx, wbytes, hipMemcpyDeviceToDevice, g_stream));
             const int nchunks = (int)(amax / CH);
             auto enqueue_chunk = [&](int c) -> int {
                 const int64_t step0 = (int64_t)c * CH;
@@ -2509,8 +2516,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                     if (r) return r;
                 }
                 hipLaunchKernelGGL((pit_acq_monitor_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const Cx<R> *)err, (int64_t)(TrSyms * Niter), step0, CH,
-                                   nsel, (const int64_t *)modes_dev, plateau, ctrl);
-                if (o.acq_anneal >= 0) hipLaunchKernelGGL((pit_acq_anneal_kernel<R>), dim3(1), dim3(1), 0, g_stream, mu_acq, (const R *)mu_dev, o.acq_anneal > 0 ? (double)o.acq_anneal : 2.0);
+                                   nsel, (const int64_t *)modes_dev, plateau, ctrl, mu_acq, (const R *)mu_dev, o.acq_anneal < 0 ? -1.0 : (o.acq_anneal > 0 ? (double)o.acq_anneal : 2.0));
                 return QH_OK;
             };
             // All chunks are enqueued at once and the host does not wait for any of them: once the plateau is reached (or the run diverged) the
@@ -2541,7 +2547,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                                       hipMemcpyDeviceToDevice, g_stream));
         }
         // ================================================================ pass-0 start taps
-        hipLaunchKernelGGL(pit_sweep_kernel, dim3(1), dim3(1), 0, g_stream, ctrl);
+        // (the per-sweep fields of the control block are reset by pit_seed_kernel below)
         const double *rot_use = nullptr;
         if (seed_phase) {
             int nwin = PIT_SEEDWIN;                                   // head staged in LDS: shortened until it fits the default 64 KiB
@@ -2555,7 +2561,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         }
         // segment 0 starts from the taps the sweep starts from in the reference (before the acquisition moved them), unrotated
         const Cx<R> *w_exact = o.start == 1 ? nullptr : ((it == 0 && o.acquire) ? (const Cx<R> *)w_start : (const Cx<R> *)wx);
-        hipLaunchKernelGGL((pit_seed_kernel<R>), dim3(sg.S), dim3(256), 0, g_stream, (const Cx<R> *)wx, nmodes, ntot, (const int64_t *)modes_dev, nsel, rot_use, X, w_exact);
+        hipLaunchKernelGGL((pit_seed_kernel<R>), dim3(sg.S), dim3(256), 0, g_stream, (const Cx<R> *)wx, nmodes, ntot, (const int64_t *)modes_dev, nsel, rot_use, X, w_exact, Y, ctrl);
         if (ssb) {
             // the coarse model of this sweep, measured at its seed taps: two small launches on the library's helper stream, beside pass 0 (which
             // does not need it; its analysis waits for it) and beside the basis build of a cold sweep on the other stream.
@@ -2603,9 +2609,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             } else if (p > 0) {
                 QH_HIP(hipMemcpyAsync(X + wset, Y, (size_t)(sg.S - 1) * wbytes, hipMemcpyDeviceToDevice, g_stream));   // X[s] = end taps of s-1
                 QH_HIP(hipMemcpyAsync(Y, X, (size_t)sg.S * wbytes, hipMemcpyDeviceToDevice, g_stream));
-            } else {
-                QH_HIP(hipMemcpyAsync(Y, X, (size_t)sg.S * wbytes, hipMemcpyDeviceToDevice, g_stream));
-            }
+            }                                                       // (pass 0: pit_seed_kernel wrote the start taps into X and Y)
             if (timed(p)) QH_HIP(hipEventRecord(ev.t0[p], g_stream));
             if (seg_form) {
                 SegArgs<R> sa;
