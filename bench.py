@@ -729,11 +729,12 @@ def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_
         ok_same = all(d <= tol_check for d in dev.get("out_rms_dev_same_angle", dev["out_rms_dev_vs_exact"]))
         ok_tap = all(d <= 3 * tol_check for d in dev["tap_rel_dev_vs_exact"])
         ok_ser = all(abs(a - b) <= SER_TOL_ERRORS for a, b in zip(errs_a, [e for e, _ in errs]))
+        ok_err = all(d <= 3 * tol_check for row in dev["err_trace_rms_dev_vs_exact"] for d in row)
         # every entry of `checks` is part of the certificate (all must hold); figures that are reported but not held to the tolerance
         # are under `info` - the recovered output over ALL symbols includes the windows in which a near-tie of the phase search's arg-min
         # fell the other way (one test-angle step, whatever the tolerance; the reference's own float32 / float64 runs differ there too)
         tb["checks"] = dict(converged=tb["converged"], equaliser_out_rms_dev_le_tol=bool(ok_eq), recovered_out_rms_dev_on_same_angle_symbols_le_tol=bool(ok_same),
-                            tap_rel_dev_le_3tol=bool(ok_tap), errors_within_3=bool(ok_ser), tol=tol_check)
+                            tap_rel_dev_le_3tol=bool(ok_tap), err_trace_rms_dev_le_3tol=bool(ok_err), errors_within_3=bool(ok_ser), tol=tol_check)
         tb["info"] = dict(recovered_out_rms_dev_all_symbols=dev["out_rms_dev_vs_exact"], other_angle_symbol_fraction=dev.get("bps_angle_mismatch_fraction"),
                           exact_form_stages=[st["stage"] for st in tb["stages"] if st.get("exact_form")])
         tb["certified"] = bool(all(v for k, v in tb["checks"].items() if k != "tol"))
@@ -857,6 +858,7 @@ def pmc_json(name, workload):
 
 
 TOL_DEFAULT = 1e-3         # library default of tier b: estimated relative rms deviation of the equaliser output from the sequential recurrence
+TOL_TIGHT = 1e-4           # SURVEY.md 8c's complex64 bar (rtol 1e-4 taps, atol 1e-4 output / error): what the headline is held to since round 5
 
 
 # ------------------------------------------------------------------------------------------------------------ main
@@ -938,9 +940,12 @@ def main():
             _lib.sync()
         cm.barrier()
 
-    pit = dict(tol=args.tol) if args.tol > 0 else {}
+    # Headline tolerance: the TIGHTEST of (1e-4, 1e-3) at which tier b certifies itself in this run (--tol fixes one).  1e-4 is SURVEY.md 8c's
+    # bar for complex64 (the exact path is held to it against the golden vectors); 1e-3 was the headline tolerance of rounds 2-4.
+    tol_ladder = [args.tol] if args.tol > 0 else [TOL_TIGHT, TOL_DEFAULT]
+    pit = dict(tol=tol_ladder[0])
     overlap = args.tier == "b" and not args.no_overlap and not args.dry_run
-    tol_check = args.tol if args.tol > 0 else TOL_DEFAULT
+    tol_check = tol_ladder[0]
     if args.dry_run:
         rx = DryReceiver(cfg, nsym, args.tier)
         for _ in range(args.warmup):
@@ -978,8 +983,18 @@ def main():
         tier_b = tier_b_block(cfg, rx, stage_names, pass_ms, acq_ms, reports, nsym * args.steps / elapsed / 1e6, elapsed / args.steps * 1e3, errs, nsym)
         tier_b["certified"] = tier_b["converged"]
     elif args.tier == "b":
-        tier_b, tier_a, ex = run_pair(cfg, sig, nsym, args.steps, args.warmup, barrier_sync, pit, args.exact_steps if world == 1 else 0, tol_check, overlap=overlap, in_flight=args.in_flight)
+        tried = []
+        for t_ in tol_ladder:
+            pit, tol_check = dict(tol=t_), t_
+            tier_b, tier_a, ex = run_pair(cfg, sig, nsym, args.steps, args.warmup, barrier_sync, pit, args.exact_steps if world == 1 else 0, tol_check, overlap=overlap, in_flight=args.in_flight)
+            if tier_b["certified"] or world > 1:         # (N > 1: every rank must take the same rung - the tightest; its certificate is all-reduced below)
+                break
+            tried.append(dict(tol=t_, certified=False, checks=tier_b.get("checks"), passes=[st["P"] for st in tier_b["stages"]], value=tier_b["value"],
+                              out_rms_dev_vs_exact=tier_b.get("out_rms_dev_vs_exact"), tap_rel_dev_vs_exact=tier_b.get("tap_rel_dev_vs_exact")))
+            del ex
         rx, stage_names, stage_ms, elapsed, errs, reports = ex["rx"], ex["names"], ex["stage_ms"], ex["elapsed"], ex["errs"], ex["reports"]
+        if tried:
+            tier_b["tighter_tolerances_not_certified"] = tried
     else:
         rx = make_receiver(cfg, sig, tier="a")
         rx.load(sig)
@@ -1063,7 +1078,7 @@ def main():
     out["config"]["train_mode"] = (
         ("parallel-in-time solver of the reference's recurrence (tier b, tol %g), certified in-run.  Device: estimated rms deviation of the equaliser output from the "
          "sequential recurrence < tol on every stage (a stage that is not certified is redone in the exact form inside the call)" % tol_check
-         + ("; measured against the exact path on the same capture, two levels: (1) equaliser output <= tol (relative rms) and taps <= 3 tol (relative norm) - every symbol; "
+         + ("; measured against the exact path on the same capture, two levels: (1) equaliser output <= tol (relative rms), taps <= 3 tol (relative norm), error traces <= 3 tol (rms) - every symbol; "
             "(2) recovered output (after the phase search) <= tol on the symbols where both searches chose the same test angle; the other symbols (fraction f = %s per mode: "
             "near-ties of the arg-min over the test angles, one angle step apart whatever the tolerance) are reported, not held to tol; symbol-error counts within +-%d"
             % (["%.2g" % v for v in (tier_b.get("bps_angle_mismatch_fraction") or [])], SER_TOL_ERRORS)
@@ -1185,6 +1200,17 @@ def main():
                                        err_trace_rms_dev_vs_exact=dv["err_trace_rms_dev_vs_exact"],
                                        note="informational: the same solver held to a 10 x looser deviation (SER-equivalent tier of SURVEY 7.3-1(b)); never the headline")
             del rx2, rxa, ex2
+            if abs(tol_check - TOL_DEFAULT) > 1e-12:
+                # the library's default tolerance (the headline of rounds 2-4) beside the headline's, with its own certificate against the exact path
+                tb3, _, ex3 = run_pair(cfg, sig, nsym, ksteps, 1, barrier_sync, dict(pit, tol=TOL_DEFAULT), 1, TOL_DEFAULT, overlap=overlap)
+                out["tier_b_tol_1e-3"] = dict(tol=TOL_DEFAULT, value=tb3["value"], ms_per_step=tb3["ms_per_step"], one_capture_at_a_time=(tb3.get("pipelining") or {}).get("one_capture_at_a_time"),
+                                              certified=tb3["certified"], checks=tb3.get("checks"), info=tb3.get("info"), errors=tb3["errors"],
+                                              passes=[st["P"] for st in tb3["stages"]], est_deviation_rms=[st["est_deviation_rms"][-1:] for st in tb3["stages"]],
+                                              eq_rms_dev_vs_exact=tb3.get("eq_rms_dev_vs_exact"), out_rms_dev_same_angle=tb3.get("out_rms_dev_same_angle"),
+                                              out_rms_dev_vs_exact=tb3["out_rms_dev_vs_exact"], tap_rel_dev_vs_exact=tb3["tap_rel_dev_vs_exact"],
+                                              err_trace_rms_dev_vs_exact=tb3["err_trace_rms_dev_vs_exact"],
+                                              note="informational: the same solver at the library's default tolerance 1e-3 (the headline tolerance of rounds 2-4)")
+                del ex3
             if overlap and args.in_flight == 1:
                 out["two_in_flight"] = in_flight_block(cfg, sig, nsym, 2, 2 * max(4, min(args.steps, 20)), barrier_sync, pit)
             if args.workload == "c3":
@@ -1192,6 +1218,21 @@ def main():
                 for key in ("ns", "c2"):
                     out[key] = shape_block(key, barrier_sync, pit, 10, overlap=overlap)
                 out["adaptive_step"] = adaptive_block()
+                # SURVEY.md 8c's tolerance on the three BASELINE shapes, each with the in-run certificate against the exact path
+                rows = dict(c3=dict(value=tier_b["value"], certified=tier_b["certified"], checks=tier_b.get("checks"), passes=[st["P"] for st in tier_b["stages"]],
+                                    eq_rms_dev_vs_exact=tier_b.get("eq_rms_dev_vs_exact"), tap_rel_dev_vs_exact=tier_b.get("tap_rel_dev_vs_exact"),
+                                    err_trace_rms_dev_vs_exact=tier_b.get("err_trace_rms_dev_vs_exact"), out_rms_dev_same_angle=tier_b.get("out_rms_dev_same_angle"),
+                                    other_angle_symbol_fraction=tier_b.get("bps_angle_mismatch_fraction")))
+                for key in ("ns", "c2"):
+                    b_ = out[key]["tier_b"]
+                    rows[key] = dict(value=b_["value"], certified=b_["certified"], checks=b_["checks"], passes=[st["P"] for st in b_["stages"]],
+                                     eq_rms_dev_vs_exact=b_["eq_rms_dev_vs_exact"], tap_rel_dev_vs_exact=b_["tap_rel_dev_vs_exact"],
+                                     err_trace_rms_dev_vs_exact=b_["err_trace_rms_dev_vs_exact"], out_rms_dev_same_angle=b_["out_rms_dev_same_angle"],
+                                     other_angle_symbol_fraction=b_["bps_angle_mismatch_fraction"])
+                out["tier_b_tight"] = dict(tol=tol_check, certified=bool(all(r["certified"] for r in rows.values())), **rows,
+                                           held="equaliser output <= tol (relative rms, every symbol), taps <= 3 tol (relative norm), error traces <= 3 tol (rms, signal units), "
+                                                "recovered output <= tol on every symbol whose test angle agrees with the exact path's (the share of the others is reported), "
+                                                "symbol errors within +-%d, every stage certified by the device's own estimate" % SER_TOL_ERRORS)
             _lib.call("qh_release_scratch")
         except Exception as e:                    # informational blocks never take the headline down
             out["extra_shapes_error"] = "%s: %s" % (type(e).__name__, e)

@@ -1,6 +1,7 @@
 // Runtime part of libqampy_hip: device selection, the library stream, device memory, events, error text.
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 #include <mutex>
 #include <vector>
 #include <string.h>
@@ -24,6 +25,27 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
     (void)hipGetLastError();
     return QH_ERR_HIP;
 }
+
+// Production knobs: set through the C ABI (qh_set_reserved_cus / qh_set_gram_budget_gb / qh_set_default_tier); the environment variables of
+// the same name are read ONCE, as the initial value, never in a launch path.
+static std::atomic<int> g_reserved_cus{-1};
+static std::atomic<double> g_gram_budget_gb{-1.0};
+static std::atomic<int> g_default_tier{0};
+static std::atomic<double> g_default_tol{1e-3};
+static int reserved_cus()
+{
+    int v = g_reserved_cus.load();
+    if (v < 0) { const char *e = getenv("QAMPY_HIP_RESERVED_CUS"); v = e ? atoi(e) : 32; if (v < 0) v = 0; g_reserved_cus.store(v); }
+    return v;
+}
+double gram_budget_gb()
+{
+    double v = g_gram_budget_gb.load();
+    if (v < 0) { const char *e = getenv("QAMPY_HIP_GRAM_BUDGET_GB"); v = e ? atof(e) : 160.0; if (!(v > 0)) v = 160.0; g_gram_budget_gb.store(v); }
+    return v;
+}
+int default_tier() { return g_default_tier.load(); }
+double default_tier_tol() { return g_default_tol.load(); }
 
 static int init_device(int device)
 {
@@ -56,12 +78,11 @@ static int init_device(int device)
         // stream 2 is where a caller overlaps chip-wide streaming work (filter output -> phase search) with the latency-bound trainers
         // of the next capture on stream 0: lowest queue priority, so that the trainers' workgroups are dispatched first
         if (i == 2) {
-            // ... and kept off the first 32 compute units (QAMPY_HIP_RESERVED_CUS): its single-wave workgroups fill every CU they may
+            // ... and kept off the first 32 compute units (qh_set_reserved_cus): its single-wave workgroups fill every CU they may
             // use to the LDS limit, and a trainer's one-workgroup kernels that need most of a CU's LDS (eigen-solver: 107 KiB; acquisition)
             // would otherwise wait for the whole phase search to drain (measured at C3: eigen-solver 1.1 ms instead of 0.5 ms, step
             // 3.95 ms with 0..16 CUs kept free, 3.50 ms with 24..48)
-            const char *e = getenv("QAMPY_HIP_RESERVED_CUS");
-            const int reserved = e ? atoi(e) : 32;
+            const int reserved = reserved_cus();
             const int ncu = prop.multiProcessorCount;
             if (reserved > 0 && reserved < ncu) {
                 std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
@@ -157,6 +178,29 @@ int qh_set_trainer(int form)
     qh::g_trainer = form;
     return QH_OK;
 }
+
+int qh_set_reserved_cus(int n)
+{
+    if (n < 0) { qh::set_error("qh_set_reserved_cus: n >= 0"); return QH_ERR_ARG; }
+    qh::g_reserved_cus.store(n);
+    return QH_OK;
+}
+int qh_set_gram_budget_gb(double gb)
+{
+    if (!(gb > 0)) { qh::set_error("qh_set_gram_budget_gb: gb > 0"); return QH_ERR_ARG; }
+    qh::g_gram_budget_gb.store(gb);
+    return QH_OK;
+}
+int qh_get_gram_budget_gb(double *gb) { *gb = qh::gram_budget_gb(); return QH_OK; }
+int qh_set_default_tier(int tier, double tol)
+{
+    if (tier != 0 && tier != 1) { qh::set_error("qh_set_default_tier: 0 = tier a (exact sequential recurrence), 1 = tier b (parallel in time)"); return QH_ERR_ARG; }
+    if (tol < 0 || tol > 0.1) { qh::set_error("qh_set_default_tier: 0 <= tol <= 0.1 (0 = the library default 1e-3)"); return QH_ERR_ARG; }
+    qh::g_default_tier.store(tier);
+    qh::g_default_tol.store(tol > 0 ? tol : 1e-3);
+    return QH_OK;
+}
+int qh_get_default_tier(int *tier, double *tol) { *tier = qh::default_tier(); *tol = qh::default_tier_tol(); return QH_OK; }
 
 int qh_abi_version(void) { return QH_ABI_VERSION; }
 

@@ -460,12 +460,11 @@ template <typename R> __global__ void gather_kernel(R *dst, const R *src, int n,
     if (c < nch) dst[c] = src[(size_t)c * n + n - 1];
 }
 
-// scratch the Gram tables of one call may take: QAMPY_HIP_GRAM_BUDGET_GB (default 160 of the 288 GB); longer captures / larger channel banks
+// scratch the Gram tables of one call may take: qh_set_gram_budget_gb (default 160 of the 288 GB); longer captures / larger channel banks
 // are trained in time chunks
 static size_t gram_budget()
 {
-    const char *e = getenv("QAMPY_HIP_GRAM_BUDGET_GB");
-    const double gb = e ? atof(e) : 160.0;
+    const double gb = gram_budget_gb();               // (qh_set_gram_budget_gb; no environment look-up in the launch path)
     return (size_t)((gb > 0.001 ? gb : 0.001) * 1073741824.0);
 }
 

@@ -2659,7 +2659,13 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                     hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 0>), dim3((ncol + PIT_MC - 1) / PIT_MC), dim3(pit_mfma_threads(ntot)), pit_mfma_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
                 };
                 if (p == 0 && model_event) QH_HIP(hipStreamWaitEvent(g_stream, model_event, 0));       // the sweep's coarse model (other stream)
-                if (p == 0) forward((const Cx<R> *)X, Xe);           // start taps of the sweep into the eigenbasis (kept up to date from here on)
+                // Start taps of this pass into the eigenbasis - in EVERY pass (round 5).  Rounds 3-4 projected them once per sweep and kept x~ up to
+                // date in the eigenbasis (x~ <- theta x~ + D~, pit_recur_eig_kernel) while the back product updated X itself (X <- theta X + V D~).
+                // The two copies part by the rounding of the products and by what V lacks to be unitary (7e-6 per entry, single-precision Jacobi)
+                // times the correction - ~1e-6 per boundary, the same sign from boundary to boundary - and a fixed point of the TRACKED copy
+                // leaves exactly that as a true defect at every boundary; the weakly excited directions (coefficient ~1) add them up over the
+                // whole sweep: 1.0-1.7e-3 of tap deviation at C3 whatever the tolerance, invisible to the estimate (profiles/r05_tap_floor.txt).
+                forward((const Cx<R> *)X, Xe);
                 forward((const Cx<R> *)Y, Ye);
                 hipLaunchKernelGGL(pit_bound_kernel, dim3((nbnd + nsel + 3) / 4), dim3(256), 0, g_stream, (const Zf *)Xe, (const Zf *)Ye, (const Zf *)Yprev, lam, ntot, sg.S, nsel, sym,
                                    (const PitCtrl *)ctrl, dfc, pw, gph, ualpha);

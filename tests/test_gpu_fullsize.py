@@ -9,9 +9,11 @@ same capture, with FLOAT tolerances - not only error counts:
     error traces      rms per stage and mode (signal units)  <= 3 tol
     symbol errors     after the phase search, per mode       within +-3 of the oracle's
 
-tol = 1e-3, the library default of tier b.  The two-level statement for the RECOVERED output (after the arg-min over the test
-angles) lives in bench.py's certificate; here the recovered signals are compared through their decisions.
+tol = 1e-3 (the library default of tier b) AND tol = 1e-4 - SURVEY.md 8c's own bar for complex64 (rtol 1e-4 taps, atol 1e-4 output /
+error traces), the tolerance bench.py's headline is held to since round 5.  The two-level statement for the RECOVERED output (after the
+arg-min over the test angles) lives in bench.py's certificate; here the recovered signals are compared through their decisions.
 """
+import functools
 import numpy as np
 import pytest
 
@@ -23,7 +25,7 @@ from qampy_amd.pipeline import ResidentReceiver
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-3
+TOLS = [1e-3, 1e-4]
 CASES = {
     "c3": dict(M=64, nsym=2 ** 22, ntaps=41, methods=("cma", "mrde"), mu=(2e-4, 2e-4), A=64, snr=30, lw=100.),
     "c2": dict(M=16, nsym=2 ** 20, ntaps=21, methods=("mcma",), mu=(1e-3,), A=32, snr=25, lw=50e3),
@@ -49,35 +51,79 @@ def _oracle_chain(c, E, coded):
     return np.asarray(w), errs, np.asarray(eq), (eq * np.exp(1j * ph)).astype(np.complex64)
 
 
-@pytest.mark.parametrize("key", ["c2", "c3", "ns"])
-def test_tier_b_at_full_size_against_the_oracle(key):
+@functools.lru_cache(maxsize=1)
+def _capture_and_oracle(key):
+    """The capture (device + host copy) and the oracle's results for it: once per shape, shared by the tolerances (maxsize 1: a 10^7-symbol
+    capture with its traces is ~1.3 GB of host memory)."""
     c = CASES[key]
     d = synth.make_capture_dev(c["M"], c["nsym"], nmodes=2, snr_db=c["snr"], theta=np.pi / 5.6, dgd=30e-12, linewidth=c["lw"], seed=1000)
     E = d["E"].to_host()
+    return d, E, _oracle_chain(c, E, d["alphabet_host"])
+
+
+@pytest.mark.parametrize("tol", TOLS, ids=lambda t: "tol%g" % t)
+@pytest.mark.parametrize("key", ["c2", "c3", "ns"])
+def test_tier_b_at_full_size_against_the_oracle(key, tol):
+    c = CASES[key]
+    d, E, (wo, eo, qo, oo) = _capture_and_oracle(key)
     coded = d["alphabet_host"]
     rx = ResidentReceiver(2, E.shape[1], 2, c["M"], c["ntaps"], c["mu"], methods=c["methods"], Niter=(1,) * len(c["methods"]), Mtestangles=c["A"], Nbps=20,
-                          alphabet=coded, tier="b")
+                          alphabet=coded, tier="b", pit=dict(tol=tol))
     rx.E.copy_from(d["E"])
     rx.run()
     res = rx.fetch()
     reps = rx.pit_reports()
     assert all(r["converged"] for r in reps), reps
+    assert all(abs(r["tol"] - tol) < 1e-12 for r in reps), reps
     # what the headline is quoted on: the parallel-in-time solver certified every stage itself (no exact-form way out was needed)
     assert not any(r["exact_form"] for r in reps), reps
-    wo, eo, qo, oo = _oracle_chain(c, E, coded)
     for m in range(2):
         g = 1j ** int(np.rint(np.angle(np.vdot(res["wxy"][m].ravel(), wo[m].ravel())) / (np.pi / 2)))       # a common quarter turn is a symmetry
         assert g == 1, "tier b starts from the caller's taps: same quadrant as the sequential recurrence"
         tap = np.linalg.norm(wo[m] - res["wxy"][m]) / np.linalg.norm(wo[m])
         out = np.sqrt(np.mean(np.abs(qo[m] - res["eq"][m]) ** 2) / np.mean(np.abs(qo[m]) ** 2))
-        assert tap <= 3 * TOL, (key, m, "taps", tap)
-        assert out <= TOL, (key, m, "equaliser output", out)
+        assert tap <= 3 * tol, (key, m, "taps", tap)
+        assert out <= tol, (key, m, "equaliser output", out)
         for s in range(len(c["methods"])):
             et = np.sqrt(np.mean(np.abs(eo[s][m] - res["err"][s][m]) ** 2))
-            assert et <= 3 * TOL, (key, m, "error trace of stage %d" % s, et)
+            assert et <= 3 * tol, (key, m, "error trace of stage %d" % s, et)
     # decisions after carrier recovery: tier b on the device against the oracle's recovered signal through the same harness
     ser_b = ber.cal_ser_dev(rx.out, d["idx_tx"], rx.alphabet, 256, 8192, 2000)
     oo_dev = _lib.DeviceArray.from_host(np.ascontiguousarray(oo))
     ser_o = ber.cal_ser_dev(oo_dev, d["idx_tx"], rx.alphabet, 256, 8192, 2000)
     for m in range(2):
         assert abs(ser_b[m]["errors"] - ser_o[m]["errors"]) <= 3, (key, m, ser_b[m], ser_o[m])
+
+
+def test_config1_exact_shape_against_the_oracle():
+    """BASELINE.json configs[0] at its exact shape (QPSK, 1 polarisation, 2 samples per symbol, 2^16 symbols, 11-tap CMA, mu = 1e-3; the plumbing
+    of Scripts/cma_equaliser.py; CPU-only by definition in BASELINE, run here through both tiers): taps, error trace and filter output of the exact path
+    and of tier b against the oracle at the complex64 parity tolerance (tests/conftest.py), symbol errors identical."""
+    nsym, nt = 2 ** 16, 11
+    d = synth.make_capture_dev(4, nsym, nmodes=1, snr_db=14, theta=None, dgd=30e-12, linewidth=0., seed=1000)
+    E = d["E"].to_host()
+    w0 = host._init_taps(nt, 1, 1, np.complex64)
+    tr = host._cal_training_symbol_len(2, nt, E.shape[1])
+    sy = host._reshape_symbols(None, "cma", 4, np.complex64, 1)
+    eo, wo, _ = oracle.train_equaliser(E, tr, 1, 2, np.float32(1e-3), w0.copy(), None, False, sy, "cma", fast=True)
+    qo = np.asarray(oracle.apply_filter_to_signal(E, 2, wo, fast=True))
+    for tier, tol in (("a", 1e-4), ("b", 1e-4)):
+        rx = ResidentReceiver(1, E.shape[1], 2, 4, nt, (1e-3,), methods=("cma",), Niter=(1,), Mtestangles=None, alphabet=d["alphabet_host"], tier=tier,
+                              pit=dict(tol=1e-4) if tier == "b" else None)
+        rx.E.copy_from(d["E"])
+        rx.run()
+        res = rx.fetch()
+        # cma is phase blind: tier b's result is the sequential recurrence's up to a common phase of the output mode (DESIGN.md 3.2.1 gauge)
+        g = np.exp(1j * np.angle(np.vdot(res["wxy"][0].ravel(), np.asarray(wo)[0].ravel()))) if tier == "b" else 1.0
+        if tier == "b":
+            assert all(r["converged"] for r in rx.pit_reports())
+            assert abs(np.angle(g)) < 5e-3
+        tap = np.linalg.norm(np.asarray(wo)[0] - g * res["wxy"][0]) / np.linalg.norm(np.asarray(wo)[0])
+        out = np.sqrt(np.mean(np.abs(qo[0] - g * res["eq"][0]) ** 2) / np.mean(np.abs(qo[0]) ** 2))
+        et = np.sqrt(np.mean(np.abs(np.asarray(eo)[0] - g * res["err"][0][0]) ** 2))
+        assert tap <= 3 * tol and out <= tol and et <= 3 * tol, (tier, tap, out, et)
+        # decisions (QPSK without carrier recovery: modulo the quarter-turn ambiguity the harness resolves)
+        ser = ber.cal_ser_dev(rx.eq, d["idx_tx"], _lib.DeviceArray.from_host(np.ascontiguousarray(d["alphabet_host"], dtype=np.complex64)), 256, 8192, 2000)
+        ser_o = ber.cal_ser_dev(_lib.DeviceArray.from_host(np.ascontiguousarray(qo.astype(np.complex64))), d["idx_tx"],
+                                _lib.DeviceArray.from_host(np.ascontiguousarray(d["alphabet_host"], dtype=np.complex64)), 256, 8192, 2000)
+        assert abs(ser[0]["errors"] - ser_o[0]["errors"]) <= 3, (tier, ser, ser_o)
