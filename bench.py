@@ -746,6 +746,54 @@ def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_
     return tb, ta, dict(rx=rx, names=names, stage_ms=stage_ms, elapsed=elapsed, errs=errs, reports=reports)
 
 
+def api_end_to_end_block(cfg, sig, nsym, tol, rx_ref, reps=3):
+    """What a drop-in user gets, PCIe included: numpy arrays in -> ``qampy_amd.equalisation.dual_mode_equalisation`` (or equalise_signal for a
+    one-stage recipe) with the process-wide default tier set to b (``qampy_amd.set_default_tier("b", tol)`` - no ``tier=`` keyword at the call,
+    exactly what the reference's callers write, qampy/equalisation.py:194-264) -> ``qampy_amd.phaserec.bps`` (qampy/phaserec.py:62-92) -> numpy
+    arrays out (taps, both error traces, equalised signal, recovered signal, phase).  Checked against the resident receiver's results on the
+    same capture (same solver, same tolerance: identical)."""
+    import qampy_amd
+    from qampy_amd import equalisation as api_eq, phaserec as api_ph, _lib
+    was = qampy_amd.get_default_tier()
+    qampy_amd.set_default_tier("b", tol)
+    try:
+        def once():
+            if len(cfg["methods"]) == 2:
+                out, wxy, errs = api_eq.dual_mode_equalisation(sig, cfg["mu"], cfg["ntaps"], Niter=cfg["niter"], methods=cfg["methods"],
+                                                               adaptive_stepsize=cfg["adaptive"])
+            else:
+                out, wxy, e1 = api_eq.equalise_signal(sig, cfg["mu"][0], Ntaps=cfg["ntaps"], Niter=cfg["niter"][0], method=cfg["methods"][0],
+                                                      adaptive_stepsize=cfg["adaptive"][0], apply=True)
+                errs = (e1,)
+            rec, ph = api_ph.bps(out, cfg["A"], cfg["Nbps"])
+            return out, wxy, errs, rec, ph
+        res = once()                                            # warm-up (pools, scratch)
+        _lib.sync()
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = once()
+            t.append(time.perf_counter() - t0)
+        out, wxy, errs, rec, ph = res
+        nbytes_in = np.asarray(sig).nbytes + np.asarray(out).nbytes
+        nbytes_out = sum(np.asarray(e).nbytes for e in errs) + np.asarray(out).nbytes + np.asarray(rec).nbytes + np.asarray(ph).nbytes
+        ref = rx_ref.fetch()
+        same = dict(taps=bool(np.array_equal(np.asarray(wxy), ref["wxy"])), equalised=bool(np.array_equal(np.asarray(out), ref["eq"])),
+                    recovered=bool(np.array_equal(np.asarray(rec), ref["out"])),
+                    taps_max_abs_dev=float(np.max(np.abs(np.asarray(wxy) - ref["wxy"]))),
+                    recovered_rel_rms_dev=float(np.sqrt(np.mean(np.abs(np.asarray(rec) - ref["out"]) ** 2) / np.mean(np.abs(ref["out"]) ** 2))))
+        best = min(t)
+        return dict(value=round(nsym / best / 1e6, 3), unit="MSym/s", ms_per_capture=round(best * 1e3, 3), runs_ms=[round(x * 1e3, 3) for x in t], tol=tol,
+                    host_bytes_in=int(nbytes_in), host_bytes_out=int(nbytes_out),
+                    pcie_floor_ms=round((nbytes_in / 54.5e9 + nbytes_out / 55e9) * 1e3, 2),
+                    same_as_resident_receiver=same,
+                    what="numpy in -> qampy_amd.equalisation.dual_mode_equalisation -> qampy_amd.phaserec.bps -> numpy out; default tier b set process-wide "
+                         "(qampy_amd.set_default_tier), results on pooled pinned memory, stage 1's error trace copied back while stage 2 trains, the rows of "
+                         "the phase search pipelined over both PCIe directions; pcie_floor_ms = the bytes that cross at ~55 GB/s one after the other")
+    finally:
+        qampy_amd.set_default_tier(*was)
+
+
 def in_flight_block(cfg, sig, nsym, n, steps, barrier_sync, pit):
     """Informational: `n` captures on the GPU at a time (pipeline.ReceiverGroup, one host thread + library stream set per receiver), `steps` passes in
     total, no events inside the timed region; every receiver certified by the device and bit-identical to receiver 0."""
@@ -1211,6 +1259,10 @@ def main():
                                               err_trace_rms_dev_vs_exact=tb3["err_trace_rms_dev_vs_exact"],
                                               note="informational: the same solver at the library's default tolerance 1e-3 (the headline tolerance of rounds 2-4)")
                 del ex3
+            if cfg["A"]:
+                rxe = make_receiver(cfg, sig, tier="b", pit=pit); rxe.load(sig); rxe.run(); _lib.sync()
+                out["api_end_to_end"] = api_end_to_end_block(cfg, sig, nsym, tol_check, rxe)
+                del rxe
             if overlap and args.in_flight == 1:
                 out["two_in_flight"] = in_flight_block(cfg, sig, nsym, 2, 2 * max(4, min(args.steps, 20)), barrier_sync, pit)
             if args.workload == "c3":

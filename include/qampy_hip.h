@@ -39,7 +39,7 @@ extern "C" {
  * arguments.  History: 1 = round 1; 2 = round 2 (qh_bps_recover_*_dev gained `angles`, qh_train_equaliser_*_pit_dev takes
  * (gram, opts, report), the *_seg_dev entry points were removed - unversioned at the time); 3 = round 3 (qh_pit_opts:
  * start, dev_safety; qh_pit_report: deviation[]); 4 = qh_pit_opts: adaptive. */
-#define QH_ABI_VERSION 7
+#define QH_ABI_VERSION 8
 int qh_abi_version(void);
 
 /* ---- status codes (python shim: 1,2 -> ValueError, 3,4 -> RuntimeError) */
@@ -67,9 +67,17 @@ int qh_memset(void *dptr, int value, size_t bytes);
 int qh_memcpy_h2d(void *dptr, const void *hptr, size_t bytes);
 int qh_memcpy_d2h(void *hptr, const void *dptr, size_t bytes);
 int qh_memcpy_d2d(void *dst, const void *src, size_t bytes);
+/* Pinned host memory from a library pool + asynchronous copies on the current library stream (ABI 8): the mirrored host layers return
+ * ndarrays that view pooled pinned buffers (one DMA at the PCIe rate, no bounce copy, no first-touch page faults), and copy a stage's
+ * error trace back while the next stage trains.  qh_stream_sync waits for the current stream only. */
+int qh_pinned_alloc(void **hptr, size_t bytes);
+int qh_pinned_free(void *hptr);
+int qh_memcpy_h2d_async(void *dptr, const void *hptr, size_t bytes);
+int qh_memcpy_d2h_async(void *hptr, const void *dptr, size_t bytes);
+int qh_stream_sync(void);
 /* Threading: the library keeps per-process state (current device and stream, grow-only scratch buffers, trainer selection) and
  * is meant to be driven by ONE host thread, like the reference's extension modules under the GIL; error text is per thread.
- * qh_release_scratch frees the grow-only scratch buffers (Gram tables above all - up to QAMPY_HIP_GRAM_BUDGET_GB) after
+ * qh_release_scratch frees the grow-only scratch buffers (Gram tables above all - up to qh_set_gram_budget_gb) after
  * draining both streams; they are re-allocated on demand. */
 int qh_release_scratch(void);
 int qh_thread_release(void);                   /* destroy the calling thread's streams and scratch buffers (they come back on the next call): a worker
@@ -231,16 +239,30 @@ int qh_count_errors_dev(const int32_t *idx_rx, const int32_t *idx_tx, int64_t n,
  * to direct / lookahead / iterative, then decides), 1 direct, 2 look-ahead, 3 block-iterative.  All forms give the
  * reference's results up to the order of floating-point additions; a form that cannot take a call falls through. */
 int qh_set_trainer(int form);
+/* Production knobs (ABI 8; rounds 1-4 read environment variables in the launch paths).  The environment variables of the same meaning
+ * (QAMPY_HIP_RESERVED_CUS, QAMPY_HIP_GRAM_BUDGET_GB) are read ONCE, as the initial value, when the value is first needed.
+ *   qh_set_reserved_cus(n)     compute units library stream 2 stays off (default 32; 0: none); applies to streams created afterwards - call it before a
+ *                              thread's first library call, or after qh_thread_release
+ *   qh_set_gram_budget_gb(gb)  scratch the Gram tables of one call may take (default 160 of the 288 GB); longer captures / larger banks train in time chunks
+ *   qh_set_default_tier(tier, tol)
+ *                              what the DROP-IN host-array trainers (qh_train_equaliser_c64 / _c128 - the entry points a binding of the reference's
+ *                              `train_equaliser` export calls) run: 0 = tier a, the exact sequential recurrence (default); 1 = tier b, the
+ *                              same recurrence solved in parallel in time to `tol` (0 = 1e-3; SURVEY.md 8c's complex64 bar is 1e-4), total: a call no
+ *                              parallel-in-time solver exists for, or one the passes do not certify, runs in the exact form inside the call.
+ *                              qh_last_pit_report: the device's report of the calling thread's most recent such solve. */
+int qh_set_reserved_cus(int n);
+int qh_set_gram_budget_gb(double gb);
+int qh_get_gram_budget_gb(double *gb);
+int qh_set_default_tier(int tier, double tol);
+int qh_get_default_tier(int *tier, double *tol);
 /* Environment switches the library reads (measurement / test aids: each forces a path the automatic choice would not take at that size,
  * none selects a different algorithm; every one is exercised through this C ABI by the -m gpu tests named):
  *   QAMPY_HIP_TRAINER = direct | lookahead | iterative   form of the exact trainer, like qh_set_trainer (tests/test_gpu_parity.py)
- *   QAMPY_HIP_GRAM_BUDGET_GB = N                          scratch the Gram tables of one call may take, else time chunks (test_gpu_parity.py)
  *   QAMPY_HIP_PIT_FORM = segment | block                  parallel in time: throughput / latency form of the passes (tests/test_gpu_pit.py)
  *   QAMPY_HIP_SEG_LANES = 8 | 16                          throughput form: lanes per chain (tests/test_gpu_pit.py)
  *   QAMPY_HIP_PIT_PROBE = 1                               complex64: the complex128 analysis of a pass (probe of the capture) (tests/test_gpu_pit.py)
  *   QAMPY_HIP_PIT_TIMING = all | none                     which relaxation passes get HIP events (qh_pit_last_timing; scripts/pit_exp.py)
  *   QAMPY_HIP_BPS = tile, QAMPY_HIP_BPS_FUSED = 1         phase search: tile kernel for complex64 / search + unwrap + de-rotation in one kernel (test_gpu_parity.py)
- *   QAMPY_HIP_RESERVED_CUS = N                            compute units library stream 2 stays off (default 32; 0: none) - read when a thread's streams are created
  *   QAMPY_HIP_LA_PROFILE = 1                              developer aid: cycle split of workgroup 0 of the block trainers on stderr */
 
 /* ---- parallel-in-time training ("tier B": opt-in, NOT the reference's order of evaluation) -----------
@@ -365,6 +387,7 @@ int qh_pit_basis_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntap
  * the timed relaxation passes in order (all sweeps) and the sum of the acquisition chunks.  An event idles the stream for ~5.6 us,
  * so by default ONE pass per sweep is timed (pass 1); environment QAMPY_HIP_PIT_TIMING = all (every pass) | none. */
 int qh_pit_last_timing(float *pass_ms, int max_passes, int *npass, float *acq_ms);
+int qh_last_pit_report(qh_pit_report *out);      /* host copy of the report of the calling thread's most recent host-array solve through tier b (qh_set_default_tier) */
 int qh_train_equaliser_c64_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
                                    void *wx, int ntaps, const int64_t *modes, int nsel, const void *symbols, int64_t nsy,
                                    int method, void *err, int zero_err, const void *gram, const qh_pit_opts *opts,

@@ -10,5 +10,6 @@ Python host code calling hand-written HIP kernels through the ctypes C ABI of in
 Triton, no CPU fallback.
 """
 from . import core, equalisation, phaserec, signals, theory  # noqa: F401
+from ._lib import set_default_tier, get_default_tier  # noqa: F401   (tier a = exact recurrence, the default; tier b = parallel in time, INTEGRATION.md 1)
 
 __version__ = "0.1.0"

@@ -142,10 +142,16 @@ class _Field:
     def __init__(self, E, real):
         E = np.asarray(E)
         self.real = real
-        self.host = _convert_sig_to_real(E) if real else np.array(E, copy=True, order="C", subok=False)
+        # (complex path: the capture is only read - uploaded once - so a C-contiguous array is used as it is; the reference's wrappers copy
+        # it, equalisation.py:166-167, 532: 128 MiB of memcpy and page faults per call at C3)
+        self.host = _convert_sig_to_real(E) if real else np.ascontiguousarray(np.asarray(E))
         self.rows, self.L = self.host.shape
         self.dtype = self.host.dtype
-        self.dev = None if real else _kernels.ResidentField(self.host)
+        self.dev = None if real else _kernels.ResidentField(self.host, defer=True)       # (finish() before the call returns)
+
+    def finish(self):
+        if self.dev is not None:
+            self.dev.finish()
 
     def mode_rows(self, modes):
         """Rows of the field the call trains: the modes, plus their quadrature rows in the real-stacked layout."""
@@ -213,6 +219,11 @@ _PIT_REPORTS = []
 
 
 
+def _lib_default_tier():
+    from ... import _lib
+    return _lib.get_default_tier()
+
+
 def last_pit_reports():
     """Tier b: what the device decided in the most recent call - one dict per stage (segments, passes, defect per pass,
     converged, acquisition).  ``converged`` False means the result is NOT certified as equivalent to the sequential recurrence."""
@@ -220,12 +231,16 @@ def last_pit_reports():
 
 
 def _tier_options(kwargs, nstages, cold):
-    """``tier="a"`` (default): the exact sequential recurrence.  ``tier="b"``: the same recurrence solved in parallel in time
+    """``tier="a"`` (the default unless ``qampy_amd.set_default_tier("b", tol)`` changed it): the exact sequential recurrence.  ``tier="b"``: the same recurrence solved in parallel in time
      - complex-valued blind / decision-directed methods, fixed step sizes or the reference's adaptive step
     (cma / mcma / sbd / mddma; a sweep the solver cannot certify is redone in the exact form); ``pit`` = one dict of solver options for
     all stages or one per stage.  Returns one options dict (or None) per stage."""
-    tier, pit = kwargs.pop("tier", "a"), kwargs.pop("pit", None)
+    tier, pit = kwargs.pop("tier", None), kwargs.pop("pit", None)
     del _PIT_REPORTS[:]
+    if tier is None:                              # the process-wide default (qampy_amd.set_default_tier; "a" unless set)
+        tier, tol0 = _lib_default_tier()
+        if tier == "b" and pit is None:
+            pit = dict(tol=tol0)
     if tier == "a":
         return [None] * nstages
     if tier != "b":
@@ -259,8 +274,10 @@ def equalise_signal(E, os, mu, M, wxy=None, Ntaps=None, TrSyms=None, Niter=1, me
     field = _Field(E, method in REAL_VALUED)
     rows = field.mode_rows(modes)
     taps, err = field.train(os, mu, M, field.taps(wxy, Ntaps), TrSyms, Niter, method, adaptive_stepsize, symbols, rows, pit=pit)
+    out = field.filtered(os, taps, rows) if apply else None
+    field.finish()                                # the error trace crossed PCIe while the filter ran
     if apply:
-        return field.filtered(os, taps, rows), taps, err
+        return out, taps, err
     return taps, err
 
 
@@ -292,8 +309,10 @@ def dual_mode_equalisation(E, os, mu, M, wxy=None, Ntaps=None, TrSyms=(None, Non
     for k in range(2):
         taps, err = field.train(os, mu[k], M, taps, TrSyms[k], Niter[k], stages[k], adaptive_stepsize[k], sy[k], rows, pit=pits[k])
         errs.append(err)
+    out = field.filtered(os, taps, rows) if apply else None
+    field.finish()                                # (stage 1's error trace crossed PCIe while stage 2 trained)
     if apply:
-        return field.filtered(os, taps, rows), taps, tuple(errs)
+        return out, taps, tuple(errs)
     return taps, tuple(errs)
 
 

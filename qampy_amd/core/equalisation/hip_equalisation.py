@@ -202,7 +202,11 @@ class ResidentField:
     :func:`apply_filter_to_signal` minus the field argument: host arrays in and out, ``wx`` updated in place.
     """
 
-    def __init__(self, E):
+    def __init__(self, E, defer=False):
+        """``defer``: the big results (error traces, filter output) come back as arrays on pooled pinned memory whose copies are only ENQUEUED -
+        on the library's stream 2, behind the stage that produced them, so that the error trace of one stage crosses PCIe while the next stage
+        trains - and are complete after :meth:`finish` (the mirrored host layer calls it before it returns).  Default: every method returns
+        complete arrays."""
         suf, rt, ct = _lib.suffix(E.dtype)
         if not np.iscomplexobj(E):
             raise TypeError("ResidentField holds a complex field")
@@ -211,6 +215,57 @@ class ResidentField:
             raise TypeError("E must be 2-d")
         self.shape, self.ct, self.rt = E.shape, ct, rt
         self.dev = DeviceArray.from_host(E)
+        self.defer = bool(defer)
+        self._pending = []
+
+    def _pit_options(self, pit, TrSyms, os, mu, ntaps, nsel, adaptive):
+        """What the resident receiver hands the solver so that a call never waits for the device to tell it something the host knows
+        (pipeline.ResidentReceiver): the host copy of the step, the segment grid, the acquisition chunk (the library's own rule on the capture's
+        power) and ONE eigenbasis of the capture's window covariance for all stages of the call, built beside the first stage."""
+        o = dict(pit)
+        nmodes, L = self.shape
+        if _adaptive_flag(adaptive) == 0 and float(mu) > 0:
+            o.setdefault("mu_hint", float(mu))
+            o.setdefault("segments", pit_auto_segments(TrSyms, float(mu), nsel, cold=bool(o.get("acquire"))))
+            if o.get("acquire") and not o.get("acq_chunk"):
+                o["acq_chunk"] = pit_acq_chunk(self._power(), float(mu), nmodes * int(ntaps), self.rt, o.get("gear"), o.get("acq_bound"))
+        if nmodes * int(ntaps) <= 128 and not o.get("basis") and o.get("correction", -1) != 0:
+            key = (int(os), int(ntaps), int(TrSyms))
+            if getattr(self, "_basis_key", None) != key:
+                self._basis = pit_basis_dev(self.dev, os, ntaps, TrSyms, getattr(self, "_basis", None), overlap=True)
+                self._basis_key = key
+            o["basis"] = self._basis.ptr
+        return o
+
+    def _power(self):
+        if getattr(self, "_pw", None) is None:
+            head = DeviceArray((self.shape[0], min(self.shape[1], 4096)), self.ct)
+            for r in range(self.shape[0]):                     # the first 4096 samples of every row, as pit_setup_kernel averages them
+                _lib.call("qh_memcpy_d2d", head.row(r).ptr, self.dev.row(r).ptr, head.row(r).nbytes)
+            self._pw = float(np.mean(np.abs(head.to_host().astype(np.complex128)) ** 2))
+        return self._pw
+
+    def _result(self, darr):
+        """Device -> host copy of a finished result: one DMA into pooled pinned memory, on stream 2 behind an event of the current stream."""
+        if darr.nbytes < _lib.PINNED_MIN_BYTES:
+            return darr.to_host()
+        ev = _lib.Event()
+        ev.record()
+        _lib.call("qh_use_stream", 2)
+        try:
+            _lib.call("qh_stream_wait_event", ev.ptr)
+            out = darr.to_host(pinned=True, wait=not self.defer)
+        finally:
+            _lib.call("qh_use_stream", 0)
+        if self.defer:
+            self._pending.append((darr, ev))           # the device array stays alive until the copy has run
+        return out
+
+    def finish(self):
+        """Wait for the copies :meth:`train` / :meth:`apply` left in flight (``defer=True``)."""
+        if self._pending:
+            _lib.sync()
+            del self._pending[:]
 
     def train(self, TrSyms, Niter, os, mu, wx, modes, adaptive, symbols, method, pit=None):
         """``pit``: ``None`` for the exact sequential recurrence, or a dict of ``qh_pit_opts`` fields for the parallel-in-time
@@ -235,10 +290,17 @@ class ResidentField:
             train_equaliser_dev(self.dev, TrSyms, Niter, os, dmu, dw, modes, adaptive, dsy, method, derr, zero_err=True)
         else:
             rep = PitReportBuffer()
-            train_equaliser_dev(self.dev, TrSyms, Niter, os, dmu, dw, modes, adaptive, dsy, method, derr, zero_err=True, pit=dict(pit), report=rep)
+            train_equaliser_dev(self.dev, TrSyms, Niter, os, dmu, dw, modes, adaptive, dsy, method, derr, zero_err=True,
+                                pit=self._pit_options(pit, TrSyms, os, mu, wx.shape[-1], _as_modes(modes, nmodes).size, adaptive), report=rep)
             self.last_report = rep.read()
         wx[...] = dw.to_host()
-        return derr.to_host(), wx, self.rt(dmu.to_host()[0])
+        mu_out = self.rt(dmu.to_host()[0])
+        err = self._result(derr)
+        if self.defer:
+            # freeing device memory waits for the whole device (like hipFree): with the error trace's copy in flight that wait would serialise
+            # it with the next stage - the small operands of this stage are therefore released in finish(), after the copies
+            self._pending.append((dw, dsy, dmu, locals().get("rep")))
+        return err, wx, mu_out
 
     def apply(self, os, wx, modes=None):
         if os <= 0:
@@ -252,8 +314,12 @@ class ResidentField:
             raise ValueError("largest mode number is larger than shape of signal")
         N = max((L - wx.shape[-1] + 1) // os, 0)
         out = DeviceArray((modes.size, N), self.ct)
-        apply_filter_to_signal_dev(self.dev, os, DeviceArray.from_host(wx), modes, out)
-        return out.to_host()
+        dw = DeviceArray.from_host(wx)
+        apply_filter_to_signal_dev(self.dev, os, dw, modes, out)
+        res = self._result(out)
+        if self.defer:
+            self._pending.append((dw,))
+        return res
 
 
 class ResidentJobs:
@@ -465,6 +531,18 @@ def pit_last_timing():
     n, acq = C.c_int(0), C.c_float(0)
     _lib.call("qh_pit_last_timing", buf, _lib.PIT_MAXPASS, C.byref(n), C.byref(acq))
     return [float(buf[i]) for i in range(n.value)], float(acq.value)
+
+
+def pit_acq_chunk(power, mu, ntot, rt=np.float32, gear=None, bound=None):
+    """Chunk length of a cold sweep's acquisition by the library's own rule (csrc/train_pit.h: pit_setup_kernel + train_pit_dev):
+    ``mu_acq = clamp(gear mu, mu, bound / (ntot power))`` in the capture's precision, chunk = ``2 / mu_acq`` rounded to the nearest power of two,
+    256 .. 4096.  ``power``: mean |sample|^2 over the first ``min(L, 4096)`` samples of all rows."""
+    gear, bound = float(gear or 8.0), float(bound or 0.08)
+    ma = min(gear * mu, bound / (int(ntot) * max(float(power), 1e-30)))
+    if not ma > mu:
+        ma = mu
+    ma = max(float(rt(ma)), 1e-12)
+    return int(min(max(2 ** int(np.floor(np.log2(2.0 / ma) + 0.5)), 256), 4096))
 
 
 def pit_effective_segments(S, TrSyms):

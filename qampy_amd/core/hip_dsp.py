@@ -86,10 +86,41 @@ def bps_recover(E, Mtestangles, symbols, N):
     if L == 0:
         return np.zeros((nm, 0), ct), np.zeros((nm, 0), rt)
     D = _lib.DeviceArray
-    dE, dsy, dang = D.from_host(np.ascontiguousarray(E)), D.from_host(symbols), D.from_host(test_angle_grid(Mtestangles, rt))
-    idx, ph, out = D((nm, L), np.int32), D((nm, L), rt), D((nm, L), ct)
-    bps_recover_dev(dE, Mtestangles, dsy, N, idx, ph, out, angles=dang)
-    return out.to_host(), ph.to_host()
+    E = np.ascontiguousarray(E)
+    dsy, dang = D.from_host(symbols), D.from_host(test_angle_grid(Mtestangles, rt))
+    dE, idx, ph, out = D((nm, L), ct), D((nm, L), np.int32), D((nm, L), rt), D((nm, L), ct)
+    if E.nbytes < _lib.PINNED_MIN_BYTES:
+        dE.set(E)
+        bps_recover_dev(dE, Mtestangles, dsy, N, idx, ph, out, angles=dang)
+        return out.to_host(), ph.to_host()
+    # Rows (modes) are independent: row r + 1 goes up (stream 1) while row r is searched (stream 0) and row r - 1 comes back (stream 2, into
+    # pooled pinned memory) - PCIe carries both directions at once; all searches on ONE stream (they share the library's scratch buffers).
+    h_out, h_ph = _lib.pinned_empty((nm, L), ct), _lib.pinned_empty((nm, L), rt)
+    ev_up, ev_done = [_lib.Event() for _ in range(nm)], [_lib.Event() for _ in range(nm)]
+    try:
+        for r in range(nm):
+            _lib.call("qh_use_stream", 1)
+            _lib.call("qh_memcpy_h2d_async", dE.row(r).ptr, E[r].ctypes.data, E[r].nbytes)
+            ev_up[r].record()
+            _lib.call("qh_use_stream", 0)
+            _lib.call("qh_stream_wait_event", ev_up[r].ptr)
+            bps_recover_dev(_row2d(dE, r), Mtestangles, dsy, N, _row2d(idx, r), _row2d(ph, r), _row2d(out, r), angles=dang)
+            ev_done[r].record()
+            _lib.call("qh_use_stream", 2)
+            _lib.call("qh_stream_wait_event", ev_done[r].ptr)
+            _lib.call("qh_memcpy_d2h_async", h_out[r].ctypes.data, out.row(r).ptr, h_out[r].nbytes)
+            _lib.call("qh_memcpy_d2h_async", h_ph[r].ctypes.data, ph.row(r).ptr, h_ph[r].nbytes)
+    finally:
+        _lib.call("qh_use_stream", 0)
+    _lib.sync()
+    return h_out, h_ph
+
+
+def _row2d(a, r):
+    """Row ``r`` of a 2-d DeviceArray as a (1, L) view."""
+    v = a.row(r)
+    v.shape = (1,) + tuple(v.shape)
+    return v
 
 
 def comp_freq_offset(E, freq_offset, os=1):

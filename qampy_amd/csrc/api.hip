@@ -150,11 +150,53 @@ void pool_free(void *p, size_t cap)
     }
     (void)hipFree(p);
 }
+static std::vector<std::pair<void *, size_t>> g_dlive;            // pooled buffers handed out by qh_malloc: pointer -> capacity
 static void pool_release()
 {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto &v : g_pool) { for (void *p : v) (void)hipFree(p); v.clear(); }
     g_pool_bytes = 0;
+}
+
+// ---- pinned host memory for results (size classes like the device pool): the mirrored host layers hand back ndarrays that VIEW these buffers, so
+// a result crosses PCIe once, by DMA at the link rate, into memory whose pages exist already - a fresh pageable array costs a bounce copy inside the
+// runtime plus a page fault per 4 KiB on first touch (measured round 4: 20 GB/s device -> host against 54 GB/s the other way)
+static std::vector<void *> g_hpool[POOL_CLASSES];
+static size_t g_hpool_bytes = 0;
+static constexpr size_t HPOOL_BYTES = (size_t)8 << 30;
+static std::vector<std::pair<void *, size_t>> g_hlive;            // buffers handed out: pointer -> capacity
+int pinned_alloc(size_t bytes, void **p)
+{
+    const int k = pool_class(bytes ? bytes : 1);
+    const size_t cap = (size_t)1 << k;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!g_hpool[k].empty()) { *p = g_hpool[k].back(); g_hpool[k].pop_back(); g_hpool_bytes -= cap; g_hlive.emplace_back(*p, cap); return QH_OK; }
+    }
+    QH_HIP(hipHostMalloc(p, cap, hipHostMallocDefault));
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_hlive.emplace_back(*p, cap);
+    return QH_OK;
+}
+int pinned_free(void *p)
+{
+    size_t cap = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (size_t i = 0; i < g_hlive.size(); i++)
+            if (g_hlive[i].first == p) { cap = g_hlive[i].second; g_hlive[i] = g_hlive.back(); g_hlive.pop_back(); break; }
+        if (!cap) { set_error("qh_pinned_free: not a live buffer of qh_pinned_alloc"); return QH_ERR_ARG; }
+        const int k = pool_class(cap);
+        if ((int)g_hpool[k].size() < POOL_KEEP && g_hpool_bytes + cap <= HPOOL_BYTES) { g_hpool[k].push_back(p); g_hpool_bytes += cap; return QH_OK; }
+    }
+    (void)hipHostFree(p);
+    return QH_OK;
+}
+static void hpool_release()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &v : g_hpool) { for (void *p : v) (void)hipHostFree(p); v.clear(); }
+    g_hpool_bytes = 0;
 }
 
 int scratch(int slot, size_t bytes, void **p)
@@ -239,6 +281,7 @@ int qh_release_scratch(void)
         qh::g_scratch[i] = nullptr; qh::g_scratch_n[i] = 0;
     }
     qh::pool_release();
+    qh::hpool_release();
     return QH_OK;
 }
 int qh_thread_release(void)
@@ -277,16 +320,40 @@ int qh_stream_wait_event(void *ev)
     QH_HIP(hipStreamWaitEvent(qh::g_stream, (hipEvent_t)ev, 0));
     return QH_OK;
 }
+// Device memory for the callers' arrays.  Requests up to 1 GiB come from the staging pool (size classes 2^k; a freed buffer goes back to it): the
+// mirrored host layers allocate their capture, error traces and outputs per call, and hipMalloc / hipFree of 64 MiB buffers cost ~0.5 ms each
+// (19 allocations = 10 ms of a 28 ms C3 call chain, measured round 5).  Larger requests (channel banks) go to hipMalloc directly.
+static constexpr size_t QH_POOLED_MAX = (size_t)1 << 30;
 int qh_malloc(void **dptr, size_t bytes)
 {
     int rc = qh::ensure_init();
     if (rc) return rc;
-    QH_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    if (bytes <= QH_POOLED_MAX) {
+        size_t cap = 0;
+        if ((rc = qh::pool_alloc(bytes ? bytes : 1, dptr, &cap))) return rc;
+        std::lock_guard<std::mutex> lk(qh::g_mu);
+        qh::g_dlive.emplace_back(*dptr, cap);
+        return QH_OK;
+    }
+    QH_HIP(hipMalloc(dptr, bytes));
     return QH_OK;
 }
 int qh_free(void *dptr)
 {
-    if (dptr) QH_HIP(hipFree(dptr));
+    if (!dptr) return QH_OK;
+    size_t cap = 0;
+    {
+        std::lock_guard<std::mutex> lk(qh::g_mu);
+        for (size_t i = 0; i < qh::g_dlive.size(); i++)
+            if (qh::g_dlive[i].first == dptr) { cap = qh::g_dlive[i].second; qh::g_dlive[i] = qh::g_dlive.back(); qh::g_dlive.pop_back(); break; }
+    }
+    if (cap) {
+        // like hipFree: nothing on the device may still use the buffer when it becomes available again (any stream of any thread)
+        QH_HIP(hipDeviceSynchronize());
+        qh::pool_free(dptr, cap);
+        return QH_OK;
+    }
+    QH_HIP(hipFree(dptr));
     return QH_OK;
 }
 int qh_memset(void *dptr, int value, size_t bytes)
@@ -312,6 +379,35 @@ int qh_memcpy_d2h(void *hptr, const void *dptr, size_t bytes)
     QH_HIP(hipStreamSynchronize(qh::g_stream));
     return QH_OK;
 }
+/* asynchronous forms on the current library stream (the host buffer should be pinned: qh_pinned_alloc, else the runtime stages the copy) */
+int qh_memcpy_h2d_async(void *dptr, const void *hptr, size_t bytes)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    if (bytes) QH_HIP(hipMemcpyAsync(dptr, hptr, bytes, hipMemcpyHostToDevice, qh::g_stream));
+    return QH_OK;
+}
+int qh_memcpy_d2h_async(void *hptr, const void *dptr, size_t bytes)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    if (bytes) QH_HIP(hipMemcpyAsync(hptr, dptr, bytes, hipMemcpyDeviceToHost, qh::g_stream));
+    return QH_OK;
+}
+int qh_stream_sync(void)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    QH_HIP(hipStreamSynchronize(qh::g_stream));
+    return QH_OK;
+}
+int qh_pinned_alloc(void **hptr, size_t bytes)
+{
+    int rc = qh::ensure_init();
+    if (rc) return rc;
+    return qh::pinned_alloc(bytes, hptr);
+}
+int qh_pinned_free(void *hptr) { return hptr ? qh::pinned_free(hptr) : QH_OK; }
 int qh_memcpy_d2d(void *dst, const void *src, size_t bytes)
 {
     int rc = qh::ensure_init();

@@ -18,6 +18,7 @@
 //     short run, sliding for the rest, written to a padded LDS plane;
 //   * one thread per symbol scans the A sums for the first strict minimum (tie -> lowest angle, like the reference).
 #include "common.h"
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -578,7 +579,7 @@ int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, cons
         }
         const size_t lds = ((size_t)2 * N * 64 + BS_G * BS_TP + 1 + 2 * BPS_MAX_LEVELS + 1) * sizeof(float) + (rec ? (2 * N * 64 < C ? (size_t)C * sizeof(int) : 0) + (((size_t)C + 1 + 15) & ~(size_t)15) : 0) +
                            (s.alpha_lds ? (size_t)M * sizeof(Cx<float>) : 0) + 16;
-        static bool sattr = false;
+        static std::atomic<bool> sattr{false};
         if (!sattr) {
             QH_HIP(hipFuncSetAttribute((const void *)bps_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             QH_HIP(hipFuncSetAttribute((const void *)bps_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -593,7 +594,7 @@ int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, cons
     size_t lds = 0;
     const int T = bps_tile<R>(A, N, &lds);
     QH_REQUIRE(T >= 8, "bps: averaging window 2N x test angles does not fit the LDS tile");
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     if (!attr_set) {
         QH_HIP(hipFuncSetAttribute((const void *)bps_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BPS_LDS_BUDGET));
         QH_HIP(hipFuncSetAttribute((const void *)bps_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BPS_LDS_BUDGET));

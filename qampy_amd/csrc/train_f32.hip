@@ -6,6 +6,9 @@ int qh_train_equaliser_c64(const void *E, int nmodes, int64_t L, int64_t TrSyms,
                            int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
                            int method, void *err)
 {
+    // the process-wide default tier (qh_set_default_tier): a = the exact sequential recurrence, b = the same recurrence solved in parallel in time
+    if (qh::default_tier() == 1)
+        return qh::train_host_tier_b<float>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, qh::default_tier_tol());
     return qh::train_host<float>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err);
 }
 int qh_train_equaliser_c64_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
@@ -37,6 +40,11 @@ int qh_train_equaliser_c64_pit_dev(const void *E, int nmodes, int64_t L, int64_t
                                     const void *gram, const qh_pit_opts *opts, void *report_dev)
 {
     return qh::train_pit_dev<float>(E, nmodes, L, TrSyms, Niter, os, mu_dev, wx, ntaps, modes, nsel, symbols, nsy, method, err, zero_err, gram, opts, report_dev);
+}
+int qh_last_pit_report(qh_pit_report *out)
+{
+    *out = qh::last_host_report();                   // the calling thread's most recent host-array solve through tier b (qh_set_default_tier)
+    return QH_OK;
 }
 int qh_pit_last_timing(float *pass_ms, int max_passes, int *npass, float *acq_ms)
 {

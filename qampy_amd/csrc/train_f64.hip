@@ -6,6 +6,9 @@ int qh_train_equaliser_c128(const void *E, int nmodes, int64_t L, int64_t TrSyms
                             int ntaps, const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy,
                             int method, void *err)
 {
+    // the process-wide default tier (qh_set_default_tier): a = the exact sequential recurrence, b = the same recurrence solved in parallel in time
+    if (qh::default_tier() == 1)
+        return qh::train_host_tier_b<double>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err, qh::default_tier_tol());
     return qh::train_host<double>(E, nmodes, L, TrSyms, Niter, os, mu, wx, ntaps, modes, nsel, adaptive, symbols, nsy, method, err);
 }
 int qh_train_equaliser_c128_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, double *mu_dev,

@@ -2119,8 +2119,8 @@ int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t T
     else if (ept <= 32) hipLaunchKernelGGL((pit_cov_kernel<R, 32>), dim3(PIT_COVB), dim3(256), lds, st, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
     else hipLaunchKernelGGL((pit_cov_kernel<R, 64>), dim3(PIT_COVB), dim3(256), lds, st, (const Cx<R> *)E, nmodes, L, os, ntaps, TrSyms, ncov, part);
     hipLaunchKernelGGL(pit_cov_reduce_kernel, dim3((unsigned)((msz + 63) / 64)), dim3(256), 0, st, (const Z *)part, (int)msz, PIT_COVB, Rc);
-    static bool attr_set = false;
-    if (!attr_set) { QH_HIP(hipFuncSetAttribute((const void *)pit_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); attr_set = true; }
+    static std::atomic<bool> attr_set{false};                     // (several host threads may make their first call at the same time: setting it twice is harmless, a torn flag is not)
+    if (!attr_set.load(std::memory_order_acquire)) { QH_HIP(hipFuncSetAttribute((const void *)pit_jacobi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256)); attr_set.store(true, std::memory_order_release); }
     const int nsweep = PIT_EIGSWEEPS;
     // rotations logged by the solver, applied to V row by row afterwards; block form while two copies of A fit the LDS (n <= 96), else
     // the row / column form
@@ -2135,8 +2135,8 @@ int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t T
     }
     const size_t blds = 2 * (size_t)ntot * (ntot + 1) * sizeof(Zf) + 256;
     if (logged && blds <= 160 * 1024 - 2048) {          // (the kernel's static LDS: the round's pairs and rotations)
-        static bool battr = false;
-        if (!battr) { QH_HIP(hipFuncSetAttribute((const void *)pit_jacobi_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); battr = true; }
+        static std::atomic<bool> battr{false};
+        if (!battr.load(std::memory_order_acquire)) { QH_HIP(hipFuncSetAttribute((const void *)pit_jacobi_blk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048)); battr.store(true, std::memory_order_release); }
         hipLaunchKernelGGL(pit_jacobi_blk_kernel, dim3(1), dim3(1024), blds, st, (const Z *)Rc, ntot, 1.0 / (double)ncov, (double *)basis, nsweep, glog);
     } else
     hipLaunchKernelGGL(pit_jacobi_kernel, dim3(1), dim3(1024), jlds, st, (const Z *)Rc, ntot, 1.0 / (double)ncov, (double *)basis,
@@ -2239,9 +2239,11 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     }
     if (S == 0 && adaptive) S = (int)((TrSyms - head) / seg_want < PIT_MAXSEG ? (TrSyms - head) / seg_want : PIT_MAXSEG);
     if (S == 0) {
-        R mu_h = 0;
-        QH_HIP(hipMemcpyAsync(&mu_h, mu_dev, sizeof(R), hipMemcpyDeviceToHost, g_stream));
-        QH_HIP(hipStreamSynchronize(g_stream));
+        R mu_h = (R)o.mu_hint;                                    // the caller's host copy of the step, if it gave one: no read-back, no synchronisation
+        if (!(o.mu_hint > 0)) {
+            QH_HIP(hipMemcpyAsync(&mu_h, mu_dev, sizeof(R), hipMemcpyDeviceToHost, g_stream));
+            QH_HIP(hipStreamSynchronize(g_stream));
+        }
         S = pit_auto_segments(TrSyms, (double)mu_h, nsel, o.acquire);
     }
     const int64_t nblk_all = (TrSyms - head) / LA_B;
@@ -2452,13 +2454,13 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         if (o.corr_beta < 0) beta = 0.0;
     }
     const size_t glds = ((size_t)PIT_EIGMAX * PIT_EIGMAX + (size_t)PIT_EIGMAX * PIT_GT) * sizeof(Zf);
-    static bool gemm_attr = false;
-    if (want_corr && !gemm_attr) {
+    static std::atomic<bool> gemm_attr{false};
+    if (want_corr && !gemm_attr.load(std::memory_order_acquire)) {
         QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         QH_HIP(hipFuncSetAttribute((const void *)pit_cgemm_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         QH_HIP(hipFuncSetAttribute((const void *)pit_basis_mfma_kernel<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         QH_HIP(hipFuncSetAttribute((const void *)pit_basis_mfma_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-                gemm_attr = true;
+        gemm_attr.store(true, std::memory_order_release);
     }
 
     LaArgs<R> la;
@@ -2815,6 +2817,69 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                                (const int64_t *)modes_dev, nsel, (const double *)theta, (const PitCtrl *)ctrl, -1);
         QH_HIP(hipGetLastError());
     }
+    return QH_OK;
+}
+
+// ---- the drop-in host-array trainer through tier b (qh_set_default_tier(1, tol)): what qh_train_equaliser_c64 / _c128 run when the
+// process-wide default tier is b.  Same arguments, same results as train_host up to the stated tolerance: the arrays are staged exactly as there, the
+// sweep is solved in parallel in time (cold start - gear-shifted acquisition first - when every trained mode starts from a centre-spike tap set, as the
+// reference's wrappers initialise them, equalisation.py:243-249), the reference's adaptive step is solved mode after mode (one shared step size), and
+// a call no parallel-in-time solver exists for, or one the passes do not certify, runs in the exact form inside train_pit_dev - the report of the
+// (last) solve stays readable through qh_last_pit_report.
+inline qh_pit_report &last_host_report() { static thread_local qh_pit_report r; return r; }
+template <typename R>
+int train_host_tier_b(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu, void *wx, int ntaps,
+                      const int64_t *modes, int nsel, int adaptive, const void *symbols, int64_t nsy, int method, void *err, double tol)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (method < 0 || method > QH_M_SBD_DATA) { set_error("unknown equaliser method id"); return QH_ERR_METHOD; }
+    QH_REQUIRE(nmodes >= 1 && L >= 1 && ntaps >= 1 && nsy >= 1 && TrSyms >= 0 && Niter >= 0 && nsel >= 1 && nsel <= 16, "train_equaliser: bad sizes");
+    for (int j = 0; j < nsel; j++) QH_REQUIRE(modes[j] >= 0 && modes[j] < nmodes, "train_equaliser: mode number >= nmodes");
+    const size_t cs = sizeof(Cx<R>);
+    // cold start? every trained mode's tap set is a centre spike (one tap equal to 1, the rest 0)
+    bool cold = true;
+    {
+        const Cx<R> *w = (const Cx<R> *)wx;
+        const size_t ntot = (size_t)nmodes * ntaps;
+        for (int j = 0; j < nsel && cold; j++) {
+            int nz = 0;
+            for (size_t f = 0; f < ntot; f++) {
+                const Cx<R> v = w[(size_t)modes[j] * ntot + f];
+                if (v.re != 0 || v.im != 0) { nz++; if (!(v.re == 1 && v.im == 0)) nz = 2; }
+                if (nz > 1) break;
+            }
+            cold = nz == 1;
+        }
+    }
+    DevBuf dE, dw, ds, de, dmu, drep;
+    if ((rc = dE.from_host(E, (size_t)nmodes * L * cs))) return rc;
+    if ((rc = dw.from_host(wx, (size_t)nmodes * nmodes * ntaps * cs))) return rc;
+    if ((rc = ds.from_host(symbols, (size_t)nmodes * nsy * cs))) return rc;
+    if ((rc = dmu.from_host(mu, sizeof(R)))) return rc;
+    if ((rc = de.alloc((size_t)nmodes * TrSyms * Niter * cs))) return rc;
+    if ((rc = drep.alloc(sizeof(qh_pit_report)))) return rc;
+    QH_HIP(hipMemsetAsync(drep.p, 0, sizeof(qh_pit_report), g_stream));
+    qh_pit_opts o;
+    memset(&o, 0, sizeof(o));
+    o.phase_seed = -1; o.corr_beta = -1; o.correction = -1;
+    o.tol = tol;
+    o.adaptive = adaptive;
+    if (adaptive == 1) {
+        // the reference carries ONE step size from mode to mode (pythran_equalisation.py:163-172): the modes in turn, each from the step the one before left
+        for (int j = 0; j < nsel; j++)
+            if ((rc = train_pit_dev<R>(dE.p, nmodes, L, TrSyms, Niter, os, (R *)dmu.p, dw.p, ntaps, modes + j, 1, ds.p, nsy, method, de.p, j == 0 ? 1 : 0, nullptr, &o, drep.p))) return rc;
+    } else {
+        o.acquire = cold ? 1 : 0;
+        if (!adaptive && *mu > 0) o.mu_hint = (double)*mu;
+        if (!adaptive && *mu > 0) o.segments = pit_auto_segments(TrSyms, (double)*mu, nsel, o.acquire);
+        if ((rc = train_pit_dev<R>(dE.p, nmodes, L, TrSyms, Niter, os, (R *)dmu.p, dw.p, ntaps, modes, nsel, ds.p, nsy, method, de.p, 1, nullptr, &o, drep.p))) return rc;
+    }
+    if ((rc = dw.to_host(wx, dw.n))) return rc;
+    if ((rc = de.to_host(err, de.n))) return rc;
+    if ((rc = dmu.to_host(mu, sizeof(R)))) return rc;
+    if ((rc = drep.to_host(&last_host_report(), sizeof(qh_pit_report)))) return rc;
+    QH_HIP(hipStreamSynchronize(g_stream));
     return QH_OK;
 }
 

@@ -63,6 +63,10 @@ class ResidentReceiver:
         self.tier = tier
         pit = pit or {}
         self.pit = [dict(p) for p in pit] if isinstance(pit, (tuple, list)) else [dict(pit) for _ in methods]
+        for o in self.pit:
+            if o.get("acq_chunk"):
+                o["_acq_chunk_user"] = True        # the caller fixed the chunk length: load() leaves it alone
+        self._owner_thread = None                  # set by ReceiverGroup: the stages of this receiver are enqueued by that thread only
         self.pit_report = None
         self.pit_timing = [([], 0.) for _ in methods]
         self.mu0 = tuple(self.rt(m) for m in mu)
@@ -101,10 +105,24 @@ class ResidentReceiver:
 
     # ------------------------------------------------------------------------------------------ data movement
     def load(self, E):
-        """Host -> HBM copy of the capture (outside any timed region)."""
+        """Host -> HBM copy of the capture (outside any timed region).  Tier b: the chunk length of a cold stage's acquisition follows the
+        capture's power (2 / the gear-shifted step, rounded to a power of two: csrc/train_pit.h) - it is re-derived here for EVERY capture from
+        the host copy, by the library's own rule, so that the result of a capture never depends on which capture the receiver saw first and
+        no call has to wait for the device to say it."""
         E = np.ascontiguousarray(np.asarray(E), dtype=self.ct)
         assert E.shape == (self.nmodes, self.L)
         self.E.set(E)
+        self._acq_asked = [False] * self.nstage
+        if self.tier == "b":
+            npow = min(self.L, 4096)
+            power = float(np.mean(np.abs(E[:, :npow].astype(np.complex128)) ** 2))
+            for s_, o in enumerate(self.pit):
+                if o.get("acquire") and not self.adaptive[s_] and not o.get("_acq_chunk_user"):
+                    o["acq_chunk"] = self._acq_chunk_rule(power, float(self.mu0[s_]), o)
+                    self._acq_asked[s_] = True
+
+    def _acq_chunk_rule(self, power, mu, o):
+        return _k.pit_acq_chunk(power, mu, self.nmodes * self.Ntaps, self.rt, o.get("gear"), o.get("acq_bound"))
 
     # ------------------------------------------------------------------------------------------ stages (enqueue only)
     def reset(self):
@@ -113,14 +131,23 @@ class ResidentReceiver:
         for m, m0 in zip(self.mu, self.mu_init):
             m.copy_from(m0)
 
+    def _bound(self):
+        """A receiver of a ReceiverGroup caches state of its worker thread (that thread's library streams, events, scratch slots - a Gram table
+        pointer into them): its stages must be enqueued by that thread (``group.map(fn, which=[i])``), or nothing orders them against the
+        worker's streams."""
+        import threading
+        if self._owner_thread is not None and threading.get_ident() != self._owner_thread:
+            raise RuntimeError("this receiver belongs to a ReceiverGroup: enqueue its stages on its worker thread (group.map(lambda rx: ..., which=[i]) or group.run)")
+
     def build_gram(self):
         """Gram terms of the look-ahead trainer: once per capture, shared by all modes, stages and sweeps."""
+        self._bound()
         self._gram = None
         if self.tier == "a":
             # shared table only when a block form will read it (>= 128 steps) and it fits the library's scratch budget - otherwise
             # the trainers chunk the sweep themselves (csrc/train_impl.h: gram_budget), which a caller's table would switch off
             import os as _os
-            budget = float(_os.environ.get("QAMPY_HIP_GRAM_BUDGET_GB", 160.)) * 2 ** 30
+            budget = _lib.gram_budget_gb() * 2 ** 30
             fits = self.TrSyms[0] * 1024 * (np.dtype(self.ct).itemsize // 8) <= budget
             if len(set(self.TrSyms)) == 1 and self.TrSyms[0] >= 128 and fits and _os.environ.get("QAMPY_HIP_TRAINER", "") != "direct":
                 self._gram = _k.gram_build_dev(self.E, self.os, self.Ntaps, self.TrSyms[0])
@@ -133,16 +160,21 @@ class ResidentReceiver:
 
     def train(self, stage):
         tb = self.tier == "b"
+        self._bound()
         _k.train_equaliser_dev(self.E, self.TrSyms[stage], self.Niter[stage], self.os, self.mu[stage], self.wxy, self.modes,
                                self.adaptive[stage], self.symbols[stage], self.methods[stage], self.err[stage],
-                               gram=getattr(self, "_gram", None), pit=self.pit[stage] if tb else None,
+                               gram=getattr(self, "_gram", None), pit={k: v for k, v in self.pit[stage].items() if not k.startswith("_")} if tb else None,
                                report=self.pit_report[stage] if tb else None)
         if tb:
             self.pit_timing[stage] = _k.pit_last_timing()      # host-side copy of the HIP-event times: no synchronisation
             o = self.pit[stage]
-            if o.get("acquire") and not o.get("acq_chunk") and not self.adaptive[stage]:
-                # the chunk length of the acquisition (2 / the gear-shifted step the device derives from the signal power) as the first
-                # capture used it: handed back from now on, so that later calls do not wait for the device to say it (one read, once)
+            asked = getattr(self, "_acq_asked", None) or [False] * self.nstage
+            if o.get("acquire") and not o.get("acq_chunk") and not self.adaptive[stage] and not asked[stage]:
+                # a capture that was put into self.E directly (device-side synthesis, tests): the chunk length the device derived for it is
+                # read back ONCE (this synchronises: the one read of the receiver's life, whatever the report says - a sweep the library
+                # sent to the exact form has no acquisition to report and is not asked again); load() derives it on the host instead
+                asked[stage] = True
+                self._acq_asked = asked
                 a = self.pit_report[stage].read()["acquisition"]
                 if a["chunks"] > 0 and a["steps"] > 0:
                     o["acq_chunk"] = int(a["steps"] // a["chunks"])
@@ -164,9 +196,11 @@ class ResidentReceiver:
         self._recover()
 
     def _apply(self):
+        self._bound()
         _k.apply_filter_to_signal_dev(self.E, self.os, self.wxy, self.modes, self.eq)
 
     def _recover(self):
+        self._bound()
         _dsp.bps_recover_dev(self.eq, self.Mtestangles, self.alphabet, self.Nbps, self.idx, self.ph, self.out, angles=self.angles)
 
     def run(self, overlap=False, mark=None):
@@ -299,6 +333,9 @@ class ReceiverGroup:
             t.start()
 
     def _work(self, i):
+        import threading
+        if hasattr(self.rx[i], "_owner_thread"):
+            self.rx[i]._owner_thread = threading.get_ident()
         while True:
             job = self._jobs[i].get()
             if job is None:
@@ -358,6 +395,15 @@ class ReceiverGroup:
         for t in self._threads:
             t.join(timeout=10.)
         self._threads = []
+        for r in self.rx:                          # what pointed into the worker threads' (now released) scratch buffers and streams
+            for name in ("_gram", "_ev_post", "_ev_ready"):
+                if hasattr(r, name):
+                    setattr(r, name, None)
+            for name in ("_post_pending", "_post_running"):
+                if hasattr(r, name):
+                    setattr(r, name, False)
+            if hasattr(r, "_owner_thread"):
+                r._owner_thread = None
 
     def __del__(self):
         try:
@@ -470,8 +516,7 @@ class ChannelBank:
     def _train_stages(self, r):
         # one Gram table per channel shared by the stages when the bank's tables fit the library's scratch budget; otherwise
         # the trainers build them per time chunk themselves (csrc/train_impl.h: gram_budget)
-        import os as _os
-        budget = float(_os.environ.get("QAMPY_HIP_GRAM_BUDGET_GB", 160.)) * 2 ** 30
+        budget = _lib.gram_budget_gb() * 2 ** 30
         per_step = (256 if self.trainer == 3 else 1024) * (np.dtype(self.ct).itemsize // 8)
         fits = self.nch * self.TrSyms[0] * per_step <= budget
         self._gram = _k.gram_build_batch_dev(self.E, self.os, self.Ntaps, self.TrSyms[0]) if (len(set(self.TrSyms)) == 1 and fits) else None

@@ -6,8 +6,11 @@ from oracle import oracle
 
 
 class OracleField:                          # stands in for hip_equalisation.ResidentField (the capture resident in HBM)
-    def __init__(self, E):
+    def __init__(self, E, defer=False):
         self.E = E
+
+    def finish(self):
+        pass
 
     def train(self, *a):
         return oracle.train_equaliser(self.E, *a)

@@ -12,7 +12,7 @@ import pytest
 from conftest import CT, RT, TOL, golden_cases
 from oracle import oracle
 import qampy_amd
-from qampy_amd import synth, theory
+from qampy_amd import synth, theory, _lib
 from qampy_amd.signals import SignalQAM
 from qampy_amd.core.equalisation import hip_equalisation as hk
 from qampy_amd.core.equalisation import equalisation as core_eq
@@ -349,8 +349,12 @@ def test_time_chunked_training_equals_unchunked(monkeypatch, method, M):
         _, w0, _ = hk.train_equaliser(E, tr, 2, 2, np.float32(2e-3), w0, None, False, core_eq._reshape_symbols(None, "mcma", M, np.complex64, 2), "mcma")
     sy = core_eq._reshape_symbols(None, method, M, np.complex64, 2)
     e1, w1, _ = hk.train_equaliser(E, tr, 2, 2, np.float32(3e-4), w0.copy(), None, False, sy, method)
-    monkeypatch.setenv("QAMPY_HIP_GRAM_BUDGET_GB", "0.004")          # 4 MiB: chunks of 4096 steps (the minimum)
-    e2, w2, _ = hk.train_equaliser(E, tr, 2, 2, np.float32(3e-4), w0.copy(), None, False, sy, method)
+    budget = _lib.gram_budget_gb()
+    _lib.call("qh_set_gram_budget_gb", 0.004)                        # 4 MiB: chunks of 4096 steps (the minimum)
+    try:
+        e2, w2, _ = hk.train_equaliser(E, tr, 2, 2, np.float32(3e-4), w0.copy(), None, False, sy, method)
+    finally:
+        _lib.call("qh_set_gram_budget_gb", budget)
     assert np.all(np.isfinite(w2)) and np.abs(e2[:, -1]).min() > 0
     if method in ("mrde", "sbd"):
         assert np.array_equal(w1, w2) and np.array_equal(e1, e2)
