@@ -1053,6 +1053,8 @@ def main():
         tier_a = dict(method="exact sequential recurrence (reference order of evaluation)", value=round(nsym * args.steps / elapsed / 1e6, 4), unit="MSym/s",
                       steps=args.steps, ms_per_step=round(elapsed / args.steps * 1e3, 3), stages_ms={n: round(t, 3) for n, t in zip(stage_names, stage_ms)},
                       errors=[e for e, _ in errs])
+    per_rank = np.zeros((1, world)); per_rank[0, rank] = elapsed / args.steps * 1e3
+    per_rank_ms = [round(float(x), 3) for x in sharding.reduce_sum_counts(per_rank, cm)[0]]          # every rank's own ms per step
     elapsed = sharding.reduce_max_time(elapsed, cm)
     certified_local = 1.0 if (args.tier == "a" or tier_b["certified"]) else 0.0
     certified_all = int(round(sharding.reduce_sum_counts([[certified_local]], cm)[0, 0])) == world
@@ -1089,7 +1091,7 @@ def main():
                stages_ms={n: round(t, 3) for n, t in zip(stage_names, stage_ms)},
                ser=dict(per_mode_rank0=[e / max(n, 1) for e, n in errs], errors_rank0=[e for e, _ in errs], errors_all=int(counts_all[:, 0].sum()),
                         symbols_all=int(counts_all[:, 1].sum())),
-               device=_lib.device_name(), comm_backend=comm_backend)
+               device=_lib.device_name(), comm_backend=comm_backend, ms_per_step_per_rank=per_rank_ms)
     if comm_note:
         out["config"]["comm_note"] = comm_note
     if split:

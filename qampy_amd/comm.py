@@ -302,17 +302,13 @@ class Comm:
         def work():
             box["r"] = self._init_rccl(lib, uid)
 
-        sys.stdout.flush()
-        keep = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            t = threading.Thread(target=work, daemon=True)
-            t.start()
-            t.join(timeout)
-        finally:
-            sys.stdout.flush()
-            os.dup2(keep, 1)
-            os.close(keep)
+        # RCCL's own messages: warnings only, to stderr (rounds 2-4 pointed file descriptor 1 at stderr around the call instead - a process-wide
+        # side effect on every thread that happened to print meanwhile)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+        t = threading.Thread(target=work, daemon=True)
+        t.start()
+        t.join(timeout)
         if t.is_alive():
             self.stuck = True
             return False, "ncclCommInitRank did not return within %g s" % timeout

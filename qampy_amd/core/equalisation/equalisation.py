@@ -250,7 +250,11 @@ def _tier_options(kwargs, nstages, cold):
         raise ValueError("pit needs one options dict per stage")
     for k, o in enumerate(per_stage):
         o.setdefault("acquire", 1 if (k == 0 and cold) else 0)     # centre-spike start taps: sequential acquisition first
-        # (every stage is held to the same tolerance: what a seeding stage leaves in the weakly excited tap directions reaches the result undamped)
+    if not isinstance(pit, (list, tuple)):
+        # `tol` bounds what the call returns (output <= tol, taps and error traces <= 3 tol): the last stage is certified at tol, an earlier one -
+        # which returns an error trace and hands on taps - at 2 tol (pipeline.ResidentReceiver.NONFINAL_TOL_FACTOR; one dict per stage overrides)
+        for o in per_stage[:-1]:
+            o["tol"] = 2.0 * float(o.get("tol") or 1e-3)
     return per_stage
 
 

@@ -74,7 +74,7 @@ def test_tier_b_at_full_size_against_the_oracle(key, tol):
     res = rx.fetch()
     reps = rx.pit_reports()
     assert all(r["converged"] for r in reps), reps
-    assert all(abs(r["tol"] - tol) < 1e-12 for r in reps), reps
+    assert abs(reps[-1]["tol"] - tol) < 1e-12 and all(abs(r["tol"] - ResidentReceiver.NONFINAL_TOL_FACTOR * tol) < 1e-12 for r in reps[:-1]), reps
     # what the headline is quoted on: the parallel-in-time solver certified every stage itself (no exact-form way out was needed)
     assert not any(r["exact_form"] for r in reps), reps
     for m in range(2):

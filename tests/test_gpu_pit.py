@@ -207,7 +207,7 @@ def test_ser_equivalence_at_scale():
         # the device's certificate: the last pass's estimated rms deviation is below the tolerance it was held to
         assert all(st["deviation_rms"][-1] < st["tol"] and st["deviation"][-1] < 3 * st["tol"] for st in res[k]["rep"]), res[k]["rep"]
     assert all(st["passes"] <= 10 for st in res["b"]["rep"]) and all(st["passes"] <= 6 for st in res["b_loose"]["rep"]), (res["b"]["rep"], res["b_loose"]["rep"])
-    assert all(st["tol"] == 1e-3 for st in res["b"]["rep"])
+    assert res["b"]["rep"][-1]["tol"] == 1e-3 and res["b"]["rep"][0]["tol"] == ResidentReceiver.NONFINAL_TOL_FACTOR * 1e-3     # (non-final stage: error trace and taps, 3 tol)
     # measured deviation from the exact path, which starts from the same taps (modulo a common quarter turn per mode): relative tap
     # deviation, rms deviation of the equalised signal, rms deviation of the error traces (in units of the signal rms; an error
     # function multiplies an output deviation by its slope, up to ~2 for cma)

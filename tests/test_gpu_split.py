@@ -86,3 +86,21 @@ def test_rccl_single_rank_and_duplicate_device_fallback():
     rep = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rep["ranks"] == [2.0] and rep["backend"] in ("rccl", "tcp"), (rep, out.stderr[-1500:])
     assert rep["backend"] == "rccl" or "rccl unavailable" in rep["note"]
+
+
+def test_rccl_world2_communicator_and_bench_when_two_gpus_are_visible():
+    """With >= 2 devices visible: a world-2 RCCL communicator (qampy_amd.comm through ctypes: ncclCommInitRank on two ranks, one GPU each) carries
+    bench.py's reductions and the line says so - so that the driver's 8-GPU run is not RCCL's first run with more than one rank.  Skipped on
+    the 1-GPU boxes of the test tier."""
+    from qampy_amd import _lib
+    if _lib.device_count() < 2:
+        pytest.skip("one GPU visible: RCCL refuses two ranks on one device (covered above)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    env.pop("QAMPY_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nsym", str(2 ** 20), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--bank", "0", "--no-extra-shapes"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rep = json.loads(line)
+    assert rep.get("comm_backend") == "rccl", (rep.get("comm_backend"), rep.get("config", {}).get("comm_note"), out.stderr[-1500:])
+    assert rep["n_gpus"] == 2 and rep["ranks_seen"] == 2 and rep["scaling"] == "weak" and len(rep["ms_per_step_per_rank"]) == 2
+    assert min(rep["ms_per_step_per_rank"]) > 0 and rep["ser"]["errors_all"] == 0

@@ -47,8 +47,11 @@ def oracle_kernels(monkeypatch):
     k = core_eq._kernels
 
     class OracleField:                      # stands in for hip_equalisation.ResidentField (the capture resident in HBM)
-        def __init__(self, E):
+        def __init__(self, E, defer=False):
             self.E = E
+
+        def finish(self):
+            pass
 
         def train(self, *a):
             return oracle.train_equaliser(self.E, *a)
@@ -271,18 +274,23 @@ def _config5_chain(cap, dtype):
 
 
 @pytest.mark.gpu
-def test_config5_256qam_against_oracle_kernel_chain(monkeypatch):
+@pytest.mark.parametrize("prec", ["c128", "c64"])
+def test_config5_256qam_against_oracle_kernel_chain(monkeypatch, prec):
     """BASELINE config 5 as stated: 256-QAM payload, 2^16-symbol frames, 2 modes, 2 SPS, frequency offset and modal delay -
     frame sync, pilot-sequence equaliser (data-aided second stage), filter over the frame and pilot phase recovery on the HIP
-    kernels against the same host layer running on the oracle's kernels."""
+    kernels against the same host layer running on the oracle's kernels; complex128 and complex64 (the performance dtype of the path)."""
     from qampy_amd import synth
+    dtype = np.complex128 if prec == "c128" else np.complex64
     cap = synth.make_pilot_capture()
-    hip = _config5_chain(cap, np.complex128)
+    hip = _config5_chain(cap, dtype)
     k = core_eq._kernels
 
     class OracleField:
-        def __init__(self, E):
+        def __init__(self, E, defer=False):
             self.E = E
+
+        def finish(self):
+            pass
 
         def train(self, *a):
             return oracle.train_equaliser(self.E, *a)
@@ -297,8 +305,16 @@ def test_config5_256qam_against_oracle_kernel_chain(monkeypatch):
     monkeypatch.setattr(k, "train_equaliser_windows_search", _oracle_search)
     monkeypatch.setattr(phaserecovery._dsp, "comp_freq_offset", _numpy_cfo)
     monkeypatch.setattr(phaserecovery._dsp, "pilot_phase_trace", _numpy_trace)
-    cpu = _config5_chain(cap, np.complex128)
+    cpu = _config5_chain(cap, dtype)
     assert hip["ok"] and cpu["ok"] and np.array_equal(hip["shifts"], cpu["shifts"])
-    np.testing.assert_allclose(hip["taps"], cpu["taps"], rtol=1e-8, atol=1e-8)
-    np.testing.assert_allclose(hip["out"], cpu["out"], rtol=0, atol=1e-6)
-    assert np.array_equal(hip["ser"], cpu["ser"]) and hip["ser"].max() < 5e-2
+    if prec == "c128":
+        np.testing.assert_allclose(hip["taps"], cpu["taps"], rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(hip["out"], cpu["out"], rtol=0, atol=1e-6)
+        assert np.array_equal(hip["ser"], cpu["ser"]) and hip["ser"].max() < 5e-2
+    else:
+        # complex64: 2 x 30 sweeps of the adaptive-step recurrence in single precision on both sides, in different summation orders (tests/conftest.py:
+        # rtol / atol 1e-4 for one sweep of a few thousand steps); the 256-QAM decisions of the two chains may part on a few symbols of 2 x 2^16
+        tap_dev = float(np.max(np.abs(hip["taps"] - cpu["taps"])))
+        out_dev = float(np.sqrt(np.mean(np.abs(hip["out"] - cpu["out"]) ** 2) / np.mean(np.abs(cpu["out"]) ** 2)))
+        assert tap_dev <= 1e-3 and out_dev <= 2e-3, (tap_dev, out_dev)
+        assert np.max(np.abs(hip["ser"] - cpu["ser"])) <= 3e-4 and hip["ser"].max() < 5e-2, (hip["ser"], cpu["ser"])
