@@ -149,7 +149,7 @@ def timed_steps(rx, steps, warmup, barrier_sync, overlap=False):
     if overlap:
         order = ["start", "gram"] + ["train%d" % s for s in range(rx.nstage)] + ["apply"]
         for _ in range(warmup):
-            rx.run(overlap=True)
+            rx.run(overlap=True, prefetch=True)
         rx.wait_post()
         pool = [_lib.Event() for _ in range(steps * (len(order) + 2) + 2)]
         marks = [dict() for _ in range(steps + 1)]
@@ -168,7 +168,7 @@ def timed_steps(rx, steps, warmup, barrier_sync, overlap=False):
         barrier_sync()
         t0 = time.perf_counter()
         for k in range(steps):
-            rx.run(overlap=True, mark=marker(k))
+            rx.run(overlap=True, mark=marker(k), prefetch=True)      # (prefetch: the next capture's acquisition + eigenbasis beside this capture's cold stage)
         rx.wait_post(marker(steps))
         barrier_sync()
         elapsed = time.perf_counter() - t0
@@ -206,7 +206,7 @@ def timed_group(group, steps, warmup, barrier_sync, overlap=True):
     pass_ms = [[] for _ in range(rx0.nstage)]
     acq_ms = [[] for _ in range(rx0.nstage)]
     order = ["start", "gram"] + ["train%d" % s for s in range(rx0.nstage)] + ["apply"]
-    group.run(warmup * n, overlap=overlap)
+    group.run(warmup * n, overlap=overlap, prefetch=overlap)
     pools = [[_lib.Event() for _ in range((steps // n + 2) * (len(order) + 3) + 4)] for _ in range(n)]
     marks = {}
 
@@ -225,7 +225,7 @@ def timed_group(group, steps, warmup, barrier_sync, overlap=True):
         return m
     barrier_sync()
     t0 = time.perf_counter()
-    group.run(steps, overlap=overlap, mark=mark)
+    group.run(steps, overlap=overlap, mark=mark, prefetch=overlap)
     barrier_sync()
     elapsed = time.perf_counter() - t0
     full = [d for d in marks.values() if "apply" in d]
@@ -800,10 +800,10 @@ def in_flight_block(cfg, sig, nsym, n, steps, barrier_sync, pit):
     g = make_group(n, cfg, sig, pit)
     try:
         g.load(sig)
-        g.run(2 * n)
+        g.run(2 * n, prefetch=True)
         barrier_sync()
         t0 = time.perf_counter()
-        g.run(steps)
+        g.run(steps, prefetch=True)
         barrier_sync()
         el = time.perf_counter() - t0
         res = [r.fetch() for r in g.rx]

@@ -357,6 +357,13 @@ typedef struct qh_pit_opts {
                              * below acq_anneal x mu; < 0: every chunk at the gear-shifted step (rounds 2-3) (ABI 6) */
     double mu_hint;         /* fixed step: the caller's HOST copy of *mu (> 0), so that the call does not have to read it back; with it - and acq_chunk
                              * given when acquire != 0 - the call enqueues its whole prologue without a host synchronisation (0: read back) (ABI 7) */
+    void *prepared;         /* cold start (acquire != 0): NULL, or the device buffer a qh_pit_prepare_*_dev call for THIS capture, these start taps, this step
+                             * size and method filled: the acquisition has run already (beside the previous capture's training, on another stream) -
+                             * the call adopts its taps and report fields instead of running it.  The caller orders the two (qh_stream_wait_event). (ABI 8) */
+    void (*on_pass0)(void *user);   /* NULL, or a function the call invokes ONCE, on the calling thread, right after it has enqueued the first relaxation pass: the
+                             * place to enqueue work for OTHER library streams (the previous capture's phase search, the next capture's preparation) whose
+                             * launches would otherwise sit in front of this sweep's; it must leave the current library stream as it found it (ABI 8) */
+    void *on_pass0_user;
 } qh_pit_opts;
 typedef struct qh_pit_report {
     int32_t segments, passes, converged, acq_chunks;
@@ -387,6 +394,16 @@ int qh_pit_basis_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntap
  * the timed relaxation passes in order (all sweeps) and the sum of the acquisition chunks.  An event idles the stream for ~5.6 us,
  * so by default ONE pass per sweep is timed (pass 1); environment QAMPY_HIP_PIT_TIMING = all (every pass) | none. */
 int qh_pit_last_timing(float *pass_ms, int max_passes, int *npass, float *acq_ms);
+/* The sequential part of a COLD sweep ahead of time (ABI 8): the gear-shifted acquisition of a capture depends on the capture, the start taps, the step
+ * size and the error function only - not on anything the previous capture's training produces - so a receiver that is handed capture after capture runs
+ * it for capture k + 1 on another library stream while capture k trains (pipeline.ResidentReceiver.run(prefetch=True)), and hands the result to the
+ * training call through qh_pit_opts.prepared.  Same kernels on the same data as the acquisition inside the call: bit-identical results.
+ * opts: as for the training call (segments, mu_hint and acq_chunk must be given - the call never synchronises); prep: device memory of
+ * qh_pit_prepare_bytes(...) bytes.  Returns QH_ERR_ARG with "not preparable" for a sweep whose acquisition cannot run ahead (decision-directed or
+ * adaptive stages, latency-form passes): the caller then simply does not pass `prepared`. */
+int qh_pit_prepare_bytes(int nmodes, int ntaps, int64_t acq_steps, size_t elem_bytes, size_t *bytes);
+int qh_pit_prepare_c64_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int os, const float *mu_dev, const void *wx0, int ntaps,
+                           const int64_t *modes, int nsel, const void *symbols, int64_t nsy, int method, const qh_pit_opts *opts, void *prep, size_t prep_bytes);
 int qh_last_pit_report(qh_pit_report *out);      /* host copy of the report of the calling thread's most recent host-array solve through tier b (qh_set_default_tier) */
 int qh_train_equaliser_c64_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, float *mu_dev,
                                    void *wx, int ntaps, const int64_t *modes, int nsel, const void *symbols, int64_t nsy,

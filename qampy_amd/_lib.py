@@ -84,6 +84,8 @@ SIGNATURES = {
     "qh_train_equaliser_c64_pit_dev": [_vp, _i, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp],
     "qh_train_equaliser_c128_pit_dev": [_vp, _i, _i64, _i64, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _vp, _i, _vp, _vp, _vp],
     "qh_pit_auto_segments": [_i64, C.c_double, _i, _i, C.POINTER(_i)],
+    "qh_pit_prepare_bytes": [_i, _i, _i64, _sz, C.POINTER(_sz)],
+    "qh_pit_prepare_c64_dev": [_vp, _i, _i64, _i64, _i, _vp, _vp, _i, _vp, _i, _vp, _i64, _i, _vp, _vp, _sz],
     "qh_pit_last_timing": [_pf, _i, C.POINTER(_i), _pf],
     "qh_pit_basis_bytes": [_i, C.POINTER(_sz)],
     "qh_pit_basis_c64_dev": [_vp, _i, _i64, _i, _i, _i64, _vp, _i],
@@ -119,8 +121,11 @@ class PitOpts(C.Structure):
                 ("tol", C.c_double), ("gear", C.c_double), ("acq_bound", C.c_double), ("acq_plateau", C.c_double),
                 ("acq_chunk", C.c_int64), ("acq_max", C.c_int64), ("correction", C.c_int32), ("head_steps", C.c_int32), ("basis", C.c_void_p), ("corr_beta", C.c_double),
                 ("seg_first", C.c_int32), ("seg_count", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p),
-                ("start", C.c_int32), ("exchange_on_stream", C.c_int32), ("dev_safety", C.c_double), ("adaptive", C.c_int32), ("exact_redo_off", C.c_int32), ("head_auto_off", C.c_int32), ("acq_anneal", C.c_int32), ("mu_hint", C.c_double)]
+                ("start", C.c_int32), ("exchange_on_stream", C.c_int32), ("dev_safety", C.c_double), ("adaptive", C.c_int32), ("exact_redo_off", C.c_int32), ("head_auto_off", C.c_int32), ("acq_anneal", C.c_int32), ("mu_hint", C.c_double), ("prepared", C.c_void_p), ("on_pass0", C.c_void_p), ("on_pass0_user", C.c_void_p)]
 
+
+#: signature of ``qh_pit_opts.on_pass0``: (user) -> None
+PIT_HOOK = C.CFUNCTYPE(None, C.c_void_p)
 
 #: signature of ``qh_pit_opts.exchange``: (user, device pointer of the segments' end taps, bytes) -> 0
 PIT_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)

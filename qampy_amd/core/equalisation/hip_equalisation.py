@@ -525,6 +525,45 @@ def pit_basis_dev(E, os, ntaps, TrSyms, basis=None, overlap=False):
     return basis
 
 
+def _pit_opts(pit):
+    o = _lib.PitOpts()
+    o.phase_seed = -1
+    o.correction = -1
+    o.corr_beta = -1.
+    for k, v in pit.items():
+        if not hasattr(o, k):
+            raise ValueError("unknown parallel-in-time option %s" % k)
+        setattr(o, k, v)
+    return o
+
+
+def pit_prepare_bytes(nmodes, ntaps, acq_steps, dtype=np.complex64):
+    n = C.c_size_t(0)
+    _lib.call("qh_pit_prepare_bytes", int(nmodes), int(ntaps), int(acq_steps), np.dtype(dtype).itemsize, C.byref(n))
+    return n.value
+
+
+def pit_prepare_dev(E, TrSyms, os, mu, wx0, modes, symbols, method, pit, prep):
+    """The acquisition of a cold tier-b sweep AHEAD of the training call (``qh_pit_prepare_c64_dev``), enqueued on the current library stream: ``wx0``
+    the start taps (not modified), ``mu`` the 1-element DeviceArray of the step, ``pit`` the options of the training call (``segments``, ``mu_hint``,
+    ``acq_chunk`` given), ``prep`` a DeviceArray of :func:`pit_prepare_bytes`.  Hand ``prep.ptr`` to the training call as ``pit["prepared"]`` (after
+    ordering the two streams).  Returns False - nothing enqueued - when the sweep's acquisition cannot run ahead."""
+    suf, rt, ct = _lib.suffix(E.dtype)
+    if suf != "32":
+        return False
+    nmodes, L = E.shape
+    modes = _as_modes(modes, nmodes)
+    o = _pit_opts(pit)
+    try:
+        _lib.call("qh_pit_prepare_c64_dev", E.ptr, nmodes, L, int(TrSyms), int(os), mu.ptr, wx0.ptr, wx0.shape[-1], _lib.ptr(modes), modes.size,
+                  symbols.ptr, symbols.shape[1], _lib.METHOD_ID[method], C.byref(o), prep.ptr, prep.nbytes)
+    except ValueError as e:
+        if "not preparable" in str(e):
+            return False
+        raise
+    return True
+
+
 def pit_last_timing():
     """Kernel time of the trainer launches of the most recent parallel-in-time call: ``(pass_ms list, acquisition ms)``."""
     buf = (C.c_float * _lib.PIT_MAXPASS)()

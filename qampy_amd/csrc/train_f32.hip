@@ -54,6 +54,16 @@ int qh_pit_last_timing(float *pass_ms, int max_passes, int *npass, float *acq_ms
     *acq_ms = t.acq_ms;
     return QH_OK;
 }
+int qh_pit_prepare_bytes(int nmodes, int ntaps, int64_t acq_steps, size_t elem_bytes, size_t *bytes)
+{
+    *bytes = elem_bytes == 16 ? qh::pit_prep_layout<double>(nmodes, ntaps, acq_steps).total : qh::pit_prep_layout<float>(nmodes, ntaps, acq_steps).total;
+    return QH_OK;
+}
+int qh_pit_prepare_c64_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int os, const float *mu_dev, const void *wx0, int ntaps,
+                           const int64_t *modes, int nsel, const void *symbols, int64_t nsy, int method, const qh_pit_opts *opts, void *prep, size_t prep_bytes)
+{
+    return qh::pit_prepare<float>(E, nmodes, L, TrSyms, os, mu_dev, wx0, ntaps, modes, nsel, symbols, nsy, method, opts, prep, prep_bytes);
+}
 int qh_pit_auto_segments(int64_t TrSyms, double mu, int nsel, int cold, int *segments)
 {
     *segments = qh::pit_auto_segments(TrSyms, mu, nsel, cold);

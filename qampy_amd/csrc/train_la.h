@@ -504,15 +504,15 @@ template <typename R> static size_t gram_bytes(int64_t TrSyms)
 // nch captures (nch, nmodes, L) -> nch Gram tables, gram_bytes() apart, in ONE scratch allocation
 // L: usable samples per row starting at E, Lp: row pitch (0 = L), ch_stride: samples between channels (0 = nmodes * Lp)
 template <typename R> int gram_build(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void **gram, int nch = 1,
-                                     int64_t Lp = 0, int64_t ch_stride = 0)
+                                     int64_t Lp = 0, int64_t ch_stride = 0, void *into = nullptr)
 {
     if (Lp <= 0) Lp = L;
     if (ch_stride <= 0) ch_stride = (int64_t)nmodes * Lp;
     int rc = ensure_init();
     if (rc) return rc;
     const size_t bytes = gram_bytes<R>(TrSyms);
-    void *G0 = nullptr;
-    if ((rc = scratch(4, bytes * (size_t)nch, &G0))) return rc;
+    void *G0 = into;                                             // (the caller's buffer - gram_bytes(TrSyms) x nch - or the library's scratch)
+    if (!G0 && (rc = scratch(4, bytes * (size_t)nch, &G0))) return rc;
     const int64_t nblk = (TrSyms + LA_B - 1) / LA_B;
     const size_t lds = (size_t)nmodes * ((2 * LA_B - 1) * os + ntaps) * sizeof(Cx<R>);
     QH_REQUIRE(lds <= 64 * 1024, "gram: nmodes*(127*os+ntaps) samples exceed the LDS tile");

@@ -2147,6 +2147,124 @@ int pit_basis(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t T
     return QH_OK;
 }
 
+// ---- the acquisition of a cold sweep ahead of time (qh_pit_prepare_*_dev / qh_pit_opts.prepared) -----------------------------------------------
+// Layout of a preparation buffer: [PitCtrl][mu_acq, 64 B][modes_dev, 128 B][acquired taps][start taps][error trace of the acquisition range][Gram table]
+struct PitPrepLayout { size_t ctrl, mu_acq, modes, wx, w0, err, gram, total; int64_t err_pitch; };
+template <typename R> inline PitPrepLayout pit_prep_layout(int nmodes, int ntaps, int64_t acq_steps)
+{
+    PitPrepLayout l;
+    auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t wset = (size_t)nmodes * nmodes * ntaps * sizeof(Cx<R>);
+    l.err_pitch = (acq_steps + LA_B + 63) / 64 * 64;
+    l.ctrl = 0; l.mu_acq = up(sizeof(PitCtrl)); l.modes = l.mu_acq + 64; l.wx = up(l.modes + 128); l.w0 = up(l.wx + wset);
+    l.err = up(l.w0 + wset); l.gram = up(l.err + (size_t)nmodes * l.err_pitch * sizeof(Cx<R>));
+    l.total = up(l.gram + gram_bytes<R>(l.err_pitch));
+    return l;
+}
+// the training call adopts a prepared acquisition: its taps (unless it diverged: then the sweep starts from the caller's taps, as pit_acq_finish_kernel
+// leaves them) and what the report says about it
+template <typename R> __global__ void __launch_bounds__(256) pit_adopt_kernel(Cx<R> *wx, const Cx<R> *wx_prep, int n, const PitCtrl *p, PitCtrl *c, R *mu_acq, const R *mu_acq_prep)
+{
+    QH_WAVE_FIRST();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (!p->diverged && i < n) wx[i] = wx_prep[i];
+    if (i == 0) {
+        c->acq_chunks = p->acq_chunks; c->acq_steps = p->acq_steps; c->acq_done = 1; c->diverged = p->diverged; c->mu_acq = p->mu_acq;
+        for (int q = 0; q < QH_PIT_MAXCHUNK; q++) c->acq_err[q] = p->acq_err[q];
+        *mu_acq = *mu_acq_prep;
+    }
+}
+template <typename R>
+int pit_prepare(const void *E, int nmodes, int64_t L, int64_t TrSyms, int os, const R *mu_dev, const void *wx0, int ntaps, const int64_t *modes, int nsel,
+                const void *symbols, int64_t nsy, int method, const qh_pit_opts *opts, void *prep, size_t prep_bytes)
+{
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (method < 0 || method > QH_M_SBD_DATA) { set_error("unknown equaliser method id"); return QH_ERR_METHOD; }
+    QH_REQUIRE(opts && prep, "pit prepare: options and a preparation buffer are needed");
+    QH_REQUIRE(nmodes >= 1 && ntaps >= 1 && os >= 1 && TrSyms >= 1 && nsel >= 1 && nsel <= 16 && nsy >= 1, "pit prepare: bad sizes");
+    QH_REQUIRE((TrSyms - 1) * os + ntaps <= L, "pit prepare: field shorter than TrSyms*os + ntaps");
+    for (int j = 0; j < nsel; j++) QH_REQUIRE(modes[j] >= 0 && modes[j] < nmodes, "pit prepare: mode number >= nmodes");
+    const qh_pit_opts &o = *opts;
+    QH_REQUIRE(o.acquire != 0 && o.adaptive == 0 && o.segments > 1 && o.mu_hint > 0 && o.acq_chunk > 0 && o.head_steps == 0 && !o.exchange,
+               "pit prepare: not preparable (a cold fixed-step sweep with segments, mu_hint and acq_chunk given)");
+    const int ntot = nmodes * ntaps;
+    // ---- the decisions of train_pit_dev that the acquisition depends on (same rules: the two must run the same kernels)
+    int S = o.segments;
+    const int64_t nblk_all = TrSyms / LA_B;
+    if ((int64_t)S * 4 > nblk_all) S = (int)(nblk_all / 4);
+    QH_REQUIRE(S >= 2, "pit prepare: not preparable (nothing to parallelise)");
+    const int64_t seg_len = nblk_all / S * LA_B;
+    const char *force = trainer_force();
+    const bool decision = method == QH_M_SBD || method == QH_M_MDDMA || method == QH_M_DD;
+    const bool bi_ok = force[0] != 'd' && force[0] != 'l' && bi_supported(method, 0, nmodes, ntaps, os, seg_len, nsy, sizeof(Cx<R>));
+    bool seg_ok = force[0] == 0 && seg_supported(method, nmodes, ntaps, os, nsy, sizeof(Cx<R>), nsel);
+    {
+        const char *pf = getenv("QAMPY_HIP_PIT_FORM");
+        if (pf && pf[0] == 'b') seg_ok = false;
+        else if (!(pf && pf[0] == 's') && (int64_t)S * nsel < 512) seg_ok = false;
+    }
+    const bool la_ok = force[0] != 'd' && la_supported(method, 0, nmodes, ntaps, os, seg_len, nsy);
+    const bool use_bi = bi_ok && (decision || !la_ok || force[0] == 'i');
+    const bool block_form = use_bi || la_ok;
+    QH_REQUIRE(seg_ok && block_form && !decision && method != QH_M_SBD_DATA && la_shape_ok(nmodes, ntaps, os),
+               "pit prepare: not preparable (throughput-form passes, block-form acquisition, blind error function)");
+    const bool pair_tab = use_bi ? la_shape_ok(nmodes, ntaps, os) : true;
+    const double gear = o.gear > 0 ? o.gear : 8.0, bound = o.acq_bound > 0 ? o.acq_bound : 0.08, plateau = o.acq_plateau > 0 ? o.acq_plateau : 0.8;
+    int64_t acq_ch = (o.acq_chunk + LA_B - 1) / LA_B * LA_B;
+    int64_t amax = o.acq_max > 0 ? o.acq_max : 2 * acq_ch;
+    if (amax > TrSyms / 2 && o.acq_max <= 0) amax = TrSyms / 2;
+    if (amax > TrSyms) amax = TrSyms;
+    const PitPrepLayout lay = pit_prep_layout<R>(nmodes, ntaps, amax);
+    QH_REQUIRE(prep_bytes >= lay.total, "pit prepare: preparation buffer too small (qh_pit_prepare_bytes)");
+    char *pb = (char *)prep;
+    PitCtrl *ctrl = (PitCtrl *)(pb + lay.ctrl);
+    R *mu_acq = (R *)(pb + lay.mu_acq);
+    int64_t *modes_dev = (int64_t *)(pb + lay.modes);
+    Cx<R> *wxp = (Cx<R> *)(pb + lay.wx), *w0 = (Cx<R> *)(pb + lay.w0), *errp = (Cx<R> *)(pb + lay.err);
+    const size_t wset = (size_t)nmodes * ntot, wbytes = wset * sizeof(Cx<R>);
+    PitSeg sg; sg.S = S; sg.len = seg_len; sg.extra = nblk_all - (seg_len / LA_B) * S; sg.tail = TrSyms - nblk_all * LA_B; sg.begin = 0;
+    const int64_t npow = L < 4096 ? L : 4096;
+    hipLaunchKernelGGL((pit_setup_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const Cx<R> *)E, nmodes, L, npow, ntot, mu_dev, gear, bound, o.tol > 0 ? o.tol : 1e-3, sg, ctrl, mu_acq);
+    PitInit init{};
+    init.cd[0] = wxp; init.cs[0] = wx0; init.cn[0] = (unsigned)wbytes;
+    init.cd[1] = w0; init.cs[1] = wx0; init.cn[1] = (unsigned)wbytes;
+    init.modes_dev = modes_dev; init.nsel = nsel;
+    for (int j = 0; j < 16; j++) init.modes[j] = j < nsel ? modes[j] : 0;
+    hipLaunchKernelGGL(pit_init_kernel, dim3(32), dim3(256), 0, g_stream, init);
+    const int64_t ngram = (amax / LA_B + 1) * LA_B < TrSyms ? (amax / LA_B + 1) * LA_B : TrSyms;
+    QH_REQUIRE(ngram <= lay.err_pitch, "pit prepare: acquisition range exceeds the preparation buffer");
+    void *G = nullptr;
+    rc = pair_tab ? gram_build<R>(E, nmodes, L, os, ntaps, ngram, &G, 1, 0, 0, pb + lay.gram) : QH_ERR_ARG;
+    if (rc) return rc;
+    const int64_t g_per_step = LA_B;
+    int64_t CH = acq_ch;
+    if (CH * QH_PIT_MAXCHUNK < amax) CH = (amax + QH_PIT_MAXCHUNK - 1) / QH_PIT_MAXCHUNK;
+    CH = (CH + LA_B - 1) / LA_B * LA_B;
+    if (CH < 4 * LA_B) CH = 4 * LA_B;
+    const int nchunks = (int)(amax / CH);
+    LaArgs<R> la;
+    la.E = (const Cx<R> *)E; la.symbols = (const Cx<R> *)symbols; la.err = errp; la.G = (const GramPair<R> *)G; la.gpair = 1;
+    la.mu = mu_acq; la.mu_out = nullptr; la.mu_cs = 0; la.mu_ms = 0;
+    la.L = L; la.Lp = L; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = lay.err_pitch;
+    la.nmodes = nmodes; la.ntaps = ntaps; la.os = os; la.nsel = nsel; la.method = method;
+    la.E_cs = 0; la.err_cs = 0; la.G_cs = 0; la.wx_cs = 0;
+    for (int j = 0; j < 16; j++) la.modes[j] = j < nsel ? modes[j] : 0;
+    la.prof = nullptr; la.seg = 0; la.seg_extra = 0; la.seg_tail = 0; la.skip = &ctrl->acq_done; la.niter = 1;
+    for (int c = 0; c < nchunks; c++) {
+        const int64_t step0 = (int64_t)c * CH;
+        LaArgs<R> lp = la;
+        lp.E = (const Cx<R> *)E + step0 * os; lp.L = L - step0 * os; lp.TrSyms = CH; lp.nch = 1; lp.wx = wxp;
+        lp.G = (const GramPair<R> *)G + step0 * g_per_step; lp.err_off = step0;
+        if ((rc = use_bi ? launch_bi<R>(lp) : launch_la<R>(lp))) return rc;
+        hipLaunchKernelGGL((pit_acq_monitor_kernel<R>), dim3(1), dim3(256), 0, g_stream, (const Cx<R> *)errp, (int64_t)lay.err_pitch, step0, CH,
+                           nsel, (const int64_t *)modes_dev, plateau, ctrl, mu_acq, mu_dev, o.acq_anneal < 0 ? -1.0 : (o.acq_anneal > 0 ? (double)o.acq_anneal : 2.0));
+    }
+    hipLaunchKernelGGL((pit_acq_finish_kernel<R>), dim3((unsigned)((wset + 255) / 256)), dim3(256), 0, g_stream, wxp, (const Cx<R> *)w0, (int)wset, ctrl);
+    QH_HIP(hipGetLastError());
+    return QH_OK;
+}
+
 template <typename R>
 int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, int os, R *mu_dev, void *wx, int ntaps,
                   const int64_t *modes, int nsel, const void *symbols, int64_t nsy, int method, void *err, int zero_err,
@@ -2361,7 +2479,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     // start, the gear-shifted step size pit_setup_kernel chose (it sizes the acquisition chunks).  A caller that hands over its host copy of
     // the step (mu_hint) and the chunk length (acq_chunk: from the report of an earlier capture) spares the call its one synchronisation -
     // ~90 us of idle GPU per stage at C3.
-    const bool need_mu = adaptive || !(o.mu_hint > 0), need_acq = o.acquire && !(o.acq_chunk > 0);
+    const bool prepared = o.prepared != nullptr && o.acquire && !adaptive && head == 0 && Niter >= 1;
+    const bool need_mu = adaptive || !(o.mu_hint > 0), need_acq = o.acquire && !(o.acq_chunk > 0) && !prepared;
     R mu_acq_h = 0;                                               // the gear-shifted step size pit_setup_kernel chose (sizes the acquisition run)
     if (need_acq) QH_HIP(hipMemcpyAsync(&mu_acq_h, mu_acq, sizeof(R), hipMemcpyDeviceToHost, g_stream));
     R mu_host = need_mu ? (R)1 : (R)o.mu_hint;
@@ -2400,7 +2519,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         if (amax > TrSyms) amax = TrSyms;
     }
     void *G = const_cast<void *>(gram);
-    if (block_form && !G && (!seg_form || amax > 0)) {
+    if (prepared) QH_REQUIRE(seg_form && o.acq_chunk > 0, "train_equaliser: a prepared acquisition belongs to throughput-form passes with acq_chunk given (qh_pit_prepare_*_dev said so)");
+    if (block_form && !G && (!seg_form || amax > 0) && !prepared) {
         const int64_t n = seg_form ? (amax / LA_B + 1) * LA_B < TrSyms ? (amax / LA_B + 1) * LA_B : TrSyms : TrSyms;
         rc = pair_tab ? gram_build<R>(E, nmodes, L, os, ntaps, n, &G) : gram_cur_build<R>(E, nmodes, L, os, ntaps, n, &G);
         if (rc) return rc;
@@ -2497,7 +2617,14 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     QH_HIP(hipGetLastError());
     for (int it = 0; it < Niter; it++) {
         // ================================================================ acquisition (first sweep of a cold start)
-        if (it == 0 && o.acquire) {
+        if (it == 0 && prepared) {
+            // the acquisition ran ahead of the call (qh_pit_prepare_*_dev, on another stream beside the previous capture's training): adopt it
+            const PitPrepLayout lay = pit_prep_layout<R>(nmodes, ntaps, amax);
+            const char *pb = (const char *)o.prepared;
+            hipLaunchKernelGGL((pit_adopt_kernel<R>), dim3((unsigned)((wset + 255) / 256)), dim3(256), 0, g_stream, (Cx<R> *)wx, (const Cx<R> *)(pb + lay.wx), (int)wset,
+                               (const PitCtrl *)(pb + lay.ctrl), ctrl, mu_acq, (const R *)(pb + lay.mu_acq));
+            QH_HIP(hipGetLastError());
+        } else if (it == 0 && o.acquire) {
             int64_t CH = acq_ch;
             if (CH * QH_PIT_MAXCHUNK < amax) CH = (amax + QH_PIT_MAXCHUNK - 1) / QH_PIT_MAXCHUNK;
             CH = (CH + LA_B - 1) / LA_B * LA_B;
@@ -2705,6 +2832,11 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         // a pass enqueued in vain costs a dozen empty launches (~55 us), about as much as the idle round trip it would save:
         // expected defect of pass p = PIT_CONTRACT x the defect of pass p - 1 (the first pass never converges from seeds).
         if ((rc = enqueue_pass(0))) return rc;
+        if (it == 0 && o.on_pass0) {                              // the caller's work for the other streams: enqueued while pass 0 keeps the device busy
+            hipStream_t keep = g_stream;
+            o.on_pass0(o.on_pass0_user);
+            g_stream = keep;
+        }
         bool ahead = false;                                       // pass p + 1 already in the stream
         bool certified = false;                                   // the sweep's last decision: stopped AND below the tolerance
         for (int p = 0; p < npass; p++) {

@@ -121,6 +121,8 @@ class ResidentReceiver:
         E = np.ascontiguousarray(np.asarray(E), dtype=self.ct)
         assert E.shape == (self.nmodes, self.L)
         self.E.set(E)
+        if getattr(self, "_prep", None) is not None:
+            self.invalidate()
         self._acq_asked = [False] * self.nstage
         if self.tier == "b":
             npow = min(self.L, 4096)
@@ -167,13 +169,39 @@ class ResidentReceiver:
             for o in self.pit:
                 o["basis"] = self._basis.ptr
 
-    def train(self, stage):
+    def train(self, stage, hook=None):
+        """``hook`` (tier b): a callable the library invokes once, right after it has enqueued the sweep's first relaxation pass
+        (``qh_pit_opts.on_pass0``) - work for the other library streams is enqueued there, while the device is busy, instead of in front of
+        this sweep's launches; called after the sweep if the library never got to a first pass (exact form)."""
         tb = self.tier == "b"
         self._bound()
+        opts = {k: v for k, v in self.pit[stage].items() if not k.startswith("_")} if tb else None
+        if tb and stage == 0 and getattr(self, "_use_prep", None) is not None:
+            opts["prepared"] = self._use_prep.ptr
+            self._use_prep = None
+        fired, failed = [False], []
+        if hook is not None and tb:
+            import ctypes as _C
+
+            def _cb(_user):
+                if not fired[0]:
+                    fired[0] = True
+                    try:
+                        hook()
+                    except BaseException as e:        # (never through the C frames: re-raised below)
+                        failed.append(e)
+                    finally:
+                        _lib.call("qh_use_stream", 0)
+            self._hook_keepalive = _lib.PIT_HOOK(_cb)
+            opts["on_pass0"] = _C.cast(self._hook_keepalive, _C.c_void_p).value
         _k.train_equaliser_dev(self.E, self.TrSyms[stage], self.Niter[stage], self.os, self.mu[stage], self.wxy, self.modes,
                                self.adaptive[stage], self.symbols[stage], self.methods[stage], self.err[stage],
-                               gram=getattr(self, "_gram", None), pit={k: v for k, v in self.pit[stage].items() if not k.startswith("_")} if tb else None,
-                               report=self.pit_report[stage] if tb else None)
+                               gram=getattr(self, "_gram", None), pit=opts, report=self.pit_report[stage] if tb else None)
+        if hook is not None and not fired[0]:
+            fired[0] = True
+            hook()
+        if failed:
+            raise failed[0]
         if tb:
             self.pit_timing[stage] = _k.pit_last_timing()      # host-side copy of the HIP-event times: no synchronisation
             o = self.pit[stage]
@@ -212,7 +240,76 @@ class ResidentReceiver:
         self._bound()
         _dsp.bps_recover_dev(self.eq, self.Mtestangles, self.alphabet, self.Nbps, self.idx, self.ph, self.out, angles=self.angles)
 
-    def run(self, overlap=False, mark=None):
+    # ------------------------------------------------------------------------------------------ the next capture's sequential prologue, ahead of time
+    def load_next(self, E):
+        """Host -> HBM copy of the capture that follows the one in ``self.E`` (second input buffer): ``run(prefetch=True)`` processes ``E``, prepares
+        this one beside it and swaps the two buffers when it is done with ``E`` - so the call sequence of a streaming receiver is ``load(c0)``,
+        ``load_next(c1)``, ``run()``, ``load_next(c2)``, ``run()``, ..."""
+        E = np.ascontiguousarray(np.asarray(E), dtype=self.ct)
+        assert E.shape == (self.nmodes, self.L)
+        if getattr(self, "E_next", None) is None:
+            self.E_next = DeviceArray((self.nmodes, self.L), self.ct)
+        self.E_next.set(E)
+        self._next_loaded = True
+
+    def invalidate(self):
+        """Forget what was prepared ahead (after the capture in ``self.E`` / ``self.E_next`` was changed by hand)."""
+        self._prep_ready = [False, False]
+
+    def _prepare_next(self):
+        """Tier b, cold first stage: the acquisition and the eigenbasis of the NEXT capture - both depend on the capture only, not on anything this
+        capture's training produces - are enqueued on library stream 1 now, so that they run beside this capture's cold stage (whose passes leave
+        32 compute units free for exactly that, csrc/train_pit.h) instead of in front of the next capture's passes (qh_pit_prepare_*_dev).  The next
+        capture is ``E_next`` (``load_next``), or - a receiver fed the same resident capture again and again, as bench.py does - ``E`` itself."""
+        o = self.pit[0]
+        if self.tier != "b" or not o.get("acquire") or self.adaptive[0] or self.ct != np.complex64 or not getattr(self, "_basis", None):
+            return
+        if not (o.get("acq_chunk") and o.get("mu_hint") and o.get("segments", 0) > 1):
+            return
+        self._prep_init()
+        slot = 1 - self._prep_cur
+        amax = 2 * ((int(o["acq_chunk"]) + 63) // 64 * 64) if not o.get("acq_max") else int(o["acq_max"])
+        need = _k.pit_prepare_bytes(self.nmodes, self.Ntaps, amax, self.ct)
+        if self._prep[slot] is None or self._prep[slot].nbytes < need:
+            self._prep[slot] = DeviceArray((need,), np.uint8)
+        nxt = self.E_next if getattr(self, "_next_loaded", False) else self.E
+        _lib.call("qh_use_stream", 1)             # (_ev_main: recorded by run() on stream 0 when the next capture was in place)
+        try:
+            _lib.call("qh_stream_wait_event", self._ev_main.ptr)
+            if getattr(self, "_post_running", False):
+                _lib.call("qh_stream_wait_event", self._ev_post.ptr)        # (the previous capture's phase search: see run)
+            ok = _k.pit_prepare_dev(nxt, self.TrSyms[0], self.os, self.mu_init[0], self.wxy0, self.modes, self.symbols[0], self.methods[0],
+                                    {k: v for k, v in o.items() if not k.startswith("_") and k not in ("basis", "prepared")}, self._prep[slot])
+            if ok:
+                self._basis_alt = _k.pit_basis_dev(nxt, self.os, self.Ntaps, self.TrSyms[0], self._basis_alt, overlap=False)
+                self._ev_prep[slot].record()
+        finally:
+            _lib.call("qh_use_stream", 0)
+        self._prep_ready[slot] = bool(ok)
+
+    def _prep_init(self):
+        if getattr(self, "_prep", None) is None:
+            self._prep, self._prep_ready, self._prep_cur = [None, None], [False, False], 0
+            self._basis_alt, self._ev_main, self._ev_prep = None, _lib.Event(), [_lib.Event(), _lib.Event()]
+
+    def _adopt_prepared(self):
+        """Start of a run: if the previous run prepared this capture, its eigenbasis and its acquisition are there already."""
+        self._use_prep = None
+        if getattr(self, "_prep", None) is None:
+            return False
+        slot = 1 - self._prep_cur
+        if not self._prep_ready[slot]:
+            return False
+        self._prep_ready[slot] = False
+        self._prep_cur = slot
+        self._basis, self._basis_alt = self._basis_alt, self._basis
+        _lib.call("qh_stream_wait_event", self._ev_prep[slot].ptr)
+        for o in self.pit:
+            o["basis"] = self._basis.ptr
+        self._use_prep = self._prep[slot]
+        return True
+
+    def run(self, overlap=False, mark=None, prefetch=False):
         """One pass of the hot path over the resident capture; returns without synchronising.
 
         ``overlap=True`` (a receiver that is handed capture after capture): the phase search of this pass is left PENDING and goes
@@ -224,22 +321,49 @@ class ResidentReceiver:
         a pass are complete after ``wait_post()`` (enqueues what is pending; stream 0 waits for it) or ``fetch()`` (the host waits
         too).  Bit-identical to ``overlap=False``: the same kernels on the same data, in another order.
 
+        ``prefetch=True`` (tier b, consecutive captures): the acquisition and the eigenbasis of the NEXT capture are enqueued on stream 1 at the
+        start of this run and adopted by the next one (``_prepare_next``); results bit-identical to ``prefetch=False``.
+
         ``mark(name)`` (bench.py): called on the stream the stage was enqueued on after "start", "gram", "train<s>", "apply", "bps",
         and around the overlapped phase search ("post_begin", "post_end")."""
         m = mark or (lambda name: None)
         self.reset()
         m("start")
-        self.build_gram()
+        adopted = self._adopt_prepared() if prefetch else False
+        if not adopted:
+            self._use_prep = None
+            self.build_gram()
         m("gram")
-        self._enqueue_post(m)                     # phase search of the previous overlapped pass, beside the stages below
+
+        def side_work():
+            self._enqueue_post(m)                 # phase search of the previous overlapped pass, beside the stages below
+            if prefetch:
+                # ... and BEHIND that phase search: started together with it, the next capture's covariance kernel (chip-wide, streaming), eigen-solver
+                # and acquisition crowd the first pass of this capture - 454 instead of 290 us, the model kernels 319 instead of 47
+                # (profiles/r05_timeline_prefetch_v1.txt); the phase search is through ~1 ms into the capture, the preparation then has the rest of
+                # the cold stage (whose passes leave 32 CUs free)
+                self._prepare_next()
+        # With prefetch the ~25 launches of that side work are made from INSIDE the first stage's call, right after its first pass is enqueued
+        # (qh_pit_opts.on_pass0): in front of it they cost ~0.2 ms of host time during which stream 0 had nothing to run.
+        defer = bool(prefetch and self.tier == "b" and adopted)
+        if prefetch and self.tier == "b":
+            self._prep_init()
+            self._ev_main.record()                # stream 0 up to here: the capture the preparation reads is in place
+        if not defer:
+            side_work()
         for s in range(self.nstage):
-            self.train(s)
+            self.train(s, hook=side_work if (defer and s == 0) else None)
             m("train%d" % s)
         if getattr(self, "_post_running", False):
             _lib.call("qh_stream_wait_event", self._ev_post.ptr)        # the filter output of the previous pass has been consumed
             self._post_running = False
         self._apply()
         m("apply")
+        if prefetch and getattr(self, "_next_loaded", False):
+            # the capture load_next() brought - prepared above, where that was possible - is the next one to be processed; the old one's buffer takes
+            # the next load_next()
+            self.E, self.E_next = self.E_next, self.E
+            self._next_loaded = False
         if not self.Mtestangles:
             return
         if not overlap:
@@ -248,13 +372,13 @@ class ResidentReceiver:
             return
         if getattr(self, "_ev_post", None) is None:
             self._ev_ready, self._ev_post = _lib.Event(), _lib.Event()
+        self._ev_ready.record()                   # stream 0 up to here: the filter output the pending phase search reads
         self._post_pending = True
 
     def _enqueue_post(self, mark=None):
         if not getattr(self, "_post_pending", False):
             return
-        self._ev_ready.record()                   # stream 0 up to here: filter of the pending pass, covariance kernel of the next one
-        _lib.call("qh_use_stream", 2)
+        _lib.call("qh_use_stream", 2)             # (_ev_ready: recorded behind the filter of the pass whose phase search is pending)
         try:
             _lib.call("qh_stream_wait_event", self._ev_ready.ptr)
             if mark:
@@ -373,7 +497,7 @@ class ReceiverGroup:
             r.load(E)
         self._sync()
 
-    def run(self, steps, overlap=True, mark=None):
+    def run(self, steps, overlap=True, mark=None, prefetch=False):
         """``steps`` passes of the hot path in total, receiver ``i`` taking passes i, i + n, ...; returns when all are complete on the
         device.  ``overlap``: as ResidentReceiver.run.  ``mark(i, k)``: a mark callback for pass k of receiver i (bench.py)."""
         n = len(self.rx)
@@ -382,7 +506,7 @@ class ReceiverGroup:
         def job(i):
             def go(rx):
                 for k in range(share[i]):
-                    rx.run(overlap=overlap, mark=mark(i, k) if mark else None)
+                    rx.run(overlap=overlap, mark=mark(i, k) if mark else None, **({"prefetch": True} if prefetch else {}))
                 rx.wait_post(mark(i, share[i]) if mark else None)
                 self._sync()                   # this thread's streams
             return go
