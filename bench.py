@@ -674,10 +674,26 @@ def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_
         names, _ = stage_list(rx)
         elapsed, stage_ms, pass_ms, acq_ms = timed_steps(rx, steps, warmup, barrier_sync, overlap=overlap)
     reports = rx.pit_reports()
+    pass_all = None
+    if group is None and not getattr(rx, "exchanges", None):
+        # every relaxation pass timed (an event pair per pass: ~11 us of idle stream per pass - a run of its own, after the timed region, in the same
+        # mode): the dominant kernel's AVERAGE launch duration for the roofline (the timed region itself times one pass per sweep, pass 1)
+        from qampy_amd import _lib as _l
+        _l.call("qh_set_pit_timing", 2)
+        try:
+            _, _, pass_all, _ = timed_steps(rx, max(2, min(steps, 5)), 1, barrier_sync, overlap=overlap)
+        finally:
+            _l.call("qh_set_pit_timing", 1)
     ser_rows = rx.ser(sig.symbols, maxlag=256, window=8192, trim=2000) if cfg["A"] else []
     errs = [(d["errors"], d["compared"]) for d in ser_rows]
     tb = tier_b_block(cfg, rx, names, pass_ms, acq_ms, reports, nsym * steps / elapsed / 1e6, elapsed / steps * 1e3, errs, nsym)
     tb["stages_ms"] = {n: round(t, 3) for n, t in zip(names, stage_ms)}
+    if pass_all is not None:
+        for s_, st in enumerate(tb["stages"]):
+            flat = [p for step in pass_all[s_] for p in step]
+            per_pass = [float(np.mean([step[q] for step in pass_all[s_] if len(step) > q])) for q in range(max((len(step) for step in pass_all[s_]), default=0))]
+            st["pass_ms_all_launches"] = round(float(np.mean(flat)), 4) if flat else None
+            st["pass_ms_by_pass"] = [round(x, 4) for x in per_pass]
     if group is not None:
         # every receiver of the group: certified by the device, and bit for bit the result of receiver 0
         others = [g.fetch() for g in group.rx[1:]]
@@ -792,6 +808,105 @@ def api_end_to_end_block(cfg, sig, nsym, tol, rx_ref, reps=3):
                          "the phase search pipelined over both PCIe directions; pcie_floor_ms = the bytes that cross at ~55 GB/s one after the other")
     finally:
         qampy_amd.set_default_tier(*was)
+
+
+def ref_benchmarks_block(tol, cpu=True):
+    """The reference's OWN benchmark definitions (/root/reference/test/test_benchmarks.py: test_equalisation_prec :57-80, test_bps :38-47,
+    test_apply_filter_benchmark :128-150, test_quantize_precision :22-30, test_select_angles_benchmark :152-176) through the same call
+    surface - host arrays in and out, PCIe included - on captures of the same shape from this repository's generator: best of 3 wall times of
+    the call the reference hands to pytest-benchmark; beside each, the oracle's reference-flag build on the same arrays (all host threads)."""
+    from qampy_amd import synth, equalisation as api_eq, phaserec as api_ph, theory
+    from qampy_amd.core import hip_dsp
+    from qampy_amd.core.equalisation import equalisation as host, hip_equalisation as hk
+    from oracle import oracle
+
+    def best(fn, n=3):
+        fn()
+        t = []
+        for _ in range(n):
+            t0 = time.perf_counter(); r = fn(); t.append(time.perf_counter() - t0)
+        return round(min(t) * 1e3, 3), r
+    rows = []
+    # ---- test_equalisation_prec: QPSK, 10^5 symbols, 2 modes, 2 samples / symbol, 40 taps, mu = 4e-4, adaptive step, 14 dB, PMD
+    for dt in (np.complex64, np.complex128):
+        sig = synth.make_capture(4, 10 ** 5, nmodes=2, os=2, snr_db=14, theta=np.pi / 5.45, dgd=75e-12, linewidth=0., fb=40e9, beta=0.1, seed=7, dtype=dt)
+        E = np.ascontiguousarray(np.asarray(sig))
+        for method in ("cma", "mcma", "sbd", "mddma", "dd"):
+            row = dict(bench="equalise_signal", method=method, dtype=np.dtype(dt).name, nsym=10 ** 5, ntaps=40, adaptive_stepsize=True)
+            row["tier_a_ms"], (w_a, e_a) = best(lambda: api_eq.equalise_signal(sig, 4e-4, Ntaps=40, method=method, adaptive_stepsize=True, tier="a"))
+            row["tier_b_ms"], (w_b, e_b) = best(lambda: api_eq.equalise_signal(sig, 4e-4, Ntaps=40, method=method, adaptive_stepsize=True, tier="b", pit=dict(tol=tol)))
+            rep = host.last_pit_reports()
+            row["tier_b_exact_form"] = bool(rep and rep[0].get("exact_form"))
+            row["tier_b_tap_rel_dev"] = float(np.linalg.norm(w_a - w_b) / np.linalg.norm(w_a))
+            if cpu:
+                tr = host._cal_training_symbol_len(2, 40, E.shape[1])
+                sy = host._reshape_symbols(sig.coded_symbols if method in host.DECISION_BASED else None, method, 4, dt, 2)
+                rt = np.float32 if dt is np.complex64 else np.float64
+                row["cpu_port_ms"], _ = best(lambda: oracle.train_equaliser(E, tr, 1, 2, rt(4e-4), host._init_taps(40, 2, 2, dt), None, True, sy, method, fast=True))
+            rows.append(row)
+    # ---- test_bps: 64-QAM, 2^12 symbols (x 2 modes here), 64 test angles, N = 11
+    for dt in (np.complex64, np.complex128):
+        s1 = synth.make_capture(64, 2 ** 12, nmodes=2, os=1, snr_db=35, linewidth=0., seed=8, dtype=dt) * np.exp(1j * np.pi / 5.1)
+        row = dict(bench="bps", dtype=np.dtype(dt).name, nsym=2 ** 12, test_angles=64, N=11)
+        row["hip_ms"], _ = best(lambda: api_ph.bps(s1, 64, 11))
+        if cpu:
+            rt = np.float32 if dt is np.complex64 else np.float64
+            ang = np.linspace(-np.pi / 4, np.pi / 4, 64, endpoint=False, dtype=rt).reshape(1, -1)
+            a1 = np.ascontiguousarray(np.asarray(s1))
+            row["cpu_port_ms"], _ = best(lambda: [oracle.bps(a1[m], ang, s1.coded_symbols.astype(dt), 11, fast=True) for m in range(2)])
+        rows.append(row)
+    # ---- test_apply_filter_benchmark: 2^17 symbols, 2 modes, 40 taps
+    for dt in (np.complex64, np.complex128):
+        sig = synth.make_capture(4, 2 ** 17, nmodes=2, os=2, snr_db=14, linewidth=0., fb=40e9, seed=9, dtype=dt)
+        wxy, _ = api_eq.equalise_signal(sig, 4e-4, Ntaps=40, method="mcma")
+        row = dict(bench="apply_filter", dtype=np.dtype(dt).name, nsym=2 ** 17, ntaps=40)
+        row["hip_ms"], _ = best(lambda: api_eq.apply_filter(sig, wxy))
+        if cpu:
+            E = np.ascontiguousarray(np.asarray(sig))
+            row["cpu_port_ms"], _ = best(lambda: oracle.apply_filter_to_signal(E, 2, wxy, fast=True))
+        rows.append(row)
+    # ---- test_quantize_precision: make_decision on 2^20 symbols of 128-QAM; test_select_angles_benchmark: 2^17 indices into a 64-angle grid
+    for dt in (np.complex64, np.complex128):
+        al = np.ascontiguousarray(theory.coded_symbols_qam(128, dtype=dt))
+        x = np.ascontiguousarray(al[np.random.default_rng(3).integers(0, 128, 2 ** 20)])
+        row = dict(bench="make_decision", dtype=np.dtype(dt).name, nsym=2 ** 20, M=128)
+        row["hip_ms"], _ = best(lambda: hk.make_decision(x, al))
+        if cpu:
+            row["cpu_port_ms"], _ = best(lambda: oracle.make_decision(x, al, fast=True))
+        rows.append(row)
+        rt = np.float32 if dt is np.complex64 else np.float64
+        ang = np.linspace(-np.pi / 4, np.pi / 4, 64, endpoint=False, dtype=rt).reshape(1, -1)
+        idx = np.random.default_rng(4).integers(0, 64, 2 ** 17).astype(np.int32)
+        row = dict(bench="select_angles", dtype=np.dtype(rt).name, n=2 ** 17, test_angles=64)
+        row["hip_ms"], _ = best(lambda: hip_dsp.select_angles(ang, idx))
+        if cpu:
+            row["cpu_port_ms"], _ = best(lambda: oracle.select_angles(ang, idx))
+        rows.append(row)
+    return dict(rows=rows, note="the reference's pytest-benchmark shapes (test/test_benchmarks.py) through the mirrored call surface, host arrays in and out (PCIe, allocation "
+                                "and launch latency included: at 10^5 symbols the exact recurrence IS the call - 2 chains of 10^5 dependent steps - and tier b has too few "
+                                "segments to fill the chip); cpu_port_ms = the oracle's reference-flag build on the same arrays, all host threads")
+
+
+def survey_recipe_block(barrier_sync, tol):
+    """SURVEY.md 8d's LITERAL C3 recipe - mu = (1e-3, 5e-4), linewidth 5 kHz - and what is closest to it that the reference's own recurrence converges on
+    at 2^22 symbols.  Measured with the exact path (profiles/r05_survey_recipe_exact_path.txt: three seeds x linewidths 0 / 1 / 5 kHz x 2^16 .. 2^22): at
+    these step sizes the cma -> mrde chain converges on every capture of <= 2^18 symbols and FAILS on at least one mode of every 2^22-symbol capture, at
+    every linewidth including 0 (the constant-modulus stage's misadjustment at mu = 1e-3 lets a mode slip within 4 million steps); at half the step sizes
+    it converges at 0 and 1 kHz.  Rows: the literal recipe at 2^18 (converges) and at 2^22 (the exact path's symbol errors; tier b then returns the exact
+    form for the stage whose trajectory is not a contraction), and (5e-4, 2.5e-4) at 1 kHz and 2^22."""
+    rows = []
+    for name, mu, lw, lg in (("literal, 2^18", (1e-3, 5e-4), 5e3, 18), ("literal, 2^22", (1e-3, 5e-4), 5e3, 22), ("half steps, 1 kHz, 2^22", (5e-4, 2.5e-4), 1e3, 22)):
+        cfg = dict(WORKLOADS["c3"], mu=mu, linewidth=lw, nsym=2 ** lg, label="64-QAM 2-pol 2 SPS 2^%d sym, 41-tap CMA->MRDE mu %s, %g Hz" % (lg, mu, lw))
+        sig = make_input(cfg, cfg["nsym"], 1000)
+        tb, ta, ex = run_pair(cfg, sig, cfg["nsym"], 3, 1, barrier_sync, dict(tol=tol), 1, tol, overlap=False)
+        rows.append(dict(recipe=name, mu=list(mu), linewidth_hz=lw, nsym=cfg["nsym"], errors_exact=ta["errors"], errors_tier_b=tb["errors"],
+                         exact_path_converges=bool(max(ta["errors"]) < 0.01 * cfg["nsym"]), tier_b_ms=tb["ms_per_step"], tier_b_MSym_s=tb["value"],
+                         exact_ms=ta["ms_per_step"], certified=tb["certified"], checks=tb.get("checks"),
+                         stages=[dict(stage=st["stage"], S=st["S"], seg_len=st["seg_len"], P=st["P"], exact_form=st.get("exact_form", False),
+                                      est_deviation_rms=st["est_deviation_rms"][-1:]) for st in tb["stages"]],
+                         eq_rms_dev_vs_exact=tb.get("eq_rms_dev_vs_exact"), tap_rel_dev_vs_exact=tb.get("tap_rel_dev_vs_exact")))
+        del ex, sig
+    return dict(tol=tol, rows=rows, note="one capture at a time (no overlap), 3 timed passes each; see the docstring of bench.survey_recipe_block and DESIGN.md 6")
 
 
 def in_flight_block(cfg, sig, nsym, n, steps, barrier_sync, pit):
@@ -1137,8 +1252,11 @@ def main():
 
     # ---- roofline of the dominant kernel (largest total kernel time per step)
     if use_b or uncertified_b:
-        cands = [(tier_b["stages"][s]["pass_ms"] * tier_b["stages"][s]["P"], "train%d:%s relaxation pass" % (s + 1, cfg["methods"][s]),
-                  train_bytes[s], tier_b["stages"][s]["pass_ms"]) for s in range(rx.nstage)]
+        # launch duration of a pass kernel: the average over ALL its launches (every pass event-timed in a run of its own, run_pair), else pass 1's
+        def _pms(st_):
+            return st_.get("pass_ms_all_launches") or st_["pass_ms"]
+        cands = [(_pms(tier_b["stages"][s]) * tier_b["stages"][s]["P"], "train%d:%s relaxation pass" % (s + 1, cfg["methods"][s]),
+                  train_bytes[s], _pms(tier_b["stages"][s])) for s in range(rx.nstage)]
         cands.append((stage_ms[0], "gram", stage_bytes[0], stage_ms[0]))
         if cfg["A"]:
             cands.append((stage_ms[-1], "bps_recover", stage_bytes[-1], stage_ms[-1]))
@@ -1192,6 +1310,10 @@ def main():
                             issue=dict(achieved=round(winstr / (kms * 1e-3) / 1e9, 1), peak=VALU_PEAK_GINSTR, unit="G wave-instr/s", valu_instr_per_wave_step=round(ipw, 1),
                                        irreducible_pk_fma_per_wave_step=round((64 // lpc) * 2 * ntot * 4 / 2 / 64.0, 1), valu_instr_source=src),
                             chains=int(chains), lanes_per_chain=lpc, waves=int(waves), waves_per_simd=round(waves / 1024.0, 2), steps_per_chain=int(st["seg_len"]),
+                            launch_ms_by_pass=st.get("pass_ms_by_pass"), launch_ms_pass1_in_timed_region=st["pass_ms"],
+                            launch_ms_source="average over ALL launches of the kernel, every pass event-timed on the library stream in a run of its own right after the timed region "
+                                             "(same receiver, same mode: consecutive captures, phase search and next capture's preparation beside the passes); "
+                                             "the first pass of a sweep shares the chip with them (launch_ms_by_pass)" if st.get("pass_ms_all_launches") else "pass 1 of every sweep, event-timed inside the timed region",
                             note="one launch trains all segments of the sweep (%d lanes per chain, %d chains per wave64, one wave per SIMD); frac = algorithmic flops of the "
                                  "recurrence / packed-fp32 vector peak; issue_frac = vector instructions issued / nominal issue rate; `hbm`: algorithmic bytes of one sweep "
                                  "(read E, write err) against 8 TB/s" % (lpc, 64 // lpc))
@@ -1272,6 +1394,8 @@ def main():
                 for key in ("ns", "c2"):
                     out[key] = shape_block(key, barrier_sync, pit, 10, overlap=overlap)
                 out["adaptive_step"] = adaptive_block()
+                out["survey_recipe"] = survey_recipe_block(barrier_sync, tol_check)
+                out["ref_benchmarks"] = ref_benchmarks_block(tol_check, cpu=not args.no_cpu_baseline)
                 # SURVEY.md 8c's tolerance on the three BASELINE shapes, each with the in-run certificate against the exact path
                 rows = dict(c3=dict(value=tier_b["value"], certified=tier_b["certified"], checks=tier_b.get("checks"), passes=[st["P"] for st in tier_b["stages"]],
                                     eq_rms_dev_vs_exact=tier_b.get("eq_rms_dev_vs_exact"), tap_rel_dev_vs_exact=tier_b.get("tap_rel_dev_vs_exact"),

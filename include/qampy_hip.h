@@ -250,6 +250,8 @@ int qh_set_trainer(int form);
  *                              same recurrence solved in parallel in time to `tol` (0 = 1e-3; SURVEY.md 8c's complex64 bar is 1e-4), total: a call no
  *                              parallel-in-time solver exists for, or one the passes do not certify, runs in the exact form inside the call.
  *                              qh_last_pit_report: the device's report of the calling thread's most recent such solve. */
+int qh_set_pit_timing(int mode);      /* which relaxation passes of a tier-b sweep get HIP events (qh_pit_last_timing): 0 none, 1 pass 1 of every sweep (default: an event
+                                        * idles the stream for ~5.6 us), 2 every pass (bench.py's roofline run) */
 int qh_set_reserved_cus(int n);
 int qh_set_gram_budget_gb(double gb);
 int qh_get_gram_budget_gb(double *gb);
@@ -261,7 +263,7 @@ int qh_get_default_tier(int *tier, double *tol);
  *   QAMPY_HIP_PIT_FORM = segment | block                  parallel in time: throughput / latency form of the passes (tests/test_gpu_pit.py)
  *   QAMPY_HIP_SEG_LANES = 8 | 16                          throughput form: lanes per chain (tests/test_gpu_pit.py)
  *   QAMPY_HIP_PIT_PROBE = 1                               complex64: the complex128 analysis of a pass (probe of the capture) (tests/test_gpu_pit.py)
- *   QAMPY_HIP_PIT_TIMING = all | none                     which relaxation passes get HIP events (qh_pit_last_timing; scripts/pit_exp.py)
+ *   QAMPY_HIP_PIT_TIMING = all | none                     initial value of qh_set_pit_timing (scripts/pit_exp.py)
  *   QAMPY_HIP_BPS = tile, QAMPY_HIP_BPS_FUSED = 1         phase search: tile kernel for complex64 / search + unwrap + de-rotation in one kernel (test_gpu_parity.py)
  *   QAMPY_HIP_LA_PROFILE = 1                              developer aid: cycle split of workgroup 0 of the block trainers on stderr */
 
@@ -392,7 +394,7 @@ int qh_pit_basis_c64_dev(const void *E, int nmodes, int64_t L, int os, int ntaps
 int qh_pit_basis_c128_dev(const void *E, int nmodes, int64_t L, int os, int ntaps, int64_t TrSyms, void *basis, int overlap);
 /* kernel time (HIP events on the library stream) of the trainer launches of the most recent qh_train_equaliser_*_pit_dev call:
  * the timed relaxation passes in order (all sweeps) and the sum of the acquisition chunks.  An event idles the stream for ~5.6 us,
- * so by default ONE pass per sweep is timed (pass 1); environment QAMPY_HIP_PIT_TIMING = all (every pass) | none. */
+ * so by default ONE pass per sweep is timed (pass 1); qh_set_pit_timing(2) times every pass. */
 int qh_pit_last_timing(float *pass_ms, int max_passes, int *npass, float *acq_ms);
 /* The sequential part of a COLD sweep ahead of time (ABI 8): the gear-shifted acquisition of a capture depends on the capture, the start taps, the step
  * size and the error function only - not on anything the previous capture's training produces - so a receiver that is handed capture after capture runs

@@ -96,6 +96,7 @@ SIGNATURES = {
     "qh_memcpy_d2h_async": [_vp, _vp, _sz],
     "qh_stream_sync": [],
     "qh_set_trainer": [_i],
+    "qh_set_pit_timing": [_i],
     "qh_set_reserved_cus": [_i],
     "qh_set_gram_budget_gb": [C.c_double],
     "qh_get_gram_budget_gb": [C.POINTER(C.c_double)],

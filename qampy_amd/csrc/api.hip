@@ -44,6 +44,13 @@ double gram_budget_gb()
     if (v < 0) { const char *e = getenv("QAMPY_HIP_GRAM_BUDGET_GB"); v = e ? atof(e) : 160.0; if (!(v > 0)) v = 160.0; g_gram_budget_gb.store(v); }
     return v;
 }
+static std::atomic<int> g_pit_timing{-1};
+int pit_timing_mode()
+{
+    int v = g_pit_timing.load();
+    if (v < 0) { const char *e = getenv("QAMPY_HIP_PIT_TIMING"); v = !e ? 1 : (e[0] == 'a' ? 2 : (e[0] == 'n' ? 0 : 1)); g_pit_timing.store(v); }
+    return v;
+}
 int default_tier() { return g_default_tier.load(); }
 double default_tier_tol() { return g_default_tol.load(); }
 
@@ -231,6 +238,12 @@ int qh_set_gram_budget_gb(double gb)
 {
     if (!(gb > 0)) { qh::set_error("qh_set_gram_budget_gb: gb > 0"); return QH_ERR_ARG; }
     qh::g_gram_budget_gb.store(gb);
+    return QH_OK;
+}
+int qh_set_pit_timing(int mode)
+{
+    if (mode < 0 || mode > 2) { qh::set_error("qh_set_pit_timing: 0 none, 1 the second pass of every sweep (default), 2 every pass"); return QH_ERR_ARG; }
+    qh::g_pit_timing.store(mode);
     return QH_OK;
 }
 int qh_get_gram_budget_gb(double *gb) { *gb = qh::gram_budget_gb(); return QH_OK; }

@@ -34,6 +34,7 @@ hipStream_t side_stream();       // the library stream that is NOT the current o
 hipStream_t helper_stream();     // a third stream for small launches beside both (the coarse model of a tier-b sweep)
 const char *trainer_force();   // "" (automatic) or "direct" / "lookahead" / "iterative": qh_set_trainer(), else QAMPY_HIP_TRAINER
 double gram_budget_gb();         // scratch the Gram tables of one call may take (qh_set_gram_budget_gb; default: QAMPY_HIP_GRAM_BUDGET_GB read once, else 160)
+int pit_timing_mode();            // which relaxation passes of a tier-b sweep get HIP events: 0 none, 1 pass 1 (default), 2 all (qh_set_pit_timing)
 int default_tier();               // 0: tier a (exact), 1: tier b - what the drop-in host-array trainers run (qh_set_default_tier)
 double default_tier_tol();        // tolerance of the default tier b (qh_set_default_tier)
 int scratch(int slot, size_t bytes, void **p);   // grow-only device scratch, slots 0..11

@@ -2546,6 +2546,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     // keeps the probe-based analysis, whose defect vectors are formed in double precision before they are projected
     // (QAMPY_HIP_PIT_PROBE=1 forces it for complex64 too: tests compare the two)
     const bool eig = want_corr && sizeof(R) == 4 && !(getenv("QAMPY_HIP_PIT_PROBE") && atoi(getenv("QAMPY_HIP_PIT_PROBE")) != 0);
+    const bool eig_path = eig && !(o.exchange != nullptr);        // (a capture split over processes keeps everything on one stream)
     // Measured coarse model (pit_model_kernel): gain and the 2 x 2 block of the signal direction from the capture itself.  opts.correction = 2
     // keeps round 3's model (one formula gain per error function, diagonal in the eigenbasis, extra damping beta) for comparisons.
     const bool tables_ok = method == QH_M_CMA || method == QH_M_SGNCMA || method == QH_M_MCMA || method == QH_M_RDE || method == QH_M_MRDE ||
@@ -2709,7 +2710,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         // ================================================================ relaxation passes
         // HIP events around the trainer launch of a pass (qh_pit_last_timing): an event is ~5.6 us of idle stream, so by default only
         // pass 1 of a sweep is timed (pass 0 of a cold sweep shares the chip with the basis build); QAMPY_HIP_PIT_TIMING = all | none
-        static const int timing_mode = [] { const char *e = getenv("QAMPY_HIP_PIT_TIMING"); return !e ? 1 : (e[0] == 'a' ? 2 : (e[0] == 'n' ? 0 : 1)); }();
+        const int timing_mode = pit_timing_mode();                // (qh_set_pit_timing; the environment variable QAMPY_HIP_PIT_TIMING = all | none is its initial value)
         auto decide_args = [&](int p, const float *dm, const float2 *ye, float2 *yprev, int ne, int ncol_e, int corr_wanted) {
             PitDecideArgs<R> d;
             d.dfc = dfc; d.pw = pw; d.nb = (int)((sg.S - 1) * nsel); d.Ylast = (const Cx<R> *)(Y + (size_t)(sg.S - 1) * wset); d.n = (int)wset; d.wx = (Cx<R> *)wx; d.c = ctrl;
@@ -2739,6 +2740,23 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 QH_HIP(hipMemcpyAsync(X + wset, Y, (size_t)(sg.S - 1) * wbytes, hipMemcpyDeviceToDevice, g_stream));   // X[s] = end taps of s-1
                 QH_HIP(hipMemcpyAsync(Y, X, (size_t)sg.S * wbytes, hipMemcpyDeviceToDevice, g_stream));
             }                                                       // (pass 0: pit_seed_kernel wrote the start taps into X and Y)
+            // The start taps of this pass go into the eigenbasis BESIDE the pass (helper stream): they are final once the back product (or the seed
+            // kernel) has run, the product is 8-10 us on a chip the pass leaves half empty, and the analysis only needs it after the pass.
+            static thread_local hipEvent_t ev_x = nullptr, ev_xe = nullptr;
+            // (measured, C3 tol 1e-4, same box, alternating: 1021-1023 MSym/s with the product aside, 1029-1031 with it in line - the two cross-stream
+            // event waits per pass cost what the 8 us product costs.  Off; QAMPY_HIP_PIT_XASIDE=1 switches it on for measurements.)
+            static const bool x_aside_on = [] { const char *e = getenv("QAMPY_HIP_PIT_XASIDE"); return e && atoi(e) != 0; }();
+            const bool x_aside = eig_path && x_aside_on;
+            if (x_aside) {
+                if (!ev_x) { QH_HIP(hipEventCreateWithFlags(&ev_x, hipEventDisableTiming)); QH_HIP(hipEventCreateWithFlags(&ev_xe, hipEventDisableTiming)); }
+                hipStream_t hs = helper_stream();
+                QH_HIP(hipEventRecord(ev_x, g_stream));
+                QH_HIP(hipStreamWaitEvent(hs, ev_x, 0));
+                if (o.basis && pit_basis_sync().pending) QH_HIP(hipStreamWaitEvent(hs, pit_basis_sync().out, 0));      // (a basis still being built on the other stream)
+                hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 0>), dim3((ncol + PIT_MC - 1) / PIT_MC), dim3(pit_mfma_threads(ntot)), pit_mfma_lds(ntot), hs, Vb, (const Cx<R> *)X, (const Zf *)nullptr, Xe,
+                                   ntot, ncol, (const PitCtrl *)ctrl, fz);
+                QH_HIP(hipEventRecord(ev_xe, hs));
+            }
             if (timed(p)) QH_HIP(hipEventRecord(ev.t0[p], g_stream));
             if (seg_form) {
                 SegArgs<R> sa;
@@ -2794,7 +2812,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 // times the correction - ~1e-6 per boundary, the same sign from boundary to boundary - and a fixed point of the TRACKED copy
                 // leaves exactly that as a true defect at every boundary; the weakly excited directions (coefficient ~1) add them up over the
                 // whole sweep: 1.0-1.7e-3 of tap deviation at C3 whatever the tolerance, invisible to the estimate (profiles/r05_tap_floor.txt).
-                forward((const Cx<R> *)X, Xe);
+                if (x_aside) QH_HIP(hipStreamWaitEvent(g_stream, ev_xe, 0));        // (the product itself ran beside the pass: see above)
+                else forward((const Cx<R> *)X, Xe);
                 forward((const Cx<R> *)Y, Ye);
                 hipLaunchKernelGGL(pit_bound_kernel, dim3((nbnd + nsel + 3) / 4), dim3(256), 0, g_stream, (const Zf *)Xe, (const Zf *)Ye, (const Zf *)Yprev, lam, ntot, sg.S, nsel, sym,
                                    (const PitCtrl *)ctrl, dfc, pw, gph, ualpha);

