@@ -997,6 +997,9 @@ template <typename R> struct PitFuse {
     const int64_t *modes_dev;
     int nmodes, nsel;
     float damp = 1.f;                // X = theta X + damp V D~ (1: the full correction)
+    // forward product of TWO tap-set arrays in one launch (MODE 0): blocks [0, nb) take T -> Out, blocks [nb, 2 nb) take T2 -> Out2 (nb = ceil(ncol / 16))
+    const Cx<R> *T2 = nullptr;
+    float2 *Out2 = nullptr;
 };
 // A2 = the matrix whose ROWS are read: V for the forward product (op(A) = V^H: op(A)[m][k] = conj(V[k][m])), V^T for the back
 // transform (op(A) = V: op(A)[m][k] = V^T[k][m]) - consecutive threads read consecutive m either way.
@@ -1332,7 +1335,10 @@ __global__ void __launch_bounds__(64 * (PIT_EIGMAX / 16)) pit_basis_mfma_kernel(
     Zf *Bs = reinterpret_cast<Zf *>(pit_smem);                // [np][PIT_MBP]
     Zf *Ct = Bs + (size_t)(n + 4) * PIT_MBP;                  // [PIT_MC][PIT_EIGMAX + 1] (MODE 1: transposition of the result)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, nt = blockDim.x;
-    const int col0 = blockIdx.x * PIT_MC;
+    const int nb1 = (ncol + PIT_MC - 1) / PIT_MC;
+    const bool second = MODE == 0 && (int)blockIdx.x >= nb1;   // (block-uniform: the second array of a two-array forward product)
+    if (second) { T = fz.T2; Out = reinterpret_cast<Zf *>(fz.Out2); }
+    const int col0 = ((int)blockIdx.x - (second ? nb1 : 0)) * PIT_MC;
     const size_t wset = (size_t)fz.nmodes * n;
     // op(A) - 54 KB, the same for every block and launch, L2 resident - goes from global memory straight into the A operand
     // (lane: row 16 wave + (lane & 15), k + (lane >> 4); 8 steps prefetched), the B tile through LDS (shared by the waves)
@@ -2805,6 +2811,11 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 auto forward = [&](const Cx<R> *src, Zf *dst) {      // dst = V^H src
                     hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 0>), dim3((ncol + PIT_MC - 1) / PIT_MC), dim3(pit_mfma_threads(ntot)), pit_mfma_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, fz);
                 };
+                auto forward2 = [&](const Cx<R> *src, Zf *dst, const Cx<R> *src2, Zf *dst2) {      // both products in ONE launch (a launch is ~4.5 us whatever it does)
+                    PitFuse<R> f2 = fz;
+                    f2.T2 = src2; f2.Out2 = reinterpret_cast<float2 *>(dst2);
+                    hipLaunchKernelGGL((pit_basis_mfma_kernel<R, 0>), dim3(2 * ((ncol + PIT_MC - 1) / PIT_MC)), dim3(pit_mfma_threads(ntot)), pit_mfma_lds(ntot), g_stream, Vb, src, (const Zf *)nullptr, dst, ntot, ncol, (const PitCtrl *)ctrl, f2);
+                };
                 if (p == 0 && model_event) QH_HIP(hipStreamWaitEvent(g_stream, model_event, 0));       // the sweep's coarse model (other stream)
                 // Start taps of this pass into the eigenbasis - in EVERY pass (round 5).  Rounds 3-4 projected them once per sweep and kept x~ up to
                 // date in the eigenbasis (x~ <- theta x~ + D~, pit_recur_eig_kernel) while the back product updated X itself (X <- theta X + V D~).
@@ -2812,9 +2823,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 // times the correction - ~1e-6 per boundary, the same sign from boundary to boundary - and a fixed point of the TRACKED copy
                 // leaves exactly that as a true defect at every boundary; the weakly excited directions (coefficient ~1) add them up over the
                 // whole sweep: 1.0-1.7e-3 of tap deviation at C3 whatever the tolerance, invisible to the estimate (profiles/r05_tap_floor.txt).
-                if (x_aside) QH_HIP(hipStreamWaitEvent(g_stream, ev_xe, 0));        // (the product itself ran beside the pass: see above)
-                else forward((const Cx<R> *)X, Xe);
-                forward((const Cx<R> *)Y, Ye);
+                if (x_aside) { QH_HIP(hipStreamWaitEvent(g_stream, ev_xe, 0)); forward((const Cx<R> *)Y, Ye); }       // (the product of X ran beside the pass: see above)
+                else forward2((const Cx<R> *)X, Xe, (const Cx<R> *)Y, Ye);
                 hipLaunchKernelGGL(pit_bound_kernel, dim3((nbnd + nsel + 3) / 4), dim3(256), 0, g_stream, (const Zf *)Xe, (const Zf *)Ye, (const Zf *)Yprev, lam, ntot, sg.S, nsel, sym,
                                    (const PitCtrl *)ctrl, dfc, pw, gph, ualpha);
                 hipLaunchKernelGGL((pit_gauge_kernel<R>), dim3(ssb ? 2 : 1), dim3(PIT_GT_THREADS), 0, g_stream, (const double *)gph, sg.S, nsel, ctrl, theta, (const double *)pw,
