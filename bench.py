@@ -465,8 +465,11 @@ class _OracleKernels:
         self.k, self.saved = k, {n: getattr(k, n) for n in ("ResidentField", "ResidentJobs", "train_equaliser", "apply_filter_to_signal", "train_equaliser_windows_search")}
 
         class OracleField:
-            def __init__(self, E):
+            def __init__(self, E, defer=False):
                 self.E = E
+
+            def finish(self):
+                pass
 
             def train(self, *a):
                 return oracle.train_equaliser(self.E, *a, fast=True)
@@ -1052,9 +1055,11 @@ def main():
                     help="N > 1: ONE capture, the segments of the tier-b trainer spread over the ranks with an all-reduce of their end taps per pass "
                          "(qampy_amd.distributed; strong scaling, informational - the default is one independent capture per GPU)")
     ap.add_argument("--c5-frames", type=int, default=9, help="workload c5: frames in the synthetic capture (the first and the last are cut by the frame offset)")
-    ap.add_argument("--allow-tcp", action="store_true",
-                    help="N > 1 on GPUs: go on with the host-side socket collectives when RCCL cannot start (default: exit non-zero - a multi-GPU line must not be "
-                         "produced without RCCL ever being used)")
+    ap.add_argument("--require-rccl", action="store_true",
+                    help="N > 1 with one GPU per rank: refuse to run (exit 3) when the process group could not be built on RCCL.  Default since round 5: go on with the socket "
+                         "backend - the data path has no collective (one independent capture per rank; the group only carries barriers, the max of the elapsed time and error "
+                         "counters) - and flag it: comm_backend = 'tcp', comm_degraded = true, the reason in config.comm_note")
+    ap.add_argument("--allow-tcp", action="store_true", help="(kept for older command lines: the default since round 5, see --require-rccl)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: kernels replaced by a sleep, socket collectives - exercises launcher + reductions")
     args = ap.parse_args()
 
@@ -1087,10 +1092,11 @@ def main():
     backend = "tcp" if args.dry_run else os.environ.get("QAMPY_BENCH_BACKEND", "auto")
     cm = Comm(device=dev, backend=backend)
     ranks_seen = int(round(sharding.reduce_sum_counts([[1.0]], cm)[0, 0]))
-    if world > 1 and not args.dry_run and cm.backend != "rccl" and not args.allow_tcp and ndev >= world:
+    comm_degraded = bool(world > 1 and not args.dry_run and cm.backend != "rccl" and ndev >= world)
+    if comm_degraded and args.require_rccl:
         # every rank has its own GPU and the group is still not RCCL: refuse (all ranks agreed on the backend, so all of them leave here)
         if rank == 0:
-            print(json.dumps(dict(error="N = %d ranks on %d visible GPUs but the process group is '%s', not RCCL (%s); --allow-tcp to run with host-side collectives"
+            print(json.dumps(dict(error="N = %d ranks on %d visible GPUs but the process group is '%s', not RCCL (%s); without --require-rccl the run goes on with host-side collectives and says so"
                                         % (world, ndev, cm.backend, cm.note or "no reason recorded"), n_gpus=world, ranks_seen=ranks_seen, comm_backend=cm.backend)))
         cm.close()
         sys.stdout.flush()
@@ -1206,7 +1212,7 @@ def main():
                stages_ms={n: round(t, 3) for n, t in zip(stage_names, stage_ms)},
                ser=dict(per_mode_rank0=[e / max(n, 1) for e, n in errs], errors_rank0=[e for e, _ in errs], errors_all=int(counts_all[:, 0].sum()),
                         symbols_all=int(counts_all[:, 1].sum())),
-               device=_lib.device_name(), comm_backend=comm_backend, ms_per_step_per_rank=per_rank_ms)
+               device=_lib.device_name(), comm_backend=comm_backend, comm_degraded=comm_degraded, ms_per_step_per_rank=per_rank_ms)
     if comm_note:
         out["config"]["comm_note"] = comm_note
     if split:
