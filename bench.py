@@ -1394,7 +1394,7 @@ def main():
                 out["api_end_to_end"] = api_end_to_end_block(cfg, sig, nsym, tol_check, rxe)
                 del rxe
             if overlap and args.in_flight == 1:
-                out["two_in_flight"] = in_flight_block(cfg, sig, nsym, 2, 2 * max(4, min(args.steps, 20)), barrier_sync, pit)
+                out["three_in_flight"] = in_flight_block(cfg, sig, nsym, 3, 3 * max(4, min(args.steps, 20)), barrier_sync, pit)
             if args.workload == "c3":
                 out["cert_24dB"] = cert_snr_block(cfg, 24.0, min(nsym, 1 << 21), 1001, barrier_sync, pit, overlap=overlap)
                 for key in ("ns", "c2"):

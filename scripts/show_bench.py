@@ -9,8 +9,9 @@ for k in ("value", "ms_per_step", "headline_tier", "stages_ms", "speedup_vs_cpu"
 for k in ("one_receiver", "one_capture_at_a_time"):
     if d.get(k):
         print(k, d[k]["value"], d[k]["ms_per_step"], d[k].get("stages_ms"))
-if d.get("two_in_flight"):
-    print("two_in_flight", {k: v for k, v in d["two_in_flight"].items() if k != "note"})
+for key in ("two_in_flight", "three_in_flight"):
+    if d.get(key):
+        print(key, {k: v for k, v in d[key].items() if k != "note"})
 tb = d.get("tier_b")
 if tb and tb.get("in_flight"):
     print("in_flight", {k: v for k, v in tb["in_flight"].items() if k not in ("what", "one_receiver")})
