@@ -135,7 +135,7 @@ def stage_list(rx):
     return names, fns
 
 
-def timed_steps(rx, steps, warmup, barrier_sync, overlap=False):
+def timed_steps(rx, steps, warmup, barrier_sync, overlap=False, pool=None):
     """W warm-up passes, then exactly K passes bracketed by barrier + device sync; HIP events between the stages.  Returns
     (elapsed s, mean stage ms, per-step pass kernel ms of tier b).
 
@@ -148,15 +148,28 @@ def timed_steps(rx, steps, warmup, barrier_sync, overlap=False):
     acq_ms = [[] for _ in range(rx.nstage)]
     if overlap:
         order = ["start", "gram"] + ["train%d" % s for s in range(rx.nstage)] + ["apply"]
+        fed = [0]
+
+        def feed():
+            # consecutive captures that DIFFER: the next member of the resident pool goes into the receiver's second input buffer (a reference, no
+            # copy); run() prepares it beside this capture's cold stage and swaps the buffers when it is done with the current one
+            if pool:
+                fed[0] += 1
+                rx.E_next = pool[fed[0] % len(pool)]
+                rx._next_loaded = True
+        if pool:
+            rx.E = pool[0]
+            rx.invalidate() if getattr(rx, "_prep", None) is not None else None
         for _ in range(warmup):
+            feed()
             rx.run(overlap=True, prefetch=True)
         rx.wait_post()
-        pool = [_lib.Event() for _ in range(steps * (len(order) + 2) + 2)]
+        evpool = [_lib.Event() for _ in range(steps * (len(order) + 2) + 2)]
         marks = [dict() for _ in range(steps + 1)]
 
         def marker(k):
             def mark(name):
-                e = pool.pop()
+                e = evpool.pop()
                 e.record()
                 marks[k][name] = e
                 if name.startswith("train"):
@@ -168,10 +181,19 @@ def timed_steps(rx, steps, warmup, barrier_sync, overlap=False):
         barrier_sync()
         t0 = time.perf_counter()
         for k in range(steps):
+            feed()
             rx.run(overlap=True, mark=marker(k), prefetch=True)      # (prefetch: the next capture's acquisition + eigenbasis beside this capture's cold stage)
         rx.wait_post(marker(steps))
         barrier_sync()
         elapsed = time.perf_counter() - t0
+        if pool:
+            # back to the pool's first capture (the one the exact path, the CPU legs and the SER harness work on): one untimed pass, so that the results,
+            # reports and deviations read after this call belong to it
+            rx.E = pool[0]
+            rx._next_loaded = False
+            rx.invalidate()
+            rx.run(overlap=True)
+            rx.wait_post()
         stage_ms = [float(np.mean([marks[k][order[j + 1]].elapsed_ms(marks[k][order[j]]) for k in range(steps)])) for j in range(len(order) - 1)]
         if rx.Mtestangles:
             stage_ms.append(float(np.mean([mk["post_end"].elapsed_ms(mk["post_begin"]) for mk in marks if "post_end" in mk])))
@@ -656,14 +678,26 @@ def tier_b_block(cfg, rx, stage_names, pass_ms, acq_ms, reports, value, ms, errs
                                   note="whole step against the fully fused lower bound of 88 B per symbol period"))
 
 
-def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_check, overlap=False, in_flight=1):
+def make_pool(cfg, nsym, rx, first_seed, ncap):
+    """`ncap` resident captures for one receiver: its own (already loaded: seed `first_seed`) and ncap - 1 more synthesised on the device, seeds
+    1000 + ((first_seed - 1000 + j) mod ncap) - the ranks of an N-GPU run rotate through the SAME captures, each starting at its own."""
+    from qampy_amd import synth
+    pool = [rx.E]
+    for j in range(1, ncap):
+        seed = 1000 + ((first_seed - 1000 + j) % ncap)
+        pool.append(synth.make_capture_dev(cfg["M"], nsym, nmodes=cfg.get("nmodes", 2), os=2, snr_db=cfg["snr_db"], theta=np.pi / 5.6 if cfg.get("nmodes", 2) == 2 else None,
+                                           dgd=30e-12, linewidth=cfg["linewidth"], fb=20e9, beta=0.1, seed=seed)["E"])
+    return pool
+
+
+def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_check, overlap=False, in_flight=1, pool_n=1, first_seed=1000):
     """Tier b (timed, `steps` passes) and the exact path beside it on the same resident capture: both blocks, the measured
     deviation and the certificate.  Returns (tier_b, tier_a, extras for the roofline).
 
     overlap: the timed passes are consecutive captures of a running receiver (ResidentReceiver.run(overlap=True): phase search of pass k
     beside the training of pass k + 1); the same receiver is then timed one capture at a time as well (`one_capture_at_a_time`)."""
     overlap = bool(overlap and cfg["A"])
-    group = None
+    group, pool = None, None
     if in_flight > 1 and overlap:
         # `in_flight` captures on the GPU at a time (pipeline.ReceiverGroup): the timed K passes are dealt round robin to that many receivers
         group = make_group(in_flight, cfg, sig, pit)
@@ -675,7 +709,8 @@ def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_
         rx = make_receiver(cfg, sig, tier="b", pit=pit)
         rx.load(sig)
         names, _ = stage_list(rx)
-        elapsed, stage_ms, pass_ms, acq_ms = timed_steps(rx, steps, warmup, barrier_sync, overlap=overlap)
+        pool = make_pool(cfg, nsym, rx, first_seed, pool_n) if (overlap and pool_n > 1) else None
+        elapsed, stage_ms, pass_ms, acq_ms = timed_steps(rx, steps, warmup, barrier_sync, overlap=overlap, pool=pool)
     reports = rx.pit_reports()
     pass_all = None
     if group is None and not getattr(rx, "exchanges", None):
@@ -684,13 +719,18 @@ def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_
         from qampy_amd import _lib as _l
         _l.call("qh_set_pit_timing", 2)
         try:
-            _, _, pass_all, _ = timed_steps(rx, max(2, min(steps, 5)), 1, barrier_sync, overlap=overlap)
+            _, _, pass_all, _ = timed_steps(rx, max(2, min(steps, 5)), 1, barrier_sync, overlap=overlap, pool=pool)
         finally:
             _l.call("qh_set_pit_timing", 1)
     ser_rows = rx.ser(sig.symbols, maxlag=256, window=8192, trim=2000) if cfg["A"] else []
     errs = [(d["errors"], d["compared"]) for d in ser_rows]
     tb = tier_b_block(cfg, rx, names, pass_ms, acq_ms, reports, nsym * steps / elapsed / 1e6, elapsed / steps * 1e3, errs, nsym)
     tb["stages_ms"] = {n: round(t, 3) for n, t in zip(names, stage_ms)}
+    if pool:
+        tb["capture_pool"] = dict(captures=len(pool), seeds=[first_seed] + [1000 + ((first_seed - 1000 + j) % len(pool)) for j in range(1, len(pool))],
+                                  what="the K timed captures are DIFFERENT captures: a pool of resident captures rotated through the receiver's two input buffers (references, no "
+                                       "copies); stages / passes / deviations / symbol errors in this block belong to the pool's first capture (seed %d), processed once more "
+                                       "after the timed region" % first_seed)
     if pass_all is not None:
         for s_, st in enumerate(tb["stages"]):
             flat = [p for step in pass_all[s_] for p in step]
@@ -890,6 +930,44 @@ def ref_benchmarks_block(tol, cpu=True):
                                 "segments to fill the chip); cpu_port_ms = the oracle's reference-flag build on the same arrays, all host threads")
 
 
+def capture_pool_block(cfg, nsym, tol, barrier_sync, ncap=8, rounds=3):
+    """Informational: K consecutive captures that are DIFFERENT captures - a pool of `ncap` resident captures (seeds 1000 .. 1000 + ncap - 1: the captures the
+    ranks of an `ncap`-GPU run get) rotated through one running receiver (overlap + prefetch through its second input buffer, no copies).  The headline
+    feeds the same resident capture K times; the number of passes a capture needs depends on the capture (profiles/r05_seed_sweep.txt), so this is the
+    receiver's AVERAGE throughput over captures, and the spread is what an N-GPU line with one fixed capture per rank shows as inefficiency."""
+    from qampy_amd import synth, _lib
+    caps = [synth.make_capture_dev(cfg["M"], nsym, nmodes=2, os=2, snr_db=cfg["snr_db"], theta=np.pi / 5.6, dgd=30e-12, linewidth=cfg["linewidth"], fb=20e9, beta=0.1, seed=1000 + j)
+            for j in range(ncap)]
+    class _S:                                       # (make_receiver only reads shape and alphabet)
+        shape = (2, 2 * nsym); coded_symbols = caps[0]["alphabet_host"]
+    rx = make_receiver(cfg, _S, tier="b", pit=dict(tol=tol))
+    rx.load(caps[0]["E"].to_host())                 # (derives the acquisition chunk on the host)
+    pool = [c["E"] for c in caps]
+    rx.E = pool[0]
+
+    def feed(k):
+        rx.E_next = pool[(k + 1) % ncap]
+        rx._next_loaded = True
+    per_cap = []
+    for k in range(ncap):                           # warm-up round: every capture once, its report read
+        feed(k)
+        rx.run(overlap=True, prefetch=True)
+        rx.wait_post()
+        per_cap.append([(r["passes"], bool(r["converged"]), bool(r["exact_form"])) for r in rx.pit_reports()])
+    barrier_sync()
+    t0 = time.perf_counter()
+    for k in range(rounds * ncap):
+        feed(k)
+        rx.run(overlap=True, prefetch=True)
+    rx.wait_post()
+    barrier_sync()
+    el = time.perf_counter() - t0
+    n = rounds * ncap
+    return dict(captures=ncap, steps=n, value=round(nsym * n / el / 1e6, 3), unit="MSym/s", ms_per_step=round(el / n * 1e3, 3), tol=tol,
+                passes_per_capture=[[p for p, _, _ in row] for row in per_cap], all_certified_by_the_device=bool(all(c and not x for row in per_cap for _, c, x in row)),
+                note="informational: consecutive captures that differ (seeds 1000 .. %d, the captures of an %d-GPU run), rotated through one receiver" % (1000 + ncap - 1, ncap))
+
+
 def survey_recipe_block(barrier_sync, tol):
     """SURVEY.md 8d's LITERAL C3 recipe - mu = (1e-3, 5e-4), linewidth 5 kHz - and what is closest to it that the reference's own recurrence converges on
     at 2^22 symbols.  Measured with the exact path (profiles/r05_survey_recipe_exact_path.txt: three seeds x linewidths 0 / 1 / 5 kHz x 2^16 .. 2^22): at
@@ -1047,6 +1125,8 @@ def main():
     ap.add_argument("--bank-trainer", default="iterative", choices=["auto", "iterative"])
     ap.add_argument("--bank", type=int, default=128, help="channels of the informational channel-bank run at N=1 (0 = skip)")
     ap.add_argument("--cpu-bank-workers", type=int, default=-1, help="concurrent single-threaded CPU pipelines of the bank's CPU leg (-1: min(cores, 128), 0: skip)")
+    ap.add_argument("--pool", type=int, default=8, help="tier b, consecutive captures: resident captures rotated through the receiver (seeds 1000 + ((rank + j) mod pool)); 1 = the same "
+                                                       "capture every step (rounds 1-4)")
     ap.add_argument("--in-flight", type=int, default=1, help="tier b: captures on the GPU at a time (pipeline.ReceiverGroup, one host thread per receiver); 1 = one receiver")
     ap.add_argument("--no-overlap", action="store_true", help="tier b: time one capture at a time only (default: consecutive captures, the phase search of "
                                                               "pass k on stream 2 beside the training of pass k + 1)")
@@ -1155,7 +1235,8 @@ def main():
         tried = []
         for t_ in tol_ladder:
             pit, tol_check = dict(tol=t_), t_
-            tier_b, tier_a, ex = run_pair(cfg, sig, nsym, args.steps, args.warmup, barrier_sync, pit, args.exact_steps if world == 1 else 0, tol_check, overlap=overlap, in_flight=args.in_flight)
+            tier_b, tier_a, ex = run_pair(cfg, sig, nsym, args.steps, args.warmup, barrier_sync, pit, args.exact_steps if world == 1 else 0, tol_check, overlap=overlap, in_flight=args.in_flight,
+                                          pool_n=max(1, args.pool), first_seed=sharding.channel_seed(rank))
             if tier_b["certified"] or world > 1:         # (N > 1: every rank must take the same rung - the tightest; its certificate is all-reduced below)
                 break
             tried.append(dict(tol=t_, certified=False, checks=tier_b.get("checks"), passes=[st["P"] for st in tier_b["stages"]], value=tier_b["value"],
@@ -1224,7 +1305,11 @@ def main():
         if tier_b.get("pipelining"):
             # value / ms_per_step: K consecutive captures through one running receiver (step time = K passes / elapsed); the figure for a single
             # capture handed over and waited for is beside it
-            out["config"]["pipelining"] = "consecutive captures; phase search of pass k (stream 2) beside the training of pass k + 1 (stream 0); --no-overlap for one at a time"
+            out["config"]["pipelining"] = ("consecutive captures; phase search of capture k (stream 2) and acquisition + eigenbasis of capture k + 2 (stream 1) beside the training of "
+                                           "capture k + 1 (stream 0); --no-overlap for one at a time")
+            if tier_b.get("capture_pool"):
+                out["config"]["capture_pool"] = ("%d different resident captures per GPU (seeds %s), rotated: consecutive captures differ; --pool 1 feeds the same capture every step"
+                                                 % (tier_b["capture_pool"]["captures"], tier_b["capture_pool"]["seeds"]))
             out["one_capture_at_a_time"] = tier_b["pipelining"]["one_capture_at_a_time"]
         if tier_b.get("in_flight"):
             out["config"]["in_flight"] = "%d captures on the GPU at a time (ReceiverGroup: one host thread + stream set per receiver); --in-flight 1 for one receiver" % tier_b["in_flight"]["receivers"]
@@ -1401,6 +1486,13 @@ def main():
                     out[key] = shape_block(key, barrier_sync, pit, 10, overlap=overlap)
                 out["adaptive_step"] = adaptive_block()
                 out["survey_recipe"] = survey_recipe_block(barrier_sync, tol_check)
+                if args.pool > 1 and overlap:
+                    tb1, _, ex1 = run_pair(cfg, sig, nsym, ksteps, 1, barrier_sync, pit, 0, tol_check, overlap=overlap)
+                    out["same_capture_every_step"] = dict(value=tb1["value"], ms_per_step=tb1["ms_per_step"], passes=[st["P"] for st in tb1["stages"]],
+                                                          note="informational: the workload of rounds 1-4 - the SAME resident capture (seed 1000) K times; the headline rotates %d different captures" % args.pool)
+                    del ex1
+                else:
+                    out["capture_pool"] = capture_pool_block(cfg, nsym, tol_check, barrier_sync)
                 out["ref_benchmarks"] = ref_benchmarks_block(tol_check, cpu=not args.no_cpu_baseline)
                 # SURVEY.md 8c's tolerance on the three BASELINE shapes, each with the in-run certificate against the exact path
                 rows = dict(c3=dict(value=tier_b["value"], certified=tier_b["certified"], checks=tier_b.get("checks"), passes=[st["P"] for st in tier_b["stages"]],
