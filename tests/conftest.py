@@ -23,6 +23,10 @@ class Golden:
         self._files = {}
         with open(os.path.join(GOLDEN, "cases.json")) as f:
             self.cases = json.load(f)
+        extra = os.path.join(GOLDEN, "cases_cross.json")           # non-square alphabets (tests/golden/gen_golden_cross.py)
+        if os.path.exists(extra):
+            with open(extra) as f:
+                self.cases.update(json.load(f))
 
     def __getitem__(self, name):
         if name not in self._files:

@@ -42,6 +42,27 @@ def test_train_equaliser_golden(golden, case):
     assert np.all(err[unsel] == 0)
 
 
+@pytest.mark.parametrize("form", ["auto", "direct"])
+@pytest.mark.parametrize("case", golden_cases("train_cross"), ids=lambda c: c["name"])
+def test_train_equaliser_cross_qam_golden(golden, case, form, monkeypatch):
+    """Non-square alphabets (32- / 128-QAM) against the reference's outputs: the decision is a search over ALL symbols with the reference's
+    first-minimum rule (det_symbol, pythran_equalisation.py:240-265) - in the form the library picks and in the direct form."""
+    if form == "direct":
+        monkeypatch.setenv("QAMPY_HIP_TRAINER", "direct")
+    else:
+        monkeypatch.delenv("QAMPY_HIP_TRAINER", raising=False)
+    g = golden["train_cross"]
+    n, dn = case["name"], case["dtype"]
+    E = np.ascontiguousarray(g[case["input"] + "_E"].astype(CT[dn]))
+    wx = g[n + "__wx0"].copy()
+    err, wx2, mu = hk.train_equaliser(E, case["TrSyms"], case["Niter"], case["os"], RT[dn](case["mu"]), wx,
+                                      np.array(case["modes"]), case["adaptive"], g[n + "__symbols"], case["method"])
+    assert wx2 is wx and err.dtype == CT[dn] and err.shape == g[n + "__err"].shape
+    _close(wx, g[n + "__wx"], dn)
+    _close(err, g[n + "__err"], dn, scale=3)
+    np.testing.assert_allclose(mu, g[n + "__mu"], rtol=1e-9 if dn == "c128" else 2e-4)
+
+
 @pytest.mark.parametrize("case", [c for c in golden_cases("train") if c.get("real")], ids=lambda c: c["name"])
 def test_train_equaliser_realvalued_golden(golden, case):
     g = golden["train"]

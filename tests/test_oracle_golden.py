@@ -31,6 +31,22 @@ def test_train_equaliser(golden, case):
     _close(mu, g[n + "__mu"], dn)
 
 
+@pytest.mark.parametrize("case", golden_cases("train_cross"), ids=lambda c: c["name"])
+def test_train_equaliser_cross_qam(golden, case):
+    """32- / 128-QAM (cross constellations): decision-directed and partition-based error functions where no per-axis slicer applies
+    (tests/golden/gen_golden_cross.py; pythran_equalisation.py:240-265 det_symbol, :4-9 partition_value)."""
+    g = golden["train_cross"]
+    n, dn = case["name"], case["dtype"]
+    E = np.ascontiguousarray(g[case["input"] + "_E"].astype(CT[dn]))
+    wx = g[n + "__wx0"].copy()
+    err, wx, mu = oracle.train_equaliser(E, case["TrSyms"], case["Niter"], case["os"], RT[dn](case["mu"]), wx,
+                                         np.array(case["modes"]), case["adaptive"], g[n + "__symbols"], case["method"])
+    assert err.dtype == CT[dn] and err.shape == g[n + "__err"].shape
+    _close(wx, g[n + "__wx"], dn)
+    _close(err, g[n + "__err"], dn, scale=10)
+    _close(mu, g[n + "__mu"], dn)
+
+
 @pytest.mark.parametrize("case", [c for c in golden_cases("train") if c.get("real")], ids=lambda c: c["name"])
 def test_train_equaliser_realvalued(golden, case):
     g = golden["train"]
