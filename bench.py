@@ -565,7 +565,8 @@ def run_c5(args, cfg):
     one = pilot_chain(cap, frames=[0])                      # the same capture, first frame only (what rounds 1-3 timed)
     # the sequential heart of a frame: Niter sweeps x 3 stages x seq_len steps of the exact recurrence with the adaptive step, two modes side by side
     steps_per_frame = 3 * 30 * 1024
-    out = dict(metric="equalised MSym/s (2-pol, 2 SPS)", value=round(cfg["nsym"] * nfr * args.steps / el / 1e6, 4), unit="MSym/s", n_gpus=1, ranks_seen=1, steps=args.steps,
+    out = dict(metric="equalised MSym/s (2-pol, 2 SPS; a step recovers %d frames of one capture)" % nfr, value=round(cfg["nsym"] * nfr * args.steps / el / 1e6, 4), unit="MSym/s", n_gpus=1,
+               ranks_seen=1, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(el / args.steps * 1e3, 3), ms_per_frame=round(el / args.steps / nfr * 1e3, 3), higher_is_better=True, scaling="weak",
                vs_baseline=None, dtype="f32", data="synthetic",
                config=dict(workload=cfg["label"], key="c5", frame_len=cfg["nsym"], frames_captured=args.c5_frames, frames_recovered=nfr, ntaps=[17, 45],

@@ -149,6 +149,15 @@ def train_equaliser_realvalued(E, TrSyms, Niter, os, mu, wx, modes, adaptive, sy
     return err, wx, rt(mu_c.value)
 
 
+def _host_result(shape, dtype):
+    """Host array a kernel's output is copied into: from the library's pinned pool when it is large enough for the DMA rate to matter
+    (an ordinary ndarray to the caller either way), zero-filled like the reference's ``np.zeros`` when small."""
+    n = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+    if n >= _lib.PINNED_MIN_BYTES:
+        return _lib.pinned_empty(shape, dtype)
+    return np.zeros(shape, dtype=dtype)
+
+
 def apply_filter_to_signal(E, os, wx, modes=None):
     """Butterfly FIR + decimation, ``out (n_sel, (L-ntaps+1)//os)`` (pythran_equalisation.py:33-76); 4 dtypes."""
     suf, rt, ct = _lib.suffix(E.dtype)
@@ -163,7 +172,7 @@ def apply_filter_to_signal(E, os, wx, modes=None):
     if modes.size and modes.max() >= wx.shape[0]:
         raise ValueError("largest mode number is larger than shape of signal")
     N = max((L - ntaps + 1) // os, 0)
-    out = np.zeros((modes.size, N), dtype=E.dtype)
+    out = _host_result((modes.size, N), E.dtype)
     name = "qh_apply_filter_" + (("c64" if suf == "32" else "c128") if np.iscomplexobj(E) else "f" + suf)
     if wx.shape[0] != nmodes:
         raise ValueError("wx must be (nmodes, nmodes, ntaps)")

@@ -150,7 +150,9 @@ def pilot_phase_trace(E, knots, knot_phase):
     kph = np.ascontiguousarray(knot_phase, dtype=np.float64)
     if kph.shape != (E.shape[0], knots.size) or knots.size < 1:
         raise ValueError("one phase per mode and knot")
-    out, trace = np.empty_like(E), np.empty_like(E)
+    big = E.nbytes >= _lib.PINNED_MIN_BYTES                       # results through the pinned pool: one DMA at the link rate each
+    out = _lib.pinned_empty(E.shape, E.dtype) if big else np.empty_like(E)
+    trace = _lib.pinned_empty(E.shape, E.dtype) if big else np.empty_like(E)
     _lib.call("qh_pilot_phase_trace_c" + ("64" if suf == "32" else "128"), _lib.ptr(E), E.shape[0], E.shape[1], _lib.ptr(knots), _lib.ptr(kph), knots.size,
               _lib.ptr(out), _lib.ptr(trace))
     return out, trace

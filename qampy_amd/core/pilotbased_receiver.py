@@ -168,7 +168,8 @@ def pilot_based_cpe_new(signal, pilot_symbs, pilot_idx, frame_len, seq_len=None,
         raise AssertionError("averaged phase and new indices are not the same shape")
     # the phase at every symbol (linear between the knots, constant outside: np.interp) and its removal: one pass over the frame(s) on the device
     keep = nframes * frame_len
-    field = np.ascontiguousarray(rows[:, :span], dtype=sent.dtype)
+    # precision as numpy's promotion gives it in the reference (signal * exp(-1j trace), :327): the wider of the signal and the pilots
+    field = np.ascontiguousarray(rows[:, :span], dtype=np.result_type(rows.dtype, sent.dtype, np.complex64))
     corrected, trace = phaserecovery._dsp.pilot_phase_trace(field, knots, knot_phase)
     return corrected[:, :keep], trace[:, :keep]
 

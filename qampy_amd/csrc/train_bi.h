@@ -112,6 +112,57 @@ __device__ __forceinline__ double bperm(double v, int byte_addr)
 }
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114;
 
+// Decision on an ARBITRARY alphabet inside the block-iterative form (round 5; 32- / 128-QAM crosses, where no per-axis slicer exists).  After the
+// exchange the 8 lanes of a group hold the same output y; lane v of the group scans the symbols [v ceil(M / 8), (v + 1) ceil(M / 8)) from LDS with the
+// reference's strict `<` (det_symbol, pythran_equalisation.py:258-264: first minimum in symbol order, from d0 = 1000 and the symbol 1 + 0j), then the
+// group takes the smallest distance with ties to the LOWER index - the reference's first minimum - in three DPP exchanges; the winner's symbol is
+// read back from LDS by index.  ceil(M / 8) distance evaluations per lane and sweep instead of M per step.
+constexpr int BI_GEN_MAXSYM = 256;
+template <typename T> __device__ __forceinline__ T bi_xchg(T v, int lvl)
+{
+    return lvl == 0 ? dpp_mov<DPP_QUAD_1032>(v) : (lvl == 1 ? dpp_mov<DPP_QUAD_2301>(v) : dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+}
+template <typename R> __device__ __forceinline__ Cx<R> bi_nearest_general(Cx<R> y, const Cx<R> *alph, int M, int vv)
+{
+    static_assert(BI_W == 8, "three exchange levels cover a group of 8 lanes");
+    const int per = (M + BI_W - 1) / BI_W;
+    R best = (R)1000;
+    int bidx = 0x7fffffff;                                            // "nothing closer than 1000": det_symbol's initial symbol survives
+    const int k0 = vv * per;
+    for (int u = 0; u < per; u++) {
+        const int k = k0 + u;
+        if (k < M) {
+            const Cx<R> c = alph[k];
+            const R dr = y.re - c.re, di = y.im - c.im;
+            const R d = fma_(dr, dr, di * di);
+            if (d < best) { best = d; bidx = k; }
+        }
+    }
+#pragma unroll
+    for (int lvl = 0; lvl < 3; lvl++) {
+        const R od = bi_xchg<R>(best, lvl);
+        const int oi = __builtin_bit_cast(int, bi_xchg<float>(__builtin_bit_cast(float, bidx), lvl));
+        const bool take = od < best || (od == best && oi < bidx);
+        best = take ? od : best; bidx = take ? oi : bidx;
+    }
+    if (bidx == 0x7fffffff) return Cx<R>{(R)1, (R)0};
+    return alph[bidx];
+}
+// error function of a decision-directed method given the decided symbol (la_errfn's formulas; SCALE: the step size folded in)
+template <typename R, int METHOD, bool SCALE> __device__ __forceinline__ Cx<R> bi_dd_error(Cx<R> y, Cx<R> sdec, R mu)
+{
+    using v2 = typename V2<R>::type;
+    const v2 yy = {y.re, y.im}, s = {sdec.re, sdec.im};
+    v2 d;
+    if constexpr (METHOD == QH_M_SBD) d = (s - yy) * __builtin_elementwise_abs(s);
+    else if constexpr (METHOD == QH_M_MDDMA) d = (s * s - yy * yy) * yy;
+    else d = s - yy;
+    if constexpr (SCALE) d = d * mu;
+    return Cx<R>{d.x, d.y};
+}
+struct BiScaled { static constexpr bool value = true; };
+struct BiPlain { static constexpr bool value = false; };
+
 template <typename R, int METHOD, int NPART, bool ADAPT = false>
 __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
 {
@@ -144,6 +195,11 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
     Cx<R> *wbuf = TW + BI_MAXTAPS * BI_PAD;                            // [BI_MAXTAPS]      taps, wave-uniform reads
     Cx<R> *win = wbuf + BI_MAXTAPS;                                    // [2][nmodes][wpitch] sample windows (block parity)
     BiAd<R> *adx = reinterpret_cast<BiAd<R> *>(win + 2 * wsz);         // [2][BI_W] adaptive-step exchange (ADAPT only)
+    // decision-directed method without slicer tables: the alphabet itself, scanned per decision (bi_nearest_general)
+    constexpr bool GEN = NPART == 0 && (METHOD == QH_M_SBD || METHOD == QH_M_MDDMA || METHOD == QH_M_DD);
+    Cx<R> *alph = reinterpret_cast<Cx<R> *>(adx + 2 * BI_W);           // [nsy] (GEN only)
+    const int nalph = GEN ? (int)a.nsy : 0;
+    if constexpr (GEN) for (int k2 = threadIdx.x; k2 < nalph; k2 += BI_NT) alph[k2] = sy[k2];      // (barriers follow before the first decision)
 
     // ---- constants of the error function
     LaConst<R, NPART> K;
@@ -171,6 +227,12 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         xo[s] = k2 * wpitch + (fc - k2 * a.ntaps);
     }
     const int rr = lane / BI_W, vv = lane % BI_W;                      // reduction layout: group rr <-> row, lane vv of the group <-> wave
+    // the error function of an output that is identical in the 8 lanes of its group
+    auto errf = [&](Cx<R> yv, Cx<R> sd, auto SC) __attribute__((always_inline)) -> Cx<R> {
+        constexpr bool SCALE = decltype(SC)::value;
+        if constexpr (GEN) return bi_dd_error<R, METHOD, SCALE>(yv, bi_nearest_general<R>(yv, alph, nalph, vv), K.mu);
+        else return la_errfn<R, METHOD, NPART, SCALE>(yv, K, sd);
+    };
     // window offset of tap f0 + lane of the own slice (prior dot products fetch it with v_readlane); 0 for padding taps
     int toffv;
     {
@@ -328,7 +390,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
                     return true;
                 }
                 const Cx<R> eprev0 = w == 0 ? e_carry : Cx<R>{readlane(ax.er, w > 0 ? w - 1 : 0), readlane(ax.ei, w > 0 ? w - 1 : 0)};
-                const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K, sdat);
+                const Cx<R> e = errf(y, sdat, BiPlain{});
                 const Cx<R> ec{bperm(e.re, csrc), bperm(e.im, csrc)};       // compact: lane <-> row cl
                 Cx<R> ep{dpp_mov<DPP_ROW_SHR1>(ec.re), dpp_mov<DPP_ROW_SHR1>(ec.im)};
                 if (cl == 0) ep = eprev0;
@@ -349,7 +411,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
                 S_own = S_new; e_last = el_new;
             } else {
                 if (!__any(got.flag != 0)) return true;                    // nobody's c moved in the last sweep: y is the fixed point
-                c_new = la_errfn<R, METHOD, NPART, true>(y, K, sdat);
+                c_new = errf(y, sdat, BiScaled{});
                 const unsigned long long mv = __builtin_amdgcn_ballot_w64(c_new.re != c_old.re || c_new.im != c_old.im);
                 changed = (unsigned)mv | (unsigned)(mv >> 32);             // wave-uniform: non-zero when any own c moved
             }
@@ -368,7 +430,7 @@ __global__ void __launch_bounds__(BI_NT) train_bi_kernel(LaArgs<R> a)
         }
         // ---------------------------------------------------------------- results of the block
         const unsigned long long pt1 = a.prof ? clock64() : 0;
-        const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K, sdat);
+        const Cx<R> e = errf(y, sdat, BiPlain{});
         if (vv == 0 && s0 + BI_JW * w + rr < TrSyms) eown[s0] = e;
         // taps: this wave's steps into all taps (lane <-> taps lane, lane + 64).  Steps past TrSyms (partial last block) have
         // all-zero Gram rows, so they never touched the sweeps; their c (non-zero for decision-directed functions) is dropped here
@@ -536,6 +598,14 @@ inline bool bi_shape_ok(int nmodes, int ntaps, int os, size_t elem)
     return (size_t)2 * LA_B * BI_PAD * (elem + 16) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch) * elem + 2 * BI_W * 2 * elem <= 64 * 1024;
 }
 
+// decision-directed methods on an alphabet without per-axis slicer (bi_nearest_general): the alphabet rides in LDS behind the kernel's other arrays
+inline bool bi_general_ok(int nmodes, int ntaps, int os, int64_t nsy, size_t elem)
+{
+    if (nsy < 1 || nsy > BI_GEN_MAXSYM || !bi_shape_ok(nmodes, ntaps, os, elem)) return false;
+    const int wpitch = ((LA_B - 1) * os + ntaps + 1) & ~1;
+    return (size_t)2 * LA_B * BI_PAD * (elem + 16) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch + (size_t)nsy) * elem + 2 * BI_W * 2 * elem <= 64 * 1024;
+}
+
 inline bool bi_supported(int method, int adaptive, int nmodes, int ntaps, int os, int64_t TrSyms, int64_t nsy, size_t elem)
 {
     (void)adaptive;                       // the adaptive step runs in this form too (one mode after the other, mu carried)
@@ -544,7 +614,7 @@ inline bool bi_supported(int method, int adaptive, int nmodes, int ntaps, int os
     switch (method) {
     case QH_M_CMA: case QH_M_SGNCMA: case QH_M_CMA2: case QH_M_MCMA: return true;
     case QH_M_RDE: case QH_M_MRDE: return nsy - (nsy + 1) / 2 >= 1 && nsy - (nsy + 1) / 2 <= LA_MAXPART;
-    case QH_M_SBD: case QH_M_MDDMA: case QH_M_DD: return true;      // if the alphabet is square: slicer_tables() decides
+    case QH_M_SBD: case QH_M_MDDMA: case QH_M_DD: return true;      // square alphabets: slicer_tables(); any other: bi_general_ok()
     case QH_M_SBD_DATA: return true;
     default: return false;
     }
@@ -554,6 +624,11 @@ template <typename R, int METHOD, bool ADAPT> static int launch_bi_dd(const LaAr
 {
     dim3 grid(a.nsel, a.nch), block(BI_NT);
 #define QH_BI_DD(N) case N: hipLaunchKernelGGL((train_bi_kernel<R, METHOD, N, ADAPT>), grid, block, lds, g_stream, a); break;
+    if (a.dd_general) {         // any alphabet: the symbols themselves in LDS (bi_nearest_general)
+        if (a.nsy < 1 || a.nsy > BI_GEN_MAXSYM) { set_error("block-iterative trainer: alphabet too large for the general decision"); return QH_ERR_ARG; }
+        hipLaunchKernelGGL((train_bi_kernel<R, METHOD, 0, ADAPT>), grid, block, lds + (size_t)a.nsy * sizeof(Cx<R>), g_stream, a);
+        return QH_OK;
+    }
     switch (npart) {            // 4-, 16-, 64-, 256-QAM
         QH_BI_DD(1) QH_BI_DD(3) QH_BI_DD(7) QH_BI_DD(15)
     default: set_error("block-iterative trainer: unsupported slicer size"); return QH_ERR_ARG;

@@ -67,6 +67,8 @@ template <typename R> struct TrainArgs {
 template <typename R> struct Tables {
     // lane-resident copies of symbols[mode, :]  (lane j holds entry j and, for the split tables, entry ncode + j)
     R a_re, a_im;   // alphabet / codebook entry of this lane
+    R b_re[3], b_im[3];   // decision alphabets of 65 .. 256 symbols: entries lane + 64, lane + 128, lane + 192 (`wide`)
+    bool wide;
     R p_re, p_im;   // partition entry of this lane (RDE / MRDE)
     int n, ncode, npart;
     bool serial;        // tables larger than a wave: wave-uniform serial scans over `glob`
@@ -83,7 +85,7 @@ template <typename R> __device__ __forceinline__ int partition_index(R signal, R
 
 template <typename R> __device__ __forceinline__ Cx<R> nearest_symbol(Cx<R> X, const Tables<R> &T, int lane)
 {
-    if (!T.serial) {
+    if (!T.serial && !T.wide) {
         R dr = X.re - T.a_re, di = X.im - T.a_im;
         R d = fma_(dr, dr, di * di);
         if (lane >= T.n) d = (R)3.0e38;
@@ -93,7 +95,33 @@ template <typename R> __device__ __forceinline__ Cx<R> nearest_symbol(Cx<R> X, c
         int j = __builtin_ctzll(m);                                 // first minimum == strict `<` scan order
         return Cx<R>{readlane(T.a_re, j), readlane(T.a_im, j)};
     }
-    // serial scan for alphabets larger than a wave (wave-uniform, every lane does the same work)
+    if (T.wide) {
+        // 65 .. 256 symbols, four per lane in registers: smallest distance of the wave, then the FIRST index that has it - entries are
+        // striped (lane + 64 u), so the first stripe with a hit holds it and its lowest lane is it (det_symbol's strict `<` scan, :258-264)
+        R d[4];
+        {
+            const R dr = X.re - T.a_re, di = X.im - T.a_im;
+            d[0] = fma_(dr, dr, di * di);                             // (lane < 64 <= n)
+        }
+#pragma unroll
+        for (int u = 1; u < 4; u++) {
+            const R dr = X.re - T.b_re[u - 1], di = X.im - T.b_im[u - 1];
+            d[u] = lane + 64 * u < T.n ? fma_(dr, dr, di * di) : (R)3.0e38;
+        }
+        const R dmin = wave_min(min_(min_(d[0], d[1]), min_(d[2], d[3])));
+        if (!(dmin < (R)1000.)) return Cx<R>{(R)1, (R)0};
+        unsigned long long m = __ballot(d[0] == dmin);
+        if (m) { const int j = __builtin_ctzll(m); return Cx<R>{readlane(T.a_re, j), readlane(T.a_im, j)}; }
+#pragma unroll
+        for (int u = 1; u < 3; u++) {
+            m = __ballot(d[u] == dmin);
+            if (m) { const int j = __builtin_ctzll(m); return Cx<R>{readlane(T.b_re[u - 1], j), readlane(T.b_im[u - 1], j)}; }
+        }
+        m = __ballot(d[3] == dmin);
+        const int j = __builtin_ctzll(m);
+        return Cx<R>{readlane(T.b_re[2], j), readlane(T.b_im[2], j)};
+    }
+    // serial scan for alphabets larger than four waves (wave-uniform, every lane does the same work)
     R d0 = (R)1000.;
     Cx<R> s{(R)1, (R)0};
     for (int j = 0; j < T.n; j++) {
@@ -241,7 +269,8 @@ __device__ __forceinline__ R run_chain(const TrainArgs<R> &a, const ChainLds<R> 
     T.ncode = (T.n + 1) / 2;           // np.array_split(symbs, 2): the first half takes the extra element
     T.npart = T.n - T.ncode;
     T.a_re = T.a_im = T.p_re = T.p_im = 0;
-    T.serial = false;
+    for (int u = 0; u < 3; u++) T.b_re[u] = T.b_im[u] = 0;
+    T.serial = false; T.wide = false;
     R R_re = 0, R_im = 0;
     if constexpr (METHOD == QH_M_CMA || METHOD == QH_M_SGNCMA || METHOD == QH_M_CMA2 || METHOD == QH_M_MCMA) {
         Cx<R> c = ldg(sy);
@@ -252,7 +281,13 @@ __device__ __forceinline__ R run_chain(const TrainArgs<R> &a, const ChainLds<R> 
         T.serial = T.ncode > MAX_TABLE;
     } else if constexpr (METHOD == QH_M_SBD || METHOD == QH_M_MDDMA || METHOD == QH_M_DD) {
         if (lane < T.n && lane < MAX_TABLE) { Cx<R> c = ldg(sy + lane); T.a_re = c.re; T.a_im = c.im; }
-        T.serial = T.n > MAX_TABLE;
+        T.wide = T.n > MAX_TABLE && T.n <= 4 * MAX_TABLE;
+        T.serial = T.n > 4 * MAX_TABLE;
+        if (T.wide) {
+#pragma unroll
+            for (int u = 1; u < 4; u++)
+                if (lane + 64 * u < T.n) { Cx<R> c = ldg(sy + lane + 64 * u); T.b_re[u - 1] = c.re; T.b_im[u - 1] = c.im; }
+        }
     }
 
     Cx<R> *errow = a.err + (size_t)mode * (a.TrSyms * a.Niter);
@@ -519,14 +554,16 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         const bool decision = method == QH_M_SBD || method == QH_M_MDDMA || method == QH_M_DD;
         void *dd_table = nullptr;
         int dd_npart = -1;
-        if (bi_ok && decision) {     // square alphabets only: per-axis slicer tables in the rde / mrde layout
+        bool dd_general = false;
+        if (bi_ok && decision) {     // square alphabets: per-axis slicer tables in the rde / mrde layout; any other (32- / 128-QAM crosses): scan of the alphabet
             if ((rc = slicer_tables<R>(symbols, nmodes, nsy, modes, nsel, &dd_table, &dd_npart))) return rc;
-            bi_ok = dd_npart == 1 || dd_npart == 3 || dd_npart == 7 || dd_npart == 15;
+            if (!(dd_npart == 1 || dd_npart == 3 || dd_npart == 7 || dd_npart == 15)) bi_ok = dd_general = bi_general_ok(nmodes, ntaps, os, nsy, sizeof(Cx<R>));
         }
         const bool la_ok = !direct && la_supported(method, adaptive, nmodes, ntaps, os, TrSyms, nsy);
         const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
         const bool pair = la_shape_ok(nmodes, ntaps, os);          // layout of the Gram terms of this capture (qh_gram_build_*)
-        const bool use_bi = bi_ok && (partitioned || decision || adaptive || method == QH_M_SBD_DATA || !la_ok || (force[0] == 'i'));
+        // (round 5: the adaptive step and the data-aided error run on the look-ahead chain too - ~2x fewer cycles per step than the block sweeps)
+        const bool use_bi = bi_ok && ((partitioned && !adaptive) || decision || !la_ok || (force[0] == 'i'));
         if (use_bi || la_ok) {
             // block-iterative form (train_bi.h): 8 wavefronts per output mode solve each 64-step block by fixed-point sweeps;
             // look-ahead form (train_la.h): one chain wave + three helper waves per output mode
@@ -542,13 +579,14 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
                 if (fit < TrSyms) CH = fit > 64 * LA_B ? fit : 64 * LA_B;
             }
             LaArgs<R> la;
-            la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.gpair = pair_tab ? 1 : 0; la.mu = mu_dev; la.mu_out = use_bi ? (R *)mu_dev : nullptr;
+            la.wx = a.wx; la.symbols = a.symbols; la.err = a.err; la.gpair = pair_tab ? 1 : 0; la.mu = mu_dev; la.mu_out = (R *)mu_dev;
             la.Lp = Lp; la.nsy = nsy; la.sy_pitch = nsy; la.err_pitch = TrSyms * Niter; la.nmodes = nmodes; la.ntaps = ntaps;
             la.os = os; la.nsel = nsel; la.method = method;
             la.nch = nch; la.E_cs = Ecs; la.wx_cs = (int64_t)nmodes * ntot; la.err_cs = (int64_t)nmodes * TrSyms * Niter; la.mu_cs = 1;
             la.mu_ms = 0;
             for (int j = 0; j < 16; j++) la.modes[j] = a.modes[j];
-            if (use_bi && decision) {   // the kernel reads the slicer table like an mrde table: row pitch 2*BI_DD_MAXLEV, 2*npart+1 used
+            la.dd_general = use_bi && dd_general;
+            if (use_bi && decision && !dd_general) {   // the kernel reads the slicer table like an mrde table: row pitch 2*BI_DD_MAXLEV, 2*npart+1 used
                 la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV;
             }
             la.prof = nullptr; la.seg = 0; la.seg_extra = 0; la.seg_tail = 0; la.skip = nullptr; la.niter = 1;
@@ -561,7 +599,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             // adaptive = 1: mu is carried from sweep to sweep and from mode to mode -> one mode after the other;
             // adaptive = 2: every mode owns a step size (scratch array, seeded with mu) -> all modes concurrently
             R *mu_modes = nullptr;
-            if (per_mode && use_bi) {
+            if (per_mode) {
                 void *pm = nullptr;
                 if ((rc = scratch(6, (size_t)nch * nsel * sizeof(R), &pm))) return rc;
                 mu_modes = (R *)pm;
@@ -575,7 +613,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
             for (int jm = 0; jm < nmode_runs; jm++) {
                 if (adaptive && !mu_modes) la.modes[0] = a.modes[jm];
                 // block-iterative form, sweep not chunked: ALL sweeps in one launch (the kernel loops over them with taps and step size on chip)
-                const bool sweeps_inside = use_bi && CH >= TrSyms && Niter > 1;
+                const bool sweeps_inside = CH >= TrSyms && Niter > 1;
                 for (int it = 0; it < (sweeps_inside ? 1 : Niter); it++) {             // else one launch per sweep (and chunk): taps go through HBM in between
                     la.niter = sweeps_inside ? Niter : 1;
                     for (int64_t step0 = 0; step0 < TrSyms;) {
@@ -594,7 +632,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
                         la.E = Ec; la.L = L - step0 * os; la.TrSyms = n; la.G = (const GramPair<R> *)G;
                         la.G_cs = (int64_t)((pair_tab ? gram_bytes<R>(n) : gram_cur_bytes<R>(n)) / sizeof(GramPair<R>));
                         la.err_off = (int64_t)it * TrSyms + step0;
-                        if ((rc = use_bi ? launch_bi<R>(la, adaptive != 0) : launch_la<R>(la))) return rc;
+                        if ((rc = use_bi ? launch_bi<R>(la, adaptive != 0) : launch_la<R>(la, adaptive != 0))) return rc;
                         step0 += n;
                     }
                 }

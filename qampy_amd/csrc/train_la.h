@@ -244,6 +244,8 @@ template <typename R> struct LaArgs {
     const int *skip;            // optional device flag: non-zero -> the launch does nothing (device-side early termination)
     int niter;                  // block-iterative kernel: sweeps over the same TrSyms steps inside ONE launch (taps and step size stay on chip;
                                 // sweep `it` writes its errors at err_off + it * TrSyms); 0 / 1 = one sweep
+    int dd_general = 0;         // block-iterative kernel, decision-directed methods: != 0 - `symbols` is the alphabet itself (nsy <= BI_GEN_MAXSYM entries per
+                                // mode, any constellation: 32- / 128-QAM crosses) and every decision is det_symbol's scan over all of it; 0 - slicer tables
 };
 
 // per-channel view of the arrays of a launch (channel bank: fixed strides; segmented sweep: see LaArgs::seg)
@@ -281,7 +283,18 @@ template <typename R> struct LaLds {
     Cx<R> wbuf[LA_NH][64];           // a helper's tap slice, read back wave-uniformly for the prior dot products
 };
 
-template <typename R, int METHOD, int NPART>
+// ADAPT (round 5): the reference's adaptive step (adapt_step, pythran_equalisation.py:12-16,171-172) on the chain wave.  The step size in force is a
+// wave-uniform value; after step i >= 1 of a sweep it becomes mu / (1 + mu |e_{i-1}|^2) unless the errors of steps i and i - 1 agree in the sign of
+// both components.  Kept as r = 1 / mu ( r += |e_{i-1}|^2 : one addition, no rounding drift through repeated divisions) with mu = 1 / r per step;
+// the sign test runs on c = mu e (mu > 0: same signs, and c is at hand in vector registers).  One mode per step size: the host launches the modes
+// in turn (adaptive = 1, mu carried) or hands every mode its own (adaptive = 2), as for the block-iterative form.  ~12 instructions per step more
+// than the fixed step.  niter > 1: the reference's Niter loop inside the launch - taps stay in the helpers' registers, the step size on the chain wave.
+template <typename R> __device__ __forceinline__ R la_recip(R r)
+{
+    if constexpr (sizeof(R) == 4) return __builtin_amdgcn_rcpf(r);      // 1 ulp; mu is re-derived from the exactly accumulated r every step
+    else return (R)1 / r;
+}
+template <typename R, int METHOD, int NPART, bool ADAPT = false>
 __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
 {
     if (a.skip && *a.skip) return;
@@ -308,6 +321,7 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
     const int64_t TrSyms = vw.TrSyms;
     const int nblk = (int)((TrSyms + LA_B - 1) / LA_B);
     const Cx<R> *sy = a.symbols + (size_t)mode * a.sy_pitch;
+    const int nsweep = a.niter > 1 ? a.niter : 1;
 
     if (wave == 0) {
         // ============================================================ chain wave: lanes <-> the 64 steps of a block
@@ -319,27 +333,47 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
         }
         K.code0_re = K.R_re; K.code0_im = K.R_im;       // np.array_split(symbs, 2): NPART + 1 codes, then NPART partitions
         tab_fill<R, NPART>(K.tab, sy, 0, NPART + 1);
-        Cx<R> *errow = aerr + (size_t)mode * a.err_pitch + a.err_off;
-        Cx<R> ynext{0, 0};
         const GramPair<R> *grow = aG + lane;           // this lane's column of the Gram rows
         GramPair<R> ga[LA_PD], gb[LA_PD];               // two register sets: one is consumed while the other one loads
 #pragma unroll
         for (int u = 0; u < LA_PD; u++) ga[u] = grow[(size_t)u * LA_B];
+        // adaptive step: r = 1 / mu and mu itself (wave-uniform vector registers), the last step's c and |e|^2
+        R r_ad = ADAPT ? (R)1 / K.mu : (R)0, mu_ad = K.mu;
+        R cpr = 0, cpi = 0, sqp = 0;
+        R mu_vec = 0;                                   // lane j: the step size step j of the block ran with
+        Cx<R> sdat{0, 0};                               // data-aided: lane <-> the training symbol of its step
         // one LMS step in look-ahead form: c_j from lane j's (final) output, then both pending output sets move
-        auto step = [&](Cx<R> &y, Cx<R> &yn, const GramPair<R> &g, int j) {
-            const Cx<R> c = la_errfn<R, METHOD, NPART, true>(y, K);
-            const R cr = readlane(c.re, j), ci = readlane(c.im, j);        // c_j, wave-uniform
+        auto step = [&](Cx<R> &y, Cx<R> &yn, const GramPair<R> &g, int j, bool valid) {
+            R cr, ci;
+            if constexpr (ADAPT) {
+                const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K, sdat);
+                const R er = readlane(e.re, j), ei = readlane(e.im, j);        // e_j, wave-uniform
+                cr = mu_ad * er; ci = mu_ad * ei;
+                mu_vec = lane == j ? mu_ad : mu_vec;
+                const bool keep = cr * cpr > 0 && ci * cpi > 0;
+                r_ad += (keep || !valid) ? (R)0 : sqp;                         // (sqp = 0 in front of a sweep's first step: no adaptation there)
+                mu_ad = la_recip<R>(r_ad);
+                cpr = cr; cpi = ci; sqp = fma_(er, er, ei * ei);
+            } else {
+                const Cx<R> c = la_errfn<R, METHOD, NPART, true>(y, K, sdat);
+                cr = readlane(c.re, j); ci = readlane(c.im, j);                // c_j, wave-uniform
+            }
             // steps >= nvalid of a partial last block have all-zero Gram rows: they change nothing
             y.re = fma_(cr, g.cur.re, fma_(-ci, g.cur.im, y.re));
             y.im = fma_(cr, g.cur.im, fma_(ci, g.cur.re, y.im));
             yn.re = fma_(cr, g.next.re, fma_(-ci, g.next.im, yn.re));
             yn.im = fma_(cr, g.next.im, fma_(ci, g.next.re, yn.im));
         };
-        __syncthreads();                                               // barrier 0: Q_0 is ready
         unsigned long long t_wait = 0, t_work = 0, t_mark = __builtin_readcyclecounter();
+        for (int it = 0; it < nsweep; it++) {
+        Cx<R> *errow = aerr + (size_t)mode * a.err_pitch + a.err_off + (int64_t)it * TrSyms;
+        Cx<R> ynext{0, 0};
+        sqp = 0;                                                       // the reference adapts from the second step of a sweep on (:171)
+        __syncthreads();                                               // barrier 0 of the sweep: Q_0 is ready
         for (int k = 0; k < nblk; k++) {
             const int64_t s0 = (int64_t)k * LA_B;
             const int nvalid = (int)((TrSyms - s0) < LA_B ? (TrSyms - s0) : LA_B);
+            if constexpr (METHOD == QH_M_SBD_DATA) sdat = sy[s0 + lane < TrSyms ? s0 + lane : TrSyms - 1];
             Cx<R> y = ynext;
 #pragma unroll
             for (int h = 0; h < LA_NH; h++) {
@@ -348,20 +382,25 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
             }
             ynext = Cx<R>{0, 0};
             const GramPair<R> *gr = grow + (size_t)s0 * LA_B;
+            // rows behind this block: the next block's, or - last block of a sweep that is followed by another - block 0's again
+            const GramPair<R> *gnx = (k + 1 == nblk && it + 1 < nsweep) ? grow : gr + (size_t)LA_B * LA_B;
 #pragma unroll 1
             for (int j0 = 0; j0 < LA_B; j0 += 2 * LA_PD) {                  // keep this loop rolled: 16 steps per trip
 #pragma unroll
                 for (int u = 0; u < LA_PD; u++) gb[u] = gr[(size_t)(j0 + LA_PD + u) * LA_B];
 #pragma unroll
-                for (int u = 0; u < LA_PD; u++) step(y, ynext, ga[u], j0 + u);
+                for (int u = 0; u < LA_PD; u++) step(y, ynext, ga[u], j0 + u, j0 + u < nvalid);
+                const GramPair<R> *g2 = j0 + 2 * LA_PD < LA_B ? gr + (size_t)(j0 + 2 * LA_PD) * LA_B : gnx;
 #pragma unroll
-                for (int u = 0; u < LA_PD; u++) ga[u] = gr[(size_t)(j0 + 2 * LA_PD + u) * LA_B];   // may be the next block's rows
+                for (int u = 0; u < LA_PD; u++) ga[u] = g2[(size_t)u * LA_B];
 #pragma unroll
-                for (int u = 0; u < LA_PD; u++) step(y, ynext, gb[u], j0 + LA_PD + u);
+                for (int u = 0; u < LA_PD; u++) step(y, ynext, gb[u], j0 + LA_PD + u, j0 + LA_PD + u < nvalid);
             }
             // every lane now holds its final output: error trace + step-size-scaled errors for the tap update
-            const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K);
-            Cx<R> c = la_errfn<R, METHOD, NPART, true>(y, K);           // exactly the values the steps above used
+            const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K, sdat);
+            Cx<R> c;
+            if constexpr (ADAPT) c = Cx<R>{mu_vec * e.re, mu_vec * e.im};   // exactly the values the steps above used
+            else c = la_errfn<R, METHOD, NPART, true>(y, K, sdat);
             if (lane >= nvalid) c = Cx<R>{0, 0};
             if (lane < nvalid) stg(errow + s0 + lane, e);
             lds.cbuf[k & 1][lane] = c;
@@ -369,6 +408,8 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
             __syncthreads();                                           // barrier k+1
             if (a.prof) { const unsigned long long t = __builtin_readcyclecounter(); t_wait += t - t_mark; t_mark = t; }
         }
+        }   // sweeps
+        if constexpr (ADAPT) if (lane == 0) a.mu_out[ch * a.mu_cs + (int64_t)blockIdx.x * a.mu_ms] = mu_ad;
         if (a.prof && blockIdx.x == 0 && lane == 0) { a.prof[0] = t_work; a.prof[1] = t_wait; }
         return;
     }
@@ -470,11 +511,12 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
         lds.qbuf[h][kb & 1][lane] = live ? acc : Cx<R>{0, 0};
     };
 
+    unsigned long long t_wait = 0, t_upd = 0, t_pri = 0, t_mark = __builtin_readcyclecounter();
+    for (int it = 0; it < nsweep; it++) {
     stage_load(sp, 0);
     stage_store(sp, win_p);
     prior(0);
-    __syncthreads();                                                   // barrier 0
-    unsigned long long t_wait = 0, t_upd = 0, t_pri = 0, t_mark = __builtin_readcyclecounter();
+    __syncthreads();                                                   // barrier 0 of the sweep
     for (int k = 0; k < nblk; k++) {
 #ifndef LA_SKIP_HELPER
         if (k >= 1) stage_load(su, k - 1);                             // both windows' loads go out first ...
@@ -487,10 +529,11 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
         __syncthreads();                                               // barrier k+1
         if (a.prof) { const unsigned long long t = __builtin_readcyclecounter(); t_wait += t - t_mark; t_mark = t; }
     }
-    if (a.prof && blockIdx.x == 0 && lane == 0) { a.prof[4 * wave] = t_upd; a.prof[4 * wave + 1] = t_pri; a.prof[4 * wave + 2] = t_wait; }
     stage_load(su, nblk - 1);
     stage_store(su, win_u);
     update(nblk - 1);                                                  // taps at the end of the sweep
+    }   // sweeps
+    if (a.prof && blockIdx.x == 0 && lane == 0) { a.prof[4 * wave] = t_upd; a.prof[4 * wave + 1] = t_pri; a.prof[4 * wave + 2] = t_wait; }
     if (own) stg(wrow + fl, w);
 }
 
@@ -540,11 +583,13 @@ inline bool la_shape_ok(int nmodes, int ntaps, int os)
 
 inline bool la_supported(int method, int adaptive, int nmodes, int ntaps, int os, int64_t TrSyms, int64_t nsy)
 {
-    if (adaptive || TrSyms < 2 * LA_B) return false;
+    (void)adaptive;                       // the adaptive step runs on the chain wave (one mode per step size: the caller launches accordingly)
+    if (TrSyms < 2 * LA_B) return false;
     if (!la_shape_ok(nmodes, ntaps, os)) return false;
     switch (method) {
     case QH_M_CMA: case QH_M_SGNCMA: case QH_M_CMA2: case QH_M_MCMA: return true;
     case QH_M_RDE: case QH_M_MRDE: return nsy - (nsy + 1) / 2 >= 1 && nsy - (nsy + 1) / 2 <= LA_MAXPART;
+    case QH_M_SBD_DATA: return nsy >= TrSyms;              // one training symbol per step of the sweep
     default: return false;
     }
 }
@@ -555,11 +600,11 @@ template <typename R> static size_t la_lds_bytes(const LaArgs<R> &a)
     return sizeof(LaLds<R>) + (size_t)LA_NH * 2 * (a.nmodes * wpitch + 2) * sizeof(Cx<R>);
 }
 
-template <typename R, int METHOD> static int launch_la_parts(const LaArgs<R> &a, int npart)
+template <typename R, int METHOD, bool ADAPT> static int launch_la_parts(const LaArgs<R> &a, int npart)
 {
     dim3 grid(a.nsel, a.nch), block(64 * (1 + LA_NH));
     const size_t lds = la_lds_bytes(a);
-#define QH_LA_NP(N) case N: hipLaunchKernelGGL((train_la_kernel<R, METHOD, N>), grid, block, lds, g_stream, a); break;
+#define QH_LA_NP(N) case N: hipLaunchKernelGGL((train_la_kernel<R, METHOD, N, ADAPT>), grid, block, lds, g_stream, a); break;
     switch (npart) {
         QH_LA_NP(1) QH_LA_NP(2) QH_LA_NP(3) QH_LA_NP(4) QH_LA_NP(5) QH_LA_NP(6) QH_LA_NP(7) QH_LA_NP(8)
     default: set_error("look-ahead trainer: unsupported partition count"); return QH_ERR_ARG;
@@ -568,23 +613,30 @@ template <typename R, int METHOD> static int launch_la_parts(const LaArgs<R> &a,
     return QH_OK;
 }
 
-template <typename R> int launch_la(const LaArgs<R> &a)
+template <typename R, bool ADAPT> static int launch_la_t(const LaArgs<R> &a)
 {
     dim3 grid(a.nsel, a.nch), block(64 * (1 + LA_NH));
     const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
     const size_t lds = la_lds_bytes(a);
     int rc = QH_OK;
     switch (a.method) {
-    case QH_M_CMA: case QH_M_SGNCMA: hipLaunchKernelGGL((train_la_kernel<R, QH_M_CMA, 0>), grid, block, lds, g_stream, a); break;
-    case QH_M_CMA2: hipLaunchKernelGGL((train_la_kernel<R, QH_M_CMA2, 0>), grid, block, lds, g_stream, a); break;
-    case QH_M_MCMA: hipLaunchKernelGGL((train_la_kernel<R, QH_M_MCMA, 0>), grid, block, lds, g_stream, a); break;
-    case QH_M_RDE: rc = launch_la_parts<R, QH_M_RDE>(a, npart); break;
-    case QH_M_MRDE: rc = launch_la_parts<R, QH_M_MRDE>(a, npart); break;
+    case QH_M_CMA: case QH_M_SGNCMA: hipLaunchKernelGGL((train_la_kernel<R, QH_M_CMA, 0, ADAPT>), grid, block, lds, g_stream, a); break;
+    case QH_M_CMA2: hipLaunchKernelGGL((train_la_kernel<R, QH_M_CMA2, 0, ADAPT>), grid, block, lds, g_stream, a); break;
+    case QH_M_MCMA: hipLaunchKernelGGL((train_la_kernel<R, QH_M_MCMA, 0, ADAPT>), grid, block, lds, g_stream, a); break;
+    case QH_M_RDE: rc = launch_la_parts<R, QH_M_RDE, ADAPT>(a, npart); break;
+    case QH_M_MRDE: rc = launch_la_parts<R, QH_M_MRDE, ADAPT>(a, npart); break;
+    case QH_M_SBD_DATA: hipLaunchKernelGGL((train_la_kernel<R, QH_M_SBD_DATA, 0, ADAPT>), grid, block, lds, g_stream, a); break;
     default: return QH_ERR_METHOD;
     }
     if (rc) return rc;
     QH_HIP(hipGetLastError());
     return QH_OK;
+}
+
+// adaptive: one step size per workgroup (mu in / mu_out); the caller launches one mode at a time (nsel = 1) when mu is carried from mode to mode
+template <typename R> int launch_la(const LaArgs<R> &a, bool adaptive = false)
+{
+    return adaptive ? launch_la_t<R, true>(a) : launch_la_t<R, false>(a);
 }
 
 }  // namespace qh

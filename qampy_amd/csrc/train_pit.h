@@ -2210,7 +2210,7 @@ int pit_prepare(const void *E, int nmodes, int64_t L, int64_t TrSyms, int os, co
         if (pf && pf[0] == 'b') seg_ok = false;
         else if (!(pf && pf[0] == 's') && (int64_t)S * nsel < 512) seg_ok = false;
     }
-    const bool la_ok = force[0] != 'd' && la_supported(method, 0, nmodes, ntaps, os, seg_len, nsy);
+    const bool la_ok = force[0] != 'd' && method != QH_M_SBD_DATA && la_supported(method, 0, nmodes, ntaps, os, seg_len, nsy);
     const bool use_bi = bi_ok && (decision || !la_ok || force[0] == 'i');
     const bool block_form = use_bi || la_ok;
     QH_REQUIRE(seg_ok && block_form && !decision && method != QH_M_SBD_DATA && la_shape_ok(nmodes, ntaps, os),
@@ -2400,11 +2400,13 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     const bool decision = method == QH_M_SBD || method == QH_M_MDDMA || method == QH_M_DD;
     void *dd_table = nullptr;
     int dd_npart = -1;
+    bool dd_general = false;
     bool seg_ok = force[0] == 0 && seg_supported(method, nmodes, ntaps, os, nsy, sizeof(Cx<R>), nsel);
     if ((bi_ok || seg_ok) && decision) {
         if ((rc = slicer_tables<R>(symbols, nmodes, nsy, modes, nsel, &dd_table, &dd_npart))) return rc;
         const bool sq = dd_npart == 1 || dd_npart == 3 || dd_npart == 7 || dd_npart == 15;
-        bi_ok = bi_ok && sq; seg_ok = seg_ok && sq;
+        dd_general = bi_ok && !sq && bi_general_ok(nmodes, ntaps, os, nsy, sizeof(Cx<R>));        // crosses: block form with the alphabet scan
+        bi_ok = bi_ok && (sq || dd_general); seg_ok = seg_ok && sq;
     }
     // Form of the passes.  Few chains: the latency forms (look-ahead / block-iterative, one workgroup per chain).  Many
     // chains: the throughput form (train_seg.h: 16 lanes per chain, no Gram table).  QAMPY_HIP_PIT_FORM = segment | block forces.
@@ -2433,7 +2435,7 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         QH_REQUIRE(own_first >= 0 && own_count >= 0 && own_first + own_count <= sg.S, "train_equaliser: owned segments outside the segment grid");
         QH_REQUIRE(Niter == 1, "train_equaliser: a capture split over processes is trained in one sweep");
     }
-    const bool la_ok = force[0] != 'd' && la_supported(method, 0, nmodes, ntaps, os, sg.len, nsy);
+    const bool la_ok = force[0] != 'd' && method != QH_M_SBD_DATA && la_supported(method, 0, nmodes, ntaps, os, sg.len, nsy);
     const bool partitioned = method == QH_M_RDE || method == QH_M_MRDE;
     (void)partitioned;
     // With the chip full the stage is bound by instruction issue, not by one chain's latency: the look-ahead form (~25
@@ -2597,7 +2599,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     la.nmodes = nmodes; la.ntaps = ntaps; la.os = os; la.nsel = nsel; la.method = method;
     la.E_cs = 0; la.err_cs = 0; la.G_cs = 0; la.wx_cs = (int64_t)wset;
     for (int j = 0; j < 16; j++) la.modes[j] = j < nsel ? modes[j] : 0;
-    if ((use_bi || seg_form) && decision) { la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV; }
+    la.dd_general = use_bi && !seg_form && dd_general;
+    if ((use_bi || seg_form) && decision && !la.dd_general) { la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV; }
     la.prof = nullptr; la.seg = 0; la.seg_extra = 0; la.seg_tail = 0; la.skip = nullptr; la.niter = 1;
     TrainArgs<R> ta;
     ta.E = (const Cx<R> *)E; ta.symbols = (const Cx<R> *)symbols; ta.err = (Cx<R> *)err; ta.mu = mu_dev;

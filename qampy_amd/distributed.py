@@ -36,16 +36,18 @@ class SplitCaptureReceiver(ResidentReceiver):
         if comm is None:
             raise ValueError("SplitCaptureReceiver needs the process group (qampy_amd.comm.Comm)")
         kw["tier"] = "b"
-        if any(kw.get("adaptive_stepsize", (False, False))):
+        super().__init__(*args, **kw)
+        if any(self.adaptive):                         # (however it was passed: by keyword or by position)
             raise ValueError("split capture: the adaptive step is solved one output mode at a time inside one process (csrc/train_pit.h); "
                              "use a fixed step size, or a ResidentReceiver per rank")
-        super().__init__(*args, **kw)
         self.comm = comm
         self.rank, self.world = comm.rank, comm.world
         self.exchanged_bytes = 0
         self.exchanges = 0
         from .core.equalisation import hip_equalisation as _k
         for s_, o in enumerate(self.pit):              # the grid the library will really use (it keeps >= 4 blocks per segment)
+            if int(o["segments"]) == 0:                # "automatic": the library's own count for this sweep, as it would pick it
+                o["segments"] = _k.pit_auto_segments(self.TrSyms[s_], float(self.mu0[s_]), self.modes.size, cold=bool(o.get("acquire")))
             o["segments"] = _k.pit_effective_segments(o["segments"], self.TrSyms[s_])
             if int(o["segments"]) < self.world:
                 raise ValueError("split capture: stage %d has %d segments, too few to be shared by %d ranks" % (s_, int(o["segments"]), self.world))

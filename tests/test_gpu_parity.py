@@ -265,7 +265,7 @@ def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, 
     """The three exact trainers (look-ahead: train_la.h, block-iterative: train_bi.h, direct: train_impl.h) and the oracle
     agree to rounding, including a partial last block, several sweeps, a mode subset and shapes only some of them take
     (122 taps: no look-ahead kernel, the forced form then falls through to the next one).  Decision-directed functions run
-    block-iterative on square alphabets (per-axis slicer tables) and direct on the others (32-QAM cross)."""
+    block-iterative: per-axis slicer tables on square alphabets, a scan of the alphabet on the others (32-QAM cross)."""
     nsym = 5000 + 37
     sig = synth.make_capture(M, nsym, nmodes=nmodes, snr_db=28, theta=np.pi / 5.6 if nmodes == 2 else None, dgd=30e-12,
                              seed=99, dtype=CT[dn])
@@ -304,7 +304,8 @@ def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, 
 @pytest.mark.parametrize("dn", ["c64", "c128"])
 def test_adaptive_step_forms_agree(monkeypatch, method, M, ntaps, nmodes, dn):
     """adapt_step (pythran_equalisation.py:12-16, :171-172) in the block-iterative form (1/mu as a prefix sum inside the
-    sweeps) against the direct form and the oracle: taps, errors and the final mu, which is carried over sweeps and modes."""
+    sweeps) and in the look-ahead form (1/mu carried by the chain wave, all sweeps in one launch) against the direct form and the
+    oracle: taps, errors and the final mu, which is carried over sweeps and modes."""
     nsym = 3000 + 11
     sig = synth.make_capture(M, nsym, nmodes=nmodes, snr_db=26, theta=np.pi / 5.6 if nmodes == 2 else None, dgd=30e-12,
                              seed=123, dtype=CT[dn])
@@ -322,9 +323,13 @@ def test_adaptive_step_forms_agree(monkeypatch, method, M, ntaps, nmodes, dn):
     ed, wd, mud = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, True, sy, method)
     monkeypatch.setenv("QAMPY_HIP_TRAINER", "iterative")
     ei, wi, mui = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, True, sy, method)
+    monkeypatch.setenv("QAMPY_HIP_TRAINER", "lookahead")     # round 5: the adaptive step on the look-ahead chain (blind methods; others fall through)
+    el, wl, mul = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, True, sy, method)
+    monkeypatch.delenv("QAMPY_HIP_TRAINER")                  # and whatever the library picks by itself
+    ea, wa, mua = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, True, sy, method)
     assert muo < 0.95 * mu                                   # the step size really moved
     t = dict(rtol=1e-9, atol=1e-11) if dn == "c128" else dict(rtol=3e-4, atol=3e-5)
-    for w, e, m in ((wd, ed, mud), (wi, ei, mui)):
+    for w, e, m in ((wd, ed, mud), (wi, ei, mui), (wl, el, mul), (wa, ea, mua)):
         np.testing.assert_allclose(w, wo, **t)
         np.testing.assert_allclose(e, eo, rtol=t["rtol"], atol=t["atol"] * 5)
         np.testing.assert_allclose(m, muo, rtol=1e-9 if dn == "c128" else 3e-4)
