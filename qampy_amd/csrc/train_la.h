@@ -168,8 +168,9 @@ __device__ __forceinline__ Cx<R> la_errfn(Cx<R> y, const LaConst<R, NPART> &k, C
     const v2 yy = {y.re, y.im};
     v2 e;
     if constexpr (METHOD == QH_M_CMA || METHOD == QH_M_SGNCMA) {
-        const R t = fma_(y.re, y.re, y.im * y.im);
-        const R d = SCALE ? fma_(-k.mu, t, k.mu * k.R_re) : k.R_re - t;       // (R - |y|^2) [* mu]
+        R d;
+        if constexpr (SCALE) { const R t = fma_(y.re, y.re, y.im * y.im); d = fma_(-k.mu, t, k.mu * k.R_re); }     // (R - |y|^2) mu
+        else d = fma_(-y.im, y.im, fma_(-y.re, y.re, k.R_re));                  // R - |y|^2 in two instructions (the adaptive chain counts them)
         e = yy * d;
     } else if constexpr (METHOD == QH_M_CMA2) {
         const R x2r = fma_(y.re, y.re, -(y.im * y.im)), x2i = (R)2 * y.re * y.im;
@@ -289,6 +290,8 @@ template <typename R> struct LaLds {
 // the sign test runs on c = mu e (mu > 0: same signs, and c is at hand in vector registers).  One mode per step size: the host launches the modes
 // in turn (adaptive = 1, mu carried) or hands every mode its own (adaptive = 2), as for the block-iterative form.  ~12 instructions per step more
 // than the fixed step.  niter > 1: the reference's Niter loop inside the launch - taps stay in the helpers' registers, the step size on the chain wave.
+struct LaYes { static constexpr bool value = true; };
+struct LaNo { static constexpr bool value = false; };
 template <typename R> __device__ __forceinline__ R la_recip(R r)
 {
     if constexpr (sizeof(R) == 4) return __builtin_amdgcn_rcpf(r);      // 1 ulp; mu is re-derived from the exactly accumulated r every step
@@ -333,25 +336,30 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
         }
         K.code0_re = K.R_re; K.code0_im = K.R_im;       // np.array_split(symbs, 2): NPART + 1 codes, then NPART partitions
         tab_fill<R, NPART>(K.tab, sy, 0, NPART + 1);
-        const GramPair<R> *grow = aG + lane;           // this lane's column of the Gram rows
+        const GramPair<R> *grow = aG;                  // Gram rows: uniform base + lane (scalar base + 32-bit lane offset: no vector address arithmetic per load)
         GramPair<R> ga[LA_PD], gb[LA_PD];               // two register sets: one is consumed while the other one loads
 #pragma unroll
-        for (int u = 0; u < LA_PD; u++) ga[u] = grow[(size_t)u * LA_B];
+        for (int u = 0; u < LA_PD; u++) ga[u] = grow[u * LA_B + lane];
         // adaptive step: r = 1 / mu and mu itself (wave-uniform vector registers), the last step's c and |e|^2
         R r_ad = ADAPT ? (R)1 / K.mu : (R)0, mu_ad = K.mu;
         R cpr = 0, cpi = 0, sqp = 0;
         R mu_vec = 0;                                   // lane j: the step size step j of the block ran with
         Cx<R> sdat{0, 0};                               // data-aided: lane <-> the training symbol of its step
         // one LMS step in look-ahead form: c_j from lane j's (final) output, then both pending output sets move
-        auto step = [&](Cx<R> &y, Cx<R> &yn, const GramPair<R> &g, int j, bool valid) {
+        // (CHECK: only the partial last block of a sweep holds steps past TrSyms - the chain wave pays ~7 cycles for EVERY instruction it issues,
+        // scalar ones included, so full blocks run without the test)
+        auto step = [&](Cx<R> &y, Cx<R> &yn, const GramPair<R> &g, int j, auto CHECK, int nvalid) {
             R cr, ci;
             if constexpr (ADAPT) {
                 const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K, sdat);
                 const R er = readlane(e.re, j), ei = readlane(e.im, j);        // e_j, wave-uniform
                 cr = mu_ad * er; ci = mu_ad * ei;
                 mu_vec = lane == j ? mu_ad : mu_vec;
-                const bool keep = cr * cpr > 0 && ci * cpi > 0;
-                r_ad += (keep || !valid) ? (R)0 : sqp;                         // (sqp = 0 in front of a sweep's first step: no adaptation there)
+                // both products positive <=> the smaller one is (one compare instead of two and a scalar AND; NaN: the run has diverged either way)
+                const R pr = cr * cpr, pi = ci * cpi;
+                bool keep = min_(pr, pi) > 0;
+                if constexpr (decltype(CHECK)::value) keep = keep || j >= nvalid;
+                r_ad += keep ? (R)0 : sqp;                                     // (sqp = 0 in front of a sweep's first step: no adaptation there)
                 mu_ad = la_recip<R>(r_ad);
                 cpr = cr; cpi = ci; sqp = fma_(er, er, ei * ei);
             } else {
@@ -359,10 +367,26 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
                 cr = readlane(c.re, j); ci = readlane(c.im, j);                // c_j, wave-uniform
             }
             // steps >= nvalid of a partial last block have all-zero Gram rows: they change nothing
-            y.re = fma_(cr, g.cur.re, fma_(-ci, g.cur.im, y.re));
-            y.im = fma_(cr, g.cur.im, fma_(ci, g.cur.re, y.im));
-            yn.re = fma_(cr, g.next.re, fma_(-ci, g.next.im, yn.re));
-            yn.im = fma_(cr, g.next.im, fma_(ci, g.next.re, yn.im));
+            if constexpr (ADAPT && sizeof(R) == 4) {
+                // c sits in a vector register pair here: two packed FMAs per output set with the swizzles in the operand modifiers (hipcc builds
+                // (-ci, ci) with two extra instructions per step, and the chain wave pays ~7 cycles for every instruction it issues)
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 c2 = {cr, ci};
+                auto cmad = [&](Cx<R> &acc, const Cx<R> &gg) {
+                    f2 a2 = {acc.re, acc.im};
+                    const f2 g2 = {gg.re, gg.im};
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(a2) : "v"(c2), "v"(g2));     // (-ci g.im, ci g.re) + acc
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a2) : "v"(c2), "v"(g2));                                  // (cr g.re, cr g.im) + that
+                    acc.re = a2.x; acc.im = a2.y;
+                };
+                cmad(y, g.cur);
+                cmad(yn, g.next);
+            } else {
+                y.re = fma_(cr, g.cur.re, fma_(-ci, g.cur.im, y.re));
+                y.im = fma_(cr, g.cur.im, fma_(ci, g.cur.re, y.im));
+                yn.re = fma_(cr, g.next.re, fma_(-ci, g.next.im, yn.re));
+                yn.im = fma_(cr, g.next.im, fma_(ci, g.next.re, yn.im));
+            }
         };
         unsigned long long t_wait = 0, t_work = 0, t_mark = __builtin_readcyclecounter();
         for (int it = 0; it < nsweep; it++) {
@@ -384,18 +408,21 @@ __global__ void __launch_bounds__(64 * (1 + LA_NH)) train_la_kernel(LaArgs<R> a)
             const GramPair<R> *gr = grow + (size_t)s0 * LA_B;
             // rows behind this block: the next block's, or - last block of a sweep that is followed by another - block 0's again
             const GramPair<R> *gnx = (k + 1 == nblk && it + 1 < nsweep) ? grow : gr + (size_t)LA_B * LA_B;
+            auto block = [&](auto CHECK) {
 #pragma unroll 1
-            for (int j0 = 0; j0 < LA_B; j0 += 2 * LA_PD) {                  // keep this loop rolled: 16 steps per trip
+                for (int j0 = 0; j0 < LA_B; j0 += 2 * LA_PD) {              // keep this loop rolled: 16 steps per trip
 #pragma unroll
-                for (int u = 0; u < LA_PD; u++) gb[u] = gr[(size_t)(j0 + LA_PD + u) * LA_B];
+                    for (int u = 0; u < LA_PD; u++) gb[u] = (gr + (size_t)(j0 + LA_PD) * LA_B)[u * LA_B + lane];
 #pragma unroll
-                for (int u = 0; u < LA_PD; u++) step(y, ynext, ga[u], j0 + u, j0 + u < nvalid);
-                const GramPair<R> *g2 = j0 + 2 * LA_PD < LA_B ? gr + (size_t)(j0 + 2 * LA_PD) * LA_B : gnx;
+                    for (int u = 0; u < LA_PD; u++) step(y, ynext, ga[u], j0 + u, CHECK, nvalid);
+                    const GramPair<R> *g2 = j0 + 2 * LA_PD < LA_B ? gr + (size_t)(j0 + 2 * LA_PD) * LA_B : gnx;
 #pragma unroll
-                for (int u = 0; u < LA_PD; u++) ga[u] = g2[(size_t)u * LA_B];
+                    for (int u = 0; u < LA_PD; u++) ga[u] = g2[u * LA_B + lane];
 #pragma unroll
-                for (int u = 0; u < LA_PD; u++) step(y, ynext, gb[u], j0 + LA_PD + u, j0 + LA_PD + u < nvalid);
-            }
+                    for (int u = 0; u < LA_PD; u++) step(y, ynext, gb[u], j0 + LA_PD + u, CHECK, nvalid);
+                }
+            };
+            if (ADAPT && nvalid < LA_B) block(LaYes{}); else block(LaNo{});
             // every lane now holds its final output: error trace + step-size-scaled errors for the tap update
             const Cx<R> e = la_errfn<R, METHOD, NPART, false>(y, K, sdat);
             Cx<R> c;
