@@ -573,9 +573,11 @@ template <typename R> int gram_cur_build(const void *E, int nmodes, int64_t L, i
     const int64_t nblk = (TrSyms + LA_B - 1) / LA_B;
     const size_t lds = (size_t)nmodes * ((LA_B - 1) * os + ntaps) * sizeof(Cx<R>);
     QH_REQUIRE(lds <= 64 * 1024, "gram: nmodes*(63*os+ntaps) samples exceed the LDS tile");
-    for (int c = 0; c < nch && nblk > 0; c++)
-        hipLaunchKernelGGL((gram_slide_kernel<R, false>), dim3((unsigned)nblk), dim3(256), lds, g_stream, (const Cx<R> *)E + (size_t)c * ch_stride,
-                           nmodes, L, Lp, os, ntaps, TrSyms, (Cx<R> *)((char *)G + bytes * (size_t)c));
+    for (int c0 = 0; c0 < nch && nblk > 0; c0 += 65535) {          // one launch for the bank (blockIdx.y = channel; grid.y limit)
+        const int nc = nch - c0 < 65535 ? nch - c0 : 65535;
+        hipLaunchKernelGGL((gram_slide_kernel<R, false>), dim3((unsigned)nblk, (unsigned)nc), dim3(256), lds, g_stream, (const Cx<R> *)E + (size_t)c0 * ch_stride,
+                           nmodes, L, Lp, os, ntaps, TrSyms, (Cx<R> *)((char *)G + bytes * (size_t)c0), ch_stride, (int64_t)(bytes / sizeof(Cx<R>)));
+    }
     QH_HIP(hipGetLastError());
     *gram = G;
     return QH_OK;

@@ -489,6 +489,12 @@ template <typename R> __global__ void spread_kernel(R *dst, const R *src, int n,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) dst[i] = src[i / n];
 }
+// dst[i] = src[i mod n]: one set of start taps -> one per window / channel
+template <typename T> __global__ void tile_kernel(T *dst, const T *src, unsigned n, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) dst[i] = src[i % n];
+}
 template <typename R> __global__ void gather_kernel(R *dst, const R *src, int n, int nch)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -757,13 +763,17 @@ int train_windows_host(const void *E, int nmodes, int64_t L, const int64_t *win_
     if ((rc = de.alloc((size_t)nwin * esz * cs))) return rc;
     if ((rc = dmo.alloc((size_t)nwin * sizeof(R)))) return rc;
     QH_HIP(hipMemsetAsync(de.p, 0, de.n ? de.n : 1, g_stream));
-    for (int v = 0; v < nwin; v++)                       // every window starts from (and keeps, for unselected modes) the initial taps
-        QH_HIP(hipMemcpyAsync((char *)dwo.p + (size_t)v * wsz * cs, dw.p, wsz * cs, hipMemcpyDeviceToDevice, g_stream));
+    // every window starts from (and keeps, for unselected modes) the initial taps (one launch: hundreds of small copies were ~1 ms of the frame search)
+    hipLaunchKernelGGL((tile_kernel<Cx<R>>), dim3((unsigned)(((size_t)nwin * wsz + 255) / 256)), dim3(256), 0, g_stream, (Cx<R> *)dwo.p, (const Cx<R> *)dw.p, (unsigned)wsz, (size_t)nwin * wsz);
     // equally spaced windows are the channels of a bank whose captures overlap: a FEW of them go to the latency forms of the
     // trainer (3 x fewer cycles per step on the critical path).  Hundreds of windows fill the chip either way, and then the direct
     // form - one wave per chain instead of four or eight - is the cheaper one: 260 windows x 2 modes of the config-5 frame search
     // take 3.4 ms direct, 5.6 ms block-iterative (measured), so it keeps them, as it does irregular starts and the other methods.
-    bool strided = (int64_t)nwin * nsel <= 64 && (nwin == 1 || win_start[1] > win_start[0]);
+    // (round 5: the look-ahead chain with the adaptive step and all sweeps in one launch - 65 ns per step against the direct form's 165 - takes
+    // the windows of the frame search whenever it is the form train_dev would pick and the Gram tables of all windows fit the scratch budget)
+    const bool la_pick = la_supported(method, adaptive ? 1 : 0, nmodes, ntaps, os, TrSyms, nsy) && trainer_force()[0] != 'i' && trainer_force()[0] != 'd' &&
+                         (adaptive || !(method == QH_M_RDE || method == QH_M_MRDE)) && nwin <= 1024 && (size_t)nwin * gram_bytes<R>(TrSyms) <= gram_budget();
+    bool strided = ((int64_t)nwin * nsel <= 64 || la_pick) && (nwin == 1 || win_start[1] > win_start[0]);
     for (int v = 2; v < nwin && strided; v++) strided = win_start[v] - win_start[v - 1] == win_start[1] - win_start[0];
     if (TrSyms > 0 && Niter > 0 && strided && block_forms_ok<R>(method, adaptive ? 1 : 0, nmodes, ntaps, os, TrSyms, nsy)) {
         hipLaunchKernelGGL((spread_kernel<R>), dim3((unsigned)((nwin + 63) / 64)), dim3(64), 0, g_stream, (R *)dmo.p, (const R *)dmu.p, nwin, nwin);

@@ -41,9 +41,11 @@ __host__ __device__ constexpr int gram_tri_row(int j) { return j * (LA_B - 1) - 
 // Rounding: a slid sum carries at most 31 x 2 os extra additions; the trainers see Gram terms good to a few 1e-7 relative
 // either way (and every form of the trainer is compared with the oracle on its own).
 template <typename R, bool PAIR>
-__global__ void __launch_bounds__(256) gram_slide_kernel(const Cx<R> *E, int nmodes, int64_t L, int64_t Lp, int os, int ntaps, int64_t TrSyms, Cx<R> *G)
+__global__ void __launch_bounds__(256) gram_slide_kernel(const Cx<R> *E, int nmodes, int64_t L, int64_t Lp, int os, int ntaps, int64_t TrSyms, Cx<R> *G,
+                                                         int64_t e_cs = 0, int64_t g_cs = 0)
 {
     QH_WAVE_FIRST();
+    E += (int64_t)blockIdx.y * e_cs; G += (int64_t)blockIdx.y * g_cs;          // channel bank: one table per channel, all in ONE launch (blockIdx.y)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Cx<R> *tile = reinterpret_cast<Cx<R> *>(smem);
     constexpr int NT = PAIR ? 2 * LA_B : LA_B;                    // targets reachable from a block: this block (+ the next one)
@@ -586,12 +588,12 @@ template <typename R> int gram_build(const void *E, int nmodes, int64_t L, int o
     const int64_t nblk = (TrSyms + LA_B - 1) / LA_B;
     const size_t lds = (size_t)nmodes * ((2 * LA_B - 1) * os + ntaps) * sizeof(Cx<R>);
     QH_REQUIRE(lds <= 64 * 1024, "gram: nmodes*(127*os+ntaps) samples exceed the LDS tile");
-    for (int c = 0; c < nch; c++) {
-        char *G = (char *)G0 + bytes * (size_t)c;
-        // rows past the last block are read by the prefetch queue only: keep them zero
-        QH_HIP(hipMemsetAsync(G + (size_t)nblk * LA_B * LA_B * sizeof(GramPair<R>), 0, (size_t)2 * LA_PD * LA_B * sizeof(GramPair<R>), g_stream));
-        if (nblk > 0) hipLaunchKernelGGL((gram_slide_kernel<R, true>), dim3((unsigned)nblk), dim3(256), lds, g_stream,
-                                         (const Cx<R> *)E + (size_t)c * ch_stride, nmodes, L, Lp, os, ntaps, TrSyms, (Cx<R> *)G);
+    // rows past the last block are read by the prefetch queue only: keep them zero (one strided fill for the whole bank)
+    QH_HIP(hipMemset2DAsync((char *)G0 + (size_t)nblk * LA_B * LA_B * sizeof(GramPair<R>), bytes, 0, (size_t)2 * LA_PD * LA_B * sizeof(GramPair<R>), (size_t)nch, g_stream));
+    for (int c0 = 0; c0 < nch && nblk > 0; c0 += 65535) {          // (grid.y limit)
+        const int nc = nch - c0 < 65535 ? nch - c0 : 65535;
+        hipLaunchKernelGGL((gram_slide_kernel<R, true>), dim3((unsigned)nblk, (unsigned)nc), dim3(256), lds, g_stream, (const Cx<R> *)E + (size_t)c0 * ch_stride, nmodes, L, Lp,
+                           os, ntaps, TrSyms, (Cx<R> *)((char *)G0 + bytes * (size_t)c0), ch_stride, (int64_t)(bytes / sizeof(Cx<R>)));
     }
     QH_HIP(hipGetLastError());
     *gram = G0;
