@@ -18,12 +18,14 @@
 #include <stdlib.h>
 #include "train_la.h"
 
+#include <atomic>
 namespace qh {
 
 constexpr int BI_W = 8;                  // wavefronts per workgroup (2 per SIMD: more only queue up behind the SIMD's issue port)
 constexpr int BI_JW = LA_B / BI_W;       // steps owned by a wave
 constexpr int BI_PAD = BI_W + 1;         // row pitch of the [i][w] exchange buffers (bank-conflict padding)
 constexpr int BI_MAXTAPS = 128;          // taps per output mode (2 per lane in the tap-update layout)
+constexpr size_t BI_LDS_MAX = 160 * 1024 - 256;   // LDS a workgroup of this kernel may ask for (the CU's 160 KiB; above 64 KiB the launcher sets the attribute)
 
 // sum over groups of BI_W consecutive lanes; every lane of a group gets the group's total (fixed order -> deterministic)
 __device__ __forceinline__ void group_csum(float &re, float &im)
@@ -597,15 +599,16 @@ inline bool bi_shape_ok(int nmodes, int ntaps, int os, size_t elem)
     if ((force[0] == 'd' || force[0] == 'l')) return false;      // "direct" / "lookahead": A/B measurements, tests
     if (nmodes * ntaps > BI_MAXTAPS) return false;
     const int wpitch = ((LA_B - 1) * os + ntaps + 1) & ~1;
-    return (size_t)2 * LA_B * BI_PAD * (elem + 16) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch) * elem + 2 * BI_W * 2 * elem <= 64 * 1024;
+    return (size_t)2 * LA_B * BI_PAD * (elem + 16) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch) * elem + 2 * BI_W * 2 * elem <= BI_LDS_MAX;
 }
 
 // decision-directed methods on an alphabet without per-axis slicer (bi_nearest_general): the alphabet rides in LDS behind the kernel's other arrays
 inline bool bi_general_ok(int nmodes, int ntaps, int os, int64_t nsy, size_t elem)
 {
     if (nsy < 1 || nsy > BI_GEN_MAXSYM || !bi_shape_ok(nmodes, ntaps, os, elem)) return false;
+    if (elem > 8 && nsy > 64) return false;           // double precision, > 64 symbols: the direct form's in-register search is as fast (measured 32.5 against 35 ms, 128-QAM)
     const int wpitch = ((LA_B - 1) * os + ntaps + 1) & ~1;
-    return (size_t)2 * LA_B * BI_PAD * (elem + 16) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch + (size_t)nsy) * elem + 2 * BI_W * 2 * elem <= 64 * 1024;
+    return (size_t)2 * LA_B * BI_PAD * (elem + 16) + ((size_t)BI_MAXTAPS * BI_PAD + BI_MAXTAPS + (size_t)2 * nmodes * wpitch + (size_t)nsy) * elem + 2 * BI_W * 2 * elem <= BI_LDS_MAX;
 }
 
 inline bool bi_supported(int method, int adaptive, int nmodes, int ntaps, int os, int64_t TrSyms, int64_t nsy, size_t elem)
@@ -622,13 +625,27 @@ inline bool bi_supported(int method, int adaptive, int nmodes, int ntaps, int os
     }
 }
 
+// One launch of the kernel; shapes whose arrays need more than the 64 KiB a workgroup gets by default (complex128 with two or more modes) ask for the
+// CU's whole LDS once per kernel instance (160 KiB on gfx950; one workgroup per CU then, which is what a latency chain wants anyway).
+template <typename R, int METHOD, int NPART, bool ADAPT> static void bi_launch(dim3 grid, dim3 block, size_t lds, const LaArgs<R> &a)
+{
+    if (lds > 64 * 1024) {
+        static std::atomic<bool> allowed{false};
+        if (!allowed.load(std::memory_order_acquire)) {
+            (void)hipFuncSetAttribute((const void *)train_bi_kernel<R, METHOD, NPART, ADAPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BI_LDS_MAX);
+            allowed.store(true, std::memory_order_release);
+        }
+    }
+    hipLaunchKernelGGL((train_bi_kernel<R, METHOD, NPART, ADAPT>), grid, block, lds, g_stream, a);
+}
+
 template <typename R, int METHOD, bool ADAPT> static int launch_bi_dd(const LaArgs<R> &a, int npart, size_t lds)
 {
     dim3 grid(a.nsel, a.nch), block(BI_NT);
-#define QH_BI_DD(N) case N: hipLaunchKernelGGL((train_bi_kernel<R, METHOD, N, ADAPT>), grid, block, lds, g_stream, a); break;
+#define QH_BI_DD(N) case N: bi_launch<R, METHOD, N, ADAPT>(grid, block, lds, a); break;
     if (a.dd_general) {         // any alphabet: the symbols themselves in LDS (bi_nearest_general)
         if (a.nsy < 1 || a.nsy > BI_GEN_MAXSYM) { set_error("block-iterative trainer: alphabet too large for the general decision"); return QH_ERR_ARG; }
-        hipLaunchKernelGGL((train_bi_kernel<R, METHOD, 0, ADAPT>), grid, block, lds + (size_t)a.nsy * sizeof(Cx<R>), g_stream, a);
+        bi_launch<R, METHOD, 0, ADAPT>(grid, block, lds + (size_t)a.nsy * sizeof(Cx<R>), a);
         return QH_OK;
     }
     switch (npart) {            // 4-, 16-, 64-, 256-QAM
@@ -642,7 +659,7 @@ template <typename R, int METHOD, bool ADAPT> static int launch_bi_dd(const LaAr
 template <typename R, int METHOD, bool ADAPT> static int launch_bi_parts(const LaArgs<R> &a, int npart, size_t lds)
 {
     dim3 grid(a.nsel, a.nch), block(BI_NT);
-#define QH_BI_NP(N) case N: hipLaunchKernelGGL((train_bi_kernel<R, METHOD, N, ADAPT>), grid, block, lds, g_stream, a); break;
+#define QH_BI_NP(N) case N: bi_launch<R, METHOD, N, ADAPT>(grid, block, lds, a); break;
     switch (npart) {
         QH_BI_NP(1) QH_BI_NP(2) QH_BI_NP(3) QH_BI_NP(4) QH_BI_NP(5) QH_BI_NP(6) QH_BI_NP(7) QH_BI_NP(8)
     default: set_error("block-iterative trainer: unsupported partition count"); return QH_ERR_ARG;
@@ -658,15 +675,15 @@ template <typename R, bool ADAPT> static int launch_bi_t(const LaArgs<R> &a)
     const size_t lds = bi_lds_bytes<R>(a.nmodes, a.ntaps, a.os);
     int rc = QH_OK;
     switch (a.method) {
-    case QH_M_CMA: case QH_M_SGNCMA: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_CMA, 0, ADAPT>), grid, block, lds, g_stream, a); break;
-    case QH_M_CMA2: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_CMA2, 0, ADAPT>), grid, block, lds, g_stream, a); break;
-    case QH_M_MCMA: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_MCMA, 0, ADAPT>), grid, block, lds, g_stream, a); break;
+    case QH_M_CMA: case QH_M_SGNCMA: bi_launch<R, QH_M_CMA, 0, ADAPT>(grid, block, lds, a); break;
+    case QH_M_CMA2: bi_launch<R, QH_M_CMA2, 0, ADAPT>(grid, block, lds, a); break;
+    case QH_M_MCMA: bi_launch<R, QH_M_MCMA, 0, ADAPT>(grid, block, lds, a); break;
     case QH_M_RDE: rc = launch_bi_parts<R, QH_M_RDE, ADAPT>(a, npart, lds); break;
     case QH_M_MRDE: rc = launch_bi_parts<R, QH_M_MRDE, ADAPT>(a, npart, lds); break;
     case QH_M_SBD: rc = launch_bi_dd<R, QH_M_SBD, ADAPT>(a, npart, lds); break;
     case QH_M_MDDMA: rc = launch_bi_dd<R, QH_M_MDDMA, ADAPT>(a, npart, lds); break;
     case QH_M_DD: rc = launch_bi_dd<R, QH_M_DD, ADAPT>(a, npart, lds); break;
-    case QH_M_SBD_DATA: hipLaunchKernelGGL((train_bi_kernel<R, QH_M_SBD_DATA, 0, ADAPT>), grid, block, lds, g_stream, a); break;
+    case QH_M_SBD_DATA: bi_launch<R, QH_M_SBD_DATA, 0, ADAPT>(grid, block, lds, a); break;
     default: return QH_ERR_METHOD;
     }
     if (rc) return rc;
