@@ -720,7 +720,7 @@ def run_pair(cfg, sig, nsym, steps, warmup, barrier_sync, pit, exact_steps, tol_
         from qampy_amd import _lib as _l
         _l.call("qh_set_pit_timing", 2)
         try:
-            _, _, pass_all, _ = timed_steps(rx, max(2, min(steps, 5)), 1, barrier_sync, overlap=overlap, pool=pool)
+            _, _, pass_all, _ = timed_steps(rx, max(2, min(steps, 16)), 1, barrier_sync, overlap=overlap, pool=pool)      # (two rounds of the capture pool: a 5-step sample let one disturbed pass move the average by 10 %)
         finally:
             _l.call("qh_set_pit_timing", 1)
     ser_rows = rx.ser(sig.symbols, maxlag=256, window=8192, trim=2000) if cfg["A"] else []
