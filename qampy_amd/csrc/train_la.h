@@ -154,6 +154,12 @@ template <int N> __device__ __forceinline__ void tab_lookup_med3(float sqr, floa
     }
 }
 
+// the codes of a table times m (the segment trainer folds the step size into them: see seg_errfn_d)
+template <typename R, int N> __device__ __forceinline__ void tab_scale_codes(PartTab<R, N> &t, R m)
+{
+    if constexpr (N > 0) { t.code_re *= m; t.code_im *= m; tab_scale_codes<R, N - 1>(t.next, m); }
+}
+
 template <typename R, int NPART> struct LaConst {
     R mu, R_re, R_im, code0_re, code0_im;
     PartTab<R, NPART> tab;
@@ -163,32 +169,60 @@ template <typename R, int NPART> struct LaConst {
 // path); SCALE = false: the plain error for the trace.  Written on 2-vectors so that hipcc emits v_pk_* for float.
 template <typename R> struct V2 { typedef R type __attribute__((ext_vector_type(2))); };
 
+// the four blind error functions of the form e = d(y) * y (d a real factor: cma, rde; or one factor per axis: mcma, mrde):
+// the factor alone, for callers that want both e and a rotated copy of it straight from y (train_seg.h)
+template <int METHOD> constexpr bool la_errfn_is_dy = METHOD == QH_M_CMA || METHOD == QH_M_SGNCMA || METHOD == QH_M_MCMA || METHOD == QH_M_RDE || METHOD == QH_M_MRDE;
+template <typename R, int METHOD, int NPART, bool SCALE>
+__device__ __forceinline__ auto la_errfn_d(Cx<R> y, const LaConst<R, NPART> &k)
+{
+    using v2 = typename V2<R>::type;
+    const v2 yy = {y.re, y.im};
+    if constexpr (METHOD == QH_M_CMA || METHOD == QH_M_SGNCMA) {
+        R d;
+        if constexpr (SCALE) { const R t = fma_(y.re, y.re, y.im * y.im); d = fma_(-k.mu, t, k.mu * k.R_re); }     // (R - |y|^2) mu
+        else d = fma_(-y.im, y.im, fma_(-y.re, y.re, k.R_re));                  // R - |y|^2 in two instructions (the adaptive chain counts them)
+        return d;
+    } else if constexpr (METHOD == QH_M_MCMA) {
+        const v2 Rc = {k.R_re, k.R_im};
+        v2 d = Rc - yy * yy;
+        if constexpr (SCALE) d = d * k.mu;
+        return d;
+    } else if constexpr (METHOD == QH_M_RDE) {
+        const R sq = fma_(y.re, y.re, y.im * y.im);
+        R d = tab_lookup<R, NPART, false>(sq, k.code0_re, k.tab) - sq;
+        if constexpr (SCALE) d = d * k.mu;
+        return d;
+    } else if constexpr (METHOD == QH_M_MRDE) {
+        const v2 sq = yy * yy;
+        v2 r;
+        if constexpr (sizeof(R) == 4) {
+            float rr = k.code0_re, ri = k.code0_im;
+            tab_lookup_med3<NPART>(sq.x, sq.y, rr, ri, k.tab);
+            r = v2{rr, ri};
+        } else {
+            r = v2{tab_lookup<R, NPART, false>(sq.x, k.code0_re, k.tab), tab_lookup<R, NPART, true>(sq.y, k.code0_im, k.tab)};
+        }
+        v2 d = r - sq;
+        if constexpr (SCALE) d = d * k.mu;
+        return d;
+    } else {
+        return (R)0;       // (not of this form: callers test la_errfn_is_dy first; kept instantiable for generic lambdas that name it in a discarded branch)
+    }
+}
+
 template <typename R, int METHOD, int NPART, bool SCALE>
 __device__ __forceinline__ Cx<R> la_errfn(Cx<R> y, const LaConst<R, NPART> &k, Cx<R> sdata = Cx<R>{0, 0})
 {
     using v2 = typename V2<R>::type;
     const v2 yy = {y.re, y.im};
     v2 e;
-    if constexpr (METHOD == QH_M_CMA || METHOD == QH_M_SGNCMA) {
-        R d;
-        if constexpr (SCALE) { const R t = fma_(y.re, y.re, y.im * y.im); d = fma_(-k.mu, t, k.mu * k.R_re); }     // (R - |y|^2) mu
-        else d = fma_(-y.im, y.im, fma_(-y.re, y.re, k.R_re));                  // R - |y|^2 in two instructions (the adaptive chain counts them)
-        e = yy * d;
+    if constexpr (la_errfn_is_dy<METHOD>) {
+        e = yy * la_errfn_d<R, METHOD, NPART, SCALE>(y, k);
     } else if constexpr (METHOD == QH_M_CMA2) {
         const R x2r = fma_(y.re, y.re, -(y.im * y.im)), x2i = (R)2 * y.re * y.im;
         const R m = SCALE ? k.mu : (R)1;
         const R dr = (k.R_re - x2r) * m, di = (k.R_im - x2i) * m;
         e = v2{fma_(dr, y.re, -(di * y.im)), fma_(dr, y.im, di * y.re)};
-    } else if constexpr (METHOD == QH_M_MCMA) {
-        const v2 Rc = {k.R_re, k.R_im};
-        v2 d = Rc - yy * yy;
-        if constexpr (SCALE) d = d * k.mu;
-        e = d * yy;
-    } else if constexpr (METHOD == QH_M_RDE) {
-        const R sq = fma_(y.re, y.re, y.im * y.im);
-        R d = tab_lookup<R, NPART, false>(sq, k.code0_re, k.tab) - sq;
-        if constexpr (SCALE) d = d * k.mu;
-        e = yy * d;
     } else if constexpr (METHOD == QH_M_SBD_DATA) {        // :219-223, the training symbol of this step comes with the call
         const v2 s = {sdata.re, sdata.im};
         v2 d = (s - yy) * __builtin_elementwise_abs(s);
@@ -206,19 +240,6 @@ __device__ __forceinline__ Cx<R> la_errfn(Cx<R> y, const LaConst<R, NPART> &k, C
         else d = s - yy;
         if constexpr (SCALE) d = d * k.mu;
         e = d;
-    } else {   // QH_M_MRDE
-        const v2 sq = yy * yy;
-        v2 r;
-        if constexpr (sizeof(R) == 4) {
-            float rr = k.code0_re, ri = k.code0_im;
-            tab_lookup_med3<NPART>(sq.x, sq.y, rr, ri, k.tab);
-            r = v2{rr, ri};
-        } else {
-            r = v2{tab_lookup<R, NPART, false>(sq.x, k.code0_re, k.tab), tab_lookup<R, NPART, true>(sq.y, k.code0_im, k.tab)};
-        }
-        v2 d = r - sq;
-        if constexpr (SCALE) d = d * k.mu;
-        e = d * yy;
     }
     return Cx<R>{e.x, e.y};
 }

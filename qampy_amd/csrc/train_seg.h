@@ -91,6 +91,14 @@ __device__ __forceinline__ sg_f2 pk_im_rot(sg_f2 x, sg_f2 b, sg_f2 acc)
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(d) : "v"(x), "v"(b), "v"(acc));
     return d;
 }
+// acc + x.im * (-b.im, b.re): the second half of a complex multiply-add acc + x * b
+__device__ __forceinline__ sg_f2 pk_imw(sg_f2 x, sg_f2 b, sg_f2 acc)
+{
+    sg_f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(d) : "v"(x), "v"(b), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ sg_d2 pk_imw(sg_d2 x, sg_d2 b, sg_d2 acc) { return __builtin_elementwise_fma(sg_d2{x.y, x.y}, sg_d2{-b.y, b.x}, acc); }
 __device__ __forceinline__ sg_d2 pk_re(sg_d2 x, sg_d2 b, sg_d2 acc) { return __builtin_elementwise_fma(sg_d2{x.x, x.x}, b, acc); }
 __device__ __forceinline__ sg_d2 pk_im(sg_d2 x, sg_d2 b, sg_d2 acc) { return __builtin_elementwise_fma(sg_d2{x.y, x.y}, b, acc); }
 __device__ __forceinline__ sg_d2 pk_im_rot(sg_d2 x, sg_d2 b, sg_d2 acc) { return __builtin_elementwise_fma(sg_d2{x.y, x.y}, sg_d2{b.y, -b.x}, acc); }
@@ -135,6 +143,239 @@ __device__ __forceinline__ void row8_csum(double &re, double &im)
 template <int LPC, typename R> __device__ __forceinline__ void chain_csum(R &re, R &im)
 {
     if (LPC == 8) row8_csum(re, im); else row16_csum(re, im);
+}
+
+
+// ---- one step of the 16-lane layout as two hand-scheduled blocks (single precision, 4 or 6 taps per lane, unrolled groups of steps)
+// A lone wave issues one instruction per turn of its SIMD (~4.3 cycles) whatever the instruction is - an s_nop costs as much as
+// a packed FMA - and gfx950 wants 2 wait states between a VALU write and a DPP read of it and 1 after every packed operation
+// before its result is read.  Round 4's step paid 8 s_nop and 2 s_waitcnt for that (58 issue slots, 46 of them VALU), most of them
+// padding the compiler puts around inline-assembly instructions: to it they are opaque nodes that it places anywhere and then pads
+// (an operand written by the instruction right before an asm statement costs an s_nop, whatever the statement does with it).  So the
+// step is TWO statements with the error function (the compiler's) in between, and each schedules itself:
+//   block A  y = sum w x over the lane's taps as P = sum x.re w, R = sum x.im w on the even / odd taps (four accumulators, every FMA
+//            four instructions after the one it depends on), P0 + P1, R0 + R1, y = P + i R (ONE packed add with a rotated, half-negated
+//            operand), the four DPP levels.  The wait states in there hold work that has to be done anyway and does not depend on it:
+//            the two selects that park the PREVIOUS step's error in its lane of the trace group (KEEP) and the ds_read_b128 of the
+//            window of the NEXT pair of steps (NL of them, at immediate offsets from one address register per group - the compiler is
+//            out of the LDS business in this loop, so it also stops placing an s_waitcnt before every first use: one per pair, sg_wait_lds);
+//   block B  w += c conj(x) as two rounds of packed FMAs, x.re (c.re, c.im) and x.im (c.im, -c.re) - the rotated copy of c comes from
+//            the error function's factors with one more packed multiply (pk_rot_mul) - and the zeroing of the padding taps, ordered so
+//            that nothing reads what the instruction before it wrote, block A of the next step included.
+// v[248:255] are scratch of block A (the halves of a packed sum feed the DPP adds; operands of inline assembly have no sub-registers to name).
+typedef float sg_f4 __attribute__((ext_vector_type(4)));
+#define SG_PRE "v_pk_mul_f32 v[248:249], %[x0], %[w0] op_sel_hi:[0,1]\n\t" \
+               "v_pk_mul_f32 v[250:251], %[x0], %[w0] op_sel:[1,0] op_sel_hi:[1,1]\n\t" \
+               "v_pk_mul_f32 v[252:253], %[x1], %[w1] op_sel_hi:[0,1]\n\t" \
+               "v_pk_mul_f32 v[254:255], %[x1], %[w1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+#define SG_EV(j) "v_pk_fma_f32 v[248:249], %[x" #j "], %[w" #j "], v[248:249] op_sel_hi:[0,1,1]\n\t" \
+                 "v_pk_fma_f32 v[250:251], %[x" #j "], %[w" #j "], v[250:251] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define SG_OD(j) "v_pk_fma_f32 v[252:253], %[x" #j "], %[w" #j "], v[252:253] op_sel_hi:[0,1,1]\n\t" \
+                 "v_pk_fma_f32 v[254:255], %[x" #j "], %[w" #j "], v[254:255] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define SG_DOT4 SG_PRE SG_EV(2) SG_OD(3)
+#define SG_DOT6 SG_PRE SG_EV(2) SG_OD(3) SG_EV(4) SG_OD(5)
+#define SG_SUMP "v_pk_add_f32 v[248:249], v[248:249], v[252:253]\n\t"
+#define SG_SUMR "v_pk_add_f32 v[250:251], v[250:251], v[254:255]\n\t"
+#define SG_SUMY "v_pk_add_f32 v[254:255], v[248:249], v[250:251] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+#define SG_LV(ctl) "v_add_f32_dpp v254, v254, v254 " ctl " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp v255, v255, v255 " ctl " row_mask:0xf bank_mask:0xf\n\t"
+#define SG_L1 SG_LV("quad_perm:[1,0,3,2]")
+#define SG_L2 SG_LV("quad_perm:[2,3,0,1]")
+#define SG_L3 SG_LV("row_half_mirror")
+#define SG_L4 "v_add_f32_dpp v246, v254, v254 row_mirror row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp v247, v255, v255 row_mirror row_mask:0xf bank_mask:0xf\n\t" \
+              "v_pk_mul_f32 %[sq], v[246:247], v[246:247]\n\t"
+#define SG_KR "v_cndmask_b32_e64 %[ebr], %[ebr], %[per], %[mk]\n\t"
+#define SG_KI "v_cndmask_b32_e64 %[ebi], %[ebi], %[pei], %[mk]\n\t"
+#define SG_LD(n) "ds_read_b128 %[d" #n "], %[la] offset:%[o" #n "]\n\t"
+#define SG_N0 "s_nop 0\n\t"
+#define SG_N1 "s_nop 1\n\t"
+// the sums, the parked error, the window pieces and the tree, by (KEEP, NL)
+#define SG_K1 SG_SUMP SG_KR SG_SUMR SG_KI SG_SUMY SG_LD(0) SG_N0 SG_L1 SG_N0 SG_L2 SG_N0 SG_L3 SG_N0 SG_L4
+#define SG_K2 SG_SUMP SG_KR SG_SUMR SG_KI SG_SUMY SG_LD(0) SG_LD(1) SG_L1 SG_N0 SG_L2 SG_N0 SG_L3 SG_N0 SG_L4
+#define SG_F1 SG_SUMP SG_LD(0) SG_SUMR SG_N0 SG_SUMY SG_N1 SG_L1 SG_N0 SG_L2 SG_N0 SG_L3 SG_N0 SG_L4
+#define SG_F2 SG_SUMP SG_LD(0) SG_SUMR SG_LD(1) SG_SUMY SG_N1 SG_L1 SG_N0 SG_L2 SG_N0 SG_L3 SG_N0 SG_L4
+#define SG_IN4_ [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [la] "v"(la)
+#define SG_IN6_ SG_IN4_, [x4] "v"(x[4]), [x5] "v"(x[5]), [w4] "v"(w[4]), [w5] "v"(w[5])
+#define SG_KOUT_ , [ebr] "+v"(ebr), [ebi] "+v"(ebi)
+#define SG_KIN_ , [per] "v"(per), [pei] "v"(pei), [mk] "s"(mk)
+#define SG_CLOB_ "memory", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+// x[0 .. TPL), w[0 .. TPL): the samples and taps of this step; y: the chain's output, in every lane (the pair v[246:247]: the DPP adds write its
+// halves, what follows reads it as a packed operand), sq = (y.re^2, y.im^2) - every blind error function starts with it, and behind the block's
+// last DPP add it costs no wait state; ebr / ebi: the lane's slot of the trace group, (per, pei) parked there in the lanes of mask mk; d0, d1:
+// window pieces read from LDS address la + O0 (+ 16)
+template <int TPL, bool KEEP, int NL, int O0>
+__device__ __forceinline__ void seg_block_a(const sg_f2 (&x)[TPL], const sg_f2 (&w)[TPL], sg_f2 &y, sg_f2 &sq, float &ebr, float &ebi,
+                                            float per, float pei, unsigned long long mk, unsigned la, sg_f4 &d0, sg_f4 &d1)
+{
+    static_assert((TPL == 4 || TPL == 6) && (NL == 1 || NL == 2), "layouts with 4 or 6 taps per lane: one or two window pieces per step");
+#define SG_A(DOT, IN) \
+    if constexpr (KEEP && NL == 1) asm volatile(DOT SG_K1 : [y] "={v[246:247]}"(y), [sq] "=&v"(sq) SG_KOUT_, [d0] "=&v"(d0) : IN SG_KIN_, [o0] "n"(O0) : SG_CLOB_); \
+    else if constexpr (KEEP) asm volatile(DOT SG_K2 : [y] "={v[246:247]}"(y), [sq] "=&v"(sq) SG_KOUT_, [d0] "=&v"(d0), [d1] "=&v"(d1) : IN SG_KIN_, [o0] "n"(O0), [o1] "n"(O0 + 16) : SG_CLOB_); \
+    else if constexpr (NL == 1) asm volatile(DOT SG_F1 : [y] "={v[246:247]}"(y), [sq] "=&v"(sq), [d0] "=&v"(d0) : IN, [o0] "n"(O0) : SG_CLOB_); \
+    else asm volatile(DOT SG_F2 : [y] "={v[246:247]}"(y), [sq] "=&v"(sq), [d0] "=&v"(d0), [d1] "=&v"(d1) : IN, [o0] "n"(O0), [o1] "n"(O0 + 16) : SG_CLOB_);
+    if constexpr (TPL == 4) { SG_A(SG_DOT4, SG_IN4_) } else { SG_A(SG_DOT6, SG_IN6_) }
+#undef SG_A
+    if constexpr (!KEEP) { (void)ebr; (void)ebi; (void)per; (void)pei; (void)mk; }
+}
+// block B: w[j] += x[j].re (c.re, c.im) + x[j].im (cr.re, cr.im) with cr = (c.im, -c.re); the NR padding taps (the last ones) times tm = 0 / 1
+#define SG_UR(j) "v_pk_fma_f32 %[w" #j "], %[x" #j "], %[c], %[w" #j "] op_sel_hi:[0,1,1]\n\t"
+#define SG_UI(j) "v_pk_fma_f32 %[w" #j "], %[x" #j "], %[cr], %[w" #j "] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+#define SG_UM(j) "v_pk_mul_f32 %[w" #j "], %[w" #j "], %[tm]\n\t"
+#define SG_W4_ [w0] "+v"(w[0]), [w1] "+v"(w[1]), [w2] "+v"(w[2]), [w3] "+v"(w[3])
+#define SG_W6_ SG_W4_, [w4] "+v"(w[4]), [w5] "+v"(w[5])
+#define SG_X4_ [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [c] "v"(c), [cr] "v"(cr)
+#define SG_X6_ SG_X4_, [x4] "v"(x[4]), [x5] "v"(x[5])
+template <int TPL, int NR>
+__device__ __forceinline__ void seg_block_b(const sg_f2 (&x)[TPL], sg_f2 (&w)[TPL], sg_f2 c, sg_f2 cr, sg_f2 tm)
+{
+    static_assert((TPL == 4 || TPL == 6) && NR >= 0 && NR <= 3, "layouts with 4 or 6 taps per lane, up to three padding taps");
+    // (both rounds start with the padding taps: a tap's second FMA comes TPL - 1 instructions after its first, the zeroing of a padding
+    // tap at least three after its second, and the first instruction of the next block A reads w[0], written at least two before the end)
+    if constexpr (TPL == 6) {
+        if constexpr (NR == 0) asm volatile(SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UR(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UI(5) : SG_W6_ : SG_X6_);
+        else if constexpr (NR == 1) asm volatile(SG_UR(5) SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UI(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UM(5) : SG_W6_ : SG_X6_, [tm] "v"(tm));
+        else if constexpr (NR == 2) asm volatile(SG_UR(5) SG_UR(4) SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UI(5) SG_UI(4) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UM(5) SG_UM(4) : SG_W6_ : SG_X6_, [tm] "v"(tm));
+        else asm volatile(SG_UR(5) SG_UR(4) SG_UR(3) SG_UR(0) SG_UR(1) SG_UR(2) SG_UI(5) SG_UI(4) SG_UI(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UM(5) SG_UM(4) SG_UM(3) : SG_W6_ : SG_X6_, [tm] "v"(tm));
+    } else {
+        if constexpr (NR == 0) asm volatile(SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) : SG_W4_ : SG_X4_);
+        else if constexpr (NR == 1) asm volatile(SG_UR(3) SG_UR(0) SG_UR(1) SG_UR(2) SG_UI(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UM(3) : SG_W4_ : SG_X4_, [tm] "v"(tm));
+        else if constexpr (NR == 2) asm volatile(SG_UR(3) SG_UR(2) SG_UR(0) SG_UR(1) SG_UI(3) SG_UI(2) SG_UI(0) SG_UI(1) SG_UM(3) SG_UM(2) : SG_W4_ : SG_X4_, [tm] "v"(tm));
+        else asm volatile(SG_UR(3) SG_UR(2) SG_UR(1) SG_UR(0) SG_UI(3) SG_UI(2) SG_UI(1) SG_UI(0) SG_UM(3) SG_UM(2) SG_UM(1) : SG_W4_ : SG_X4_, [tm] "v"(tm));
+    }
+    if constexpr (NR == 0) (void)tm;
+}
+// block B for error functions of the form e = d(y) y: c = mu e and its rotated copy are the block's first two instructions (d: the factor
+// with the step size folded in - one per axis, or ONE real factor in the low half of its operand (D1) - written by the compiler's last
+// instruction before the block; c is returned for the trace)
+#define SG_CV "v_pk_mul_f32 %[c], %[yy], %[d]\n\tv_pk_mul_f32 %[cr], %[yy], %[d] op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
+#define SG_C1 "v_pk_mul_f32 %[c], %[yy], %[d] op_sel_hi:[1,0]\n\tv_pk_mul_f32 %[cr], %[yy], %[d] op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
+#define SG_Y4_ [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [yy] "v"(yy), [d] "v"(d)
+#define SG_Y6_ SG_Y4_, [x4] "v"(x[4]), [x5] "v"(x[5])
+#define SG_CO_ , [c] "=&v"(c), [cr] "=&v"(cr)
+template <int TPL, int NR, bool D1>
+__device__ __forceinline__ sg_f2 seg_block_b2(const sg_f2 (&x)[TPL], sg_f2 (&w)[TPL], sg_f2 yy, sg_f2 d, sg_f2 tm)
+{
+    static_assert((TPL == 4 || TPL == 6) && NR >= 0 && NR <= 3, "layouts with 4 or 6 taps per lane, up to three padding taps");
+    sg_f2 c, cr;
+#define SG_B2(CM) \
+    if constexpr (TPL == 6) { \
+        if constexpr (NR == 0) asm volatile(CM SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UR(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UI(5) : SG_W6_ SG_CO_ : SG_Y6_); \
+        else if constexpr (NR == 1) asm volatile(CM SG_UR(5) SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UI(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UM(5) : SG_W6_ SG_CO_ : SG_Y6_, [tm] "v"(tm)); \
+        else if constexpr (NR == 2) asm volatile(CM SG_UR(5) SG_UR(4) SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UI(5) SG_UI(4) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UM(5) SG_UM(4) : SG_W6_ SG_CO_ : SG_Y6_, [tm] "v"(tm)); \
+        else asm volatile(CM SG_UR(5) SG_UR(4) SG_UR(3) SG_UR(0) SG_UR(1) SG_UR(2) SG_UI(5) SG_UI(4) SG_UI(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UM(5) SG_UM(4) SG_UM(3) : SG_W6_ SG_CO_ : SG_Y6_, [tm] "v"(tm)); \
+    } else { \
+        if constexpr (NR == 0) asm volatile(CM SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) : SG_W4_ SG_CO_ : SG_Y4_); \
+        else if constexpr (NR == 1) asm volatile(CM SG_UR(3) SG_UR(0) SG_UR(1) SG_UR(2) SG_UI(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UM(3) : SG_W4_ SG_CO_ : SG_Y4_, [tm] "v"(tm)); \
+        else if constexpr (NR == 2) asm volatile(CM SG_UR(3) SG_UR(2) SG_UR(0) SG_UR(1) SG_UI(3) SG_UI(2) SG_UI(0) SG_UI(1) SG_UM(3) SG_UM(2) : SG_W4_ SG_CO_ : SG_Y4_, [tm] "v"(tm)); \
+        else asm volatile(CM SG_UR(3) SG_UR(2) SG_UR(1) SG_UR(0) SG_UI(3) SG_UI(2) SG_UI(1) SG_UI(0) SG_UM(3) SG_UM(2) SG_UM(1) : SG_W4_ SG_CO_ : SG_Y4_, [tm] "v"(tm)); \
+    }
+    if constexpr (D1) { SG_B2(SG_C1) } else { SG_B2(SG_CV) }
+#undef SG_B2
+    if constexpr (NR == 0) (void)tm;
+    return c;
+}
+#undef SG_CV
+#undef SG_C1
+#undef SG_Y4_
+#undef SG_Y6_
+#undef SG_CO_
+#undef SG_PRE
+#undef SG_EV
+#undef SG_OD
+#undef SG_DOT4
+#undef SG_DOT6
+#undef SG_SUMP
+#undef SG_SUMR
+#undef SG_SUMY
+#undef SG_LV
+#undef SG_L1
+#undef SG_L2
+#undef SG_L3
+#undef SG_L4
+#undef SG_KR
+#undef SG_KI
+#undef SG_LD
+#undef SG_N0
+#undef SG_N1
+#undef SG_K1
+#undef SG_K2
+#undef SG_F1
+#undef SG_F2
+#undef SG_IN4_
+#undef SG_IN6_
+#undef SG_KOUT_
+#undef SG_KIN_
+#undef SG_CLOB_
+#undef SG_UR
+#undef SG_UI
+#undef SG_UM
+#undef SG_W4_
+#undef SG_W6_
+#undef SG_X4_
+#undef SG_X6_
+// (e.im, -e.re) of e = d * y, component by component, from y and d: the rotated operand of the second round of the tap update
+__device__ __forceinline__ sg_f2 pk_rot_mul(sg_f2 y, sg_f2 d)
+{
+    sg_f2 o;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(o) : "v"(y), "v"(d));
+    return o;
+}
+// the same with one real factor d in the low half of its operand (the high half is not read)
+__device__ __forceinline__ sg_f2 pk_rot_mul1(sg_f2 y, sg_f2 d)
+{
+    sg_f2 o;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(o) : "v"(y), "v"(d));
+    return o;
+}
+// the window pieces asked for during the previous pair of steps have arrived (their only reader waits here: data dependence pins the order)
+template <int NQ> __device__ __forceinline__ void sg_wait_lds(sg_f4 (&q)[NQ])
+{
+    static_assert(NQ >= 2 && NQ <= 5, "window of 4 to 10 samples");
+    if constexpr (NQ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]));
+    else if constexpr (NQ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]));
+    else if constexpr (NQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]));
+}
+
+// the factor d of c = mu e = d y for the blind error functions of that form, from y and (y.re^2, y.im^2), with the step size folded in as far
+// as it goes (cma: mu R - mu |y|^2 is one FMA; mcma: one packed FMA; mrde: the codes of the table come pre-scaled by mu - Ks - so that
+// mu (r - y^2) is one packed FMA behind the look-up; rde: as la_errfn has it).  Same functions as la_errfn, rounded differently in the last bit.
+// tab_lookup_med3 (train_la.h) in two phases: h_p = (sq - part_p) 2^60 for every partition, then r = med3(r, code_p, h_p) partition by partition
+template <int N, int P, int NH> __device__ __forceinline__ void seg_med3_diffs(sg_f2 sq, const PartTab<float, N> &t, sg_f2 (&h)[NH])
+{
+    if constexpr (N > 0) {
+        constexpr float BIG = 1152921504606846976.0f;                 // 2^60
+        h[P] = sq * BIG - sg_f2{t.part_re, t.part_im} * BIG;
+        seg_med3_diffs<N - 1, P + 1>(sq, t.next, h);
+    }
+}
+template <int N, int P, int NH> __device__ __forceinline__ void seg_med3_pick(float &rr, float &ri, const PartTab<float, N> &t, const sg_f2 (&h)[NH])
+{
+    if constexpr (N > 0) {
+        rr = __builtin_amdgcn_fmed3f(rr, t.code_re, h[P].x);
+        ri = __builtin_amdgcn_fmed3f(ri, t.code_im, h[P].y);
+        seg_med3_pick<N - 1, P + 1>(rr, ri, t.next, h);
+    }
+}
+template <int METHOD, int NPART>
+__device__ __forceinline__ auto seg_errfn_d(sg_f2 sq, const LaConst<float, NPART> &k, const LaConst<float, NPART> &ks)
+{
+    if constexpr (METHOD == QH_M_CMA || METHOD == QH_M_SGNCMA) {
+        return __builtin_fmaf(-k.mu, sq.x + sq.y, k.mu * k.R_re);
+    } else if constexpr (METHOD == QH_M_MCMA) {
+        return __builtin_elementwise_fma(sq, sg_f2{-k.mu, -k.mu}, sg_f2{k.mu * k.R_re, k.mu * k.R_im});
+    } else if constexpr (METHOD == QH_M_RDE) {
+        const float s = sq.x + sq.y;
+        return (tab_lookup<float, NPART, false>(s, k.code0_re, k.tab) - s) * k.mu;
+    } else {   // QH_M_MRDE
+        // (the compiler's own order - one packed FMA for a partition, its two med3, the next FMA into the same registers - pays a wait state per
+        // partition: all the differences first, then the two med3 chains, interleaved)
+        sg_f2 h[NPART > 0 ? NPART : 1];
+        seg_med3_diffs<NPART, 0>(sq, ks.tab, h);
+        __builtin_amdgcn_sched_barrier(0);
+        float rr = ks.code0_re, ri = ks.code0_im;
+        seg_med3_pick<NPART, 0>(rr, ri, ks.tab, h);
+        return __builtin_elementwise_fma(sq, sg_f2{-k.mu, -k.mu}, sg_f2{rr, ri});
+    }
 }
 
 constexpr int SG_PITCH = 192;      // samples per LDS row (one segment window of one input mode): 3 pieces of 64
@@ -203,6 +444,9 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     { const Cx<R> c0 = sy[0]; K.R_re = c0.re; K.R_im = c0.im; }
     K.code0_re = K.R_re; K.code0_im = K.R_im;
     tab_fill<R, NPART>(K.tab, sy, 0, NPART + 1);
+    LaConst<R, NPART> Ks = K;                                   // codes times the step size (fixed step, single precision: seg_errfn_d)
+    Ks.code0_re *= K.mu; Ks.code0_im *= K.mu;
+    tab_scale_codes<R, NPART>(Ks.tab, K.mu);
     // ADAPT: the chain's step size as r = 1 / mu (adapt_step adds |e_prev|^2 to it unless both component products of successive
     // errors are positive), the previous error, the sum of the step sizes used
     R ad_r = 1, ad_sum = 0;
@@ -250,6 +494,9 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     // selects per step - the groups are unrolled, so "is this my step" is a loop-invariant lane mask in a scalar register pair, not a
     // compare per step) and stores it when the group is complete: one coalesced store per chain and group.
     R ebr = 0, ebi = 0;
+    unsigned long long mks[LPC];                                // "lane u of its chain" as wave-wide lane masks (the selects of the fused lane tree)
+#pragma unroll
+    for (int u = 0; u < LPC; u++) mks[u] = __builtin_amdgcn_ballot_w64(l16 == u);
     // fixed step: the step-size-scaled error mu e is what the update needs; the trace is taken from it (x 1 / mu when a group of LPC errors is
     // stored) instead of evaluating the error function a second time without the factor (2-3 instructions per step; the host sends
     // sweeps with mu = 0 to the exact path)
@@ -268,26 +515,29 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     // one step on the samples x[OFF .. OFF + TPL); returns the error (unscaled) of the step
     // (always_inline: a lambda left as a call takes the taps - captured by reference - through scratch memory, as the 2-taps-per-lane
     // layout did: 5000 instead of 300 cycles per step)
-    auto step = [&](auto XO, v2 (&x)[WIN], int gstep, auto CHK, auto RG) __attribute__((always_inline)) -> Cx<R> {
-        constexpr int OFF = decltype(XO)::value;
-        // y = sum w x  (no conjugate, pythran_equalisation.py:24-31): two accumulators, combined before the reduction
-        // (NCH accumulator chains per product, taps j, j + NCH, ... each: a packed FMA that reads the result of another one needs four
-        // independent instructions in between, or the assembler pads with s_nop - each a lost issue slot of this lone wave)
-        constexpr int NCH = TPL >= 6 ? 3 : (TPL >= 4 ? 2 : 1);
-        v2 pa[NCH], ra[NCH];
+    // y = sum w x over this lane's taps (no conjugate, pythran_equalisation.py:24-31), accumulated as the complex number it is: tap j
+    // adds x.re * (w.re, w.im) and x.im * (-w.im, w.re) to accumulator j mod NACC (pk_re / pk_imw: the rotation of w is an operand
+    // selector, not an instruction), so the partial sums need NACC - 1 packed additions and nothing else before the lane tree
+    // (round 4 kept the two products per tap apart: 4 additions to combine them + 2 more to form re / im).  A packed FMA that
+    // reads the result of another one wants three or four independent instructions in between (a lone wave issues every ~4.3
+    // cycles, the packed pipe answers after ~13): NACC chains, the re-parts of a group of NACC taps first, then their im-parts.
+    constexpr int NACC = TPL == 6 ? 3 : (TPL <= 2 ? TPL : 4);
+    auto dot = [&](auto xof) __attribute__((always_inline)) -> v2 {
+        v2 acc[NACC];
 #pragma unroll
-        for (int q = 0; q < NCH; q++) { pa[q] = pk_re0(x[OFF + q], w[q]); ra[q] = pk_im0(x[OFF + q], w[q]); }   // x.re * (w.re, w.im), x.im * (w.re, w.im)
+        for (int b = 0; b < TPL; b += NACC) {
 #pragma unroll
-        for (int j = NCH; j < TPL; j++) {
-            pa[j % NCH] = pk_re(x[OFF + j], w[j], pa[j % NCH]);
-            ra[j % NCH] = pk_im(x[OFF + j], w[j], ra[j % NCH]);
+            for (int q = 0; q < NACC; q++) if (b + q < TPL) acc[q] = b == 0 ? pk_re0(xof(q), w[q]) : pk_re(xof(b + q), w[b + q], acc[q]);
+#pragma unroll
+            for (int q = 0; q < NACC; q++) if (b + q < TPL) acc[q] = pk_imw(xof(b + q), w[b + q], acc[q]);
         }
-        v2 p = pa[0], r = ra[0];
+        v2 ysum = acc[0];
 #pragma unroll
-        for (int q = 1; q < NCH; q++) { p += pa[q]; r += ra[q]; }
-        R yr = p.x - r.y, yi = p.y + r.x;
-        chain_csum<LPC>(yr, yi);
-        const Cx<R> y{yr, yi};
+        for (int q = 1; q < NACC; q++) ysum += acc[q];
+        return ysum;
+    };
+    // error function of the chain's output y and the tap update with it; returns the error of the step (fixed step: times mu)
+    auto finish = [&](Cx<R> y, auto xof, int gstep, auto CHK, auto RG) __attribute__((always_inline)) -> Cx<R> {
         Cx<R> e{0, 0};
         Cx<R> cc;
         if constexpr (ADAPT) {
@@ -314,10 +564,21 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         v2 ct = c1;
         if (NR > 0) ct = c1 * tailmask;
 #pragma unroll
-        for (int j = 0; j < TPL; j++) w[j] = pk_re(x[OFF + j], j >= TPL - NR ? ct : c1, w[j]);        // two rounds: no instruction waits
+        for (int j = 0; j < TPL; j++) w[j] = pk_re(xof(j), j >= TPL - NR ? ct : c1, w[j]);        // two rounds: no instruction waits
 #pragma unroll
-        for (int j = 0; j < TPL; j++) w[j] = pk_im_rot(x[OFF + j], j >= TPL - NR ? ct : c1, w[j]);    // for the one right before it
+        for (int j = 0; j < TPL; j++) w[j] = pk_im_rot(xof(j), j >= TPL - NR ? ct : c1, w[j]);    // for the one right before it
         return e;
+    };
+    // one step on the samples x[OFF .. OFF + TPL); returns the error of the step
+    // (always_inline: a lambda left as a call takes the taps - captured by reference - through scratch memory, as the 2-taps-per-lane
+    // layout did: 5000 instead of 300 cycles per step)
+    auto step = [&](auto XO, v2 (&x)[WIN], int gstep, auto CHK, auto RG) __attribute__((always_inline)) -> Cx<R> {
+        constexpr int OFF = decltype(XO)::value;
+        auto xof = [&](int j) __attribute__((always_inline)) -> v2 { return x[OFF + j]; };
+        const v2 ysum = dot(xof);
+        R yr = ysum.x, yi = ysum.y;
+        chain_csum<LPC>(yr, yi);
+        return finish(Cx<R>{yr, yi}, xof, gstep, CHK, RG);
     };
     auto keep = [&](Cx<R> e, int u) __attribute__((always_inline)) { const bool mine = l16 == u; ebr = mine ? e.re : ebr; ebi = mine ? e.im : ebi; };
     auto run_chunk = [&](const Cx<R> *xs, int xstep, int ibase, int nst, auto CHK, auto RG, auto OS2) __attribute__((always_inline)) {
@@ -325,6 +586,65 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         v2 xa[WIN], xb[WIN];
         int i = 0;
         // ---- whole groups of LPC steps
+        constexpr bool FAST = sizeof(R) == 4 && !ADAPT && LPC == 16 && (TPL == 4 || TPL == 6);
+        if constexpr (FAST) {
+            // single precision, 16 lanes per chain, 2 samples per symbol: the same pairs of steps on windows of TPL + 2 samples, the
+            // windows as 128-bit pieces; the pieces of the next pair's window are asked for from inside the lane trees of this pair
+            // and the previous step's error is parked there too (tree16_fused).  Lanes without taps walk through the zero row.
+            if (os2) {
+                constexpr int NQ = WIN / 2, NLA = (NQ + 1) / 2;
+                sg_f4 qa[NQ], qb[NQ];
+                const sg_f4 *xq = reinterpret_cast<const sg_f4 *>(xs);
+                unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(const char *)xs;   // LDS byte address of step i's window
+#pragma unroll
+                for (int j = 0; j < NQ; j++) qa[j] = xq[j];
+                auto fstep = [&](auto XO, sg_f4 (&q)[NQ], sg_f4 (&qn)[NQ], auto P0, auto NL_, auto BOFF, auto KU, Cx<R> pend, int gstep) __attribute__((always_inline)) -> Cx<R> {
+                    constexpr int OFF = decltype(XO)::value, p0 = decltype(P0)::value, nl = decltype(NL_)::value, ku = decltype(KU)::value;
+                    constexpr bool chk = decltype(CHK)::value != 0;
+                    constexpr int NR = decltype(RG)::value;
+                    v2 x[TPL];
+#pragma unroll
+                    for (int j = 0; j < TPL; j++) {
+                        const sg_f4 v = q[(OFF + j) >> 1];
+                        x[j] = ((OFF + j) & 1) ? v2{v.z, v.w} : v2{v.x, v.y};
+                    }
+                    v2 y, sq;
+                    seg_block_a<TPL, (ku >= 0), nl, decltype(BOFF)::value + 16 * p0>(x, w, y, sq, ebr, ebi, pend.re, pend.im, mks[ku >= 0 ? ku : 0], la,
+                                                                                     qn[p0], qn[nl > 1 ? p0 + 1 : p0]);
+                    // c = mu e(y) and w += c conj(x)
+                    v2 c1;
+                    if constexpr (la_errfn_is_dy<METHOD> && !chk) {
+                        const auto d = seg_errfn_d<METHOD, NPART>(sq, K, Ks);
+                        if constexpr (sizeof(d) == sizeof(R)) { v2 dd = __builtin_nondeterministic_value(dd); dd.x = d; c1 = seg_block_b2<TPL, NR, true>(x, w, y, dd, tailmask); }
+                        else c1 = seg_block_b2<TPL, NR, false>(x, w, y, d, tailmask);
+                    } else {
+                        Cx<R> cc = la_errfn<R, METHOD, NPART, true>(Cx<R>{y.x, y.y}, K);
+                        if (chk && gstep >= my_steps) cc = Cx<R>{0, 0};              // past the end of this chain's segment: nothing moves
+                        c1 = v2{cc.re, cc.im};
+                        seg_block_b<TPL, NR>(x, w, c1, v2{cc.im, -cc.re}, tailmask);
+                    }
+                    return Cx<R>{c1.x, c1.y};
+                };
+                for (; i + LPC <= nst; i += LPC) {
+                    Cx<R> pend{0, 0};
+                    auto quad = [&](auto U) __attribute__((always_inline)) {
+                        constexpr int u = decltype(U)::value;
+                        const int g = ibase + i + u;
+                        pend = fstep(SgInt<0>{}, qa, qb, SgInt<0>{}, SgInt<NLA>{}, SgInt<(u + 2) * 16>{}, SgInt<u - 1>{}, pend, g);
+                        pend = fstep(SgInt<2>{}, qa, qb, SgInt<NLA>{}, SgInt<NQ - NLA>{}, SgInt<(u + 2) * 16>{}, SgInt<u>{}, pend, g + 1);
+                        sg_wait_lds(qb);
+                        pend = fstep(SgInt<0>{}, qb, qa, SgInt<0>{}, SgInt<NLA>{}, SgInt<(u + 4) * 16>{}, SgInt<u + 1>{}, pend, g + 2);    // (may look past the chunk: inside the row's slack)
+                        pend = fstep(SgInt<2>{}, qb, qa, SgInt<NLA>{}, SgInt<NQ - NLA>{}, SgInt<(u + 4) * 16>{}, SgInt<u + 2>{}, pend, g + 3);
+                        sg_wait_lds(qa);
+                    };
+                    quad(SgInt<0>{}); quad(SgInt<4>{}); quad(SgInt<8>{}); quad(SgInt<12>{});
+                    keep(pend, LPC - 1);
+                    const int gi = ibase + i + l16;
+                    if (gi < my_steps) stg(errow + gi, Cx<R>{ebr * inv_mu, ebi * inv_mu});
+                    la += LPC * 16;                                 // 16 steps x 2 samples x 8 bytes
+                }
+            }
+        } else
         if (os2) {
             // 2 samples per symbol: steps i and i + 1 read x[2 i .. 2 i + TPL + 2) - ONE window of TPL + 2 samples serves both (13 LDS
             // words instead of 22 at 11 taps per lane); the window of the next pair is read while this one computes
