@@ -39,7 +39,7 @@ extern "C" {
  * arguments.  History: 1 = round 1; 2 = round 2 (qh_bps_recover_*_dev gained `angles`, qh_train_equaliser_*_pit_dev takes
  * (gram, opts, report), the *_seg_dev entry points were removed - unversioned at the time); 3 = round 3 (qh_pit_opts:
  * start, dev_safety; qh_pit_report: deviation[]); 4 = qh_pit_opts: adaptive. */
-#define QH_ABI_VERSION 8
+#define QH_ABI_VERSION 9
 int qh_abi_version(void);
 
 /* ---- status codes (python shim: 1,2 -> ValueError, 3,4 -> RuntimeError) */
@@ -209,6 +209,15 @@ int qh_bps_recover_c64_dev(const void *E, int nm, int64_t L, const void *angles,
                            void *ph, void *Eout);
 int qh_bps_recover_c128_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *symbols, int M, int N, int32_t *idx,
                             void *ph, void *Eout);
+/* the same in `nparts` calls (ABI 9): parts 0 .. nparts - 2 search a run of the signal each, part nparts - 1 searches the rest, unwraps and de-rotates.
+ * A receiver that processes capture after capture enqueues one part behind each relaxation pass of the NEXT capture's training (qh_pit_opts.on_pass):
+ * the chip-wide search then runs in the short analysis between two passes, where the chip is idle, instead of beside a pass, which it slows down.
+ * Same kernels on the same data: the results do not depend on nparts.  The parts of one search are issued by one thread, in order, on one stream,
+ * with no other phase search of that thread in between. */
+int qh_bps_recover_part_c64_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *symbols, int M, int N, int32_t *idx,
+                                void *ph, void *Eout, int part, int nparts);
+int qh_bps_recover_part_c128_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *symbols, int M, int N, int32_t *idx,
+                                 void *ph, void *Eout, int part, int nparts);
 
 /* ---- comp_freq_offset (pilot receiver; qampy/core/phaserecovery.py:435-473): out[k, n] = E[k, n] exp(-2 pi i (n + 1) fo[k] / os),
  * fo (nmodes,) in units of the symbol rate, E / out (nmodes, L) host arrays */
@@ -366,6 +375,12 @@ typedef struct qh_pit_opts {
                              * place to enqueue work for OTHER library streams (the previous capture's phase search, the next capture's preparation) whose
                              * launches would otherwise sit in front of this sweep's; it must leave the current library stream as it found it (ABI 8) */
     void *on_pass0_user;
+    void (*on_pass)(void *user, int sweep, int pass);   /* NULL, or a function the call invokes on the calling thread right after it has enqueued the TRAINER launch of
+                             * relaxation pass `pass` of sweep `sweep` (before the pass's analysis launches): the place to enqueue chip-wide work of other library
+                             * streams behind an event recorded here - it then starts when the trainer is done, in the ~70 us analysis during which the chip is
+                             * otherwise idle (qh_bps_recover_part_*_dev).  A pass enqueued ahead of the decision that ends the sweep still calls it (its launches
+                             * do nothing).  It must leave the current library stream as it found it (ABI 9) */
+    void *on_pass_user;
 } qh_pit_opts;
 typedef struct qh_pit_report {
     int32_t segments, passes, converged, acq_chunks;

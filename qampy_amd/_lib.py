@@ -69,6 +69,7 @@ SIGNATURES = {
     "qh_apply_filter_c64_dev": _APPLY, "qh_apply_filter_c128_dev": _APPLY,
     "qh_bps_c64": _BPS, "qh_bps_c128": _BPS, "qh_bps_c64_dev": _BPS, "qh_bps_c128_dev": _BPS,
     "qh_bps_recover_c64_dev": _RECOVER, "qh_bps_recover_c128_dev": _RECOVER,
+    "qh_bps_recover_part_c64_dev": _RECOVER + [_i, _i], "qh_bps_recover_part_c128_dev": _RECOVER + [_i, _i],
     "qh_comp_freq_offset_c64": [_vp, _i, _i64, _vp, _i, _vp], "qh_comp_freq_offset_c128": [_vp, _i, _i64, _vp, _i, _vp],
     "qh_pilot_phase_trace_c64": [_vp, _i, _i64, _vp, _vp, _i, _vp, _vp], "qh_pilot_phase_trace_c128": [_vp, _i, _i64, _vp, _vp, _i, _vp, _vp],
     "qh_select_angles_f32": _SELECT, "qh_select_angles_f64": _SELECT,
@@ -113,7 +114,7 @@ SIGNATURES = {
 }
 
 PIT_MAXPASS, PIT_MAXCHUNK = 24, 32
-ABI_VERSION = 8              # QH_ABI_VERSION of include/qampy_hip.h
+ABI_VERSION = 9              # QH_ABI_VERSION of include/qampy_hip.h
 
 
 class PitOpts(C.Structure):
@@ -122,11 +123,15 @@ class PitOpts(C.Structure):
                 ("tol", C.c_double), ("gear", C.c_double), ("acq_bound", C.c_double), ("acq_plateau", C.c_double),
                 ("acq_chunk", C.c_int64), ("acq_max", C.c_int64), ("correction", C.c_int32), ("head_steps", C.c_int32), ("basis", C.c_void_p), ("corr_beta", C.c_double),
                 ("seg_first", C.c_int32), ("seg_count", C.c_int32), ("exchange", C.c_void_p), ("exchange_user", C.c_void_p),
-                ("start", C.c_int32), ("exchange_on_stream", C.c_int32), ("dev_safety", C.c_double), ("adaptive", C.c_int32), ("exact_redo_off", C.c_int32), ("head_auto_off", C.c_int32), ("acq_anneal", C.c_int32), ("mu_hint", C.c_double), ("prepared", C.c_void_p), ("on_pass0", C.c_void_p), ("on_pass0_user", C.c_void_p)]
+                ("start", C.c_int32), ("exchange_on_stream", C.c_int32), ("dev_safety", C.c_double), ("adaptive", C.c_int32), ("exact_redo_off", C.c_int32), ("head_auto_off", C.c_int32), ("acq_anneal", C.c_int32), ("mu_hint", C.c_double), ("prepared", C.c_void_p), ("on_pass0", C.c_void_p), ("on_pass0_user", C.c_void_p),
+                ("on_pass", C.c_void_p), ("on_pass_user", C.c_void_p)]
 
 
 #: signature of ``qh_pit_opts.on_pass0``: (user) -> None
 PIT_HOOK = C.CFUNCTYPE(None, C.c_void_p)
+
+#: signature of ``qh_pit_opts.on_pass``: (user, sweep, pass) -> None
+PIT_PASS_HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int)
 
 #: signature of ``qh_pit_opts.exchange``: (user, device pointer of the segments' end taps, bytes) -> 0
 PIT_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)

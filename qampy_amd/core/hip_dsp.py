@@ -58,17 +58,24 @@ def test_angle_grid(Mtestangles, rt):
     return np.linspace(-np.pi / 4, np.pi / 4, int(Mtestangles), endpoint=False, dtype=rt).reshape(1, -1)
 
 
-def bps_recover_dev(E, Mtestangles, symbols, N, idx, ph, Eout, angles=None):
+def bps_recover_dev(E, Mtestangles, symbols, N, idx, ph, Eout, angles=None, part=0, nparts=1):
     """
     Device-resident carrier recovery of all modes at once: BPS index, grid look-up, ``np.unwrap`` of the interior and
     de-rotation (host layer qampy/core/phaserecovery.py:145-159) without leaving HBM.  All arguments except the integers
     are DeviceArrays: E, Eout (nmodes, L) complex; ph (nmodes, L) real; idx (nmodes, L) int32; ``angles`` the (A,) grid of
     :func:`test_angle_grid` (``None``: formed on the device in the signal's precision).
+
+    ``part`` / ``nparts``: the work in ``nparts`` calls (``qh_bps_recover_part_*_dev``) - parts ``0 .. nparts - 2`` search a run of the signal each,
+    the last one searches the rest, unwraps and de-rotates; same results, see ``ResidentReceiver.run(overlap=True)`` for what it is good for.
     """
     suf, rt, ct = _lib.suffix(E.dtype)
     nm, L = E.shape
-    _lib.call("qh_bps_recover_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, nm, L, angles.ptr if angles is not None else None,
-              int(Mtestangles), symbols.ptr, int(np.prod(symbols.shape)), int(N), idx.ptr, ph.ptr, Eout.ptr)
+    if nparts == 1:
+        _lib.call("qh_bps_recover_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, nm, L, angles.ptr if angles is not None else None,
+                  int(Mtestangles), symbols.ptr, int(np.prod(symbols.shape)), int(N), idx.ptr, ph.ptr, Eout.ptr)
+    else:
+        _lib.call("qh_bps_recover_part_c" + ("64" if suf == "32" else "128") + "_dev", E.ptr, nm, L, angles.ptr if angles is not None else None,
+                  int(Mtestangles), symbols.ptr, int(np.prod(symbols.shape)), int(N), idx.ptr, ph.ptr, Eout.ptr, int(part), int(nparts))
 
 
 def bps_recover(E, Mtestangles, symbols, N):

@@ -283,6 +283,7 @@ struct BpsStreamArgs {
     int32_t *idx;                // (nm, L)
     int64_t L;
     int A, M, N, C, alpha_lds;
+    int chunk0;                  // chunk of block 0 (a launch may cover a part of the chunks: bps_dev's part / nparts)
     // REC (search + np.unwrap + de-rotation in this one kernel): per-symbol phase and recovered symbols out, and the look-back cells
     float *ph;                   // (nm, L)
     Cx<float> *Eout;             // (nm, L)
@@ -337,7 +338,7 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
     const int64_t L = a.L;
     const Cx<float> *E = a.E + (size_t)blockIdx.y * L;
     int32_t *idx = a.idx + (size_t)blockIdx.y * L;
-    const int64_t c0 = (int64_t)blockIdx.x * a.C;
+    const int64_t c0 = (int64_t)(blockIdx.x + a.chunk0) * a.C;
     const int64_t c1 = c0 + a.C < L ? c0 + a.C : L;                   // outputs [c0, c1)
     const int ngroups = (a.C + W - 1 + (REC ? 1 : 0) + BS_G - 1) / BS_G;      // REC: one output more at the front (the jump into the chunk needs index c0 - 1)
     const int64_t lstart = c0 + a.C - 1 + a.N - (int64_t)ngroups * BS_G + 1;   // first distance row; row l completes the window of output l - N
@@ -543,8 +544,11 @@ template <> inline bool bps_stream_ok<float>(int64_t p, int A, int N, int M)
 // nm rows of length L (consecutive in memory) against one angle grid; idx likewise
 template <typename R>
 int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, const void *symbols, int M, int N, int32_t *idx, int nm = 1,
-            void *ph = nullptr, void *Eout = nullptr, bool *recovered = nullptr)
+            void *ph = nullptr, void *Eout = nullptr, bool *recovered = nullptr, int part = 0, int nparts = 1)
 {
+    // part / nparts (streaming kernel only): this call searches the part-th of nparts runs of chunks - a caller that wants the search in
+    // pieces (between the relaxation passes of the next capture's training, pipeline.py) makes nparts calls; the alphabet is analysed by
+    // part 0 (scratch slot 3 of the calling thread: nothing else of this thread may search in between).  Other kernels: part nparts - 1 does it all.
     if (recovered) *recovered = false;
     int rc = ensure_init();
     if (rc) return rc;
@@ -552,10 +556,14 @@ int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, cons
     QH_REQUIRE(p == 1 || p == L, "bps: p must be either 1 or the length of the input signal");
     QH_REQUIRE(p == 1 || nm == 1, "bps: a per-symbol angle grid goes with a single row");
     if (L == 0) return QH_OK;
+    QH_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "bps: bad part of the search");
+    const bool stream = bps_stream_ok<R>(p, A, N, M);
+    if (!stream && part != nparts - 1) return QH_OK;
     void *desc = nullptr;
     if ((rc = scratch(3, sizeof(AlphabetDesc<R>), &desc))) return rc;
-    hipLaunchKernelGGL((analyse_alphabet_kernel<R>), dim3(1), dim3(64), 0, g_stream, (const Cx<R> *)symbols, M, (AlphabetDesc<R> *)desc);
-    if (bps_stream_ok<R>(p, A, N, M)) {
+    if (!stream || part == 0)
+        hipLaunchKernelGGL((analyse_alphabet_kernel<R>), dim3(1), dim3(64), 0, g_stream, (const Cx<R> *)symbols, M, (AlphabetDesc<R> *)desc);
+    if (stream) {
         BpsStreamArgs s;
         s.E = (const Cx<float> *)E; s.angles = (const float *)angles; s.symbols = (const Cx<float> *)symbols;
         s.desc = (const AlphabetDesc<float> *)desc; s.idx = idx; s.L = L; s.A = A; s.M = M; s.N = N;
@@ -568,8 +576,10 @@ int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, cons
         // sincos, second pass over the symbols) is a latency chain inside a kernel whose speed is the number of waves a CU holds.
         const char *fe = getenv("QAMPY_HIP_BPS_FUSED");
         const int fused = (fe && fe[0] == '1') ? 1 : 0;
-        const bool rec = fused && ph != nullptr && Eout != nullptr && A <= 255;
+        const bool rec = fused && ph != nullptr && Eout != nullptr && A <= 255 && nparts == 1;
         const unsigned nchunk = (unsigned)((L + C - 1) / C);
+        const unsigned ch0 = (unsigned)((uint64_t)nchunk * part / nparts), ch1 = (unsigned)((uint64_t)nchunk * (part + 1) / nparts);
+        s.chunk0 = (int)ch0;
         s.ph = (float *)ph; s.Eout = (Cx<float> *)Eout; s.state = nullptr;
         if (rec) {
             void *st = nullptr;
@@ -586,7 +596,7 @@ int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, cons
             sattr = true;
         }
         if (rec) hipLaunchKernelGGL(bps_stream_kernel<true>, dim3(nchunk, nm), dim3(64), lds, g_stream, s);
-        else hipLaunchKernelGGL(bps_stream_kernel<false>, dim3(nchunk, nm), dim3(64), lds, g_stream, s);
+        else if (ch1 > ch0) hipLaunchKernelGGL(bps_stream_kernel<false>, dim3(ch1 - ch0, nm), dim3(64), lds, g_stream, s);
         if (recovered) *recovered = rec;
         QH_HIP(hipGetLastError());
         return QH_OK;
@@ -781,21 +791,26 @@ template <typename R> __global__ void linspace_kernel(R *angles, int A)
 // angles: the (A,) test-angle grid in HBM as the host layer builds it (np.linspace in double, cast to the signal's precision,
 // phaserecovery.py:145), or nullptr for a grid formed on the device in the signal's precision
 template <typename R>
-int bps_recover_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *symbols, int M, int N, int32_t *idx, void *ph, void *Eout)
+int bps_recover_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *symbols, int M, int N, int32_t *idx, void *ph, void *Eout,
+                    int part = 0, int nparts = 1)
 {
     int rc = ensure_init();
     if (rc) return rc;
     QH_REQUIRE(nm >= 1 && L >= 1 && A >= 1, "bps_recover: bad sizes");
+    // in pieces (qh_bps_recover_part_*): parts 0 .. nparts - 2 search a run of chunks each, the last part searches the rest, unwraps and de-rotates;
+    // a grid formed on the device is formed by part 0 and stays in scratch slot 0 of the calling thread
+    QH_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "bps_recover: bad part");
     const int64_t nchunk = (L + UW_CHUNK - 1) / UW_CHUNK;
     void *dang = const_cast<void *>(angles), *dchunk = nullptr;     // grow-only library scratch: no allocation / sync in the steady state
     if ((rc = scratch(1, (size_t)nm * nchunk * sizeof(int), &dchunk))) return rc;
     if (!dang) {
         if ((rc = scratch(0, (size_t)A * sizeof(R), &dang))) return rc;
-        hipLaunchKernelGGL((linspace_kernel<R>), dim3((A + 63) / 64), dim3(64), 0, g_stream, (R *)dang, A);
+        if (part == 0) hipLaunchKernelGGL((linspace_kernel<R>), dim3((A + 63) / 64), dim3(64), 0, g_stream, (R *)dang, A);
     }
     bool recovered = false;
-    if ((rc = bps_dev<R>(E, L, dang, 1, A, symbols, M, N, idx, nm, ph, Eout, &recovered))) return rc;
+    if ((rc = bps_dev<R>(E, L, dang, 1, A, symbols, M, N, idx, nm, ph, Eout, &recovered, part, nparts))) return rc;
     if (recovered) return QH_OK;                                   // the streaming kernel unwrapped and de-rotated as well
+    if (part != nparts - 1) return QH_OK;
     hipLaunchKernelGGL((unwrap_partial_kernel<R>), dim3((unsigned)nchunk, nm), dim3(UW_THREADS), 0, g_stream, idx, L, N, (const R *)dang,
                        (int *)dchunk, nchunk);
     hipLaunchKernelGGL(unwrap_scan_kernel, dim3(nm), dim3(1024), 0, g_stream, (int *)dchunk, nchunk);
@@ -1000,6 +1015,10 @@ int qh_bps_recover_c64_dev(const void *E, int nm, int64_t L, const void *angles,
 { return qh::bps_recover_dev<float>(E, nm, L, angles, A, s, M, N, idx, ph, Eout); }
 int qh_bps_recover_c128_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *s, int M, int N, int32_t *idx, void *ph, void *Eout)
 { return qh::bps_recover_dev<double>(E, nm, L, angles, A, s, M, N, idx, ph, Eout); }
+int qh_bps_recover_part_c64_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *s, int M, int N, int32_t *idx, void *ph, void *Eout, int part, int nparts)
+{ return qh::bps_recover_dev<float>(E, nm, L, angles, A, s, M, N, idx, ph, Eout, part, nparts); }
+int qh_bps_recover_part_c128_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *s, int M, int N, int32_t *idx, void *ph, void *Eout, int part, int nparts)
+{ return qh::bps_recover_dev<double>(E, nm, L, angles, A, s, M, N, idx, ph, Eout, part, nparts); }
 int qh_select_angles_f32(const void *angles, int64_t p, int A, const int64_t *idx, int64_t L, void *out)
 { return qh::select_angles_host<float>(angles, p, A, idx, L, out); }
 int qh_select_angles_f64(const void *angles, int64_t p, int A, const int64_t *idx, int64_t L, void *out)

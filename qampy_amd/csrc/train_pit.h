@@ -2794,6 +2794,11 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 { int r = launch_any<R>(ts); if (r) return r; }
             }
             if (timed(p)) QH_HIP(hipEventRecord(ev.t1[p], g_stream));
+            if (o.on_pass) {                                        // the caller's chip-wide work for the analysis gap behind this trainer launch (other streams)
+                hipStream_t keep = g_stream;
+                o.on_pass(o.on_pass_user, it, p);
+                g_stream = keep;
+            }
             if (split) {
                 // one capture over several processes: the end taps of the segments trained elsewhere arrive through the caller's
                 // all-reduce (zeros here, the trained taps there); from then on every process works on identical data

@@ -395,7 +395,9 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     // of the same CU stay empty - each of the pair then issues every other turn (measured: 783 instead of 553 cycles per step).
     // Naming the last VGPR and one AGPR as clobbered pushes the allocation past half the register file, so that a second wave
     // never fits (any layout, any precision; with more chains than SIMDs the waves queue up and still run alone).
+#ifndef QH_SEG_DUAL                                             // (build switch for measurements: two waves may share a SIMD)
     asm volatile("" ::: "v255", "a0");                          // allocation = 256 VGPRs + the first AGPR granule > half the file
+#endif
     // What CAN share the SIMD is a narrow streaming kernel of another stream (the phase search of the previous capture, 64 registers a
     // wave: pipeline.py run(overlap=True)); this wave is the latency-bound one, so it goes first whenever both have an instruction ready.
     __builtin_amdgcn_s_setprio(3);
@@ -613,10 +615,17 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
                                                                                      qn[p0], qn[nl > 1 ? p0 + 1 : p0]);
                     // c = mu e(y) and w += c conj(x)
                     v2 c1;
-                    if constexpr (la_errfn_is_dy<METHOD> && !chk) {
-                        const auto d = seg_errfn_d<METHOD, NPART>(sq, K, Ks);
-                        if constexpr (sizeof(d) == sizeof(R)) { v2 dd = __builtin_nondeterministic_value(dd); dd.x = d; c1 = seg_block_b2<TPL, NR, true>(x, w, y, dd, tailmask); }
-                        else c1 = seg_block_b2<TPL, NR, false>(x, w, y, d, tailmask);
+                    if constexpr (la_errfn_is_dy<METHOD>) {
+                        // (the same arithmetic with and without the end-of-segment test: which waves take which variant depends on how the chains of a
+                        // launch fall into waves, and the result of a chain must not - a capture split over several processes trains other runs of chains)
+                        auto d = seg_errfn_d<METHOD, NPART>(sq, K, Ks);
+                        if constexpr (sizeof(d) == sizeof(R)) {
+                            if (chk && gstep >= my_steps) d = 0;                    // past the end of this chain's segment: nothing moves
+                            v2 dd = __builtin_nondeterministic_value(dd); dd.x = d; c1 = seg_block_b2<TPL, NR, true>(x, w, y, dd, tailmask);
+                        } else {
+                            if (chk && gstep >= my_steps) d = v2{0, 0};
+                            c1 = seg_block_b2<TPL, NR, false>(x, w, y, d, tailmask);
+                        }
                     } else {
                         Cx<R> cc = la_errfn<R, METHOD, NPART, true>(Cx<R>{y.x, y.y}, K);
                         if (chk && gstep >= my_steps) cc = Cx<R>{0, 0};              // past the end of this chain's segment: nothing moves

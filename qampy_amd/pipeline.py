@@ -14,6 +14,8 @@ Layout in HBM (complex64 for the headline configs):
     eq       (nmodes, N)            equalised, decimated signal, N = (L - Nt + 1)//os
     idx, ph, out (nmodes, N)        BPS index, applied phase, phase-recovered symbols
 """
+import os as _os
+
 import numpy as np
 
 from . import _lib
@@ -43,6 +45,9 @@ class ResidentReceiver:
                  TrSyms=(None, None), Mtestangles=64, Nbps=20, dtype=np.complex64, alphabet=None, modes=None, tier="a", pit=None):
         suf, self.rt, self.ct = _lib.suffix(dtype)
         self.nmodes, self.L, self.os, self.M, self.Ntaps = int(nmodes), int(L), int(os), int(M), int(Ntaps)
+        # run(overlap=True), tier b: the pending phase search in parts between the next capture's relaxation passes.  0: as many parts as the previous
+        # capture had passes, less one; 1: one launch beside the first passes (rounds 3-4); n > 1: n parts.  (QAMPY_POST_PARTS: initial value, measurements)
+        self.post_parts = int(_os.environ.get("QAMPY_POST_PARTS", "0"))
         self.nstage = len(methods)
         self.methods = tuple(m.lower() for m in methods)
         for m in self.methods:
@@ -169,10 +174,13 @@ class ResidentReceiver:
             for o in self.pit:
                 o["basis"] = self._basis.ptr
 
-    def train(self, stage, hook=None):
+    def train(self, stage, hook=None, pass_hook=None):
         """``hook`` (tier b): a callable the library invokes once, right after it has enqueued the sweep's first relaxation pass
         (``qh_pit_opts.on_pass0``) - work for the other library streams is enqueued there, while the device is busy, instead of in front of
-        this sweep's launches; called after the sweep if the library never got to a first pass (exact form)."""
+        this sweep's launches; called after the sweep if the library never got to a first pass (exact form).
+
+        ``pass_hook(sweep, p)`` (tier b): invoked right after the trainer launch of EVERY relaxation pass (``qh_pit_opts.on_pass``) - see
+        ``run(overlap=True)``."""
         tb = self.tier == "b"
         self._bound()
         opts = {k: v for k, v in self.pit[stage].items() if not k.startswith("_")} if tb else None
@@ -180,6 +188,18 @@ class ResidentReceiver:
             opts["prepared"] = self._use_prep.ptr
             self._use_prep = None
         fired, failed = [False], []
+        if pass_hook is not None and tb:
+            import ctypes as _C
+
+            def _pcb(_user, sweep, p):
+                try:
+                    pass_hook(int(sweep), int(p))
+                except BaseException as e:            # (never through the C frames: re-raised below)
+                    failed.append(e)
+                finally:
+                    _lib.call("qh_use_stream", 0)
+            self._pass_hook_keepalive = _lib.PIT_PASS_HOOK(_pcb)
+            opts["on_pass"] = _C.cast(self._pass_hook_keepalive, _C.c_void_p).value
         if hook is not None and tb:
             import ctypes as _C
 
@@ -236,9 +256,9 @@ class ResidentReceiver:
         self._bound()
         _k.apply_filter_to_signal_dev(self.E, self.os, self.wxy, self.modes, self.eq)
 
-    def _recover(self):
+    def _recover(self, part=0, nparts=1):
         self._bound()
-        _dsp.bps_recover_dev(self.eq, self.Mtestangles, self.alphabet, self.Nbps, self.idx, self.ph, self.out, angles=self.angles)
+        _dsp.bps_recover_dev(self.eq, self.Mtestangles, self.alphabet, self.Nbps, self.idx, self.ph, self.out, angles=self.angles, part=part, nparts=nparts)
 
     # ------------------------------------------------------------------------------------------ the next capture's sequential prologue, ahead of time
     def load_next(self, E):
@@ -278,6 +298,8 @@ class ResidentReceiver:
             _lib.call("qh_stream_wait_event", self._ev_main.ptr)
             if getattr(self, "_post_running", False):
                 _lib.call("qh_stream_wait_event", self._ev_post.ptr)        # (the previous capture's phase search: see run)
+            if getattr(self, "_hook_calls", 0) > 0:
+                _lib.call("qh_stream_wait_event", self._ev_pass.ptr)        # (phase search in parts: the chip-wide covariance kernel starts behind a trainer launch, like the parts)
             ok = _k.pit_prepare_dev(nxt, self.TrSyms[0], self.os, self.mu_init[0], self.wxy0, self.modes, self.symbols[0], self.methods[0],
                                     {k: v for k, v in o.items() if not k.startswith("_") and k not in ("basis", "prepared")}, self._prep[slot])
             if ok:
@@ -334,9 +356,32 @@ class ResidentReceiver:
             self._use_prep = None
             self.build_gram()
         m("gram")
+        # The pending phase search IN PARTS (tier b): one part behind each relaxation pass of this capture's training (pass_hook below).  A pass keeps
+        # the chip's SIMDs busy with one latency-bound wave each, and a chip-wide streaming kernel beside it costs it a third of its speed (every one
+        # of its instructions may find the SIMD taken for four cycles: 0.36 instead of 0.27 ms per pass, profiles/r05_c3_timeline.txt); the ~70 us
+        # of analysis between two passes run on a handful of CUs.  A part is gated by an event behind the pass's trainer launch, so it starts when
+        # the trainer is done and is through - or nearly - when the next one starts.  Number of parts: the trainer launches of the previous capture less
+        # two (one may have been enqueued in vain ahead of the decision that ended a sweep; the last part also unwraps and de-rotates and should not
+        # hold up this capture's filter, which overwrites what it reads: C3, 5 + 4 passes, 1 / 5 / 6 / 8 / 10 / 12 parts: 1046 / 1056 / 1083 / 1086 /
+        # 1037 / 977 MSym/s on one box); what is left when the training is over is enqueued then.  Bit-identical to one launch.
+        parts_mode = self.tier == "b" and int(getattr(self, "post_parts", 0)) != 1
+        self._hook_calls = 0
+        if parts_mode and getattr(self, "_post_pending", False):
+            fixed = int(getattr(self, "post_parts", 0))
+            self._post_n = fixed if fixed > 1 else max(1, min(16, int(getattr(self, "_hook_calls_prev", 10)) - 2))
+            self._post_next, self._post_mark = 0, m
+        if getattr(self, "_ev_pass", None) is None:
+            self._ev_pass = _lib.Event()
+
+        def on_pass(sweep, p):
+            self._hook_calls += 1
+            self._ev_pass.record()                # stream 0: behind the trainer launch of this pass
+            if getattr(self, "_post_pending", False) and parts_mode:
+                self._post_part(gated=True)
 
         def side_work():
-            self._enqueue_post(m)                 # phase search of the previous overlapped pass, beside the stages below
+            if not parts_mode:
+                self._enqueue_post(m)             # phase search of the previous overlapped pass, beside the stages below
             if prefetch:
                 # ... and BEHIND that phase search: started together with it, the next capture's covariance kernel (chip-wide, streaming), eigen-solver
                 # and acquisition crowd the first pass of this capture - 454 instead of 290 us, the model kernels 319 instead of 47
@@ -352,8 +397,11 @@ class ResidentReceiver:
         if not defer:
             side_work()
         for s in range(self.nstage):
-            self.train(s, hook=side_work if (defer and s == 0) else None)
+            self.train(s, hook=side_work if (defer and s == 0) else None, pass_hook=on_pass if parts_mode else None)
             m("train%d" % s)
+        if parts_mode:
+            self._hook_calls_prev = self._hook_calls if self._hook_calls > 0 else getattr(self, "_hook_calls_prev", 9)
+            self._enqueue_post(m)                 # parts the passes did not take
         if getattr(self, "_post_running", False):
             _lib.call("qh_stream_wait_event", self._ev_post.ptr)        # the filter output of the previous pass has been consumed
             self._post_running = False
@@ -374,10 +422,41 @@ class ResidentReceiver:
             self._ev_ready, self._ev_post = _lib.Event(), _lib.Event()
         self._ev_ready.record()                   # stream 0 up to here: the filter output the pending phase search reads
         self._post_pending = True
+        self._post_n = self._post_next = 0        # (not started: the next run decides whether it goes in parts)
+
+    def _post_part(self, gated):
+        """The next part of the pending phase search onto stream 2; ``gated``: behind ``_ev_pass`` (the trainer launch of the pass that just went
+        onto stream 0)."""
+        i, n = self._post_next, self._post_n
+        mark = getattr(self, "_post_mark", None)
+        _lib.call("qh_use_stream", 2)
+        try:
+            if gated:
+                _lib.call("qh_stream_wait_event", self._ev_pass.ptr)
+            if i == 0:
+                _lib.call("qh_stream_wait_event", self._ev_ready.ptr)      # the filter output the search reads
+                if mark:
+                    mark("post_begin")
+            self._recover(part=i, nparts=n)
+            if i == n - 1:
+                if mark:
+                    mark("post_end")
+                self._ev_post.record()
+        finally:
+            _lib.call("qh_use_stream", 0)
+        self._post_next = i + 1
+        if i == n - 1:
+            self._post_pending, self._post_running = False, True
 
     def _enqueue_post(self, mark=None):
         if not getattr(self, "_post_pending", False):
             return
+        if getattr(self, "_post_n", 0) and getattr(self, "_post_next", 0) > 0:      # a search already under way in parts: the rest of them, now
+            while getattr(self, "_post_pending", False):
+                self._post_part(gated=False)
+            self._post_n = 0
+            return
+        self._post_n = 0
         _lib.call("qh_use_stream", 2)             # (_ev_ready: recorded behind the filter of the pass whose phase search is pending)
         try:
             _lib.call("qh_stream_wait_event", self._ev_ready.ptr)
@@ -458,6 +537,12 @@ class ReceiverGroup:
         self._sync = sync if sync is not None else _lib.sync
         self._release = release if release is not None else (lambda: _lib.call("qh_thread_release"))
         self.rx = [(factory or ResidentReceiver)(*args, **kw) for _ in range(int(n))]
+        if len(self.rx) > 1:
+            # several captures in flight fill one another's gaps; a phase search held back for the gaps of ONE of them only waits (C3, three receivers:
+            # 1175 MSym/s with the search in one launch, 993 in parts)
+            for r in self.rx:
+                if hasattr(r, "post_parts") and "QAMPY_POST_PARTS" not in _os.environ:
+                    r.post_parts = 1
         self._sync()
         self._jobs = [queue.SimpleQueue() for _ in self.rx]
         self._done = queue.SimpleQueue()
