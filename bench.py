@@ -70,7 +70,7 @@ WORKLOADS["c5"] = dict(M=256, nsym=2 ** 16, ntaps=45, methods=("cma", "sbd_data"
                        label="pilot-based 256-QAM 2-pol 2 SPS, 2^16-symbol frames: frame sync + data-aided pilot equaliser + filter + pilot phase recovery")
 VALU_PEAK_TFLOPS = 157.3        # fp32 vector (packed FMA), MI355X_MICROARCH.md
 VALU_PEAK_GINSTR = 614.4        # wave64 fp32 instructions per second, nominal: 1024 SIMDs x 2.4 GHz / 4 cycles (measured, clock-throttled ceilings: 697 plain v_fma, 537 v_pk_fma - profiles/r02_ubench_issue.txt)
-SEG_INSTR_PER_WAVE_STEP = {16: 66, 8: 82}    # train_seg_kernel main loop per wave and step by lanes per chain (ISA count incl. s_nop / s_waitcnt at 41 taps x 2 modes; the counters of profiles/pmc_instr_*.json replace it when they belong to these sources)
+SEG_INSTR_PER_WAVE_STEP = {16: 51, 8: 82}    # train_seg_kernel main loop per wave and step by lanes per chain (ISA count incl. s_nop / s_waitcnt / ds_read at 41 taps x 2 modes, cma, DESIGN.md 3.2.2: 43 VALU + 5 s_nop + 2 ds_read + 0.6 s_waitcnt at 16 lanes since round 5; the counters of profiles/pmc_instr_*.json replace it when they belong to these sources)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FUSED_BYTES_PER_SYM = 88   # read E once, write err1, err2, out, ph (complex64, 2 modes, 2 samples/symbol)
 SER_TOL_ERRORS = 3         # decisions: tier b's symbol errors per mode within this many of the exact path's (ONE of the checks; see run_pair)

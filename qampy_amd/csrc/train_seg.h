@@ -36,6 +36,7 @@ template <typename R> struct SegArgs {
     const int *skip;
     int q_first, q_count;          // chains [q_first, q_first + q_count) of the S * nsel are trained by this launch (q_count = 0: all)
     int lpm, pitch, rag, nslots;   // lanes per input mode, LDS row pitch (samples), padding taps in the last lane of a mode, segment windows per wave
+    int ch;                        // steps per staged chunk (SG_CH, or SG_CH_LONG where the layout has the longer rows and the filter fits them)
     // adaptive step (ADAPT kernels, pythran_equalisation.py:12-16, :171-172): per chain r = 1 / mu and the previous error at the start of
     // its segment in, at the end out, and the sum of the step sizes its steps used (the coarse model's mu T); adapt_first = 0: the
     // sweep's step 0 belongs to this grid (no adaptation after it)
@@ -380,6 +381,11 @@ __device__ __forceinline__ auto seg_errfn_d(sg_f2 sq, const LaConst<float, NPART
 
 constexpr int SG_PITCH = 192;      // samples per LDS row (one segment window of one input mode): 3 pieces of 64
 constexpr int SG_PIECES = SG_PITCH / 64;
+// The 16-lane layout in single precision (fixed step) stages chunks of 128 steps where they fit - rows of 5 pieces: what a chunk costs beside its steps
+// (address arithmetic of the staging loads, stores, the two fences, the first window, the dispatch on the padding count) is ~170 vector instructions,
+// 2.6 per step at 64 steps per chunk - 6 % of the wave's instruction stream (SQ_INSTS_VALU 45.7 per step against 43.1 in the unrolled loop).
+constexpr int SG_CH_LONG = 128, SG_PITCH_LONG = 320;
+template <typename R, int LPC, bool ADAPT> struct SgRow { static constexpr int pitch = (sizeof(R) == 4 && LPC == 16 && !ADAPT) ? SG_PITCH_LONG : SG_PITCH; };
 // rows per buffer (segment windows of the wave x input modes) = chains per wave; staging registers per lane = rows x pieces
 constexpr int SG_MAXRAG = 3;       // padding taps a lane may hold (handled by selects on its last three tap slots)
 
@@ -388,7 +394,9 @@ template <typename R, int METHOD, int NPART, int TPL, int LPC, bool ADAPT = fals
 __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
 {
     constexpr int CPW = 64 / LPC;                               // chains per wave
-    constexpr int SG_ROWS = ADAPT ? 2 * CPW : CPW, SG_NSTG = SG_ROWS * SG_PIECES;   // (ADAPT: one output mode per launch - every chain of the wave its own segment window)
+    constexpr int PITCH = SgRow<R, LPC, ADAPT>::pitch, PIECES = PITCH / 64;
+    constexpr int SG_ROWS = ADAPT ? 2 * CPW : CPW, SG_NSTG = SG_ROWS * PIECES;   // (ADAPT: one output mode per launch - every chain of the wave its own segment window)
+    const int CH = a.ch;                                         // steps per staged chunk
     if (a.skip && *a.skip) return;
     // One wave per SIMD, by construction.  A launch of this kernel has about as many single-wave workgroups as the chip has SIMDs
     // (992 at C3's mrde stage); with <= 256 VGPRs two of them fit on a SIMD and the dispatcher does pair them up while other SIMDs
@@ -402,7 +410,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     // wave: pipeline.py run(overlap=True)); this wave is the latency-bound one, so it goes first whenever both have an instruction ready.
     __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) char sg_smem[];
-    Cx<R> *lds = reinterpret_cast<Cx<R> *>(sg_smem);          // [SG_ROWS][SG_PITCH] + zero row [SG_PITCH]  (ONE buffer: the next chunk waits in registers
+    Cx<R> *lds = reinterpret_cast<Cx<R> *>(sg_smem);          // [SG_ROWS][PITCH] + zero row [PITCH]  (ONE buffer: the next chunk waits in registers
                                                               // while this one computes and is stored after it - one wave per workgroup, LDS operations in program order)
     using v2 = typename V2<R>::type;
     const int lane = threadIdx.x;
@@ -456,9 +464,9 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     bool ad_skip0 = false;                                      // this chain's step 0 is step 0 of the sweep: no adaptation after it
     if constexpr (ADAPT) { ad_r = a.r_in[qc]; ad_ep = a.e_in[qc]; ad_skip0 = a.adapt_first == 0 && my_start == 0; }
 
-    // ---- LDS windows: SG_ROWS rows of SG_PITCH samples per buffer, one per (segment window, input mode)
-    constexpr int rowsz = SG_PITCH;
-    constexpr int bufsz = SG_ROWS * SG_PITCH;
+    // ---- LDS windows: SG_ROWS rows of PITCH samples per buffer, one per (segment window, input mode)
+    constexpr int rowsz = PITCH;
+    constexpr int bufsz = SG_ROWS * PITCH;
     const int nrow = nslot * a.nmodes;                          // <= SG_ROWS (checked on the host)
     Cx<R> *zero_row = lds + bufsz;
     for (int e = lane; e < rowsz; e += 64) zero_row[e] = Cx<R>{0, 0};
@@ -473,10 +481,10 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
     Cx<R> stg_r[SG_NSTG];
     // global loads of chunk `chunk` into registers (no wait) ...
     auto stage_load = [&](int chunk) __attribute__((always_inline)) {
-        const int64_t adv = (int64_t)chunk * SG_CH * os_;
+        const int64_t adv = (int64_t)chunk * CH * os_;
 #pragma unroll
         for (int u = 0; u < SG_NSTG; u++) {
-            const int row = u / SG_PIECES, piece = u % SG_PIECES;
+            const int row = u / PIECES, piece = u % PIECES;
             if (row < nrow) {
                 int64_t g = rowbase[row] + adv + piece * 64 + lane;
                 if (g > rowlim[row]) g = rowlim[row];           // reads stay inside their row of the capture
@@ -489,7 +497,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         Cx<R> *dst = lds;
 #pragma unroll
         for (int u = 0; u < SG_NSTG; u++)
-            if (u / SG_PIECES < nrow) dst[u * 64 + lane] = stg_r[u];
+            if (u / PIECES < nrow) dst[u * 64 + lane] = stg_r[u];
     };
     Cx<R> *errow = a.err + (size_t)mode * a.err_pitch + a.err_off + my_start;
     // The error of a step is the same in all lanes of its chain; lane l keeps the error of step l of a group of LPC steps (two
@@ -686,7 +694,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         }
     };
 
-    const int nchunk = (max_steps + SG_CH - 1) / SG_CH;
+    const int nchunk = (max_steps + CH - 1) / CH;
     stage_load(0);
     stage_store(0);
     __syncthreads();
@@ -694,8 +702,8 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         if (c + 1 < nchunk) stage_load(c + 1);                  // in flight while this chunk computes
         const Cx<R> *xs = has ? lds + (slot * a.nmodes + kin) * rowsz + t0 : zero_row;
         const int xstep = has ? os_ : 0;
-        const int ibase = c * SG_CH;
-        const int nst = (max_steps - ibase) < SG_CH ? (max_steps - ibase) : SG_CH;
+        const int ibase = c * CH;
+        const int nst = (max_steps - ibase) < CH ? (max_steps - ibase) : CH;
         auto run2 = [&](auto RG, auto OS2) __attribute__((always_inline)) {
             if (ibase + nst <= min_steps) run_chunk(xs, xstep, ibase, nst, SgInt<0>{}, RG, OS2);
             else run_chunk(xs, xstep, ibase, nst, SgInt<1>{}, RG, OS2);
@@ -867,9 +875,11 @@ template <typename R> int launch_seg(SegArgs<R> a, int method, bool adaptive = f
     const int tpl = seg_tpl(a.nmodes, a.ntaps, lpc);
     a.lpm = (a.ntaps + tpl - 1) / tpl;
     a.rag = a.lpm * tpl - a.ntaps;
-    a.pitch = SG_PITCH;
+    const bool long_rows = sizeof(R) == 4 && lpc == 16 && !adaptive;          // SgRow<R, LPC, ADAPT>::pitch
+    a.pitch = long_rows ? SG_PITCH_LONG : SG_PITCH;
+    a.ch = (long_rows && (SG_CH_LONG + 4) * a.os + a.ntaps + 8 <= SG_PITCH_LONG) ? SG_CH_LONG : SG_CH;
     a.nslots = seg_slots(a.nsel, cpw);
-    const size_t lds = (size_t)((adaptive ? 2 * cpw : cpw) + 1) * SG_PITCH * sizeof(Cx<R>);
+    const size_t lds = (size_t)((adaptive ? 2 * cpw : cpw) + 1) * a.pitch * sizeof(Cx<R>);
     dim3 grid((nq + cpw - 1) / cpw);
     const int npart = (int)(a.nsy - (a.nsy + 1) / 2);
     int rc;

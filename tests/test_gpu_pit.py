@@ -530,6 +530,63 @@ def test_overlapped_passes_give_the_results_of_one_capture_at_a_time(tier):
         assert np.array_equal(res0[k], serial[0][k]), (tier, k, "plain run after overlapped ones")
 
 
+@pytest.mark.parametrize("parts", [1, 3, 8, 16])
+def test_phase_search_in_parts_between_the_passes_is_bit_identical(parts):
+    """run(overlap=True), tier b: the pending phase search goes onto stream 2 in `post_parts` parts, one behind each trainer launch of the next capture
+    (qh_pit_opts.on_pass, qh_bps_recover_part_c64_dev); more parts than passes: the rest when the training is over.  Three captures handed over one
+    after the other: every result bit for bit that of one capture at a time."""
+    nsym, M, ntaps, mu = 2 ** 17, 64, 41, (1e-3, 5e-4)
+    caps = [synth.make_capture_dev(M, nsym, nmodes=2, snr_db=30, theta=np.pi / 5.6, dgd=30e-12, linewidth=100., seed=sd) for sd in (1000, 1003, 1001)]
+    kw = dict(methods=("cma", "mrde"), Niter=(1, 1), Mtestangles=64, Nbps=20, alphabet=caps[0]["alphabet_host"])
+    rx = ResidentReceiver(2, 2 * nsym, 2, M, ntaps, mu, tier="b", **kw)
+    serial = []
+    for c in caps:
+        rx.E.copy_from(c["E"])
+        rx.run()
+        serial.append(rx.fetch())
+    rx.post_parts = parts
+    got = []
+    for i, c in enumerate(caps):
+        rx.E.copy_from(c["E"])
+        rx.run(overlap=True)                    # the search of capture i - 1 in parts between this capture's passes
+        if i > 0:
+            _lib.sync()
+            got.append({k: getattr(rx, k).to_host() for k in ("out", "ph", "idx")})
+    got.append(rx.fetch())                      # the search of the last capture: pending until here
+    for i in range(len(caps)):
+        for k in ("out", "ph", "idx"):
+            assert np.array_equal(got[i][k], serial[i][k]), (parts, i, k)
+    for k in ("wxy", "eq"):
+        assert np.array_equal(got[-1][k], serial[-1][k]), (parts, k)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_bps_recover_in_parts_equals_one_call(dtype):
+    """qh_bps_recover_part_*_dev: nparts calls give what one call gives (streaming kernel: a run of chunks per part; the other kernels: the last part
+    does it all)."""
+    from qampy_amd.core import hip_dsp
+    from qampy_amd import theory
+    rng = np.random.default_rng(5)
+    M, L, A, N = 16, 70001, 32, 12
+    sy = theory.cal_symbols_qam(M).astype(dtype)
+    sy /= np.sqrt(np.mean(np.abs(sy) ** 2))
+    ph = np.cumsum(rng.normal(0, 2e-2, (2, L)), axis=1)
+    E = (sy[rng.integers(0, M, (2, L))] * np.exp(1j * ph) + 0.05 * (rng.normal(size=(2, L)) + 1j * rng.normal(size=(2, L)))).astype(dtype)
+    D = _lib.DeviceArray
+    rt = np.float32 if dtype == np.complex64 else np.float64
+    dE, dsy, dang = D.from_host(E), D.from_host(sy), D.from_host(hip_dsp.test_angle_grid(A, rt))
+    res = []
+    for nparts in (1, 2, 7):
+        idx, pho, out = D((2, L), np.int32), D((2, L), rt), D((2, L), dtype)
+        for part in range(nparts):
+            hip_dsp.bps_recover_dev(dE, A, dsy, N, idx, pho, out, angles=dang, part=part, nparts=nparts)
+        _lib.sync()
+        res.append((idx.to_host(), pho.to_host(), out.to_host()))
+    for r in res[1:]:
+        for a, b in zip(r, res[0]):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("tier", ["a", "b"])
 def test_receiver_group_gives_every_capture_the_single_receiver_result(tier):
     """pipeline.ReceiverGroup: two captures in flight, one host thread and one set of library streams / scratch buffers each (csrc/api.hip keeps
