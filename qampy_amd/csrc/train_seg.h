@@ -384,6 +384,8 @@ constexpr int SG_PIECES = SG_PITCH / 64;
 // The 16-lane layout in single precision (fixed step) stages chunks of 128 steps where they fit - rows of 5 pieces: what a chunk costs beside its steps
 // (address arithmetic of the staging loads, stores, the two fences, the first window, the dispatch on the padding count) is ~170 vector instructions,
 // 2.6 per step at 64 steps per chunk - 6 % of the wave's instruction stream (SQ_INSTS_VALU 45.7 per step against 43.1 in the unrolled loop).
+// (256 steps per chunk - 23 KiB of LDS per wave - are faster one capture at a time, 4.48 against 4.57 ms, and slower over consecutive captures: the phase
+// search beside the passes is bound by the waves a CU holds, i.e. by the LDS the passes leave it - 976 against 1107 MSym/s)
 constexpr int SG_CH_LONG = 128, SG_PITCH_LONG = 320;
 template <typename R, int LPC, bool ADAPT> struct SgRow { static constexpr int pitch = (sizeof(R) == 4 && LPC == 16 && !ADAPT) ? SG_PITCH_LONG : SG_PITCH; };
 // rows per buffer (segment windows of the wave x input modes) = chains per wave; staging registers per lane = rows x pieces
