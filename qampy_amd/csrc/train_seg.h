@@ -202,20 +202,22 @@ typedef float sg_f4 __attribute__((ext_vector_type(4)));
 // x[0 .. TPL), w[0 .. TPL): the samples and taps of this step; y: the chain's output, in every lane (the pair v[246:247]: the DPP adds write its
 // halves, what follows reads it as a packed operand), sq = (y.re^2, y.im^2) - every blind error function starts with it, and behind the block's
 // last DPP add it costs no wait state; ebr / ebi: the lane's slot of the trace group, (per, pei) parked there in the lanes of mask mk; d0, d1:
-// window pieces read from LDS address la + O0 (+ 16)
-template <int TPL, bool KEEP, int NL, int O0>
+// window pieces read from LDS address la + O0 (+ 16); xm0 .. xm[NR - 1]: the samples of the NR padding taps (the last ones) times tm - 0 in the
+// last lane of an input mode, 1 elsewhere: block B updates the padding taps with THOSE, so they stay the zeros they start as, and zeroing them
+// costs a wait state of the tree instead of an instruction of block B.
+// The 32 statements (taps per lane x KEEP x pieces x padding taps) are written by scripts/gen_seg_blocks.py, which fills the wait states of the
+// sums and of the tree from one list of independent instructions in a fixed order.
+template <int TPL, bool KEEP, int NL, int NR, int O0>
 __device__ __forceinline__ void seg_block_a(const sg_f2 (&x)[TPL], const sg_f2 (&w)[TPL], sg_f2 &y, sg_f2 &sq, float &ebr, float &ebi,
-                                            float per, float pei, unsigned long long mk, unsigned la, sg_f4 &d0, sg_f4 &d1)
+                                            float per, float pei, unsigned long long mk, unsigned la, sg_f4 &d0, sg_f4 &d1, sg_f2 tm, sg_f2 &xm0, sg_f2 &xm1, sg_f2 &xm2)
 {
-    static_assert((TPL == 4 || TPL == 6) && (NL == 1 || NL == 2), "layouts with 4 or 6 taps per lane: one or two window pieces per step");
-#define SG_A(DOT, IN) \
-    if constexpr (KEEP && NL == 1) asm volatile(DOT SG_K1 : [y] "={v[246:247]}"(y), [sq] "=&v"(sq) SG_KOUT_, [d0] "=&v"(d0) : IN SG_KIN_, [o0] "n"(O0) : SG_CLOB_); \
-    else if constexpr (KEEP) asm volatile(DOT SG_K2 : [y] "={v[246:247]}"(y), [sq] "=&v"(sq) SG_KOUT_, [d0] "=&v"(d0), [d1] "=&v"(d1) : IN SG_KIN_, [o0] "n"(O0), [o1] "n"(O0 + 16) : SG_CLOB_); \
-    else if constexpr (NL == 1) asm volatile(DOT SG_F1 : [y] "={v[246:247]}"(y), [sq] "=&v"(sq), [d0] "=&v"(d0) : IN, [o0] "n"(O0) : SG_CLOB_); \
-    else asm volatile(DOT SG_F2 : [y] "={v[246:247]}"(y), [sq] "=&v"(sq), [d0] "=&v"(d0), [d1] "=&v"(d1) : IN, [o0] "n"(O0), [o1] "n"(O0 + 16) : SG_CLOB_);
-    if constexpr (TPL == 4) { SG_A(SG_DOT4, SG_IN4_) } else { SG_A(SG_DOT6, SG_IN6_) }
-#undef SG_A
+    static_assert((TPL == 4 || TPL == 6) && (NL == 1 || NL == 2) && NR >= 0 && NR <= 3, "layouts with 4 or 6 taps per lane: one or two window pieces per step, up to three padding taps");
+#include "train_seg_blocks.inc"
     if constexpr (!KEEP) { (void)ebr; (void)ebi; (void)per; (void)pei; (void)mk; }
+    if constexpr (NL < 2) (void)d1;
+    if constexpr (NR < 1) { (void)tm; (void)xm0; }
+    if constexpr (NR < 2) (void)xm1;
+    if constexpr (NR < 3) (void)xm2;
 }
 // block B: w[j] += x[j].re (c.re, c.im) + x[j].im (cr.re, cr.im) with cr = (c.im, -c.re); the NR padding taps (the last ones) times tm = 0 / 1
 #define SG_UR(j) "v_pk_fma_f32 %[w" #j "], %[x" #j "], %[c], %[w" #j "] op_sel_hi:[0,1,1]\n\t"
@@ -620,9 +622,12 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
                         const sg_f4 v = q[(OFF + j) >> 1];
                         x[j] = ((OFF + j) & 1) ? v2{v.z, v.w} : v2{v.x, v.y};
                     }
-                    v2 y, sq;
-                    seg_block_a<TPL, (ku >= 0), nl, decltype(BOFF)::value + 16 * p0>(x, w, y, sq, ebr, ebi, pend.re, pend.im, mks[ku >= 0 ? ku : 0], la,
-                                                                                     qn[p0], qn[nl > 1 ? p0 + 1 : p0]);
+                    v2 y, sq, xm0, xm1, xm2;
+                    seg_block_a<TPL, (ku >= 0), nl, NR, decltype(BOFF)::value + 16 * p0>(x, w, y, sq, ebr, ebi, pend.re, pend.im, mks[ku >= 0 ? ku : 0], la,
+                                                                                         qn[p0], qn[nl > 1 ? p0 + 1 : p0], tailmask, xm0, xm1, xm2);
+                    if constexpr (NR >= 1) x[TPL - 1] = xm0;                  // (the padding taps are updated with masked samples: they stay zero)
+                    if constexpr (NR >= 2) x[TPL - 2] = xm1;
+                    if constexpr (NR >= 3) x[TPL - 3] = xm2;
                     // c = mu e(y) and w += c conj(x)
                     v2 c1;
                     if constexpr (la_errfn_is_dy<METHOD>) {
@@ -631,16 +636,16 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
                         auto d = seg_errfn_d<METHOD, NPART>(sq, K, Ks);
                         if constexpr (sizeof(d) == sizeof(R)) {
                             if (chk && gstep >= my_steps) d = 0;                    // past the end of this chain's segment: nothing moves
-                            v2 dd = __builtin_nondeterministic_value(dd); dd.x = d; c1 = seg_block_b2<TPL, NR, true>(x, w, y, dd, tailmask);
+                            v2 dd = __builtin_nondeterministic_value(dd); dd.x = d; c1 = seg_block_b2<TPL, 0, true>(x, w, y, dd, tailmask);
                         } else {
                             if (chk && gstep >= my_steps) d = v2{0, 0};
-                            c1 = seg_block_b2<TPL, NR, false>(x, w, y, d, tailmask);
+                            c1 = seg_block_b2<TPL, 0, false>(x, w, y, d, tailmask);
                         }
                     } else {
                         Cx<R> cc = la_errfn<R, METHOD, NPART, true>(Cx<R>{y.x, y.y}, K);
                         if (chk && gstep >= my_steps) cc = Cx<R>{0, 0};              // past the end of this chain's segment: nothing moves
                         c1 = v2{cc.re, cc.im};
-                        seg_block_b<TPL, NR>(x, w, c1, v2{cc.im, -cc.re}, tailmask);
+                        seg_block_b<TPL, 0>(x, w, c1, v2{cc.im, -cc.re}, tailmask);
                     }
                     return Cx<R>{c1.x, c1.y};
                 };
