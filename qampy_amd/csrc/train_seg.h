@@ -219,6 +219,21 @@ __device__ __forceinline__ void seg_block_a(const sg_f2 (&x)[TPL], const sg_f2 (
     if constexpr (NR < 2) (void)xm1;
     if constexpr (NR < 3) (void)xm2;
 }
+// block B of the previous step (its samples xp - padding taps masked -, its output yp and factor dp: c = dp yp) and block A of this step in ONE
+// statement: the compiler has nothing to pad between them.  c lives in v[244:245] for the tap update and for the selects that park it (lane mask mk);
+// written by scripts/gen_seg_blocks.py like block A.
+template <int TPL, bool D1, int NL, int NR, int O0>
+__device__ __forceinline__ void seg_block_ba(const sg_f2 (&xp)[TPL], sg_f2 yp, sg_f2 dp, const sg_f2 (&x)[TPL], sg_f2 (&w)[TPL], sg_f2 &y, sg_f2 &sq, float &ebr, float &ebi,
+                                             unsigned long long mk, unsigned la, sg_f4 &d0, sg_f4 &d1, sg_f2 tm, sg_f2 &xm0, sg_f2 &xm1, sg_f2 &xm2)
+{
+    static_assert((TPL == 4 || TPL == 6) && (NL == 1 || NL == 2) && NR >= 0 && NR <= 3, "layouts with 4 or 6 taps per lane: one or two window pieces per step, up to three padding taps");
+    sg_f2 cr;
+#include "train_seg_blocks_ba.inc"
+    if constexpr (NL < 2) (void)d1;
+    if constexpr (NR < 1) { (void)tm; (void)xm0; }
+    if constexpr (NR < 2) (void)xm1;
+    if constexpr (NR < 3) (void)xm2;
+}
 // block B: w[j] += x[j].re (c.re, c.im) + x[j].im (cr.re, cr.im) with cr = (c.im, -c.re); the NR padding taps (the last ones) times tm = 0 / 1
 #define SG_UR(j) "v_pk_fma_f32 %[w" #j "], %[x" #j "], %[c], %[w" #j "] op_sel_hi:[0,1,1]\n\t"
 #define SG_UI(j) "v_pk_fma_f32 %[w" #j "], %[x" #j "], %[cr], %[w" #j "] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
@@ -612,6 +627,10 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
                 unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(const char *)xs;   // LDS byte address of step i's window
 #pragma unroll
                 for (int j = 0; j < NQ; j++) qa[j] = xq[j];
+                // The steps are software-pipelined by half a step: block B of step i - 1 and block A of step i are ONE statement (seg_block_ba) wherever
+                // the error function has the form d(y) y, so a group of 16 steps is  A | e B+A e B+A ... e B+A e | B  - (xp, yp, dp) carry step i - 1's samples
+                // (padding taps masked), output and factor to it.  Other error functions: A, e, B per step.
+                v2 xp[TPL], yp = v2{0, 0}, dp = v2{0, 0};
                 auto fstep = [&](auto XO, sg_f4 (&q)[NQ], sg_f4 (&qn)[NQ], auto P0, auto NL_, auto BOFF, auto KU, Cx<R> pend, int gstep) __attribute__((always_inline)) -> Cx<R> {
                     constexpr int OFF = decltype(XO)::value, p0 = decltype(P0)::value, nl = decltype(NL_)::value, ku = decltype(KU)::value;
                     constexpr bool chk = decltype(CHK)::value != 0;
@@ -623,24 +642,33 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
                         x[j] = ((OFF + j) & 1) ? v2{v.z, v.w} : v2{v.x, v.y};
                     }
                     v2 y, sq, xm0, xm1, xm2;
-                    seg_block_a<TPL, (ku >= 0), nl, NR, decltype(BOFF)::value + 16 * p0>(x, w, y, sq, ebr, ebi, pend.re, pend.im, mks[ku >= 0 ? ku : 0], la,
+                    if constexpr (la_errfn_is_dy<METHOD> && ku >= 0) {
+                        constexpr bool d1 = sizeof(decltype(seg_errfn_d<METHOD, NPART>(sq, K, Ks))) == sizeof(R);
+                        seg_block_ba<TPL, d1, nl, NR, decltype(BOFF)::value + 16 * p0>(xp, yp, dp, x, w, y, sq, ebr, ebi, mks[ku >= 0 ? ku : 0], la,
                                                                                          qn[p0], qn[nl > 1 ? p0 + 1 : p0], tailmask, xm0, xm1, xm2);
+                    } else {
+                        seg_block_a<TPL, (ku >= 0), nl, NR, decltype(BOFF)::value + 16 * p0>(x, w, y, sq, ebr, ebi, pend.re, pend.im, mks[ku >= 0 ? ku : 0], la,
+                                                                                             qn[p0], qn[nl > 1 ? p0 + 1 : p0], tailmask, xm0, xm1, xm2);
+                    }
                     if constexpr (NR >= 1) x[TPL - 1] = xm0;                  // (the padding taps are updated with masked samples: they stay zero)
                     if constexpr (NR >= 2) x[TPL - 2] = xm1;
                     if constexpr (NR >= 3) x[TPL - 3] = xm2;
                     // c = mu e(y) and w += c conj(x)
-                    v2 c1;
+                    v2 c1 = v2{0, 0};
                     if constexpr (la_errfn_is_dy<METHOD>) {
                         // (the same arithmetic with and without the end-of-segment test: which waves take which variant depends on how the chains of a
                         // launch fall into waves, and the result of a chain must not - a capture split over several processes trains other runs of chains)
                         auto d = seg_errfn_d<METHOD, NPART>(sq, K, Ks);
                         if constexpr (sizeof(d) == sizeof(R)) {
                             if (chk && gstep >= my_steps) d = 0;                    // past the end of this chain's segment: nothing moves
-                            v2 dd = __builtin_nondeterministic_value(dd); dd.x = d; c1 = seg_block_b2<TPL, 0, true>(x, w, y, dd, tailmask);
+                            dp = __builtin_nondeterministic_value(dp); dp.x = d;
                         } else {
                             if (chk && gstep >= my_steps) d = v2{0, 0};
-                            c1 = seg_block_b2<TPL, 0, false>(x, w, y, d, tailmask);
+                            dp = d;
                         }
+                        yp = y;                                                     // block B of this step: in front of the next step's block A, or behind the group
+#pragma unroll
+                        for (int j = 0; j < TPL; j++) xp[j] = x[j];
                     } else {
                         Cx<R> cc = la_errfn<R, METHOD, NPART, true>(Cx<R>{y.x, y.y}, K);
                         if (chk && gstep >= my_steps) cc = Cx<R>{0, 0};              // past the end of this chain's segment: nothing moves
@@ -648,6 +676,12 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
                         seg_block_b<TPL, 0>(x, w, c1, v2{cc.im, -cc.re}, tailmask);
                     }
                     return Cx<R>{c1.x, c1.y};
+                };
+                // block B of the last step of a group (error functions of the form d(y) y); returns its c = mu e
+                auto last_b = [&]() __attribute__((always_inline)) -> Cx<R> {
+                    constexpr bool d1 = sizeof(decltype(seg_errfn_d<METHOD, NPART>(yp, K, Ks))) == sizeof(R);
+                    const v2 c = seg_block_b2<TPL, 0, d1>(xp, w, yp, dp, tailmask);
+                    return Cx<R>{c.x, c.y};
                 };
                 for (; i + LPC <= nst; i += LPC) {
                     Cx<R> pend{0, 0};
@@ -662,6 +696,7 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
                         sg_wait_lds(qa);
                     };
                     quad(SgInt<0>{}); quad(SgInt<4>{}); quad(SgInt<8>{}); quad(SgInt<12>{});
+                    if constexpr (la_errfn_is_dy<METHOD>) pend = last_b();
                     keep(pend, LPC - 1);
                     const int gi = ibase + i + l16;
                     if (gi < my_steps) stg(errow + gi, Cx<R>{ebr * inv_mu, ebi * inv_mu});

@@ -59,6 +59,31 @@ def block(tpl, keep, nl, nr):
     return body
 
 
+def block_b(tpl, d1, xname="xp"):
+    """block B in front of block A of the next step (one statement: no padding between the two): c = d y into v[244:245] (the selects of the
+    A part park it), its rotated copy, the two rounds of the tap update with the PREVIOUS step's samples"""
+    if d1:
+        s = ["v_pk_mul_f32 v[244:245], %[yp], %[dp] op_sel_hi:[1,0]", "v_pk_mul_f32 %[cr], %[yp], %[dp] op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]"]
+    else:
+        s = ["v_pk_mul_f32 v[244:245], %[yp], %[dp]", "v_pk_mul_f32 %[cr], %[yp], %[dp] op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]"]
+    s += ["v_pk_fma_f32 %%[w%d], %%[%s%d], v[244:245], %%[w%d] op_sel_hi:[0,1,1]" % (j, xname, j, j) for j in range(tpl)]
+    s += ["v_pk_fma_f32 %%[w%d], %%[%s%d], %%[cr], %%[w%d] op_sel:[1,0,0] op_sel_hi:[1,1,1]" % (j, xname, j, j) for j in range(tpl)]
+    return s
+
+
+def operands_ba(tpl, nl, nr):
+    outs = ['[y] "={v[246:247]}"(y)', '[sq] "=&v"(sq)', '[cr] "=&v"(cr)', '[ebr] "+v"(ebr)', '[ebi] "+v"(ebi)']
+    outs += ['[w%d] "+v"(w[%d])' % (j, j) for j in range(tpl)]
+    outs += ['[d%d] "=&v"(d%d)' % (k, k) for k in range(nl)]
+    outs += ['[xm%d] "=&v"(xm%d)' % (k, k) for k in range(nr)]
+    ins = ['[x%d] "v"(x[%d])' % (j, j) for j in range(tpl)] + ['[xp%d] "v"(xp[%d])' % (j, j) for j in range(tpl)]
+    ins += ['[yp] "v"(yp)', '[dp] "v"(dp)', '[la] "v"(la)', '[mk] "s"(mk)']
+    if nr:
+        ins.append('[tm] "v"(tm)')
+    ins += ['[o%d] "n"(O0 + %d)' % (k, 16 * k) for k in range(nl)]
+    return outs, ins
+
+
 def operands(tpl, keep, nl, nr):
     outs = ['[y] "={v[246:247]}"(y)', '[sq] "=&v"(sq)']
     if keep:
@@ -99,6 +124,31 @@ def main():
     with open(OUT, "w") as f:
         f.write("\n".join(lines) + "\n")
     print("wrote", OUT, len(lines), "lines")
+    # ---- block B of step i - 1 and block A of step i in ONE statement (seg_block_ba)
+    lines = ["// GENERATED by scripts/gen_seg_blocks.py - do not edit.  Block B of the previous step followed by block A of this one (train_seg.h: seg_block_ba):",
+             "// one statement, so that the compiler has nothing to pad between them.  c = d y of the previous step lives in v[244:245]: the tap update reads it and the",
+             "// selects of the A part park it (KEEP is implied: there is a previous step)."]
+    first = True
+    for tpl in (4, 6):
+        for d1 in (1, 0):
+            for nl in (1, 2):
+                for nr in range(0, 4):
+                    body = block_b(tpl, d1) + [i.replace("%[per]", "v244").replace("%[pei]", "v245") for i in block(tpl, 1, nl, nr)]
+                    outs, ins = operands_ba(tpl, nl, nr)
+                    cond = "TPL == %d && %sD1 && NL == %d && NR == %d" % (tpl, "" if d1 else "!", nl, nr)
+                    lines.append("%sif constexpr (%s)" % ("" if first else "else ", cond))
+                    first = False
+                    lines.append("    asm volatile(")
+                    for ins_ in body:
+                        lines.append('        "%s\\n\\t"' % ins_)
+                    lines.append("        : %s" % ", ".join(outs))
+                    lines.append("        : %s" % ", ".join(ins))
+                    lines.append('        : "memory", "v244", "v245", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");')
+    lines.append('else static_assert(TPL == 4 || TPL == 6, "blocks B + A: layouts with 4 or 6 taps per lane");')
+    out2 = OUT.replace("train_seg_blocks.inc", "train_seg_blocks_ba.inc")
+    with open(out2, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("wrote", out2, len(lines), "lines")
 
 
 if __name__ == "__main__":
