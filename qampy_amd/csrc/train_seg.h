@@ -147,58 +147,25 @@ template <int LPC, typename R> __device__ __forceinline__ void chain_csum(R &re,
 }
 
 
-// ---- one step of the 16-lane layout as two hand-scheduled blocks (single precision, 4 or 6 taps per lane, unrolled groups of steps)
-// A lone wave issues one instruction per turn of its SIMD (~4.3 cycles) whatever the instruction is - an s_nop costs as much as
+// ---- one step of the 16-lane layout as hand-scheduled blocks (single precision, 4 or 6 taps per lane, unrolled groups of steps)
+// A lone wave issues one instruction per turn of its SIMD (~5 cycles) whatever the instruction is - an s_nop costs as much as
 // a packed FMA - and gfx950 wants 2 wait states between a VALU write and a DPP read of it and 1 after every packed operation
 // before its result is read.  Round 4's step paid 8 s_nop and 2 s_waitcnt for that (58 issue slots, 46 of them VALU), most of them
 // padding the compiler puts around inline-assembly instructions: to it they are opaque nodes that it places anywhere and then pads
 // (an operand written by the instruction right before an asm statement costs an s_nop, whatever the statement does with it).  So the
-// step is TWO statements with the error function (the compiler's) in between, and each schedules itself:
+// step is made of statements that schedule themselves, with the error function (the compiler's) in between:
 //   block A  y = sum w x over the lane's taps as P = sum x.re w, R = sum x.im w on the even / odd taps (four accumulators, every FMA
 //            four instructions after the one it depends on), P0 + P1, R0 + R1, y = P + i R (ONE packed add with a rotated, half-negated
-//            operand), the four DPP levels.  The wait states in there hold work that has to be done anyway and does not depend on it:
-//            the two selects that park the PREVIOUS step's error in its lane of the trace group (KEEP) and the ds_read_b128 of the
-//            window of the NEXT pair of steps (NL of them, at immediate offsets from one address register per group - the compiler is
-//            out of the LDS business in this loop, so it also stops placing an s_waitcnt before every first use: one per pair, sg_wait_lds);
-//   block B  w += c conj(x) as two rounds of packed FMAs, x.re (c.re, c.im) and x.im (c.im, -c.re) - the rotated copy of c comes from
-//            the error function's factors with one more packed multiply (pk_rot_mul) - and the zeroing of the padding taps, ordered so
-//            that nothing reads what the instruction before it wrote, block A of the next step included.
-// v[248:255] are scratch of block A (the halves of a packed sum feed the DPP adds; operands of inline assembly have no sub-registers to name).
+//            operand), the four DPP levels, (y.re^2, y.im^2).  The wait states in there hold work that has to be done anyway and does
+//            not depend on it: the two selects that park the PREVIOUS step's error in its lane of the trace group (KEEP), the
+//            ds_read_b128 of the window of the NEXT pair of steps (NL of them, at immediate offsets from one address register per group -
+//            the compiler is out of the LDS business in this loop, so it also stops placing an s_waitcnt before every first use: one
+//            per pair, sg_wait_lds), the samples of the padding taps times the lane's 0 / 1 mask;
+//   block B  c = d y and its rotated copy, then w += c conj(x) as two rounds of packed FMAs, x.re (c.re, c.im) and x.im (c.im, -c.re),
+//            a tap's second FMA TPL - 1 instructions behind its first - in ONE statement with block A of the next step (seg_block_ba).
+// v[244:255] are scratch of the blocks (the halves of a packed sum feed the DPP adds and the selects; operands of inline assembly have no
+// sub-registers to name).  DESIGN.md 3.2.2.
 typedef float sg_f4 __attribute__((ext_vector_type(4)));
-#define SG_PRE "v_pk_mul_f32 v[248:249], %[x0], %[w0] op_sel_hi:[0,1]\n\t" \
-               "v_pk_mul_f32 v[250:251], %[x0], %[w0] op_sel:[1,0] op_sel_hi:[1,1]\n\t" \
-               "v_pk_mul_f32 v[252:253], %[x1], %[w1] op_sel_hi:[0,1]\n\t" \
-               "v_pk_mul_f32 v[254:255], %[x1], %[w1] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
-#define SG_EV(j) "v_pk_fma_f32 v[248:249], %[x" #j "], %[w" #j "], v[248:249] op_sel_hi:[0,1,1]\n\t" \
-                 "v_pk_fma_f32 v[250:251], %[x" #j "], %[w" #j "], v[250:251] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-#define SG_OD(j) "v_pk_fma_f32 v[252:253], %[x" #j "], %[w" #j "], v[252:253] op_sel_hi:[0,1,1]\n\t" \
-                 "v_pk_fma_f32 v[254:255], %[x" #j "], %[w" #j "], v[254:255] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-#define SG_DOT4 SG_PRE SG_EV(2) SG_OD(3)
-#define SG_DOT6 SG_PRE SG_EV(2) SG_OD(3) SG_EV(4) SG_OD(5)
-#define SG_SUMP "v_pk_add_f32 v[248:249], v[248:249], v[252:253]\n\t"
-#define SG_SUMR "v_pk_add_f32 v[250:251], v[250:251], v[254:255]\n\t"
-#define SG_SUMY "v_pk_add_f32 v[254:255], v[248:249], v[250:251] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
-#define SG_LV(ctl) "v_add_f32_dpp v254, v254, v254 " ctl " row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp v255, v255, v255 " ctl " row_mask:0xf bank_mask:0xf\n\t"
-#define SG_L1 SG_LV("quad_perm:[1,0,3,2]")
-#define SG_L2 SG_LV("quad_perm:[2,3,0,1]")
-#define SG_L3 SG_LV("row_half_mirror")
-#define SG_L4 "v_add_f32_dpp v246, v254, v254 row_mirror row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp v247, v255, v255 row_mirror row_mask:0xf bank_mask:0xf\n\t" \
-              "v_pk_mul_f32 %[sq], v[246:247], v[246:247]\n\t"
-#define SG_KR "v_cndmask_b32_e64 %[ebr], %[ebr], %[per], %[mk]\n\t"
-#define SG_KI "v_cndmask_b32_e64 %[ebi], %[ebi], %[pei], %[mk]\n\t"
-#define SG_LD(n) "ds_read_b128 %[d" #n "], %[la] offset:%[o" #n "]\n\t"
-#define SG_N0 "s_nop 0\n\t"
-#define SG_N1 "s_nop 1\n\t"
-// the sums, the parked error, the window pieces and the tree, by (KEEP, NL)
-#define SG_K1 SG_SUMP SG_KR SG_SUMR SG_KI SG_SUMY SG_LD(0) SG_N0 SG_L1 SG_N0 SG_L2 SG_N0 SG_L3 SG_N0 SG_L4
-#define SG_K2 SG_SUMP SG_KR SG_SUMR SG_KI SG_SUMY SG_LD(0) SG_LD(1) SG_L1 SG_N0 SG_L2 SG_N0 SG_L3 SG_N0 SG_L4
-#define SG_F1 SG_SUMP SG_LD(0) SG_SUMR SG_N0 SG_SUMY SG_N1 SG_L1 SG_N0 SG_L2 SG_N0 SG_L3 SG_N0 SG_L4
-#define SG_F2 SG_SUMP SG_LD(0) SG_SUMR SG_LD(1) SG_SUMY SG_N1 SG_L1 SG_N0 SG_L2 SG_N0 SG_L3 SG_N0 SG_L4
-#define SG_IN4_ [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [w0] "v"(w[0]), [w1] "v"(w[1]), [w2] "v"(w[2]), [w3] "v"(w[3]), [la] "v"(la)
-#define SG_IN6_ SG_IN4_, [x4] "v"(x[4]), [x5] "v"(x[5]), [w4] "v"(w[4]), [w5] "v"(w[5])
-#define SG_KOUT_ , [ebr] "+v"(ebr), [ebi] "+v"(ebi)
-#define SG_KIN_ , [per] "v"(per), [pei] "v"(pei), [mk] "s"(mk)
-#define SG_CLOB_ "memory", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 // x[0 .. TPL), w[0 .. TPL): the samples and taps of this step; y: the chain's output, in every lane (the pair v[246:247]: the DPP adds write its
 // halves, what follows reads it as a packed operand), sq = (y.re^2, y.im^2) - every blind error function starts with it, and behind the block's
 // last DPP add it costs no wait state; ebr / ebi: the lane's slot of the trace group, (per, pei) parked there in the lanes of mask mk; d0, d1:
@@ -234,34 +201,23 @@ __device__ __forceinline__ void seg_block_ba(const sg_f2 (&xp)[TPL], sg_f2 yp, s
     if constexpr (NR < 2) (void)xm1;
     if constexpr (NR < 3) (void)xm2;
 }
-// block B: w[j] += x[j].re (c.re, c.im) + x[j].im (cr.re, cr.im) with cr = (c.im, -c.re); the NR padding taps (the last ones) times tm = 0 / 1
+// block B on its own (behind the last step of a group, and for the error functions that are not of the form d(y) y): w[j] += x[j].re (c.re, c.im) +
+// x[j].im (cr.re, cr.im) with cr = (c.im, -c.re); x: the step's samples with those of the padding taps masked (block A's xm)
 #define SG_UR(j) "v_pk_fma_f32 %[w" #j "], %[x" #j "], %[c], %[w" #j "] op_sel_hi:[0,1,1]\n\t"
 #define SG_UI(j) "v_pk_fma_f32 %[w" #j "], %[x" #j "], %[cr], %[w" #j "] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
-#define SG_UM(j) "v_pk_mul_f32 %[w" #j "], %[w" #j "], %[tm]\n\t"
 #define SG_W4_ [w0] "+v"(w[0]), [w1] "+v"(w[1]), [w2] "+v"(w[2]), [w3] "+v"(w[3])
 #define SG_W6_ SG_W4_, [w4] "+v"(w[4]), [w5] "+v"(w[5])
 #define SG_X4_ [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [c] "v"(c), [cr] "v"(cr)
 #define SG_X6_ SG_X4_, [x4] "v"(x[4]), [x5] "v"(x[5])
-template <int TPL, int NR>
-__device__ __forceinline__ void seg_block_b(const sg_f2 (&x)[TPL], sg_f2 (&w)[TPL], sg_f2 c, sg_f2 cr, sg_f2 tm)
+template <int TPL>
+__device__ __forceinline__ void seg_block_b(const sg_f2 (&x)[TPL], sg_f2 (&w)[TPL], sg_f2 c, sg_f2 cr)
 {
-    static_assert((TPL == 4 || TPL == 6) && NR >= 0 && NR <= 3, "layouts with 4 or 6 taps per lane, up to three padding taps");
-    // (both rounds start with the padding taps: a tap's second FMA comes TPL - 1 instructions after its first, the zeroing of a padding
-    // tap at least three after its second, and the first instruction of the next block A reads w[0], written at least two before the end)
-    if constexpr (TPL == 6) {
-        if constexpr (NR == 0) asm volatile(SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UR(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UI(5) : SG_W6_ : SG_X6_);
-        else if constexpr (NR == 1) asm volatile(SG_UR(5) SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UI(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UM(5) : SG_W6_ : SG_X6_, [tm] "v"(tm));
-        else if constexpr (NR == 2) asm volatile(SG_UR(5) SG_UR(4) SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UI(5) SG_UI(4) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UM(5) SG_UM(4) : SG_W6_ : SG_X6_, [tm] "v"(tm));
-        else asm volatile(SG_UR(5) SG_UR(4) SG_UR(3) SG_UR(0) SG_UR(1) SG_UR(2) SG_UI(5) SG_UI(4) SG_UI(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UM(5) SG_UM(4) SG_UM(3) : SG_W6_ : SG_X6_, [tm] "v"(tm));
-    } else {
-        if constexpr (NR == 0) asm volatile(SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) : SG_W4_ : SG_X4_);
-        else if constexpr (NR == 1) asm volatile(SG_UR(3) SG_UR(0) SG_UR(1) SG_UR(2) SG_UI(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UM(3) : SG_W4_ : SG_X4_, [tm] "v"(tm));
-        else if constexpr (NR == 2) asm volatile(SG_UR(3) SG_UR(2) SG_UR(0) SG_UR(1) SG_UI(3) SG_UI(2) SG_UI(0) SG_UI(1) SG_UM(3) SG_UM(2) : SG_W4_ : SG_X4_, [tm] "v"(tm));
-        else asm volatile(SG_UR(3) SG_UR(2) SG_UR(1) SG_UR(0) SG_UI(3) SG_UI(2) SG_UI(1) SG_UI(0) SG_UM(3) SG_UM(2) SG_UM(1) : SG_W4_ : SG_X4_, [tm] "v"(tm));
-    }
-    if constexpr (NR == 0) (void)tm;
+    static_assert(TPL == 4 || TPL == 6, "layouts with 4 or 6 taps per lane");
+    // (a tap's second FMA comes TPL - 1 instructions after its first; the first instruction of the next block A reads w[0], written TPL before the end)
+    if constexpr (TPL == 6) asm volatile(SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UR(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UI(5) : SG_W6_ : SG_X6_);
+    else asm volatile(SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) : SG_W4_ : SG_X4_);
 }
-// block B for error functions of the form e = d(y) y: c = mu e and its rotated copy are the block's first two instructions (d: the factor
+// the same for error functions of the form e = d(y) y: c = mu e and its rotated copy are the block's first two instructions (d: the factor
 // with the step size folded in - one per axis, or ONE real factor in the low half of its operand (D1) - written by the compiler's last
 // instruction before the block; c is returned for the trace)
 #define SG_CV "v_pk_mul_f32 %[c], %[yy], %[d]\n\tv_pk_mul_f32 %[cr], %[yy], %[d] op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
@@ -269,26 +225,16 @@ __device__ __forceinline__ void seg_block_b(const sg_f2 (&x)[TPL], sg_f2 (&w)[TP
 #define SG_Y4_ [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [yy] "v"(yy), [d] "v"(d)
 #define SG_Y6_ SG_Y4_, [x4] "v"(x[4]), [x5] "v"(x[5])
 #define SG_CO_ , [c] "=&v"(c), [cr] "=&v"(cr)
-template <int TPL, int NR, bool D1>
-__device__ __forceinline__ sg_f2 seg_block_b2(const sg_f2 (&x)[TPL], sg_f2 (&w)[TPL], sg_f2 yy, sg_f2 d, sg_f2 tm)
+template <int TPL, bool D1>
+__device__ __forceinline__ sg_f2 seg_block_b2(const sg_f2 (&x)[TPL], sg_f2 (&w)[TPL], sg_f2 yy, sg_f2 d)
 {
-    static_assert((TPL == 4 || TPL == 6) && NR >= 0 && NR <= 3, "layouts with 4 or 6 taps per lane, up to three padding taps");
+    static_assert(TPL == 4 || TPL == 6, "layouts with 4 or 6 taps per lane");
     sg_f2 c, cr;
 #define SG_B2(CM) \
-    if constexpr (TPL == 6) { \
-        if constexpr (NR == 0) asm volatile(CM SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UR(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UI(5) : SG_W6_ SG_CO_ : SG_Y6_); \
-        else if constexpr (NR == 1) asm volatile(CM SG_UR(5) SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UI(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UM(5) : SG_W6_ SG_CO_ : SG_Y6_, [tm] "v"(tm)); \
-        else if constexpr (NR == 2) asm volatile(CM SG_UR(5) SG_UR(4) SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UI(5) SG_UI(4) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UM(5) SG_UM(4) : SG_W6_ SG_CO_ : SG_Y6_, [tm] "v"(tm)); \
-        else asm volatile(CM SG_UR(5) SG_UR(4) SG_UR(3) SG_UR(0) SG_UR(1) SG_UR(2) SG_UI(5) SG_UI(4) SG_UI(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UM(5) SG_UM(4) SG_UM(3) : SG_W6_ SG_CO_ : SG_Y6_, [tm] "v"(tm)); \
-    } else { \
-        if constexpr (NR == 0) asm volatile(CM SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) : SG_W4_ SG_CO_ : SG_Y4_); \
-        else if constexpr (NR == 1) asm volatile(CM SG_UR(3) SG_UR(0) SG_UR(1) SG_UR(2) SG_UI(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UM(3) : SG_W4_ SG_CO_ : SG_Y4_, [tm] "v"(tm)); \
-        else if constexpr (NR == 2) asm volatile(CM SG_UR(3) SG_UR(2) SG_UR(0) SG_UR(1) SG_UI(3) SG_UI(2) SG_UI(0) SG_UI(1) SG_UM(3) SG_UM(2) : SG_W4_ SG_CO_ : SG_Y4_, [tm] "v"(tm)); \
-        else asm volatile(CM SG_UR(3) SG_UR(2) SG_UR(1) SG_UR(0) SG_UI(3) SG_UI(2) SG_UI(1) SG_UI(0) SG_UM(3) SG_UM(2) SG_UM(1) : SG_W4_ SG_CO_ : SG_Y4_, [tm] "v"(tm)); \
-    }
+    if constexpr (TPL == 6) asm volatile(CM SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UR(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UI(5) : SG_W6_ SG_CO_ : SG_Y6_); \
+    else asm volatile(CM SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) : SG_W4_ SG_CO_ : SG_Y4_);
     if constexpr (D1) { SG_B2(SG_C1) } else { SG_B2(SG_CV) }
 #undef SG_B2
-    if constexpr (NR == 0) (void)tm;
     return c;
 }
 #undef SG_CV
@@ -296,36 +242,8 @@ __device__ __forceinline__ sg_f2 seg_block_b2(const sg_f2 (&x)[TPL], sg_f2 (&w)[
 #undef SG_Y4_
 #undef SG_Y6_
 #undef SG_CO_
-#undef SG_PRE
-#undef SG_EV
-#undef SG_OD
-#undef SG_DOT4
-#undef SG_DOT6
-#undef SG_SUMP
-#undef SG_SUMR
-#undef SG_SUMY
-#undef SG_LV
-#undef SG_L1
-#undef SG_L2
-#undef SG_L3
-#undef SG_L4
-#undef SG_KR
-#undef SG_KI
-#undef SG_LD
-#undef SG_N0
-#undef SG_N1
-#undef SG_K1
-#undef SG_K2
-#undef SG_F1
-#undef SG_F2
-#undef SG_IN4_
-#undef SG_IN6_
-#undef SG_KOUT_
-#undef SG_KIN_
-#undef SG_CLOB_
 #undef SG_UR
 #undef SG_UI
-#undef SG_UM
 #undef SG_W4_
 #undef SG_W6_
 #undef SG_X4_
@@ -673,14 +591,14 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
                         Cx<R> cc = la_errfn<R, METHOD, NPART, true>(Cx<R>{y.x, y.y}, K);
                         if (chk && gstep >= my_steps) cc = Cx<R>{0, 0};              // past the end of this chain's segment: nothing moves
                         c1 = v2{cc.re, cc.im};
-                        seg_block_b<TPL, 0>(x, w, c1, v2{cc.im, -cc.re}, tailmask);
+                        seg_block_b<TPL>(x, w, c1, v2{cc.im, -cc.re});
                     }
                     return Cx<R>{c1.x, c1.y};
                 };
                 // block B of the last step of a group (error functions of the form d(y) y); returns its c = mu e
                 auto last_b = [&]() __attribute__((always_inline)) -> Cx<R> {
                     constexpr bool d1 = sizeof(decltype(seg_errfn_d<METHOD, NPART>(yp, K, Ks))) == sizeof(R);
-                    const v2 c = seg_block_b2<TPL, 0, d1>(xp, w, yp, dp, tailmask);
+                    const v2 c = seg_block_b2<TPL, d1>(xp, w, yp, dp);
                     return Cx<R>{c.x, c.y};
                 };
                 for (; i + LPC <= nst; i += LPC) {
