@@ -4,7 +4,9 @@
 from one list of independent instructions in a fixed priority.  Run after changing the schedule; the output is committed."""
 import os
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qampy_amd", "csrc", "train_seg_blocks.inc")
+import sys
+
+OUT = os.path.join(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "qampy_amd", "csrc"), "train_seg_blocks.inc")
 
 DPP = " row_mask:0xf bank_mask:0xf"
 
@@ -99,6 +101,57 @@ def operands(tpl, keep, nl, nr):
     return outs, ins
 
 
+# ---- the wait states gfx950 wants, checked on every generated statement (the hardware does not interlock them):
+#   * a register written by a packed operation (v_pk_*) is not read by the NEXT instruction;
+#   * a register written by a VALU instruction is not read through DPP by either of the next TWO instructions.
+def _regs(tok):
+    """registers named by one operand token: v254 -> {v254}; v[248:249] -> {v248, v249}; %[w0] -> {%w0} (a compiler-assigned operand is one unit)"""
+    tok = tok.strip().rstrip(",")
+    if tok.startswith("%["):
+        return {tok[1:].strip("[]")}
+    if tok.startswith("v["):
+        a, b = tok[2:-1].split(":")
+        return {"v%d" % k for k in range(int(a), int(b) + 1)}
+    if tok.startswith("v") and tok[1:].isdigit():
+        return {tok}
+    return set()
+
+
+def _parse(ins):
+    op, rest = ins.split(None, 1) if " " in ins else (ins, "")
+    if op.startswith("s_"):
+        return op, set(), set(), False
+    toks = []
+    for t in rest.replace(", ", ",").split(","):
+        t = t.strip()
+        if t.startswith(("op_sel", "neg_", "quad_perm", "row_", "bank_", "offset")):
+            break
+        toks.append(t.split()[0] if t else t)
+    dst = _regs(toks[0]) if toks else set()
+    src = set().union(*[_regs(t) for t in toks[1:]]) if len(toks) > 1 else set()
+    if op.startswith("ds_read"):
+        src = _regs(toks[1]) if len(toks) > 1 else set()
+    if op.startswith("v_cndmask"):
+        src |= dst                                            # (in-out)
+    return op, dst, src, "_dpp" in op
+
+
+def check(body, what):
+    hist = []                                                 # (op, dst) of the instructions issued so far, s_nop N as N + 1 entries
+    for ins in body:
+        op, dst, src, dpp = _parse(ins)
+        if op == "s_nop":
+            hist += [("s_nop", set())] * (int(ins.split()[1]) + 1)
+            continue
+        if hist:
+            pop, pdst = hist[-1]
+            assert not (pop.startswith("v_pk_") and (pdst & src)), "%s: '%s' reads what the packed operation right before it wrote" % (what, ins)
+        if dpp:
+            for back in hist[-2:]:
+                assert not (back[0].startswith("v_") and (back[1] & src)), "%s: '%s' reads through DPP what one of the two instructions before it wrote" % (what, ins)
+        hist.append((op, dst))
+
+
 def main():
     lines = ["// GENERATED by scripts/gen_seg_blocks.py - do not edit.  Block A of the segment trainer's step (train_seg.h: seg_block_a) for every",
              "// (taps per lane, KEEP, window pieces NL, padding taps NR): the statement's instructions in issue order, one per line.",
@@ -110,6 +163,7 @@ def main():
             for nl in (1, 2):
                 for nr in range(0, 4):
                     body = block(tpl, keep, nl, nr)
+                    check(body, "block A tpl %d keep %d nl %d nr %d" % (tpl, keep, nl, nr))
                     outs, ins = operands(tpl, keep, nl, nr)
                     cond = "TPL == %d && %sKEEP && NL == %d && NR == %d" % (tpl, "" if keep else "!", nl, nr)
                     lines.append("%sif constexpr (%s)" % ("" if first else "else ", cond))
@@ -134,6 +188,7 @@ def main():
             for nl in (1, 2):
                 for nr in range(0, 4):
                     body = block_b(tpl, d1) + [i.replace("%[per]", "v244").replace("%[pei]", "v245") for i in block(tpl, 1, nl, nr)]
+                    check(body, "blocks B + A tpl %d d1 %d nl %d nr %d" % (tpl, d1, nl, nr))
                     outs, ins = operands_ba(tpl, nl, nr)
                     cond = "TPL == %d && %sD1 && NL == %d && NR == %d" % (tpl, "" if d1 else "!", nl, nr)
                     lines.append("%sif constexpr (%s)" % ("" if first else "else ", cond))
