@@ -298,7 +298,7 @@ class ResidentReceiver:
             _lib.call("qh_stream_wait_event", self._ev_main.ptr)
             if getattr(self, "_post_running", False):
                 _lib.call("qh_stream_wait_event", self._ev_post.ptr)        # (the previous capture's phase search: see run)
-            if getattr(self, "_hook_calls", 0) > 0:
+            if getattr(self, "_hook_calls", 0) > 0:                       # (run() recorded it behind the first trainer launch)
                 _lib.call("qh_stream_wait_event", self._ev_pass.ptr)        # (phase search in parts: the chip-wide covariance kernel starts behind a trainer launch, like the parts)
             ok = _k.pit_prepare_dev(nxt, self.TrSyms[0], self.os, self.mu_init[0], self.wxy0, self.modes, self.symbols[0], self.methods[0],
                                     {k: v for k, v in o.items() if not k.startswith("_") and k not in ("basis", "prepared")}, self._prep[slot])
@@ -375,8 +375,10 @@ class ResidentReceiver:
 
         def on_pass(sweep, p):
             self._hook_calls += 1
-            self._ev_pass.record()                # stream 0: behind the trainer launch of this pass
-            if getattr(self, "_post_pending", False) and parts_mode:
+            pend = parts_mode and getattr(self, "_post_pending", False)
+            if pend or (prefetch and self._hook_calls == 1):      # (nothing to gate: no packet on stream 0 either)
+                self._ev_pass.record()            # stream 0: behind the trainer launch of this pass
+            if pend:
                 self._post_part(gated=True)
 
         def side_work():
