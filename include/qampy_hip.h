@@ -211,7 +211,7 @@ int qh_bps_recover_c128_dev(const void *E, int nm, int64_t L, const void *angles
                             void *ph, void *Eout);
 /* the same in `nparts` calls (ABI 9): parts 0 .. nparts - 2 search a run of the signal each, part nparts - 1 searches the rest, unwraps and de-rotates.
  * A receiver that processes capture after capture enqueues one part behind each relaxation pass of the NEXT capture's training (qh_pit_opts.on_pass):
- * the chip-wide search then runs in the short analysis between two passes, where the chip is idle, instead of beside a pass, which it slows down.
+ * a part of an eighth of the search is one wave per SIMD: it starts in the short analysis between two passes and spends the next pass in the issue slots that pass leaves, where the whole search at once slows a pass by a third.
  * Same kernels on the same data: the results do not depend on nparts.  The parts of one search are issued by one thread, in order, on one stream,
  * with no other phase search of that thread in between. */
 int qh_bps_recover_part_c64_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *symbols, int M, int N, int32_t *idx,

@@ -359,8 +359,9 @@ class ResidentReceiver:
         # The pending phase search IN PARTS (tier b): one part behind each relaxation pass of this capture's training (pass_hook below).  A pass keeps
         # the chip's SIMDs busy with one latency-bound wave each, and a chip-wide streaming kernel beside it costs it a third of its speed (every one
         # of its instructions may find the SIMD taken for four cycles: 0.36 instead of 0.27 ms per pass, profiles/r05_c3_timeline.txt); the ~70 us
-        # of analysis between two passes run on a handful of CUs.  A part is gated by an event behind the pass's trainer launch, so it starts when
-        # the trainer is done and is through - or nearly - when the next one starts.  Number of parts: the trainer launches of the previous capture less
+        # of analysis between two passes run on a handful of CUs.  A part is gated by an event behind the pass's trainer launch: it starts when the
+        # trainer is done and - an eighth of the search being one wave per SIMD - spends the next pass in the issue slots that pass leaves (0-3 % of the
+        # pass instead of a third); the events space the parts one pass apart.  Number of parts: the trainer launches of the previous capture less
         # two (one may have been enqueued in vain ahead of the decision that ended a sweep; the last part also unwraps and de-rotates and should not
         # hold up this capture's filter, which overwrites what it reads: C3, 5 + 4 passes, 1 / 5 / 6 / 8 / 10 / 12 parts: 1046 / 1056 / 1083 / 1086 /
         # 1037 / 977 MSym/s on one box); what is left when the training is over is enqueued then.  Bit-identical to one launch.
