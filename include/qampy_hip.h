@@ -210,8 +210,8 @@ int qh_bps_recover_c64_dev(const void *E, int nm, int64_t L, const void *angles,
 int qh_bps_recover_c128_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *symbols, int M, int N, int32_t *idx,
                             void *ph, void *Eout);
 /* the same in `nparts` calls (ABI 9): parts 0 .. nparts - 2 search a run of the signal each, part nparts - 1 searches the rest, unwraps and de-rotates.
- * A receiver that processes capture after capture enqueues one part behind each relaxation pass of the NEXT capture's training (qh_pit_opts.on_pass):
- * a part of an eighth of the search is one wave per SIMD: it starts in the short analysis between two passes and spends the next pass in the issue slots that pass leaves, where the whole search at once slows a pass by a third.
+ * A receiver that processes capture after capture enqueues one part beside each relaxation pass of the NEXT capture's training (qh_pit_opts.on_pass):
+ * a part of an eighth of the search is one wave per SIMD: it starts with a pass's trainer and lives on the issue slots that pass leaves, where the whole search at once slows a pass by a third.
  * Same kernels on the same data: the results do not depend on nparts.  The parts of one search are issued by one thread, in order, on one stream,
  * with no other phase search of that thread in between. */
 int qh_bps_recover_part_c64_dev(const void *E, int nm, int64_t L, const void *angles, int A, const void *symbols, int M, int N, int32_t *idx,
@@ -375,11 +375,12 @@ typedef struct qh_pit_opts {
                              * place to enqueue work for OTHER library streams (the previous capture's phase search, the next capture's preparation) whose
                              * launches would otherwise sit in front of this sweep's; it must leave the current library stream as it found it (ABI 8) */
     void *on_pass0_user;
-    void (*on_pass)(void *user, int sweep, int pass);   /* NULL, or a function the call invokes on the calling thread right after it has enqueued the TRAINER launch of
-                             * relaxation pass `pass` of sweep `sweep` (before the pass's analysis launches): the place to enqueue chip-wide work of other library
-                             * streams behind an event recorded here - it then starts when the trainer is done, in the ~70 us analysis during which the chip is
-                             * otherwise idle (qh_bps_recover_part_*_dev).  A pass enqueued ahead of the decision that ends the sweep still calls it (its launches
-                             * do nothing).  It must leave the current library stream as it found it (ABI 9) */
+    void (*on_pass)(void *user, int sweep, int pass);   /* NULL, or a function the call invokes on the calling thread right BEFORE it enqueues the trainer launch of
+                             * relaxation pass `pass` of sweep `sweep`: the place to enqueue chip-wide work of other library streams behind an event recorded
+                             * here - it then starts together with the trainer and runs beside it (qh_bps_recover_part_*_dev: a part of the phase search small
+                             * enough to be one wave per SIMD costs the pass 0-3 %), not in the ~70 us of analysis behind the trainer, which are the critical
+                             * path.  A pass enqueued ahead of the decision that ends the sweep still calls it (its launches do nothing).  It must leave the
+                             * current library stream as it found it (ABI 9) */
     void *on_pass_user;
 } qh_pit_opts;
 typedef struct qh_pit_report {

@@ -2766,6 +2766,15 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                                    ntot, ncol, (const PitCtrl *)ctrl, fz);
                 QH_HIP(hipEventRecord(ev_xe, hs));
             }
+            if (o.on_pass) {
+                // the caller's chip-wide work for other streams, to run BESIDE this pass's trainer: an event recorded here is behind everything of the
+                // pass before (its back product), so what is gated on it starts with the trainer - not in the analysis behind it, where it would share
+                // the chip with the control path, which is the critical path (hook behind the trainer launch: gaps of 88-90 instead of 70-75 us between
+                // the passes, C3 1137-1146 against 1163-1167 MSym/s)
+                hipStream_t keep = g_stream;
+                o.on_pass(o.on_pass_user, it, p);
+                g_stream = keep;
+            }
             if (timed(p)) QH_HIP(hipEventRecord(ev.t0[p], g_stream));
             if (seg_form) {
                 SegArgs<R> sa;
@@ -2794,11 +2803,6 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
                 { int r = launch_any<R>(ts); if (r) return r; }
             }
             if (timed(p)) QH_HIP(hipEventRecord(ev.t1[p], g_stream));
-            if (o.on_pass) {                                        // the caller's chip-wide work for the analysis gap behind this trainer launch (other streams)
-                hipStream_t keep = g_stream;
-                o.on_pass(o.on_pass_user, it, p);
-                g_stream = keep;
-            }
             if (split) {
                 // one capture over several processes: the end taps of the segments trained elsewhere arrive through the caller's
                 // all-reduce (zeros here, the trained taps there); from then on every process works on identical data

@@ -179,7 +179,7 @@ class ResidentReceiver:
         (``qh_pit_opts.on_pass0``) - work for the other library streams is enqueued there, while the device is busy, instead of in front of
         this sweep's launches; called after the sweep if the library never got to a first pass (exact form).
 
-        ``pass_hook(sweep, p)`` (tier b): invoked right after the trainer launch of EVERY relaxation pass (``qh_pit_opts.on_pass``) - see
+        ``pass_hook(sweep, p)`` (tier b): invoked right before the trainer launch of EVERY relaxation pass (``qh_pit_opts.on_pass``) - see
         ``run(overlap=True)``."""
         tb = self.tier == "b"
         self._bound()
@@ -298,8 +298,9 @@ class ResidentReceiver:
             _lib.call("qh_stream_wait_event", self._ev_main.ptr)
             if getattr(self, "_post_running", False):
                 _lib.call("qh_stream_wait_event", self._ev_post.ptr)        # (the previous capture's phase search: see run)
-            if getattr(self, "_hook_calls", 0) > 0:                       # (run() recorded it behind the first trainer launch)
-                _lib.call("qh_stream_wait_event", self._ev_pass.ptr)        # (phase search in parts: the chip-wide covariance kernel starts behind a trainer launch, like the parts)
+            # (NOT behind the first trainer launch like the parts of the phase search: its chip-wide kernels - setup, Gram terms, covariance - then share
+            # the ~70 us of analysis behind passes 0 and 1 with the control path, which is the critical path: gaps of 130 / 123 instead of 90 us,
+            # 1120-1124 against 1135-1144 MSym/s; beside pass 0 they cost that pass 2 %)
             ok = _k.pit_prepare_dev(nxt, self.TrSyms[0], self.os, self.mu_init[0], self.wxy0, self.modes, self.symbols[0], self.methods[0],
                                     {k: v for k, v in o.items() if not k.startswith("_") and k not in ("basis", "prepared")}, self._prep[slot])
             if ok:
@@ -356,15 +357,15 @@ class ResidentReceiver:
             self._use_prep = None
             self.build_gram()
         m("gram")
-        # The pending phase search IN PARTS (tier b): one part behind each relaxation pass of this capture's training (pass_hook below).  A pass keeps
-        # the chip's SIMDs busy with one latency-bound wave each, and a chip-wide streaming kernel beside it costs it a third of its speed (every one
-        # of its instructions may find the SIMD taken for four cycles: 0.36 instead of 0.27 ms per pass, profiles/r05_c3_timeline.txt); the ~70 us
-        # of analysis between two passes run on a handful of CUs.  A part is gated by an event behind the pass's trainer launch: it starts when the
-        # trainer is done and - an eighth of the search being one wave per SIMD - spends the next pass in the issue slots that pass leaves (0-3 % of the
-        # pass instead of a third); the events space the parts one pass apart.  Number of parts: the trainer launches of the previous capture less
-        # two (one may have been enqueued in vain ahead of the decision that ended a sweep; the last part also unwraps and de-rotates and should not
-        # hold up this capture's filter, which overwrites what it reads: C3, 5 + 4 passes, 1 / 5 / 6 / 8 / 10 / 12 parts: 1046 / 1056 / 1083 / 1086 /
-        # 1037 / 977 MSym/s on one box); what is left when the training is over is enqueued then.  Bit-identical to one launch.
+        # The pending phase search IN PARTS (tier b): one part beside each relaxation pass of this capture's training (pass_hook below).  A pass keeps
+        # the chip's SIMDs busy with one latency-bound wave each, and the whole search beside it - as many single-wave workgroups per SIMD as the LDS
+        # allows - costs it a third of its speed (0.36 instead of 0.27 ms per pass).  A part of an eighth of the search is ONE wave per SIMD: gated by an
+        # event in front of a pass's trainer launch it starts with the trainer, lives on the issue slots the trainer's lone waves leave (0-3 % of the
+        # pass) and the events space the parts one pass apart.  (Gated BEHIND the trainer launch the parts start in the ~70 us of analysis between two
+        # passes and share the chip with the control path, which is the critical path: 1137-1146 against 1163-1167 MSym/s at C3.)  Number of parts: the
+        # trainer launches of the previous capture less two (one may have been enqueued in vain ahead of the decision that ended a sweep; the last part
+        # also unwraps and de-rotates and should not hold up this capture's filter, which overwrites what it reads); what is left when the training is
+        # over is enqueued then.  Bit-identical to one launch.
         parts_mode = self.tier == "b" and int(getattr(self, "post_parts", 0)) != 1
         self._hook_calls = 0
         if parts_mode and getattr(self, "_post_pending", False):
@@ -377,8 +378,8 @@ class ResidentReceiver:
         def on_pass(sweep, p):
             self._hook_calls += 1
             pend = parts_mode and getattr(self, "_post_pending", False)
-            if pend or (prefetch and self._hook_calls == 1):      # (nothing to gate: no packet on stream 0 either)
-                self._ev_pass.record()            # stream 0: behind the trainer launch of this pass
+            if pend:                              # (nothing to gate: no packet on stream 0 either)
+                self._ev_pass.record()            # stream 0: in front of the trainer launch of this pass
             if pend:
                 self._post_part(gated=True)
 
@@ -428,8 +429,8 @@ class ResidentReceiver:
         self._post_n = self._post_next = 0        # (not started: the next run decides whether it goes in parts)
 
     def _post_part(self, gated):
-        """The next part of the pending phase search onto stream 2; ``gated``: behind ``_ev_pass`` (the trainer launch of the pass that just went
-        onto stream 0)."""
+        """The next part of the pending phase search onto stream 2; ``gated``: behind ``_ev_pass`` (recorded in front of the trainer launch that is
+        about to go onto stream 0)."""
         i, n = self._post_next, self._post_n
         mark = getattr(self, "_post_mark", None)
         _lib.call("qh_use_stream", 2)
