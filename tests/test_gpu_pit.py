@@ -532,7 +532,7 @@ def test_overlapped_passes_give_the_results_of_one_capture_at_a_time(tier):
 
 @pytest.mark.parametrize("parts", [1, 3, 8, 16])
 def test_phase_search_in_parts_between_the_passes_is_bit_identical(parts):
-    """run(overlap=True), tier b: the pending phase search goes onto stream 2 in `post_parts` parts, one behind each trainer launch of the next capture
+    """run(overlap=True), tier b: the pending phase search goes onto stream 2 in `post_parts` parts, one beside each trainer launch of the next capture
     (qh_pit_opts.on_pass, qh_bps_recover_part_c64_dev); more parts than passes: the rest when the training is over.  Three captures handed over one
     after the other: every result bit for bit that of one capture at a time."""
     nsym, M, ntaps, mu = 2 ** 17, 64, 41, (1e-3, 5e-4)
