@@ -295,7 +295,12 @@ def pinned_empty(shape, dtype):
     shape = tuple(int(x) for x in np.atleast_1d(shape))
     n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
     p = _vp()
-    call("qh_pinned_alloc", C.byref(p), max(n, 1))
+    try:
+        call("qh_pinned_alloc", C.byref(p), max(n, 1))
+    except (RuntimeError, MemoryError):
+        # pinnable host memory exhausted (a caller keeping many large results alive): an ordinary pageable array, as the reference would
+        # allocate - copies into it are still correct after the stream is synchronised, only slower
+        return np.empty(shape, dtype=dtype)
     buf = (C.c_ubyte * max(n, 1)).from_address(p.value)
     weakref.finalize(buf, _pinned_release, p.value)
     return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)

@@ -139,7 +139,9 @@ class _Field:
     each of its compiled calls (equalisation.py:166, :532, three times per dual-mode call).
     """
 
-    def __init__(self, E, real):
+    def __init__(self, E, real, defer=False):
+        """``defer=True`` (only :func:`equalise_signal` / :func:`dual_mode_equalisation`, which call :meth:`finish` before they return): big
+        results come back on pinned memory with their copies still in flight.  Every other user gets complete arrays from each call."""
         E = np.asarray(E)
         self.real = real
         # (complex path: the capture is only read - uploaded once - so a C-contiguous array is used as it is; the reference's wrappers copy
@@ -147,7 +149,7 @@ class _Field:
         self.host = _convert_sig_to_real(E) if real else np.ascontiguousarray(np.asarray(E))
         self.rows, self.L = self.host.shape
         self.dtype = self.host.dtype
-        self.dev = None if real else _kernels.ResidentField(self.host, defer=True)       # (finish() before the call returns)
+        self.dev = None if real else _kernels.ResidentField(self.host, defer=bool(defer))
 
     def finish(self):
         if self.dev is not None:
@@ -275,7 +277,7 @@ def equalise_signal(E, os, mu, M, wxy=None, Ntaps=None, TrSyms=None, Niter=1, me
     """
     method = _method_name(method)
     pit = _tier_options(kwargs, 1, wxy is None)[0]
-    field = _Field(E, method in REAL_VALUED)
+    field = _Field(E, method in REAL_VALUED, defer=True)          # finish() below, before the call returns
     rows = field.mode_rows(modes)
     taps, err = field.train(os, mu, M, field.taps(wxy, Ntaps), TrSyms, Niter, method, adaptive_stepsize, symbols, rows, pit=pit)
     out = field.filtered(os, taps, rows) if apply else None
@@ -306,7 +308,7 @@ def dual_mode_equalisation(E, os, mu, M, wxy=None, Ntaps=None, TrSyms=(None, Non
     else:
         s3 = np.asarray(symbols)
         sy = (s3[0], s3[1]) if s3.ndim == 3 else (s3, s3)
-    field = _Field(E, real[0])
+    field = _Field(E, real[0], defer=True)                        # finish() below, before the call returns
     rows = field.mode_rows(modes)
     taps = field.taps(wxy, Ntaps)
     errs = []

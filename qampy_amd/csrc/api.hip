@@ -4,6 +4,7 @@
 #include <atomic>
 #include <mutex>
 #include <vector>
+#include <unordered_map>
 #include <string.h>
 
 namespace qh {
@@ -136,6 +137,7 @@ static constexpr int POOL_CLASSES = 48, POOL_KEEP = 8;
 static constexpr size_t POOL_BYTES = (size_t)24 << 30;
 static std::vector<void *> g_pool[POOL_CLASSES];
 static size_t g_pool_bytes = 0;
+static void pool_release();
 static int pool_class(size_t bytes) { int k = 8; while (((size_t)1 << k) < bytes && k < POOL_CLASSES - 1) k++; return k; }
 int pool_alloc(size_t bytes, void **p, size_t *cap)
 {
@@ -145,7 +147,15 @@ int pool_alloc(size_t bytes, void **p, size_t *cap)
         std::lock_guard<std::mutex> lk(g_mu);
         if (!g_pool[k].empty()) { *p = g_pool[k].back(); g_pool[k].pop_back(); g_pool_bytes -= *cap; return QH_OK; }
     }
-    QH_HIP(hipMalloc(p, *cap));
+    hipError_t e = hipMalloc(p, *cap);
+    if (e == hipErrorOutOfMemory) {
+        // the idle buffers of the pool (up to POOL_BYTES) are the first thing to give back before the caller sees an allocation fail
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        pool_release();
+        e = hipMalloc(p, *cap);
+    }
+    QH_HIP(e);
     return QH_OK;
 }
 void pool_free(void *p, size_t cap)
@@ -157,7 +167,7 @@ void pool_free(void *p, size_t cap)
     }
     (void)hipFree(p);
 }
-static std::vector<std::pair<void *, size_t>> g_dlive;            // pooled buffers handed out by qh_malloc: pointer -> capacity
+static std::unordered_map<void *, size_t> g_dlive;                 // pooled buffers handed out by qh_malloc: pointer -> capacity
 static void pool_release()
 {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -345,10 +355,17 @@ int qh_malloc(void **dptr, size_t bytes)
         size_t cap = 0;
         if ((rc = qh::pool_alloc(bytes ? bytes : 1, dptr, &cap))) return rc;
         std::lock_guard<std::mutex> lk(qh::g_mu);
-        qh::g_dlive.emplace_back(*dptr, cap);
+        qh::g_dlive[*dptr] = cap;
         return QH_OK;
     }
-    QH_HIP(hipMalloc(dptr, bytes));
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        qh::pool_release();
+        e = hipMalloc(dptr, bytes);
+    }
+    QH_HIP(e);
     return QH_OK;
 }
 int qh_free(void *dptr)
@@ -357,8 +374,8 @@ int qh_free(void *dptr)
     size_t cap = 0;
     {
         std::lock_guard<std::mutex> lk(qh::g_mu);
-        for (size_t i = 0; i < qh::g_dlive.size(); i++)
-            if (qh::g_dlive[i].first == dptr) { cap = qh::g_dlive[i].second; qh::g_dlive[i] = qh::g_dlive.back(); qh::g_dlive.pop_back(); break; }
+        auto it = qh::g_dlive.find(dptr);
+        if (it != qh::g_dlive.end()) { cap = it->second; qh::g_dlive.erase(it); }
     }
     if (cap) {
         // like hipFree: nothing on the device may still use the buffer when it becomes available again (any stream of any thread)
