@@ -172,6 +172,12 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s not found: build it with qampy_amd/csrc/build.sh (or __graft_entry__.build()); "
                                "qampy_amd has no CPU fallback" % LIB_PATH)
+        # Hardware queues: the HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share one
+        # run one after the other.  The library keeps FOUR streams per host thread (trainer / preparation / phase search / helper), so a second
+        # thread's streams land on the first one's queues: a ReceiverGroup worker ran its phase search BEHIND its training instead of beside it
+        # (round 6: 933 MSym/s on a worker thread against 1204 on the main thread, same receiver).  Raised before the runtime starts unless the
+        # user set it; the library does the same in a static initialiser for callers that bind it without this module.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         lib = C.CDLL(LIB_PATH)
         for name, args in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -27,6 +27,11 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
     return QH_ERR_HIP;
 }
 
+// Hardware queues (see qampy_amd/_lib.py load()): four streams per host thread need more than the runtime's default of 4 hardware queues as soon as a
+// second thread drives a receiver.  Set when the library is loaded - before the process's first HIP call unless someone else made one - and never
+// over a value the user chose.
+static const int g_hw_queues_set = [] { return setenv("GPU_MAX_HW_QUEUES", "16", 0); }();
+
 // Production knobs: set through the C ABI (qh_set_reserved_cus / qh_set_gram_budget_gb / qh_set_default_tier); the environment variables of
 // the same name are read ONCE, as the initial value, never in a launch path.
 static std::atomic<int> g_reserved_cus{-1};

@@ -26,11 +26,31 @@ from qampy_amd.pipeline import ResidentReceiver
 pytestmark = pytest.mark.gpu
 
 TOLS = [1e-3, 1e-4]
+EW_RTOL = EW_ATOL = 1e-4          # tests/conftest.py's complex64 bar (np.testing.assert_allclose) - what the EXACT path is held to element by element
+
+
+def _elementwise(ref, got):
+    """assert_allclose's criterion as a measurement: share of elements with |got - ref| <= atol + rtol |ref|, largest deviation."""
+    d = np.abs(got - ref)
+    ok = d <= EW_ATOL + EW_RTOL * np.abs(ref)
+    return float(np.mean(ok)), float(d.max())
+
+
+def _record(row):
+    """Measured element-wise figures, one JSON line per (shape, tolerance, quantity): gpurun_out/elementwise_fullsize.jsonl (copied to profiles/)."""
+    import json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "elementwise_fullsize.jsonl"), "a") as f:
+        f.write(json.dumps(row) + "\n")
 CASES = {
     "c3": dict(M=64, nsym=2 ** 22, ntaps=41, methods=("cma", "mrde"), mu=(2e-4, 2e-4), A=64, snr=30, lw=100.),
     "c2": dict(M=16, nsym=2 ** 20, ntaps=21, methods=("mcma",), mu=(1e-3,), A=32, snr=25, lw=50e3),
     # the north star's own size: 10^7 symbol periods of the C3 recipe (8-lane chains: 3584 / 4096 segments)
     "ns": dict(M=64, nsym=10 ** 7, ntaps=41, methods=("cma", "mrde"), mu=(2e-4, 2e-4), A=64, snr=30, lw=100.),
+    # SURVEY.md 8d's recipe at HALF its step sizes and 1 kHz - the largest steps at which the reference's own recurrence converges at 2^22
+    # (profiles/r05_survey_recipe_exact_path.txt) - against the ORACLE, at both tolerances (round-5 verdict: it was held GPU against GPU at 1e-3 only)
+    "sr": dict(M=64, nsym=2 ** 22, ntaps=41, methods=("cma", "mrde"), mu=(5e-4, 2.5e-4), A=64, snr=30, lw=1e3),
 }
 
 
@@ -62,7 +82,7 @@ def _capture_and_oracle(key):
 
 
 @pytest.mark.parametrize("tol", TOLS, ids=lambda t: "tol%g" % t)
-@pytest.mark.parametrize("key", ["c2", "c3", "ns"])
+@pytest.mark.parametrize("key", ["c2", "c3", "ns", "sr"])
 def test_tier_b_at_full_size_against_the_oracle(key, tol):
     c = CASES[key]
     d, E, (wo, eo, qo, oo) = _capture_and_oracle(key)
@@ -87,6 +107,16 @@ def test_tier_b_at_full_size_against_the_oracle(key, tol):
         for s in range(len(c["methods"])):
             et = np.sqrt(np.mean(np.abs(eo[s][m] - res["err"][s][m]) ** 2))
             assert et <= 3 * tol, (key, m, "error trace of stage %d" % s, et)
+        # ---- element by element, at the bar the exact path is held to (rtol = atol = 1e-4): taps and equaliser output in full at tol = 1e-4;
+        # the error traces are measured and reported (an error function turns an output deviation into 1.3 - 1.5 x as much trace deviation)
+        sh_t, mx_t = _elementwise(wo[m], res["wxy"][m])
+        sh_q, mx_q = _elementwise(qo[m], res["eq"][m])
+        tr_rows = [_elementwise(eo[s][m], res["err"][s][m]) for s in range(len(c["methods"]))]
+        _record(dict(shape=key, tol=tol, mode=m, taps=dict(share=sh_t, max_abs=mx_t), equaliser_out=dict(share=sh_q, max_abs=mx_q),
+                     err_traces=[dict(stage=c["methods"][s], share=a_, max_abs=b_) for s, (a_, b_) in enumerate(tr_rows)]))
+        if tol <= 1e-4:
+            assert sh_t == 1.0, (key, m, "taps element-wise", sh_t, mx_t)
+            assert sh_q == 1.0, (key, m, "equaliser output element-wise", sh_q, mx_q)
     # decisions after carrier recovery: tier b on the device against the oracle's recovered signal through the same harness
     ser_b = ber.cal_ser_dev(rx.out, d["idx_tx"], rx.alphabet, 256, 8192, 2000)
     oo_dev = _lib.DeviceArray.from_host(np.ascontiguousarray(oo))
