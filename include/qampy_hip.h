@@ -39,7 +39,7 @@ extern "C" {
  * arguments.  History: 1 = round 1; 2 = round 2 (qh_bps_recover_*_dev gained `angles`, qh_train_equaliser_*_pit_dev takes
  * (gram, opts, report), the *_seg_dev entry points were removed - unversioned at the time); 3 = round 3 (qh_pit_opts:
  * start, dev_safety; qh_pit_report: deviation[]); 4 = qh_pit_opts: adaptive. */
-#define QH_ABI_VERSION 9
+#define QH_ABI_VERSION 10
 int qh_abi_version(void);
 
 /* ---- status codes (python shim: 1,2 -> ValueError, 3,4 -> RuntimeError) */
@@ -244,8 +244,8 @@ int qh_make_decision_c128_dev(const void *E, int64_t L, const void *symbols, int
 int qh_count_errors_dev(const int32_t *idx_rx, const int32_t *idx_tx, int64_t n, int64_t lag, int64_t ntx,
                         unsigned long long *count_dev);
 
-/* Form of the exact trainer for subsequent calls: 0 automatic (default; the QAMPY_HIP_TRAINER environment variable, if set
- * to direct / lookahead / iterative, then decides), 1 direct, 2 look-ahead, 3 block-iterative.  All forms give the
+/* Form of the exact trainer for subsequent calls: 0 automatic (default), 1 direct, 2 look-ahead, 3 block-iterative (the same
+ * switch as qh_set_form("trainer", ...)).  All forms give the
  * reference's results up to the order of floating-point additions; a form that cannot take a call falls through. */
 int qh_set_trainer(int form);
 /* Production knobs (ABI 8; rounds 1-4 read environment variables in the launch paths).  The environment variables of the same meaning
@@ -266,15 +266,22 @@ int qh_set_gram_budget_gb(double gb);
 int qh_get_gram_budget_gb(double *gb);
 int qh_set_default_tier(int tier, double tol);
 int qh_get_default_tier(int *tier, double *tol);
-/* Environment switches the library reads (measurement / test aids: each forces a path the automatic choice would not take at that size,
- * none selects a different algorithm; every one is exercised through this C ABI by the -m gpu tests named):
- *   QAMPY_HIP_TRAINER = direct | lookahead | iterative   form of the exact trainer, like qh_set_trainer (tests/test_gpu_parity.py)
- *   QAMPY_HIP_PIT_FORM = segment | block                  parallel in time: throughput / latency form of the passes (tests/test_gpu_pit.py)
- *   QAMPY_HIP_SEG_LANES = 8 | 16                          throughput form: lanes per chain (tests/test_gpu_pit.py)
- *   QAMPY_HIP_PIT_PROBE = 1                               complex64: the complex128 analysis of a pass (probe of the capture) (tests/test_gpu_pit.py)
- *   QAMPY_HIP_PIT_TIMING = all | none                     initial value of qh_set_pit_timing (scripts/pit_exp.py)
- *   QAMPY_HIP_BPS = tile, QAMPY_HIP_BPS_FUSED = 1         phase search: tile kernel for complex64 / search + unwrap + de-rotation in one kernel (test_gpu_parity.py)
- *   QAMPY_HIP_LA_PROFILE = 1                              developer aid: cycle split of workgroup 0 of the block trainers on stderr */
+/* Test / measurement hooks (ABI 10; rounds 1-5 read environment variables in the launch paths): each forces a kernel form the automatic choice would
+ * not take at that size, none selects a different algorithm, every one is exercised through this C ABI by the -m gpu tests named.  The launch paths read
+ * ONE table of atomics; the environment variables of the same meaning (QAMPY_HIP_TRAINER, QAMPY_HIP_PIT_FORM, QAMPY_HIP_SEG_LANES, QAMPY_HIP_PIT_PROBE,
+ * QAMPY_HIP_BPS, QAMPY_HIP_BPS_FUSED, QAMPY_HIP_PIT_XASIDE, QAMPY_HIP_LA_PROFILE) are read ONCE, when the library is loaded, as the table's initial values.
+ *   key          values                                        what
+ *   "trainer"    auto | direct | lookahead | iterative          form of the exact trainer, like qh_set_trainer (tests/test_gpu_parity.py)
+ *   "pit_form"   auto | segment | block                         parallel in time: throughput / latency form of the passes (tests/test_gpu_pit.py)
+ *   "seg_lanes"  0 | 8 | 16                                     throughput form: lanes per chain (tests/test_gpu_pit.py)
+ *   "pit_probe"  0 | 1                                          complex64: the complex128 analysis of a pass (probe of the capture) (tests/test_gpu_pit.py)
+ *   "bps"        auto | tile | lds | fused                      phase search: tile kernel for complex64 / streaming kernel with the LDS ring only (no
+ *                                                               register-ring kernel) / search + unwrap + de-rotation in one kernel (tests/test_gpu_parity.py)
+ *   "pit_xaside" 0 | 1                                          start taps into the eigenbasis beside the pass (measurement)
+ *   "la_profile" 0 | 1                                          developer aid: cycle split of workgroup 0 of the block trainers on stderr
+ * qh_set_form returns QH_ERR_ARG for an unknown key or value; a NULL or empty value resets the key to automatic. */
+int qh_set_form(const char *key, const char *value);
+int qh_get_form(const char *key, int *value);
 
 /* ---- parallel-in-time training ("tier B": opt-in, NOT the reference's order of evaluation) -----------
  * The sweep of TrSyms steps is cut into S contiguous segments that are trained CONCURRENTLY with the exact kernels

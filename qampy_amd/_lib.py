@@ -97,6 +97,8 @@ SIGNATURES = {
     "qh_memcpy_d2h_async": [_vp, _vp, _sz],
     "qh_stream_sync": [],
     "qh_set_trainer": [_i],
+    "qh_set_form": [C.c_char_p, C.c_char_p],
+    "qh_get_form": [C.c_char_p, C.POINTER(_i)],
     "qh_set_pit_timing": [_i],
     "qh_set_reserved_cus": [_i],
     "qh_set_gram_budget_gb": [C.c_double],
@@ -114,7 +116,7 @@ SIGNATURES = {
 }
 
 PIT_MAXPASS, PIT_MAXCHUNK = 24, 32
-ABI_VERSION = 9              # QH_ABI_VERSION of include/qampy_hip.h
+ABI_VERSION = 10             # QH_ABI_VERSION of include/qampy_hip.h
 
 
 class PitOpts(C.Structure):
@@ -209,6 +211,19 @@ def check(rc):
 
 def call(name, *args):
     check(getattr(load(), name)(*args))
+
+
+def set_form(key, value=None):
+    """Test / measurement hook (``qh_set_form``, include/qampy_hip.h): force a kernel form - ``set_form("trainer", "direct")``,
+    ``set_form("pit_form", "segment")``, ``set_form("seg_lanes", 8)``, ``set_form("bps", "tile")`` ...; ``None`` / ``""`` / ``0``: automatic."""
+    v = "" if value is None else str(value)
+    call("qh_set_form", str(key).encode(), v.encode())
+
+
+def get_form(key):
+    v = _i(0)
+    call("qh_get_form", str(key).encode(), C.byref(v))
+    return v.value
 
 
 def ptr(a):

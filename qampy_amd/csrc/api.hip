@@ -126,15 +126,46 @@ int ensure_init()
 // grow-only scratch slots so that the resident pipeline never allocates (and never synchronises) inside a timed region
 thread_local void *g_scratch[16] = {nullptr};
 thread_local size_t g_scratch_n[16] = {0};
-// form of the exact trainer: 0 = automatic (or the QAMPY_HIP_TRAINER environment variable), 1 direct, 2 look-ahead, 3 block-iterative
-int g_trainer = 0;
+// ---- the table of form switches (common.h FormKey; qh_set_form / qh_set_trainer).  Values:
+//   trainer    0 automatic, 1 direct, 2 lookahead, 3 iterative          pit_form   0 automatic, 1 segment (throughput form), 2 block (latency forms)
+//   seg_lanes  0 automatic, 8, 16                                       pit_probe  1: complex64 takes the complex128 analysis of a pass
+//   bps        0 automatic, 1 tile kernel for complex64, 2 streaming kernel with the LDS ring only, 3 search + unwrap + de-rotation fused
+//   pit_xaside 1: start taps into the eigenbasis beside the pass         la_profile 1: cycle split of workgroup 0 of the block trainers
+static std::atomic<int> g_form[FORM_COUNT];
+struct FormName { const char *key, *env; };
+static const FormName FORM_NAMES[FORM_COUNT] = {
+    {"trainer", "QAMPY_HIP_TRAINER"}, {"pit_form", "QAMPY_HIP_PIT_FORM"}, {"seg_lanes", "QAMPY_HIP_SEG_LANES"}, {"pit_probe", "QAMPY_HIP_PIT_PROBE"},
+    {"bps", "QAMPY_HIP_BPS"}, {"pit_xaside", "QAMPY_HIP_PIT_XASIDE"}, {"la_profile", "QAMPY_HIP_LA_PROFILE"}};
+static int form_parse(int k, const char *v, int *out)
+{
+    if (!v || !v[0]) { *out = 0; return 0; }
+    switch (k) {
+    case FORM_TRAINER: *out = v[0] == 'd' ? 1 : (v[0] == 'l' ? 2 : (v[0] == 'i' ? 3 : (v[0] == 'a' || v[0] == '0' ? 0 : -1))); break;
+    case FORM_PIT: *out = v[0] == 's' ? 1 : (v[0] == 'b' ? 2 : (v[0] == 'a' || v[0] == '0' ? 0 : -1)); break;
+    case FORM_SEG_LANES: { const int n = atoi(v); *out = (n == 8 || n == 16 || n == 0) ? n : -1; break; }
+    case FORM_BPS: *out = v[0] == 't' ? 1 : (v[0] == 'l' ? 2 : (v[0] == 'f' ? 3 : (v[0] == 'a' || v[0] == '0' ? 0 : -1))); break;
+    default: *out = atoi(v) != 0 ? 1 : 0; break;
+    }
+    return *out < 0 ? -1 : 0;
+}
+// the environment, ONCE, when the library is loaded (QAMPY_HIP_BPS_FUSED=1 was round 3's spelling of bps = fused)
+static const int g_form_env_read = [] {
+    for (int k = 0; k < FORM_COUNT; k++) {
+        int v = 0;
+        if (form_parse(k, getenv(FORM_NAMES[k].env), &v) == 0) g_form[k].store(v);
+    }
+    const char *f = getenv("QAMPY_HIP_BPS_FUSED");
+    if (f && f[0] == '1' && g_form[FORM_BPS].load() == 0) g_form[FORM_BPS].store(3);
+    return 0;
+}();
+int form(FormKey k) { return g_form[k].load(std::memory_order_relaxed); }
 const char *trainer_force()
 {
-    switch (g_trainer) {
+    switch (form(FORM_TRAINER)) {
     case 1: return "direct";
     case 2: return "lookahead";
     case 3: return "iterative";
-    default: { const char *e = getenv("QAMPY_HIP_TRAINER"); return e ? e : ""; }
+    default: return "";
     }
 }
 // ---- pool of staging buffers (DevBuf): size classes 2^k bytes, at most POOL_KEEP idle buffers per class and POOL_BYTES in total
@@ -239,8 +270,28 @@ extern "C" {
 int qh_set_trainer(int form)
 {
     if (form < 0 || form > 3) { qh::set_error("qh_set_trainer: 0 automatic, 1 direct, 2 lookahead, 3 iterative"); return QH_ERR_ARG; }
-    qh::g_trainer = form;
+    qh::g_form[qh::FORM_TRAINER].store(form);
     return QH_OK;
+}
+int qh_set_form(const char *key, const char *value)
+{
+    if (!key) { qh::set_error("qh_set_form: key"); return QH_ERR_ARG; }
+    for (int k = 0; k < qh::FORM_COUNT; k++) {
+        if (strcmp(key, qh::FORM_NAMES[k].key) != 0) continue;
+        int v = 0;
+        if (qh::form_parse(k, value, &v) != 0) { qh::set_error(std::string("qh_set_form: value '") + (value ? value : "") + "' is not one of key '" + key + "'"); return QH_ERR_ARG; }
+        qh::g_form[k].store(v);
+        return QH_OK;
+    }
+    qh::set_error(std::string("qh_set_form: unknown key '") + key + "'");
+    return QH_ERR_ARG;
+}
+int qh_get_form(const char *key, int *value)
+{
+    for (int k = 0; key && k < qh::FORM_COUNT; k++)
+        if (strcmp(key, qh::FORM_NAMES[k].key) == 0) { *value = qh::g_form[k].load(); return QH_OK; }
+    qh::set_error("qh_get_form: unknown key");
+    return QH_ERR_ARG;
 }
 
 int qh_set_reserved_cus(int n)

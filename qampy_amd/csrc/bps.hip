@@ -284,6 +284,8 @@ struct BpsStreamArgs {
     int64_t L;
     int A, M, N, C, alpha_lds;
     int chunk0;                  // chunk of block 0 (a launch may cover a part of the chunks: bps_dev's part / nparts)
+    int reg_lo, reg_hi;          // chunks [reg_lo, reg_hi) belong to bps_stream40_kernel IF the alphabet turns out to be one it takes (bs40_takes: both kernels
+                                 // read the device-side descriptor and exactly one of them works on such a chunk - the host never waits for the analysis)
     // REC (search + np.unwrap + de-rotation in this one kernel): per-symbol phase and recovered symbols out, and the look-back cells
     float *ph;                   // (nm, L)
     Cx<float> *Eout;             // (nm, L)
@@ -291,6 +293,31 @@ struct BpsStreamArgs {
 };
 
 template <int K> struct BsKind { static constexpr int value = K; };
+// First arg-min over the angles for the 16 symbols of a transposed block (dmin starts at 1000, strict `<`: pythran_dsp.py:31-41): lane <-> (symbol,
+// quarter of the angles), 16 conflict-free reads, then two exchange steps over the quarters with ties to the lower index.  Selects, no branches.
+__device__ __forceinline__ int bs_argmin16(const float *tb, int sym, int quarter)
+{
+    float m = 1000.f;
+    int best = 0;
+    const float *row = tb + sym * BS_TP + quarter * 16;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const float v = row[k];
+        const bool lt = v < m;
+        m = lt ? v : m;
+        best = lt ? quarter * 16 + k : best;
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float m2 = __shfl_xor(m, o);
+        const int b2 = __shfl_xor(best, o);
+        const bool take = (m2 < m) | ((m2 == m) & (b2 < best));
+        m = take ? m2 : m;
+        best = take ? b2 : best;
+    }
+    return best;
+}
+__device__ __forceinline__ bool bs40_takes(const AlphabetDesc<float> *d);
 template <typename R> __device__ __forceinline__ int unwrap_jump(const R *angles, int kprev, int kcur);
 typedef float bs_f2 __attribute__((ext_vector_type(2)));
 // both axes at once: u = (|t.re|, |t.im|), d_k = u - (l_re[k], l_im[k]) is ONE packed subtraction per level pair; the minima are
@@ -346,6 +373,7 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
     // ---- alphabet
     const int product = a.desc->product, symmetric = a.desc->symmetric;
     const int nre = a.desc->nre, nim = a.desc->nim;
+    if (!REC && (int)(blockIdx.x + a.chunk0) >= a.reg_lo && (int)(blockIdx.x + a.chunk0) < a.reg_hi && bs40_takes(a.desc)) return;      // (wave-uniform; before any barrier)
     bs_f2 lev2[16];                                                   // positive halves (re, im), in SGPRs
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -399,6 +427,7 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
     const int sym = lane & (BS_G - 1), quarter = lane >> 4;
     Cx<float> xnext = load_group(lstart);
     auto run = [&](auto KIND) {
+    constexpr int kind = decltype(KIND)::value;
     for (int g = 0; g < ngroups; g++) {
         const int64_t lg = lstart + (int64_t)g * BS_G;
         const Cx<float> xg = xnext;
@@ -428,22 +457,36 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
                 tb[k * BS_TP + lane] = full ? s : s + bias;
             }
         };
-        if (lg >= 0 && lg + BS_G <= L) rows(BsKind<0>{}); else rows(BsKind<1>{});        // wave-uniform
+        // Fast rows (round 6): a full grid (A = 64: no lane without an angle), at most four positive levels per axis, the 16 rows inside the
+        // capture and the 16 ring cells contiguous.  The symbols come through the SCALAR cache (uniform address: two s_load_dwordx16 per
+        // group, nothing for the vector unit - the generic rows take them from a coalesced vector load with two v_readlane per row), the ring
+        // cells and the transposed block are addressed with immediate offsets from one base register per group, and there is no bias select:
+        // 17 vector instructions per row (rotation 2, |t| 2, level differences 4, minima 4, squared distance 3, window 2) against 22.
+        // The same arithmetic in the same order: bit-identical distances, sums and indices.
+        if (kind == 3 && full && lg >= 0 && lg + BS_G <= L && slot + BS_G <= W) {         // wave-uniform
+            typedef const __attribute__((address_space(4))) bs_f2 *bs_cptr;
+            const bs_cptr eg = (bs_cptr)(const void *)(E + lg);                          // (read-only for the whole launch: constant address space)
+            bs_f2 xs[BS_G];
+#pragma unroll
+            for (int k = 0; k < BS_G; k++) xs[k] = eg[k];
+            float *cell0 = ring + slot * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < BS_G; k++) {
+                const float old = cell0[k * 64];
+                const bs_f2 tt = __builtin_elementwise_fma(bs_f2{xs[k].x, xs[k].x}, rot_cs, bs_f2{xs[k].y, xs[k].y} * rot_ns);
+                const bs_f2 mm = bs_axes_sym<true>(tt, lev2, nlmax);
+                float d = fma_(mm.x, mm.x, mm.y * mm.y);
+                d = d < 100.f ? d : 100.f;
+                cell0[k * 64] = d;
+                s += d;
+                s -= old;
+                tb[k * BS_TP + lane] = s;
+            }
+            slot = slot + BS_G == W ? 0 : slot + BS_G;
+        } else if (lg >= 0 && lg + BS_G <= L) rows(BsKind<0>{}); else rows(BsKind<1>{});        // wave-uniform
         __syncthreads();
         // ---- first arg-min over the angles for the 16 symbols of the block (dmin starts at 1000, strict `<`, :31-41)
-        float m = 1000.f;
-        int best = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const float v = tb[sym * BS_TP + quarter * 16 + k];
-            if (v < m) { m = v; best = quarter * 16 + k; }
-        }
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-            const float m2 = __shfl_xor(m, o);
-            const int b2 = __shfl_xor(best, o);
-            if (m2 < m || (m2 == m && b2 < best)) { m = m2; best = b2; }
-        }
+        const int best = bs_argmin16(tb, sym, quarter);
         const int64_t i = lg + sym - a.N;
         const int bo = (i >= a.N && i < L - a.N) ? best : 0;
         if (quarter == 0 && i >= c0 && i < c1) idx[i] = bo;
@@ -522,6 +565,87 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
     }
 }
 
+// ---- Register-ring form of the streaming search (round 6) for the shape the path's own callers run at full size: A = 64 test angles (no idle lane),
+// N = 20 (window of 2N = 40 rows), a mirror-symmetric product alphabet with at most four positive levels per axis (QPSK ... 64-QAM), chunks whose rows
+// all lie inside the capture.  The window of a lane (its 40 last distances) is private to the lane, so it does not have to live in LDS: here it is 40
+// REGISTERS, addressed statically because the loop body is unrolled over lcm(16, 40) = 80 rows (five arg-min blocks).  Per row that removes both ring
+// accesses (LDS traffic 3 -> 1 operation per row + the arg-min reads), and per wave 10 KiB of the 14 KiB of LDS: the number of resident waves is then set
+// by the registers (~84: 5 per SIMD) instead of the LDS (11 per CU = 2.75 per SIMD), which is what the kernel's speed hangs on (measured round 3: 5 KiB
+// more LDS per wave cost a fifth).  Symbols through the scalar cache, 17 vector instructions per row + 3.8 for the arg-min.  The SAME operations in the
+// same order as bps_stream_kernel (window start at ring position (16 g) mod 40, direct re-summation oldest to newest every 128 rows): bit-identical.
+__device__ __forceinline__ bool bs40_takes(const AlphabetDesc<float> *d)
+{
+    return d->symmetric != 0 && d->nre <= 8 && d->nim <= 8;
+}
+__global__ void __launch_bounds__(64) bps_stream40_kernel(BpsStreamArgs a)
+{
+    constexpr int W = 40, N = 20, GB = 5;                             // GB arg-min blocks of BS_G rows = 2 W rows per trip of the loop
+    __shared__ float tb[BS_G * BS_TP + 1];
+    if (!bs40_takes(a.desc)) return;                                  // (bps_stream_kernel does these chunks then)
+    const int lane = threadIdx.x;
+    const int64_t L = a.L;
+    const Cx<float> *E = a.E + (size_t)blockIdx.y * L;
+    int32_t *idx = a.idx + (size_t)blockIdx.y * L;
+    const int64_t c0 = (int64_t)(blockIdx.x + a.chunk0) * a.C;
+    const int64_t c1 = c0 + a.C < L ? c0 + a.C : L;
+    const int ngroups = (a.C + W - 1 + BS_G - 1) / BS_G;
+    const int64_t lstart = c0 + a.C - 1 + N - (int64_t)ngroups * BS_G + 1;
+    const int nre = a.desc->nre, nim = a.desc->nim;
+    bs_f2 lev2[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {                                    // (only the first four are read: bs_axes_sym<true>)
+        lev2[k].x = k < nre / 2 ? a.desc->re[nre / 2 + k] : 3.0e38f;
+        lev2[k].y = k < nim / 2 ? a.desc->im[nim / 2 + k] : 3.0e38f;
+    }
+    float cs, sn;
+    sincosf(a.angles[lane], &sn, &cs);
+    const bs_f2 rot_cs = {cs, sn}, rot_ns = {-sn, cs};
+    float ring[W];
+#pragma unroll
+    for (int r = 0; r < W; r++) ring[r] = 0.f;
+    float s = 0.f;
+    const int sym = lane & (BS_G - 1), quarter = lane >> 4;
+    typedef const __attribute__((address_space(4))) bs_f2 *bs_cptr;
+    for (int g0 = 0; g0 < ngroups; g0 += GB) {
+#pragma unroll
+        for (int gg = 0; gg < GB; gg++) {
+            const int g = g0 + gg;
+            if (g >= ngroups) break;                                  // wave-uniform
+            const int64_t lg = lstart + (int64_t)g * BS_G;
+            const bs_cptr eg = (bs_cptr)(const void *)(E + lg);
+            bs_f2 xs[BS_G];
+#pragma unroll
+            for (int k = 0; k < BS_G; k++) xs[k] = eg[k];
+            if (g > 0 && (g % BS_REANCHOR) == 0) {                    // direct 2N-term sum, oldest to newest
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < W; k++) t += ring[(gg * BS_G + k) % W];
+                s = t;
+            }
+#pragma unroll
+            for (int k = 0; k < BS_G; k++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int r = (gg * BS_G + k) % W;                    // compile-time after unrolling
+                const float old = ring[r];
+                const bs_f2 tt = __builtin_elementwise_fma(bs_f2{xs[k].x, xs[k].x}, rot_cs, bs_f2{xs[k].y, xs[k].y} * rot_ns);
+                const bs_f2 mm = bs_axes_sym<true>(tt, lev2, 4);
+                float d = fma_(mm.x, mm.x, mm.y * mm.y);
+                d = d < 100.f ? d : 100.f;
+                ring[r] = d;
+                s += d;
+                s -= old;
+                tb[k * BS_TP + lane] = s;
+            }
+            __syncthreads();
+            const int best = bs_argmin16(tb, sym, quarter);
+            const int64_t i = lg + sym - N;
+            const int bo = (i >= N && i < L - N) ? best : 0;
+            if (quarter == 0 && i >= c0 && i < c1) idx[i] = bo;
+            __syncthreads();
+        }
+    }
+}
+
 template <typename R> static int bps_tile(int A, int N, size_t *lds)
 {
     // largest T with (T + 2N - 1)*A + T*(A + 1) elements (+ the rotator table) inside the LDS budget
@@ -533,11 +657,12 @@ template <typename R> static int bps_tile(int A, int N, size_t *lds)
     return (int)T;
 }
 
+// qh_set_form("bps", ...): 0 automatic, 1 tile kernel for complex64 too, 2 streaming kernel with the LDS ring only (no register-ring kernel), 3 fused
+inline bool bps_reg_ring() { return form(FORM_BPS) == 0; }
 template <typename R> inline bool bps_stream_ok(int64_t, int, int, int) { return false; }
 template <> inline bool bps_stream_ok<float>(int64_t p, int A, int N, int M)
 {
-    const char *e = getenv("QAMPY_HIP_BPS");                           // "tile": force the tile kernel (tests compare the two)
-    const bool off = e && !strcmp(e, "tile");
+    const bool off = form(FORM_BPS) == 1;                              // the tile kernel forced (tests compare the two)
     return !off && p == 1 && A <= 64 && 2 * N <= BS_MAXRING && M >= 1;
 }
 
@@ -571,11 +696,10 @@ int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, cons
         int C = 1024;                                            // longer chunks: less halo (2N - 1 rows each); shorter: more waves
         while (C > 128 && ((L + C - 1) / C) * nm < 4096) C /= 2;
         s.C = C;
-        // search + unwrap + de-rotation in ONE kernel (QAMPY_HIP_BPS_FUSED=1).  Opt-in: measured at C3 it is slower than the search
+        // search + unwrap + de-rotation in ONE kernel (qh_set_form("bps", "fused")).  Opt-in: measured at C3 it is slower than the search
         // followed by the three small unwrap / de-rotation launches (0.80 against 0.70 ms) - the tail of a chunk (jump scan, look-back,
         // sincos, second pass over the symbols) is a latency chain inside a kernel whose speed is the number of waves a CU holds.
-        const char *fe = getenv("QAMPY_HIP_BPS_FUSED");
-        const int fused = (fe && fe[0] == '1') ? 1 : 0;
+        const int fused = form(FORM_BPS) == 3 ? 1 : 0;
         const bool rec = fused && ph != nullptr && Eout != nullptr && A <= 255 && nparts == 1;
         const unsigned nchunk = (unsigned)((L + C - 1) / C);
         const unsigned ch0 = (unsigned)((uint64_t)nchunk * part / nparts), ch1 = (unsigned)((uint64_t)nchunk * (part + 1) / nparts);
@@ -595,8 +719,29 @@ int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, cons
             QH_HIP(hipFuncSetAttribute((const void *)bps_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             sattr = true;
         }
+        // chunks of the register-ring kernel (A = 64, N = 20, every row of the chunk inside the capture): [r_lo, r_hi) of this part
+        s.reg_lo = s.reg_hi = 0;
+        if (!rec && A == 64 && N == 20 && bps_reg_ring()) {
+            const int ngroups = (C + 2 * N - 1 + BS_G - 1) / BS_G;
+            const int64_t back = (int64_t)ngroups * BS_G - (C - 1 + N + 1);            // lstart = c0 - back >= 0
+            int64_t lo = back > 0 ? (back + C - 1) / C : 0;
+            int64_t hi = (L - N) / C;                                                    // (c + 1) C + N <= L
+            if (lo < (int64_t)ch0) lo = ch0;
+            if (hi > (int64_t)ch1) hi = ch1;
+            if (hi > lo) { s.reg_lo = (int)lo; s.reg_hi = (int)hi; }
+        }
         if (rec) hipLaunchKernelGGL(bps_stream_kernel<true>, dim3(nchunk, nm), dim3(64), lds, g_stream, s);
-        else if (ch1 > ch0) hipLaunchKernelGGL(bps_stream_kernel<false>, dim3(ch1 - ch0, nm), dim3(64), lds, g_stream, s);
+        else if (ch1 > ch0) {
+            if (s.reg_hi > s.reg_lo) {
+                // the chunks in front of and behind the register kernel's range in their own launches (a few waves), its range in BOTH kernels: each
+                // looks at the descriptor and exactly one of them does the work (an alphabet the register kernel does not take: the waves of that
+                // launch return at once)
+                BpsStreamArgs r = s;
+                r.chunk0 = s.reg_lo;
+                hipLaunchKernelGGL(bps_stream40_kernel, dim3(s.reg_hi - s.reg_lo, nm), dim3(64), 0, g_stream, r);
+            }
+            hipLaunchKernelGGL(bps_stream_kernel<false>, dim3(ch1 - ch0, nm), dim3(64), lds, g_stream, s);
+        }
         if (recovered) *recovered = rec;
         QH_HIP(hipGetLastError());
         return QH_OK;

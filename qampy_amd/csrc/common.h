@@ -32,6 +32,11 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 int ensure_init();
 hipStream_t side_stream();       // the library stream that is NOT the current one (work overlapped with the current stream)
 hipStream_t helper_stream();     // a third stream for small launches beside both (the coarse model of a tier-b sweep)
+// Test / measurement hooks (qh_set_form): every switch that forces a kernel form the automatic choice would not take at that size lives in ONE table of
+// atomics, set through the C ABI; the launch paths read the table, never the environment.  (The environment variables of rounds 1-5 - QAMPY_HIP_TRAINER,
+// QAMPY_HIP_PIT_FORM, ... - are read ONCE, when the library is loaded, as the table's initial values: scripts/ that export them keep working.)
+enum FormKey { FORM_TRAINER = 0, FORM_PIT, FORM_SEG_LANES, FORM_PIT_PROBE, FORM_BPS, FORM_PIT_XASIDE, FORM_LA_PROFILE, FORM_COUNT };
+int form(FormKey k);
 const char *trainer_force();   // "" (automatic) or "direct" / "lookahead" / "iterative": qh_set_trainer(), else QAMPY_HIP_TRAINER
 double gram_budget_gb();         // scratch the Gram tables of one call may take (qh_set_gram_budget_gb; default: QAMPY_HIP_GRAM_BUDGET_GB read once, else 160)
 int pit_timing_mode();            // which relaxation passes of a tier-b sweep get HIP events: 0 none, 1 pass 1 (default), 2 all (qh_set_pit_timing)

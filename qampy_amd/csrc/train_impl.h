@@ -551,7 +551,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
         // exact semantics.  Blind methods with a fixed step run in the look-ahead (train_la.h) or block-iterative
         // (train_bi.h) form, everything else (decision-directed, data-aided, adaptive step, tiny captures) in the direct
         // form below.  Same results up to the order of additions.
-        // Trainer choice.  QAMPY_HIP_TRAINER = direct | lookahead | iterative forces one form (A/B measurements, tests);
+        // Trainer choice.  qh_set_trainer / qh_set_form("trainer", "direct" | "lookahead" | "iterative") forces one form (A/B measurements, tests);
         // otherwise the block-iterative form takes the partitioned error functions (rde, mrde: one evaluation per sweep
         // instead of one per step), the look-ahead chain the cheap ones (cma, mcma, cma2), whichever of the two fits.
         const char *force = trainer_force();
@@ -596,7 +596,7 @@ int train_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Niter, i
                 la.symbols = (const Cx<R> *)dd_table; la.nsy = 2 * dd_npart + 1; la.sy_pitch = 2 * BI_DD_MAXLEV;
             }
             la.prof = nullptr; la.seg = 0; la.seg_extra = 0; la.seg_tail = 0; la.skip = nullptr; la.niter = 1;
-            if (getenv("QAMPY_HIP_LA_PROFILE")) {                // developer aid: cycle split of workgroup 0
+            if (form(FORM_LA_PROFILE)) {                         // developer aid: cycle split of workgroup 0 (qh_set_form("la_profile", "1"))
                 void *pp = nullptr;
                 if ((rc = scratch(5, 16 * sizeof(unsigned long long), &pp))) return rc;
                 QH_HIP(hipMemsetAsync(pp, 0, 16 * sizeof(unsigned long long), g_stream));

@@ -2206,9 +2206,9 @@ int pit_prepare(const void *E, int nmodes, int64_t L, int64_t TrSyms, int os, co
     const bool bi_ok = force[0] != 'd' && force[0] != 'l' && bi_supported(method, 0, nmodes, ntaps, os, seg_len, nsy, sizeof(Cx<R>));
     bool seg_ok = force[0] == 0 && seg_supported(method, nmodes, ntaps, os, nsy, sizeof(Cx<R>), nsel);
     {
-        const char *pf = getenv("QAMPY_HIP_PIT_FORM");
-        if (pf && pf[0] == 'b') seg_ok = false;
-        else if (!(pf && pf[0] == 's') && (int64_t)S * nsel < 512) seg_ok = false;
+        const int pf = form(FORM_PIT);                            // qh_set_form("pit_form", "segment" | "block")
+        if (pf == 2) seg_ok = false;
+        else if (pf != 1 && (int64_t)S * nsel < 512) seg_ok = false;
     }
     const bool la_ok = force[0] != 'd' && method != QH_M_SBD_DATA && la_supported(method, 0, nmodes, ntaps, os, seg_len, nsy);
     const bool use_bi = bi_ok && (decision || !la_ok || force[0] == 'i');
@@ -2409,11 +2409,11 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
         bi_ok = bi_ok && (sq || dd_general); seg_ok = seg_ok && sq;
     }
     // Form of the passes.  Few chains: the latency forms (look-ahead / block-iterative, one workgroup per chain).  Many
-    // chains: the throughput form (train_seg.h: 16 lanes per chain, no Gram table).  QAMPY_HIP_PIT_FORM = segment | block forces.
+    // chains: the throughput form (train_seg.h: 16 lanes per chain, no Gram table).  qh_set_form("pit_form", "segment" | "block") forces.
     {
-        const char *pf = getenv("QAMPY_HIP_PIT_FORM");
-        if (pf && pf[0] == 'b') seg_ok = false;
-        else if (!(pf && pf[0] == 's') && (int64_t)sg.S * nsel < 512) seg_ok = false;
+        const int pf = form(FORM_PIT);
+        if (pf == 2) seg_ok = false;
+        else if (pf != 1 && (int64_t)sg.S * nsel < 512) seg_ok = false;
     }
     if (adaptive) {
         // the adaptive solver needs the throughput form of the passes; a tap layout / alphabet it cannot take: the exact form (converged = 2)
@@ -2552,8 +2552,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
     }
     // complex64: the analysis of a pass runs in the eigenbasis (pit_basis_gemm_kernel / pit_bound_kernel / pit_recur_eig_kernel); complex128
     // keeps the probe-based analysis, whose defect vectors are formed in double precision before they are projected
-    // (QAMPY_HIP_PIT_PROBE=1 forces it for complex64 too: tests compare the two)
-    const bool eig = want_corr && sizeof(R) == 4 && !(getenv("QAMPY_HIP_PIT_PROBE") && atoi(getenv("QAMPY_HIP_PIT_PROBE")) != 0);
+    // (qh_set_form("pit_probe", "1") forces it for complex64 too: tests compare the two)
+    const bool eig = want_corr && sizeof(R) == 4 && form(FORM_PIT_PROBE) == 0;
     const bool eig_path = eig && !(o.exchange != nullptr);        // (a capture split over processes keeps everything on one stream)
     // Measured coarse model (pit_model_kernel): gain and the 2 x 2 block of the signal direction from the capture itself.  opts.correction = 2
     // keeps round 3's model (one formula gain per error function, diagonal in the eigenbasis, extra damping beta) for comparisons.
@@ -2753,9 +2753,8 @@ int train_pit_dev(const void *E, int nmodes, int64_t L, int64_t TrSyms, int Nite
             // kernel) has run, the product is 8-10 us on a chip the pass leaves half empty, and the analysis only needs it after the pass.
             static thread_local hipEvent_t ev_x = nullptr, ev_xe = nullptr;
             // (measured, C3 tol 1e-4, same box, alternating: 1021-1023 MSym/s with the product aside, 1029-1031 with it in line - the two cross-stream
-            // event waits per pass cost what the 8 us product costs.  Off; QAMPY_HIP_PIT_XASIDE=1 switches it on for measurements.)
-            static const bool x_aside_on = [] { const char *e = getenv("QAMPY_HIP_PIT_XASIDE"); return e && atoi(e) != 0; }();
-            const bool x_aside = eig_path && x_aside_on;
+            // event waits per pass cost what the 8 us product costs.  Off; qh_set_form("pit_xaside", "1") switches it on for measurements.)
+            const bool x_aside = eig_path && form(FORM_PIT_XASIDE) != 0;
             if (x_aside) {
                 if (!ev_x) { QH_HIP(hipEventCreateWithFlags(&ev_x, hipEventDisableTiming)); QH_HIP(hipEventCreateWithFlags(&ev_xe, hipEventDisableTiming)); }
                 hipStream_t hs = helper_stream();

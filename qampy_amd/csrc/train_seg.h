@@ -728,10 +728,10 @@ constexpr int SG_LPC8_MIN = 4096 + 1;    // chains from which 8 lanes per chain 
                                          // shorter instruction stream of the 16-lane layout wins (C3, 3840 chains: 275 against 390 us per pass)
 template <typename R> inline int seg_lanes(int nmodes, int ntaps, int nsel, int nq)
 {
-    const char *e = getenv("QAMPY_HIP_SEG_LANES");                  // 8 | 16: force (measurements, tests)
+    const int e = form(FORM_SEG_LANES);                             // qh_set_form("seg_lanes", "8" | "16"): force (measurements, tests)
     const bool can8 = sizeof(R) == 4 && seg_tpl(nmodes, ntaps, 8) != 0 && seg_slots(nsel, 8) * nmodes <= 8;
-    if (e && atoi(e) == 16) return 16;
-    if (e && atoi(e) == 8) return can8 ? 8 : 16;
+    if (e == 16) return 16;
+    if (e == 8) return can8 ? 8 : 16;
     return can8 && nq >= SG_LPC8_MIN ? 8 : 16;
 }
 

@@ -165,7 +165,7 @@ class ResidentReceiver:
             import os as _os
             budget = _lib.gram_budget_gb() * 2 ** 30
             fits = self.TrSyms[0] * 1024 * (np.dtype(self.ct).itemsize // 8) <= budget
-            if len(set(self.TrSyms)) == 1 and self.TrSyms[0] >= 128 and fits and _os.environ.get("QAMPY_HIP_TRAINER", "") != "direct":
+            if len(set(self.TrSyms)) == 1 and self.TrSyms[0] >= 128 and fits and _lib.get_form("trainer") != 1:
                 self._gram = _k.gram_build_dev(self.E, self.os, self.Ntaps, self.TrSyms[0])
         elif len(set(self.TrSyms)) == 1 and self.nmodes * self.Ntaps <= 128:
             # tier b builds what its passes need itself (no Gram table in the throughput form, csrc/train_seg.h); what the stages

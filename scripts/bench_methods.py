@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Per-method cost of the exact trainers: every complex error function on one device-resident capture, in each kernel form
-that takes it (QAMPY_HIP_TRAINER = direct | lookahead | iterative).  Prints one JSON line; cycles assume 2.4 GHz."""
+that takes it (qh_set_form("trainer", direct | lookahead | iterative)).  Prints one JSON line; cycles assume 2.4 GHz."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+from qampy_amd import _lib as _qlib
 from qampy_amd import synth, _lib
 from qampy_amd._lib import DeviceArray, Event
 from qampy_amd.core.equalisation import equalisation as eq, hip_equalisation as hk
@@ -25,9 +26,9 @@ for method in os.environ.get("BM_METHODS", "cma,mcma,cma2,rde,mrde,sbd,mddma,dd"
     derr = DeviceArray((2, tr), np.complex64)
     dmu = DeviceArray.from_host(np.array([1e-4 if method != "cma2" else 1e-6], np.float32))
     for form in ("direct", "lookahead", "iterative", "default"):
-        os.environ.pop("QAMPY_HIP_TRAINER", None)
+        _qlib.set_form("trainer", None)
         if form != "default":
-            os.environ["QAMPY_HIP_TRAINER"] = form
+            _qlib.set_form("trainer", form)
         for adaptive in (False, True, "per-mode"):
             if adaptive and form not in ("default", "iterative"):
                 continue
@@ -43,5 +44,5 @@ for method in os.environ.get("BM_METHODS", "cma,mcma,cma2,rde,mrde,sbd,mddma,dd"
             wf = dw.to_host()
             res["%s/%s%s" % (method, form, "+adaptive" if adaptive is True else ("+adaptive(per-mode)" if adaptive else ""))] = dict(ms=round(ms, 2), cycles_per_step=round(ms * 1e-3 * 2.4e9 / tr, 1),
                                                                                    finite=bool(np.all(np.isfinite(wf))))
-os.environ.pop("QAMPY_HIP_TRAINER", None)
+_qlib.set_form("trainer", None)
 print(json.dumps(dict(what="%d-QAM 2-pol, %d symbols, %d taps, one sweep, both output modes concurrently (gram build included)" % (M, nsym, ntaps), results=res)))

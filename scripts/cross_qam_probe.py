@@ -7,6 +7,7 @@ train_bi.h bi_nearest_general) against the direct form on the same capture - dev
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+from qampy_amd import _lib as _qlib
 from qampy_amd import synth, _lib
 from qampy_amd.core.equalisation import hip_equalisation as hk
 
@@ -30,9 +31,9 @@ for M in (32, 128, 64):
                 res = {}
                 for form in ("direct", "auto"):
                     if form == "direct":
-                        os.environ["QAMPY_HIP_TRAINER"] = "direct"
+                        _qlib.set_form("trainer", "direct")
                     else:
-                        os.environ.pop("QAMPY_HIP_TRAINER", None)
+                        _qlib.set_form("trainer", None)
                     best = 1e9
                     for rep in range(2):
                         wx = pre.copy()

@@ -4,6 +4,7 @@ choice (and a randomly forced form) against the oracle in complex128 (tight tole
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+from qampy_amd import _lib as _qlib
 from qampy_amd import _lib
 from qampy_amd.core.equalisation import equalisation as eq, hip_equalisation as hk
 from oracle import oracle
@@ -46,9 +47,9 @@ for case in range(n_cases):
             eo[m] = e1[m]
     else:
         eo, wo, muo = oracle.train_equaliser(E, tr, niter, os_, mu, w0.copy(), modes, bool(adaptive), sy, method)
-    os.environ.pop("QAMPY_HIP_TRAINER", None)
+    _qlib.set_form("trainer", None)
     if form:
-        os.environ["QAMPY_HIP_TRAINER"] = form
+        _qlib.set_form("trainer", form)
     try:
         with np.errstate(all="ignore"):
             e, w, mu2 = hk.train_equaliser(E, tr, niter, os_, mu, w0.copy(), modes, [False, True, "per-mode"][adaptive], sy, method)
@@ -68,5 +69,5 @@ for case in range(n_cases):
             desc["exception"] = repr(w)
         fails.append(desc)
         print("FAIL", desc, flush=True)
-os.environ.pop("QAMPY_HIP_TRAINER", None)
+_qlib.set_form("trainer", None)
 print("fuzz: %d cases, %d failures, %.1f s" % (n_cases, len(fails), time.time() - t0))

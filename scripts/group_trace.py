@@ -9,7 +9,7 @@ n, baton, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 parts = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 cfg = bench.WORKLOADS["c3"]
 sig = bench.make_input(cfg, cfg["nsym"], 1000)
-_lib.call("qh_set_pass_baton", baton)
+assert baton == 0, "the pass baton was measured and dropped (profiles/r06_pass_baton.txt)"
 g = ReceiverGroup(n, sig.shape[0], sig.shape[1], 2, cfg["M"], cfg["ntaps"], cfg["mu"], methods=cfg["methods"], Niter=cfg["niter"], adaptive_stepsize=cfg["adaptive"],
                   TrSyms=(None, None), Mtestangles=cfg["A"], Nbps=cfg["Nbps"], dtype=np.complex64, alphabet=sig.coded_symbols, tier="b", pit=dict(tol=1e-4))
 for r in g.rx:

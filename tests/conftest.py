@@ -49,6 +49,32 @@ def golden_cases(group):
     return _GOLDEN.cases[group]
 
 
+class _Forms:
+    """The library's form switches (``qh_set_form``: test hooks of include/qampy_hip.h) for the duration of a test: ``forms.set("trainer", "direct")``;
+    everything a test set goes back to automatic when it ends.  (Rounds 1-5 steered the kernels through environment variables read in the launch paths.)"""
+
+    def __init__(self):
+        self._touched = set()
+
+    def set(self, key, value):
+        from qampy_amd import _lib
+        _lib.set_form(key, value)
+        self._touched.add(key)
+
+    def reset(self, key=None):
+        from qampy_amd import _lib
+        for k in ([key] if key else list(self._touched)):
+            _lib.set_form(k, None)
+            self._touched.discard(k)
+
+
+@pytest.fixture
+def forms():
+    f = _Forms()
+    yield f
+    f.reset()
+
+
 CT = {"c64": np.complex64, "c128": np.complex128}
 RT = {"c64": np.float32, "c128": np.float64}
 

@@ -77,7 +77,7 @@ def test_apply_filter_full_size_linearity_and_impulse(capture_c3):
 
 
 @pytest.mark.parametrize("method", ["cma", "mrde"])
-def test_zero_step_sweep_equals_filter_output(monkeypatch, capture_c3, method):
+def test_zero_step_sweep_equals_filter_output(capture_c3, method, forms):
     """mu = 0 over 2^22 symbols: taps unchanged and err = errfn(filter output) - ties both trainers to the apply kernel."""
     E = np.ascontiguousarray(np.asarray(capture_c3))
     nt = 41
@@ -94,7 +94,7 @@ def test_zero_step_sweep_equals_filter_output(monkeypatch, capture_c3, method):
         ri = codes.imag[np.sum(y.imag[..., None] ** 2 > parts.imag, axis=-1)]
         want = (rr - y.real ** 2) * y.real + 1j * (ri - y.imag ** 2) * y.imag
     for form in ("lookahead", "direct"):
-        monkeypatch.setenv("QAMPY_HIP_TRAINER", form)
+        forms.set("trainer", form)
         if form == "direct":                                   # the direct form is ~3x slower: a quarter of the capture
             trn = tr // 4
         else:
@@ -189,7 +189,7 @@ def test_resident_receiver_device_ser_equals_host_ser():
 @pytest.mark.parametrize("methods,adaptive", [(("mcma", "sbd"), (False, False)), (("cma", "mrde"), (False, False)),
                                               (("mcma", "mddma"), (True, True)), (("mcma", "sbd"), ("per-mode", "per-mode"))])
 @pytest.mark.parametrize("trainer", ["auto", "iterative"])
-def test_channel_bank_equals_single_receivers(monkeypatch, methods, adaptive, trainer):
+def test_channel_bank_equals_single_receivers(methods, adaptive, trainer, forms):
     """A bank of independent captures trained in ONE launch per stage (channel = blockIdx.y) gives bit-identical taps,
     errors and recovered symbols to one ResidentReceiver per capture."""
     from qampy_amd.pipeline import ChannelBank, ResidentReceiver
@@ -204,7 +204,7 @@ def test_channel_bank_equals_single_receivers(monkeypatch, methods, adaptive, tr
         bank.load(c, sg)
     bank.run()
     if trainer != "auto":
-        monkeypatch.setenv("QAMPY_HIP_TRAINER", trainer)         # the single receivers in the same form
+        forms.set("trainer", trainer)         # the single receivers in the same form
     for c, sg in enumerate(sigs):
         rx = ResidentReceiver(2, L, 2, M, 15, (2e-3, 5e-4)[:len(methods)], alphabet=sg.coded_symbols, **kw)
         rx.load(sg)

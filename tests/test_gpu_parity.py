@@ -44,13 +44,13 @@ def test_train_equaliser_golden(golden, case):
 
 @pytest.mark.parametrize("form", ["auto", "direct"])
 @pytest.mark.parametrize("case", golden_cases("train_cross"), ids=lambda c: c["name"])
-def test_train_equaliser_cross_qam_golden(golden, case, form, monkeypatch):
+def test_train_equaliser_cross_qam_golden(golden, case, form, forms):
     """Non-square alphabets (32- / 128-QAM) against the reference's outputs: the decision is a search over ALL symbols with the reference's
     first-minimum rule (det_symbol, pythran_equalisation.py:240-265) - in the form the library picks and in the direct form."""
     if form == "direct":
-        monkeypatch.setenv("QAMPY_HIP_TRAINER", "direct")
+        forms.set("trainer", "direct")
     else:
-        monkeypatch.delenv("QAMPY_HIP_TRAINER", raising=False)
+        forms.reset("trainer")
     g = golden["train_cross"]
     n, dn = case["name"], case["dtype"]
     E = np.ascontiguousarray(g[case["input"] + "_E"].astype(CT[dn]))
@@ -261,7 +261,7 @@ def test_edge_cases():
                                                    ("sbd", 16, 21, 2), ("sbd", 64, 41, 2), ("mddma", 64, 15, 2), ("dd", 4, 9, 1),
                                                    ("dd", 256, 11, 2), ("sbd", 32, 13, 2)])
 @pytest.mark.parametrize("dn", ["c64", "c128"])
-def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, nmodes, dn):
+def test_lookahead_trainer_equals_direct_trainer(method, M, ntaps, nmodes, dn, forms):
     """The three exact trainers (look-ahead: train_la.h, block-iterative: train_bi.h, direct: train_impl.h) and the oracle
     agree to rounding, including a partial last block, several sweeps, a mode subset and shapes only some of them take
     (122 taps: no look-ahead kernel, the forced form then falls through to the next one).  Decision-directed functions run
@@ -281,11 +281,11 @@ def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, 
     mu = RT[dn](3e-4 if method != "cma2" else 1e-4)
     modes = None if nmodes < 3 else np.array([2, 0])
     eo, wo, _ = oracle.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, False, sy, method)
-    monkeypatch.setenv("QAMPY_HIP_TRAINER", "direct")
+    forms.set("trainer", "direct")
     ed, wd, _ = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, False, sy, method)
-    monkeypatch.setenv("QAMPY_HIP_TRAINER", "lookahead")
+    forms.set("trainer", "lookahead")
     el, wl, _ = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, False, sy, method)
-    monkeypatch.setenv("QAMPY_HIP_TRAINER", "iterative")     # block-iterative form (train_bi.h): fixed-point sweeps per 64-step block
+    forms.set("trainer", "iterative")     # block-iterative form (train_bi.h): fixed-point sweeps per 64-step block
     ei, wi, _ = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, False, sy, method)
     ei2, wi2, _ = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, False, sy, method)
     assert np.array_equal(wi, wi2) and np.array_equal(ei, ei2)          # fixed reduction order: bit-reproducible
@@ -302,7 +302,7 @@ def test_lookahead_trainer_equals_direct_trainer(monkeypatch, method, M, ntaps, 
 @pytest.mark.parametrize("method,M,ntaps,nmodes", [("cma", 4, 17, 2), ("mcma", 16, 21, 2), ("mrde", 64, 41, 2), ("sbd", 16, 21, 2),
                                                    ("mddma", 64, 13, 2), ("dd", 16, 9, 3), ("rde", 16, 15, 1)])
 @pytest.mark.parametrize("dn", ["c64", "c128"])
-def test_adaptive_step_forms_agree(monkeypatch, method, M, ntaps, nmodes, dn):
+def test_adaptive_step_forms_agree(method, M, ntaps, nmodes, dn, forms):
     """adapt_step (pythran_equalisation.py:12-16, :171-172) in the block-iterative form (1/mu as a prefix sum inside the
     sweeps) and in the look-ahead form (1/mu carried by the chain wave, all sweeps in one launch) against the direct form and the
     oracle: taps, errors and the final mu, which is carried over sweeps and modes."""
@@ -319,13 +319,13 @@ def test_adaptive_step_forms_agree(monkeypatch, method, M, ntaps, nmodes, dn):
     mu = RT[dn](5e-3)
     modes = None if nmodes < 3 else np.array([2, 0])
     eo, wo, muo = oracle.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, True, sy, method)
-    monkeypatch.setenv("QAMPY_HIP_TRAINER", "direct")
+    forms.set("trainer", "direct")
     ed, wd, mud = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, True, sy, method)
-    monkeypatch.setenv("QAMPY_HIP_TRAINER", "iterative")
+    forms.set("trainer", "iterative")
     ei, wi, mui = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, True, sy, method)
-    monkeypatch.setenv("QAMPY_HIP_TRAINER", "lookahead")     # round 5: the adaptive step on the look-ahead chain (blind methods; others fall through)
+    forms.set("trainer", "lookahead")     # round 5: the adaptive step on the look-ahead chain (blind methods; others fall through)
     el, wl, mul = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, True, sy, method)
-    monkeypatch.delenv("QAMPY_HIP_TRAINER")                  # and whatever the library picks by itself
+    forms.reset("trainer")                  # and whatever the library picks by itself
     ea, wa, mua = hk.train_equaliser(E, tr, 2, 2, mu, w0.copy(), modes, True, sy, method)
     assert muo < 0.95 * mu                                   # the step size really moved
     t = dict(rtol=1e-9, atol=1e-11) if dn == "c128" else dict(rtol=3e-4, atol=3e-5)
@@ -338,7 +338,7 @@ def test_adaptive_step_forms_agree(monkeypatch, method, M, ntaps, nmodes, dn):
 @pytest.mark.parametrize("nmodes,ntaps,os_,tr", [(1, 1, 1, 128), (1, 5, 1, 129), (2, 7, 3, 191), (2, 64, 2, 192), (4, 31, 2, 200), (8, 16, 2, 130),
                                                 (8, 3, 1, 257), (2, 33, 4, 128), (3, 42, 2, 321)])
 @pytest.mark.parametrize("method", ["mcma", "mrde", "sbd"])
-def test_exact_trainer_forms_on_boundary_shapes(monkeypatch, nmodes, ntaps, os_, tr, method):
+def test_exact_trainer_forms_on_boundary_shapes(nmodes, ntaps, os_, tr, method, forms):
     """Smallest captures the block forms take (128 steps), partial / full last blocks, 1 to 8 modes, 1 to 128 taps per output
     mode, oversampling 1 to 4, adaptive and fixed step: every form the shape admits equals the oracle."""
     rng = np.random.default_rng(nmodes * 1000 + ntaps * 10 + os_)
@@ -354,7 +354,7 @@ def test_exact_trainer_forms_on_boundary_shapes(monkeypatch, nmodes, ntaps, os_,
     for adaptive in (False, True):
         eo, wo, muo = oracle.train_equaliser(E, tr, 2, os_, np.float64(1e-3), w0.copy(), modes, adaptive, sy, method)
         for form in ("direct", "lookahead", "iterative"):
-            monkeypatch.setenv("QAMPY_HIP_TRAINER", form)
+            forms.set("trainer", form)
             e, w, mu = hk.train_equaliser(E, tr, 2, os_, np.float64(1e-3), w0.copy(), modes, adaptive, sy, method)
             np.testing.assert_allclose(w, wo, rtol=1e-9, atol=1e-11, err_msg="%s adaptive=%s" % (form, adaptive))
             np.testing.assert_allclose(e, eo, rtol=1e-9, atol=1e-10, err_msg="%s adaptive=%s" % (form, adaptive))
@@ -362,7 +362,7 @@ def test_exact_trainer_forms_on_boundary_shapes(monkeypatch, nmodes, ntaps, os_,
 
 
 @pytest.mark.parametrize("method,M", [("cma", 16), ("mcma", 16), ("mrde", 64), ("sbd", 16)])
-def test_time_chunked_training_equals_unchunked(monkeypatch, method, M):
+def test_time_chunked_training_equals_unchunked(method, M):
     """When the Gram tables of a call exceed the scratch budget the sweep runs chunk after chunk (taps handed on through HBM):
     same results - bit for bit in the block-iterative form (it restarts every block from the taps anyway), to rounding in the
     look-ahead form - for any capture length."""
@@ -451,10 +451,50 @@ def _alphabets():
             "qam64_rect": (q64.real * 1.0 + 1j * q64.imag * 0.5).astype(np.complex64)}         # symmetric product with different levels per axis
 
 
+@pytest.mark.parametrize("name", ["qam4", "qam16", "qam64", "qam64_rect", "qam256", "qam16_shifted", "irregular16"])
+@pytest.mark.parametrize("L", [1024 + 39, 2 * 1024 + 20, 5 * 1024 + 20, 5 * 1024 + 21, 40 * 1024 + 777, 1 << 20])
+def test_bps_register_ring_kernel_is_bit_identical_to_the_lds_ring_kernel(name, L, forms):
+    """Round 6: A = 64, N = 20 - the chunks whose rows all lie inside the capture go to bps_stream40_kernel (window in registers, symbols through the
+    scalar cache) when the alphabet is a mirror-symmetric product with at most four positive levels per axis; the others, and every other alphabet, stay
+    with bps_stream_kernel (both kernels read the device-side descriptor, exactly one works on a chunk).  Same operations in the same order: the indices
+    are IDENTICAL to the LDS-ring kernel's on every symbol - for alphabets the register kernel takes, for those it declines, at every chunk count
+    (none / one / several interior chunks; a last chunk that just is / just is not interior)."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(repr((name, L)).encode()))
+    alphabet = _alphabets()[name]
+    scale = np.sqrt(np.mean(np.abs(alphabet) ** 2))
+    sig = (alphabet[rng.integers(0, alphabet.size, L)] * np.exp(1j * (0.2 + 0.002 * np.cumsum(rng.normal(size=L)))) +
+           0.04 * scale * (rng.normal(size=L) + 1j * rng.normal(size=L))).astype(np.complex64)
+    ang = np.linspace(-np.pi / 4, np.pi / 4, 64, endpoint=False, dtype=np.float32).reshape(1, -1)
+    forms.set("bps", "lds")
+    i_lds = hip_dsp.bps(sig, ang, alphabet, 20)
+    forms.reset("bps")
+    i_reg = hip_dsp.bps(sig, ang, alphabet, 20)
+    assert np.array_equal(i_reg, i_lds), (name, L, int(np.count_nonzero(i_reg != i_lds)))
+    # two rows at once (the receiver's call: both modes in one launch) and in parts
+    from qampy_amd._lib import DeviceArray
+    two = np.ascontiguousarray(np.stack([sig, sig[::-1]]))
+    dE, dsy, dang = DeviceArray.from_host(two), DeviceArray.from_host(alphabet), DeviceArray.from_host(ang.ravel())
+    res = []
+    for form, nparts in (("lds", 1), (None, 1), (None, 3)):
+        forms.set("bps", form)
+        idx, ph, out = DeviceArray((2, L), np.int32, zero=True), DeviceArray((2, L), np.float32), DeviceArray((2, L), np.complex64)
+        for part in range(nparts):
+            hip_dsp.bps_recover_dev(dE, 64, dsy, 20, idx, ph, out, angles=dang, part=part, nparts=nparts)
+        _lib.sync()
+        res.append((idx.to_host(), ph.to_host(), out.to_host()))
+    forms.reset("bps")
+    for r in res[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(r, res[0]))
+    # (the one-row call above may cut the capture into chunks of another length - the library sizes them for the number of waves - and then re-sums its
+    # windows at other rows: not compared bit for bit with the two-row call)
+    assert np.mean(res[0][0][0] != i_lds) < 2e-3
+
+
 @pytest.mark.parametrize("name", ["qam4", "qam16", "qam64", "qam256", "qam1024", "qam16_shifted", "qam32_cross", "irregular16", "qam64_rect"])
 @pytest.mark.parametrize("L,A,N", [(1, 64, 3), (39, 64, 20), (40, 64, 20), (41, 33, 20), (1000, 64, 20), (3 * 1024 + 17, 64, 20), (5000, 5, 1), (4097, 64, 96),
                                    (2500, 17, 33)])
-def test_bps_stream_kernel_equals_tile_kernel_and_double_oracle(monkeypatch, name, L, A, N):
+def test_bps_stream_kernel_equals_tile_kernel_and_double_oracle(name, L, A, N, forms):
     """complex64, one grid of <= 64 angles: the streaming kernel (lane <-> angle, LDS ring, every alphabet kind handled in the
     kernel) against the tile kernel on the same data and against the oracle run in double precision on the same values (the
     'true' arg-min: no running-sum drift).  Edges: capture shorter than / equal to / one longer than the window, ragged chunks,
@@ -466,11 +506,11 @@ def test_bps_stream_kernel_equals_tile_kernel_and_double_oracle(monkeypatch, nam
     sig = (alphabet[rng.integers(0, alphabet.size, L)] * np.exp(1j * (0.2 + 0.002 * np.cumsum(rng.normal(size=L)))) +
            0.04 * scale * (rng.normal(size=L) + 1j * rng.normal(size=L))).astype(np.complex64)
     ang = np.linspace(-np.pi / 4, np.pi / 4, A, endpoint=False, dtype=np.float32).reshape(1, -1)
-    monkeypatch.delenv("QAMPY_HIP_BPS", raising=False)
+    forms.reset("bps")
     i_s = hip_dsp.bps(sig, ang, alphabet, N)
-    monkeypatch.setenv("QAMPY_HIP_BPS", "tile")
+    forms.set("bps", "tile")
     i_t = hip_dsp.bps(sig, ang, alphabet, N)
-    monkeypatch.delenv("QAMPY_HIP_BPS", raising=False)
+    forms.reset("bps")
     i_o = oracle.bps(sig.astype(np.complex128), ang.astype(np.float64), alphabet.astype(np.complex128), N)
     assert i_s.shape == i_t.shape == (L,) and i_s.dtype == np.int32
     assert np.all(i_s[:N] == 0) and np.all(i_s[max(L - N, 0):] == 0)
@@ -517,7 +557,7 @@ def test_window_batch_equals_one_call_per_window(nwin, hop, method, adaptive, dn
         np.testing.assert_allclose(wbest[m], wx[best[m]], **t)
 
 
-def test_fused_search_unwrap_derotation_equals_separate_kernels(monkeypatch):
+def test_fused_search_unwrap_derotation_equals_separate_kernels(forms):
     """QAMPY_HIP_BPS_FUSED=1: search, np.unwrap (decoupled look-back over the chunks) and de-rotation in ONE kernel - same index, phase
     and recovered symbols as the search followed by the three unwrap / de-rotation launches, on a capture with real phase wander
     (the unwrapped phase leaves the grid's range many times) and at a length that is not a multiple of the chunk."""
@@ -527,7 +567,7 @@ def test_fused_search_unwrap_derotation_equals_separate_kernels(monkeypatch):
     alpha = DeviceArray.from_host(np.ascontiguousarray(sig.coded_symbols, dtype=np.complex64))
     res = {}
     for fused in ("0", "1"):
-        monkeypatch.setenv("QAMPY_HIP_BPS_FUSED", fused)
+        forms.set("bps", "fused" if fused == "1" else "auto")
         idx, ph, out = DeviceArray(E.shape, np.int32), DeviceArray(E.shape, np.float32), DeviceArray(E.shape, np.complex64)
         hip_dsp.bps_recover_dev(E, 32, alpha, 20, idx, ph, out, angles=DeviceArray.from_host(hip_dsp.test_angle_grid(32, np.float32)))
         res[fused] = (idx.to_host(), ph.to_host(), out.to_host())

@@ -49,12 +49,12 @@ def _run_pit(E, tr, niter, mu, w0, sy, method, pit, rt):
 
 @pytest.mark.parametrize("form", ["auto", "direct", "segment16", "segment8"])
 @pytest.mark.parametrize("method,M", [("mcma", 16), ("cma", 16), ("mrde", 64), ("sbd", 16)])
-def test_relaxation_fixed_point_is_the_sequential_recurrence(method, M, form, monkeypatch):
+def test_relaxation_fixed_point_is_the_sequential_recurrence(method, M, form, forms):
     if form.startswith("segment"):              # the throughput form (train_seg.h) with 16 / 8 lanes per chain, forced at this small size
-        monkeypatch.setenv("QAMPY_HIP_PIT_FORM", "segment")
-        monkeypatch.setenv("QAMPY_HIP_SEG_LANES", form[7:])
+        forms.set("pit_form", "segment")
+        forms.set("seg_lanes", form[7:])
     elif form != "auto":
-        monkeypatch.setenv("QAMPY_HIP_TRAINER", form)
+        forms.set("trainer", form)
     sig, E, tr, w0, sy, rt = _setup(method, M)
     eo, wo, _ = hk.train_equaliser(E, tr, 2, 2, rt(5e-4), w0.copy(), None, False, sy, method)
     S = 4
@@ -70,11 +70,11 @@ def test_relaxation_fixed_point_is_the_sequential_recurrence(method, M, form, mo
 @pytest.mark.parametrize("analysis", ["eigen", "probe"])
 @pytest.mark.parametrize("lanes", ["16", "8"])
 @pytest.mark.parametrize("method,M", [("mcma", 16), ("cma", 64), ("mrde", 64)])
-def test_coarse_correction_converges_to_the_exact_trajectory(method, M, lanes, analysis, monkeypatch):
-    monkeypatch.setenv("QAMPY_HIP_PIT_FORM", "segment")
-    monkeypatch.setenv("QAMPY_HIP_SEG_LANES", lanes)
+def test_coarse_correction_converges_to_the_exact_trajectory(method, M, lanes, analysis, forms):
+    forms.set("pit_form", "segment")
+    forms.set("seg_lanes", lanes)
     # analysis of a pass: in the eigenbasis of the input covariance (complex64 default) or with the round-2 probe of the capture
-    monkeypatch.setenv("QAMPY_HIP_PIT_PROBE", "1" if analysis == "probe" else "0")
+    forms.set("pit_probe", "1" if analysis == "probe" else "0")
     """16 segments, tight tolerance: the defect falls fast with the correction and the result agrees with the exact
     trainer far below the gradient noise; plain relaxation needs (many) more passes for the same defect."""
     sig, E, tr, w0, sy, rt = _setup(method, M, nsym=2 ** 16, ntaps=21)
@@ -91,9 +91,9 @@ def test_coarse_correction_converges_to_the_exact_trajectory(method, M, lanes, a
 
 
 @pytest.mark.parametrize("form", ["auto", "segment"])
-def test_complex128_and_oracle(form, monkeypatch):
+def test_complex128_and_oracle(form, forms):
     if form == "segment":                       # the throughput form in double precision (16 lanes per chain; 8 lanes are single precision only)
-        monkeypatch.setenv("QAMPY_HIP_PIT_FORM", "segment")
+        forms.set("pit_form", "segment")
     sig, E, tr, w0, sy, rt = _setup("mcma", 16, dtype=np.complex128)
     eo, wo, _ = oracle.train_equaliser(E, tr, 1, 2, 5e-4, w0.copy(), None, False, sy, "mcma")
     w, e, rep = _run_pit(E, tr, 1, 5e-4, w0, sy, "mcma", dict(segments=4, max_passes=4, tol=1e-14, correction=0, phase_seed=0, acquire=0, exact_redo_off=1), rt)
@@ -143,12 +143,12 @@ def test_tier_b_is_total_calls_without_a_parallel_solver_take_the_exact_form(met
 
 
 @pytest.mark.parametrize("method,M,niter", [("cma", 16, 1), ("cma", 16, 2), ("mcma", 16, 2), ("mrde", 64, 1), ("sbd", 16, 1)])
-def test_uncertified_sweep_is_redone_in_the_exact_form(method, M, niter, monkeypatch):
+def test_uncertified_sweep_is_redone_in_the_exact_form(method, M, niter, forms):
     """A sweep the passes do not certify - here: one pass against a tolerance it cannot meet - is redone in the exact form from the taps the
     call started with, inside the call: taps AND error trace are the exact entry point's bit for bit (for cma this includes NOT turning
     the exact trace by the gauge phases of the failed pass), the report says ``exact_form``; with ``exact_redo_off`` the same call
     hands back the uncertified result and says ``converged`` False."""
-    monkeypatch.setenv("QAMPY_HIP_PIT_FORM", "segment")
+    forms.set("pit_form", "segment")
     sig, E, tr, w0, sy, rt = _setup(method, M, nsym=2 ** 15, ntaps=21)
     pit = dict(segments=16, max_passes=1, tol=1e-9, acquire=0)
     (wa, ea, _), (wb, eb, _), rep = _exact_and_tier_b(E, tr, niter, 1e-3, w0, sy, method, False, pit, rt)
@@ -160,7 +160,7 @@ def test_uncertified_sweep_is_redone_in_the_exact_form(method, M, niter, monkeyp
 
 
 @pytest.mark.parametrize("method", ["cma", "mcma"])
-def test_adaptive_sweep_that_falls_back_returns_the_exact_error_trace(method, monkeypatch):
+def test_adaptive_sweep_that_falls_back_returns_the_exact_error_trace(method):
     """The adaptive solver's way out (a sweep not certified within the passes) writes the error trace in the exact form; it must come back
     as it is - for cma (continuous symmetry) NOT turned by the gauge phases of the failed passes - and every mode's report must
     survive (``per_mode``)."""
@@ -293,10 +293,10 @@ def test_tier_b_through_the_mirrored_api():
 
 
 @pytest.mark.parametrize("os_", [1])
-def test_segment_form_at_other_sampling_rates(os_, monkeypatch):
+def test_segment_form_at_other_sampling_rates(os_, forms):
     """The throughput form shares one sample window per PAIR of steps at 2 samples per symbol; every other rate takes its plain
     step-by-step loop: S passes of plain relaxation over S segments are the sequential recurrence there too."""
-    monkeypatch.setenv("QAMPY_HIP_PIT_FORM", "segment")
+    forms.set("pit_form", "segment")
     sig = synth.make_capture(16, 2 ** 13, nmodes=2, os=os_, snr_db=28, theta=np.pi / 5.6, dgd=30e-12, seed=43, dtype=np.complex64)
     E = np.ascontiguousarray(np.asarray(sig))
     ntaps = 9

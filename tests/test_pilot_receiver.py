@@ -115,9 +115,9 @@ def test_pilot_chain_on_gpu(golden):
 
 
 @pytest.mark.gpu
-def test_window_batch_equals_single_calls(golden, monkeypatch):
+def test_window_batch_equals_single_calls(golden, forms):
     """frame_sync's one-launch batch gives exactly what separate equalise_signal calls give (same kernel, same order)."""
-    monkeypatch.setenv("QAMPY_HIP_TRAINER", "direct")        # the batch runs the direct-form kernel
+    forms.set("trainer", "direct")        # the batch runs the direct-form kernel
     g = golden["pilot"]
     E = np.ascontiguousarray(g["rx"].astype(np.complex64))
     starts = np.arange(2, 20) * 256
