@@ -218,6 +218,7 @@ class _Field:
 
 #: device reports (qh_pit_report as dicts) of the tier-b stages of the most recent equalise_signal / dual_mode_equalisation call
 _PIT_REPORTS = []
+NONFINAL_TOL_FACTOR = 2.0        # tier b, one options dict for several stages: an earlier stage is certified at this multiple of `tol` (pipeline.ResidentReceiver shares it)
 
 
 
@@ -236,7 +237,12 @@ def _tier_options(kwargs, nstages, cold):
     """``tier="a"`` (the default unless ``qampy_amd.set_default_tier("b", tol)`` changed it): the exact sequential recurrence.  ``tier="b"``: the same recurrence solved in parallel in time
      - complex-valued blind / decision-directed methods, fixed step sizes or the reference's adaptive step
     (cma / mcma / sbd / mddma; a sweep the solver cannot certify is redone in the exact form); ``pit`` = one dict of solver options for
-    all stages or one per stage.  Returns one options dict (or None) per stage."""
+    all stages or one per stage.  Returns one options dict (or None) per stage.
+
+    Tolerance per stage: ``tol`` bounds what the CALL returns - equaliser output <= tol, taps and error traces <= 3 tol.  With ONE dict for a
+    multi-stage call the LAST stage is certified at ``tol`` and every earlier one at ``NONFINAL_TOL_FACTOR * tol`` (2 tol: it returns an error trace
+    and hands on taps, both held to 3 tol; ``last_pit_reports()`` shows the tolerance each stage ran at).  ``pit=dict(tol=..., tol_exact=True)`` or one
+    dict per stage holds every stage to exactly the tolerance given."""
     tier, pit = kwargs.pop("tier", None), kwargs.pop("pit", None)
     del _PIT_REPORTS[:]
     if tier is None:                              # the process-wide default (qampy_amd.set_default_tier; "a" unless set)
@@ -255,8 +261,11 @@ def _tier_options(kwargs, nstages, cold):
     if not isinstance(pit, (list, tuple)):
         # `tol` bounds what the call returns (output <= tol, taps and error traces <= 3 tol): the last stage is certified at tol, an earlier one -
         # which returns an error trace and hands on taps - at 2 tol (pipeline.ResidentReceiver.NONFINAL_TOL_FACTOR; one dict per stage overrides)
-        for o in per_stage[:-1]:
-            o["tol"] = 2.0 * float(o.get("tol") or 1e-3)
+        if not (pit or {}).get("tol_exact"):
+            for o in per_stage[:-1]:
+                o["tol"] = NONFINAL_TOL_FACTOR * float(o.get("tol") or 1e-3)
+    for o in per_stage:
+        o.pop("tol_exact", None)
     return per_stage
 
 

@@ -129,7 +129,7 @@ thread_local size_t g_scratch_n[16] = {0};
 // ---- the table of form switches (common.h FormKey; qh_set_form / qh_set_trainer).  Values:
 //   trainer    0 automatic, 1 direct, 2 lookahead, 3 iterative          pit_form   0 automatic, 1 segment (throughput form), 2 block (latency forms)
 //   seg_lanes  0 automatic, 8, 16                                       pit_probe  1: complex64 takes the complex128 analysis of a pass
-//   bps        0 automatic, 1 tile kernel for complex64, 2 streaming kernel with the LDS ring only, 3 search + unwrap + de-rotation fused
+//   bps        0 automatic, 1 tile kernel for complex64, 2 streaming kernel with the LDS ring only, 3 search + unwrap + de-rotation fused, 4 plain (round 5's rows)
 //   pit_xaside 1: start taps into the eigenbasis beside the pass         la_profile 1: cycle split of workgroup 0 of the block trainers
 static std::atomic<int> g_form[FORM_COUNT];
 struct FormName { const char *key, *env; };
@@ -143,7 +143,7 @@ static int form_parse(int k, const char *v, int *out)
     case FORM_TRAINER: *out = v[0] == 'd' ? 1 : (v[0] == 'l' ? 2 : (v[0] == 'i' ? 3 : (v[0] == 'a' || v[0] == '0' ? 0 : -1))); break;
     case FORM_PIT: *out = v[0] == 's' ? 1 : (v[0] == 'b' ? 2 : (v[0] == 'a' || v[0] == '0' ? 0 : -1)); break;
     case FORM_SEG_LANES: { const int n = atoi(v); *out = (n == 8 || n == 16 || n == 0) ? n : -1; break; }
-    case FORM_BPS: *out = v[0] == 't' ? 1 : (v[0] == 'l' ? 2 : (v[0] == 'f' ? 3 : (v[0] == 'a' || v[0] == '0' ? 0 : -1))); break;
+    case FORM_BPS: *out = v[0] == 't' ? 1 : (v[0] == 'l' ? 2 : (v[0] == 'f' ? 3 : (v[0] == 'p' ? 4 : (v[0] == 'a' || v[0] == '0' ? 0 : -1)))); break;
     default: *out = atoi(v) != 0 ? 1 : 0; break;
     }
     return *out < 0 ? -1 : 0;

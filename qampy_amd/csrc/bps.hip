@@ -36,6 +36,7 @@ template <> __device__ __forceinline__ void sincos_<double>(double x, double *s,
 // per-axis minima of |t_re - a_r| / |t_im - b_i| - bit-identical to the brute-force scan (rounding is monotone and
 // the product inside the fma is exact), at 2*sqrt(M) instead of M candidate evaluations.
 constexpr int BPS_MAX_LEVELS = 32;
+constexpr int BPS_DESC_RING = 16;       // descriptors / device-formed angle grids a thread rotates through (one per call)
 template <typename R> struct AlphabetDesc {
     int product;            // 1: cartesian product detected
     int symmetric;          // 1: product alphabet whose sorted levels are mirror images on both axes (l_k == -l_{n-1-k}, n even)
@@ -284,6 +285,7 @@ struct BpsStreamArgs {
     int64_t L;
     int A, M, N, C, alpha_lds;
     int chunk0;                  // chunk of block 0 (a launch may cover a part of the chunks: bps_dev's part / nparts)
+    int fast_rows;               // 0: the generic rows only (qh_set_form("bps", "plain"): measurements)
     int reg_lo, reg_hi;          // chunks [reg_lo, reg_hi) belong to bps_stream40_kernel IF the alphabet turns out to be one it takes (bs40_takes: both kernels
                                  // read the device-side descriptor and exactly one of them works on such a chunk - the host never waits for the analysis)
     // REC (search + np.unwrap + de-rotation in this one kernel): per-symbol phase and recovered symbols out, and the look-back cells
@@ -463,7 +465,7 @@ __global__ void __launch_bounds__(64) bps_stream_kernel(BpsStreamArgs a)
         // cells and the transposed block are addressed with immediate offsets from one base register per group, and there is no bias select:
         // 17 vector instructions per row (rotation 2, |t| 2, level differences 4, minima 4, squared distance 3, window 2) against 22.
         // The same arithmetic in the same order: bit-identical distances, sums and indices.
-        if (kind == 3 && full && lg >= 0 && lg + BS_G <= L && slot + BS_G <= W) {         // wave-uniform
+        if (kind == 3 && full && a.fast_rows && lg >= 0 && lg + BS_G <= L && slot + BS_G <= W) {         // wave-uniform
             typedef const __attribute__((address_space(4))) bs_f2 *bs_cptr;
             const bs_cptr eg = (bs_cptr)(const void *)(E + lg);                          // (read-only for the whole launch: constant address space)
             bs_f2 xs[BS_G];
@@ -672,8 +674,8 @@ int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, cons
             void *ph = nullptr, void *Eout = nullptr, bool *recovered = nullptr, int part = 0, int nparts = 1)
 {
     // part / nparts (streaming kernel only): this call searches the part-th of nparts runs of chunks - a caller that wants the search in
-    // pieces (between the relaxation passes of the next capture's training, pipeline.py) makes nparts calls; the alphabet is analysed by
-    // part 0 (scratch slot 3 of the calling thread: nothing else of this thread may search in between).  Other kernels: part nparts - 1 does it all.
+    // pieces (between the relaxation passes of the next capture's training, pipeline.py) makes nparts calls, each complete in itself (its own
+    // alphabet analysis: the parts share no state).  Other kernels: part nparts - 1 does it all.
     if (recovered) *recovered = false;
     int rc = ensure_init();
     if (rc) return rc;
@@ -684,10 +686,17 @@ int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, cons
     QH_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "bps: bad part of the search");
     const bool stream = bps_stream_ok<R>(p, A, N, M);
     if (!stream && part != nparts - 1) return QH_OK;
+    // The alphabet is analysed by EVERY call (every part of a search in parts) into the next of BPS_DESC_RING descriptors of the calling thread: a part
+    // carries no state of the part before it, and another search of the same thread in between - on this or another of its streams - cannot
+    // overwrite a descriptor a kernel in flight still reads (round 5 kept ONE descriptor per thread, written by part 0 only).
     void *desc = nullptr;
-    if ((rc = scratch(3, sizeof(AlphabetDesc<R>), &desc))) return rc;
-    if (!stream || part == 0)
-        hipLaunchKernelGGL((analyse_alphabet_kernel<R>), dim3(1), dim3(64), 0, g_stream, (const Cx<R> *)symbols, M, (AlphabetDesc<R> *)desc);
+    {
+        void *ring = nullptr;
+        static thread_local unsigned desc_next = 0;
+        if ((rc = scratch(3, BPS_DESC_RING * sizeof(AlphabetDesc<double>), &ring))) return rc;
+        desc = (char *)ring + (size_t)(desc_next++ % BPS_DESC_RING) * sizeof(AlphabetDesc<double>);
+    }
+    hipLaunchKernelGGL((analyse_alphabet_kernel<R>), dim3(1), dim3(64), 0, g_stream, (const Cx<R> *)symbols, M, (AlphabetDesc<R> *)desc);
     if (stream) {
         BpsStreamArgs s;
         s.E = (const Cx<float> *)E; s.angles = (const float *)angles; s.symbols = (const Cx<float> *)symbols;
@@ -719,29 +728,45 @@ int bps_dev(const void *E, int64_t L, const void *angles, int64_t p, int A, cons
             QH_HIP(hipFuncSetAttribute((const void *)bps_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
             sattr = true;
         }
-        // chunks of the register-ring kernel (A = 64, N = 20, every row of the chunk inside the capture): [r_lo, r_hi) of this part
+        // chunks of the register-ring kernel (A = 64, N = 20, every row of the chunk inside the capture): [lo, hi) of this part
         s.reg_lo = s.reg_hi = 0;
-        if (!rec && A == 64 && N == 20 && bps_reg_ring()) {
+        s.fast_rows = form(FORM_BPS) == 4 ? 0 : 1;
+        int64_t lo = 0, hi = 0;
+        if (!rec && A == 64 && N == 20 && C > 128) {
             const int ngroups = (C + 2 * N - 1 + BS_G - 1) / BS_G;
             const int64_t back = (int64_t)ngroups * BS_G - (C - 1 + N + 1);            // lstart = c0 - back >= 0
-            int64_t lo = back > 0 ? (back + C - 1) / C : 0;
-            int64_t hi = (L - N) / C;                                                    // (c + 1) C + N <= L
+            lo = back > 0 ? (back + C - 1) / C : 0;
+            hi = (L - N) / C;                                                            // (c + 1) C + N <= L
             if (lo < (int64_t)ch0) lo = ch0;
             if (hi > (int64_t)ch1) hi = ch1;
-            if (hi > lo) { s.reg_lo = (int)lo; s.reg_hi = (int)hi; }
+            if (hi <= lo) lo = hi = 0;
         }
         if (rec) hipLaunchKernelGGL(bps_stream_kernel<true>, dim3(nchunk, nm), dim3(64), lds, g_stream, s);
-        else if (ch1 > ch0) {
-            if (s.reg_hi > s.reg_lo) {
-                // the chunks in front of and behind the register kernel's range in their own launches (a few waves), its range in BOTH kernels: each
-                // looks at the descriptor and exactly one of them does the work (an alphabet the register kernel does not take: the waves of that
-                // launch return at once)
-                BpsStreamArgs r = s;
-                r.chunk0 = s.reg_lo;
-                hipLaunchKernelGGL(bps_stream40_kernel, dim3(s.reg_hi - s.reg_lo, nm), dim3(64), 0, g_stream, r);
+        else if (ch1 > ch0 && hi > lo) {
+            // The chunks in front of and behind that range hold rows outside the capture and take the generic rows: ONE wave per chunk of 1024 symbols would
+            // be a lone, latency-bound wave of ~0.1 ms behind a search of 0.36 ms - they are searched in pieces of 128 symbols instead (8 waves side by
+            // side; whatever the form, so that the forms stay bit-identical).  The range itself goes to BOTH kernels: each looks at the device-side
+            // descriptor and exactly one of them does the work (an alphabet the register kernel does not take: its waves return at once).
+            auto edge = [&](int64_t c_from, int64_t c_to) {
+                if (c_to <= c_from) return;
+                BpsStreamArgs e = s;
+                e.C = 128;
+                e.chunk0 = (int)(c_from * (C / 128));
+                const int64_t end = c_to * C < L ? c_to * C : L;
+                const unsigned n = (unsigned)((end - c_from * C + 127) / 128);
+                hipLaunchKernelGGL(bps_stream_kernel<false>, dim3(n, nm), dim3(64), lds, g_stream, e);
+            };
+            edge(ch0, lo);
+            edge(hi, ch1);
+            BpsStreamArgs r = s;
+            r.chunk0 = (int)lo;
+            if (bps_reg_ring()) {
+                r.reg_lo = (int)lo; r.reg_hi = (int)hi;
+                hipLaunchKernelGGL(bps_stream40_kernel, dim3((unsigned)(hi - lo), nm), dim3(64), 0, g_stream, r);
             }
+            hipLaunchKernelGGL(bps_stream_kernel<false>, dim3((unsigned)(hi - lo), nm), dim3(64), lds, g_stream, r);
+        } else if (ch1 > ch0)
             hipLaunchKernelGGL(bps_stream_kernel<false>, dim3(ch1 - ch0, nm), dim3(64), lds, g_stream, s);
-        }
         if (recovered) *recovered = rec;
         QH_HIP(hipGetLastError());
         return QH_OK;
@@ -943,14 +968,17 @@ int bps_recover_dev(const void *E, int nm, int64_t L, const void *angles, int A,
     if (rc) return rc;
     QH_REQUIRE(nm >= 1 && L >= 1 && A >= 1, "bps_recover: bad sizes");
     // in pieces (qh_bps_recover_part_*): parts 0 .. nparts - 2 search a run of chunks each, the last part searches the rest, unwraps and de-rotates;
-    // a grid formed on the device is formed by part 0 and stays in scratch slot 0 of the calling thread
     QH_REQUIRE(nparts >= 1 && part >= 0 && part < nparts, "bps_recover: bad part");
     const int64_t nchunk = (L + UW_CHUNK - 1) / UW_CHUNK;
     void *dang = const_cast<void *>(angles), *dchunk = nullptr;     // grow-only library scratch: no allocation / sync in the steady state
     if ((rc = scratch(1, (size_t)nm * nchunk * sizeof(int), &dchunk))) return rc;
-    if (!dang) {
-        if ((rc = scratch(0, (size_t)A * sizeof(R), &dang))) return rc;
-        if (part == 0) hipLaunchKernelGGL((linspace_kernel<R>), dim3((A + 63) / 64), dim3(64), 0, g_stream, (R *)dang, A);
+    if (!dang) {                                                  // (formed by every part, into the next of a ring of grids: see the alphabet descriptors in bps_dev)
+        void *ring = nullptr;
+        static thread_local unsigned grid_next = 0;
+        const size_t one = ((size_t)A * sizeof(R) + 255) & ~(size_t)255;
+        if ((rc = scratch(0, BPS_DESC_RING * one, &ring))) return rc;
+        dang = (char *)ring + (size_t)(grid_next++ % BPS_DESC_RING) * one;
+        hipLaunchKernelGGL((linspace_kernel<R>), dim3((A + 63) / 64), dim3(64), 0, g_stream, (R *)dang, A);
     }
     bool recovered = false;
     if ((rc = bps_dev<R>(E, L, dang, 1, A, symbols, M, N, idx, nm, ph, Eout, &recovered, part, nparts))) return rc;

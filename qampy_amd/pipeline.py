@@ -39,7 +39,7 @@ class ResidentReceiver:
     parameters (``Mtestangles=None`` skips carrier recovery).
     """
 
-    NONFINAL_TOL_FACTOR = 2.0
+    NONFINAL_TOL_FACTOR = _host.NONFINAL_TOL_FACTOR
 
     def __init__(self, nmodes, L, os, M, Ntaps, mu, methods=("cma", "mrde"), Niter=(1, 1), adaptive_stepsize=(False, False),
                  TrSyms=(None, None), Mtestangles=64, Nbps=20, dtype=np.complex64, alphabet=None, modes=None, tier="a", pit=None):
@@ -586,15 +586,19 @@ class ReceiverGroup:
             r.load(E)
         self._sync()
 
-    def run(self, steps, overlap=True, mark=None, prefetch=False):
+    def run(self, steps, overlap=True, mark=None, prefetch=False, feed=None):
         """``steps`` passes of the hot path in total, receiver ``i`` taking passes i, i + n, ...; returns when all are complete on the
-        device.  ``overlap``: as ResidentReceiver.run.  ``mark(i, k)``: a mark callback for pass k of receiver i (bench.py)."""
+        device.  ``overlap``: as ResidentReceiver.run.  ``mark(i, k)``: a mark callback for pass k of receiver i (bench.py).
+        ``feed(i, k, rx)``: called on receiver ``i``'s thread before its ``k``-th pass - where a caller hands it the capture that follows
+        (``rx.load_next(...)``, or a resident array as ``rx.E_next`` with ``rx._next_loaded = True``)."""
         n = len(self.rx)
         share = [len(range(i, int(steps), n)) for i in range(n)]
 
         def job(i):
             def go(rx):
                 for k in range(share[i]):
+                    if feed is not None:
+                        feed(i, k, rx)
                     rx.run(overlap=overlap, mark=mark(i, k) if mark else None, **({"prefetch": True} if prefetch else {}))
                 rx.wait_post(mark(i, share[i]) if mark else None)
                 self._sync()                   # this thread's streams
