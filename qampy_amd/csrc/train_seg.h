@@ -176,12 +176,15 @@ typedef float sg_f4 __attribute__((ext_vector_type(4)));
 // sums and of the tree from one list of independent instructions in a fixed order.
 template <int TPL, bool KEEP, int NL, int NR, int O0>
 __device__ __forceinline__ void seg_block_a(const sg_f2 (&x)[TPL], const sg_f2 (&w)[TPL], sg_f2 &y, sg_f2 &sq, float &ebr, float &ebi,
-                                            float per, float pei, unsigned long long mk, unsigned la, sg_f4 &d0, sg_f4 &d1, sg_f2 tm, sg_f2 &xm0, sg_f2 &xm1, sg_f2 &xm2)
+                                            float per, float pei, unsigned long long mk, unsigned la, sg_f4 &d0, sg_f4 &d1, sg_f4 &d2, sg_f4 &d3, sg_f2 tm, sg_f2 &xm0, sg_f2 &xm1, sg_f2 &xm2)
 {
-    static_assert((TPL == 4 || TPL == 6) && (NL == 1 || NL == 2) && NR >= 0 && NR <= 3, "layouts with 4 or 6 taps per lane: one or two window pieces per step, up to three padding taps");
+    static_assert(((TPL == 4 || TPL == 6) && (NL == 1 || NL == 2)) || (TPL == 11 && (NL == 3 || NL == 4)), "4 or 6 taps per lane: one or two window pieces per step; 11: three or four");
+    static_assert(NR >= 0 && NR <= 3, "up to three padding taps");
 #include "train_seg_blocks.inc"
     if constexpr (!KEEP) { (void)ebr; (void)ebi; (void)per; (void)pei; (void)mk; }
     if constexpr (NL < 2) (void)d1;
+    if constexpr (NL < 3) (void)d2;
+    if constexpr (NL < 4) (void)d3;
     if constexpr (NR < 1) { (void)tm; (void)xm0; }
     if constexpr (NR < 2) (void)xm1;
     if constexpr (NR < 3) (void)xm2;
@@ -191,12 +194,15 @@ __device__ __forceinline__ void seg_block_a(const sg_f2 (&x)[TPL], const sg_f2 (
 // written by scripts/gen_seg_blocks.py like block A.
 template <int TPL, bool D1, int NL, int NR, int O0>
 __device__ __forceinline__ void seg_block_ba(const sg_f2 (&xp)[TPL], sg_f2 yp, sg_f2 dp, const sg_f2 (&x)[TPL], sg_f2 (&w)[TPL], sg_f2 &y, sg_f2 &sq, float &ebr, float &ebi,
-                                             unsigned long long mk, unsigned la, sg_f4 &d0, sg_f4 &d1, sg_f2 tm, sg_f2 &xm0, sg_f2 &xm1, sg_f2 &xm2)
+                                             unsigned long long mk, unsigned la, sg_f4 &d0, sg_f4 &d1, sg_f4 &d2, sg_f4 &d3, sg_f2 tm, sg_f2 &xm0, sg_f2 &xm1, sg_f2 &xm2)
 {
-    static_assert((TPL == 4 || TPL == 6) && (NL == 1 || NL == 2) && NR >= 0 && NR <= 3, "layouts with 4 or 6 taps per lane: one or two window pieces per step, up to three padding taps");
+    static_assert(((TPL == 4 || TPL == 6) && (NL == 1 || NL == 2)) || (TPL == 11 && (NL == 3 || NL == 4)), "4 or 6 taps per lane: one or two window pieces per step; 11: three or four");
+    static_assert(NR >= 0 && NR <= 3, "up to three padding taps");
     sg_f2 cr;
 #include "train_seg_blocks_ba.inc"
     if constexpr (NL < 2) (void)d1;
+    if constexpr (NL < 3) (void)d2;
+    if constexpr (NL < 4) (void)d3;
     if constexpr (NR < 1) { (void)tm; (void)xm0; }
     if constexpr (NR < 2) (void)xm1;
     if constexpr (NR < 3) (void)xm2;
@@ -207,14 +213,19 @@ __device__ __forceinline__ void seg_block_ba(const sg_f2 (&xp)[TPL], sg_f2 yp, s
 #define SG_UI(j) "v_pk_fma_f32 %[w" #j "], %[x" #j "], %[cr], %[w" #j "] op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
 #define SG_W4_ [w0] "+v"(w[0]), [w1] "+v"(w[1]), [w2] "+v"(w[2]), [w3] "+v"(w[3])
 #define SG_W6_ SG_W4_, [w4] "+v"(w[4]), [w5] "+v"(w[5])
+#define SG_W11_ SG_W6_, [w6] "+v"(w[6]), [w7] "+v"(w[7]), [w8] "+v"(w[8]), [w9] "+v"(w[9]), [w10] "+v"(w[10])
 #define SG_X4_ [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [c] "v"(c), [cr] "v"(cr)
 #define SG_X6_ SG_X4_, [x4] "v"(x[4]), [x5] "v"(x[5])
+#define SG_X11_ SG_X6_, [x6] "v"(x[6]), [x7] "v"(x[7]), [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10])
+#define SG_UR11 SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UR(5) SG_UR(6) SG_UR(7) SG_UR(8) SG_UR(9) SG_UR(10)
+#define SG_UI11 SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UI(5) SG_UI(6) SG_UI(7) SG_UI(8) SG_UI(9) SG_UI(10)
 template <int TPL>
 __device__ __forceinline__ void seg_block_b(const sg_f2 (&x)[TPL], sg_f2 (&w)[TPL], sg_f2 c, sg_f2 cr)
 {
-    static_assert(TPL == 4 || TPL == 6, "layouts with 4 or 6 taps per lane");
+    static_assert(TPL == 4 || TPL == 6 || TPL == 11, "layouts with 4, 6 or 11 taps per lane");
     // (a tap's second FMA comes TPL - 1 instructions after its first; the first instruction of the next block A reads w[0], written TPL before the end)
-    if constexpr (TPL == 6) asm volatile(SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UR(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UI(5) : SG_W6_ : SG_X6_);
+    if constexpr (TPL == 11) asm volatile(SG_UR11 SG_UI11 : SG_W11_ : SG_X11_);
+    else if constexpr (TPL == 6) asm volatile(SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UR(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UI(5) : SG_W6_ : SG_X6_);
     else asm volatile(SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) : SG_W4_ : SG_X4_);
 }
 // the same for error functions of the form e = d(y) y: c = mu e and its rotated copy are the block's first two instructions (d: the factor
@@ -224,14 +235,16 @@ __device__ __forceinline__ void seg_block_b(const sg_f2 (&x)[TPL], sg_f2 (&w)[TP
 #define SG_C1 "v_pk_mul_f32 %[c], %[yy], %[d] op_sel_hi:[1,0]\n\tv_pk_mul_f32 %[cr], %[yy], %[d] op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
 #define SG_Y4_ [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [yy] "v"(yy), [d] "v"(d)
 #define SG_Y6_ SG_Y4_, [x4] "v"(x[4]), [x5] "v"(x[5])
+#define SG_Y11_ SG_Y6_, [x6] "v"(x[6]), [x7] "v"(x[7]), [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10])
 #define SG_CO_ , [c] "=&v"(c), [cr] "=&v"(cr)
 template <int TPL, bool D1>
 __device__ __forceinline__ sg_f2 seg_block_b2(const sg_f2 (&x)[TPL], sg_f2 (&w)[TPL], sg_f2 yy, sg_f2 d)
 {
-    static_assert(TPL == 4 || TPL == 6, "layouts with 4 or 6 taps per lane");
+    static_assert(TPL == 4 || TPL == 6 || TPL == 11, "layouts with 4, 6 or 11 taps per lane");
     sg_f2 c, cr;
 #define SG_B2(CM) \
-    if constexpr (TPL == 6) asm volatile(CM SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UR(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UI(5) : SG_W6_ SG_CO_ : SG_Y6_); \
+    if constexpr (TPL == 11) asm volatile(CM SG_UR11 SG_UI11 : SG_W11_ SG_CO_ : SG_Y11_); \
+    else if constexpr (TPL == 6) asm volatile(CM SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UR(4) SG_UR(5) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) SG_UI(4) SG_UI(5) : SG_W6_ SG_CO_ : SG_Y6_); \
     else asm volatile(CM SG_UR(0) SG_UR(1) SG_UR(2) SG_UR(3) SG_UI(0) SG_UI(1) SG_UI(2) SG_UI(3) : SG_W4_ SG_CO_ : SG_Y4_);
     if constexpr (D1) { SG_B2(SG_C1) } else { SG_B2(SG_CV) }
 #undef SG_B2
@@ -241,13 +254,18 @@ __device__ __forceinline__ sg_f2 seg_block_b2(const sg_f2 (&x)[TPL], sg_f2 (&w)[
 #undef SG_C1
 #undef SG_Y4_
 #undef SG_Y6_
+#undef SG_Y11_
 #undef SG_CO_
+#undef SG_UR11
+#undef SG_UI11
 #undef SG_UR
 #undef SG_UI
 #undef SG_W4_
 #undef SG_W6_
+#undef SG_W11_
 #undef SG_X4_
 #undef SG_X6_
+#undef SG_X11_
 // (e.im, -e.re) of e = d * y, component by component, from y and d: the rotated operand of the second round of the tap update
 __device__ __forceinline__ sg_f2 pk_rot_mul(sg_f2 y, sg_f2 d)
 {
@@ -265,8 +283,10 @@ __device__ __forceinline__ sg_f2 pk_rot_mul1(sg_f2 y, sg_f2 d)
 // the window pieces asked for during the previous pair of steps have arrived (their only reader waits here: data dependence pins the order)
 template <int NQ> __device__ __forceinline__ void sg_wait_lds(sg_f4 (&q)[NQ])
 {
-    static_assert(NQ >= 2 && NQ <= 5, "window of 4 to 10 samples");
-    if constexpr (NQ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]));
+    static_assert(NQ >= 2 && NQ <= 7, "window of 4 to 14 samples");
+    if constexpr (NQ == 7) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]), "+v"(q[6]));
+    else if constexpr (NQ == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[5]));
+    else if constexpr (NQ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]));
     else if constexpr (NQ == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]));
     else if constexpr (NQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]));
@@ -533,18 +553,26 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
         v2 xa[WIN], xb[WIN];
         int i = 0;
         // ---- whole groups of LPC steps
-        constexpr bool FAST = sizeof(R) == 4 && !ADAPT && LPC == 16 && (TPL == 4 || TPL == 6);
+        constexpr bool FAST = sizeof(R) == 4 && !ADAPT && ((LPC == 16 && (TPL == 4 || TPL == 6)) || (LPC == 8 && TPL == 11));
         if constexpr (FAST) {
             // single precision, 16 lanes per chain, 2 samples per symbol: the same pairs of steps on windows of TPL + 2 samples, the
             // windows as 128-bit pieces; the pieces of the next pair's window are asked for from inside the lane trees of this pair
             // and the previous step's error is parked there too (tree16_fused).  Lanes without taps walk through the zero row.
             if (os2) {
-                constexpr int NQ = WIN / 2, NLA = (NQ + 1) / 2;
+                // (11 taps per lane - the 8-lane layout, round 6: a window of 13 samples, seven pieces with the last half unused; a lane's window starts
+                // at a multiple of 88 bytes, so the pieces are pairs of 64-bit reads there - ds_read2_b64 in the blocks, v2 loads here)
+                constexpr int NQ = (WIN + 1) / 2, NLA = (NQ + 1) / 2;
                 sg_f4 qa[NQ], qb[NQ];
-                const sg_f4 *xq = reinterpret_cast<const sg_f4 *>(xs);
                 unsigned la = (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(const char *)xs;   // LDS byte address of step i's window
+                if constexpr (TPL == 11) {
+                    const v2 *xv = reinterpret_cast<const v2 *>(xs);
 #pragma unroll
-                for (int j = 0; j < NQ; j++) qa[j] = xq[j];
+                    for (int j = 0; j < NQ; j++) { const v2 lo = xv[2 * j], hi = xv[2 * j + 1]; qa[j] = sg_f4{lo.x, lo.y, hi.x, hi.y}; }
+                } else {
+                    const sg_f4 *xq = reinterpret_cast<const sg_f4 *>(xs);
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) qa[j] = xq[j];
+                }
                 // The steps are software-pipelined by half a step: block B of step i - 1 and block A of step i are ONE statement (seg_block_ba) wherever
                 // the error function has the form d(y) y, so a group of 16 steps is  A | e B+A e B+A ... e B+A e | B  - (xp, yp, dp) carry step i - 1's samples
                 // (padding taps masked), output and factor to it.  Other error functions: A, e, B per step.
@@ -563,10 +591,12 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
                     if constexpr (la_errfn_is_dy<METHOD> && ku >= 0) {
                         constexpr bool d1 = sizeof(decltype(seg_errfn_d<METHOD, NPART>(sq, K, Ks))) == sizeof(R);
                         seg_block_ba<TPL, d1, nl, NR, decltype(BOFF)::value + 16 * p0>(xp, yp, dp, x, w, y, sq, ebr, ebi, mks[ku >= 0 ? ku : 0], la,
-                                                                                         qn[p0], qn[nl > 1 ? p0 + 1 : p0], tailmask, xm0, xm1, xm2);
+                                                                                         qn[p0], qn[nl > 1 ? p0 + 1 : p0], qn[nl > 2 ? p0 + 2 : p0], qn[nl > 3 ? p0 + 3 : p0],
+                                                                                         tailmask, xm0, xm1, xm2);
                     } else {
                         seg_block_a<TPL, (ku >= 0), nl, NR, decltype(BOFF)::value + 16 * p0>(x, w, y, sq, ebr, ebi, pend.re, pend.im, mks[ku >= 0 ? ku : 0], la,
-                                                                                             qn[p0], qn[nl > 1 ? p0 + 1 : p0], tailmask, xm0, xm1, xm2);
+                                                                                             qn[p0], qn[nl > 1 ? p0 + 1 : p0], qn[nl > 2 ? p0 + 2 : p0], qn[nl > 3 ? p0 + 3 : p0],
+                                                                                             tailmask, xm0, xm1, xm2);
                     }
                     if constexpr (NR >= 1) x[TPL - 1] = xm0;                  // (the padding taps are updated with masked samples: they stay zero)
                     if constexpr (NR >= 2) x[TPL - 2] = xm1;
@@ -613,7 +643,8 @@ __global__ void __launch_bounds__(64) train_seg_kernel(SegArgs<R> a)
                         pend = fstep(SgInt<2>{}, qb, qa, SgInt<NLA>{}, SgInt<NQ - NLA>{}, SgInt<(u + 4) * 16>{}, SgInt<u + 2>{}, pend, g + 3);
                         sg_wait_lds(qa);
                     };
-                    quad(SgInt<0>{}); quad(SgInt<4>{}); quad(SgInt<8>{}); quad(SgInt<12>{});
+                    quad(SgInt<0>{}); quad(SgInt<4>{});
+                    if constexpr (LPC == 16) { quad(SgInt<8>{}); quad(SgInt<12>{}); }
                     if constexpr (la_errfn_is_dy<METHOD>) pend = last_b();
                     keep(pend, LPC - 1);
                     const int gi = ibase + i + l16;

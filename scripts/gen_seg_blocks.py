@@ -34,8 +34,17 @@ def lv(ctl, dst=("v254", "v255")):
     return ["v_add_f32_dpp %s, v254, v254 %s%s" % (dst[0], ctl, DPP), "v_add_f32_dpp %s, v255, v255 %s%s" % (dst[1], ctl, DPP)]
 
 
+def lanes_of(tpl):
+    """11 taps per lane is the 8-lanes-per-chain layout (41 taps x 2 input modes on 8 lanes, 3 DPP levels); 4 and 6 taps per lane the 16-lane one"""
+    return 8 if tpl == 11 else 16
+
+
 def block(tpl, keep, nl, nr):
-    ld = ["ds_read_b128 %%[d%d], %%[la] offset:%%[o%d]" % (k, k) for k in range(nl)]
+    if tpl == 11:
+        # a lane's window starts at 11 k samples = 88 k bytes: 8-byte aligned only - the pieces are pairs of 64-bit reads (offsets in units of 8 bytes)
+        ld = ["ds_read2_b64 %%[d%d], %%[la] offset0:%%[p%d] offset1:%%[q%d]" % (k, k, k) for k in range(nl)]
+    else:
+        ld = ["ds_read_b128 %%[d%d], %%[la] offset:%%[o%d]" % (k, k) for k in range(nl)]
     xm = ["v_pk_mul_f32 %%[xm%d], %%[x%d], %%[tm]" % (k, tpl - 1 - k) for k in range(nr)]
     body = dot(tpl) + [SUMP, SUMR]
     if keep:
@@ -51,10 +60,13 @@ def block(tpl, keep, nl, nr):
         body.append("s_nop 0")
     elif len(g) == 0:
         body.append("s_nop 1")
-    levels = [lv("quad_perm:[1,0,3,2]"), lv("quad_perm:[2,3,0,1]"), lv("row_half_mirror"), lv("row_mirror", ("v246", "v247"))]
+    if lanes_of(tpl) == 8:
+        levels = [lv("quad_perm:[1,0,3,2]"), lv("quad_perm:[2,3,0,1]"), lv("row_half_mirror", ("v246", "v247"))]
+    else:
+        levels = [lv("quad_perm:[1,0,3,2]"), lv("quad_perm:[2,3,0,1]"), lv("row_half_mirror"), lv("row_mirror", ("v246", "v247"))]
     for i, l in enumerate(levels):
         body += l
-        if i < 3:
+        if i < len(levels) - 1:
             body.append(fill.pop(0) if fill else "s_nop 0")   # a DPP add reads the level before it: one more instruction in between
     body.append("v_pk_mul_f32 %[sq], v[246:247], v[246:247]")
     body += fill                                              # (what found no slot)
@@ -82,8 +94,14 @@ def operands_ba(tpl, nl, nr):
     ins += ['[yp] "v"(yp)', '[dp] "v"(dp)', '[la] "v"(la)', '[mk] "s"(mk)']
     if nr:
         ins.append('[tm] "v"(tm)')
-    ins += ['[o%d] "n"(O0 + %d)' % (k, 16 * k) for k in range(nl)]
+    ins += imm(tpl, nl)
     return outs, ins
+
+
+def imm(tpl, nl):
+    if tpl == 11:
+        return ['[p%d] "n"((O0 + %d) / 8)' % (k, 16 * k) for k in range(nl)] + ['[q%d] "n"((O0 + %d) / 8 + 1)' % (k, 16 * k) for k in range(nl)]
+    return ['[o%d] "n"(O0 + %d)' % (k, 16 * k) for k in range(nl)]
 
 
 def operands(tpl, keep, nl, nr):
@@ -97,7 +115,7 @@ def operands(tpl, keep, nl, nr):
         ins += ['[per] "v"(per)', '[pei] "v"(pei)', '[mk] "s"(mk)']
     if nr:
         ins.append('[tm] "v"(tm)')
-    ins += ['[o%d] "n"(O0 + %d)' % (k, 16 * k) for k in range(nl)]
+    ins += imm(tpl, nl)
     return outs, ins
 
 
@@ -158,9 +176,9 @@ def main():
              "// Filling rule: R0 + R1 -> [park re | first piece] -> y; two slots behind y and one behind each of the first three DPP levels take, in this order,",
              "// the window pieces, the second select of the parked error, the padding taps' samples times the lane's 0 / 1 mask; s_nop where nothing is left."]
     first = True
-    for tpl in (4, 6):
+    for tpl in (4, 6, 11):
         for keep in (1, 0):
-            for nl in (1, 2):
+            for nl in ((3, 4) if tpl == 11 else (1, 2)):
                 for nr in range(0, 4):
                     body = block(tpl, keep, nl, nr)
                     check(body, "block A tpl %d keep %d nl %d nr %d" % (tpl, keep, nl, nr))
@@ -174,7 +192,7 @@ def main():
                     lines.append("        : %s" % ", ".join(outs))
                     lines.append("        : %s" % ", ".join(ins))
                     lines.append('        : "memory", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");')
-    lines.append('else static_assert(TPL == 4 || TPL == 6, "block A: layouts with 4 or 6 taps per lane");')
+    lines.append('else static_assert(TPL == 4 || TPL == 6 || TPL == 11, "block A: layouts with 4, 6 or 11 taps per lane");')
     with open(OUT, "w") as f:
         f.write("\n".join(lines) + "\n")
     print("wrote", OUT, len(lines), "lines")
@@ -183,9 +201,9 @@ def main():
              "// one statement, so that the compiler has nothing to pad between them.  c = d y of the previous step lives in v[244:245]: the tap update reads it and the",
              "// selects of the A part park it (KEEP is implied: there is a previous step)."]
     first = True
-    for tpl in (4, 6):
+    for tpl in (4, 6, 11):
         for d1 in (1, 0):
-            for nl in (1, 2):
+            for nl in ((3, 4) if tpl == 11 else (1, 2)):
                 for nr in range(0, 4):
                     body = block_b(tpl, d1) + [i.replace("%[per]", "v244").replace("%[pei]", "v245") for i in block(tpl, 1, nl, nr)]
                     check(body, "blocks B + A tpl %d d1 %d nl %d nr %d" % (tpl, d1, nl, nr))
@@ -199,7 +217,7 @@ def main():
                     lines.append("        : %s" % ", ".join(outs))
                     lines.append("        : %s" % ", ".join(ins))
                     lines.append('        : "memory", "v244", "v245", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");')
-    lines.append('else static_assert(TPL == 4 || TPL == 6, "blocks B + A: layouts with 4 or 6 taps per lane");')
+    lines.append('else static_assert(TPL == 4 || TPL == 6 || TPL == 11, "blocks B + A: layouts with 4, 6 or 11 taps per lane");')
     out2 = OUT.replace("train_seg_blocks.inc", "train_seg_blocks_ba.inc")
     with open(out2, "w") as f:
         f.write("\n".join(lines) + "\n")

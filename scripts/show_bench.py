@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """Compact view of a bench.py JSON line: python scripts/show_bench.py file"""
 import json, sys
-lines = [l for l in open(sys.argv[1]) if l.startswith("{")]
-d = json.loads(lines[-1])
+try:
+    d = json.load(open(sys.argv[1]))                      # bench.py --detail-out (round 6: the full result, indented)
+except ValueError:
+    lines = [l for l in open(sys.argv[1]) if l.startswith("{")]
+    d = json.loads(lines[-1])
 for k in ("value", "ms_per_step", "headline_tier", "stages_ms", "speedup_vs_cpu", "note", "extra_shapes_error"):
     if d.get(k) is not None:
         print(k, d.get(k))
