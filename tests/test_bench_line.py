@@ -76,3 +76,28 @@ def test_two_rank_line_parses_and_is_small(tmp_path):
         assert k in res, k
     assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and len(res["ms_per_step_per_rank"]) == 2 and res["comm_backend"] == "tcp"
     assert res["detail"] == detail and json.load(open(detail))["n_gpus"] == 2
+
+
+def test_two_rank_line_under_torchrun_as_the_driver_starts_it(tmp_path):
+    """The driver's own command for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N --steps K --warmup W` (here with --dry-run: no GPU).  Exactly ONE JSON line on stdout, from rank 0, compact, with both ranks seen."""
+    pytest.importorskip("torch")
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    detail = str(tmp_path / "detail.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--detail-out", detail]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 8000, lines
+    res = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in res, k
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["steps"] == 3 and res["warmup"] == 1 and len(res["ms_per_step_per_rank"]) == 2
+    assert res["value"] == pytest.approx(2 * res["config"]["nsym_per_channel"] * 3 / (res["ms_per_step"] * 3e-3) / 1e6, rel=1e-3)
