@@ -125,6 +125,7 @@ class ResidentReceiver:
         no call has to wait for the device to say it."""
         E = np.ascontiguousarray(np.asarray(E), dtype=self.ct)
         assert E.shape == (self.nmodes, self.L)
+        self._filter_done()
         self.E.set(E)
         if getattr(self, "_prep", None) is not None:
             self.invalidate()
@@ -269,8 +270,15 @@ class ResidentReceiver:
         assert E.shape == (self.nmodes, self.L)
         if getattr(self, "E_next", None) is None:
             self.E_next = DeviceArray((self.nmodes, self.L), self.ct)
+        self._filter_done()                        # (the buffer may be the capture a filter on stream 2 is still reading)
         self.E_next.set(E)
         self._next_loaded = True
+
+    def _filter_done(self):
+        """run(overlap=True) leaves the filter of the last capture on stream 2: stream 0 waits for it before an input buffer is written."""
+        if getattr(self, "_filter_pending", False):
+            _lib.call("qh_stream_wait_event", self._ev_ready.ptr)
+            self._filter_pending = False
 
     def invalidate(self):
         """Forget what was prepared ahead (after the capture in ``self.E`` / ``self.E_next`` was changed by hand)."""
@@ -406,11 +414,37 @@ class ResidentReceiver:
         if parts_mode:
             self._hook_calls_prev = self._hook_calls if self._hook_calls > 0 else getattr(self, "_hook_calls_prev", 9)
             self._enqueue_post(m)                 # parts the passes did not take
-        if getattr(self, "_post_running", False):
-            _lib.call("qh_stream_wait_event", self._ev_post.ptr)        # the filter output of the previous pass has been consumed
-            self._post_running = False
-        self._apply()
-        m("apply")
+        # The filter of this capture.  One capture at a time it follows the training on stream 0.  Consecutive captures (tier b, overlap): it goes onto
+        # stream 2 - IN FRONT of this capture's phase search, which reads its output, and behind the previous capture's search, which read the buffer it
+        # overwrites: the stream's own order is all the ordering those need - with a private copy of the taps (the next run's reset() restores the start
+        # taps), so that stream 0 goes straight on to the next capture: the filter (87 us chip-wide at C3) and its launch gaps were ~0.1 ms of the ~0.2 ms
+        # between the last pass of a capture and the first pass of the next one (round 6; profiles/r06_c3_timeline.txt).  Bit-identical.
+        aside = bool(overlap and self.Mtestangles and self.tier == "b" and getattr(self, "filter_aside", True))
+        if aside:
+            if getattr(self, "_wxy_f", None) is None:
+                self._wxy_f = DeviceArray(self.wxy.shape, self.ct)
+            if getattr(self, "_ev_trained", None) is None:
+                self._ev_trained = _lib.Event()
+            if getattr(self, "_ev_post", None) is None:
+                self._ev_ready, self._ev_post = _lib.Event(), _lib.Event()
+            self._wxy_f.copy_from(self.wxy)
+            self._ev_trained.record()
+            _lib.call("qh_use_stream", 2)
+            try:
+                _lib.call("qh_stream_wait_event", self._ev_trained.ptr)
+                _k.apply_filter_to_signal_dev(self.E, self.os, self._wxy_f, self.modes, self.eq)
+                m("apply")
+                self._ev_ready.record()            # stream 2: the filter has read the capture and written its output (load_next / load wait for it)
+            finally:
+                _lib.call("qh_use_stream", 0)
+            self._post_running = False             # (the previous search is in front of this filter on stream 2; wait_post() waits for the NEW search's event)
+            self._filter_pending = True
+        else:
+            if getattr(self, "_post_running", False):
+                _lib.call("qh_stream_wait_event", self._ev_post.ptr)        # the filter output of the previous pass has been consumed
+                self._post_running = False
+            self._apply()
+            m("apply")
         if prefetch and getattr(self, "_next_loaded", False):
             # the capture load_next() brought - prepared above, where that was possible - is the next one to be processed; the old one's buffer takes
             # the next load_next()
@@ -424,7 +458,8 @@ class ResidentReceiver:
             return
         if getattr(self, "_ev_post", None) is None:
             self._ev_ready, self._ev_post = _lib.Event(), _lib.Event()
-        self._ev_ready.record()                   # stream 0 up to here: the filter output the pending phase search reads
+        if not aside:
+            self._ev_ready.record()               # stream 0 up to here: the filter output the pending phase search reads
         self._post_pending = True
         self._post_n = self._post_next = 0        # (not started: the next run decides whether it goes in parts)
 
@@ -475,8 +510,9 @@ class ResidentReceiver:
         self._post_pending, self._post_running = False, True
 
     def wait_post(self, mark=None):
-        """After ``run(overlap=True)``: enqueue the pending phase search; work enqueued from here on (stream 0) sees its results."""
+        """After ``run(overlap=True)``: enqueue the pending phase search; work enqueued from here on (stream 0) sees its results (and the filter's)."""
         self._enqueue_post(mark)
+        self._filter_done()
         if getattr(self, "_post_running", False):
             _lib.call("qh_stream_wait_event", self._ev_post.ptr)
             self._post_running = False
@@ -622,10 +658,10 @@ class ReceiverGroup:
             t.join(timeout=10.)
         self._threads = []
         for r in self.rx:                          # what pointed into the worker threads' (now released) scratch buffers and streams
-            for name in ("_gram", "_ev_post", "_ev_ready"):
+            for name in ("_gram", "_ev_post", "_ev_ready", "_ev_trained"):
                 if hasattr(r, name):
                     setattr(r, name, None)
-            for name in ("_post_pending", "_post_running"):
+            for name in ("_post_pending", "_post_running", "_filter_pending"):
                 if hasattr(r, name):
                     setattr(r, name, False)
             if hasattr(r, "_owner_thread"):
