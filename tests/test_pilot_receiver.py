@@ -318,3 +318,27 @@ def test_config5_256qam_against_oracle_kernel_chain(monkeypatch, prec):
         out_dev = float(np.sqrt(np.mean(np.abs(hip["out"] - cpu["out"]) ** 2) / np.mean(np.abs(cpu["out"]) ** 2)))
         assert tap_dev <= 1e-3 and out_dev <= 2e-3, (tap_dev, out_dev)
         assert np.max(np.abs(hip["ser"] - cpu["ser"])) <= 3e-4 and hip["ser"].max() < 5e-2, (hip["ser"], cpu["ser"])
+
+
+@pytest.mark.gpu
+def test_long_pilot_sequence_results_are_complete_arrays(monkeypatch):
+    """with a pilot sequence long enough for its equalised copy to reach the pinned-result path (>= 1 MiB: complex128, 2 modes,
+    2^15 symbols) `equalize_pilot_sequence` read arrays whose device -> host copies were only ENQUEUED (the field deferred them and nobody called
+    finish()).  The deferral is opt-in now (only equalise_signal / dual_mode_equalisation, which finish): the result equals the one obtained with the
+    pinned path switched off, run after run."""
+    from qampy_amd import _lib, theory
+    rng = np.random.default_rng(11)
+    seq_len, os_, nt = 2 ** 15, 2, 17
+    ref = theory.coded_symbols_qam(4, dtype=np.complex128)[rng.integers(0, 4, (2, seq_len))]
+    up = np.repeat(ref, os_, axis=1)
+    h = np.array([0.08, 0.9, 0.25, -0.05])
+    rx = np.stack([np.convolve(up[0] + 0.15 * up[1], h)[:up.shape[1]], np.convolve(up[1] - 0.1j * up[0], h)[:up.shape[1]]])
+    rx = rx * np.exp(2j * np.pi * 3e-6 * np.arange(rx.shape[1]))
+    rx = np.concatenate([rx, np.zeros((2, nt + 3))], axis=1) + 0.02 * (rng.normal(size=(2, rx.shape[1] + nt + 3)) + 1j * rng.normal(size=(2, rx.shape[1] + nt + 3)))
+    kw = dict(os=os_, foe_comp=True, mu=(2e-3, 2e-3), M_pilot=4, Ntaps=nt, Niter=2, adaptive_stepsize=False, methods=("cma", "sbd_data"))
+    runs = [pil.equalize_pilot_sequence(rx, ref, np.array([0, 0]), **kw) for _ in range(3)]
+    monkeypatch.setattr(_lib, "PINNED_MIN_BYTES", 1 << 40)            # every result through the synchronous pageable path
+    taps_ref, foe_ref = pil.equalize_pilot_sequence(rx, ref, np.array([0, 0]), **kw)
+    assert np.all(np.isfinite(taps_ref)) and abs(float(foe_ref[0, 0])) > 0
+    for taps, foe in runs:
+        assert np.array_equal(taps, taps_ref) and np.array_equal(foe, foe_ref)
