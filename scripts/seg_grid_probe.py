@@ -3,8 +3,10 @@ Usage: seg_grid_probe.py workload tol  lanes:S1:S2 ...   (lanes 0 = automatic, S
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
-import bench
 from qampy_amd import _lib
+if os.environ.get("QAMPY_LIB"):                  # (measurements: another build of the library, e.g. -DQH_SEG_DUAL)
+    _lib.LIB_PATH = os.environ["QAMPY_LIB"]
+import bench
 key, tol = sys.argv[1], float(sys.argv[2])
 cfg = bench.WORKLOADS[key]; nsym = cfg["nsym"]
 sig = bench.make_input(cfg, nsym, 1000)
