@@ -1663,6 +1663,20 @@ def main():
     else:
         roofline["traffic_note"] = "no PMC traffic profile of these kernel sources under profiles/: not quoted"
     out["roofline"] = roofline
+    # ---- the phase search beside it (detail file): slicer flops of SURVEY.md 8d (2 A 25 per symbol period) / the fused recovery
+    # stage one capture at a time (search + unwrap + de-rotation, event pair on its stream); the search kernel's own duration and its instruction
+    # counters are in profiles/r06_bps_profile.txt (rocprofv3)
+    if cfg["A"] and tier_b is not None:
+        one = ((tier_b.get("pipelining") or {}).get("one_capture_at_a_time") or {}).get("stages_ms") or {}
+        ms_b = one.get("bps_recover")
+        if ms_b and ms_b > 0:
+            fl = nsym * nsel * cfg["A"] * 25.0
+            by = rx.N * bps_b["bps"]
+            out["roofline_phase_search"] = dict(bound="valu-fp32", kernel="bps_recover (analysis + search + unwrap + de-rotation, all modes)", launch_ms=round(ms_b, 3),
+                                                algorithmic_flops=int(fl), achieved=round(fl / (ms_b * 1e-3) / 1e12, 3), peak=VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                                                frac=round(fl / (ms_b * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4), algorithmic_bytes=int(by),
+                                                hbm=dict(achieved=round(by / (ms_b * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(by / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+                                                note="whole stage one capture at a time; the search kernel alone: profiles/r06_bps_profile.txt (358 us at C3: 0.24 of the peak)")
 
     # ---- the other shapes and tolerances of the default line (N = 1): loose tolerance, a capture with symbol errors, ns, c2
     if world == 1 and args.tier == "b" and not args.no_extra_shapes and not split:
