@@ -22,7 +22,14 @@ path run beside it on the same capture, the recovered output is within tol (rela
 the symbol errors within +-3 per mode.  Otherwise, or with `--tier a`, the headline is the exact path's.  Both are always in
 the line (`tier_a`, `tier_b`, `headline_tier`), and `speedup_vs_cpu` is keyed to the tier that produced `value`.
 
-The default line (N = 1, workload c3) additionally carries
+OUTPUT (round 6).  stdout carries ONE compact JSON line (`headline_line`: a whitelist, <= 6 KB enforced before it is printed) with the contract's
+keys (metric, value, unit, n_gpus, steps, warmup, ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config), `roofline`,
+`cpu_baseline`, the certificate (`tier_b.checks`, `tier_b.elementwise_summary`, `tier_b_tight`), `parity_vs_cpu`, `ser`, `ms_per_step_per_rank`,
+`comm_backend`.  The FULL result - everything listed below - is written to `--detail-out` (default gpurun_out/bench_detail.json); round 5 printed
+it all as one 30 KB line, which the driver could not parse.  The certificate at tol = 1e-4 includes the ELEMENT-WISE bar of the exact path
+(rtol = atol = 1e-4 on every tap and every equaliser-output sample).
+
+The full result (N = 1, workload c3) additionally carries
   tier_b_loose  the same solver held to tol = 1e-2 (the SER-equivalent tier), informational
   cert_24dB     the same shape at 24 dB SNR, where both paths make thousands of symbol errors: counts within 3 sigma per mode
   ns, c2        the north star's 10^7-symbol shape and BASELINE configs[1]: tier b + exact path + certificate
