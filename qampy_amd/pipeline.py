@@ -145,8 +145,9 @@ class ResidentReceiver:
     def reset(self):
         """Centre-spike taps and initial step sizes (start of ``dual_mode_equalisation``)."""
         self.wxy.copy_from(self.wxy0)
-        for m, m0 in zip(self.mu, self.mu_init):
-            m.copy_from(m0)
+        for s_, (m, m0) in enumerate(zip(self.mu, self.mu_init)):
+            if self.adaptive[s_]:                  # (a fixed step is only read by the trainers: nothing to restore - a copy is ~6 us of stream 0 between two captures)
+                m.copy_from(m0)
 
     def _bound(self):
         """A receiver of a ReceiverGroup caches state of its worker thread (that thread's library streams, events, scratch slots - a Gram table
